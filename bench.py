@@ -1,0 +1,171 @@
+#!/usr/bin/env python
+"""bench.py -- HR MPix/s of the SRFlow-LP 4x learned-prior pipeline on MI355X.
+
+A "step" = one pass of the hot path (RRDB conditioning encoder -> flow encode -> eps standardise -> prior
+UNet -> flow decode -> clamp) over one synthetic LR batch already resident in HBM.  Workload at every N:
+BASELINE.json configs[1] per GPU (SRFlow-LP 4x DF2K config, batch 8 of 160x160 LR -> 640x640), i.e. weak
+scaling; for N > 1 the step ends with the RCCL all-gather of the SR outputs.
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+         bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel: the
+hoisted level-1 3x3 conv on fp32 MFMA, timed in situ with HIP events on the launch stream),
+`roofline_coupling_inverse` (the HBM-bound fused FlowStep-inverse kernel) and `cpu_baseline` (the oracle =
+reference-faithful torch-CPU port, bounded sample: one 160x160 image)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix peak (dense)
+PEAK_HBM_GBS = 8000.0            # HBM3E 8 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="LR crops per GPU")
+    ap.add_argument("--lr", type=int, default=160, help="LR crop side")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-lr", type=int, default=160, help="LR side of the CPU-baseline sample (B=1)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    from bfsr_amd import dist as bdist, synth
+    from bfsr_amd.ops import HipOps
+    from bfsr_amd.srflow import options, spec
+    from bfsr_amd.srflow.models import create_model, models as registry
+    from bfsr_amd.srflow.test import lp_infer
+
+    rank, world, local = bdist.init()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = "cuda:%d" % local
+    ops = HipOps(dev)
+
+    opt = options.load(options.DEFAULT_CONF)
+    scale = opt["scale"]
+    sd = synth.state_dict_from_schema(spec.srflownet_schema(opt), 1234)
+    psd = synth.state_dict_from_schema(spec.srflow_prior_schema(), 4321)
+    model = create_model(opt, ops=ops)
+    model.load_network(sd)
+    prior = registry.make({"name": "unet", "args": {"depth": 3, "dim": 64, "bilinear": True, "ops": ops}, "sd": psd},
+                          load_sd=True).eval()
+
+    B, h = args.batch, args.lr
+    H = h * scale
+    # distinct seeded batches per rank and step (global sample index = seed), resident in HBM before timing
+    n_batches = max(2, min(args.steps + args.warmup, 4))
+    batches = [ops.to_device(synth.lr_batch(1000 * rank + i, B, h, h)) for i in range(n_batches)]
+
+    # in-situ timing keys: dominant MFMA conv (hoisted level-1 3x3, 320 -> 16*64) and the level-1 inverse tail
+    C1 = 12
+    key_conv = ("conv", 3, 2, 320, 16 * 64, B, H // 2, H // 2)
+    key_tail = ("flow", 1, C1, B, H // 2, H // 2, True, True, True)
+    gathered = None
+
+    def step(i):
+        nonlocal gathered
+        x = batches[i % n_batches]
+        x.add_(0.0)                       # bump the version so the conditioning cache never hits across steps
+        sr = lp_infer(model, prior, x)
+        if world > 1:
+            gathered = bdist.all_gather_batch(sr, total=B * world)
+        return sr
+
+    for i in range(args.warmup):
+        step(i)
+    ops.profile_keys = {key_conv, key_tail}
+    ops.profile = {}
+    bdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    bdist.barrier()
+    dt = time.perf_counter() - t0
+    ops.profile_keys = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    mpix = world * B * H * H / 1e6
+    value = mpix * args.steps / dt
+
+    def avg_ms(key):
+        ev = ops.profile.get(key, [])
+        return (sum(s.elapsed_time(e) for s, e in ev) / len(ev), len(ev)) if ev else (None, 0)
+
+    conv_ms, conv_n = avg_ms(key_conv)
+    tail_ms, tail_n = avg_ms(key_tail)
+    hw1 = (H // 2) * (H // 2)
+    conv_flop = 2.0 * 320 * 9 * (16 * 64) * B * hw1                  # algorithmic flops of one launch
+    tail_bytes = 20.0 * C1 * B * hw1                                 # read z,h_aff,h_ft + write z
+    roofline = None
+    if conv_ms:
+        a = conv_flop / (conv_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "conv_mfma_kernel<3,2,4> (hoisted level-1 3x3 conv 320->1024)",
+                    "achieved": round(a, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(a / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(conv_ms, 4), "launches": conv_n}
+    roof_tail = None
+    if tail_ms:
+        a = tail_bytes / (tail_ms * 1e-3) / 1e9
+        roof_tail = {"bound": "hbm", "kernel": "flow_pointwise_kernel<12,4> reverse (level-1 FlowStep inverse tail)",
+                     "achieved": round(a, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(a / PEAK_HBM_GBS, 4),
+                     "traffic": None, "avg_launch_ms": round(tail_ms, 4), "launches": tail_n}
+
+    cpu_baseline, parity = None, None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle.srflow_ref as O          # checker / baseline only
+        cl = args.cpu_lr
+        x = synth.lr_batch(99, 1, cl, cl)
+        t1 = time.perf_counter()
+        ref = O.lp_pipeline(x, sd, psd, opt, opt["network_G"]["nb"], return_all=True)
+        cdt = time.perf_counter() - t1
+        cpu_baseline = {"value": round((cl * scale) ** 2 / 1e6 / cdt, 5), "unit": "MPix/s",
+                        "cores": torch.get_num_threads(), "kind": "port",
+                        "sample": "1 image %dx%d->%dx%d, oracle lp_pipeline (reference op order, RRDB twice), %.1f s"
+                                  % (cl, cl, cl * scale, cl * scale, cdt)}
+        out = lp_infer(model, prior, x, return_all=True)
+        torch.cuda.synchronize()
+        parity = {"max_abs_sr": float((out["sr"].cpu() - ref["sr"]).abs().max()),
+                  "max_abs_sr_raw": float((out["sr_raw"].cpu() - ref["sr_raw"]).abs().max()),
+                  "ref_absmax_sr_raw": float(ref["sr_raw"].abs().max()),
+                  "sample": "same %dx%d image vs oracle" % (cl, cl)}
+
+    if rank == 0:
+        line = {
+            "metric": "HR MPix/s, SRFlow-LP 4x flow-inverse SR (160->640), LP pipeline",
+            "value": round(value, 4), "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SRFlow-LP 4x DF2K config (K=16,L=3,nb=23), batch=%d/GPU %dx%d LR synthetic -> %dx%d, "
+                                   "LP path: RRDB + encode + standardise + prior UNet + decode + clamp%s"
+                                   % (B, h, h, H, H, ", + RCCL all-gather of outputs" if world > 1 else ""),
+                       "parallelism": "dp%d" % world, "weights": "seeded synthetic (conditioned recipe)"},
+            "roofline": roofline, "roofline_coupling_inverse": roof_tail, "cpu_baseline": cpu_baseline,
+            "parity": parity,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

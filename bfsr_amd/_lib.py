@@ -1,0 +1,86 @@
+"""ctypes binding of libbfsr_hip.so (the C ABI declared in include/bfsr_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a RuntimeError
+is raised.  Build it with `bfsr_amd/csrc/build.sh` (or `__graft_entry__.build()`).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbfsr_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class BfsrConvArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("x_bs", C.c_longlong), ("Cin", C.c_int),
+        ("w", C.c_void_p),
+        ("y", C.c_void_p), ("y_bs", C.c_longlong), ("Cout", C.c_int),
+        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("KS", C.c_int), ("in_shift", C.c_int),
+        ("mtile", C.c_int),
+        ("bias", C.c_void_p),
+        ("pre_add", C.c_void_p), ("pre_add_bs", C.c_longlong),
+        ("aff_shift", C.c_void_p), ("aff_scale", C.c_void_p), ("aff_post", C.c_void_p),
+        ("act", C.c_int), ("slope", C.c_float),
+        ("post_scale", C.c_void_p),
+        ("res1", C.c_void_p), ("res1_bs", C.c_longlong), ("alpha1", C.c_float),
+        ("res2", C.c_void_p), ("res2_bs", C.c_longlong), ("alpha2", C.c_float),
+    ]
+
+
+class BfsrFlowArgs(C.Structure):
+    _fields_ = [
+        ("z_in", C.c_void_p), ("z_in_bs", C.c_longlong),
+        ("z_out", C.c_void_p), ("z_out_bs", C.c_longlong),
+        ("h_aff", C.c_void_p), ("h_aff_bs", C.c_longlong),
+        ("h_ft", C.c_void_p), ("h_ft_bs", C.c_longlong),
+        ("w", C.c_void_p), ("an_bias", C.c_void_p), ("an_escale", C.c_void_p),
+        ("B", C.c_int), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("reverse", C.c_int), ("eps", C.c_float),
+    ]
+
+
+# every symbol include/bfsr_hip.h declares: name -> (restype, argtypes)
+_LL, _I, _F, _VP = C.c_longlong, C.c_int, C.c_float, C.c_void_p
+SYMBOLS = {
+    "bfsr_abi_version": (_I, []),
+    "bfsr_conv_packed_size": (_LL, [_I, _I, _I, _I]),
+    "bfsr_pack_conv_weight": (_I, [_VP, _I, _I, _I, _I, _VP]),
+    "bfsr_conv2d": (_I, [C.POINTER(BfsrConvArgs), _VP]),
+    "bfsr_flow_pointwise": (_I, [C.POINTER(BfsrFlowArgs), _VP]),
+    "bfsr_squeeze2d": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
+    "bfsr_unsqueeze2d": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
+    "bfsr_split2d": (_I, [_VP, _LL, _VP, _LL, _VP, _LL, _I, _I, _I, _I, _I, _VP]),
+    "bfsr_standardize": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
+    "bfsr_resize": (_I, [_VP, _LL, _I, _I, _VP, _LL, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _VP]),
+    "bfsr_maxpool2": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
+    "bfsr_axpb_clamp": (_I, [_VP, _LL, _VP, _LL, _VP, _LL, _I, _I, _I, _I, _F, _F, _F, _F, _VP]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libbfsr_hip.so once; raise loudly if it is absent (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "bfsr_amd: %s not found -- the HIP extension is required (build with "
+            "bfsr_amd/csrc/build.sh or __graft_entry__.build()); there is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.bfsr_abi_version() != 1:
+        raise RuntimeError("bfsr_amd: ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(err, what):
+    if err != 0:
+        raise RuntimeError("bfsr_amd: %s failed with code %d" % (what, err))

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Build libbfsr_hip.so for gfx950 (cross-compiles without a GPU).  Usage: bfsr_amd/csrc/build.sh
+set -e
+cd "$(dirname "$0")"
+OUT=../lib
+mkdir -p "$OUT" build
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off"
+pids=()
+for f in conv_mfma flow_ops resample; do
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ ../../include/bfsr_hip.h -nt build/$f.o ]; then
+    $HIPCC $FLAGS -c $f.hip -o build/$f.o &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC build/conv_mfma.o build/flow_ops.o build/resample.o -o "$OUT/libbfsr_hip.so"
+echo "built $OUT/libbfsr_hip.so"

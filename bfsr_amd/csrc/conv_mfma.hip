@@ -1,0 +1,256 @@
+// conv_mfma.hip -- fp32 implicit-GEMM convolution (3x3 'same' / 1x1, stride 1) on the CDNA4 matrix
+// cores (v_mfma_f32_32x32x2_f32: exact fp32, 157 TFLOP/s peak on MI355X), fused epilogue.
+//
+// GEMM view per workgroup:  D[cout][pixel] = sum_{cin,tap} Wt[cout][cin,tap] * X[cin,tap][pixel]
+//   M = cout  (MR tiles of 32 per workgroup)            -> A operand = weights
+//   N = pixel (32 consecutive pixels of one image row)  -> B operand = input
+//   K = cin * taps, walked CK input channels at a time through LDS
+// With M = cout the accumulator layout puts 32 consecutive pixels of one (cout,row) in lanes 0..31,
+// so epilogue loads/stores are 128-byte coalesced in NCHW.
+//
+// Workgroup = 256 threads = 4 wave64; pixel tile = (4*NR rows) x 32 cols; each wave owns NR rows and
+// all MR cout tiles: acc[MR][NR] of 16 VGPRs each.  LDS holds the CK-channel input tile with halo
+// ([CK][TH+2][34]) and the weight slab ([CK][taps][MR*32]); two workgroups per CU overlap one
+// group's staging with the other's MFMA stream.
+#include <hip/hip_runtime.h>
+#include "../../include/bfsr_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+template <int KS> struct ConvCfg { static constexpr int CK = (KS == 3) ? 8 : 16; };
+
+template <int KS, int MR, int NR>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(BfsrConvArgs p, int tiles_x, int tiles_xy, int groups)
+{
+    constexpr int CK = ConvCfg<KS>::CK;
+    constexpr int TH = 4 * NR, TW = 32;
+    constexpr int HALO = KS - 1;
+    constexpr int IH = TH + HALO, PW = TW + HALO;
+    constexpr int NPOS = IH * PW;
+    constexpr int PPT = (NPOS + 255) / 256;          // staged positions per thread
+    constexpr int TAPS = KS * KS;
+    constexpr int MW = MR * 32;
+    constexpr int WCHUNK = CK * TAPS * MW;           // floats of weights per cin chunk
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sW = smem;                                // [CK][TAPS][MW]  (16B aligned for float4 stores)
+    float* sIn = smem + WCHUNK;                      // [CK][IH][PW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    // block id -> (cout group fastest, spatial tile, batch): groups of one tile run back to back
+    int bid = blockIdx.x;
+    const int cg = bid % groups; bid /= groups;
+    const int tile = bid % tiles_xy; const int b = bid / tiles_xy;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int x0 = tx * TW, y0 = ty * TH;
+
+    const int H = p.H, W = p.W, sh = p.in_shift;
+    const int Ws = W >> sh;
+    const long long cs_in = (long long)(H >> sh) * Ws;   // input channel stride
+    const float* __restrict__ xin = p.x + (long long)b * p.x_bs;
+    const int Cin = p.Cin;
+    const int cin_pad = (Cin + CK - 1) / CK * CK;
+    const float* __restrict__ wg = p.w + (long long)cg * cin_pad * TAPS * MW;
+
+    // per-thread staging positions (same spatial position for all CK channels)
+    int soff[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int pos = tid + i * 256;
+        const int r = pos / PW, c = pos - r * PW;
+        const int gy = y0 + r - HALO / 2, gx = x0 + c - HALO / 2;
+        const bool ok = (pos < NPOS) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        soff[i] = ok ? ((gy >> sh) * Ws + (gx >> sh)) : -1;
+    }
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int n = 0; n < NR; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    // register-staged software pipeline: the loads of chunk k+1 are in flight during the MFMAs of chunk k
+    constexpr int WV = (WCHUNK / 4 + 255) / 256;     // float4 weight loads per thread
+    float vin[PPT][CK];
+    float4 vw[WV];
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int so = soff[i] < 0 ? 0 : soff[i];      // always a valid address; masked at the LDS write
+#pragma unroll
+            for (int c = 0; c < CK; ++c) {
+                int ch = c0 + c; ch = ch < Cin ? ch : Cin - 1;
+                vin[i][c] = xin[(long long)ch * cs_in + so];
+            }
+        }
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(wg + (long long)c0 * TAPS * MW);
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            int idx = tid + i * 256; idx = idx < WCHUNK / 4 ? idx : WCHUNK / 4 - 1;
+            vw[i] = src[idx];
+        }
+    };
+    load_chunk(0);
+
+    for (int c0 = 0; c0 < cin_pad; c0 += CK) {
+        __syncthreads();
+        // ---- registers -> LDS (input tile zero padded outside the image; weight slab contiguous)
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int pos = tid + i * 256;
+            if (pos < NPOS) {
+                const bool ok = soff[i] >= 0;
+#pragma unroll
+                for (int c = 0; c < CK; ++c) sIn[c * NPOS + pos] = ok ? vin[i][c] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < WCHUNK / 4) reinterpret_cast<float4*>(sW)[idx] = vw[i];
+        }
+        __syncthreads();
+        if (c0 + CK < cin_pad) load_chunk(c0 + CK);
+        // ---- MFMA stream
+#pragma unroll
+        for (int kk = 0; kk < CK / 2; ++kk) {
+            const int c = 2 * kk + lhi;
+            const float* inC = sIn + c * NPOS + (wave * NR) * PW + l31;
+            const float* wC = sW + c * TAPS * MW + l31;
+#pragma unroll
+            for (int dx = 0; dx < KS; ++dx) {
+                float brow[NR + HALO];
+#pragma unroll
+                for (int r = 0; r < NR + HALO; ++r) brow[r] = inC[r * PW + dx];
+#pragma unroll
+                for (int dy = 0; dy < KS; ++dy) {
+                    float a[MR];
+#pragma unroll
+                    for (int m = 0; m < MR; ++m) a[m] = wC[(dy * KS + dx) * MW + m * 32];
+#pragma unroll
+                    for (int m = 0; m < MR; ++m)
+#pragma unroll
+                        for (int n = 0; n < NR; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], brow[n + dy], acc[m][n], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: lane holds pixel column l31 of row (wave*NR+n) and 16 couts per M tile
+    const int gx = x0 + l31;
+    if (gx >= W) return;
+    const long long HW = (long long)H * W;
+    const int Cout = p.Cout;
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+        const int gy = y0 + wave * NR + n;
+        if (gy >= H) continue;
+        const long long pix = (long long)gy * W + gx;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (cg * MR + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (co >= Cout) continue;
+                float v = acc[m][n][r];
+                const long long o = (long long)co * HW + pix;
+                if (p.bias) v += p.bias[co];
+                if (p.pre_add) v += p.pre_add[(long long)b * p.pre_add_bs + o];
+                if (p.aff_shift) v += p.aff_shift[co];
+                if (p.aff_scale) v *= p.aff_scale[co];
+                if (p.aff_post) v += p.aff_post[co];
+                if (p.act == BFSR_ACT_RELU) v = fmaxf(v, 0.f);
+                else if (p.act == BFSR_ACT_LRELU) v = v > 0.f ? v : v * p.slope;
+                if (p.post_scale) v *= p.post_scale[co];
+                if (p.res1) v = p.alpha1 * v + p.res1[(long long)b * p.res1_bs + o];
+                if (p.res2) v = p.alpha2 * v + p.res2[(long long)b * p.res2_bs + o];
+                p.y[(long long)b * p.y_bs + o] = v;
+            }
+        }
+    }
+}
+
+template <int KS, int MR, int NR>
+int launch_conv(const BfsrConvArgs& a, hipStream_t st)
+{
+    constexpr int CK = ConvCfg<KS>::CK;
+    constexpr int TH = 4 * NR, TW = 32, HALO = KS - 1;
+    constexpr int LDS = (CK * KS * KS * MR * 32 + CK * (TH + HALO) * (TW + HALO)) * 4;
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const int groups = ((a.Cout + 31) / 32 + MR - 1) / MR;
+    const long long nblk = (long long)tiles_x * tiles_y * groups * a.B;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return -1;
+    static bool attr_set = false;
+    if (!attr_set && LDS > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<KS, MR, NR>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, MR, NR>), dim3((unsigned)nblk), dim3(256), LDS, st, a, tiles_x,
+                       tiles_x * tiles_y, groups);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" long long bfsr_conv_packed_size(int Cout, int Cin, int KS, int mtile)
+{
+    const int CK = (KS == 3) ? 8 : 16;
+    const int cin_pad = (Cin + CK - 1) / CK * CK;
+    const int groups = ((Cout + 31) / 32 + mtile - 1) / mtile;
+    return (long long)groups * cin_pad * KS * KS * mtile * 32;
+}
+
+extern "C" int bfsr_pack_conv_weight(const float* w, int Cout, int Cin, int KS, int mtile, float* packed)
+{
+    if ((KS != 1 && KS != 3) || mtile < 1) return -1;
+    const int CK = (KS == 3) ? 8 : 16;
+    const int cin_pad = (Cin + CK - 1) / CK * CK;
+    const int MW = mtile * 32, T = KS * KS;
+    const int groups = ((Cout + 31) / 32 + mtile - 1) / mtile;
+    const long long n = (long long)groups * cin_pad * T * MW;
+    for (long long i = 0; i < n; ++i) packed[i] = 0.f;
+    for (int co = 0; co < Cout; ++co) {
+        const int g = co / MW, m = co % MW;
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int t = 0; t < T; ++t)
+                packed[(((long long)g * cin_pad + ci) * T + t) * MW + m] = w[((long long)co * Cin + ci) * T + t];
+    }
+    return 0;
+}
+
+extern "C" int bfsr_conv2d(const BfsrConvArgs* a, void* stream)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!a || !a->x || !a->w || !a->y) return -1;
+    if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cin <= 0 || a->Cout <= 0) return -1;
+    if (a->in_shift < 0 || a->in_shift > 4) return -1;
+    if (a->in_shift && (((a->H >> a->in_shift) << a->in_shift) != a->H || ((a->W >> a->in_shift) << a->in_shift) != a->W))
+        return -1;
+    // NR (rows per wave): 4 for large images, 2 when the grid would otherwise be too small
+    const long long px = (long long)a->B * a->H * a->W;
+    const bool small = px < 512LL * 512;     // fewer than ~512 tiles of 16x32
+#define BFSR_DISPATCH(KS_, MR_)                                                                  \
+    do {                                                                                         \
+        if (small) return launch_conv<KS_, MR_, 2>(*a, st);                                      \
+        return launch_conv<KS_, MR_, 4>(*a, st);                                                 \
+    } while (0)
+    if (a->KS == 3) {
+        if (a->mtile == 1) BFSR_DISPATCH(3, 1);
+        if (a->mtile == 2) BFSR_DISPATCH(3, 2);
+        if (a->mtile == 3) return launch_conv<3, 3, 2>(*a, st);
+    } else if (a->KS == 1) {
+        if (a->mtile == 1) BFSR_DISPATCH(1, 1);
+        if (a->mtile == 2) BFSR_DISPATCH(1, 2);
+        if (a->mtile == 3) return launch_conv<1, 3, 2>(*a, st);
+    }
+#undef BFSR_DISPATCH
+    return -1;
+}

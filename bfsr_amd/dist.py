@@ -1,0 +1,65 @@
+"""Data-parallel sharding of the hot path: one process per GPU, `torch.distributed` (backend "nccl" = RCCL on
+ROCm, over xGMI inside a node).  Every op on the path is per-sample (eval-mode BN/ActNorm are fixed
+per-channel affines, eps standardisation is per pixel), so the batch dimension shards exactly: rank r
+takes `lr[r*B/N:(r+1)*B/N]`, weights are replicated (each rank builds them itself) and the only exchange
+is one all-gather of the `[B/N,3,H,W]` outputs (reference: nn.DataParallel scatter/gather,
+SRFlow-LP/code/models/SRFlow_model.py:53)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init(backend=None):
+    """Initialise from the torchrun environment; returns (rank, world_size, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous near-equal split of n units (first n % world ranks get one extra)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard(batch, rank, world):
+    lo, hi = shard_bounds(batch.shape[0], rank, world)
+    return batch[lo:hi]
+
+
+def all_gather_batch(local_out, total=None):
+    """All-gather per-rank outputs along dim 0.  Equal shards use one all_gather_into_tensor (a single
+    RCCL collective); ragged shards are padded to the largest shard."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local_out
+    world = dist.get_world_size()
+    n_local = torch.tensor([local_out.shape[0]], device=local_out.device, dtype=torch.long)
+    if total is not None and total % world == 0:
+        out = local_out.new_empty((total,) + tuple(local_out.shape[1:]))
+        dist.all_gather_into_tensor(out, local_out.contiguous())
+        return out
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local)
+    counts = [int(c.item()) for c in counts]
+    m = max(counts)
+    pad = local_out.new_zeros((m,) + tuple(local_out.shape[1:]))
+    pad[:local_out.shape[0]] = local_out
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0)
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()

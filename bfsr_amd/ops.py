@@ -1,0 +1,204 @@
+"""Python face of the HIP kernels: thin wrappers that turn torch CUDA(ROCm) tensors into the
+(pointer, batch stride, dims) views of the C ABI and launch on torch's current stream.
+
+PyTorch is plumbing here (device memory, streams); all arithmetic on the hot path happens in
+libbfsr_hip.so.  `HipOps` is the only ops backend of the product; tests may substitute a CPU
+test double with the same interface to exercise the host-side schedule without a GPU.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+MODE_NEAREST, MODE_BILINEAR, MODE_BILINEAR_AC = 0, 1, 2
+
+
+def _view(t, name="tensor"):
+    """(ptr, batch_stride, C, H, W) of an NCHW fp32 view with contiguous planes."""
+    if t.dtype != torch.float32 or t.dim() != 4:
+        raise ValueError("%s: need a 4-d float32 tensor" % name)
+    B, Cc, H, W = t.shape
+    s = t.stride()
+    if not (s[3] == 1 and s[2] == W and (Cc == 1 or s[1] == H * W)):
+        raise ValueError("%s: not an NCHW plane-contiguous view (shape %s stride %s)" % (name, tuple(t.shape), s))
+    bs = s[0] if B > 1 else Cc * H * W
+    return t.data_ptr(), bs, Cc, H, W
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class PackedConv(object):
+    """A conv weight packed for the MFMA kernel (layout private to the library)."""
+    __slots__ = ("data", "Cout", "Cin", "KS", "mtile")
+
+    def __init__(self, data, Cout, Cin, KS, mtile):
+        self.data, self.Cout, self.Cin, self.KS, self.mtile = data, Cout, Cin, KS, mtile
+
+
+def default_mtile(Cout):
+    t = (Cout + 31) // 32
+    return 1 if t <= 1 else (3 if t == 3 else 2)
+
+
+class HipOps(object):
+    def __init__(self, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("bfsr_amd: no GPU visible -- the engine has no CPU path")
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        # optional in-situ timing: launches whose key is in `profile_keys` are bracketed by HIP events on the
+        # launch stream; bench.py reads `profile` (key -> [(start, end), ...]) after synchronising.
+        self.profile_keys, self.profile = None, {}
+
+    def _launch(self, key, fn):
+        if self.profile_keys is None or key not in self.profile_keys:
+            return fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st = torch.cuda.current_stream(self.device)
+        s.record(st)
+        r = fn()
+        e.record(st)
+        self.profile.setdefault(key, []).append((s, e))
+        return r
+
+    # ---- memory ---------------------------------------------------------------------------
+    def empty(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    def zeros(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float32, device=self.device)
+
+    def to_device(self, t):
+        return t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- conv -----------------------------------------------------------------------------
+    def pack_conv(self, w, mtile=None, out_perm=None):
+        """w: [Cout,Cin,KS,KS] (any device).  out_perm: optional list, packed cout j = w[out_perm[j]]."""
+        w = w.detach().to("cpu", torch.float32).contiguous()
+        if out_perm is not None:
+            w = w[torch.as_tensor(out_perm, dtype=torch.long)].contiguous()
+        Cout, Cin, KS, _ = w.shape
+        mtile = mtile or default_mtile(Cout)
+        n = self.lib.bfsr_conv_packed_size(Cout, Cin, KS, mtile)
+        packed = torch.empty(n, dtype=torch.float32)
+        _lib.check(self.lib.bfsr_pack_conv_weight(w.data_ptr(), Cout, Cin, KS, mtile, packed.data_ptr()), "pack_conv_weight")
+        return PackedConv(packed.to(self.device), Cout, Cin, KS, mtile)
+
+    def vec(self, t):
+        """A per-channel parameter vector on the device."""
+        return t.detach().reshape(-1).to(device=self.device, dtype=torch.float32).contiguous()
+
+    def conv(self, x, pw, out, in_shift=0, bias=None, pre_add=None, aff_shift=None, aff_scale=None,
+             aff_post=None, act=ACT_NONE, slope=0.2, post_scale=None, res1=None, alpha1=1.0, res2=None, alpha2=1.0):
+        xp, xbs, Cin, Hs, Ws = _view(x, "conv.x")
+        yp, ybs, Cout, H, W = _view(out, "conv.out")
+        if Cin != pw.Cin or Cout != pw.Cout or (Hs << in_shift) != H or (Ws << in_shift) != W or x.shape[0] != out.shape[0]:
+            raise ValueError("conv: shape mismatch x%s out%s weight(Cout=%d,Cin=%d) in_shift=%d" %
+                             (tuple(x.shape), tuple(out.shape), pw.Cout, pw.Cin, in_shift))
+        a = _lib.BfsrConvArgs()
+        a.x, a.x_bs, a.Cin = xp, xbs, Cin
+        a.w = pw.data.data_ptr()
+        a.y, a.y_bs, a.Cout = yp, ybs, Cout
+        a.B, a.H, a.W, a.KS, a.in_shift, a.mtile = out.shape[0], H, W, pw.KS, in_shift, pw.mtile
+        a.bias = _ptr(bias)
+        if pre_add is not None:
+            p, bs, c, h, w = _view(pre_add, "conv.pre_add")
+            assert (c, h, w) == (Cout, H, W)
+            a.pre_add, a.pre_add_bs = p, bs
+        a.aff_shift, a.aff_scale, a.aff_post = _ptr(aff_shift), _ptr(aff_scale), _ptr(aff_post)
+        a.act, a.slope = act, slope
+        a.post_scale = _ptr(post_scale)
+        if res1 is not None:
+            p, bs, c, h, w = _view(res1, "conv.res1")
+            assert (c, h, w) == (Cout, H, W)
+            a.res1, a.res1_bs, a.alpha1 = p, bs, alpha1
+        if res2 is not None:
+            p, bs, c, h, w = _view(res2, "conv.res2")
+            assert (c, h, w) == (Cout, H, W)
+            a.res2, a.res2_bs, a.alpha2 = p, bs, alpha2
+        key = ("conv", pw.KS, pw.mtile, Cin, Cout, out.shape[0], H, W)
+        _lib.check(self._launch(key, lambda: self.lib.bfsr_conv2d(C.byref(a), self._stream())), "conv2d")
+        return out
+
+    # ---- flow pointwise ---------------------------------------------------------------------
+    def flow_pointwise(self, z_in, z_out, reverse, h_aff=None, h_ft=None, w=None, an_bias=None, an_escale=None,
+                       eps=1e-4):
+        a = _lib.BfsrFlowArgs()
+        a.z_in, a.z_in_bs, Cc, H, W = _view(z_in, "flow.z_in")
+        a.z_out, a.z_out_bs, c2, h2, w2 = _view(z_out, "flow.z_out")
+        assert (Cc, H, W) == (c2, h2, w2)
+        if h_aff is not None:
+            a.h_aff, a.h_aff_bs, c, h, ww = _view(h_aff, "flow.h_aff")
+            assert (c, h, ww) == (2 * (Cc - Cc // 2), H, W)
+        if h_ft is not None:
+            a.h_ft, a.h_ft_bs, c, h, ww = _view(h_ft, "flow.h_ft")
+            assert (c, h, ww) == (2 * Cc, H, W)
+        a.w, a.an_bias, a.an_escale = _ptr(w), _ptr(an_bias), _ptr(an_escale)
+        a.B, a.C, a.H, a.W = z_in.shape[0], Cc, H, W
+        a.reverse, a.eps = int(bool(reverse)), eps
+        key = ("flow", int(bool(reverse)), Cc, z_in.shape[0], H, W, h_aff is not None, h_ft is not None, w is not None)
+        _lib.check(self._launch(key, lambda: self.lib.bfsr_flow_pointwise(C.byref(a), self._stream())),
+                   "flow_pointwise(C=%d)" % Cc)
+        return z_out
+
+    def squeeze2d(self, x, y):
+        xp, xbs, Cc, H, W = _view(x)
+        yp, ybs, c2, h2, w2 = _view(y)
+        assert (c2, h2, w2) == (4 * Cc, H // 2, W // 2)
+        _lib.check(self.lib.bfsr_squeeze2d(xp, xbs, yp, ybs, x.shape[0], Cc, H, W, self._stream()), "squeeze2d")
+        return y
+
+    def unsqueeze2d(self, x, y):
+        xp, xbs, Cc, H, W = _view(x)
+        yp, ybs, c2, h2, w2 = _view(y)
+        assert (c2 * 4, h2, w2) == (Cc, 2 * H, 2 * W)
+        _lib.check(self.lib.bfsr_unsqueeze2d(xp, xbs, yp, ybs, x.shape[0], Cc, H, W, self._stream()), "unsqueeze2d")
+        return y
+
+    def split2d(self, h, src, dst, reverse):
+        hp, hbs, c2, H, W = _view(h)
+        sp, sbs, Cc, _, _ = _view(src)
+        dp, dbs, _, _, _ = _view(dst)
+        assert c2 == 2 * Cc and dst.shape == src.shape
+        _lib.check(self.lib.bfsr_split2d(hp, hbs, sp, sbs, dp, dbs, src.shape[0], Cc, H, W, int(bool(reverse)),
+                                         self._stream()), "split2d")
+        return dst
+
+    def standardize(self, x, y):
+        xp, xbs, Cc, H, W = _view(x)
+        yp, ybs, _, _, _ = _view(y)
+        _lib.check(self.lib.bfsr_standardize(xp, xbs, yp, ybs, x.shape[0], Cc, H, W, self._stream()), "standardize")
+        return y
+
+    def resize(self, x, y, mode, r_h, r_w, window=None):
+        """window = (oy0, ox0, RH, RW): the resized image occupies that sub-window of y, rest zero."""
+        xp, xbs, Cc, IH, IW = _view(x)
+        yp, ybs, c2, OH, OW = _view(y)
+        assert Cc == c2
+        oy0, ox0, RH, RW = window if window is not None else (0, 0, OH, OW)
+        _lib.check(self.lib.bfsr_resize(xp, xbs, IH, IW, yp, ybs, OH, OW, RH, RW, oy0, ox0, x.shape[0], Cc, mode,
+                                        float(r_h), float(r_w), self._stream()), "resize")
+        return y
+
+    def maxpool2(self, x, y):
+        xp, xbs, Cc, H, W = _view(x)
+        yp, ybs, _, _, _ = _view(y)
+        _lib.check(self.lib.bfsr_maxpool2(xp, xbs, yp, ybs, x.shape[0], Cc, H, W, self._stream()), "maxpool2")
+        return y
+
+    def axpb_clamp(self, x, y, a=1.0, b=0.0, lo=-3.4e38, hi=3.4e38, r=None):
+        xp, xbs, Cc, H, W = _view(x)
+        yp, ybs, _, _, _ = _view(y)
+        rp, rbs = (None, 0)
+        if r is not None:
+            rp, rbs, _, _, _ = _view(r)
+        _lib.check(self.lib.bfsr_axpb_clamp(xp, xbs, rp, rbs, yp, ybs, x.shape[0], Cc, H, W, a, b, lo, hi,
+                                            self._stream()), "axpb_clamp")
+        return y

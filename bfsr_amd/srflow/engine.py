@@ -1,0 +1,363 @@
+"""Host-side schedule of SRFlow-LP on the HIP kernels (result-preserving restructuring of the
+reference):
+
+  * RRDB conditioning features are computed ONCE per LR batch (the reference recomputes the whole
+    RRDB in decode, SRFlowNet_arch.py:152-153) and the heads no flow level reads (`upconv2`/`HRconv`/
+    `conv_last` for 4x) are never computed;
+  * everything in the coupling nets that depends only on the conditioning features `ft` -- the whole
+    fFeatures net and the `ft` rows of fAffine's first conv (96 % of the flow MACs at level 1,
+    FlowAffineCouplingsAblation.py:108-119) -- is hoisted out of the sequential FlowStep chain,
+    batched over the K steps of a level and shared by encode and decode;
+  * inverse 1x1-conv weights are inverted once (fp64 -> fp32, Permutations.py:41 does it per call);
+  * growing concats (RDB, DenseBlock, `cat[z1, ft]`, `cat[skip, up]`) are never materialised: producers
+    write into channel slices of one buffer, consumers read channel-slice views.
+
+`ops` is the kernel backend (bfsr_amd.ops.HipOps).  No arithmetic happens in this file.
+"""
+import torch
+
+from . import spec
+from .options import opt_get
+from ..ops import ACT_LRELU, ACT_NONE, ACT_RELU, MODE_BILINEAR, MODE_BILINEAR_AC, MODE_NEAREST
+
+# fea_up{k} lives at LR resolution * 2^shift
+_KEY_SHIFT = {"fea_up0": -1, "fea_up1": 0, "fea_up2": 1, "fea_up4": 2, "fea_up8": 3}
+
+
+class _ConvP(object):
+    """A packed conv + its per-channel epilogue vectors (all device tensors)."""
+
+    def __init__(self, ops, w, bias=None, aff_shift=None, aff_scale=None, aff_post=None, post_scale=None, mtile=None):
+        self.pw = ops.pack_conv(w, mtile)
+        v = lambda t: None if t is None else ops.vec(t)
+        self.bias, self.aff_shift, self.aff_scale = v(bias), v(aff_shift), v(aff_scale)
+        self.aff_post, self.post_scale = v(aff_post), v(post_scale)
+
+    def run(self, ops, x, out, **kw):
+        return ops.conv(x, self.pw, out, bias=self.bias, aff_shift=self.aff_shift, aff_scale=self.aff_scale,
+                        aff_post=self.aff_post, post_scale=self.post_scale, **kw)
+
+
+class _Workspace(object):
+    """Named scratch buffers, reallocated only when the requested shape changes."""
+
+    def __init__(self, ops):
+        self.ops, self.bufs = ops, {}
+
+    def get(self, name, *shape):
+        t = self.bufs.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = self.ops.empty(*shape)
+            self.bufs[name] = t
+        return t
+
+
+class RRDBEncoder(object):
+    """RRDBNet trunk (RRDBNet_arch.py:67-148 / LINF-LP/models/rrdb.py:77-116): conv_first, nb x RRDB
+    (3 x RDB of five 3x3 convs), trunk_conv + skip.  `taps` = RRDB indices whose output is wanted."""
+
+    def __init__(self, ops, sd, prefix, nb, nf=64, gc=32):
+        self.ops, self.nb, self.nf, self.gc = ops, nb, nf, gc
+        g = lambda n: sd[prefix + n]
+        self.conv_first = _ConvP(ops, g("conv_first.weight"), g("conv_first.bias"))
+        self.blocks = []
+        for b in range(nb):
+            rdbs = []
+            for r in (1, 2, 3):
+                p = "RRDB_trunk.%d.RDB%d." % (b, r)
+                rdbs.append([_ConvP(ops, g(p + "conv%d.weight" % i), g(p + "conv%d.bias" % i)) for i in range(1, 6)])
+            self.blocks.append(rdbs)
+        self.trunk_conv = _ConvP(ops, g("trunk_conv.weight"), g("trunk_conv.bias"))
+        self.ws = _Workspace(ops)
+
+    def forward(self, x, out, on_block=None):
+        """x [B,3,h,w] -> out (a [B,nf,h,w] view) = fea + trunk_conv(fea).  `on_block(idx, fea_view)` is
+        called after RRDB idx with a view that is only valid during the call."""
+        ops, nf, gc = self.ops, self.nf, self.gc
+        B, _, h, w = x.shape
+        ring = [self.ws.get("dense%d" % i, B, nf + 4 * gc, h, w) for i in range(4)]
+        cur = 0
+        self.conv_first.run(ops, x, ring[cur][:, :nf])
+        for idx, rdbs in enumerate(self.blocks):
+            x_rrdb = ring[cur][:, :nf]
+            for r, convs in enumerate(rdbs):
+                D = ring[cur]
+                for i in range(4):          # conv1..4: bias + LeakyReLU, written into the next 32-ch slice
+                    convs[i].run(ops, D[:, :nf + i * gc], D[:, nf + i * gc: nf + (i + 1) * gc], act=ACT_LRELU, slope=0.2)
+                nxt = (cur + 1) % 4
+                if r < 2:                   # x5*0.2 + x
+                    convs[4].run(ops, D, ring[nxt][:, :nf], res1=D[:, :nf], alpha1=0.2)
+                else:                       # (x5*0.2 + x)*0.2 + x_rrdb
+                    convs[4].run(ops, D, ring[nxt][:, :nf], res1=D[:, :nf], alpha1=0.2, res2=x_rrdb, alpha2=0.2)
+                cur = nxt
+            if on_block is not None:
+                on_block(idx, ring[cur][:, :nf])
+        fea = ring[cur][:, :nf]
+        self.trunk_conv.run(ops, fea, out, res1=fea, alpha1=1.0)      # last_lr_fea = fea + trunk
+        return out
+
+
+class _CouplingStep(object):
+    """Device-side parameters of one FlowStep (FlowStep.py:31-86)."""
+
+
+class SRFlowEngine(object):
+    def __init__(self, opt, sd, ops, nb=None):
+        self.opt, self.ops = opt, ops
+        g = opt["network_G"]
+        self.scale = opt["scale"]
+        self.nb = nb if nb is not None else g["nb"]
+        self.layers = spec.flow_layers(opt)
+        self.level_names = spec.level_to_name(self.scale)
+        self.L = g["flow"]["L"]
+        self.block_idxs = list(opt_get(opt, ["network_G", "flow", "stackRRDB", "blocks"]) or [])
+        self.concat = bool(opt_get(opt, ["network_G", "flow", "stackRRDB", "concat"]))
+        self.n_cond = spec.n_rrdb_channels(opt) if self.concat else 64
+        if self.n_cond != spec.IN_CHANNELS_RRDB:
+            raise NotImplementedError("coupling nets hard-code 320 conditioning channels "
+                                      "(FlowAffineCouplingsAblation.py:30); got %d" % self.n_cond)
+        self.ws = _Workspace(ops)
+        self._cond_key, self._cond = None, None
+        self._load(sd)
+
+    # ------------------------------------------------------------------------------------------
+    def _load(self, sd):
+        ops = self.ops
+        sd = {k: v.detach().to("cpu", torch.float32) for k, v in sd.items()}
+        self.rrdb = RRDBEncoder(ops, sd, "RRDB.", self.nb, nf=self.opt["network_G"]["nf"])
+        need = set(self.level_names[l] for l in range(1, self.L + 1))
+        self.need_keys = need
+        g = lambda n: sd["RRDB." + n]
+        self.upconvs = {}
+        chain = [("fea_up2", "upconv1"), ("fea_up4", "upconv2"), ("fea_up8", "upconv3")]
+        deepest = max([i for i, (k, _) in enumerate(chain) if k in need], default=-1)
+        for i in range(deepest + 1):
+            k, n = chain[i]
+            self.upconvs[k] = _ConvP(ops, g(n + ".weight"), g(n + ".bias"))
+        if "fea_up0" in need and not opt_get(self.opt, ["network_G", "flow", "fea_up0"]):
+            raise ValueError("flow level needs fea_up0 but network_G.flow.fea_up0 is not enabled")
+
+        P = "flowUpsamplerNet.layers.%d."
+        self.steps = {}
+        self.splits = {}
+        for ly in self.layers:
+            p = P % ly.index
+            if ly.type == "step":
+                st = _CouplingStep()
+                C = ly.C
+                W = sd[p + "invconv.weight"]
+                st.w_fwd = ops.vec(W)
+                st.w_inv = ops.vec(torch.inverse(W.double()).float())        # Permutations.py:41, once
+                logs = sd[p + "actnorm.logs"].reshape(-1)
+                st.an_bias = ops.vec(sd[p + "actnorm.bias"])
+                st.an_exp = ops.vec(torch.exp(logs))
+                st.an_expneg = ops.vec(torch.exp(-logs))
+                if ly.coupled:
+                    cn = C // 2
+                    a = p + "affine.fAffine."
+                    w0 = sd[a + "0.weight"]
+                    st.aff0_z1 = _ConvP(ops, w0[:, :cn].contiguous(), aff_shift=sd[a + "0.actnorm.bias"],
+                                        aff_scale=torch.exp(sd[a + "0.actnorm.logs"]))
+                    st.aff0_ft_w = w0[:, cn:].contiguous()                     # hoisted (batched per level)
+                    st.aff2 = _ConvP(ops, sd[a + "2.weight"], aff_shift=sd[a + "2.actnorm.bias"],
+                                     aff_scale=torch.exp(sd[a + "2.actnorm.logs"]))
+                    st.aff4 = _ConvP(ops, sd[a + "4.weight"], bias=sd[a + "4.bias"],
+                                     post_scale=torch.exp(sd[a + "4.logs"] * 3))
+                    f = p + "affine.fFeatures."
+                    st.ft0_w = sd[f + "0.weight"]
+                    st.ft0_shift = sd[f + "0.actnorm.bias"].reshape(-1)
+                    st.ft0_scale = torch.exp(sd[f + "0.actnorm.logs"]).reshape(-1)
+                    st.ft2 = _ConvP(ops, sd[f + "2.weight"], aff_shift=sd[f + "2.actnorm.bias"],
+                                    aff_scale=torch.exp(sd[f + "2.actnorm.logs"]))
+                    st.ft4 = _ConvP(ops, sd[f + "4.weight"], bias=sd[f + "4.bias"],
+                                    post_scale=torch.exp(sd[f + "4.logs"] * 3))
+                self.steps[ly.index] = st
+            elif ly.type == "split":
+                self.splits[ly.index] = _ConvP(ops, sd[p + "conv.weight"], bias=sd[p + "conv.bias"],
+                                               post_scale=torch.exp(sd[p + "conv.logs"] * 3))
+        # batched hoisted first convs per level
+        self.hoist = {}
+        for level in range(1, self.L + 1):
+            idxs = [ly.index for ly in self.layers if ly.type == "step" and ly.coupled and ly.level == level]
+            if not idxs:
+                continue
+            wf = torch.cat([self.steps[i].ft0_w for i in idxs], 0)
+            sh = torch.cat([self.steps[i].ft0_shift for i in idxs], 0)
+            sc = torch.cat([self.steps[i].ft0_scale for i in idxs], 0)
+            wa = torch.cat([self.steps[i].aff0_ft_w for i in idxs], 0)
+            self.hoist[level] = dict(idxs=idxs,
+                                     ft0=_ConvP(ops, wf, aff_shift=sh, aff_scale=sc, mtile=2),
+                                     aff0=_ConvP(ops, wa, mtile=2))
+            for i in idxs:
+                del self.steps[i].ft0_w, self.steps[i].aff0_ft_w
+
+    # ------------------------------------------------------------------------------------------
+    def _level_hw(self, level, h, w):
+        """spatial size of flow level `level` for an LR of h x w: HR / 2^level."""
+        return (h * self.scale) >> level, (w * self.scale) >> level
+
+    def conditioning(self, lr):
+        """RRDB features + hoisted ft-only coupling activations for an LR batch (cached per tensor)."""
+        key = (lr.data_ptr(), lr._version, tuple(lr.shape))
+        if self._cond_key == key:
+            return self._cond
+        ops, ws = self.ops, self.ws
+        B, _, h, w = lr.shape
+        if (h * self.scale) % (1 << self.L) or (w * self.scale) % (1 << self.L):
+            raise ValueError("HR size must be divisible by 2^L (LR %dx%d, scale %d, L %d)" % (h, w, self.scale, self.L))
+        ft = {}
+        for level in range(1, self.L + 1):
+            hl, wl = self._level_hw(level, h, w)
+            ft[level] = ws.get("ft%d" % level, B, self.n_cond, hl, wl)
+        name2level = {self.level_names[l]: l for l in range(1, self.L + 1)}
+
+        def key_view(name):
+            if name in name2level:
+                return ft[name2level[name]][:, :64]
+            s = _KEY_SHIFT[name]
+            return ws.get("key_" + name, B, 64, h << s if s >= 0 else h >> -s, w << s if s >= 0 else w >> -s)
+
+        def on_block(idx, fea):
+            # nearest-resize the tapped RRDB output into its 64-ch slot of every level (SRFlowNet_arch.py:122-137)
+            if idx in self.block_idxs and self.concat:
+                k = self.block_idxs.index(idx)
+                for level in range(1, self.L + 1):
+                    dst = ft[level][:, 64 * (k + 1): 64 * (k + 2)]
+                    ops.resize(fea, dst, MODE_NEAREST, float(h) / dst.shape[2], float(w) / dst.shape[3])
+
+        last = key_view("fea_up1")
+        self.rrdb.forward(lr, last, on_block)
+        prev = last
+        for name in ("fea_up2", "fea_up4", "fea_up8"):       # lrelu is in-place in the reference => stored post-act
+            if name in self.upconvs:
+                cur = key_view(name)
+                self.upconvs[name].run(ops, prev, cur, in_shift=1, act=ACT_LRELU, slope=0.2)
+                prev = cur
+        if "fea_up0" in self.need_keys:
+            dst = key_view("fea_up0")       # bilinear 1/2, align_corners=False, recompute_scale_factor=True
+            ops.resize(last, dst, MODE_BILINEAR, float(h) / dst.shape[2], float(w) / dst.shape[3])
+
+        cond = {}
+        for level, hz in self.hoist.items():
+            K = len(hz["idxs"])
+            f = ft[level]
+            hl, wl = f.shape[2], f.shape[3]
+            Cz = [ly.C for ly in self.layers if ly.index == hz["idxs"][0]][0]
+            hid = ws.get("hoist_hid%d" % level, B, K * 64, hl, wl)
+            pre_aff = ws.get("pre_aff%d" % level, B, K * 64, hl, wl)
+            h_ft = ws.get("h_ft%d" % level, B, K * 2 * Cz, hl, wl)
+            hz["ft0"].run(ops, f, hid, act=ACT_RELU)
+            hz["aff0"].run(ops, f, pre_aff)
+            for k, i in enumerate(hz["idxs"]):
+                st = self.steps[i]
+                hk = hid[:, 64 * k: 64 * (k + 1)]
+                st.ft2.run(ops, hk, hk, act=ACT_RELU)            # 1x1, in place (disjoint pixel tiles)
+                st.ft4.run(ops, hk, h_ft[:, 2 * Cz * k: 2 * Cz * (k + 1)])
+            cond[level] = dict(pre_aff=pre_aff, h_ft=h_ft, slot={i: k for k, i in enumerate(hz["idxs"])}, C=Cz)
+        self._cond_key, self._cond = key, cond
+        return cond
+
+    # ------------------------------------------------------------------------------------------
+    def _self_cond(self, st, z, cnd, k, tag):
+        """h_aff = fAffine(cat[z1, ft]) with the ft rows hoisted: 3x3 on z1 (+pre_aff) -> 1x1 -> 3x3."""
+        ops, ws = self.ops, self.ws
+        B, C, H, W = z.shape
+        cn = C // 2
+        hid = ws.get("hid_%s" % tag, B, 64, H, W)
+        h_aff = ws.get("haff_%s_%d" % (tag, k & 1), B, 2 * (C - cn), H, W)
+        st.aff0_z1.run(ops, z[:, :cn], hid, pre_add=cnd["pre_aff"][:, 64 * k: 64 * (k + 1)], act=ACT_RELU)
+        st.aff2.run(ops, hid, hid, act=ACT_RELU)
+        st.aff4.run(ops, hid, h_aff)
+        return h_aff
+
+    def encode(self, gt, lr):
+        """normal flow (FlowUpsamplerNet.encode :217-251): gt [B,3,H,W] -> [eps_split..., z_final]."""
+        ops, ws = self.ops, self.ws
+        cond = self.conditioning(lr)
+        z = gt
+        epses = []
+        pending = None           # h_aff of the previous coupled step, applied lazily by the next head
+        for ly in self.layers:
+            B, _, H, W = z.shape
+            if ly.type == "squeeze":
+                if pending is not None:
+                    ops.flow_pointwise(z, z, False, h_aff=pending)
+                    pending = None
+                out = ws.get("enc_z%d" % ly.level, B, ly.C, H // 2, W // 2)
+                z = ops.squeeze2d(z, out)
+            elif ly.type == "step":
+                st = self.steps[ly.index]
+                if ly.coupled:
+                    cnd = cond[ly.level]
+                    k = cnd["slot"][ly.index]
+                    ops.flow_pointwise(z, z, False, h_aff=pending, an_bias=st.an_bias, an_escale=st.an_exp,
+                                       w=st.w_fwd, h_ft=cnd["h_ft"][:, 2 * ly.C * k: 2 * ly.C * (k + 1)])
+                    pending = self._self_cond(st, z, cnd, k, "enc%d" % ly.level)
+                else:
+                    ops.flow_pointwise(z, z, False, h_aff=pending, an_bias=st.an_bias, an_escale=st.an_exp, w=st.w_fwd)
+                    pending = None
+            else:   # split
+                if pending is not None:
+                    ops.flow_pointwise(z, z, False, h_aff=pending)
+                    pending = None
+                h = ws.get("split_h%d" % ly.index, B, 2 * ly.C_consume, H, W)
+                self.splits[ly.index].run(ops, z[:, :ly.C_pass], h)
+                e = ops.empty(B, ly.C_consume, H, W)
+                ops.split2d(h, z[:, ly.C_pass:], e, False)
+                epses.append(e)
+                z = z[:, :ly.C_pass]
+        if pending is not None:
+            ops.flow_pointwise(z, z, False, h_aff=pending)
+        zf = ops.empty(*z.shape)
+        ops.axpb_clamp(z, zf)               # detach the result from the workspace
+        epses.append(zf)
+        return epses
+
+    def decode(self, lr, epses=None, z=None, eps_std=None):
+        """reverse flow (FlowUpsamplerNet.decode :267-296): [eps_split..., z_final] -> sr [B,3,H,W]."""
+        ops, ws = self.ops, self.ws
+        cond = self.conditioning(lr)
+        epses = list(epses) if epses is not None else None
+        zin = epses.pop() if epses is not None else z
+        B = zin.shape[0]
+        cur = ws.get("dec_z_top", *zin.shape)
+        ops.axpb_clamp(zin, cur)
+        z = cur
+        # the buffer the next (lower-index) split layer concatenates into is prepared when we reach a squeeze
+        for pos in reversed(range(len(self.layers))):
+            ly = self.layers[pos]
+            _, C, H, W = z.shape
+            if ly.type == "step":
+                st = self.steps[ly.index]
+                if ly.coupled:
+                    cnd = cond[ly.level]
+                    k = cnd["slot"][ly.index]
+                    h_aff = self._self_cond(st, z, cnd, k, "dec%d" % ly.level)
+                    ops.flow_pointwise(z, z, True, h_aff=h_aff, h_ft=cnd["h_ft"][:, 2 * C * k: 2 * C * (k + 1)],
+                                       w=st.w_inv, an_bias=st.an_bias, an_escale=st.an_expneg)
+                else:
+                    ops.flow_pointwise(z, z, True, w=st.w_inv, an_bias=st.an_bias, an_escale=st.an_expneg)
+            elif ly.type == "squeeze":
+                Co = C // 4
+                nxt = self.layers[pos - 1] if pos > 0 else None
+                if nxt is not None and nxt.type == "split":
+                    full = ws.get("dec_full%d" % nxt.index, B, nxt.C, 2 * H, 2 * W)
+                    out = full[:, :nxt.C_pass]
+                    assert nxt.C_pass == Co
+                elif pos == 0:
+                    out = ops.empty(B, Co, 2 * H, 2 * W)
+                else:
+                    out = ws.get("dec_z%d" % ly.level, B, Co, 2 * H, 2 * W)
+                z = ops.unsqueeze2d(z, out)
+            else:   # split reverse (Split.py:62-76): z = cat(z1, mean + exp(logs)*eps)
+                full = ws.get("dec_full%d" % ly.index, B, ly.C, H, W)
+                assert z.data_ptr() == full.data_ptr()
+                h = ws.get("split_h%d" % ly.index, B, 2 * ly.C_consume, H, W)
+                self.splits[ly.index].run(ops, z, h)
+                if epses is not None:
+                    e = epses.pop()
+                else:   # tau path: eps ~ N(0, eps_std) sampled on device (plumbing)
+                    e = torch.randn(B, ly.C_consume, H, W, device=z.device, dtype=torch.float32) * float(eps_std or 1)
+                ops.split2d(h, e, full[:, ly.C_pass:], True)
+                z = full
+        return z

@@ -1,0 +1,94 @@
+"""`SRFlowNet` -- drop-in for the reference generator
+(SRFlow-LP/code/models/modules/SRFlowNet_arch.py:30-158), found by name through
+`networks.find_model_using_name('SRFlowNet')` exactly like the reference (networks.py:27-43).
+
+Constructor and `forward` signatures, the `epses` list convention (encode appends
+`[eps_split..., z_final]`, FlowUpsamplerNet.py:247-251; decode copies then pops from the end, :206,268,301)
+and the state_dict key names are the reference's.  The computation is scheduled by
+`bfsr_amd.srflow.engine.SRFlowEngine` on the HIP kernels.
+
+Not reproduced: `logdet` / `nll` values -- the LP inference path discards them
+(test.py:139, SRFlow_model.py:199); zeros of the right shape are returned."""
+import torch
+from torch import nn
+
+from .... import paramtree
+from ... import spec
+from ...engine import SRFlowEngine
+from ...options import opt_get
+
+
+class SRFlowNet(nn.Module):
+    def __init__(self, in_nc, out_nc, nf, nb, gc=32, scale=4, K=None, opt=None, step=None, ops=None):
+        super(SRFlowNet, self).__init__()
+        self.opt = opt
+        q = opt_get(opt, ['datasets', 'train', 'quant'])
+        self.quant = 255 if q is None else q
+        self.nb = nb
+        if opt['scale'] != scale:
+            raise ValueError("scale argument and opt['scale'] disagree")
+        schema = spec.rrdb_schema(opt, nb, nf=nf, gc=gc, in_nc=in_nc, out_nc=out_nc)
+        schema.update(spec.flow_schema(opt))
+        paramtree.attach(self, schema, paramtree.default_init(0))
+        fu = self.flowUpsamplerNet
+        fu.C = spec.final_channels(opt)                       # FlowUpsamplerNet.C after the last split
+        n_sq = sum(1 for ly in spec.flow_layers(opt) if ly.type == "squeeze")
+        fu.scaleH = fu.scaleW = float(1 << n_sq)              # 160 / H_final (FlowUpsamplerNet.py:112-115)
+        self.RRDB_training = True
+        self._ops, self._engine = ops, None
+
+    # ---- engine lifecycle -------------------------------------------------------------------
+    def load_state_dict(self, state_dict, strict=True):
+        r = super(SRFlowNet, self).load_state_dict(state_dict, strict=strict)
+        self._engine = None
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super(SRFlowNet, self)._apply(fn, *a, **k)
+        self._engine = None
+        return r
+
+    def engine(self):
+        if self._engine is None:
+            if self._ops is None:
+                from ....ops import HipOps
+                p = next(self.parameters())
+                self._ops = HipOps(p.device if p.is_cuda else None)
+            self._engine = SRFlowEngine(self.opt, self.state_dict(), self._ops, nb=self.nb)
+        return self._engine
+
+    def set_rrdb_training(self, trainable):
+        self.RRDB_training = trainable
+        return False
+
+    # ---- reference API --------------------------------------------------------------------------
+    def forward(self, gt=None, lr=None, z=None, eps_std=None, reverse=False, epses=None, reverse_with_grad=False,
+                lr_enc=None, add_gt_noise=False, step=None, y_label=None):
+        eng = self.engine()
+        dev = eng.ops.to_device
+        with torch.no_grad():
+            if not reverse:
+                return self.normal_flow(dev(gt), dev(lr), epses=epses, add_gt_noise=add_gt_noise)
+            assert lr.shape[1] == 3
+            return self.reverse_flow(dev(lr), z, eps_std=eps_std, epses=epses)
+
+    def normal_flow(self, gt, lr, y_onehot=None, epses=None, lr_enc=None, add_gt_noise=True, step=None):
+        eng = self.engine()
+        z = gt
+        if add_gt_noise:    # SRFlowNet_arch.py:93-99 (training-time dequantisation noise; plumbing on torch)
+            if opt_get(self.opt, ['network_G', 'flow', 'augmentation', 'noiseQuant'], True):
+                z = z + ((torch.rand(z.shape, device=z.device) - 0.5) / self.quant)
+        out = eng.encode(z, lr)
+        zeros = torch.zeros(gt.shape[0], device=gt.device)
+        if isinstance(epses, list):
+            epses.extend(out)
+            return epses, zeros, zeros.clone()
+        return out[-1], zeros, zeros.clone()
+
+    def reverse_flow(self, lr, z, y_onehot=None, eps_std=None, epses=None, lr_enc=None, add_gt_noise=True):
+        eng = self.engine()
+        if isinstance(epses, list):
+            sr = eng.decode(lr, epses=[eng.ops.to_device(e) for e in epses])
+        else:
+            sr = eng.decode(lr, z=eng.ops.to_device(z), eps_std=eps_std)
+        return sr, torch.zeros(lr.shape[0], device=sr.device)

@@ -86,4 +86,4 @@ def derive_scale(opt, scale):
     return dict_to_nonedict(o)
 
 
-DEFAULT_CONF = osp.join(osp.dirname(osp.abspath(__file__)), "confs", "SRFlow-LP_DF2K_4X.yml")
+DEFAULT_CONF = osp.join(osp.dirname(osp.dirname(osp.abspath(__file__))), "confs", "SRFlow-LP_DF2K_4X.yml")

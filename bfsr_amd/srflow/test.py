@@ -1,0 +1,90 @@
+"""SRFlow-LP evaluation harness -- counterpart of the reference's `test.py`
+(SRFlow-LP/code/test.py:85-175).  Usage mirrors it:  python -m bfsr_amd.srflow.test <conf.yml>
+
+`lp_infer` is the LP block (test.py:126-151) on device tensors: lr_up = bilinear x scale -> encode
+(`add_gt_noise=False`) -> per-pixel channel standardisation -> learned prior -> decode -> clamp[0,1].
+PNG I/O and PSNR/SSIM/LPIPS (Measure.py) are outside the accelerated path."""
+import glob
+import os
+import sys
+
+import numpy as np
+import torch
+
+from .models import create_model, models as registry
+from .options import load as load_opt, opt_get
+from ..ops import MODE_BILINEAR
+
+
+def load_model(conf_path, ops=None):
+    """test.py:41-49: parse conf, build the model, load `model_path` into netG."""
+    opt = load_opt(conf_path)
+    model = create_model(opt, ops=ops)
+    model_path = opt_get(opt, ['model_path'], None)
+    if model_path and os.path.exists(model_path):
+        model.load_network(load_path=model_path, network=model.netG)
+    return model, opt
+
+
+def load_prior(opt, ops=None):
+    """test.py:90-91: `models.make(torch.load(prior_model_path)['prior_model'], load_sd=True)`."""
+    spec = torch.load(opt['prior_model_path'], map_location='cpu')['prior_model']
+    args = dict(spec['args'])
+    if ops is not None:
+        args['ops'] = ops
+    prior = registry.make({'name': spec['name'], 'args': args, 'sd': spec['sd']}, load_sd=True)
+    prior.eval()
+    return prior
+
+
+def pad_lr_to_even(lr):
+    """test.py:126-130: reflect-pad H and W of an HWC uint8 LR image up to a multiple of 2."""
+    h, w, _ = lr.shape
+    return np.pad(lr, [(0, int(np.ceil(h / 2) * 2 - h)), (0, int(np.ceil(w / 2) * 2 - w)), (0, 0)], 'reflect')
+
+
+def lp_infer(model, prior_model, lr_t, return_all=False):
+    """lr_t [B,3,h,w] in [0,1] (h, w even) -> sr [B,3,s*h,s*w] clamped to [0,1]."""
+    net = model.netG.module
+    eng = net.engine()
+    ops = eng.ops
+    scale = model.opt['scale']
+    with torch.no_grad():
+        lr = ops.to_device(lr_t)
+        B, _, h, w = lr.shape
+        lr_up = ops.empty(B, 3, h * scale, w * scale)
+        ops.resize(lr, lr_up, MODE_BILINEAR, 1.0 / scale, 1.0 / scale)           # test.py:137
+        epses_lr = []
+        model.get_encode_z(lr, lr_up, epses=epses_lr, add_gt_noise=False)        # test.py:139
+        epses = [ops.standardize(e, ops.empty(*e.shape)) for e in epses_lr]      # test.py:141-145
+        epses_learned = prior_model(epses)                                       # test.py:147
+        sr_raw = model.get_sr(lq=lr, epses=epses_learned)                        # test.py:148
+        sr = ops.axpb_clamp(sr_raw, ops.empty(*sr_raw.shape), 1.0, 0.0, 0.0, 1.0)  # test.py:150
+    if return_all:
+        return dict(lr_up=lr_up, epses=epses_lr, epses_norm=epses, epses_learned=epses_learned, sr_raw=sr_raw, sr=sr)
+    return sr
+
+
+def main(argv=None):
+    argv = argv if argv is not None else sys.argv[1:]
+    if len(argv) != 1:
+        raise SystemExit("usage: python -m bfsr_amd.srflow.test <conf.yml>")
+    from PIL import Image
+    model, opt = load_model(argv[0])
+    prior = load_prior(opt)
+    scale = opt['scale']
+    lr_paths = sorted(glob.glob(os.path.join(opt['dataroot_LR'], '*.png')))
+    out_dir = os.path.join(os.path.dirname(os.path.abspath(argv[0])), '..', 'results', 'SRFlow-LP')
+    os.makedirs(out_dir, exist_ok=True)
+    for idx, p in enumerate(lr_paths):
+        lr = np.asarray(Image.open(p).convert('RGB'))
+        h, w, _ = lr.shape
+        lr_t = torch.from_numpy(pad_lr_to_even(lr).transpose(2, 0, 1)[None].astype(np.float32)) / 255
+        sr = lp_infer(model, prior, lr_t)
+        img = (np.clip(sr[0].cpu().numpy().transpose(1, 2, 0), 0, 1) * 255).astype(np.uint8)[:h * scale, :w * scale]
+        Image.fromarray(img).save(os.path.join(out_dir, "{:06d}.png".format(idx)))
+        print("wrote %06d.png" % idx)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,137 @@
+/*
+ * bfsr_hip.h -- C ABI of libbfsr_hip.so: MI355X (gfx950) kernels for the BFSR hot path
+ * (SRFlow-LP / LINF-LP latent-module forward + normalizing-flow inverse).
+ *
+ * The reference (liyuantsao/BFSR) is pure Python/PyTorch and exports no FFI; its plugin boundary
+ * is the `models` registry (LINF-LP/models/models.py:7-23, SRFlow-LP/code/models/models.py:7-23).
+ * This ABI sits *underneath* Python modules that keep the registry names; each entry point below
+ * names the reference torch call sites it replaces (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - all tensors fp32, NCHW; a "view" is (ptr, batch_stride_in_floats, C, H, W) with contiguous
+ *     H*W planes and channel stride H*W, so a channel slice of a larger buffer is a valid view;
+ *   - the caller owns every buffer (inputs, outputs, scratch); nothing is retained after a call;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), no internal sync,
+ *     no global mutable state => re-entrant across streams;
+ *   - return value: 0 on success, otherwise a hipError_t (or -1 for an unsupported argument);
+ *     no exceptions cross the ABI.
+ */
+#ifndef BFSR_HIP_H
+#define BFSR_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BFSR_ABI_VERSION 1
+
+enum { BFSR_ACT_NONE = 0, BFSR_ACT_RELU = 1, BFSR_ACT_LRELU = 2 };
+
+/* ---- dense conv (3x3 'same' or 1x1, stride 1) on fp32 MFMA, fused epilogue ----------------
+ * replaces F.conv2d / nn.Conv2d call sites on the path:
+ *   SRFlow-LP/code/models/modules/RRDBNet_arch.py:39-45,89-117 (RDB, trunk, upconv)
+ *   SRFlow-LP/code/models/modules/flow.py:59-83 (flow.Conv2d + ActNorm, Conv2dZeros)
+ *   SRFlow-LP/code/models/unet.py:23-52,101-107 and LINF-LP/models/unet.py (prior UNets)
+ *   LINF-LP/models/rrdb.py:52-58, edsr.py:30-51, linf.py:231-240,250-251 (encoders, coef/freq, MLP)
+ *
+ * epilogue order per output element v (channel c):
+ *   v = acc; v += bias[c]; v += pre_add[b,c,y,x]; v = (v + aff_shift[c]) * aff_scale[c] + aff_post[c];
+ *   v = act(v); v *= post_scale[c]; v = alpha1*v + res1[b,c,y,x]; v = alpha2*v + res2[b,c,y,x]
+ * (each stage skipped when its pointer is NULL).
+ *
+ * `w` is the packed weight produced by bfsr_pack_conv_weight (layout private to the library:
+ * [cout_group][cin_pad][tap][mtile*32], zero padded).
+ * `in_shift` s>0: the input view is (H>>s, W>>s) and is read through nearest-neighbour x2^s
+ * upsampling (RRDBNet_arch.py:105-117 `F.interpolate(..., scale_factor=2, mode='nearest')`).
+ */
+typedef struct BfsrConvArgs {
+    const float* x; long long x_bs; int Cin;
+    const float* w;
+    float* y; long long y_bs; int Cout;
+    int B, H, W, KS, in_shift;
+    int mtile;                       /* 32-wide cout tiles per workgroup the weight was packed for */
+    const float* bias;
+    const float* pre_add; long long pre_add_bs;
+    const float* aff_shift; const float* aff_scale; const float* aff_post;
+    int act; float slope;
+    const float* post_scale;
+    const float* res1; long long res1_bs; float alpha1;
+    const float* res2; long long res2_bs; float alpha2;
+} BfsrConvArgs;
+
+int bfsr_abi_version(void);
+/* number of floats of the packed weight for (Cout, Cin, KS, mtile) */
+long long bfsr_conv_packed_size(int Cout, int Cin, int KS, int mtile);
+/* host-side packing: w_oihw [Cout][Cin][KS][KS] -> packed (both host pointers) */
+int bfsr_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int KS, int mtile, float* packed);
+int bfsr_conv2d(const BfsrConvArgs* a, void* stream);
+
+/* ---- fused flow-step pointwise chain -----------------------------------------------------------
+ * One read of z / h_aff / h_ft, one write of z (the HBM-roofline "coupling inverse" kernel of
+ * BASELINE.json).  replaces, per FlowStep (SRFlow-LP/code/models/modules/):
+ *   FlowAffineCouplingsAblation.py:57-97  (cross split, sigmoid(h+2)+1e-4, affine apply)
+ *   Permutations.py:44-58                 (1x1 invertible conv; `winv`/`w` precomputed by caller)
+ *   FlowActNorms.py:61-113                (actnorm)
+ * reverse (decode, FlowStep.py:113-129):
+ *   if h_aff: z2 = z2/scale - shift            (shift,scale = h_aff[0::2], sigmoid(h_aff[1::2]+2)+eps)
+ *   if h_ft : z  = z/scaleFt - shiftFt         (from h_ft, same split, all C channels)
+ *   if w    : z  = w @ z  (w = fl32(inv(fl64(W))))    if an_bias: z = z*exp(-logs) - bias
+ * forward (encode, FlowStep.py:88-111), h_aff belongs to the PREVIOUS step's self-conditional:
+ *   if h_aff: z2 = (z2+shift)*scale
+ *   if an_bias: z = (z+bias)*exp(logs)         if w: z = w @ z
+ *   if h_ft : z = (z+shiftFt)*scaleFt
+ * `an_escale` holds exp(-logs) (reverse) or exp(logs) (forward), precomputed by the caller.
+ * z_in and z_out may alias (in-place).  C in {3..128}; h_aff has 2*(C - C/2) channels, h_ft 2*C.
+ */
+typedef struct BfsrFlowArgs {
+    const float* z_in; long long z_in_bs;
+    float* z_out; long long z_out_bs;
+    const float* h_aff; long long h_aff_bs;
+    const float* h_ft; long long h_ft_bs;
+    const float* w;            /* [C][C] row-major, or NULL */
+    const float* an_bias;      /* [C] or NULL */
+    const float* an_escale;    /* [C] */
+    int B, C, H, W;
+    int reverse;
+    float eps;                 /* affine_eps, 1e-4 */
+} BfsrFlowArgs;
+int bfsr_flow_pointwise(const BfsrFlowArgs* a, void* stream);
+
+/* squeeze2d / unsqueeze2d, factor 2 (flow.py:122-152): x [B,C,H,W] <-> y [B,4C,H/2,W/2] */
+int bfsr_squeeze2d(const float* x, long long x_bs, float* y, long long y_bs, int B, int C, int H, int W,
+                   void* stream);
+int bfsr_unsqueeze2d(const float* x, long long x_bs, float* y, long long y_bs, int B, int C, int H, int W,
+                     void* stream);
+
+/* Split2d (Split.py:48-77) given h = Conv2dZeros(z1) [B,2*Cc,H,W]: mean,logs = h[0::2], h[1::2]
+ *   forward: eps = (z2 - mean) / exp(logs)
+ *   reverse: z2  = mean + exp(logs) * eps      */
+int bfsr_split2d(const float* h, long long h_bs, const float* src, long long src_bs, float* dst,
+                 long long dst_bs, int B, int Cc, int H, int W, int reverse, void* stream);
+
+/* per-pixel channel standardisation (SRFlow-LP/code/test.py:141-145): (e-mean_c)/(std_c(unbiased)+1e-8) */
+int bfsr_standardize(const float* x, long long x_bs, float* y, long long y_bs, int B, int C, int H, int W,
+                     void* stream);
+
+/* resampling.  mode: 0 nearest (src = floor(dst*in/out), F.interpolate default),
+ * 1 bilinear align_corners=False with ratio r_h,r_w (src=(dst+0.5)*r-0.5 clamped at 0),
+ * 2 bilinear align_corners=True (src = dst*(in-1)/(out-1)).
+ * call sites: SRFlow-LP/code/test.py:137, RRDBNet_arch.py:138, SRFlowNet_arch.py:137,
+ * models/unet.py:80 (both), LINF-LP/test.py:149,171.  The output may be a padded sub-window:
+ * (oy0, ox0) is where the resized image starts inside the (OH, OW) output view, the rest is
+ * zero-filled (F.pad in unet.py:86-92). */
+int bfsr_resize(const float* x, long long x_bs, int IH, int IW, float* y, long long y_bs, int OH, int OW,
+                int RH, int RW, int oy0, int ox0, int B, int C, int mode, float r_h, float r_w, void* stream);
+
+/* MaxPool2d(2) (models/unet.py:63), floor mode */
+int bfsr_maxpool2(const float* x, long long x_bs, float* y, long long y_bs, int B, int C, int H, int W,
+                  void* stream);
+
+/* y = clamp(a*x + b + (r ? r : 0), lo, hi) elementwise over a view (test.py:150, LINF-LP/test.py:217) */
+int bfsr_axpb_clamp(const float* x, long long x_bs, const float* r, long long r_bs, float* y, long long y_bs,
+                    int B, int C, int H, int W, float a, float b, float lo, float hi, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,205 @@
+"""-m gpu: every HIP op (through the C ABI) against the CPU semantics (tests/cpu_ops.py, which the oracle and
+the golden vectors pin) on seeded inputs, including ragged sizes, channel-slice views and all epilogue stages."""
+import numpy as np
+import pytest
+import torch
+
+from cpu_ops import CpuOps
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(seed, *shape, scale=1.0):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy((g.standard_normal(shape) * scale).astype(np.float32))
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from bfsr_amd.ops import HipOps
+    return HipOps("cuda:0")
+
+
+CPU = CpuOps()
+
+
+def close(a, b, tol, what=""):
+    a = a.detach().cpu()
+    err = (a - b).abs().max().item()
+    ref = max(1.0, b.abs().max().item())
+    assert not torch.isnan(a).any(), what + ": NaN in output"
+    assert err <= tol * ref, "%s: max-abs %.3e > %.1e * %.2f" % (what, err, tol, ref)
+    return err
+
+
+CONV_CASES = [
+    # (B, Cin, Cout, H, W, KS, mtile)
+    (1, 3, 64, 16, 16, 3, 2), (2, 64, 32, 40, 72, 3, 1), (1, 96, 32, 33, 47, 3, 1), (1, 192, 64, 20, 36, 3, 2),
+    (1, 320, 128, 24, 40, 3, 2), (2, 6, 12, 18, 34, 3, 1), (1, 64, 96, 17, 65, 3, 3), (1, 48, 64, 10, 10, 3, 2),
+    (1, 64, 64, 37, 50, 1, 2), (2, 70, 27, 9, 31, 1, 1), (1, 64, 96, 16, 32, 1, 3), (1, 262, 64, 12, 33, 3, 2),
+    (1, 64, 24, 70, 130, 3, 1), (3, 12, 64, 64, 64, 3, 2),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_plain(hip, case):
+    B, Cin, Cout, H, W, KS, mt = case
+    x = rnd(1, B, Cin, H, W)
+    w = rnd(2, Cout, Cin, KS, KS, scale=1.0 / np.sqrt(Cin * KS * KS))
+    ref = CPU.conv(x, CPU.pack_conv(w, mt), torch.empty(B, Cout, H, W))
+    out = hip.conv(hip.to_device(x), hip.pack_conv(w, mt), hip.empty(B, Cout, H, W))
+    close(out, ref, 2e-5, "conv%s" % (case,))
+
+
+def test_conv_large_tile_path(hip):
+    # enough pixels to take the NR=4 (16x32 tile) path, ragged edges
+    B, Cin, Cout, H, W = 2, 64, 64, 370, 390
+    x = rnd(3, B, Cin, H, W)
+    w = rnd(4, Cout, Cin, 3, 3, scale=0.05)
+    ref = CPU.conv(x, CPU.pack_conv(w, 2), torch.empty(B, Cout, H, W))
+    out = hip.conv(hip.to_device(x), hip.pack_conv(w, 2), hip.empty(B, Cout, H, W))
+    close(out, ref, 2e-5, "conv NR=4")
+
+
+def test_conv_epilogue_all_stages(hip):
+    B, Cin, Cout, H, W = 2, 40, 48, 21, 35
+    x, w = rnd(5, B, Cin, H, W), rnd(6, Cout, Cin, 3, 3, scale=0.08)
+    v = lambda s: rnd(s, Cout, scale=0.5)
+    kw = dict(bias=v(7), aff_shift=v(8), aff_scale=torch.exp(v(9)), aff_post=v(10), post_scale=torch.exp(v(11)))
+    pre, r1, r2 = rnd(12, B, Cout, H, W), rnd(13, B, Cout, H, W), rnd(14, B, Cout, H, W)
+    for act in (0, 1, 2):
+        ref = CPU.conv(x, CPU.pack_conv(w, 2), torch.empty(B, Cout, H, W), pre_add=pre, act=act, slope=0.2,
+                       res1=r1, alpha1=0.2, res2=r2, alpha2=0.3, **kw)
+        dkw = {k: hip.vec(t) for k, t in kw.items()}
+        out = hip.conv(hip.to_device(x), hip.pack_conv(w, 2), hip.empty(B, Cout, H, W), pre_add=hip.to_device(pre),
+                       act=act, slope=0.2, res1=hip.to_device(r1), alpha1=0.2, res2=hip.to_device(r2), alpha2=0.3, **dkw)
+        close(out, ref, 2e-5, "conv epilogue act=%d" % act)
+
+
+def test_conv_channel_slice_views_and_inplace_1x1(hip):
+    # dense-block pattern: read channels [:96] of a 192-ch buffer, write channels [96:128] of the same buffer
+    B, H, W = 2, 19, 45
+    D = rnd(15, B, 192, H, W)
+    w = rnd(16, 32, 96, 3, 3, scale=0.05)
+    Dd = hip.to_device(D)
+    ref = D.clone()
+    CPU.conv(ref[:, :96].clone(), CPU.pack_conv(w, 1), ref[:, 96:128], act=2)
+    hip.conv(Dd[:, :96], hip.pack_conv(w, 1), Dd[:, 96:128], act=2)
+    close(Dd, ref, 2e-5, "conv slice views")
+    # 1x1 in place on a slice
+    w1 = rnd(17, 64, 64, 1, 1, scale=0.1)
+    ref2 = ref.clone()
+    CPU.conv(ref2[:, 64:128].clone(), CPU.pack_conv(w1, 2), ref2[:, 64:128], act=1)
+    hip.conv(Dd[:, 64:128], hip.pack_conv(w1, 2), Dd[:, 64:128], act=1)
+    close(Dd, ref2, 2e-5, "conv 1x1 in place")
+
+
+def test_conv_nearest_upsample_on_read(hip):
+    B, C, h, w_ = 2, 64, 13, 21
+    x, w = rnd(18, B, C, h, w_), rnd(19, 64, C, 3, 3, scale=0.05)
+    b = rnd(20, 64, scale=0.1)
+    ref = CPU.conv(x, CPU.pack_conv(w, 2), torch.empty(B, 64, 2 * h, 2 * w_), in_shift=1, bias=b, act=2)
+    out = hip.conv(hip.to_device(x), hip.pack_conv(w, 2), hip.empty(B, 64, 2 * h, 2 * w_), in_shift=1, bias=hip.vec(b), act=2)
+    close(out, ref, 2e-5, "conv in_shift")
+
+
+@pytest.mark.parametrize("C", [12, 24, 96])
+@pytest.mark.parametrize("reverse", [0, 1])
+@pytest.mark.parametrize("hw", [(16, 24), (7, 9)])
+def test_flow_pointwise(hip, C, reverse, hw):
+    H, W = hw
+    B = 2
+    z = rnd(30 + C, B, C, H, W)
+    ha = rnd(31 + C, B, 2 * (C - C // 2), H, W)
+    hf = rnd(32 + C, B, 2 * C, H, W)
+    q, _ = np.linalg.qr(np.random.Generator(np.random.PCG64(C)).standard_normal((C, C)))
+    Wm = torch.from_numpy(q.astype(np.float32)) + rnd(33, C, C, scale=0.02)
+    bias, es = rnd(34, C, scale=0.2), torch.exp(rnd(35, C, scale=0.2))
+    combos = [dict(h_aff=ha, h_ft=hf, w=Wm, an_bias=bias, an_escale=es), dict(w=Wm, an_bias=bias, an_escale=es),
+              dict(h_aff=ha), dict(h_ft=hf, an_bias=bias, an_escale=es)]
+    for kw in combos:
+        ref = CPU.flow_pointwise(z, torch.empty_like(z), reverse, **{k: (v.reshape(-1) if k == "w" else v) for k, v in kw.items()})
+        dkw = {k: (hip.to_device(v) if v.dim() == 4 else hip.vec(v)) for k, v in kw.items()}
+        zd = hip.to_device(z)
+        out = hip.flow_pointwise(zd, zd, reverse, **dkw)          # in place
+        close(out, ref, 1e-5, "flow_pointwise C=%d rev=%d %s" % (C, reverse, sorted(kw)))
+
+
+def test_flow_pointwise_on_channel_slice(hip):
+    # z is the first 12 channels of a wider buffer (batch stride != C*H*W)
+    B, C, H, W = 2, 12, 8, 12
+    buf = rnd(40, B, 20, H, W)
+    hf = rnd(41, B, 24, H, W)
+    ref = buf.clone()
+    CPU.flow_pointwise(buf[:, :C].clone(), ref[:, :C], 1, h_ft=hf)
+    bd = hip.to_device(buf)
+    hip.flow_pointwise(bd[:, :C], bd[:, :C], 1, h_ft=hip.to_device(hf))
+    close(bd, ref, 1e-5, "flow slice")
+
+
+def test_squeeze_unsqueeze(hip):
+    x = rnd(50, 2, 6, 10, 14)
+    y = hip.squeeze2d(hip.to_device(x), hip.empty(2, 24, 5, 7))
+    assert torch.equal(y.cpu(), CPU.squeeze2d(x, torch.empty(2, 24, 5, 7)))
+    back = hip.unsqueeze2d(y, hip.empty(2, 6, 10, 14))
+    assert torch.equal(back.cpu(), x)
+    # strided source (first 6 of 12 channels) as after a Split2d
+    big = rnd(51, 2, 12, 8, 8)
+    y2 = hip.squeeze2d(hip.to_device(big)[:, :6], hip.empty(2, 24, 4, 4))
+    assert torch.equal(y2.cpu(), CPU.squeeze2d(big[:, :6], torch.empty(2, 24, 4, 4)))
+
+
+def test_split2d_standardize(hip):
+    h, s = rnd(60, 2, 12, 9, 11, scale=0.3), rnd(61, 2, 6, 9, 11)
+    for rev in (0, 1):
+        ref = CPU.split2d(h, s, torch.empty_like(s), rev)
+        out = hip.split2d(hip.to_device(h), hip.to_device(s), hip.empty(2, 6, 9, 11), rev)
+        close(out, ref, 1e-6, "split2d rev=%d" % rev)
+    for C in (6, 96):
+        x = rnd(62 + C, 2, C, 5, 7, scale=2.0) + 0.3
+        ref = CPU.standardize(x, torch.empty_like(x))
+        out = hip.standardize(hip.to_device(x), hip.empty(*x.shape))
+        close(out, ref, 2e-6, "standardize C=%d" % C)
+
+
+RESIZE = [
+    (0, (8, 10), (16, 20), None), (0, (16, 20), (8, 10), None), (0, (7, 9), (14, 18), None),
+    (1, (8, 10), (32, 40), 0.25), (1, (16, 20), (8, 10), None), (1, (9, 7), (20, 15), None),
+    (2, (5, 6), (10, 12), None), (2, (1, 3), (2, 6), None),
+]
+
+
+@pytest.mark.parametrize("case", RESIZE)
+def test_resize_matches_torch_interpolate(hip, case):
+    import torch.nn.functional as F
+    mode, (ih, iw), (oh, ow), r = case
+    x = rnd(70, 2, 5, ih, iw)
+    if mode == 0:
+        ref = F.interpolate(x, (oh, ow))
+        rh, rw = ih / oh, iw / ow
+    elif mode == 1:
+        if r is not None:
+            ref = F.interpolate(x, scale_factor=1 / r, mode="bilinear", align_corners=False)
+            rh = rw = r
+        else:
+            ref = F.interpolate(x, (oh, ow), mode="bilinear", align_corners=False)
+            rh, rw = ih / oh, iw / ow
+    else:
+        ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+        rh = (ih - 1) / (oh - 1) if oh > 1 else 0.0
+        rw = (iw - 1) / (ow - 1) if ow > 1 else 0.0
+    out = hip.resize(hip.to_device(x), hip.empty(2, 5, oh, ow), mode, rh, rw)
+    close(out, ref, 2e-6, "resize %s" % (case,))
+
+
+def test_resize_padded_window_maxpool_clamp(hip):
+    import torch.nn.functional as F
+    x = rnd(80, 1, 4, 5, 6)
+    ref = F.pad(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True), [0, 1, 1, 0])
+    out = hip.resize(hip.to_device(x), hip.empty(1, 4, 11, 13), 2, 4 / 9, 5 / 11, window=(1, 0, 10, 12))
+    close(out, ref, 2e-6, "resize window")
+    y = rnd(81, 2, 3, 9, 11)
+    assert torch.equal(hip.maxpool2(hip.to_device(y), hip.empty(2, 3, 4, 5)).cpu(), F.max_pool2d(y, 2))
+    r = rnd(82, 2, 3, 9, 11)
+    ref = torch.clamp(0.5 * y + 0.5 + r, 0, 1)
+    close(hip.axpb_clamp(hip.to_device(y), hip.empty(2, 3, 9, 11), 0.5, 0.5, 0.0, 1.0, r=hip.to_device(r)), ref, 1e-7, "axpb")

@@ -1,0 +1,134 @@
+"""not gpu: host-side logic of the product -- checkpoint schema, config surface, registry, the engine's
+restructured schedule (run on the CPU test double against the genuine reference's golden vectors), the C-ABI
+library (loads, exports every declared symbol, host-side weight packing), and loud failure without a GPU."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from bfsr_amd import synth
+from bfsr_amd.srflow import options, spec
+from cpu_ops import CpuOps
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+T = torch.from_numpy
+
+
+def test_schema_matches_reference_checkpoints(golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, "srflow_schema.json")))
+    opt = options.load(options.DEFAULT_CONF)
+    for tag, o in (("srflownet_4x", opt), ("srflownet_8x", options.derive_scale(opt, 8))):
+        mine = [[k, list(s)] for k, (s, _) in spec.srflownet_schema(o).items()]
+        assert mine == ref[tag]
+    mine = [[k, list(s)] for k, (s, _) in spec.srflow_prior_schema().items()]
+    assert mine == ref["prior_unet"]
+
+
+def test_model_state_dict_roundtrip_and_registry():
+    from bfsr_amd.srflow.models import create_model, models as registry
+    from bfsr_amd.srflow.models.networks import find_model_using_name
+    opt = options.load(options.DEFAULT_CONF)
+    assert find_model_using_name("SRFlowNet").__name__ == "SRFlowNet"
+    m = create_model(opt, ops=CpuOps())
+    sd = synth.state_dict_from_schema(spec.srflownet_schema(opt), 5)
+    m.load_network({"module." + k: v for k, v in sd.items()})           # 'module.' prefix stripped (base_model.py:117-124)
+    back = m.netG.module.state_dict()
+    assert list(back.keys()) == list(sd.keys())
+    assert all(torch.equal(back[k], sd[k]) for k in sd)
+    with pytest.raises(RuntimeError):
+        m.netG.module.load_state_dict({k: v for k, v in list(sd.items())[:-1]}, strict=True)
+    assert "unet" in registry.models
+    p = registry.make({"name": "unet", "args": {"depth": 3, "dim": 64, "bilinear": True}}, args={"ops": CpuOps()})
+    assert list(p.state_dict().keys()) == list(spec.srflow_prior_schema().keys())
+    assert m.get_z(0.9, seed=1, batch_size=2, lr_shape=(2, 3, 160, 160)).shape == (2, 96, 80, 80)
+    assert float(m.get_z(0, batch_size=1, lr_shape=(1, 3, 16, 16)).abs().sum()) == 0.0
+
+
+def test_options_surface():
+    opt = options.load(options.DEFAULT_CONF)
+    assert opt["network_G"]["flow"]["K"] == 16 and opt["missing_key"] is None
+    assert options.opt_get(opt, ["network_G", "flow", "split", "enable"]) is True
+    assert options.opt_get(opt, ["network_G", "nope", "x"], 7) == 7
+    assert opt["network_G"]["scale"] == 4 and opt["is_train"] is False
+    ls = spec.flow_layers(opt)
+    assert len(ls) == 58 and sum(l.type == "step" for l in ls) == 54 and ls[19].type == "split"
+    assert [l.C for l in ls if l.type == "squeeze"] == [12, 24, 96]
+
+
+@pytest.mark.parametrize("fx,scale", [("srflow_e2e_4x_a", 4), ("srflow_e2e_4x_b", 4), ("srflow_e2e_8x", 8)])
+def test_engine_schedule_on_cpu_double_vs_reference_golden(golden_dir, fx, scale):
+    """The hoisted / deduplicated schedule reproduces the reference (fp32 re-association only)."""
+    from bfsr_amd.srflow.models import create_model, models as registry
+    from bfsr_amd.srflow.test import lp_infer
+    ops = CpuOps()
+    opt = options.load(options.DEFAULT_CONF)
+    if scale == 8:
+        opt = options.derive_scale(opt, 8)
+    m = create_model(opt, ops=ops)
+    m.load_network(synth.state_dict_from_schema(spec.srflownet_schema(opt), 1234))
+    prior = registry.make({"name": "unet", "args": {"depth": 3, "dim": 64, "bilinear": True, "ops": ops},
+                           "sd": synth.state_dict_from_schema(spec.srflow_prior_schema(), 4321)}, load_sd=True).eval()
+    g = np.load(os.path.join(golden_dir, fx + ".npz"))
+    out = lp_infer(m, prior, T(g["lr"]), return_all=True)
+    for i in (0, 1):
+        assert (out["epses"][i] - T(g["eps%d" % i])).abs().max() <= 5e-5
+        assert (out["epses_learned"][i] - T(g["epsl%d" % i])).abs().max() <= 5e-5
+    assert (out["sr_raw"] - T(g["sr_raw"])).abs().max() <= 1e-4
+    assert (out["sr"] - T(g["sr"])).abs().max() <= 1e-4
+    # decode(encode(x)) == x and the caller's eps list is not consumed (decode copies then pops)
+    eng = m.netG.module.engine()
+    n = len(out["epses"])
+    rt = eng.decode(T(g["lr"]), epses=out["epses"])
+    assert len(out["epses"]) == n
+    assert (rt - out["lr_up"]).abs().max() <= 1e-4
+
+
+def test_library_exports_every_declared_symbol():
+    from bfsr_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "bfsr_hip.h")).read()
+    declared = set(re.findall(r"\b(bfsr_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS.keys())
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.bfsr_abi_version() == 1
+
+
+def test_weight_packing_layout():
+    from bfsr_amd import _lib
+    lib = _lib.load()
+    Cout, Cin, KS, mt = 70, 13, 3, 2
+    w = torch.randn(Cout, Cin, KS, KS)
+    n = lib.bfsr_conv_packed_size(Cout, Cin, KS, mt)
+    cin_pad, groups = 16, 2
+    assert n == groups * cin_pad * 9 * 64
+    packed = torch.empty(n)
+    assert lib.bfsr_pack_conv_weight(w.data_ptr(), Cout, Cin, KS, mt, packed.data_ptr()) == 0
+    P = packed.view(groups, cin_pad, 9, 64)
+    for co, ci, t in ((0, 0, 0), (69, 12, 8), (64, 3, 4), (33, 7, 2)):
+        assert P[co // 64, ci, t, co % 64] == w[co, ci, t // 3, t % 3]
+    assert float(P[1, :, :, 6:].abs().sum()) == 0 and float(P[:, 13:].abs().sum()) == 0
+    assert lib.bfsr_pack_conv_weight(w.data_ptr(), Cout, Cin, 5, mt, packed.data_ptr()) != 0     # unsupported KS
+
+
+def test_no_gpu_means_loud_failure():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from bfsr_amd.ops import HipOps
+    from bfsr_amd.srflow.models import create_model
+    with pytest.raises(RuntimeError):
+        HipOps()
+    m = create_model(options.load(options.DEFAULT_CONF))
+    with pytest.raises(RuntimeError):
+        m.get_sr(torch.rand(1, 3, 16, 16), epses=[torch.zeros(1, 6, 32, 32), torch.zeros(1, 96, 8, 8)])
+
+
+def test_product_never_imports_oracle():
+    for dp, _, fs in os.walk(os.path.join(ROOT, "bfsr_amd")):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f

@@ -1,0 +1,133 @@
+"""-m gpu: SRFlow-LP end-to-end parity through the drop-in API on the HIP kernels: committed golden vectors of
+the genuine reference, the oracle on fresh seeded inputs, size-independent properties at larger sizes
+(encode->decode round trip, batch-sharding invariance), and per-stage goldens."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from bfsr_amd import synth                      # noqa: E402
+from bfsr_amd.srflow import options, spec       # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from bfsr_amd.ops import HipOps
+    return HipOps("cuda:0")
+
+
+def build(hip, scale=4):
+    from bfsr_amd.srflow.models import create_model, models as registry
+    opt = options.load(options.DEFAULT_CONF)
+    if scale != 4:
+        opt = options.derive_scale(opt, scale)
+    sd = synth.state_dict_from_schema(spec.srflownet_schema(opt), 1234)
+    psd = synth.state_dict_from_schema(spec.srflow_prior_schema(), 4321)
+    m = create_model(opt, ops=hip)
+    m.load_network(sd)
+    prior = registry.make({"name": "unet", "args": {"depth": 3, "dim": 64, "bilinear": True, "ops": hip}, "sd": psd},
+                          load_sd=True).eval()
+    return m, prior, opt, sd, psd
+
+
+@pytest.fixture(scope="module")
+def model4(hip):
+    return build(hip, 4)
+
+
+def _chk(name, got, ref, tol=1e-4):
+    got = got.detach().cpu()
+    assert not torch.isnan(got).any(), name + " NaN"
+    err = (got - ref).abs().max().item()
+    bound = tol * max(1.0, ref.abs().max().item())
+    assert err <= bound, "%s: max-abs %.3e > %.3e" % (name, err, bound)
+    return err
+
+
+@pytest.mark.parametrize("fx", ["srflow_e2e_4x_a", "srflow_e2e_4x_b"])
+def test_golden_e2e_4x(model4, golden_dir, fx):
+    from bfsr_amd.srflow.test import lp_infer
+    m, prior, opt, sd, psd = model4
+    g = np.load(os.path.join(golden_dir, fx + ".npz"))
+    out = lp_infer(m, prior, torch.from_numpy(g["lr"]), return_all=True)
+    T = lambda k: torch.from_numpy(g[k])
+    for i in (0, 1):
+        _chk("eps%d" % i, out["epses"][i], T("eps%d" % i))
+        _chk("epsn%d" % i, out["epses_norm"][i], T("epsn%d" % i))
+        _chk("epsl%d" % i, out["epses_learned"][i], T("epsl%d" % i))
+    _chk("sr_raw", out["sr_raw"], T("sr_raw"))
+    _chk("sr", out["sr"], T("sr"), 1e-4)       # north_star: <= 1e-4 max-abs on the [0,1] output
+
+
+def test_golden_e2e_8x(hip, golden_dir):
+    from bfsr_amd.srflow.test import lp_infer
+    m, prior, opt, sd, psd = build(hip, 8)
+    g = np.load(os.path.join(golden_dir, "srflow_e2e_8x.npz"))
+    out = lp_infer(m, prior, torch.from_numpy(g["lr"]), return_all=True)
+    T = lambda k: torch.from_numpy(g[k])
+    for i in (0, 1):
+        _chk("eps%d" % i, out["epses"][i], T("eps%d" % i))
+    _chk("sr_raw", out["sr_raw"], T("sr_raw"))
+    _chk("sr", out["sr"], T("sr"))
+
+
+def test_golden_rrdb_and_prior(model4, hip, golden_dir):
+    m, prior, opt, sd, psd = model4
+    eng = m.netG.module.engine()
+    g = np.load(os.path.join(golden_dir, "srflow_rrdb.npz"))
+    lr = hip.to_device(torch.from_numpy(g["lr"]))
+    eng.conditioning(lr)
+    for level, key in ((1, "fea_up2"), (2, "fea_up1"), (3, "fea_up0")):
+        _chk(key, eng.ws.bufs["ft%d" % level], torch.from_numpy(g[key]), 2e-5)
+    p = np.load(os.path.join(golden_dir, "srflow_prior.npz"))
+    for a, b, c, d in (("e0", "e1", "z0", "z1"), ("e0b", "e1b", "z0b", "z1b")):
+        out = prior([torch.from_numpy(p[a]), torch.from_numpy(p[b])])
+        _chk(c, out[0], torch.from_numpy(p[c]), 2e-5)
+        _chk(d, out[1], torch.from_numpy(p[d]), 2e-5)
+
+
+def test_vs_oracle_fresh_input_and_roundtrip(model4, hip):
+    import oracle.srflow_ref as O
+    from bfsr_amd.srflow.test import lp_infer
+    m, prior, opt, sd, psd = model4
+    lr = synth.smooth_lr_batch(11, 2, 24, 40)
+    out = lp_infer(m, prior, lr, return_all=True)
+    ref = O.lp_pipeline(lr, sd, psd, opt, 23, return_all=True)
+    _chk("sr_raw", out["sr_raw"], ref["sr_raw"])
+    _chk("sr", out["sr"], ref["sr"])
+    # invertibility: decode(encode(x)) == x
+    eng = m.netG.module.engine()
+    rt = eng.decode(hip.to_device(lr), epses=out["epses"])
+    _chk("roundtrip", rt, ref["lr_up"], 1e-4)
+
+
+def test_roundtrip_and_batch_invariance_at_bench_size(model4, hip):
+    """Size-independent properties at the BASELINE crop size (160x160 LR -> 640x640)."""
+    from bfsr_amd.ops import MODE_BILINEAR
+    m, prior, opt, sd, psd = model4
+    eng = m.netG.module.engine()
+    lr = hip.to_device(synth.smooth_lr_batch(21, 2, 160, 160))
+    lr_up = hip.resize(lr, hip.empty(2, 3, 640, 640), MODE_BILINEAR, 0.25, 0.25)
+    ep = eng.encode(lr_up, lr)
+    assert ep[0].shape == (2, 6, 320, 320) and ep[1].shape == (2, 96, 80, 80)
+    rt = eng.decode(lr, epses=ep)
+    err = (rt - lr_up).abs().max().item()
+    assert err <= 1e-4, "round trip %.3e" % err
+    # per-sample independence: sample 1 alone gives bit-identical latents (exactness of batch sharding)
+    lr1 = lr[1:2].clone()
+    lr_up1 = lr_up[1:2].clone()
+    ep1 = eng.encode(lr_up1, lr1)
+    for a, b in zip(ep, ep1):
+        assert torch.equal(a[1:2], b), "batch sharding changed the result"
+
+
+def test_tau_path_runs(model4, hip):
+    """Non-LP sampling path (get_z + Split2d sampling): finite output of the right shape."""
+    m, prior, opt, sd, psd = model4
+    lr = synth.lr_batch(31, 1, 16, 16)
+    sr, z = m.get_sr_with_z(lr, heat=0.5, seed=3)
+    assert sr.shape == (1, 3, 64, 64) and torch.isfinite(sr).all()
+    assert z.shape == (1, 96, 8, 8)

@@ -135,13 +135,22 @@ def main():
         import oracle.srflow_ref as O          # checker / baseline only
         cl = args.cpu_lr
         x = synth.lr_batch(99, 1, cl, cl)
-        t1 = time.perf_counter()
-        ref = O.lp_pipeline(x, sd, psd, opt, opt["network_G"]["nb"], return_all=True)
-        cdt = time.perf_counter() - t1
+        # the oracle is a torch-CPU program: with all 128+ hardware threads MKL-DNN is badly oversubscribed on the
+        # small convs, so the sample is timed at two pool sizes and the faster one is reported (threads stated)
+        best = None
+        for nt in sorted(set([min(16, os.cpu_count() or 1), min(32, os.cpu_count() or 1)])):
+            torch.set_num_threads(nt)
+            t1 = time.perf_counter()
+            ref = O.lp_pipeline(x, sd, psd, opt, opt["network_G"]["nb"], return_all=True)
+            cdt = time.perf_counter() - t1
+            if best is None or cdt < best[0]:
+                best = (cdt, nt)
+        cdt, nt = best
         cpu_baseline = {"value": round((cl * scale) ** 2 / 1e6 / cdt, 5), "unit": "MPix/s",
-                        "cores": torch.get_num_threads(), "kind": "port",
-                        "sample": "1 image %dx%d->%dx%d, oracle lp_pipeline (reference op order, RRDB twice), %.1f s"
-                                  % (cl, cl, cl * scale, cl * scale, cdt)}
+                        "cores": nt, "kind": "port",
+                        "sample": "1 image %dx%d->%dx%d, oracle lp_pipeline (reference op order, RRDB twice), best of "
+                                  "16/32 threads on a %d-thread host, %.1f s" % (cl, cl, cl * scale, cl * scale,
+                                                                                 os.cpu_count() or 0, cdt)}
         out = lp_infer(model, prior, x, return_all=True)
         torch.cuda.synchronize()
         parity = {"max_abs_sr": float((out["sr"].cpu() - ref["sr"]).abs().max()),

@@ -24,10 +24,17 @@ def _orthogonal(rng, n):
 def _fill(rng, shape, kind):
     shape = tuple(shape)
     n = int(np.prod(shape)) if len(shape) else 1
-    if kind in ("kaiming0.1", "kaiming"):
+    if kind in ("kaiming0.1", "kaiming", "kaiming0.3"):
         fan_in = int(np.prod(shape[1:]))
-        std = np.sqrt(2.0 / fan_in) * (0.1 if kind == "kaiming0.1" else 0.6)
+        std = np.sqrt(2.0 / fan_in) * {"kaiming0.1": 0.1, "kaiming0.3": 0.3, "kaiming": 0.6}[kind]
         a = rng.standard_normal(shape) * std
+    elif kind == "meanshift_w":                   # EDSR MeanShift (unused by forward, present in the sd)
+        a = np.eye(3).reshape(3, 3, 1, 1)
+    elif kind == "linf_last":                     # last MLP layer -> affine_info: keep the flow well conditioned
+        fan_in = int(np.prod(shape[1:]))
+        a = rng.standard_normal(shape) * np.sqrt(1.0 / fan_in) * 0.3
+    elif kind == "linf_last_bias":
+        a = rng.standard_normal(shape) * 0.05
     elif kind == "bias_small":
         a = rng.standard_normal(shape) * 0.01
     elif kind == "flowconv":                      # flow.Conv2d init, flow.py:54 (std 0.05)

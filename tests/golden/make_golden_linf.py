@@ -1,0 +1,166 @@
+"""LINF-LP golden vectors from the genuine reference (build container only; see make_golden.py)."""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+import ref_import as R  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def maxdiff(a, b):
+    return float((a - b).abs().max())
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: (npy(v) if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()})
+    print("wrote", name, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+MODEL_SPECS = {
+    "rrdb": {"name": "linf-patch", "args": {"encoder_spec": {"name": "rrdb", "args": {"no_upsampling": True}},
+                                             "imnet_spec": {"name": "flow", "args": {"name": "flow"}},
+                                             "flow_layers": 10, "num_layer": 3, "hidden_dim": 256}},
+    "edsr": {"name": "linf-patch", "args": {"encoder_spec": {"name": "edsr-baseline", "args": {"no_upsampling": True}},
+                                             "imnet_spec": {"name": "flow", "args": {"name": "flow"}},
+                                             "flow_layers": 10, "num_layer": 3, "hidden_dim": 256}},
+}
+PRIOR_SPEC = {"name": "unet", "args": {"in_chans": 27, "depth": 3, "dim": 64, "bilinear": True}}
+
+
+def gen_linf(MANIFEST):
+    from bfsr_amd import synth
+    from bfsr_amd.linf import spec as lspec
+    import oracle.linf_ref as O
+
+    man = MANIFEST.setdefault("linf", {})
+    R.use_linf()
+    models = importlib.import_module("models")
+    wrappers = importlib.import_module("datasets.wrappers")
+    test_mod = importlib.import_module("test")
+    utils = importlib.import_module("utils")
+    schema_out = {}
+
+    prior = models.make(PRIOR_SPEC).eval()
+    psch = lspec.linf_prior_schema(27)
+    assert [(k, tuple(v.shape)) for k, v in prior.state_dict().items()] == [(k, tuple(s)) for k, (s, _) in psch.items()]
+    psd = synth.state_dict_from_schema(psch, 777)
+    prior.load_state_dict(psd, strict=True)
+    schema_out["prior_unet27"] = [[k, list(v.shape)] for k, v in prior.state_dict().items()]
+
+    # make_coord
+    c = utils.make_coord((5, 7), flatten=False)
+    man["make_coord"] = maxdiff(O.make_coord((5, 7)), c)
+
+    class Pair(torch.utils.data.Dataset):
+        def __init__(self, lr, hr):
+            self.lr, self.hr = lr, hr
+
+        def __len__(self):
+            return 1
+
+        def __getitem__(self, i):
+            return self.lr, self.hr
+
+    for tag, enc, seed in (("rrdb", "rrdb", 2024), ("edsr", "edsr", 2025)):
+        mspec = MODEL_SPECS[enc]
+        model = models.make(mspec).eval()
+        sch = lspec.linf_schema(mspec["args"]["encoder_spec"])
+        ref_sd = model.state_dict()
+        assert [(k, tuple(v.shape)) for k, v in ref_sd.items()] == [(k, tuple(s)) for k, (s, _) in sch.items()], \
+            [(a, b) for a, b in zip(ref_sd.keys(), sch.keys()) if a != b][:4]
+        schema_out["linf_patch_" + enc] = [[k, list(v.shape)] for k, v in ref_sd.items()]
+        sd = synth.state_dict_from_schema(sch, seed)
+        model.load_state_dict(sd, strict=True)
+
+        cases = [("s4", 4, (12, 16)), ("s3", 3, (10, 14)), ("s2", 2, (16, 12))] if enc == "rrdb" else \
+                [("s4", 4, (16, 16)), ("s6", 6, (8, 12))]
+        for ctag, s, (h, w) in cases:
+            lr = synth.smooth_lr_batch(seed + s, 1, h, w)[0]
+            H, W = s * h, s * w
+            hr = torch.rand(3, H, W)
+            ds = wrappers.SRImplicitPairedFastPatch(Pair(lr, hr), patch_size=3)
+            item = ds[0]
+            mine = O.input_prep(lr, (H, W), 3, always_pad=True)
+            man["prep_%s_%s" % (tag, ctag)] = max(maxdiff(mine[k], item[k]) for k in ("coord", "cell", "gt_lr_up"))
+            batch = {k: v.unsqueeze(0) for k, v in item.items()}
+            # reference eval harness pieces (test.py:142-171, 217)
+            inp = (batch["inp"] - 0.5) / 0.5
+            z_lr = test_mod.batched_predict_log_p(model, inp, batch["coord"], batch["cell"], batch["gt_lr_up"]).contiguous()
+            z_learned = prior(z_lr, inp)
+            if z_learned.shape != z_lr.shape:
+                z_learned = F.interpolate(z_learned, size=z_lr.shape[-2:], mode="bilinear", align_corners=False)
+            pred = test_mod.batched_predict(model, inp, batch["coord"], batch["cell"], 0, z_learned)
+            pred = pred[..., :H, :W]
+            pred = pred + F.interpolate(inp, pred.shape[-2:], mode="bilinear", align_corners=False)
+            out = torch.clamp(pred * 0.5 + 0.5, 0, 1)
+            # round trip through the reference (decode the un-modified latent)
+            rt = test_mod.batched_predict(model, inp, batch["coord"], batch["cell"], 0, z_lr)
+            o = O.lp_pipeline({k: batch[k] for k in ("inp", "coord", "cell", "gt_lr_up")}, sd, psd, mspec, (H, W),
+                              return_all=True)
+            man["e2e_%s_%s" % (tag, ctag)] = dict(z_lr=maxdiff(o["z_lr"], z_lr), z_learned=maxdiff(o["z_learned"], z_learned),
+                                                  pred_raw=maxdiff(o["pred_raw"], pred), pred=maxdiff(o["pred"], out),
+                                                  ref_absmax=float(pred.abs().max()))
+            extra = {}
+            if ctag == "s4":
+                feat = model("gen_feat", inp=inp)
+                extra["feat"] = feat
+                man["encoder_%s" % tag] = maxdiff(O.encoder(inp, sd, mspec["args"]["encoder_spec"]), feat)
+            save("linf_e2e_%s_%s.npz" % (tag, ctag), lr=lr.unsqueeze(0), scale=np.int64(s), coord=batch["coord"],
+                 cell=batch["cell"], gt_lr_up=batch["gt_lr_up"], z_lr=z_lr, z_learned=z_learned, pred_raw=pred, pred=out,
+                 roundtrip_fold=rt, weights_seed=np.int64(seed), prior_seed=np.int64(777),
+                 weights_sha256=np.frombuffer(synth.digest(sd).encode(), dtype=np.uint8), **extra)
+
+        if enc == "edsr":
+            # the reference's own eval_psnr scalar on config 1 (48x48 -> 192x192), list-of-dicts loader
+            lr = synth.smooth_lr_batch(31, 1, 48, 48)[0]
+            hr = F.interpolate(lr.unsqueeze(0), scale_factor=4, mode="bicubic", align_corners=False).clamp(0, 1)[0]
+            item = wrappers.SRImplicitPairedFastPatch(Pair(lr, hr), patch_size=3)[0]
+            batch = {k: v.unsqueeze(0) for k, v in item.items()}
+            psnr = test_mod.eval_psnr([dict(batch)], model, prior_model=prior,
+                                      data_norm={"inp": {"sub": [0.5], "div": [0.5]}, "gt": {"sub": [0.5], "div": [0.5]}},
+                                      eval_type="div2k-4", eval_bsize=300000, patch=True)
+            o = O.lp_pipeline({k: batch[k] for k in ("inp", "coord", "cell", "gt_lr_up")}, sd, psd, mspec, (192, 192))
+            save("linf_cfg1_edsr.npz", lr=lr.unsqueeze(0), hr=hr.unsqueeze(0), psnr=np.float64(psnr), pred=o,
+                 weights_seed=np.int64(seed), prior_seed=np.int64(777))
+            man["cfg1_eval_psnr"] = float(psnr)
+
+    # downsampled-test wrapper padding rule (no pad when divisible)
+    lr = synth.smooth_lr_batch(5, 1, 6, 9)[0]
+    mine = O.input_prep(lr, (18, 27), 3, always_pad=False)
+    man["prep_downsampled_rule_shapes"] = [list(mine["coord"].shape), list(mine["gt_lr_up"].shape)]
+
+    # flow fwd/inv and prior on random inputs
+    sd = synth.state_dict_from_schema(lspec.linf_schema(MODEL_SPECS["edsr"]["args"]["encoder_spec"]), 2025)
+    R.use_linf()
+    flowmod = importlib.import_module("models.flow")
+    fl = flowmod.Flow(flow_layers=10, patch_size=3)
+    fl.load_state_dict({k[len("imnet."):]: v for k, v in sd.items() if k.startswith("imnet.")})
+    g = np.random.Generator(np.random.PCG64(9))
+    x = torch.from_numpy(g.standard_normal((50, 27)).astype(np.float32))
+    ai = torch.from_numpy((g.standard_normal((50, 540)) * 0.5).astype(np.float32))
+    z, _ = fl(x, ai)
+    xi = fl.inverse(x, ai)
+    man["flow_fwd_inv"] = max(maxdiff(O.flow_forward(x, ai, sd), z), maxdiff(O.flow_inverse(x, ai, sd), xi))
+    zq = torch.from_numpy(g.standard_normal((1, 27, 11, 9)).astype(np.float32))
+    lrq = torch.from_numpy(g.random((1, 3, 8, 6), dtype=np.float32)) * 2 - 1
+    pq = prior(zq, lrq)
+    man["prior_unet27"] = maxdiff(O.linf_prior(zq, lrq, psd), pq)
+    save("linf_ops.npz", flow_x=x, flow_ai=ai, flow_fwd=z, flow_inv=xi, prior_z=zq, prior_lr=lrq, prior_out=pq,
+         weights_seed=np.int64(2025), prior_seed=np.int64(777))
+    with open(os.path.join(HERE, "linf_schema.json"), "w") as f:
+        json.dump(schema_out, f)

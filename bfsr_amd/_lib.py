@@ -41,6 +41,29 @@ class BfsrFlowArgs(C.Structure):
     ]
 
 
+class BfsrLinfFeatArgs(C.Structure):
+    _fields_ = [
+        ("cf", C.c_void_p), ("cf_bs", C.c_longlong),
+        ("coord", C.c_void_p), ("cell", C.c_void_p), ("phase", C.c_void_p),
+        ("out", C.c_void_p), ("out_bs", C.c_longlong),
+        ("B", C.c_int), ("hidden", C.c_int), ("h", C.c_int), ("w", C.c_int), ("qh", C.c_int), ("qw", C.c_int),
+        ("dy_neg", C.c_float), ("dy_pos", C.c_float), ("dx_neg", C.c_float), ("dx_pos", C.c_float),
+        ("clamp_lo", C.c_float), ("clamp_hi", C.c_float),
+        ("cy0", C.c_float), ("cy1", C.c_float), ("cx0", C.c_float), ("cx1", C.c_float),
+    ]
+
+
+class BfsrLinfFlowArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("x_bs", C.c_longlong),
+        ("ai", C.c_void_p), ("ai_bs", C.c_longlong),
+        ("y", C.c_void_p), ("y_bs", C.c_longlong),
+        ("lin_w", C.c_void_p), ("lin_b", C.c_void_p),
+        ("B", C.c_int), ("D", C.c_int), ("layers", C.c_int), ("qh", C.c_int), ("qw", C.c_int), ("reverse", C.c_int),
+        ("eps", C.c_float),
+    ]
+
+
 # every symbol include/bfsr_hip.h declares: name -> (restype, argtypes)
 _LL, _I, _F, _VP = C.c_longlong, C.c_int, C.c_float, C.c_void_p
 SYMBOLS = {
@@ -56,6 +79,11 @@ SYMBOLS = {
     "bfsr_resize": (_I, [_VP, _LL, _I, _I, _VP, _LL, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _VP]),
     "bfsr_maxpool2": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
     "bfsr_axpb_clamp": (_I, [_VP, _LL, _VP, _LL, _VP, _LL, _I, _I, _I, _I, _F, _F, _F, _F, _VP]),
+    "bfsr_linf_features": (_I, [C.POINTER(BfsrLinfFeatArgs), _VP]),
+    "bfsr_linf_flow": (_I, [C.POINTER(BfsrLinfFlowArgs), _VP]),
+    "bfsr_patch_fold": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _I, _I, _I, _VP]),
+    "bfsr_patch_unfold": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _I, _I, _I, _VP]),
+    "bfsr_conv2d_direct": (_I, [_VP, _LL, _VP, _VP, _VP, _LL, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _VP]),
 }
 
 _lib = None

@@ -1,0 +1,157 @@
+"""Host-side schedule of LINF-LP on the HIP kernels (result-preserving restructuring of the reference):
+
+  * the encoder runs once per LR batch (the reference calls `gen_feat` again for decode, LINF-LP/test.py:22,38);
+  * `coef` and `freq` (3x3, 64->256 each, linf.py:250-251) are ONE conv 64->512, computed once instead of per
+    256-row chunk and per direction;
+  * the per-point conditioning (Fourier features -> shared 1x1 MLP -> `affine_info`, linf.py:325-391) is
+    computed once and shared by `query_log_p` and `query_rgb` (cache keyed on the feat/coord/cell tensors);
+  * `NaiveLinear` inverses are precomputed in fp64 (the reference calls `torch.linalg.solve` per query,
+    flow.py:120); log-determinants are not computed (discarded by the LP harness, test.py:43).
+  * 256-row query chunking (test.py:26-32) is result-preserving and replaced by the kernel grid.
+"""
+import torch
+
+from ..ops import ACT_LRELU, ACT_NONE, ACT_RELU, MODE_BILINEAR
+from ..srflow.engine import RRDBEncoder, _ConvP, _Workspace
+from ..srflow.unet_engine import DenseBlock, UNetBody
+
+
+class EDSREncoder(object):
+    """EDSR with no_upsampling (LINF-LP/models/edsr.py:134-146): head conv, n ResBlocks (conv-ReLU-conv, *res_scale + x),
+    body conv, + head output."""
+
+    def __init__(self, ops, sd, prefix, n_resblocks=16, res_scale=1.0):
+        self.ops, self.n, self.res_scale = ops, n_resblocks, float(res_scale)
+        g = lambda n: sd[prefix + n]
+        self.head = _ConvP(ops, g("head.0.weight"), g("head.0.bias"))
+        self.blocks = [(_ConvP(ops, g("body.%d.body.0.weight" % i), g("body.%d.body.0.bias" % i)),
+                        _ConvP(ops, g("body.%d.body.2.weight" % i), g("body.%d.body.2.bias" % i))) for i in range(n_resblocks)]
+        self.tail = _ConvP(ops, g("body.%d.weight" % n_resblocks), g("body.%d.bias" % n_resblocks))
+        self.nf = self.head.pw.Cout
+        self.ws = _Workspace(ops)
+
+    def forward(self, x, out, on_block=None):
+        ops = self.ops
+        B, _, h, w = x.shape
+        x0 = self.ws.get("head", B, self.nf, h, w)
+        a, b, t = (self.ws.get(n, B, self.nf, h, w) for n in ("a", "b", "t"))
+        self.head.run(ops, x, x0)
+        cur = x0
+        for i, (c1, c2) in enumerate(self.blocks):
+            c1.run(ops, cur, t, act=ACT_RELU)
+            nxt = a if cur is not a else b
+            c2.run(ops, t, nxt, res1=cur, alpha1=self.res_scale)
+            cur = nxt
+        self.tail.run(ops, cur, out, res1=x0, alpha1=1.0)
+        return out
+
+
+def make_encoder(ops, sd, encoder_spec):
+    name, args = encoder_spec["name"], dict(encoder_spec.get("args") or {})
+    if name == "rrdb":
+        return RRDBEncoder(ops, sd, "encoder.", args.get("nb", 23), nf=args.get("nf", 64), gc=args.get("gc", 32),
+                           skip_from_first=True), args.get("nf", 64)
+    if name == "edsr-baseline":
+        return EDSREncoder(ops, sd, "encoder.", args.get("n_resblocks", 16), args.get("res_scale", 1)), args.get("n_feats", 64)
+    raise NotImplementedError("encoder '%s' is outside the hot-path scope" % name)
+
+
+class LINFEngine(object):
+    def __init__(self, sd, ops, encoder_spec, flow_layers=10, num_layer=3, hidden_dim=256, patch_size=3):
+        self.ops, self.ws = ops, _Workspace(ops)
+        sd = {k: v.detach().to("cpu", torch.float32) for k, v in sd.items()}
+        self.hidden, self.ps, self.L = hidden_dim, patch_size, flow_layers
+        self.D = 3 * patch_size * patch_size
+        self.encoder, self.nf = make_encoder(ops, sd, encoder_spec)
+        # coef | freq as one conv (both read the same feat)
+        self.cf = _ConvP(ops, torch.cat([sd["coef.weight"], sd["freq.weight"]], 0),
+                         torch.cat([sd["coef.bias"], sd["freq.bias"]], 0), mtile=2)
+        self.phase = ops.vec(sd["phase.weight"])
+        self.mlp = []
+        for j in range(num_layer + 1):
+            self.mlp.append(_ConvP(ops, sd["layers.%d.weight" % (2 * j)], sd["layers.%d.bias" % (2 * j)], mtile=2))
+        names = ["imnet.linears.%d" % i for i in range(flow_layers)] + ["imnet.last"]
+        W = torch.stack([sd[n + "._weight"] for n in names])
+        self.lin_b = ops.vec(torch.stack([sd[n + ".bias"] for n in names]))
+        self.lin_w = ops.vec(W)
+        self.lin_winv = ops.vec(torch.inverse(W.double()).float())
+        self._feat_key = self._feat = None
+        self._cond_key = self._cond = None
+
+    # ------------------------------------------------------------------------------------------------
+    def gen_feat(self, inp):
+        key = (inp.data_ptr(), inp._version, tuple(inp.shape))
+        if self._feat_key != key:
+            B, _, h, w = inp.shape
+            out = self.ops.empty(B, self.nf, h, w)
+            self.encoder.forward(inp, out)
+            self._feat_key, self._feat = key, out
+        return self._feat
+
+    def affine_info(self, feat, coord, cell):
+        key = (feat.data_ptr(), feat._version, coord.data_ptr(), coord._version, cell.data_ptr(), tuple(coord.shape))
+        if self._cond_key == key:
+            return self._cond
+        ops, ws, HD = self.ops, self.ws, self.hidden
+        B, _, h, w = feat.shape
+        _, qh, qw, _ = coord.shape
+        cf = ws.get("cf", B, 2 * HD, h, w)
+        self.cf.run(ops, feat, cf)
+        feats = ws.get("fourier", B, 4 * HD, qh, qw)
+        ops.linf_features(cf, coord, cell, self.phase, feats, HD)
+        x = feats
+        for j, layer in enumerate(self.mlp):
+            last = j == len(self.mlp) - 1
+            y = ws.get("mlp%d" % (j & 1) if not last else "affine_info", B, layer.pw.Cout, qh, qw)
+            layer.run(ops, x, y, act=ACT_NONE if last else ACT_RELU)
+            x = y
+        self._cond_key, self._cond = key, x
+        return x
+
+    def query_log_p(self, feat, coord, cell, gt):
+        """-> z [B,D,qh,qw] (log_p is not computed)."""
+        ai = self.affine_info(feat, coord, cell)
+        z = self.ops.empty(*gt.shape)
+        return self.ops.linf_flow(gt, ai, z, self.lin_w, self.lin_b, self.L, reverse=False)
+
+    def query_rgb(self, feat, coord, cell, zmap):
+        """-> folded prediction [B,3,ps*qh,ps*qw]."""
+        ops = self.ops
+        ai = self.affine_info(feat, coord, cell)
+        B, _, qh, qw = zmap.shape
+        p = self.ws.get("flow_out", B, self.D, qh, qw)
+        ops.linf_flow(zmap, ai, p, self.lin_winv, self.lin_b, self.L, reverse=True)
+        img = ops.empty(B, 3, self.ps * qh, self.ps * qw)
+        return ops.patch_fold(p, img, self.ps)
+
+
+class LINFPriorEngine(object):
+    """LINF-LP prior `UNet.forward(x, lr)` (LINF-LP/models/unet.py:144-167)."""
+
+    def __init__(self, sd, ops, in_chans, depth=3, dim=64):
+        sd = {k: v.detach().to("cpu", torch.float32) for k, v in sd.items() if v.dtype.is_floating_point}
+        self.ops, self.ws, self.in_chans, self.dim = ops, _Workspace(ops), in_chans, dim
+        self.input_proj = DenseBlock(ops, sd, "input_proj")
+        self.lr_w = ops.to_device(sd["lr_proj.0.weight"])
+        self.lr_b = ops.vec(sd["lr_proj.0.bias"])
+        self.lr_dense = DenseBlock(ops, sd, "lr_proj.2")
+        self.body = UNetBody(ops, sd, "", depth)
+
+    def forward(self, x, lr):
+        ops, ws = self.ops, self.ws
+        B, C, H, W = x.shape
+        half = self.dim // 2
+        cat = ws.get("cat", B, self.dim, H, W)
+        self.input_proj.run(ops, ws, "ip", x, cat[:, :half])
+        _, _, h, w = lr.shape
+        oh, ow = (h + 2 - 3) // 3 + 1, (w + 2 - 3) // 3 + 1
+        e0 = ws.get("lr0", B, self.in_chans, oh, ow)
+        ops.conv_direct(lr, self.lr_w, self.lr_b, e0, 3, 1, act=ACT_LRELU, slope=0.2)
+        if (oh, ow) == (H, W):
+            self.lr_dense.run(ops, ws, "lp", e0, cat[:, half:])
+        else:
+            e1 = ws.get("lr1", B, half, oh, ow)
+            self.lr_dense.run(ops, ws, "lp", e0, e1)
+            ops.resize(e1, cat[:, half:], MODE_BILINEAR, float(oh) / H, float(ow) / W)   # size= given => r = in/out
+        out = ops.empty(B, self.in_chans, H, W)
+        return self.body.run(ws, cat, out, "u")

@@ -1,0 +1,98 @@
+"""`LINFPatch` ('linf-patch') and `LINF` ('linf') -- drop-ins for LINF-LP/models/linf.py:11-428.
+
+`forward(op, inp, feat, coord, cell, gt, temperature, zmap)` with op in {"gen_feat", "query_log_p", "query_rgb",
+"log_p", "rgb"}; nested `encoder_spec` / `imnet_spec` are resolved through the registry like the reference
+(linf.py:225,242); state_dict keys are the reference's (`encoder.*`, `coef`, `freq`, `phase`, `layers.{0,2,4,6}`,
+`imnet.linears.{i}.{bias,_weight}`, `imnet.last.*`).  `log_p` values are not computed (None is returned in their
+place; the LP harness discards them, LINF-LP/test.py:43)."""
+import torch
+from torch import nn
+
+from ... import paramtree
+from .. import spec
+from ..engine import LINFEngine
+from .models import make as _make, register
+
+
+@register('linf-patch')
+class LINFPatch(nn.Module):
+    def __init__(self, encoder_spec, imnet_spec=None, flow_layers=10, num_layer=3, hidden_dim=256, patch_size=3, ops=None):
+        super(LINFPatch, self).__init__()
+        self.patch_size = patch_size
+        self.encoder = _make(encoder_spec)
+        self.imnet = _make(imnet_spec, args={'flow_layers': flow_layers, 'patch_size': patch_size})
+        full = spec.linf_schema(self.encoder.spec, flow_layers, num_layer, hidden_dim, patch_size)
+        own = type(full)((k, v) for k, v in full.items() if not (k.startswith("encoder.") or k.startswith("imnet.")))
+        paramtree.attach(self, own, paramtree.default_init(14))
+        # keep the reference's key order: encoder.*, coef, freq, phase, layers.*, imnet.*
+        self._modules["imnet"] = self._modules.pop("imnet")
+        self._cfg = dict(encoder_spec=self.encoder.spec, flow_layers=flow_layers, num_layer=num_layer,
+                         hidden_dim=hidden_dim, patch_size=patch_size)
+        self._ops, self._engine = ops, None
+
+    def load_state_dict(self, state_dict, strict=True):
+        r = super(LINFPatch, self).load_state_dict(state_dict, strict=strict)
+        self._engine = None
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super(LINFPatch, self)._apply(fn, *a, **k)
+        self._engine = None
+        return r
+
+    def engine(self):
+        if self._engine is None:
+            if self._ops is None:
+                from ...ops import HipOps
+                p = next(self.parameters())
+                self._ops = HipOps(p.device if p.is_cuda else None)
+            self._engine = LINFEngine(self.state_dict(), self._ops, **self._cfg)
+        return self._engine
+
+    # ---- reference ops -----------------------------------------------------------------------------
+    def gen_feat(self, inp):
+        e = self.engine()
+        return e.gen_feat(e.ops.to_device(inp))
+
+    def query_log_p(self, inp, feat, coord, cell, gt):
+        e = self.engine()
+        d = e.ops.to_device
+        return None, e.query_log_p(d(feat), d(coord), d(cell), d(gt))
+
+    def query_rgb(self, inp, feat, coord, cell, temperature=0, zmap=None):
+        e = self.engine()
+        d = e.ops.to_device
+        coord = d(coord)
+        if zmap is None:     # tau path (linf.py:398): z ~ N(0,1) * temperature, sampled on device (plumbing)
+            B, qh, qw, _ = coord.shape
+            zmap = torch.randn(B, e.D, qh, qw, device=coord.device) * temperature
+        return e.query_rgb(d(feat), coord, d(cell), d(zmap))
+
+    def log_p(self, inp, coord, cell, gt):
+        return self.query_log_p(inp, self.gen_feat(inp), coord, cell, gt)
+
+    def rgb(self, inp, coord, cell, temperature=0, zmap=None):
+        return self.query_rgb(inp, self.gen_feat(inp), coord, cell, temperature, zmap)
+
+    def forward(self, op, inp=None, feat=None, coord=None, cell=None, gt=None, temperature=0, zmap=None):
+        with torch.no_grad():
+            if op == "query_log_p":
+                return self.query_log_p(inp, feat, coord, cell, gt)
+            if op == "query_rgb":
+                return self.query_rgb(inp, feat, coord, cell, temperature, zmap)
+            if op == "log_p":
+                return self.log_p(inp, coord, cell, gt)
+            if op == "rgb":
+                return self.rgb(inp, coord, cell, temperature, zmap)
+            if op == "gen_feat":
+                return self.gen_feat(inp)
+        raise ValueError("unknown op %r" % (op,))
+
+
+@register('linf')
+class LINF(LINFPatch):
+    """Pixel-wise variant (patch_size 1, linf.py:11-216).  The engine supports D=3; the reference's in-method
+    bilinear `grid_sample` skip (linf.py:193-194) is the harness' job here (`bfsr_amd.linf.test`)."""
+
+    def __init__(self, encoder_spec, imnet_spec=None, flow_layers=10, num_layer=3, hidden_dim=256, ops=None):
+        super(LINF, self).__init__(encoder_spec, imnet_spec, flow_layers, num_layer, hidden_dim, patch_size=1, ops=ops)

@@ -1,0 +1,47 @@
+"""Input preparation of the LINF-LP patch wrappers computed from the LR batch alone
+(reference LINF-LP/datasets/wrappers.py:203-238 `SRImplicitPairedFastPatch`, :572-613
+`SRImplicitDownsampledFastPatchTest`): `coord` = centres of the ps x ps HR patches (zero in the padding),
+`cell = [2/H, 2/W]`, `gt_lr_up` = ps x ps-unfolded LR-upsample residual
+`lr_up - up(down(lr_up))` (bilinear, align_corners=False).  The residual / unfold run on the HIP kernels; the
+coordinate grid is tiny index math done once per shape on the host with the reference's float arithmetic."""
+import torch
+import torch.nn.functional as F
+
+from ..ops import MODE_BILINEAR
+from .utils import make_coord
+
+_coord_cache = {}
+
+
+def patch_grid(H, W, ps=3, always_pad=True):
+    """(qh, qw, coord[qh,qw,2]) for an HR size.  always_pad: the paired wrapper pads ps - H % ps even when
+    H % ps == 0 (wrappers.py:218-219); the downsampled-test wrapper does not (:590-597)."""
+    key = (H, W, ps, always_pad)
+    if key not in _coord_cache:
+        if always_pad:
+            pad_h, pad_w = ps - H % ps, ps - W % ps
+        else:
+            pad_h = ps - H % ps if H % ps else 0
+            pad_w = ps - W % ps if W % ps else 0
+        c = F.pad(make_coord([H, W], flatten=False).permute(2, 0, 1), (0, pad_w, 0, pad_h), "constant", 0)
+        cu = c.unfold(1, ps, ps).unfold(2, ps, ps)
+        coord = cu[:, :, :, ps // 2, ps // 2].permute(1, 2, 0).contiguous()
+        _coord_cache[key] = (coord.shape[0], coord.shape[1], coord)
+    return _coord_cache[key]
+
+
+def prepare_batch(ops, inp01, hr_hw, ps=3, always_pad=True):
+    """inp01 [B,3,h,w] in [0,1] (device) -> dict(inp, coord, cell, gt_lr_up) on the device, as the DataLoader
+    would deliver them (inp un-normalised)."""
+    H, W = hr_hw
+    B, _, h, w = inp01.shape
+    qh, qw, coord = patch_grid(H, W, ps, always_pad)
+    inp_n = ops.axpb_clamp(inp01, ops.empty(B, 3, h, w), 2.0, -1.0)                 # (x - 0.5) / 0.5
+    lr_up = ops.resize(inp_n, ops.empty(B, 3, H, W), MODE_BILINEAR, float(h) / H, float(w) / W)
+    down = ops.resize(lr_up, ops.empty(B, 3, h, w), MODE_BILINEAR, float(H) / h, float(W) / w)
+    up2 = ops.resize(down, ops.empty(B, 3, H, W), MODE_BILINEAR, float(h) / H, float(w) / W)
+    res = ops.axpb_clamp(up2, up2, -1.0, 0.0, r=lr_up)                               # lr_up - up(down(lr_up))
+    gt = ops.patch_unfold(res, ops.empty(B, 3 * ps * ps, qh, qw), ps)
+    coord_b = ops.to_device(coord.unsqueeze(0).expand(B, qh, qw, 2).contiguous())
+    cell = ops.to_device(torch.tensor([[2 / H, 2 / W]], dtype=torch.float32).expand(B, 2).contiguous())
+    return dict(inp=inp01, coord=coord_b, cell=cell, gt_lr_up=gt)

@@ -1,0 +1,102 @@
+"""LINF-LP evaluation harness -- counterpart of the reference's `test.py` (LINF-LP/test.py:20-236).
+
+`lp_infer` is the LP branch of `eval_psnr` (test.py:94-171, 217) for `--patch` models with a prior:
+normalise -> encode (`query_log_p`) -> prior (+ bilinear resize if shapes differ) -> decode (`query_rgb`) ->
+crop -> `+= bilinear(inp)` -> clamp(0.5 x + 0.5).  The 256-row chunk loops of `batched_predict(_log_p)` are
+result-preserving and are replaced by the kernel grid; `gen_feat` and the per-point conditioning are computed once.
+Datasets, PNG I/O, SSIM/LPIPS are outside the accelerated path."""
+import math
+
+import torch
+
+from ..ops import MODE_BILINEAR
+from . import prep
+
+
+def batched_predict_log_p(model, inp, coord, cell, gt):
+    feat = model("gen_feat", inp=inp)
+    return model("query_log_p", inp=inp, feat=feat, coord=coord, cell=cell, gt=gt)[1]
+
+
+def batched_predict(model, inp, coord, cell, temperature, zmap=None):
+    feat = model("gen_feat", inp=inp)
+    return model("query_rgb", inp=inp, feat=feat, coord=coord, cell=cell, temperature=temperature, zmap=zmap)
+
+
+def lp_infer(model, prior_model, batch, hr_hw, temperature=0, return_all=False):
+    """batch: dict(inp [B,3,h,w] in [0,1], coord, cell, gt_lr_up) as delivered by the patch wrappers."""
+    eng = model.engine()
+    ops = eng.ops
+    d = ops.to_device
+    H, W = hr_hw
+    with torch.no_grad():
+        inp01 = d(batch['inp'])
+        B, _, h, w = inp01.shape
+        inp = ops.axpb_clamp(inp01, ops.empty(B, 3, h, w), 2.0, -1.0)            # (inp - 0.5) / 0.5  (test.py:98)
+        coord, cell, gt = d(batch['coord']), d(batch['cell']), d(batch['gt_lr_up'])
+        z_lr = batched_predict_log_p(model, inp, coord, cell, gt)                # test.py:145
+        z_learned = prior_model(z_lr, inp)                                       # test.py:147
+        if z_learned.shape != z_lr.shape:                                        # test.py:148-149
+            t = ops.empty(*z_lr.shape)
+            ops.resize(z_learned, t, MODE_BILINEAR, float(z_learned.shape[2]) / t.shape[2], float(z_learned.shape[3]) / t.shape[3])
+            z_learned = t
+        full = batched_predict(model, inp, coord, cell, temperature, z_learned)  # test.py:165
+        pred = full[..., :H, :W]                                                 # test.py:168 (a view; planes stay contiguous only if W is full)
+        if pred.shape[-1] != full.shape[-1]:
+            c = ops.empty(B, 3, H, W)
+            ops.patch_fold(eng.ws.bufs["flow_out"], c, eng.ps)                   # fold again with the crop applied
+            pred = c
+        elif pred.shape[-2] != full.shape[-2]:
+            pred = pred.contiguous()
+        skip = ops.resize(inp, ops.empty(B, 3, H, W), MODE_BILINEAR, float(h) / H, float(w) / W)   # test.py:171
+        pred_raw = ops.axpb_clamp(pred, ops.empty(B, 3, H, W), 1.0, 0.0, r=skip)
+        out = ops.axpb_clamp(pred_raw, ops.empty(B, 3, H, W), 0.5, 0.5, 0.0, 1.0)                  # test.py:217
+    if return_all:
+        return dict(z_lr=z_lr, z_learned=z_learned, pred_raw=pred_raw, pred=out)
+    return out
+
+
+def infer_from_lr(model, prior_model, inp01, scale, always_pad=True, **kw):
+    """LR tensor in -> HR tensor out: device-side input prep (prep.prepare_batch) + lp_infer."""
+    ops = model.engine().ops
+    inp01 = ops.to_device(inp01)
+    h, w = inp01.shape[-2:]
+    H, W = round(h * scale), round(w * scale)
+    batch = prep.prepare_batch(ops, inp01, (H, W), model.patch_size, always_pad)
+    return lp_infer(model, prior_model, batch, (H, W), **kw)
+
+
+def calc_psnr(sr, hr, dataset=None, scale=1, rgb_range=1):
+    """LINF-LP/utils.py:132-149."""
+    diff = (sr - hr) / rgb_range
+    if dataset is not None:
+        if dataset == 'benchmark':
+            shave = scale
+            if diff.size(1) > 1:
+                gray = diff.new_tensor([65.738, 129.057, 25.064]).view(1, 3, 1, 1) / 256
+                diff = diff.mul(gray).sum(dim=1)
+        elif dataset == 'div2k':
+            shave = scale
+        else:
+            raise NotImplementedError
+        valid = diff[..., shave:-shave, shave:-shave]
+    else:
+        valid = diff
+    return -10 * torch.log10(valid.pow(2).mean())
+
+
+def eval_psnr(loader, model, prior_model, eval_type=None, patch=True, temperature=0):
+    """Average PSNR over an iterable of batch dicts (LP branch of the reference's eval_psnr)."""
+    tot, n = 0.0, 0
+    for batch in loader:
+        H, W = batch['gt'].shape[-2:]
+        pred = lp_infer(model, prior_model, batch, (H, W), temperature)
+        gt = batch['gt'].to(pred.device)
+        if eval_type is None:
+            p = calc_psnr(pred, gt)
+        else:
+            kind, s = eval_type.split('-')
+            p = calc_psnr(pred, gt, dataset=kind, scale=int(s))
+        tot += float(p) * pred.shape[0]
+        n += pred.shape[0]
+    return tot / max(n, 1)

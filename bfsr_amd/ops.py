@@ -202,3 +202,58 @@ class HipOps(object):
         _lib.check(self.lib.bfsr_axpb_clamp(xp, xbs, rp, rbs, yp, ybs, x.shape[0], Cc, H, W, a, b, lo, hi,
                                             self._stream()), "axpb_clamp")
         return y
+
+    # ---- LINF-LP ------------------------------------------------------------------------------------
+    def linf_features(self, cf, coord, cell, phase, out, hidden):
+        """cf [B,2*hidden,h,w], coord [B,qh,qw,2] contiguous, cell [B,2], phase [hidden/2,2] -> out [B,4*hidden,qh,qw]."""
+        import numpy as np
+        a = _lib.BfsrLinfFeatArgs()
+        a.cf, a.cf_bs, c2, h, w = _view(cf, "linf.cf")
+        a.out, a.out_bs, c4, qh, qw = _view(out, "linf.out")
+        assert c2 == 2 * hidden and c4 == 4 * hidden and tuple(coord.shape) == (cf.shape[0], qh, qw, 2)
+        assert coord.is_contiguous() and cell.is_contiguous() and phase.is_contiguous()
+        a.coord, a.cell, a.phase = coord.data_ptr(), cell.data_ptr(), phase.data_ptr()
+        a.B, a.hidden, a.h, a.w, a.qh, a.qw = cf.shape[0], hidden, h, w, qh, qw
+        rx, ry, e = 2 / h / 2, 2 / w / 2, 1e-6            # linf.py:332-341 (python doubles -> float32 at the add)
+        a.dy_neg, a.dy_pos, a.dx_neg, a.dx_pos = -1 * rx + e, 1 * rx + e, -1 * ry + e, 1 * ry + e
+        a.clamp_lo, a.clamp_hi = -1 + 1e-6, 1 - 1e-6
+        a.cy0, a.cy1, a.cx0, a.cx1 = -1 + 1.0 / h, 2 * (1.0 / h), -1 + 1.0 / w, 2 * (1.0 / w)
+        _lib.check(self.lib.bfsr_linf_features(C.byref(a), self._stream()), "linf_features")
+        return out
+
+    def linf_flow(self, x, ai, y, lin_w, lin_b, layers, reverse, eps=1e-4):
+        a = _lib.BfsrLinfFlowArgs()
+        a.x, a.x_bs, D, qh, qw = _view(x, "linf_flow.x")
+        a.ai, a.ai_bs, ca, _, _ = _view(ai, "linf_flow.ai")
+        a.y, a.y_bs, _, _, _ = _view(y, "linf_flow.y")
+        assert ca == 2 * D * layers and lin_w.numel() == (layers + 1) * D * D and lin_b.numel() == (layers + 1) * D
+        a.lin_w, a.lin_b = lin_w.data_ptr(), lin_b.data_ptr()
+        a.B, a.D, a.layers, a.qh, a.qw, a.reverse, a.eps = x.shape[0], D, layers, qh, qw, int(bool(reverse)), eps
+        key = ("linf_flow", int(bool(reverse)), D, x.shape[0], qh, qw)
+        _lib.check(self._launch(key, lambda: self.lib.bfsr_linf_flow(C.byref(a), self._stream())), "linf_flow(D=%d)" % D)
+        return y
+
+    def patch_fold(self, p, img, ps):
+        pp, pbs, cp, qh, qw = _view(p)
+        ip, ibs, Cc, H, W = _view(img)
+        assert cp == Cc * ps * ps
+        _lib.check(self.lib.bfsr_patch_fold(pp, pbs, ip, ibs, p.shape[0], Cc, qh, qw, H, W, ps, self._stream()), "patch_fold")
+        return img
+
+    def patch_unfold(self, img, p, ps):
+        pp, pbs, cp, qh, qw = _view(p)
+        ip, ibs, Cc, H, W = _view(img)
+        assert cp == Cc * ps * ps
+        _lib.check(self.lib.bfsr_patch_unfold(ip, ibs, pp, pbs, p.shape[0], Cc, qh, qw, H, W, ps, self._stream()), "patch_unfold")
+        return p
+
+    def conv_direct(self, x, w, bias, y, stride, pad, act=ACT_NONE, slope=0.2):
+        """w [Cout,Cin,KS,KS] contiguous device tensor."""
+        xp, xbs, Cin, H, W = _view(x)
+        yp, ybs, Cout, OH, OW = _view(y)
+        KS = w.shape[2]
+        assert w.is_contiguous() and tuple(w.shape[:2]) == (Cout, Cin)
+        assert OH == (H + 2 * pad - KS) // stride + 1 and OW == (W + 2 * pad - KS) // stride + 1
+        _lib.check(self.lib.bfsr_conv2d_direct(xp, xbs, w.data_ptr(), _ptr(bias), yp, ybs, x.shape[0], Cin, Cout, H, W, KS,
+                                               stride, pad, act, slope, self._stream()), "conv2d_direct")
+        return y

@@ -56,8 +56,11 @@ class RRDBEncoder(object):
     """RRDBNet trunk (RRDBNet_arch.py:67-148 / LINF-LP/models/rrdb.py:77-116): conv_first, nb x RRDB
     (3 x RDB of five 3x3 convs), trunk_conv + skip.  `taps` = RRDB indices whose output is wanted."""
 
-    def __init__(self, ops, sd, prefix, nb, nf=64, gc=32):
-        self.ops, self.nb, self.nf, self.gc = ops, nb, nf, gc
+    def __init__(self, ops, sd, prefix, nb, nf=64, gc=32, skip_from_first=False):
+        # skip_from_first: LINF's RRDBNet adds the conv_first output (`fea = fea + trunk`, LINF-LP/models/rrdb.py:105-107)
+        # whereas SRFlow's adds the trunk output (`last_lr_fea = fea + trunk` after the loop rebinds `fea`,
+        # RRDBNet_arch.py:92-103)
+        self.ops, self.nb, self.nf, self.gc, self.skip_from_first = ops, nb, nf, gc, skip_from_first
         g = lambda n: sd[prefix + n]
         self.conv_first = _ConvP(ops, g("conv_first.weight"), g("conv_first.bias"))
         self.blocks = []
@@ -78,6 +81,10 @@ class RRDBEncoder(object):
         ring = [self.ws.get("dense%d" % i, B, nf + 4 * gc, h, w) for i in range(4)]
         cur = 0
         self.conv_first.run(ops, x, ring[cur][:, :nf])
+        first = None
+        if self.skip_from_first:
+            first = self.ws.get("first", B, nf, h, w)
+            ops.axpb_clamp(ring[cur][:, :nf], first)
         for idx, rdbs in enumerate(self.blocks):
             x_rrdb = ring[cur][:, :nf]
             for r, convs in enumerate(rdbs):
@@ -93,7 +100,7 @@ class RRDBEncoder(object):
             if on_block is not None:
                 on_block(idx, ring[cur][:, :nf])
         fea = ring[cur][:, :nf]
-        self.trunk_conv.run(ops, fea, out, res1=fea, alpha1=1.0)      # last_lr_fea = fea + trunk
+        self.trunk_conv.run(ops, fea, out, res1=first if first is not None else fea, alpha1=1.0)   # skip + trunk
         return out
 
 

@@ -131,6 +131,47 @@ int bfsr_maxpool2(const float* x, long long x_bs, float* y, long long y_bs, int 
 int bfsr_axpb_clamp(const float* x, long long x_bs, const float* r, long long r_bs, float* y, long long y_bs,
                     int B, int C, int H, int W, float a, float b, float lo, float hi, void* stream);
 
+/* ---- LINF-LP ------------------------------------------------------------------------------------------
+ * local-ensemble Fourier features (LINF-LP/models/linf.py:344-388): for each query point and each of the 4
+ * neighbouring LR cells (coord shifted by +-half a cell + 1e-6, clamped, nearest lookup) emit
+ * w * coef (.) [cos(pi f) | sin(pi f)], f = freq . rel_coord + phase(rel_cell); ensemble weights are the
+ * diagonally swapped areas.  cf = [coef | freq] ([B, 2*hidden, h, w], one conv), coord [B,qh,qw,2] (y,x),
+ * cell [B,2], phase [hidden/2, 2]; out [B, 4*hidden, qh, qw].  The four shifts (vx*rx+1e-6 as float) and the
+ * clamp bounds are passed in so the host computes them exactly like the reference (double -> float). */
+typedef struct BfsrLinfFeatArgs {
+    const float* cf; long long cf_bs;
+    const float* coord; const float* cell; const float* phase;
+    float* out; long long out_bs;
+    int B, hidden, h, w, qh, qw;
+    float dy_neg, dy_pos, dx_neg, dx_pos, clamp_lo, clamp_hi;
+    float cy0, cy1, cx0, cx1;      /* LR cell centres: cy0 + cy1*i = float(-1+1/h) + float(2/h)*i (utils.py:113-115) */
+} BfsrLinfFeatArgs;
+int bfsr_linf_features(const BfsrLinfFeatArgs* a, void* stream);
+
+/* local implicit coupling flow (LINF-LP/models/flow.py:44-63) over D = 3*ps*ps vectors on the query grid:
+ * x,y [B,D,qh,qw]; ai = affine_info [B, 2*D*layers, qh, qw]; lin_w [layers+1][D][D] holds W (forward) or
+ * inv(W) (reverse, precomputed by the caller), lin_b [layers+1][D]; last entry = `last` linear. */
+typedef struct BfsrLinfFlowArgs {
+    const float* x; long long x_bs;
+    const float* ai; long long ai_bs;
+    float* y; long long y_bs;
+    const float* lin_w; const float* lin_b;
+    int B, D, layers, qh, qw, reverse;
+    float eps;
+} BfsrLinfFlowArgs;
+int bfsr_linf_flow(const BfsrLinfFlowArgs* a, void* stream);
+
+/* F.fold of ps x ps patches (linf.py:401-406) + crop: p [B,C*ps*ps,qh,qw] -> img [B,C,H,W], H <= ps*qh */
+int bfsr_patch_fold(const float* p, long long p_bs, float* img, long long img_bs, int B, int C, int qh, int qw,
+                    int H, int W, int ps, void* stream);
+/* zero-pad + unfold (datasets/wrappers.py:224-228): img [B,C,H,W] -> p [B,C*ps*ps,qh,qw] */
+int bfsr_patch_unfold(const float* img, long long img_bs, float* p, long long p_bs, int B, int C, int qh, int qw,
+                      int H, int W, int ps, void* stream);
+/* small direct strided conv (+bias, +activation): LINF prior `lr_proj.0` (LINF-LP/models/unet.py:118) */
+int bfsr_conv2d_direct(const float* x, long long x_bs, const float* w, const float* bias, float* y, long long y_bs,
+                       int B, int Cin, int Cout, int H, int W, int KS, int stride, int pad, int act, float slope,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -168,3 +168,80 @@ class CpuOps(object):
             v = v + r
         y.copy_(torch.clamp(v, lo, hi))
         return y
+
+    # ---- LINF-LP ------------------------------------------------------------------------------------
+    def linf_features(self, cf, coord, cell, phase, out, hidden):
+        import numpy as np
+        coef, freq = cf[:, :hidden], cf[:, hidden:]
+        h, w = cf.shape[-2:]
+        rx, ry, e = 2 / h / 2, 2 / w / 2, 1e-6
+        seq = lambda n: (-1 + 1.0 / n) + (2 * (1.0 / n)) * torch.arange(n).float()
+        fc = torch.stack(torch.meshgrid(seq(h), seq(w), indexing="ij"), 0).unsqueeze(0).expand(cf.shape[0], 2, h, w)
+        freqs, coefs, areas = [], [], []
+        for vx in (-1, 1):
+            for vy in (-1, 1):
+                c_ = coord.clone()
+                c_[..., 0] += vx * rx + e
+                c_[..., 1] += vy * ry + e
+                c_.clamp_(-1 + 1e-6, 1 - 1e-6)
+                q = F.grid_sample(fc, c_.flip(-1), mode="nearest", align_corners=False)
+                rel = coord.permute(0, 3, 1, 2) - q
+                rel[:, 0] *= h
+                rel[:, 1] *= w
+                rc = cell.clone()
+                rc[:, 0] *= h
+                rc[:, 1] *= w
+                co = F.grid_sample(coef, c_.flip(-1), mode="nearest", align_corners=False)
+                fr = F.grid_sample(freq, c_.flip(-1), mode="nearest", align_corners=False)
+                fr = torch.stack(torch.split(fr, hidden // 2, dim=1), dim=2)
+                fr = torch.sum(fr * rel.unsqueeze(1), dim=2) + F.linear(rc, phase.view(hidden // 2, 2))[..., None, None]
+                freqs.append(torch.cat((torch.cos(np.pi * fr), torch.sin(np.pi * fr)), 1))
+                coefs.append(co)
+                areas.append(torch.abs(rel[:, 0] * rel[:, 1]) + 1e-9)
+        tot = torch.stack(areas).sum(0)
+        areas = [areas[3], areas[2], areas[1], areas[0]]
+        out.copy_(torch.cat([((areas[i] / tot).unsqueeze(1) * coefs[i]) * freqs[i] for i in range(4)], 1))
+        return out
+
+    def linf_flow(self, x, ai, y, lin_w, lin_b, layers, reverse, eps=1e-4):
+        B, D, qh, qw = x.shape
+        v = x.permute(0, 2, 3, 1).reshape(-1, D)
+        a = ai.permute(0, 2, 3, 1).reshape(-1, 2 * D * layers)
+        Wm, bb = lin_w.view(layers + 1, D, D), lin_b.view(layers + 1, D)
+        sc = lambda i: torch.sigmoid(a[:, 2 * D * i: 2 * D * i + D] + 2.0) + eps
+        sh = lambda i: a[:, 2 * D * i + D: 2 * D * (i + 1)]
+        if not reverse:
+            for i in range(layers):
+                v = F.linear(v, Wm[i], bb[i])
+                v = v * sc(i) + sh(i)
+            v = F.linear(v, Wm[layers], bb[layers])
+        else:
+            v = F.linear(v - bb[layers], Wm[layers])
+            for i in reversed(range(layers)):
+                v = (v - sh(i)) / sc(i)
+                v = F.linear(v - bb[i], Wm[i])
+        y.copy_(v.reshape(B, qh, qw, D).permute(0, 3, 1, 2))
+        return y
+
+    def patch_fold(self, p, img, ps):
+        B, cp, qh, qw = p.shape
+        full = F.fold(p.reshape(B, cp, -1), output_size=(qh * ps, qw * ps), kernel_size=(ps, ps), stride=ps)
+        img.copy_(full[..., :img.shape[2], :img.shape[3]])
+        return img
+
+    def patch_unfold(self, img, p, ps):
+        B, Cc, H, W = img.shape
+        qh, qw = p.shape[2], p.shape[3]
+        x = F.pad(img, (0, qw * ps - W, 0, qh * ps - H))
+        u = x.unfold(2, ps, ps).unfold(3, ps, ps)               # B C qh qw ps ps
+        p.copy_(u.contiguous().view(B, Cc, qh, qw, ps * ps).permute(0, 1, 4, 2, 3).reshape(B, Cc * ps * ps, qh, qw))
+        return p
+
+    def conv_direct(self, x, w, bias, y, stride, pad, act=ACT_NONE, slope=0.2):
+        v = F.conv2d(x, w, bias, stride, pad)
+        if act == ACT_RELU:
+            v = F.relu(v)
+        elif act == ACT_LRELU:
+            v = F.leaky_relu(v, slope)
+        y.copy_(v)
+        return y

@@ -1,0 +1,128 @@
+"""-m gpu: LINF-LP kernels and end-to-end parity on the HIP path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from bfsr_amd import synth                       # noqa: E402
+from bfsr_amd.linf import spec as lspec          # noqa: E402
+from cpu_ops import CpuOps                       # noqa: E402
+from test_linf_cpu import CASES, mspec, weights  # noqa: E402
+
+T = torch.from_numpy
+CPU = CpuOps()
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from bfsr_amd.ops import HipOps
+    return HipOps("cuda:0")
+
+
+def rnd(seed, *shape, scale=1.0):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy((g.standard_normal(shape) * scale).astype(np.float32))
+
+
+def close(a, b, tol, what=""):
+    a = a.detach().cpu()
+    assert not torch.isnan(a).any(), what + " NaN"
+    err = (a - b).abs().max().item()
+    assert err <= tol * max(1.0, b.abs().max().item()), "%s: %.3e" % (what, err)
+
+
+@pytest.mark.parametrize("hw,q", [((8, 12), (21, 33)), ((16, 16), (22, 22)), ((5, 7), (30, 9))])
+def test_linf_features(hip, hw, q):
+    import oracle.linf_ref as O
+    h, w = hw
+    qh, qw = q
+    B, HD = 2, 256
+    cf = rnd(1, B, 2 * HD, h, w)
+    phase = rnd(2, HD // 2, 2, scale=0.5)
+    H, W = qh * 3 - 1, qw * 3 - 2
+    prep = O.batch_prep(torch.rand(B, 3, h, w), (H, W))
+    coord, cell = prep["coord"], prep["cell"]
+    assert coord.shape[1:3] == (qh, qw)
+    ref = CPU.linf_features(cf, coord, cell, phase.reshape(-1), torch.empty(B, 4 * HD, qh, qw), HD)
+    out = hip.linf_features(hip.to_device(cf), hip.to_device(coord), hip.to_device(cell), hip.vec(phase),
+                            hip.empty(B, 4 * HD, qh, qw), HD)
+    close(out, ref, 5e-6, "linf_features")
+
+
+@pytest.mark.parametrize("D", [27, 3])
+@pytest.mark.parametrize("reverse", [0, 1])
+def test_linf_flow(hip, D, reverse):
+    L, B, qh, qw = 10, 2, 13, 17
+    q = np.stack([np.linalg.qr(np.random.Generator(np.random.PCG64(i)).standard_normal((D, D)))[0] for i in range(L + 1)])
+    Wm = torch.from_numpy(q.astype(np.float32)) * torch.from_numpy(np.random.Generator(np.random.PCG64(5)).uniform(0.8, 1.25, (L + 1, 1, D)).astype(np.float32))
+    Wuse = torch.inverse(Wm.double()).float() if reverse else Wm
+    bb = rnd(3, L + 1, D, scale=0.1)
+    x, ai = rnd(4, B, D, qh, qw), rnd(5, B, 2 * D * L, qh, qw, scale=0.5)
+    ref = CPU.linf_flow(x, ai, torch.empty_like(x), Wuse.reshape(-1), bb.reshape(-1), L, reverse)
+    out = hip.linf_flow(hip.to_device(x), hip.to_device(ai), hip.empty(*x.shape), hip.vec(Wuse), hip.vec(bb), L, reverse)
+    close(out, ref, 1e-5, "linf_flow")
+
+
+def test_fold_unfold_direct_conv(hip):
+    import torch.nn.functional as F
+    p = rnd(6, 2, 27, 5, 7)
+    for H, W in ((15, 21), (13, 19)):
+        ref = CPU.patch_fold(p, torch.empty(2, 3, H, W), 3)
+        assert torch.equal(hip.patch_fold(hip.to_device(p), hip.empty(2, 3, H, W), 3).cpu(), ref)
+        img = rnd(7, 2, 3, H, W)
+        ref = CPU.patch_unfold(img, torch.empty(2, 27, 5, 7), 3)
+        assert torch.equal(hip.patch_unfold(hip.to_device(img), hip.empty(2, 27, 5, 7), 3).cpu(), ref)
+    x, w, b = rnd(8, 2, 3, 16, 23), rnd(9, 27, 3, 3, 3, scale=0.3), rnd(10, 27, scale=0.1)
+    ref = F.leaky_relu(F.conv2d(x, w, b, 3, 1), 0.2)
+    out = hip.conv_direct(hip.to_device(x), hip.to_device(w), hip.vec(b), hip.empty(*ref.shape), 3, 1, act=2, slope=0.2)
+    close(out, ref, 1e-5, "conv_direct")
+
+
+@pytest.mark.parametrize("tag,enc,seed,c", CASES)
+def test_golden_e2e(hip, golden_dir, tag, enc, seed, c):
+    from bfsr_amd.linf.models import make
+    from bfsr_amd.linf.test import infer_from_lr, lp_infer
+    g = np.load(os.path.join(golden_dir, "linf_e2e_%s_%s.npz" % (tag, c)))
+    sd, psd = weights(enc, seed)
+    m = make(mspec(enc), args={"ops": hip}).eval()
+    m.load_state_dict(sd)
+    prior = make({"name": "unet", "args": {"in_chans": 27, "depth": 3, "dim": 64, "bilinear": True}}, args={"ops": hip}).eval()
+    prior.load_state_dict(psd)
+    s, lr = int(g["scale"]), T(g["lr"])
+    H, W = s * lr.shape[2], s * lr.shape[3]
+    batch = dict(inp=lr, coord=T(g["coord"]), cell=T(g["cell"]), gt_lr_up=T(g["gt_lr_up"]))
+    out = lp_infer(m, prior, batch, (H, W), return_all=True)
+    for k in ("z_lr", "z_learned", "pred_raw"):
+        close(out[k], T(g[k]), 1e-4, k)
+    assert (out["pred"].cpu() - T(g["pred"])).abs().max() <= 1e-4
+    assert (infer_from_lr(m, prior, lr, s).cpu() - T(g["pred"])).abs().max() <= 1e-4
+    if "feat" in g.files:
+        close(m("gen_feat", inp=(lr - 0.5) / 0.5), T(g["feat"]), 2e-5, "encoder")
+
+
+def test_vs_oracle_and_roundtrip_bigger(hip):
+    """Fresh input at a larger size (rrdb, x4, 64x48 LR, B=2) vs the oracle + decode(encode(x)) == x."""
+    import oracle.linf_ref as O
+    from bfsr_amd.linf.models import make
+    from bfsr_amd.linf.test import lp_infer
+    sd, psd = weights("rrdb", 2024)
+    m = make(mspec("rrdb"), args={"ops": hip}).eval()
+    m.load_state_dict(sd)
+    prior = make({"name": "unet", "args": {"in_chans": 27, "depth": 3, "dim": 64, "bilinear": True}}, args={"ops": hip}).eval()
+    prior.load_state_dict(psd)
+    lr = synth.smooth_lr_batch(3, 2, 64, 48)
+    H, W = 256, 192
+    prep = O.batch_prep(lr, (H, W))
+    ref = O.lp_pipeline(prep, sd, psd, mspec("rrdb"), (H, W), return_all=True)
+    out = lp_infer(m, prior, prep, (H, W), return_all=True)
+    close(out["z_lr"], ref["z_lr"], 1e-4, "z_lr")
+    assert (out["pred"].cpu() - ref["pred"]).abs().max() <= 1e-4
+    inp = hip.to_device((lr - 0.5) / 0.5)
+    feat = m("gen_feat", inp=inp)
+    coord, cell, gt = (hip.to_device(prep[k]) for k in ("coord", "cell", "gt_lr_up"))
+    z = m("query_log_p", feat=feat, coord=coord, cell=cell, gt=gt)[1]
+    back = hip.patch_unfold(m("query_rgb", feat=feat, coord=coord, cell=cell, zmap=z), hip.empty(*gt.shape), 3)
+    assert (back - gt).abs().max().item() <= 1e-4

@@ -36,6 +36,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8, help="LR crops per GPU")
     ap.add_argument("--lr", type=int, default=160, help="LR crop side")
+    ap.add_argument("--lanes", type=int, default=2, help="sub-batches run concurrently on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-lr", type=int, default=160, help="LR side of the CPU-baseline sample (B=1)")
     return ap.parse_args()
@@ -73,15 +74,16 @@ def main():
 
     # in-situ timing keys: dominant MFMA conv (hoisted level-1 3x3, 320 -> 16*64) and the level-1 inverse tail
     C1 = 12
-    key_conv = ("conv", 3, 2, 320, 16 * 64, B, H // 2, H // 2)
-    key_tail = ("flow", 1, C1, B, H // 2, H // 2, True, True, True)
+    Bl = B // max(1, min(args.lanes, B))          # per-lane sub-batch (launch granularity)
+    key_conv = ("conv", 3, 2, 320, 16 * 64, Bl, H // 2, H // 2)
+    key_tail = ("flow", 1, C1, Bl, H // 2, H // 2, True, True, True)
     gathered = None
 
     def step(i):
         nonlocal gathered
         x = batches[i % n_batches]
         x.add_(0.0)                       # bump the version so the conditioning cache never hits across steps
-        sr = lp_infer(model, prior, x)
+        sr = lp_infer(model, prior, x, lanes=args.lanes)
         if world > 1:
             gathered = bdist.all_gather_batch(sr, total=B * world)
         return sr
@@ -114,8 +116,8 @@ def main():
     conv_ms, conv_n = avg_ms(key_conv)
     tail_ms, tail_n = avg_ms(key_tail)
     hw1 = (H // 2) * (H // 2)
-    conv_flop = 2.0 * 320 * 9 * (16 * 64) * B * hw1                  # algorithmic flops of one launch
-    tail_bytes = 20.0 * C1 * B * hw1                                 # read z,h_aff,h_ft + write z
+    conv_flop = 2.0 * 320 * 9 * (16 * 64) * Bl * hw1                  # algorithmic flops of one launch
+    tail_bytes = 20.0 * C1 * Bl * hw1                                 # read z,h_aff,h_ft + write z
     roofline = None
     if conv_ms:
         a = conv_flop / (conv_ms * 1e-3) / 1e12
@@ -167,7 +169,7 @@ def main():
             "config": {"workload": "SRFlow-LP 4x DF2K config (K=16,L=3,nb=23), batch=%d/GPU %dx%d LR synthetic -> %dx%d, "
                                    "LP path: RRDB + encode + standardise + prior UNet + decode + clamp%s"
                                    % (B, h, h, H, H, ", + RCCL all-gather of outputs" if world > 1 else ""),
-                       "parallelism": "dp%d" % world, "weights": "seeded synthetic (conditioned recipe)"},
+                       "parallelism": "dp%d" % world, "stream_lanes": args.lanes, "weights": "seeded synthetic (conditioned recipe)"},
             "roofline": roofline, "roofline_coupling_inverse": roof_tail, "cpu_baseline": cpu_baseline,
             "parity": parity,
         }

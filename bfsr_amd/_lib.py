@@ -26,6 +26,8 @@ class BfsrConvArgs(C.Structure):
         ("post_scale", C.c_void_p),
         ("res1", C.c_void_p), ("res1_bs", C.c_longlong), ("alpha1", C.c_float),
         ("res2", C.c_void_p), ("res2_bs", C.c_longlong), ("alpha2", C.c_float),
+        ("tune", C.c_int),
+        ("w2", C.c_void_p), ("C2", C.c_int), ("s2_shift", C.c_void_p), ("s2_scale", C.c_void_p), ("act2", C.c_int),
     ]
 
 

@@ -19,12 +19,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-template <int KS> struct ConvCfg { static constexpr int CK = (KS == 3) ? 8 : 16; };
+constexpr int CIN_ALIGN = 16;      // packed weights pad Cin to a multiple of this (any CK in {8,16} divides it)
 
-template <int KS, int MR, int NR>
+template <int KS, int MR, int NR, int CK, bool FUSE2 = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(BfsrConvArgs p, int tiles_x, int tiles_xy, int groups)
 {
-    constexpr int CK = ConvCfg<KS>::CK;
     constexpr int TH = 4 * NR, TW = 32;
     constexpr int HALO = KS - 1;
     constexpr int IH = TH + HALO, PW = TW + HALO;
@@ -53,7 +52,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(BfsrConvArgs p, int t
     const long long cs_in = (long long)(H >> sh) * Ws;   // input channel stride
     const float* __restrict__ xin = p.x + (long long)b * p.x_bs;
     const int Cin = p.Cin;
-    const int cin_pad = (Cin + CK - 1) / CK * CK;
+    const int cin_pad = (Cin + CIN_ALIGN - 1) / CIN_ALIGN * CIN_ALIGN;   // stride of the packed weights
+    const int cin_loop = (Cin + CK - 1) / CK * CK;                       // channels actually walked
     const float* __restrict__ wg = p.w + (long long)cg * cin_pad * TAPS * MW;
 
     // per-thread staging positions (same spatial position for all CK channels)
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(BfsrConvArgs p, int t
     };
     load_chunk(0);
 
-    for (int c0 = 0; c0 < cin_pad; c0 += CK) {
+    for (int c0 = 0; c0 < cin_loop; c0 += CK) {
         __syncthreads();
         // ---- registers -> LDS (input tile zero padded outside the image; weight slab contiguous)
 #pragma unroll
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(BfsrConvArgs p, int t
             if (idx < WCHUNK / 4) reinterpret_cast<float4*>(sW)[idx] = vw[i];
         }
         __syncthreads();
-        if (c0 + CK < cin_pad) load_chunk(c0 + CK);
+        if (c0 + CK < cin_loop) load_chunk(c0 + CK);
         // ---- MFMA stream
 #pragma unroll
         for (int kk = 0; kk < CK / 2; ++kk) {
@@ -143,10 +143,94 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(BfsrConvArgs p, int t
         }
     }
 
-    // ---- epilogue: lane holds pixel column l31 of row (wave*NR+n) and 16 couts per M tile
-    const int gx = x0 + l31;
-    if (gx >= W) return;
     const long long HW = (long long)H * W;
+    const int gx = x0 + l31;
+
+    if constexpr (FUSE2) {
+        // ---- fused second stage: y = act2((W2 . act1(epi1(conv)) + s2_shift) * s2_scale), W2 a 1x1 conv over the MR*32
+        // stage-1 channels of this pixel tile.  The stage-1 tile goes through LDS 32 channels at a time
+        // ([32][4 waves][NR*32 px]), so the hidden tensor never touches HBM.
+        constexpr int MR2 = 2, MW2 = MR2 * 32, NPX = NR * 32;
+        float* sH = smem;                                  // [32][4*NPX]
+        float* sW2 = smem + 32 * 4 * NPX;                  // [MR*32][MW2]
+        __syncthreads();                                   // all waves finished reading the last K-chunk
+        {
+            const float4* __restrict__ src = reinterpret_cast<const float4*>(p.w2);
+            float4* dst = reinterpret_cast<float4*>(sW2);
+            for (int i = tid; i < MR * 32 * MW2 / 4; i += 256) dst[i] = src[i];
+        }
+        f32x16 acc2[MR2][NR];
+#pragma unroll
+        for (int m = 0; m < MR2; ++m)
+#pragma unroll
+            for (int n = 0; n < NR; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[m][n][r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            if (m > 0) __syncthreads();                    // previous 32-channel slab fully consumed
+#pragma unroll
+            for (int n = 0; n < NR; ++n) {
+                const int gy = y0 + wave * NR + n;
+                const bool inb = gy < H && gx < W;
+                const long long pix = (long long)gy * W + gx;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const int co = m * 32 + row;
+                    float v = acc[m][n][r];
+                    if (p.bias) v += p.bias[co];
+                    if (p.pre_add && inb && co < p.Cout) v += p.pre_add[(long long)b * p.pre_add_bs + (long long)co * HW + pix];
+                    if (p.aff_shift) v += p.aff_shift[co];
+                    if (p.aff_scale) v *= p.aff_scale[co];
+                    if (p.aff_post) v += p.aff_post[co];
+                    if (p.act == BFSR_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (p.act == BFSR_ACT_LRELU) v = v > 0.f ? v : v * p.slope;
+                    if (co >= p.Cout) v = 0.f;
+                    sH[row * (4 * NPX) + wave * NPX + n * 32 + l31] = v;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int c = 2 * kk + lhi;
+                float a2[MR2], b2[NR];
+#pragma unroll
+                for (int m2 = 0; m2 < MR2; ++m2) a2[m2] = sW2[(m * 32 + c) * MW2 + m2 * 32 + l31];
+#pragma unroll
+                for (int n = 0; n < NR; ++n) b2[n] = sH[c * (4 * NPX) + wave * NPX + n * 32 + l31];
+#pragma unroll
+                for (int m2 = 0; m2 < MR2; ++m2)
+#pragma unroll
+                    for (int n = 0; n < NR; ++n)
+                        acc2[m2][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[m2], b2[n], acc2[m2][n], 0, 0, 0);
+            }
+        }
+        if (gx >= W) return;
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+            const int gy = y0 + wave * NR + n;
+            if (gy >= H) continue;
+            const long long pix = (long long)gy * W + gx;
+#pragma unroll
+            for (int m2 = 0; m2 < MR2; ++m2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = m2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    if (co >= p.C2) continue;
+                    float v = acc2[m2][n][r];
+                    if (p.s2_shift) v += p.s2_shift[co];
+                    if (p.s2_scale) v *= p.s2_scale[co];
+                    if (p.act2 == BFSR_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (p.act2 == BFSR_ACT_LRELU) v = v > 0.f ? v : v * p.slope;
+                    p.y[(long long)b * p.y_bs + (long long)co * HW + pix] = v;
+                }
+        }
+        return;
+    }
+
+    // ---- epilogue: lane holds pixel column l31 of row (wave*NR+n) and 16 couts per M tile
+    if (gx >= W) return;
     const int Cout = p.Cout;
 #pragma unroll
     for (int n = 0; n < NR; ++n) {
@@ -177,23 +261,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(BfsrConvArgs p, int t
     }
 }
 
-template <int KS, int MR, int NR>
+template <int KS, int MR, int NR, int CK, bool FUSE2 = false>
 int launch_conv(const BfsrConvArgs& a, hipStream_t st)
 {
-    constexpr int CK = ConvCfg<KS>::CK;
     constexpr int TH = 4 * NR, TW = 32, HALO = KS - 1;
-    constexpr int LDS = (CK * KS * KS * MR * 32 + CK * (TH + HALO) * (TW + HALO)) * 4;
+    constexpr int LDS_MAIN = (CK * KS * KS * MR * 32 + CK * (TH + HALO) * (TW + HALO)) * 4;
+    constexpr int LDS_FUSE = FUSE2 ? (32 * 4 * NR * 32 + MR * 32 * 64) * 4 : 0;
+    constexpr int LDS = LDS_MAIN > LDS_FUSE ? LDS_MAIN : LDS_FUSE;
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
     const int groups = ((a.Cout + 31) / 32 + MR - 1) / MR;
     const long long nblk = (long long)tiles_x * tiles_y * groups * a.B;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return -1;
     static bool attr_set = false;
     if (!attr_set && LDS > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<KS, MR, NR>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<KS, MR, NR, CK, FUSE2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<KS, MR, NR>), dim3((unsigned)nblk), dim3(256), LDS, st, a, tiles_x,
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, MR, NR, CK, FUSE2>), dim3((unsigned)nblk), dim3(256), LDS, st, a, tiles_x,
                        tiles_x * tiles_y, groups);
     return (int)hipGetLastError();
 }
@@ -202,8 +287,7 @@ int launch_conv(const BfsrConvArgs& a, hipStream_t st)
 
 extern "C" long long bfsr_conv_packed_size(int Cout, int Cin, int KS, int mtile)
 {
-    const int CK = (KS == 3) ? 8 : 16;
-    const int cin_pad = (Cin + CK - 1) / CK * CK;
+    const int cin_pad = (Cin + CIN_ALIGN - 1) / CIN_ALIGN * CIN_ALIGN;
     const int groups = ((Cout + 31) / 32 + mtile - 1) / mtile;
     return (long long)groups * cin_pad * KS * KS * mtile * 32;
 }
@@ -211,8 +295,7 @@ extern "C" long long bfsr_conv_packed_size(int Cout, int Cin, int KS, int mtile)
 extern "C" int bfsr_pack_conv_weight(const float* w, int Cout, int Cin, int KS, int mtile, float* packed)
 {
     if ((KS != 1 && KS != 3) || mtile < 1) return -1;
-    const int CK = (KS == 3) ? 8 : 16;
-    const int cin_pad = (Cin + CK - 1) / CK * CK;
+    const int cin_pad = (Cin + CIN_ALIGN - 1) / CIN_ALIGN * CIN_ALIGN;
     const int MW = mtile * 32, T = KS * KS;
     const int groups = ((Cout + 31) / 32 + mtile - 1) / mtile;
     const long long n = (long long)groups * cin_pad * T * MW;
@@ -234,23 +317,32 @@ extern "C" int bfsr_conv2d(const BfsrConvArgs* a, void* stream)
     if (a->in_shift < 0 || a->in_shift > 4) return -1;
     if (a->in_shift && (((a->H >> a->in_shift) << a->in_shift) != a->H || ((a->W >> a->in_shift) << a->in_shift) != a->W))
         return -1;
-    // NR (rows per wave): 4 for large images, 2 when the grid would otherwise be too small
-    const long long px = (long long)a->B * a->H * a->W;
-    const bool small = px < 512LL * 512;     // fewer than ~512 tiles of 16x32
-#define BFSR_DISPATCH(KS_, MR_)                                                                  \
-    do {                                                                                         \
-        if (small) return launch_conv<KS_, MR_, 2>(*a, st);                                      \
-        return launch_conv<KS_, MR_, 4>(*a, st);                                                 \
-    } while (0)
-    if (a->KS == 3) {
-        if (a->mtile == 1) BFSR_DISPATCH(3, 1);
-        if (a->mtile == 2) BFSR_DISPATCH(3, 2);
-        if (a->mtile == 3) return launch_conv<3, 3, 2>(*a, st);
-    } else if (a->KS == 1) {
-        if (a->mtile == 1) BFSR_DISPATCH(1, 1);
-        if (a->mtile == 2) BFSR_DISPATCH(1, 2);
-        if (a->mtile == 3) return launch_conv<1, 3, 2>(*a, st);
+    // variant = (NR rows per wave, CK channels per LDS stage).  auto: NR=4 for big grids, NR=2 otherwise;
+    // a->tune = NR*100 + CK overrides (used by tools/conv_bench.py to pick the table below).
+    // auto: 16x32 tiles (NR=4) only when the launch still fills the chip for >= 4 rounds of 2 workgroups/CU
+    // (measured on MI355X, tools/conv_bench.py: hoisted 320->1024 convs gain 6-8 %, everything smaller loses)
+    const long long tiles4 = (long long)((a->W + 31) / 32) * ((a->H + 15) / 16) * a->B;
+    const long long groups_ = ((a->Cout + 31) / 32 + a->mtile - 1) / a->mtile;
+    int NR = (tiles4 * groups_ >= 4 * 512 && a->mtile <= 2) ? 4 : 2, CK = a->KS == 3 ? 8 : 16;
+    if (a->tune > 0) { NR = a->tune / 100; CK = a->tune % 100; }
+    if (a->w2) {
+        // fused 3x3 -> 1x1 (coupling nets: flow.Conv2d 3x3 + ReLU -> flow.Conv2d 1x1 + ReLU); one cout group only
+        if (a->KS != 3 || a->mtile != 2 || a->Cout > 64 || a->C2 > 64 || a->C2 <= 0 || a->res1 || a->res2 || a->post_scale) return -1;
+        return launch_conv<3, 2, 2, 8, true>(*a, st);
     }
-#undef BFSR_DISPATCH
+    const int key = a->KS * 10000 + a->mtile * 1000 + NR * 100 + CK;
+    switch (key) {
+#define V(KS_, MR_, NR_, CK_) case KS_ * 10000 + MR_ * 1000 + NR_ * 100 + CK_: return launch_conv<KS_, MR_, NR_, CK_>(*a, st);
+        V(3, 1, 2, 8) V(3, 1, 4, 8) V(3, 1, 2, 16) V(3, 1, 4, 16)
+        V(3, 2, 2, 8) V(3, 2, 4, 8) V(3, 2, 2, 16)
+        V(3, 3, 2, 8)
+        V(1, 1, 2, 16) V(1, 1, 4, 16) V(1, 2, 2, 16) V(1, 2, 4, 16) V(1, 3, 2, 16)
+#undef V
+        default: break;
+    }
+    if (a->mtile == 3 && a->tune == 0) {     // only NR=2 variants exist for 3 M-tiles
+        if (a->KS == 3) return launch_conv<3, 3, 2, 8>(*a, st);
+        if (a->KS == 1) return launch_conv<1, 3, 2, 16>(*a, st);
+    }
     return -1;
 }

@@ -96,9 +96,16 @@ class HipOps(object):
         return t.detach().reshape(-1).to(device=self.device, dtype=torch.float32).contiguous()
 
     def conv(self, x, pw, out, in_shift=0, bias=None, pre_add=None, aff_shift=None, aff_scale=None,
-             aff_post=None, act=ACT_NONE, slope=0.2, post_scale=None, res1=None, alpha1=1.0, res2=None, alpha2=1.0):
+             aff_post=None, act=ACT_NONE, slope=0.2, post_scale=None, res1=None, alpha1=1.0, res2=None, alpha2=1.0, tune=0, stage2=None):
+        """stage2 = (PackedConv 1x1, shift, scale, act): fused second conv, `out` then has stage2 Cout channels."""
         xp, xbs, Cin, Hs, Ws = _view(x, "conv.x")
         yp, ybs, Cout, H, W = _view(out, "conv.out")
+        c_final = Cout
+        if stage2 is not None:
+            pw2, s2_shift, s2_scale, act2 = stage2
+            if pw2.KS != 1 or pw2.mtile != 2 or pw2.Cin != pw.Cout or pw2.Cout != Cout:
+                raise ValueError("conv: bad fused stage")
+            Cout = pw.Cout
         if Cin != pw.Cin or Cout != pw.Cout or (Hs << in_shift) != H or (Ws << in_shift) != W or x.shape[0] != out.shape[0]:
             raise ValueError("conv: shape mismatch x%s out%s weight(Cout=%d,Cin=%d) in_shift=%d" %
                              (tuple(x.shape), tuple(out.shape), pw.Cout, pw.Cin, in_shift))
@@ -106,6 +113,8 @@ class HipOps(object):
         a.x, a.x_bs, a.Cin = xp, xbs, Cin
         a.w = pw.data.data_ptr()
         a.y, a.y_bs, a.Cout = yp, ybs, Cout
+        if stage2 is not None:
+            a.w2, a.C2, a.s2_shift, a.s2_scale, a.act2 = pw2.data.data_ptr(), c_final, _ptr(s2_shift), _ptr(s2_scale), act2
         a.B, a.H, a.W, a.KS, a.in_shift, a.mtile = out.shape[0], H, W, pw.KS, in_shift, pw.mtile
         a.bias = _ptr(bias)
         if pre_add is not None:
@@ -113,7 +122,7 @@ class HipOps(object):
             assert (c, h, w) == (Cout, H, W)
             a.pre_add, a.pre_add_bs = p, bs
         a.aff_shift, a.aff_scale, a.aff_post = _ptr(aff_shift), _ptr(aff_scale), _ptr(aff_post)
-        a.act, a.slope = act, slope
+        a.act, a.slope, a.tune = act, slope, tune
         a.post_scale = _ptr(post_scale)
         if res1 is not None:
             p, bs, c, h, w = _view(res1, "conv.res1")
@@ -123,7 +132,7 @@ class HipOps(object):
             p, bs, c, h, w = _view(res2, "conv.res2")
             assert (c, h, w) == (Cout, H, W)
             a.res2, a.res2_bs, a.alpha2 = p, bs, alpha2
-        key = ("conv", pw.KS, pw.mtile, Cin, Cout, out.shape[0], H, W)
+        key = ("conv", pw.KS, pw.mtile, Cin, Cout, out.shape[0], H, W) if stage2 is None else ("conv+1x1", Cin, Cout, out.shape[0], H, W)
         _lib.check(self._launch(key, lambda: self.lib.bfsr_conv2d(C.byref(a), self._stream())), "conv2d")
         return out
 

@@ -73,6 +73,13 @@ class RRDBEncoder(object):
         self.trunk_conv = _ConvP(ops, g("trunk_conv.weight"), g("trunk_conv.bias"))
         self.ws = _Workspace(ops)
 
+    def fork(self):
+        """Same packed weights, private scratch: lets several sub-batches run on different HIP streams."""
+        import copy
+        c = copy.copy(self)
+        c.ws = _Workspace(self.ops)
+        return c
+
     def forward(self, x, out, on_block=None):
         """x [B,3,h,w] -> out (a [B,nf,h,w] view) = fea + trunk_conv(fea).  `on_block(idx, fea_view)` is
         called after RRDB idx with a view that is only valid during the call."""
@@ -164,10 +171,10 @@ class SRFlowEngine(object):
                     a = p + "affine.fAffine."
                     w0 = sd[a + "0.weight"]
                     st.aff0_z1 = _ConvP(ops, w0[:, :cn].contiguous(), aff_shift=sd[a + "0.actnorm.bias"],
-                                        aff_scale=torch.exp(sd[a + "0.actnorm.logs"]))
+                                        aff_scale=torch.exp(sd[a + "0.actnorm.logs"]), mtile=2)
                     st.aff0_ft_w = w0[:, cn:].contiguous()                     # hoisted (batched per level)
                     st.aff2 = _ConvP(ops, sd[a + "2.weight"], aff_shift=sd[a + "2.actnorm.bias"],
-                                     aff_scale=torch.exp(sd[a + "2.actnorm.logs"]))
+                                     aff_scale=torch.exp(sd[a + "2.actnorm.logs"]), mtile=2)
                     st.aff4 = _ConvP(ops, sd[a + "4.weight"], bias=sd[a + "4.bias"],
                                      post_scale=torch.exp(sd[a + "4.logs"] * 3))
                     f = p + "affine.fFeatures."
@@ -197,6 +204,15 @@ class SRFlowEngine(object):
                                      aff0=_ConvP(ops, wa, mtile=2))
             for i in idxs:
                 del self.steps[i].ft0_w, self.steps[i].aff0_ft_w
+
+    def fork(self):
+        """A lane: shares every packed weight with `self`, owns its scratch buffers and conditioning cache."""
+        import copy
+        c = copy.copy(self)
+        c.ws = _Workspace(self.ops)
+        c.rrdb = self.rrdb.fork()
+        c._cond_key, c._cond = None, None
+        return c
 
     # ------------------------------------------------------------------------------------------
     def _level_hw(self, level, h, w):
@@ -272,8 +288,9 @@ class SRFlowEngine(object):
         cn = C // 2
         hid = ws.get("hid_%s" % tag, B, 64, H, W)
         h_aff = ws.get("haff_%s_%d" % (tag, k & 1), B, 2 * (C - cn), H, W)
-        st.aff0_z1.run(ops, z[:, :cn], hid, pre_add=cnd["pre_aff"][:, 64 * k: 64 * (k + 1)], act=ACT_RELU)
-        st.aff2.run(ops, hid, hid, act=ACT_RELU)
+        # 3x3 on z1 (+ hoisted ft partial, ActNorm, ReLU) with the 1x1 (+ActNorm, ReLU) fused as a second MFMA stage
+        st.aff0_z1.run(ops, z[:, :cn], hid, pre_add=cnd["pre_aff"][:, 64 * k: 64 * (k + 1)], act=ACT_RELU,
+                       stage2=(st.aff2.pw, st.aff2.aff_shift, st.aff2.aff_scale, ACT_RELU))
         st.aff4.run(ops, hid, h_aff)
         return h_aff
 

@@ -43,8 +43,43 @@ def pad_lr_to_even(lr):
     return np.pad(lr, [(0, int(np.ceil(h / 2) * 2 - h)), (0, int(np.ceil(w / 2) * 2 - w)), (0, 0)], 'reflect')
 
 
-def lp_infer(model, prior_model, lr_t, return_all=False):
-    """lr_t [B,3,h,w] in [0,1] (h, w even) -> sr [B,3,s*h,s*w] clamped to [0,1]."""
+def _lp_lane(eng, prior_eng, lr, scale, sr_out, keep=None):
+    """The LP block (test.py:126-151) for one sub-batch on the current stream; writes clamp(sr) into sr_out."""
+    ops = eng.ops
+    B, _, h, w = lr.shape
+    lr_up = eng.ws.get("lr_up", B, 3, h * scale, w * scale)
+    ops.resize(lr, lr_up, MODE_BILINEAR, 1.0 / scale, 1.0 / scale)               # test.py:137
+    epses_lr = eng.encode(lr_up, lr)                                             # test.py:139 (add_gt_noise=False)
+    epses = [ops.standardize(e, ops.empty(*e.shape)) for e in epses_lr]          # test.py:141-145
+    epses_learned = prior_eng.forward(epses)                                     # test.py:147
+    sr_raw = eng.decode(lr, epses=epses_learned)                                 # test.py:148
+    ops.axpb_clamp(sr_raw, sr_out, 1.0, 0.0, 0.0, 1.0)                           # test.py:150
+    if keep is not None:
+        keep.update(lr_up=lr_up, epses=epses_lr, epses_norm=epses, epses_learned=epses_learned, sr_raw=sr_raw, sr=sr_out)
+
+
+_LANES = {}
+
+
+def _lanes(net, prior_model, n):
+    """n engine lanes (lane 0 = the model's own engines) with one side stream each."""
+    key = (id(net.engine()), id(prior_model.engine()), n)
+    if key not in _LANES:
+        e0, p0 = net.engine(), prior_model.engine()
+        engs = [e0] + [e0.fork() for _ in range(n - 1)]
+        pris = [p0] + [p0.fork() for _ in range(n - 1)]
+        streams = [torch.cuda.Stream(device=e0.ops.device) for _ in range(n)]
+        _LANES.clear()
+        _LANES[key] = (engs, pris, streams)
+    return _LANES[key]
+
+
+def lp_infer(model, prior_model, lr_t, return_all=False, lanes=1):
+    """lr_t [B,3,h,w] in [0,1] (h, w even) -> sr [B,3,s*h,s*w] clamped to [0,1].
+
+    lanes > 1 splits the batch into that many sub-batches and runs them on separate HIP streams (every op is
+    per-sample, so results are unchanged): kernels of one sub-batch fill the CUs left idle by the tail of the
+    other's, which removes most of the wave-quantisation loss of the small sequential launches."""
     net = model.netG.module
     eng = net.engine()
     ops = eng.ops
@@ -52,16 +87,22 @@ def lp_infer(model, prior_model, lr_t, return_all=False):
     with torch.no_grad():
         lr = ops.to_device(lr_t)
         B, _, h, w = lr.shape
-        lr_up = ops.empty(B, 3, h * scale, w * scale)
-        ops.resize(lr, lr_up, MODE_BILINEAR, 1.0 / scale, 1.0 / scale)           # test.py:137
-        epses_lr = []
-        model.get_encode_z(lr, lr_up, epses=epses_lr, add_gt_noise=False)        # test.py:139
-        epses = [ops.standardize(e, ops.empty(*e.shape)) for e in epses_lr]      # test.py:141-145
-        epses_learned = prior_model(epses)                                       # test.py:147
-        sr_raw = model.get_sr(lq=lr, epses=epses_learned)                        # test.py:148
-        sr = ops.axpb_clamp(sr_raw, ops.empty(*sr_raw.shape), 1.0, 0.0, 0.0, 1.0)  # test.py:150
-    if return_all:
-        return dict(lr_up=lr_up, epses=epses_lr, epses_norm=epses, epses_learned=epses_learned, sr_raw=sr_raw, sr=sr)
+        sr = ops.empty(B, 3, h * scale, w * scale)
+        lanes = max(1, min(lanes, B))
+        if lanes == 1 or return_all:
+            keep = {} if return_all else None
+            _lp_lane(eng, prior_model.engine(), lr, scale, sr, keep)
+            return keep if return_all else sr
+        from ..dist import shard_bounds
+        engs, pris, streams = _lanes(net, prior_model, lanes)
+        main = torch.cuda.current_stream(ops.device)
+        for i in range(lanes):
+            lo, hi = shard_bounds(B, i, lanes)
+            streams[i].wait_stream(main)
+            with torch.cuda.stream(streams[i]):
+                _lp_lane(engs[i], pris[i], lr[lo:hi], scale, sr[lo:hi])
+        for st in streams:
+            main.wait_stream(st)
     return sr
 
 

@@ -57,6 +57,12 @@ typedef struct BfsrConvArgs {
     const float* post_scale;
     const float* res1; long long res1_bs; float alpha1;
     const float* res2; long long res2_bs; float alpha2;
+    int tune;                        /* 0 = auto; NR*100+CK forces a kernel variant (benchmarking) */
+    /* optional fused second stage (w2 != NULL): a 1x1 conv over the <= 64 stage-1 channels applied in the same
+     * kernel; y then has C2 <= 64 channels: y = act2((W2 . stage1 + s2_shift) * s2_scale).  w2 is packed with
+     * bfsr_pack_conv_weight(KS=1, mtile=2).  Stage 1 keeps bias / pre_add / aff_* / act. */
+    const float* w2; int C2;
+    const float* s2_shift; const float* s2_scale; int act2;
 } BfsrConvArgs;
 
 int bfsr_abi_version(void);

@@ -43,7 +43,7 @@ class CpuOps(object):
         return PackedConv(w, mtile)
 
     def conv(self, x, pw, out, in_shift=0, bias=None, pre_add=None, aff_shift=None, aff_scale=None, aff_post=None,
-             act=ACT_NONE, slope=0.2, post_scale=None, res1=None, alpha1=1.0, res2=None, alpha2=1.0):
+             act=ACT_NONE, slope=0.2, post_scale=None, res1=None, alpha1=1.0, res2=None, alpha2=1.0, tune=0, stage2=None):
         xin = x
         if in_shift:
             xin = F.interpolate(x, scale_factor=1 << in_shift, mode="nearest")
@@ -69,6 +69,14 @@ class CpuOps(object):
             v = alpha1 * v + res1
         if res2 is not None:
             v = alpha2 * v + res2
+        if stage2 is not None:
+            pw2, s2_shift, s2_scale, act2 = stage2
+            v = F.conv2d(v, pw2.w)
+            if s2_shift is not None:
+                v = v + _cv(s2_shift)
+            if s2_scale is not None:
+                v = v * _cv(s2_scale)
+            v = F.relu(v) if act2 == ACT_RELU else (F.leaky_relu(v, slope) if act2 == ACT_LRELU else v)
         out.copy_(v)
         return out
 

@@ -203,3 +203,20 @@ def test_resize_padded_window_maxpool_clamp(hip):
     r = rnd(82, 2, 3, 9, 11)
     ref = torch.clamp(0.5 * y + 0.5 + r, 0, 1)
     close(hip.axpb_clamp(hip.to_device(y), hip.empty(2, 3, 9, 11), 0.5, 0.5, 0.0, 1.0, r=hip.to_device(r)), ref, 1e-7, "axpb")
+
+
+@pytest.mark.parametrize("case", [(2, 6, 64, 64, 40, 70), (1, 48, 64, 64, 19, 33), (1, 12, 64, 64, 64, 64), (1, 70, 50, 40, 9, 31)])
+def test_conv_fused_1x1_second_stage(hip, case):
+    """3x3 conv (+pre_add, ActNorm affine, ReLU) with the following 1x1 conv (+affine, ReLU) fused in-kernel."""
+    B, Cin, Cmid, C2, H, W = case
+    x, w = rnd(90, B, Cin, H, W), rnd(91, Cmid, Cin, 3, 3, scale=0.1)
+    w2 = rnd(92, C2, Cmid, 1, 1, scale=0.15)
+    pre = rnd(93, B, Cmid, H, W)
+    sh1, sc1 = rnd(94, Cmid, scale=0.2), torch.exp(rnd(95, Cmid, scale=0.2))
+    sh2, sc2 = rnd(96, C2, scale=0.2), torch.exp(rnd(97, C2, scale=0.2))
+    ref = CPU.conv(x, CPU.pack_conv(w, 2), torch.empty(B, C2, H, W), pre_add=pre, aff_shift=sh1, aff_scale=sc1, act=1,
+                   stage2=(CPU.pack_conv(w2, 2), sh2, sc2, 1))
+    out = hip.conv(hip.to_device(x), hip.pack_conv(w, 2), hip.empty(B, C2, H, W), pre_add=hip.to_device(pre),
+                   aff_shift=hip.vec(sh1), aff_scale=hip.vec(sc1), act=1,
+                   stage2=(hip.pack_conv(w2, 2), hip.vec(sh2), hip.vec(sc2), 1))
+    close(out, ref, 2e-5, "fused 3x3+1x1 %s" % (case,))

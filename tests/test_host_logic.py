@@ -110,7 +110,7 @@ def test_weight_packing_layout():
     P = packed.view(groups, cin_pad, 9, 64)
     for co, ci, t in ((0, 0, 0), (69, 12, 8), (64, 3, 4), (33, 7, 2)):
         assert P[co // 64, ci, t, co % 64] == w[co, ci, t // 3, t % 3]
-    assert float(P[1, :, :, 6:].abs().sum()) == 0 and float(P[:, 13:].abs().sum()) == 0
+    assert float(P[1, :, :, 6:].abs().sum()) == 0 and float(P[:, 13:].abs().sum()) == 0     # zero padding
     assert lib.bfsr_pack_conv_weight(w.data_ptr(), Cout, Cin, 5, mt, packed.data_ptr()) != 0     # unsupported KS
 
 

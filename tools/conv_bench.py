@@ -1,0 +1,65 @@
+"""GPU micro-benchmark of bfsr_conv2d variants (tune = NR*100+CK) on the shapes of the bench workload.
+Usage (GPU box): python tools/conv_bench.py [--quick]   -> table of us / TFLOP/s per (shape, variant)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bfsr_amd.ops import HipOps  # noqa: E402
+
+SHAPES = [
+    # name, B, Cin, Cout, H, W, KS, mtile
+    ("rdb.conv1 64->32 @160", 8, 64, 32, 160, 160, 3, 1),
+    ("rdb.conv4 160->32 @160", 8, 160, 32, 160, 160, 3, 1),
+    ("rdb.conv5 192->64 @160", 8, 192, 64, 160, 160, 3, 2),
+    ("hoist L1 320->1024 @320", 8, 320, 1024, 320, 320, 3, 2),
+    ("hoist L2 320->1024 @160", 8, 320, 1024, 160, 160, 3, 2),
+    ("hoist L3 320->1024 @80", 8, 320, 1024, 80, 80, 3, 2),
+    ("L1 convA 6->64 @320", 8, 6, 64, 320, 320, 3, 2),
+    ("L1 1x1 64->64 @320", 8, 64, 64, 320, 320, 1, 2),
+    ("L1 convC 64->12 @320", 8, 64, 12, 320, 320, 3, 1),
+    ("L3 convA 48->64 @80", 8, 48, 64, 80, 80, 3, 2),
+    ("L3 convC 64->96 @80", 8, 64, 96, 80, 80, 3, 3),
+    ("unet 64->64 @320", 8, 64, 64, 320, 320, 3, 2),
+    ("unet 128->128 @160", 8, 128, 128, 160, 160, 3, 2),
+    ("unet 256->256 @40", 8, 256, 256, 40, 40, 3, 2),
+]
+TUNES = [0, 208, 408, 216, 416]
+
+
+def main():
+    ops = HipOps("cuda:0")
+    quick = "--quick" in sys.argv
+    for name, B, Cin, Cout, H, W, KS, mt in SHAPES:
+        x = torch.randn(B, Cin, H, W, device="cuda")
+        w = torch.randn(Cout, Cin, KS, KS) * 0.05
+        pw = ops.pack_conv(w, mt)
+        y = ops.empty(B, Cout, H, W)
+        flop = 2.0 * Cin * KS * KS * Cout * B * H * W
+        row = []
+        for t in TUNES:
+            if KS == 1 and t % 100 == 8:
+                row.append("   -   ")
+                continue
+            try:
+                ops.conv(x, pw, y, tune=t)
+                torch.cuda.synchronize()
+            except RuntimeError:
+                row.append("  n/a  ")
+                continue
+            n = 3 if quick else 10
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(n):
+                ops.conv(x, pw, y, tune=t)
+            e.record()
+            torch.cuda.synchronize()
+            us = s.elapsed_time(e) / n * 1e3
+            row.append("%7.0fus %5.1fTF" % (us, flop / us / 1e6))
+        print("%-26s | %s" % (name, " | ".join(row)), flush=True)
+    print("tunes:", TUNES)
+
+
+if __name__ == "__main__":
+    main()

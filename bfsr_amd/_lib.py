@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbfsr_hip.so")
+LIB_PATH = os.environ.get("BFSR_HIP_LIB") or os.path.join(_HERE, "lib", "libbfsr_hip.so")
 
 c_float_p = C.POINTER(C.c_float)
 

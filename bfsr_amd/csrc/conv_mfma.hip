@@ -56,16 +56,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(BfsrConvArgs p, int t
     const int cin_loop = (Cin + CK - 1) / CK * CK;                       // channels actually walked
     const float* __restrict__ wg = p.w + (long long)cg * cin_pad * TAPS * MW;
 
-    // per-thread staging positions (same spatial position for all CK channels)
-    int soff[PPT];
+    // Staging uses raw buffer loads (one instruction each: VGPR byte offset + SGPR channel offset, no address
+    // arithmetic in the loop).  The descriptor's range check returns 0 beyond `num_records`, which implements both
+    // the conv zero padding (out-of-image positions get an out-of-range offset) and the channel padding to CK.
+    const unsigned in_bytes = (unsigned)((long long)Cin * cs_in * 4);
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wg), 0,
+                                                                          (unsigned)(cin_pad * TAPS * MW * 4), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;            // > any valid offset (views are < 2 GiB), no 32-bit wrap
+    unsigned voff[PPT];
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
         const int pos = tid + i * 256;
         const int r = pos / PW, c = pos - r * PW;
         const int gy = y0 + r - HALO / 2, gx = x0 + c - HALO / 2;
         const bool ok = (pos < NPOS) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        soff[i] = ok ? ((gy >> sh) * Ws + (gx >> sh)) : -1;
+        voff[i] = ok ? (unsigned)((gy >> sh) * Ws + (gx >> sh)) * 4u : OOB;
     }
+    const unsigned cs_bytes = (unsigned)(cs_in * 4);
 
     f32x16 acc[MR][NR];
 #pragma unroll
@@ -80,21 +88,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(BfsrConvArgs p, int t
     float vin[PPT][CK];
     float4 vw[WV];
     auto load_chunk = [&](int c0) {
+        const unsigned sbase = (unsigned)c0 * cs_bytes;
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            const int so = soff[i] < 0 ? 0 : soff[i];      // always a valid address; masked at the LDS write
+        for (int c = 0; c < CK; ++c) {
+            const unsigned so = sbase + (unsigned)c * cs_bytes;
 #pragma unroll
-            for (int c = 0; c < CK; ++c) {
-                int ch = c0 + c; ch = ch < Cin ? ch : Cin - 1;
-                vin[i][c] = xin[(long long)ch * cs_in + so];
-            }
+            for (int i = 0; i < PPT; ++i)
+                vin[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff[i], so, 0));
         }
-        const float4* __restrict__ src = reinterpret_cast<const float4*>(wg + (long long)c0 * TAPS * MW);
+        const unsigned wbase = (unsigned)c0 * (TAPS * MW * 4);
 #pragma unroll
-        for (int i = 0; i < WV; ++i) {
-            int idx = tid + i * 256; idx = idx < WCHUNK / 4 ? idx : WCHUNK / 4 - 1;
-            vw[i] = src[idx];
-        }
+        for (int i = 0; i < WV; ++i)
+            vw[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(tid + i * 256) * 16u, wbase, 0));
     };
     load_chunk(0);
 
@@ -104,16 +109,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(BfsrConvArgs p, int t
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
             const int pos = tid + i * 256;
-            if (pos < NPOS) {
-                const bool ok = soff[i] >= 0;
+            if (i < PPT - 1 || pos < NPOS) {
 #pragma unroll
-                for (int c = 0; c < CK; ++c) sIn[c * NPOS + pos] = ok ? vin[i][c] : 0.f;
+                for (int c = 0; c < CK; ++c) sIn[c * NPOS + pos] = vin[i][c];
             }
         }
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
             const int idx = tid + i * 256;
-            if (idx < WCHUNK / 4) reinterpret_cast<float4*>(sW)[idx] = vw[i];
+            if (i < WV - 1 || idx < WCHUNK / 4) reinterpret_cast<float4*>(sW)[idx] = vw[i];
         }
         __syncthreads();
         if (c0 + CK < cin_loop) load_chunk(c0 + CK);
@@ -315,6 +319,7 @@ extern "C" int bfsr_conv2d(const BfsrConvArgs* a, void* stream)
     if (!a || !a->x || !a->w || !a->y) return -1;
     if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cin <= 0 || a->Cout <= 0) return -1;
     if (a->in_shift < 0 || a->in_shift > 4) return -1;
+    if ((long long)a->Cin * (a->H >> a->in_shift) * (a->W >> a->in_shift) * 4 >= (1LL << 31)) return -1;   // buffer offsets
     if (a->in_shift && (((a->H >> a->in_shift) << a->in_shift) != a->H || ((a->W >> a->in_shift) << a->in_shift) != a->W))
         return -1;
     // variant = (NR rows per wave, CK channels per LDS stage).  auto: NR=4 for big grids, NR=2 otherwise;

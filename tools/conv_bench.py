@@ -11,7 +11,21 @@ from bfsr_amd.ops import HipOps  # noqa: E402
 SHAPES = [
     # name, B, Cin, Cout, H, W, KS, mtile
     ("rdb.conv1 64->32 @160", 8, 64, 32, 160, 160, 3, 1),
+    ("rdb.conv1 B16", 16, 64, 32, 160, 160, 3, 1),
+    ("rdb.conv1 B32", 32, 64, 32, 160, 160, 3, 1),
+    ("rdb.conv1 B64", 64, 64, 32, 160, 160, 3, 1),
+    ("rdb.conv1 B2", 2, 64, 32, 160, 160, 3, 1),
+    ("lat Cin8 B2", 2, 8, 32, 160, 160, 3, 1),
+    ("lat Cin16 B2", 2, 16, 32, 160, 160, 3, 1),
+    ("lat Cin128 B2", 2, 128, 32, 160, 160, 3, 1),
+    ("lat Cin256 B2", 2, 256, 32, 160, 160, 3, 1),
+    ("lat Cin8 B8", 8, 8, 32, 160, 160, 3, 1),
+    ("lat Cin256 B8", 8, 256, 32, 160, 160, 3, 1),
+    ("lat Cin8 1WG", 1, 8, 32, 8, 32, 3, 1),
+    ("lat Cin256 1WG", 1, 256, 32, 8, 32, 3, 1),
     ("rdb.conv4 160->32 @160", 8, 160, 32, 160, 160, 3, 1),
+    ("rdb.conv4 B32", 32, 160, 32, 160, 160, 3, 1),
+    ("rdb.conv5 B32", 32, 192, 64, 160, 160, 3, 2),
     ("rdb.conv5 192->64 @160", 8, 192, 64, 160, 160, 3, 2),
     ("hoist L1 320->1024 @320", 8, 320, 1024, 320, 320, 3, 2),
     ("hoist L2 320->1024 @160", 8, 320, 1024, 160, 160, 3, 2),
@@ -31,14 +45,18 @@ TUNES = [0, 208, 408, 216, 416]
 def main():
     ops = HipOps("cuda:0")
     quick = "--quick" in sys.argv
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
+    tunes = [int(t) for a in sys.argv if a.startswith("--tunes=") for t in a.split("=", 1)[1].split(",")] or TUNES
     for name, B, Cin, Cout, H, W, KS, mt in SHAPES:
+        if only and not any(o in name for o in only):
+            continue
         x = torch.randn(B, Cin, H, W, device="cuda")
         w = torch.randn(Cout, Cin, KS, KS) * 0.05
         pw = ops.pack_conv(w, mt)
         y = ops.empty(B, Cout, H, W)
         flop = 2.0 * Cin * KS * KS * Cout * B * H * W
         row = []
-        for t in TUNES:
+        for t in tunes:
             if KS == 1 and t % 100 == 8:
                 row.append("   -   ")
                 continue

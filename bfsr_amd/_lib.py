@@ -19,15 +19,13 @@ class BfsrConvArgs(C.Structure):
         ("y", C.c_void_p), ("y_bs", C.c_longlong), ("Cout", C.c_int),
         ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("KS", C.c_int), ("in_shift", C.c_int),
         ("mtile", C.c_int),
-        ("bias", C.c_void_p),
+        ("epi", C.c_void_p),
         ("pre_add", C.c_void_p), ("pre_add_bs", C.c_longlong),
-        ("aff_shift", C.c_void_p), ("aff_scale", C.c_void_p), ("aff_post", C.c_void_p),
         ("act", C.c_int), ("slope", C.c_float),
-        ("post_scale", C.c_void_p),
         ("res1", C.c_void_p), ("res1_bs", C.c_longlong), ("alpha1", C.c_float),
         ("res2", C.c_void_p), ("res2_bs", C.c_longlong), ("alpha2", C.c_float),
         ("tune", C.c_int),
-        ("w2", C.c_void_p), ("C2", C.c_int), ("s2_shift", C.c_void_p), ("s2_scale", C.c_void_p), ("act2", C.c_int),
+        ("w2", C.c_void_p), ("C2", C.c_int), ("epi2", C.c_void_p), ("act2", C.c_int),
     ]
 
 

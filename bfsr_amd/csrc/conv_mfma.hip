@@ -13,6 +13,7 @@
 // ([CK][TH+2][34]) and the weight slab ([CK][taps][MR*32]); two workgroups per CU overlap one
 // group's staging with the other's MFMA stream.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "../../include/bfsr_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -149,6 +150,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(BfsrConvArgs p, int t
 
     const long long HW = (long long)H * W;
     const int gx = x0 + l31;
+    const bool col_ok = gx < W;
+    // Epilogue parameters are packed per output channel as 8 floats {bias, aff_shift, aff_scale, aff_post, post_scale}
+    // with neutral defaults, so the element math is branch-free:
+    //   v = ((acc + bias + pre_add) + aff_shift) * aff_scale + aff_post ; v = v > 0 ? v : v*slope ; v *= post_scale ;
+    //   v = alpha1*v + res1 ; v = alpha2*v + res2
+    // (slope 1 = no activation, 0 = ReLU).  Optional tensors are fetched with range-checked buffer loads: a missing
+    // tensor gets an empty descriptor and reads as 0, an out-of-image pixel gets an out-of-range offset.
+    const float slope = p.act == BFSR_ACT_NONE ? 1.f : (p.act == BFSR_ACT_RELU ? 0.f : p.slope);
+    const float4* __restrict__ epi = reinterpret_cast<const float4*>(p.epi);
+    auto chan_params = [&](const float4* __restrict__ e, int co, float4& q0, float& q1) {
+        if (e) { q0 = e[co * 2]; q1 = e[co * 2 + 1].x; }
+        else { q0 = make_float4(0.f, 0.f, 1.f, 0.f); q1 = 1.f; }
+    };
+    const unsigned out_bytes = (unsigned)((long long)p.Cout * HW * 4);
+    auto tensor_rsrc = [&](const float* t, long long bs) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(t ? t + (long long)b * bs : p.y), 0, t ? out_bytes : 0u,
+                                                 0x00020000);
+    };
 
     if constexpr (FUSE2) {
         // ---- fused second stage: y = act2((W2 . act1(epi1(conv)) + s2_shift) * s2_scale), W2 a 1x1 conv over the MR*32
@@ -163,6 +182,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(BfsrConvArgs p, int t
             float4* dst = reinterpret_cast<float4*>(sW2);
             for (int i = tid; i < MR * 32 * MW2 / 4; i += 256) dst[i] = src[i];
         }
+        const __amdgpu_buffer_rsrc_t rs_pre = tensor_rsrc(p.pre_add, p.pre_add_bs);
+        unsigned pixoff[NR];
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+            const int gy = y0 + wave * NR + n;
+            pixoff[n] = (col_ok && gy < H) ? (unsigned)(gy * W + gx) * 4u : OOB;
+        }
         f32x16 acc2[MR2][NR];
 #pragma unroll
         for (int m = 0; m < MR2; ++m)
@@ -173,23 +199,27 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(BfsrConvArgs p, int t
 #pragma unroll
         for (int m = 0; m < MR; ++m) {
             if (m > 0) __syncthreads();                    // previous 32-channel slab fully consumed
+            float pre[NR][16];
 #pragma unroll
-            for (int n = 0; n < NR; ++n) {
-                const int gy = y0 + wave * NR + n;
-                const bool inb = gy < H && gx < W;
-                const long long pix = (long long)gy * W + gx;
+            for (int r = 0; r < 16; ++r) {
+                const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const unsigned cbase = (unsigned)co * (unsigned)(HW * 4);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    const int co = m * 32 + row;
+                for (int n = 0; n < NR; ++n)
+                    pre[n][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                              rs_pre, co < p.Cout ? pixoff[n] + cbase : OOB, 0, 0));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const int co = m * 32 + row;
+                float4 q0; float q1;
+                chan_params(epi, co < p.Cout ? co : 0, q0, q1);
+#pragma unroll
+                for (int n = 0; n < NR; ++n) {
                     float v = acc[m][n][r];
-                    if (p.bias) v += p.bias[co];
-                    if (p.pre_add && inb && co < p.Cout) v += p.pre_add[(long long)b * p.pre_add_bs + (long long)co * HW + pix];
-                    if (p.aff_shift) v += p.aff_shift[co];
-                    if (p.aff_scale) v *= p.aff_scale[co];
-                    if (p.aff_post) v += p.aff_post[co];
-                    if (p.act == BFSR_ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (p.act == BFSR_ACT_LRELU) v = v > 0.f ? v : v * p.slope;
+                    v += q0.x; v += pre[n][r]; v += q0.y; v *= q0.z; v += q0.w;
+                    v = v > 0.f ? v : v * slope;
                     if (co >= p.Cout) v = 0.f;
                     sH[row * (4 * NPX) + wave * NPX + n * 32 + l31] = v;
                 }
@@ -210,59 +240,72 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(BfsrConvArgs p, int t
                         acc2[m2][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[m2], b2[n], acc2[m2][n], 0, 0, 0);
             }
         }
-        if (gx >= W) return;
+        if (!col_ok) return;
+        const float slope2 = p.act2 == BFSR_ACT_NONE ? 1.f : (p.act2 == BFSR_ACT_RELU ? 0.f : p.slope);
+        const float4* __restrict__ epi2 = reinterpret_cast<const float4*>(p.epi2);
 #pragma unroll
-        for (int n = 0; n < NR; ++n) {
-            const int gy = y0 + wave * NR + n;
-            if (gy >= H) continue;
-            const long long pix = (long long)gy * W + gx;
+        for (int m2 = 0; m2 < MR2; ++m2)
 #pragma unroll
-            for (int m2 = 0; m2 < MR2; ++m2)
+            for (int r = 0; r < 16; ++r) {
+                const int co = m2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (co >= p.C2) continue;
+                float4 q0; float q1;
+                chan_params(epi2, co, q0, q1);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = m2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    if (co >= p.C2) continue;
+                for (int n = 0; n < NR; ++n) {
+                    const int gy = y0 + wave * NR + n;
+                    if (gy >= H) continue;
                     float v = acc2[m2][n][r];
-                    if (p.s2_shift) v += p.s2_shift[co];
-                    if (p.s2_scale) v *= p.s2_scale[co];
-                    if (p.act2 == BFSR_ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (p.act2 == BFSR_ACT_LRELU) v = v > 0.f ? v : v * p.slope;
-                    p.y[(long long)b * p.y_bs + (long long)co * HW + pix] = v;
+                    v += q0.x; v += q0.y; v *= q0.z; v += q0.w;
+                    v = v > 0.f ? v : v * slope2;
+                    v *= q1;
+                    p.y[(long long)b * p.y_bs + (long long)co * HW + (long long)gy * W + gx] = v;
                 }
-        }
+            }
         return;
     }
 
-    // ---- epilogue: lane holds pixel column l31 of row (wave*NR+n) and 16 couts per M tile
-    if (gx >= W) return;
+    // ---- epilogue: lane holds pixel column l31 of rows (wave*NR+n) and 16 couts per M tile
+    if (!col_ok) return;
     const int Cout = p.Cout;
-#pragma unroll
-    for (int n = 0; n < NR; ++n) {
-        const int gy = y0 + wave * NR + n;
-        if (gy >= H) continue;
-        const long long pix = (long long)gy * W + gx;
+    const bool tensors = p.pre_add || p.res1 || p.res2;
+    auto run_epilogue = [&](auto with_tensors) {
+        constexpr bool T = decltype(with_tensors)::value;
+        const __amdgpu_buffer_rsrc_t rs_pre = tensor_rsrc(p.pre_add, p.pre_add_bs);
+        const __amdgpu_buffer_rsrc_t rs_r1 = tensor_rsrc(p.res1, p.res1_bs);
+        const __amdgpu_buffer_rsrc_t rs_r2 = tensor_rsrc(p.res2, p.res2_bs);
+        const float a1 = p.res1 ? p.alpha1 : 1.f, a2 = p.res2 ? p.alpha2 : 1.f;
 #pragma unroll
         for (int m = 0; m < MR; ++m) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = (cg * MR + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 if (co >= Cout) continue;
-                float v = acc[m][n][r];
-                const long long o = (long long)co * HW + pix;
-                if (p.bias) v += p.bias[co];
-                if (p.pre_add) v += p.pre_add[(long long)b * p.pre_add_bs + o];
-                if (p.aff_shift) v += p.aff_shift[co];
-                if (p.aff_scale) v *= p.aff_scale[co];
-                if (p.aff_post) v += p.aff_post[co];
-                if (p.act == BFSR_ACT_RELU) v = fmaxf(v, 0.f);
-                else if (p.act == BFSR_ACT_LRELU) v = v > 0.f ? v : v * p.slope;
-                if (p.post_scale) v *= p.post_scale[co];
-                if (p.res1) v = p.alpha1 * v + p.res1[(long long)b * p.res1_bs + o];
-                if (p.res2) v = p.alpha2 * v + p.res2[(long long)b * p.res2_bs + o];
-                p.y[(long long)b * p.y_bs + o] = v;
+                float4 q0; float q1;
+                chan_params(epi, co, q0, q1);
+                const long long cbase = (long long)co * HW;
+#pragma unroll
+                for (int n = 0; n < NR; ++n) {
+                    const int gy = y0 + wave * NR + n;
+                    if (gy >= H) continue;
+                    const long long o = cbase + (long long)gy * W + gx;
+                    float v = acc[m][n][r];
+                    v += q0.x;
+                    if constexpr (T) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_pre, (unsigned)o * 4u, 0, 0));
+                    v += q0.y; v *= q0.z; v += q0.w;
+                    v = v > 0.f ? v : v * slope;
+                    v *= q1;
+                    if constexpr (T) {
+                        v = a1 * v + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r1, (unsigned)o * 4u, 0, 0));
+                        v = a2 * v + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r2, (unsigned)o * 4u, 0, 0));
+                    }
+                    p.y[(long long)b * p.y_bs + o] = v;
+                }
             }
         }
-    }
+    };
+    if (tensors) run_epilogue(std::true_type{});
+    else run_epilogue(std::false_type{});
 }
 
 template <int KS, int MR, int NR, int CK, bool FUSE2 = false>
@@ -320,6 +363,7 @@ extern "C" int bfsr_conv2d(const BfsrConvArgs* a, void* stream)
     if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cin <= 0 || a->Cout <= 0) return -1;
     if (a->in_shift < 0 || a->in_shift > 4) return -1;
     if ((long long)a->Cin * (a->H >> a->in_shift) * (a->W >> a->in_shift) * 4 >= (1LL << 31)) return -1;   // buffer offsets
+    if ((long long)a->Cout * a->H * a->W * 4 >= (1LL << 31)) return -1;
     if (a->in_shift && (((a->H >> a->in_shift) << a->in_shift) != a->H || ((a->W >> a->in_shift) << a->in_shift) != a->W))
         return -1;
     // variant = (NR rows per wave, CK channels per LDS stage).  auto: NR=4 for big grids, NR=2 otherwise;
@@ -332,7 +376,7 @@ extern "C" int bfsr_conv2d(const BfsrConvArgs* a, void* stream)
     if (a->tune > 0) { NR = a->tune / 100; CK = a->tune % 100; }
     if (a->w2) {
         // fused 3x3 -> 1x1 (coupling nets: flow.Conv2d 3x3 + ReLU -> flow.Conv2d 1x1 + ReLU); one cout group only
-        if (a->KS != 3 || a->mtile != 2 || a->Cout > 64 || a->C2 > 64 || a->C2 <= 0 || a->res1 || a->res2 || a->post_scale) return -1;
+        if (a->KS != 3 || a->mtile != 2 || a->Cout > 64 || a->C2 > 64 || a->C2 <= 0 || a->res1 || a->res2) return -1;
         return launch_conv<3, 2, 2, 8, true>(*a, st);
     }
     const int key = a->KS * 10000 + a->mtile * 1000 + NR * 100 + CK;

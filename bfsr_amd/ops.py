@@ -95,14 +95,31 @@ class HipOps(object):
         """A per-channel parameter vector on the device."""
         return t.detach().reshape(-1).to(device=self.device, dtype=torch.float32).contiguous()
 
-    def conv(self, x, pw, out, in_shift=0, bias=None, pre_add=None, aff_shift=None, aff_scale=None,
-             aff_post=None, act=ACT_NONE, slope=0.2, post_scale=None, res1=None, alpha1=1.0, res2=None, alpha2=1.0, tune=0, stage2=None):
-        """stage2 = (PackedConv 1x1, shift, scale, act): fused second conv, `out` then has stage2 Cout channels."""
+    def pack_epilogue(self, Cout, bias=None, aff_shift=None, aff_scale=None, aff_post=None, post_scale=None):
+        """Per-channel epilogue vectors -> the packed [Cout,8] device tensor of the C ABI (None if all neutral)."""
+        vs = (bias, aff_shift, aff_scale, aff_post, post_scale)
+        if all(v is None for v in vs):
+            return None
+        e = torch.zeros(Cout, 8, dtype=torch.float32)
+        e[:, 2] = 1.0
+        e[:, 4] = 1.0
+        for col, v in enumerate(vs):
+            if v is not None:
+                e[:, col] = v.detach().reshape(-1).to("cpu", torch.float32)
+        return e.to(self.device)
+
+    def conv(self, x, pw, out, in_shift=0, epi=None, pre_add=None, act=ACT_NONE, slope=0.2, res1=None, alpha1=1.0,
+             res2=None, alpha2=1.0, tune=0, stage2=None, bias=None, aff_shift=None, aff_scale=None, aff_post=None,
+             post_scale=None):
+        """epi: packed per-channel parameters from pack_epilogue (the loose vector kwargs are packed on the fly, for tests).
+        stage2 = (PackedConv 1x1, epi2, act2): fused second conv, `out` then has stage2 Cout channels."""
+        if epi is None and any(v is not None for v in (bias, aff_shift, aff_scale, aff_post, post_scale)):
+            epi = self.pack_epilogue(pw.Cout, bias, aff_shift, aff_scale, aff_post, post_scale)
         xp, xbs, Cin, Hs, Ws = _view(x, "conv.x")
         yp, ybs, Cout, H, W = _view(out, "conv.out")
         c_final = Cout
         if stage2 is not None:
-            pw2, s2_shift, s2_scale, act2 = stage2
+            pw2, epi2, act2 = stage2
             if pw2.KS != 1 or pw2.mtile != 2 or pw2.Cin != pw.Cout or pw2.Cout != Cout:
                 raise ValueError("conv: bad fused stage")
             Cout = pw.Cout
@@ -114,16 +131,14 @@ class HipOps(object):
         a.w = pw.data.data_ptr()
         a.y, a.y_bs, a.Cout = yp, ybs, Cout
         if stage2 is not None:
-            a.w2, a.C2, a.s2_shift, a.s2_scale, a.act2 = pw2.data.data_ptr(), c_final, _ptr(s2_shift), _ptr(s2_scale), act2
+            a.w2, a.C2, a.epi2, a.act2 = pw2.data.data_ptr(), c_final, _ptr(epi2), act2
         a.B, a.H, a.W, a.KS, a.in_shift, a.mtile = out.shape[0], H, W, pw.KS, in_shift, pw.mtile
-        a.bias = _ptr(bias)
+        a.epi = _ptr(epi)
         if pre_add is not None:
             p, bs, c, h, w = _view(pre_add, "conv.pre_add")
             assert (c, h, w) == (Cout, H, W)
             a.pre_add, a.pre_add_bs = p, bs
-        a.aff_shift, a.aff_scale, a.aff_post = _ptr(aff_shift), _ptr(aff_scale), _ptr(aff_post)
         a.act, a.slope, a.tune = act, slope, tune
-        a.post_scale = _ptr(post_scale)
         if res1 is not None:
             p, bs, c, h, w = _view(res1, "conv.res1")
             assert (c, h, w) == (Cout, H, W)

@@ -29,13 +29,10 @@ class _ConvP(object):
 
     def __init__(self, ops, w, bias=None, aff_shift=None, aff_scale=None, aff_post=None, post_scale=None, mtile=None):
         self.pw = ops.pack_conv(w, mtile)
-        v = lambda t: None if t is None else ops.vec(t)
-        self.bias, self.aff_shift, self.aff_scale = v(bias), v(aff_shift), v(aff_scale)
-        self.aff_post, self.post_scale = v(aff_post), v(post_scale)
+        self.epi = ops.pack_epilogue(self.pw.Cout, bias, aff_shift, aff_scale, aff_post, post_scale)
 
     def run(self, ops, x, out, **kw):
-        return ops.conv(x, self.pw, out, bias=self.bias, aff_shift=self.aff_shift, aff_scale=self.aff_scale,
-                        aff_post=self.aff_post, post_scale=self.post_scale, **kw)
+        return ops.conv(x, self.pw, out, epi=self.epi, **kw)
 
 
 class _Workspace(object):
@@ -290,7 +287,7 @@ class SRFlowEngine(object):
         h_aff = ws.get("haff_%s_%d" % (tag, k & 1), B, 2 * (C - cn), H, W)
         # 3x3 on z1 (+ hoisted ft partial, ActNorm, ReLU) with the 1x1 (+ActNorm, ReLU) fused as a second MFMA stage
         st.aff0_z1.run(ops, z[:, :cn], hid, pre_add=cnd["pre_aff"][:, 64 * k: 64 * (k + 1)], act=ACT_RELU,
-                       stage2=(st.aff2.pw, st.aff2.aff_shift, st.aff2.aff_scale, ACT_RELU))
+                       stage2=(st.aff2.pw, st.aff2.epi, ACT_RELU))
         st.aff4.run(ops, hid, h_aff)
         return h_aff
 

@@ -37,7 +37,9 @@ enum { BFSR_ACT_NONE = 0, BFSR_ACT_RELU = 1, BFSR_ACT_LRELU = 2 };
  * epilogue order per output element v (channel c):
  *   v = acc; v += bias[c]; v += pre_add[b,c,y,x]; v = (v + aff_shift[c]) * aff_scale[c] + aff_post[c];
  *   v = act(v); v *= post_scale[c]; v = alpha1*v + res1[b,c,y,x]; v = alpha2*v + res2[b,c,y,x]
- * (each stage skipped when its pointer is NULL).
+ * The five per-channel vectors are passed packed: epi[c] = {bias, aff_shift, aff_scale, aff_post, post_scale, 0, 0, 0}
+ * (8 floats per channel; neutral values 0,0,1,0,1 where a stage is unused; epi == NULL = all neutral), which keeps
+ * the element math branch-free.  Tensor stages are skipped when their pointer is NULL.
  *
  * `w` is the packed weight produced by bfsr_pack_conv_weight (layout private to the library:
  * [cout_group][cin_pad][tap][mtile*32], zero padded).
@@ -50,19 +52,17 @@ typedef struct BfsrConvArgs {
     float* y; long long y_bs; int Cout;
     int B, H, W, KS, in_shift;
     int mtile;                       /* 32-wide cout tiles per workgroup the weight was packed for */
-    const float* bias;
+    const float* epi;                /* [Cout][8] packed per-channel epilogue parameters, or NULL */
     const float* pre_add; long long pre_add_bs;
-    const float* aff_shift; const float* aff_scale; const float* aff_post;
     int act; float slope;
-    const float* post_scale;
     const float* res1; long long res1_bs; float alpha1;
     const float* res2; long long res2_bs; float alpha2;
     int tune;                        /* 0 = auto; NR*100+CK forces a kernel variant (benchmarking) */
     /* optional fused second stage (w2 != NULL): a 1x1 conv over the <= 64 stage-1 channels applied in the same
-     * kernel; y then has C2 <= 64 channels: y = act2((W2 . stage1 + s2_shift) * s2_scale).  w2 is packed with
+     * kernel; y then has C2 <= 64 channels: y = epilogue2(W2 . stage1) with epi2/act2.  w2 is packed with
      * bfsr_pack_conv_weight(KS=1, mtile=2).  Stage 1 keeps bias / pre_add / aff_* / act. */
     const float* w2; int C2;
-    const float* s2_shift; const float* s2_scale; int act2;
+    const float* epi2; int act2;      /* stage-2 per-channel parameters, same packing ([C2][8]) */
 } BfsrConvArgs;
 
 int bfsr_abi_version(void);

@@ -42,8 +42,18 @@ class CpuOps(object):
             w = w[torch.as_tensor(out_perm)].contiguous()
         return PackedConv(w, mtile)
 
-    def conv(self, x, pw, out, in_shift=0, bias=None, pre_add=None, aff_shift=None, aff_scale=None, aff_post=None,
-             act=ACT_NONE, slope=0.2, post_scale=None, res1=None, alpha1=1.0, res2=None, alpha2=1.0, tune=0, stage2=None):
+    def pack_epilogue(self, Cout, bias=None, aff_shift=None, aff_scale=None, aff_post=None, post_scale=None):
+        vs = dict(bias=bias, aff_shift=aff_shift, aff_scale=aff_scale, aff_post=aff_post, post_scale=post_scale)
+        if all(v is None for v in vs.values()):
+            return None
+        return {k: (None if v is None else v.detach().reshape(-1).to(torch.float32).clone()) for k, v in vs.items()}
+
+    def conv(self, x, pw, out, in_shift=0, epi=None, pre_add=None, act=ACT_NONE, slope=0.2, res1=None, alpha1=1.0,
+             res2=None, alpha2=1.0, tune=0, stage2=None, bias=None, aff_shift=None, aff_scale=None, aff_post=None,
+             post_scale=None):
+        if epi is not None:
+            bias, aff_shift, aff_scale = epi["bias"], epi["aff_shift"], epi["aff_scale"]
+            aff_post, post_scale = epi["aff_post"], epi["post_scale"]
         xin = x
         if in_shift:
             xin = F.interpolate(x, scale_factor=1 << in_shift, mode="nearest")
@@ -70,13 +80,15 @@ class CpuOps(object):
         if res2 is not None:
             v = alpha2 * v + res2
         if stage2 is not None:
-            pw2, s2_shift, s2_scale, act2 = stage2
+            pw2, epi2, act2 = stage2
             v = F.conv2d(v, pw2.w)
-            if s2_shift is not None:
-                v = v + _cv(s2_shift)
-            if s2_scale is not None:
-                v = v * _cv(s2_scale)
+            if epi2 is not None:
+                for k, fn in (("bias", torch.add), ("aff_shift", torch.add), ("aff_scale", torch.mul), ("aff_post", torch.add)):
+                    if epi2[k] is not None:
+                        v = fn(v, _cv(epi2[k]))
             v = F.relu(v) if act2 == ACT_RELU else (F.leaky_relu(v, slope) if act2 == ACT_LRELU else v)
+            if epi2 is not None and epi2["post_scale"] is not None:
+                v = v * _cv(epi2["post_scale"])
         out.copy_(v)
         return out
 

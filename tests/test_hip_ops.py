@@ -70,7 +70,7 @@ def test_conv_epilogue_all_stages(hip):
     for act in (0, 1, 2):
         ref = CPU.conv(x, CPU.pack_conv(w, 2), torch.empty(B, Cout, H, W), pre_add=pre, act=act, slope=0.2,
                        res1=r1, alpha1=0.2, res2=r2, alpha2=0.3, **kw)
-        dkw = {k: hip.vec(t) for k, t in kw.items()}
+        dkw = dict(kw)
         out = hip.conv(hip.to_device(x), hip.pack_conv(w, 2), hip.empty(B, Cout, H, W), pre_add=hip.to_device(pre),
                        act=act, slope=0.2, res1=hip.to_device(r1), alpha1=0.2, res2=hip.to_device(r2), alpha2=0.3, **dkw)
         close(out, ref, 2e-5, "conv epilogue act=%d" % act)
@@ -99,7 +99,7 @@ def test_conv_nearest_upsample_on_read(hip):
     x, w = rnd(18, B, C, h, w_), rnd(19, 64, C, 3, 3, scale=0.05)
     b = rnd(20, 64, scale=0.1)
     ref = CPU.conv(x, CPU.pack_conv(w, 2), torch.empty(B, 64, 2 * h, 2 * w_), in_shift=1, bias=b, act=2)
-    out = hip.conv(hip.to_device(x), hip.pack_conv(w, 2), hip.empty(B, 64, 2 * h, 2 * w_), in_shift=1, bias=hip.vec(b), act=2)
+    out = hip.conv(hip.to_device(x), hip.pack_conv(w, 2), hip.empty(B, 64, 2 * h, 2 * w_), in_shift=1, bias=b, act=2)
     close(out, ref, 2e-5, "conv in_shift")
 
 
@@ -215,8 +215,8 @@ def test_conv_fused_1x1_second_stage(hip, case):
     sh1, sc1 = rnd(94, Cmid, scale=0.2), torch.exp(rnd(95, Cmid, scale=0.2))
     sh2, sc2 = rnd(96, C2, scale=0.2), torch.exp(rnd(97, C2, scale=0.2))
     ref = CPU.conv(x, CPU.pack_conv(w, 2), torch.empty(B, C2, H, W), pre_add=pre, aff_shift=sh1, aff_scale=sc1, act=1,
-                   stage2=(CPU.pack_conv(w2, 2), sh2, sc2, 1))
+                   stage2=(CPU.pack_conv(w2, 2), CPU.pack_epilogue(C2, aff_shift=sh2, aff_scale=sc2), 1))
     out = hip.conv(hip.to_device(x), hip.pack_conv(w, 2), hip.empty(B, C2, H, W), pre_add=hip.to_device(pre),
-                   aff_shift=hip.vec(sh1), aff_scale=hip.vec(sc1), act=1,
-                   stage2=(hip.pack_conv(w2, 2), hip.vec(sh2), hip.vec(sc2), 1))
+                   aff_shift=sh1, aff_scale=sc1, act=1,
+                   stage2=(hip.pack_conv(w2, 2), hip.pack_epilogue(C2, aff_shift=sh2, aff_scale=sc2), 1))
     close(out, ref, 2e-5, "fused 3x3+1x1 %s" % (case,))

@@ -36,7 +36,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8, help="LR crops per GPU")
     ap.add_argument("--lr", type=int, default=160, help="LR crop side")
-    ap.add_argument("--lanes", type=int, default=2, help="sub-batches run concurrently on separate HIP streams")
+    ap.add_argument("--lanes", type=int, default=1, help="sub-batches run concurrently on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-lr", type=int, default=160, help="LR side of the CPU-baseline sample (B=1)")
     return ap.parse_args()

@@ -35,7 +35,7 @@ class BfsrFlowArgs(C.Structure):
         ("z_out", C.c_void_p), ("z_out_bs", C.c_longlong),
         ("h_aff", C.c_void_p), ("h_aff_bs", C.c_longlong),
         ("h_ft", C.c_void_p), ("h_ft_bs", C.c_longlong),
-        ("w", C.c_void_p), ("an_bias", C.c_void_p), ("an_escale", C.c_void_p),
+        ("w", C.c_void_p), ("wt", C.c_void_p), ("an_bias", C.c_void_p), ("an_escale", C.c_void_p),
         ("B", C.c_int), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int),
         ("reverse", C.c_int), ("eps", C.c_float),
     ]

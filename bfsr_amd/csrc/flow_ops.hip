@@ -155,6 +155,81 @@ __global__ __launch_bounds__(256) void flow_pointwise_kernel(BfsrFlowArgs a, lon
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// MFMA variant for wide steps (C = 96): the CxC invertible 1x1 conv is a [C x C] x [C x pixels] GEMM, done on
+// v_mfma_f32_32x32x2_f32 with M = output channel, N = 32 pixels, K = input channel.  The B fragment (lane = pixel
+// l&31 of channel 2kk + (l>>5)) is loaded straight from global memory -- one coalesced 128-byte row per half wave --
+// and the elementwise stages that precede the matvec are applied to it in registers; W (k-major copy, `wt`) comes
+// from L1/L2.  The stages that follow the matvec run on the accumulator layout (lane = pixel, 16 channels per tile).
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+template <int C>
+__global__ __launch_bounds__(256) void flow_pointwise_mfma_kernel(BfsrFlowArgs a, long long HW)
+{
+    constexpr int CN = C / 2, MT = (C + 31) / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int b = blockIdx.y;
+    const long long pix0 = ((long long)blockIdx.x * 4 + wave) * 32;      // 32 pixels per wave
+    if (pix0 >= HW) return;
+    const long long pix = pix0 + l31;
+    const bool ok = pix < HW;
+    const long long pc = ok ? pix : HW - 1;                                 // clamped: loads stay in range
+    const float eps = a.eps;
+    const float* zi = a.z_in + (long long)b * a.z_in_bs + pc;
+    const float* ha = a.h_aff ? a.h_aff + (long long)b * a.h_aff_bs + pc : nullptr;
+    const float* hf = a.h_ft ? a.h_ft + (long long)b * a.h_ft_bs + pc : nullptr;
+    const float* __restrict__ wt = a.wt;                                    // [k][i]
+
+    f32x16_t acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+#pragma unroll 4
+    for (int kk = 0; kk < C / 2; ++kk) {
+        const int c = 2 * kk + lhi;
+        float x = zi[(long long)c * HW];
+        if (a.reverse) {
+            if (ha && c >= CN) {
+                const int j = c - CN;
+                x = x / sigmoid_scale(ha[(long long)(2 * j + 1) * HW], eps) - ha[(long long)(2 * j) * HW];
+            }
+            if (hf) x = x / sigmoid_scale(hf[(long long)(2 * c + 1) * HW], eps) - hf[(long long)(2 * c) * HW];
+        } else {
+            if (ha && c >= CN) {
+                const int j = c - CN;
+                x = (x + ha[(long long)(2 * j) * HW]) * sigmoid_scale(ha[(long long)(2 * j + 1) * HW], eps);
+            }
+            if (a.an_bias) x = (x + a.an_bias[c]) * a.an_escale[c];
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int i = m * 32 + l31;
+            const float w = i < C ? wt[c * C + i] : 0.f;
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, x, acc[m], 0, 0, 0);
+        }
+    }
+    if (!ok) return;
+    float* zo = a.z_out + (long long)b * a.z_out_bs + pix;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (i >= C) continue;
+            float y = acc[m][r];
+            if (a.reverse) {
+                if (a.an_bias) y = y * a.an_escale[i] - a.an_bias[i];
+            } else if (hf) {
+                y = (y + hf[(long long)(2 * i) * HW]) * sigmoid_scale(hf[(long long)(2 * i + 1) * HW], eps);
+            }
+            zo[(long long)i * HW] = y;
+        }
+}
+
 template <int C, int VEC>
 int launch_flow(const BfsrFlowArgs& a, hipStream_t st)
 {
@@ -267,7 +342,15 @@ extern "C" int bfsr_flow_pointwise(const BfsrFlowArgs* a, void* stream)
         case 12: return dispatch_flow_vec<12>(*a, st, 4);
         case 24: return dispatch_flow_vec<24>(*a, st, 4);
         case 48: return dispatch_flow_vec<48>(*a, st, 1);
-        case 96: return dispatch_flow_vec<96>(*a, st, 1);
+        case 96:
+            if (a->w && a->wt) {       // MFMA path needs the k-major copy of W (in-place is fine: a wave reads all
+                                       // channels of its 32 pixels before it stores any)
+                const long long HW = (long long)a->H * a->W;
+                dim3 grid((unsigned)((HW + 127) / 128), (unsigned)a->B);
+                hipLaunchKernelGGL((flow_pointwise_mfma_kernel<96>), grid, dim3(256), 0, st, *a, HW);
+                return (int)hipGetLastError();
+            }
+            return dispatch_flow_vec<96>(*a, st, 1);
         case 3: return dispatch_flow_vec<3>(*a, st, 4);
         case 6: return dispatch_flow_vec<6>(*a, st, 4);
         default: return -1;

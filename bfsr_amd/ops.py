@@ -153,7 +153,7 @@ class HipOps(object):
 
     # ---- flow pointwise ---------------------------------------------------------------------
     def flow_pointwise(self, z_in, z_out, reverse, h_aff=None, h_ft=None, w=None, an_bias=None, an_escale=None,
-                       eps=1e-4):
+                       eps=1e-4, wt=None):
         a = _lib.BfsrFlowArgs()
         a.z_in, a.z_in_bs, Cc, H, W = _view(z_in, "flow.z_in")
         a.z_out, a.z_out_bs, c2, h2, w2 = _view(z_out, "flow.z_out")
@@ -164,7 +164,7 @@ class HipOps(object):
         if h_ft is not None:
             a.h_ft, a.h_ft_bs, c, h, ww = _view(h_ft, "flow.h_ft")
             assert (c, h, ww) == (2 * Cc, H, W)
-        a.w, a.an_bias, a.an_escale = _ptr(w), _ptr(an_bias), _ptr(an_escale)
+        a.w, a.wt, a.an_bias, a.an_escale = _ptr(w), _ptr(wt), _ptr(an_bias), _ptr(an_escale)
         a.B, a.C, a.H, a.W = z_in.shape[0], Cc, H, W
         a.reverse, a.eps = int(bool(reverse)), eps
         key = ("flow", int(bool(reverse)), Cc, z_in.shape[0], H, W, h_aff is not None, h_ft is not None, w is not None)

@@ -157,8 +157,9 @@ class SRFlowEngine(object):
                 st = _CouplingStep()
                 C = ly.C
                 W = sd[p + "invconv.weight"]
-                st.w_fwd = ops.vec(W)
-                st.w_inv = ops.vec(torch.inverse(W.double()).float())        # Permutations.py:41, once
+                Winv = torch.inverse(W.double()).float()                     # Permutations.py:41, once
+                st.w_fwd, st.w_inv = ops.vec(W), ops.vec(Winv)
+                st.w_fwd_t, st.w_inv_t = ops.vec(W.t().contiguous()), ops.vec(Winv.t().contiguous())
                 logs = sd[p + "actnorm.logs"].reshape(-1)
                 st.an_bias = ops.vec(sd[p + "actnorm.bias"])
                 st.an_exp = ops.vec(torch.exp(logs))
@@ -312,10 +313,10 @@ class SRFlowEngine(object):
                     cnd = cond[ly.level]
                     k = cnd["slot"][ly.index]
                     ops.flow_pointwise(z, z, False, h_aff=pending, an_bias=st.an_bias, an_escale=st.an_exp,
-                                       w=st.w_fwd, h_ft=cnd["h_ft"][:, 2 * ly.C * k: 2 * ly.C * (k + 1)])
+                                       w=st.w_fwd, wt=st.w_fwd_t, h_ft=cnd["h_ft"][:, 2 * ly.C * k: 2 * ly.C * (k + 1)])
                     pending = self._self_cond(st, z, cnd, k, "enc%d" % ly.level)
                 else:
-                    ops.flow_pointwise(z, z, False, h_aff=pending, an_bias=st.an_bias, an_escale=st.an_exp, w=st.w_fwd)
+                    ops.flow_pointwise(z, z, False, h_aff=pending, an_bias=st.an_bias, an_escale=st.an_exp, w=st.w_fwd, wt=st.w_fwd_t)
                     pending = None
             else:   # split
                 if pending is not None:
@@ -355,9 +356,9 @@ class SRFlowEngine(object):
                     k = cnd["slot"][ly.index]
                     h_aff = self._self_cond(st, z, cnd, k, "dec%d" % ly.level)
                     ops.flow_pointwise(z, z, True, h_aff=h_aff, h_ft=cnd["h_ft"][:, 2 * C * k: 2 * C * (k + 1)],
-                                       w=st.w_inv, an_bias=st.an_bias, an_escale=st.an_expneg)
+                                       w=st.w_inv, wt=st.w_inv_t, an_bias=st.an_bias, an_escale=st.an_expneg)
                 else:
-                    ops.flow_pointwise(z, z, True, w=st.w_inv, an_bias=st.an_bias, an_escale=st.an_expneg)
+                    ops.flow_pointwise(z, z, True, w=st.w_inv, wt=st.w_inv_t, an_bias=st.an_bias, an_escale=st.an_expneg)
             elif ly.type == "squeeze":
                 Co = C // 4
                 nxt = self.layers[pos - 1] if pos > 0 else None

@@ -96,11 +96,39 @@ def lp_infer(model, prior_model, lr_t, return_all=False, lanes=1):
         from ..dist import shard_bounds
         engs, pris, streams = _lanes(net, prior_model, lanes)
         main = torch.cuda.current_stream(ops.device)
-        for i in range(lanes):
+        for st in streams:
+            st.wait_stream(main)
+
+        def run(i):
             lo, hi = shard_bounds(B, i, lanes)
-            streams[i].wait_stream(main)
-            with torch.cuda.stream(streams[i]):
+            with torch.no_grad(), torch.cuda.stream(streams[i]):
                 _lp_lane(engs[i], pris[i], lr[lo:hi], scale, sr[lo:hi])
+
+        # one host thread per lane so the launches of the lanes interleave (the C-ABI calls release the GIL); a short
+        # GIL switch interval keeps the two queues evenly fed
+        import sys
+        import threading
+        old = sys.getswitchinterval()
+        sys.setswitchinterval(5e-5)
+        try:
+            errs = []
+
+            def guard(i):
+                try:
+                    run(i)
+                except BaseException as e:      # noqa: BLE001 -- re-raised on the caller's thread
+                    errs.append(e)
+
+            ts = [threading.Thread(target=guard, args=(i,)) for i in range(1, lanes)]
+            for t in ts:
+                t.start()
+            guard(0)
+            for t in ts:
+                t.join()
+            if errs:
+                raise errs[0]
+        finally:
+            sys.setswitchinterval(old)
         for st in streams:
             main.wait_stream(st)
     return sr

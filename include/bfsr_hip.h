@@ -95,6 +95,7 @@ typedef struct BfsrFlowArgs {
     const float* h_aff; long long h_aff_bs;
     const float* h_ft; long long h_ft_bs;
     const float* w;            /* [C][C] row-major, or NULL */
+    const float* wt;           /* optional transpose of w ([k][i]); enables the MFMA path for C = 96 */
     const float* an_bias;      /* [C] or NULL */
     const float* an_escale;    /* [C] */
     int B, C, H, W;

@@ -92,7 +92,8 @@ class CpuOps(object):
         out.copy_(v)
         return out
 
-    def flow_pointwise(self, z_in, z_out, reverse, h_aff=None, h_ft=None, w=None, an_bias=None, an_escale=None, eps=1e-4):
+    def flow_pointwise(self, z_in, z_out, reverse, h_aff=None, h_ft=None, w=None, an_bias=None, an_escale=None, eps=1e-4,
+                       wt=None):
         x = z_in.clone()
         C = x.shape[1]
         cn = C // 2

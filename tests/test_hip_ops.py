@@ -123,6 +123,10 @@ def test_flow_pointwise(hip, C, reverse, hw):
         zd = hip.to_device(z)
         out = hip.flow_pointwise(zd, zd, reverse, **dkw)          # in place
         close(out, ref, 1e-5, "flow_pointwise C=%d rev=%d %s" % (C, reverse, sorted(kw)))
+        if "w" in kw:                                             # MFMA path (taken for C=96 when wt is given)
+            zd = hip.to_device(z)
+            out = hip.flow_pointwise(zd, zd, reverse, wt=hip.vec(Wm.t().contiguous()), **dkw)
+            close(out, ref, 1e-5, "flow_pointwise+wt C=%d rev=%d %s" % (C, reverse, sorted(kw)))
 
 
 def test_flow_pointwise_on_channel_slice(hip):

@@ -118,13 +118,18 @@ def main():
     hw1 = (H // 2) * (H // 2)
     conv_flop = 2.0 * 320 * 9 * (16 * 64) * Bl * hw1                  # algorithmic flops of one launch
     tail_bytes = 20.0 * C1 * Bl * hw1                                 # read z,h_aff,h_ft + write z
+    traffic = None          # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
+    tp = os.path.join(ROOT, "profiles", "r01_b_pmc_traffic.json")
+    if os.path.exists(tp) and B == 8 and h == 160:
+        traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
     roofline = None
     if conv_ms:
         a = conv_flop / (conv_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "conv_mfma_kernel<3,2,4> (hoisted level-1 3x3 conv 320->1024)",
                     "achieved": round(a, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(a / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                    "avg_launch_ms": round(conv_ms, 4), "launches": conv_n}
+                    "frac": round(a / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_b_pmc_traffic.json)",
+                    "algorithmic_flop_per_launch": conv_flop, "avg_launch_ms": round(conv_ms, 4), "launches": conv_n}
     roof_tail = None
     if tail_ms:
         a = tail_bytes / (tail_ms * 1e-3) / 1e9

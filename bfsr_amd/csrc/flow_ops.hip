@@ -168,6 +168,7 @@ template <int C>
 __global__ __launch_bounds__(256) void flow_pointwise_mfma_kernel(BfsrFlowArgs a, long long HW)
 {
     constexpr int CN = C / 2, MT = (C + 31) / 32;
+    static_assert(CN % 2 == 0, "channel pairs must not straddle the z1/z2 split");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int b = blockIdx.y;
@@ -188,28 +189,51 @@ __global__ __launch_bounds__(256) void flow_pointwise_mfma_kernel(BfsrFlowArgs a
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-#pragma unroll 4
+    // phase 1: all B fragments of this wave's 32 pixels (C/2 registers per lane) with the pre-matvec stages applied;
+    // fully unrolled so every global load is in flight at once
+    float xs[C / 2];
+#pragma unroll
+    for (int kk = 0; kk < C / 2; ++kk) xs[kk] = zi[(long long)(2 * kk + lhi) * HW];
+    if (a.reverse) {
+        if (ha) {
+#pragma unroll
+            for (int kk = CN / 2; kk < C / 2; ++kk) {       // channels >= CN (CN even): z2 = z2/scale - shift
+                const int j = 2 * kk + lhi - CN;
+                xs[kk] = xs[kk] / sigmoid_scale(ha[(long long)(2 * j + 1) * HW], eps) - ha[(long long)(2 * j) * HW];
+            }
+        }
+        if (hf) {
+#pragma unroll
+            for (int kk = 0; kk < C / 2; ++kk) {
+                const int c = 2 * kk + lhi;
+                xs[kk] = xs[kk] / sigmoid_scale(hf[(long long)(2 * c + 1) * HW], eps) - hf[(long long)(2 * c) * HW];
+            }
+        }
+    } else {
+        if (ha) {
+#pragma unroll
+            for (int kk = CN / 2; kk < C / 2; ++kk) {
+                const int j = 2 * kk + lhi - CN;
+                xs[kk] = (xs[kk] + ha[(long long)(2 * j) * HW]) * sigmoid_scale(ha[(long long)(2 * j + 1) * HW], eps);
+            }
+        }
+        if (a.an_bias) {
+#pragma unroll
+            for (int kk = 0; kk < C / 2; ++kk) {
+                const int c = 2 * kk + lhi;
+                xs[kk] = (xs[kk] + a.an_bias[c]) * a.an_escale[c];
+            }
+        }
+    }
+    // phase 2: the matvec on the matrix cores
+#pragma unroll
     for (int kk = 0; kk < C / 2; ++kk) {
         const int c = 2 * kk + lhi;
-        float x = zi[(long long)c * HW];
-        if (a.reverse) {
-            if (ha && c >= CN) {
-                const int j = c - CN;
-                x = x / sigmoid_scale(ha[(long long)(2 * j + 1) * HW], eps) - ha[(long long)(2 * j) * HW];
-            }
-            if (hf) x = x / sigmoid_scale(hf[(long long)(2 * c + 1) * HW], eps) - hf[(long long)(2 * c) * HW];
-        } else {
-            if (ha && c >= CN) {
-                const int j = c - CN;
-                x = (x + ha[(long long)(2 * j) * HW]) * sigmoid_scale(ha[(long long)(2 * j + 1) * HW], eps);
-            }
-            if (a.an_bias) x = (x + a.an_bias[c]) * a.an_escale[c];
-        }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int i = m * 32 + l31;
             const float w = i < C ? wt[c * C + i] : 0.f;
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, x, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, xs[kk], acc[m], 0, 0, 0);
         }
     }
     if (!ok) return;

@@ -80,8 +80,9 @@ class LINFEngine(object):
 
     # ------------------------------------------------------------------------------------------------
     def gen_feat(self, inp):
-        key = (inp.data_ptr(), inp._version, tuple(inp.shape))
-        if self._feat_key != key:
+        # caches keep a reference to the keyed tensors (identity + version), so recycled storage can never alias
+        key = (inp, inp._version)
+        if not (self._feat_key is not None and self._feat_key[0] is inp and self._feat_key[1] == inp._version):
             B, _, h, w = inp.shape
             out = self.ops.empty(B, self.nf, h, w)
             self.encoder.forward(inp, out)
@@ -89,8 +90,9 @@ class LINFEngine(object):
         return self._feat
 
     def affine_info(self, feat, coord, cell):
-        key = (feat.data_ptr(), feat._version, coord.data_ptr(), coord._version, cell.data_ptr(), tuple(coord.shape))
-        if self._cond_key == key:
+        key = (feat, feat._version, coord, coord._version, cell, cell._version)
+        k = self._cond_key
+        if k is not None and k[0] is feat and k[2] is coord and k[4] is cell and (k[1], k[3], k[5]) == (key[1], key[3], key[5]):
             return self._cond
         ops, ws, HD = self.ops, self.ws, self.hidden
         B, _, h, w = feat.shape

@@ -73,6 +73,10 @@ class HipOps(object):
         return torch.zeros(*shape, dtype=torch.float32, device=self.device)
 
     def to_device(self, t):
+        """Device fp32 contiguous version of t; returns t ITSELF when it already is one (the engines' caches are
+        keyed on tensor identity, so the same LR tensor passed to encode and decode shares its conditioning)."""
+        if t.device == self.device and t.dtype == torch.float32 and t.is_contiguous() and not t.requires_grad:
+            return t
         return t.detach().to(device=self.device, dtype=torch.float32).contiguous()
 
     def _stream(self):

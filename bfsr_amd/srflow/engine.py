@@ -219,8 +219,10 @@ class SRFlowEngine(object):
 
     def conditioning(self, lr):
         """RRDB features + hoisted ft-only coupling activations for an LR batch (cached per tensor)."""
-        key = (lr.data_ptr(), lr._version, tuple(lr.shape))
-        if self._cond_key == key:
+        # the cache holds a reference to the keyed tensor, so its storage cannot be recycled for another input
+        # while the entry is alive; a new tensor object or an in-place update (version bump) is a miss
+        key = (lr, lr._version)
+        if self._cond_key is not None and self._cond_key[0] is lr and self._cond_key[1] == lr._version:
             return self._cond
         ops, ws = self.ops, self.ws
         B, _, h, w = lr.shape

@@ -31,6 +31,8 @@ class CpuOps(object):
         return torch.zeros(*shape, dtype=torch.float32)
 
     def to_device(self, t):
+        if t.dtype == torch.float32 and t.is_contiguous() and not t.requires_grad:
+            return t
         return t.detach().to(torch.float32).contiguous()
 
     def vec(self, t):

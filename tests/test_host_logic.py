@@ -132,3 +132,21 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_conditioning_cache_is_keyed_on_tensor_identity():
+    """A fresh tensor that happens to reuse a freed tensor's storage must not hit the conditioning cache."""
+    from bfsr_amd.srflow.engine import SRFlowEngine
+    ops = CpuOps()
+    opt = options.load(options.DEFAULT_CONF)
+    eng = SRFlowEngine(opt, synth.state_dict_from_schema(spec.srflownet_schema(opt), 1234), ops)
+    a = synth.lr_batch(1, 1, 16, 16)
+    c1 = eng.conditioning(a)
+    assert eng.conditioning(a) is c1                       # same object, same version: hit
+    h1 = c1[1]["h_ft"].clone()
+    a.copy_(synth.lr_batch(2, 1, 16, 16))                  # in-place update bumps the version: miss
+    c2 = eng.conditioning(a)
+    assert not torch.equal(c2[1]["h_ft"], h1)
+    b = a.clone()                                          # different object with equal content: recomputed, equal
+    h2 = c2[1]["h_ft"].clone()
+    assert torch.equal(eng.conditioning(b)[1]["h_ft"], h2)

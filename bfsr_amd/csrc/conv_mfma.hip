@@ -368,11 +368,15 @@ extern "C" int bfsr_conv2d(const BfsrConvArgs* a, void* stream)
         return -1;
     // variant = (NR rows per wave, CK channels per LDS stage).  auto: NR=4 for big grids, NR=2 otherwise;
     // a->tune = NR*100 + CK overrides (used by tools/conv_bench.py to pick the table below).
-    // auto: 16x32 tiles (NR=4) only when the launch still fills the chip for >= 4 rounds of 2 workgroups/CU
-    // (measured on MI355X, tools/conv_bench.py: hoisted 320->1024 convs gain 6-8 %, everything smaller loses)
-    const long long tiles4 = (long long)((a->W + 31) / 32) * ((a->H + 15) / 16) * a->B;
+    // auto tile height from the grid size (measured on MI355X, tools/conv_bench.py): 16x32 pixel tiles (NR=4) only when
+    // the launch still fills the chip for >= 4 rounds of 2 workgroups/CU, 8x32 (NR=2) by default, 4x32 (NR=1) when even
+    // that leaves fewer than ~5 workgroups per CU (the RRDB / level-3 convs at bench size).
     const long long groups_ = ((a->Cout + 31) / 32 + a->mtile - 1) / a->mtile;
-    int NR = (tiles4 * groups_ >= 4 * 512 && a->mtile <= 2) ? 4 : 2, CK = a->KS == 3 ? 8 : 16;
+    const long long tiles4 = (long long)((a->W + 31) / 32) * ((a->H + 15) / 16) * a->B;
+    const long long tiles2 = (long long)((a->W + 31) / 32) * ((a->H + 7) / 8) * a->B;
+    int NR = 2, CK = a->KS == 3 ? 8 : 16;
+    if (tiles4 * groups_ >= 4 * 512 && a->mtile <= 2) NR = 4;
+    else if (a->KS == 3 && a->mtile <= 2 && tiles2 * groups_ < 1280) NR = 1;
     if (a->tune > 0) { NR = a->tune / 100; CK = a->tune % 100; }
     if (a->w2) {
         // fused 3x3 -> 1x1 (coupling nets: flow.Conv2d 3x3 + ReLU -> flow.Conv2d 1x1 + ReLU); one cout group only
@@ -382,8 +386,8 @@ extern "C" int bfsr_conv2d(const BfsrConvArgs* a, void* stream)
     const int key = a->KS * 10000 + a->mtile * 1000 + NR * 100 + CK;
     switch (key) {
 #define V(KS_, MR_, NR_, CK_) case KS_ * 10000 + MR_ * 1000 + NR_ * 100 + CK_: return launch_conv<KS_, MR_, NR_, CK_>(*a, st);
-        V(3, 1, 2, 8) V(3, 1, 4, 8) V(3, 1, 2, 16) V(3, 1, 4, 16)
-        V(3, 2, 2, 8) V(3, 2, 4, 8) V(3, 2, 2, 16)
+        V(3, 1, 1, 8) V(3, 1, 2, 8) V(3, 1, 4, 8)
+        V(3, 2, 1, 8) V(3, 2, 2, 8) V(3, 2, 4, 8)
         V(3, 3, 2, 8)
         V(1, 1, 2, 16) V(1, 1, 4, 16) V(1, 2, 2, 16) V(1, 2, 4, 16) V(1, 3, 2, 16)
 #undef V

@@ -32,11 +32,18 @@ def _ptr(t):
 
 
 class PackedConv(object):
-    """A conv weight packed for the MFMA kernel (layout private to the library)."""
-    __slots__ = ("data", "Cout", "Cin", "KS", "mtile")
+    """A conv weight packed for the MFMA kernel (layout private to the library).  Packings for other M-tile counts
+    are produced lazily from the kept OIHW copy: the launcher picks the M tile per call from the grid size."""
+    __slots__ = ("data", "Cout", "Cin", "KS", "mtile", "fixed", "_w", "_alts", "_ops")
 
-    def __init__(self, data, Cout, Cin, KS, mtile):
-        self.data, self.Cout, self.Cin, self.KS, self.mtile = data, Cout, Cin, KS, mtile
+    def __init__(self, data, Cout, Cin, KS, mtile, fixed=False, w=None, ops=None):
+        self.data, self.Cout, self.Cin, self.KS, self.mtile, self.fixed = data, Cout, Cin, KS, mtile, fixed
+        self._w, self._alts, self._ops = w, {mtile: data}, ops
+
+    def variant(self, mtile):
+        if mtile not in self._alts:
+            self._alts[mtile] = self._ops._pack_raw(self._w, mtile)
+        return self._alts[mtile]
 
 
 def default_mtile(Cout):
@@ -55,7 +62,7 @@ class HipOps(object):
         self.profile_keys, self.profile = None, {}
 
     def _launch(self, key, fn):
-        if self.profile_keys is None or key not in self.profile_keys:
+        if self.profile_keys is None or (self.profile_keys != "ALL" and key not in self.profile_keys):
             return fn()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         st = torch.cuda.current_stream(self.device)
@@ -83,17 +90,23 @@ class HipOps(object):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # ---- conv -----------------------------------------------------------------------------
+    def _pack_raw(self, w, mtile):
+        Cout, Cin, KS, _ = w.shape
+        n = self.lib.bfsr_conv_packed_size(Cout, Cin, KS, mtile)
+        packed = torch.empty(n, dtype=torch.float32)
+        _lib.check(self.lib.bfsr_pack_conv_weight(w.data_ptr(), Cout, Cin, KS, mtile, packed.data_ptr()), "pack_conv_weight")
+        return packed.to(self.device)
+
     def pack_conv(self, w, mtile=None, out_perm=None):
-        """w: [Cout,Cin,KS,KS] (any device).  out_perm: optional list, packed cout j = w[out_perm[j]]."""
+        """w: [Cout,Cin,KS,KS] (any device).  mtile=None lets the launcher choose 32-wide cout tiles per workgroup
+        at call time (2 by default, 1 when the grid would otherwise be too small to fill the chip)."""
         w = w.detach().to("cpu", torch.float32).contiguous()
         if out_perm is not None:
             w = w[torch.as_tensor(out_perm, dtype=torch.long)].contiguous()
         Cout, Cin, KS, _ = w.shape
+        fixed = mtile is not None
         mtile = mtile or default_mtile(Cout)
-        n = self.lib.bfsr_conv_packed_size(Cout, Cin, KS, mtile)
-        packed = torch.empty(n, dtype=torch.float32)
-        _lib.check(self.lib.bfsr_pack_conv_weight(w.data_ptr(), Cout, Cin, KS, mtile, packed.data_ptr()), "pack_conv_weight")
-        return PackedConv(packed.to(self.device), Cout, Cin, KS, mtile)
+        return PackedConv(self._pack_raw(w, mtile), Cout, Cin, KS, mtile, fixed=fixed, w=w, ops=self)
 
     def vec(self, t):
         """A per-channel parameter vector on the device."""
@@ -130,13 +143,20 @@ class HipOps(object):
         if Cin != pw.Cin or Cout != pw.Cout or (Hs << in_shift) != H or (Ws << in_shift) != W or x.shape[0] != out.shape[0]:
             raise ValueError("conv: shape mismatch x%s out%s weight(Cout=%d,Cin=%d) in_shift=%d" %
                              (tuple(x.shape), tuple(out.shape), pw.Cout, pw.Cin, in_shift))
+        mtile, wdata = pw.mtile, pw.data
+        if not pw.fixed and stage2 is None and mtile == 2 and pw.KS == 3:
+            # small grids: one 32-wide cout tile per workgroup doubles the workgroup count (measured on MI355X:
+            # RDB conv5 192->64 @ 8x160x160 goes from 99 to 120 TFLOP/s)
+            tiles = ((W + 31) // 32) * ((H + 7) // 8) * out.shape[0]
+            if tiles * ((Cout + 63) // 64) < 1280:
+                mtile, wdata = 1, pw.variant(1)
         a = _lib.BfsrConvArgs()
         a.x, a.x_bs, a.Cin = xp, xbs, Cin
-        a.w = pw.data.data_ptr()
+        a.w = wdata.data_ptr()
         a.y, a.y_bs, a.Cout = yp, ybs, Cout
         if stage2 is not None:
             a.w2, a.C2, a.epi2, a.act2 = pw2.data.data_ptr(), c_final, _ptr(epi2), act2
-        a.B, a.H, a.W, a.KS, a.in_shift, a.mtile = out.shape[0], H, W, pw.KS, in_shift, pw.mtile
+        a.B, a.H, a.W, a.KS, a.in_shift, a.mtile = out.shape[0], H, W, pw.KS, in_shift, mtile
         a.epi = _ptr(epi)
         if pre_add is not None:
             p, bs, c, h, w = _view(pre_add, "conv.pre_add")
@@ -151,7 +171,7 @@ class HipOps(object):
             p, bs, c, h, w = _view(res2, "conv.res2")
             assert (c, h, w) == (Cout, H, W)
             a.res2, a.res2_bs, a.alpha2 = p, bs, alpha2
-        key = ("conv", pw.KS, pw.mtile, Cin, Cout, out.shape[0], H, W) if stage2 is None else ("conv+1x1", Cin, Cout, out.shape[0], H, W)
+        key = ("conv", pw.KS, mtile, Cin, Cout, out.shape[0], H, W) if stage2 is None else ("conv+1x1", Cin, Cout, out.shape[0], H, W)
         _lib.check(self._launch(key, lambda: self.lib.bfsr_conv2d(C.byref(a), self._stream())), "conv2d")
         return out
 
@@ -180,14 +200,14 @@ class HipOps(object):
         xp, xbs, Cc, H, W = _view(x)
         yp, ybs, c2, h2, w2 = _view(y)
         assert (c2, h2, w2) == (4 * Cc, H // 2, W // 2)
-        _lib.check(self.lib.bfsr_squeeze2d(xp, xbs, yp, ybs, x.shape[0], Cc, H, W, self._stream()), "squeeze2d")
+        _lib.check(self._launch(("squeeze2d",) + tuple(x.shape), lambda: self.lib.bfsr_squeeze2d(xp, xbs, yp, ybs, x.shape[0], Cc, H, W, self._stream())), "squeeze2d")
         return y
 
     def unsqueeze2d(self, x, y):
         xp, xbs, Cc, H, W = _view(x)
         yp, ybs, c2, h2, w2 = _view(y)
         assert (c2 * 4, h2, w2) == (Cc, 2 * H, 2 * W)
-        _lib.check(self.lib.bfsr_unsqueeze2d(xp, xbs, yp, ybs, x.shape[0], Cc, H, W, self._stream()), "unsqueeze2d")
+        _lib.check(self._launch(("unsqueeze2d",) + tuple(x.shape), lambda: self.lib.bfsr_unsqueeze2d(xp, xbs, yp, ybs, x.shape[0], Cc, H, W, self._stream())), "unsqueeze2d")
         return y
 
     def split2d(self, h, src, dst, reverse):
@@ -195,14 +215,14 @@ class HipOps(object):
         sp, sbs, Cc, _, _ = _view(src)
         dp, dbs, _, _, _ = _view(dst)
         assert c2 == 2 * Cc and dst.shape == src.shape
-        _lib.check(self.lib.bfsr_split2d(hp, hbs, sp, sbs, dp, dbs, src.shape[0], Cc, H, W, int(bool(reverse)),
-                                         self._stream()), "split2d")
+        _lib.check(self._launch(("split2d",) + tuple(src.shape), lambda: self.lib.bfsr_split2d(hp, hbs, sp, sbs, dp, dbs, src.shape[0], Cc, H, W, int(bool(reverse)),
+                                         self._stream())), "split2d")
         return dst
 
     def standardize(self, x, y):
         xp, xbs, Cc, H, W = _view(x)
         yp, ybs, _, _, _ = _view(y)
-        _lib.check(self.lib.bfsr_standardize(xp, xbs, yp, ybs, x.shape[0], Cc, H, W, self._stream()), "standardize")
+        _lib.check(self._launch(("standardize",) + tuple(x.shape), lambda: self.lib.bfsr_standardize(xp, xbs, yp, ybs, x.shape[0], Cc, H, W, self._stream())), "standardize")
         return y
 
     def resize(self, x, y, mode, r_h, r_w, window=None):
@@ -211,14 +231,14 @@ class HipOps(object):
         yp, ybs, c2, OH, OW = _view(y)
         assert Cc == c2
         oy0, ox0, RH, RW = window if window is not None else (0, 0, OH, OW)
-        _lib.check(self.lib.bfsr_resize(xp, xbs, IH, IW, yp, ybs, OH, OW, RH, RW, oy0, ox0, x.shape[0], Cc, mode,
-                                        float(r_h), float(r_w), self._stream()), "resize")
+        _lib.check(self._launch(("resize", mode) + tuple(y.shape), lambda: self.lib.bfsr_resize(xp, xbs, IH, IW, yp, ybs, OH, OW, RH, RW, oy0, ox0, x.shape[0], Cc, mode,
+                                        float(r_h), float(r_w), self._stream())), "resize")
         return y
 
     def maxpool2(self, x, y):
         xp, xbs, Cc, H, W = _view(x)
         yp, ybs, _, _, _ = _view(y)
-        _lib.check(self.lib.bfsr_maxpool2(xp, xbs, yp, ybs, x.shape[0], Cc, H, W, self._stream()), "maxpool2")
+        _lib.check(self._launch(("maxpool2",) + tuple(x.shape), lambda: self.lib.bfsr_maxpool2(xp, xbs, yp, ybs, x.shape[0], Cc, H, W, self._stream())), "maxpool2")
         return y
 
     def axpb_clamp(self, x, y, a=1.0, b=0.0, lo=-3.4e38, hi=3.4e38, r=None):
@@ -227,8 +247,8 @@ class HipOps(object):
         rp, rbs = (None, 0)
         if r is not None:
             rp, rbs, _, _, _ = _view(r)
-        _lib.check(self.lib.bfsr_axpb_clamp(xp, xbs, rp, rbs, yp, ybs, x.shape[0], Cc, H, W, a, b, lo, hi,
-                                            self._stream()), "axpb_clamp")
+        _lib.check(self._launch(("axpb_clamp",) + tuple(x.shape), lambda: self.lib.bfsr_axpb_clamp(xp, xbs, rp, rbs, yp, ybs, x.shape[0], Cc, H, W, a, b, lo, hi,
+                                            self._stream())), "axpb_clamp")
         return y
 
     # ---- LINF-LP ------------------------------------------------------------------------------------
@@ -246,7 +266,7 @@ class HipOps(object):
         a.dy_neg, a.dy_pos, a.dx_neg, a.dx_pos = -1 * rx + e, 1 * rx + e, -1 * ry + e, 1 * ry + e
         a.clamp_lo, a.clamp_hi = -1 + 1e-6, 1 - 1e-6
         a.cy0, a.cy1, a.cx0, a.cx1 = -1 + 1.0 / h, 2 * (1.0 / h), -1 + 1.0 / w, 2 * (1.0 / w)
-        _lib.check(self.lib.bfsr_linf_features(C.byref(a), self._stream()), "linf_features")
+        _lib.check(self._launch(("linf_features",) + tuple(out.shape), lambda: self.lib.bfsr_linf_features(C.byref(a), self._stream())), "linf_features")
         return out
 
     def linf_flow(self, x, ai, y, lin_w, lin_b, layers, reverse, eps=1e-4):
@@ -265,14 +285,14 @@ class HipOps(object):
         pp, pbs, cp, qh, qw = _view(p)
         ip, ibs, Cc, H, W = _view(img)
         assert cp == Cc * ps * ps
-        _lib.check(self.lib.bfsr_patch_fold(pp, pbs, ip, ibs, p.shape[0], Cc, qh, qw, H, W, ps, self._stream()), "patch_fold")
+        _lib.check(self._launch(("patch_fold",) + tuple(img.shape), lambda: self.lib.bfsr_patch_fold(pp, pbs, ip, ibs, p.shape[0], Cc, qh, qw, H, W, ps, self._stream())), "patch_fold")
         return img
 
     def patch_unfold(self, img, p, ps):
         pp, pbs, cp, qh, qw = _view(p)
         ip, ibs, Cc, H, W = _view(img)
         assert cp == Cc * ps * ps
-        _lib.check(self.lib.bfsr_patch_unfold(ip, ibs, pp, pbs, p.shape[0], Cc, qh, qw, H, W, ps, self._stream()), "patch_unfold")
+        _lib.check(self._launch(("patch_unfold",) + tuple(img.shape), lambda: self.lib.bfsr_patch_unfold(ip, ibs, pp, pbs, p.shape[0], Cc, qh, qw, H, W, ps, self._stream())), "patch_unfold")
         return p
 
     def conv_direct(self, x, w, bias, y, stride, pad, act=ACT_NONE, slope=0.2):
@@ -282,6 +302,6 @@ class HipOps(object):
         KS = w.shape[2]
         assert w.is_contiguous() and tuple(w.shape[:2]) == (Cout, Cin)
         assert OH == (H + 2 * pad - KS) // stride + 1 and OW == (W + 2 * pad - KS) // stride + 1
-        _lib.check(self.lib.bfsr_conv2d_direct(xp, xbs, w.data_ptr(), _ptr(bias), yp, ybs, x.shape[0], Cin, Cout, H, W, KS,
-                                               stride, pad, act, slope, self._stream()), "conv2d_direct")
+        _lib.check(self._launch(("conv_direct",) + tuple(y.shape), lambda: self.lib.bfsr_conv2d_direct(xp, xbs, w.data_ptr(), _ptr(bias), yp, ybs, x.shape[0], Cin, Cout, H, W, KS,
+                                               stride, pad, act, slope, self._stream())), "conv2d_direct")
         return y

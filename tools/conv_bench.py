@@ -26,6 +26,8 @@ SHAPES = [
     ("rdb.conv4 160->32 @160", 8, 160, 32, 160, 160, 3, 1),
     ("rdb.conv4 B32", 32, 160, 32, 160, 160, 3, 1),
     ("rdb.conv5 B32", 32, 192, 64, 160, 160, 3, 2),
+    ("rdb.conv5 mt1", 8, 192, 64, 160, 160, 3, 1),
+    ("rdb.conv4 mt1 chk", 8, 160, 32, 160, 160, 3, 1),
     ("rdb.conv5 192->64 @160", 8, 192, 64, 160, 160, 3, 2),
     ("hoist L1 320->1024 @320", 8, 320, 1024, 320, 320, 3, 2),
     ("hoist L2 320->1024 @160", 8, 320, 1024, 160, 160, 3, 2),

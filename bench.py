@@ -72,11 +72,10 @@ def main():
     n_batches = max(2, min(args.steps + args.warmup, 4))
     batches = [ops.to_device(synth.lr_batch(1000 * rank + i, B, h, h)) for i in range(n_batches)]
 
-    # in-situ timing keys: dominant MFMA conv (hoisted level-1 3x3, 320 -> 16*64) and the level-1 inverse tail
+    # in-situ timing: every launch of the timed region is bracketed by HIP events on the launch stream (host cost
+    # ~2 us per launch, the loop stays GPU-bound); the dominant kernel is picked from the totals afterwards
     C1 = 12
-    Bl = B // max(1, min(args.lanes, B))          # per-lane sub-batch (launch granularity)
-    key_conv = ("conv", 3, 2, 320, 16 * 64, Bl, H // 2, H // 2)
-    key_tail = ("flow", 1, C1, Bl, H // 2, H // 2, True, True, True)
+    key_tail = ("flow", 1, C1, B, H // 2, H // 2, True, True, True)
     gathered = None
 
     def step(i):
@@ -90,7 +89,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    ops.profile_keys = {key_conv, key_tail}
+    ops.profile_keys = "ALL"
     ops.profile = {}
     bdist.barrier()
     torch.cuda.synchronize()
@@ -113,23 +112,38 @@ def main():
         ev = ops.profile.get(key, [])
         return (sum(s.elapsed_time(e) for s, e in ev) / len(ev), len(ev)) if ev else (None, 0)
 
-    conv_ms, conv_n = avg_ms(key_conv)
+    def launch_flop(k):
+        """algorithmic flops of one launch of the result-preserving schedule"""
+        if k[0] == "conv":
+            _, KS, _, Cin, Cout, b_, hh, ww = k
+            return 2.0 * Cin * KS * KS * Cout * b_ * hh * ww
+        if k[0] == "conv_up2":          # 2x2 source taps per output pixel (parity pre-summed weights)
+            _, _, Cin, Cout, b_, hh, ww = k
+            return 2.0 * Cin * 4 * Cout * b_ * hh * ww
+        return None
+
+    totals = []
+    for k, ev in ops.profile.items():
+        f = launch_flop(k)
+        if f is not None:
+            t = sum(s_.elapsed_time(e_) for s_, e_ in ev)
+            totals.append((t, k, f, len(ev)))
+    totals.sort(reverse=True)
+    step_ms_events = sum(sum(s_.elapsed_time(e_) for s_, e_ in ev) for ev in ops.profile.values()) / max(args.steps, 1)
+
+    def roof_entry(t, k, f, n):
+        a = f / (t / n * 1e-3) / 1e12
+        name = {"conv": "conv_mfma_kernel", "conv_up2": "conv_up2_kernel"}[k[0]]
+        return {"bound": "mfma", "kernel": "%s %s" % (name, list(k)), "achieved": round(a, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(a / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "algorithmic_flop_per_launch": f, "avg_launch_ms": round(t / n, 4), "launches": n,
+                "share_of_step": round(t / args.steps / step_ms_events, 4)}
+
+    roofline = roof_entry(*totals[0]) if totals else None
+    roofline_next = [roof_entry(*x) for x in totals[1:4]]
     tail_ms, tail_n = avg_ms(key_tail)
     hw1 = (H // 2) * (H // 2)
-    conv_flop = 2.0 * 320 * 9 * (16 * 64) * Bl * hw1                  # algorithmic flops of one launch
-    tail_bytes = 20.0 * C1 * Bl * hw1                                 # read z,h_aff,h_ft + write z
-    traffic = None          # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
-    tp = os.path.join(ROOT, "profiles", "r01_b_pmc_traffic.json")
-    if os.path.exists(tp) and B == 8 and h == 160:
-        traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
-    roofline = None
-    if conv_ms:
-        a = conv_flop / (conv_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "conv_mfma_kernel<3,2,4> (hoisted level-1 3x3 conv 320->1024)",
-                    "achieved": round(a, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(a / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_b_pmc_traffic.json)",
-                    "algorithmic_flop_per_launch": conv_flop, "avg_launch_ms": round(conv_ms, 4), "launches": conv_n}
+    tail_bytes = 20.0 * C1 * B * hw1                                 # read z,h_aff,h_ft + write z (SURVEY 8d)
     roof_tail = None
     if tail_ms:
         a = tail_bytes / (tail_ms * 1e-3) / 1e9
@@ -175,7 +189,8 @@ def main():
                                    "LP path: RRDB + encode + standardise + prior UNet + decode + clamp%s"
                                    % (B, h, h, H, H, ", + RCCL all-gather of outputs" if world > 1 else ""),
                        "parallelism": "dp%d" % world, "stream_lanes": args.lanes, "weights": "seeded synthetic (conditioned recipe)"},
-            "roofline": roofline, "roofline_coupling_inverse": roof_tail, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "roofline_next_kernels": roofline_next, "roofline_coupling_inverse": roof_tail,
+            "cpu_baseline": cpu_baseline,
             "parity": parity,
         }
         print(json.dumps(line))

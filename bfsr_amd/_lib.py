@@ -71,6 +71,9 @@ SYMBOLS = {
     "bfsr_conv_packed_size": (_LL, [_I, _I, _I, _I]),
     "bfsr_pack_conv_weight": (_I, [_VP, _I, _I, _I, _I, _VP]),
     "bfsr_conv2d": (_I, [C.POINTER(BfsrConvArgs), _VP]),
+    "bfsr_conv2d_up2": (_I, [C.POINTER(BfsrConvArgs), _VP]),
+    "bfsr_conv_packed_size_taps": (_LL, [_I, _I, _I, _I]),
+    "bfsr_pack_conv_weight_taps": (_I, [_VP, _I, _I, _I, _I, _VP]),
     "bfsr_flow_pointwise": (_I, [C.POINTER(BfsrFlowArgs), _VP]),
     "bfsr_squeeze2d": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
     "bfsr_unsqueeze2d": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),

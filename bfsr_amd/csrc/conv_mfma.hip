@@ -330,6 +330,171 @@ int launch_conv(const BfsrConvArgs& a, hipStream_t st)
     return (int)hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 'same' conv over a nearest-x2-upsampled input WITHOUT materialising the upsample and at 4/9 of the MACs:
+// for output pixel (2y+a, 2x+b) the nine taps of U = nearest_up2(T) land on only 2x2 source pixels
+//   rows  a=0: {y-1 <- w[-1], y <- w[0]+w[+1]}      a=1: {y <- w[-1]+w[0], y+1 <- w[+1]}      (same in x)
+// so the conv is four 2x2 convs on T (one per output parity) with pre-summed weights (16 [Cout x Cin] matrices,
+// packed as 16 "taps" t = (a*2+b)*4 + i*2+j by the host).  GEMM view per parity: M = cout, N = 32 consecutive SOURCE
+// columns (= every other output column), K = cin*4.  Workgroup = 4 waves = 4 source rows x 32 source columns ->
+// 8 x 64 output pixels; each wave keeps acc[parity][MR].  Used for the hoisted level-1 coupling convs of SRFlow, whose
+// 256 stacked-RRDB conditioning channels are the LR-resolution block taps upsampled x2 (SRFlowNet_arch.py:137).
+template <int MR>
+__global__ __launch_bounds__(256, 2) void conv_up2_kernel(BfsrConvArgs p, int tiles_x, int tiles_xy, int groups)
+{
+    constexpr int CK = 8, TH = 4, TW = 32, IH = TH + 2, PW = TW + 2, NPOS = IH * PW, TAPS = 16, MW = MR * 32;
+    constexpr int WCHUNK = CK * TAPS * MW;
+    static_assert(NPOS <= 256, "one staged position per thread");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sW = smem;                                // [CK][16][MW]
+    float* sIn = smem + WCHUNK;                      // [CK][IH][PW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int bid = blockIdx.x;
+    const int cg = bid % groups; bid /= groups;
+    const int tile = bid % tiles_xy; const int b = bid / tiles_xy;
+    const int x0 = (tile % tiles_x) * TW, y0 = (tile / tiles_x) * TH;     // source coordinates
+    const int H = p.H, W = p.W, Hs = H >> 1, Ws = W >> 1;
+    const long long cs_in = (long long)Hs * Ws;
+    const float* __restrict__ xin = p.x + (long long)b * p.x_bs;
+    const int Cin = p.Cin;
+    const int cin_pad = (Cin + CIN_ALIGN - 1) / CIN_ALIGN * CIN_ALIGN;
+    const int cin_loop = (Cin + CK - 1) / CK * CK;
+    const float* __restrict__ wg = p.w + (long long)cg * cin_pad * TAPS * MW;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0,
+                                                                           (unsigned)((long long)Cin * cs_in * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wg), 0,
+                                                                          (unsigned)(cin_pad * TAPS * MW * 4), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned voff;
+    {
+        const int r = tid / PW, c = tid - r * PW;
+        const int gy = y0 + r - 1, gx = x0 + c - 1;
+        const bool ok = tid < NPOS && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
+        voff = ok ? (unsigned)(gy * Ws + gx) * 4u : OOB;
+    }
+    const unsigned cs_bytes = (unsigned)(cs_in * 4);
+    f32x16 acc[4][MR];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][m][r] = 0.f;
+
+    constexpr int WV = (WCHUNK / 4 + 255) / 256;
+    float vin[CK];
+    float4 vw[WV];
+    auto load_chunk = [&](int c0) {
+        const unsigned sbase = (unsigned)c0 * cs_bytes;
+#pragma unroll
+        for (int c = 0; c < CK; ++c)
+            vin[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, sbase + (unsigned)c * cs_bytes, 0));
+        const unsigned wbase = (unsigned)c0 * (TAPS * MW * 4);
+#pragma unroll
+        for (int i = 0; i < WV; ++i)
+            vw[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(tid + i * 256) * 16u, wbase, 0));
+    };
+    load_chunk(0);
+    for (int c0 = 0; c0 < cin_loop; c0 += CK) {
+        __syncthreads();
+        if (tid < NPOS) {
+#pragma unroll
+            for (int c = 0; c < CK; ++c) sIn[c * NPOS + tid] = vin[c];
+        }
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int idx = tid + i * 256;
+            if (i < WV - 1 || idx < WCHUNK / 4) reinterpret_cast<float4*>(sW)[idx] = vw[i];
+        }
+        __syncthreads();
+        if (c0 + CK < cin_loop) load_chunk(c0 + CK);
+#pragma unroll
+        for (int kk = 0; kk < CK / 2; ++kk) {
+            const int c = 2 * kk + lhi;
+            const float* inC = sIn + c * NPOS + wave * PW + l31;       // source row (y0+wave) - 1 .. + 1, col x - 1 .. + 1
+            const float* wC = sW + c * TAPS * MW + l31;
+            float bf[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) bf[r][d] = inC[r * PW + d];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int t = (a * 2 + bb) * 4 + i * 2 + j;
+#pragma unroll
+                            for (int m = 0; m < MR; ++m)
+                                acc[a * 2 + bb][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wC[t * MW + m * 32], bf[a + i][bb + j],
+                                                                                       acc[a * 2 + bb][m], 0, 0, 0);
+                        }
+        }
+    }
+    // ---- epilogue (same stage order as conv_mfma_kernel)
+    const int sx = x0 + l31, sy = y0 + wave;
+    if (sx >= Ws || sy >= Hs) return;
+    const long long HW = (long long)H * W;
+    const float slope = p.act == BFSR_ACT_NONE ? 1.f : (p.act == BFSR_ACT_RELU ? 0.f : p.slope);
+    const float4* __restrict__ epi = reinterpret_cast<const float4*>(p.epi);
+    const unsigned out_bytes = (unsigned)((long long)p.Cout * HW * 4);
+    auto tensor_rsrc = [&](const float* t, long long bs) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(t ? t + (long long)b * bs : p.y), 0, t ? out_bytes : 0u, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rs_pre = tensor_rsrc(p.pre_add, p.pre_add_bs);
+    const __amdgpu_buffer_rsrc_t rs_r1 = tensor_rsrc(p.res1, p.res1_bs);
+    const __amdgpu_buffer_rsrc_t rs_r2 = tensor_rsrc(p.res2, p.res2_bs);
+    const bool tensors = p.pre_add || p.res1 || p.res2;
+    const float a1 = p.res1 ? p.alpha1 : 1.f, a2 = p.res2 ? p.alpha2 : 1.f;
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = (cg * MR + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (co >= p.Cout) continue;
+            float4 q0 = make_float4(0.f, 0.f, 1.f, 0.f); float q1 = 1.f;
+            if (epi) { q0 = epi[co * 2]; q1 = epi[co * 2 + 1].x; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long long o = (long long)co * HW + (long long)(2 * sy + (q >> 1)) * W + 2 * sx + (q & 1);
+                float v = acc[q][m][r];
+                v += q0.x;
+                if (tensors) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_pre, (unsigned)o * 4u, 0, 0));
+                v += q0.y; v *= q0.z; v += q0.w;
+                v = v > 0.f ? v : v * slope;
+                v *= q1;
+                if (tensors) {
+                    v = a1 * v + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r1, (unsigned)o * 4u, 0, 0));
+                    v = a2 * v + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r2, (unsigned)o * 4u, 0, 0));
+                }
+                p.y[(long long)b * p.y_bs + o] = v;
+            }
+        }
+}
+
+template <int MR>
+int launch_conv_up2(const BfsrConvArgs& a, hipStream_t st)
+{
+    constexpr int LDS = (8 * 16 * MR * 32 + 8 * 6 * 34) * 4;
+    const int Hs = a.H / 2, Ws = a.W / 2;
+    const int tiles_x = (Ws + 31) / 32, tiles_y = (Hs + 3) / 4;
+    const int groups = ((a.Cout + 31) / 32 + MR - 1) / MR;
+    const long long nblk = (long long)tiles_x * tiles_y * groups * a.B;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return -1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up2_kernel<MR>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_up2_kernel<MR>), dim3((unsigned)nblk), dim3(256), LDS, st, a, tiles_x, tiles_x * tiles_y, groups);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" long long bfsr_conv_packed_size(int Cout, int Cin, int KS, int mtile)
@@ -337,6 +502,43 @@ extern "C" long long bfsr_conv_packed_size(int Cout, int Cin, int KS, int mtile)
     const int cin_pad = (Cin + CIN_ALIGN - 1) / CIN_ALIGN * CIN_ALIGN;
     const int groups = ((Cout + 31) / 32 + mtile - 1) / mtile;
     return (long long)groups * cin_pad * KS * KS * mtile * 32;
+}
+
+extern "C" int bfsr_pack_conv_weight_taps(const float* w, int Cout, int Cin, int T, int mtile, float* packed)
+{
+    // w [Cout][Cin][T] -> [cout_group][cin_pad][T][mtile*32], zero padded
+    if (T < 1 || mtile < 1) return -1;
+    const int cin_pad = (Cin + CIN_ALIGN - 1) / CIN_ALIGN * CIN_ALIGN;
+    const int MW = mtile * 32;
+    const int groups = ((Cout + 31) / 32 + mtile - 1) / mtile;
+    const long long n = (long long)groups * cin_pad * T * MW;
+    for (long long i = 0; i < n; ++i) packed[i] = 0.f;
+    for (int co = 0; co < Cout; ++co) {
+        const int g = co / MW, m = co % MW;
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int t = 0; t < T; ++t)
+                packed[(((long long)g * cin_pad + ci) * T + t) * MW + m] = w[((long long)co * Cin + ci) * T + t];
+    }
+    return 0;
+}
+
+extern "C" long long bfsr_conv_packed_size_taps(int Cout, int Cin, int T, int mtile)
+{
+    const int cin_pad = (Cin + CIN_ALIGN - 1) / CIN_ALIGN * CIN_ALIGN;
+    const int groups = ((Cout + 31) / 32 + mtile - 1) / mtile;
+    return (long long)groups * cin_pad * T * mtile * 32;
+}
+
+extern "C" int bfsr_conv2d_up2(const BfsrConvArgs* a, void* stream)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!a || !a->x || !a->w || !a->y || a->w2) return -1;
+    if (a->B <= 0 || a->H <= 0 || a->W <= 0 || (a->H & 1) || (a->W & 1) || a->Cin <= 0 || a->Cout <= 0) return -1;
+    if ((long long)a->Cin * (a->H / 2) * (a->W / 2) * 4 >= (1LL << 31)) return -1;
+    if ((long long)a->Cout * a->H * a->W * 4 >= (1LL << 31)) return -1;
+    if (a->mtile == 2) return launch_conv_up2<2>(*a, st);
+    if (a->mtile == 1) return launch_conv_up2<1>(*a, st);
+    return -1;
 }
 
 extern "C" int bfsr_pack_conv_weight(const float* w, int Cout, int Cin, int KS, int mtile, float* packed)

@@ -108,6 +108,53 @@ class HipOps(object):
         mtile = mtile or default_mtile(Cout)
         return PackedConv(self._pack_raw(w, mtile), Cout, Cin, KS, mtile, fixed=fixed, w=w, ops=self)
 
+    @staticmethod
+    def presum_up2_weights(w):
+        """[Cout,Cin,3,3] -> [Cout,Cin,16]: the 3x3 taps folded onto the 2x2 source pixels each output parity of a
+        nearest-x2-upsampled input touches (tap t = (a*2+b)*4 + i*2+j; include/bfsr_hip.h bfsr_conv2d_up2)."""
+        R = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}       # (parity, source offset) -> kernel rows
+        w = w.detach().to("cpu", torch.float32)
+        out = torch.zeros(w.shape[0], w.shape[1], 16, dtype=torch.float32)
+        for a in (0, 1):
+            for b in (0, 1):
+                for i in (0, 1):
+                    for j in (0, 1):
+                        acc = None
+                        for dy in R[(a, i)]:
+                            for dx in R[(b, j)]:
+                                acc = w[:, :, dy, dx].clone() if acc is None else acc + w[:, :, dy, dx]
+                        out[:, :, (a * 2 + b) * 4 + i * 2 + j] = acc
+        return out.contiguous()
+
+    def pack_conv_up2(self, w, mtile=2):
+        """Pack a 3x3 weight for conv_up2 (conv over a nearest-x2-upsampled input at 4/9 of the MACs)."""
+        w16 = self.presum_up2_weights(w)
+        Cout, Cin, _ = w16.shape
+        n = self.lib.bfsr_conv_packed_size_taps(Cout, Cin, 16, mtile)
+        packed = torch.empty(n, dtype=torch.float32)
+        _lib.check(self.lib.bfsr_pack_conv_weight_taps(w16.data_ptr(), Cout, Cin, 16, mtile, packed.data_ptr()), "pack_taps")
+        return PackedConv(packed.to(self.device), Cout, Cin, 3, mtile, fixed=True)
+
+    def conv_up2(self, x, pw, out, epi=None, pre_add=None, act=ACT_NONE, slope=0.2):
+        """out [B,Cout,2h,2w] = epilogue(conv3x3(nearest_up2(x [B,Cin,h,w])))."""
+        xp, xbs, Cin, h, w = _view(x, "conv_up2.x")
+        yp, ybs, Cout, H, W = _view(out, "conv_up2.out")
+        if (Cin, Cout, 2 * h, 2 * w) != (pw.Cin, pw.Cout, H, W) or x.shape[0] != out.shape[0]:
+            raise ValueError("conv_up2: shape mismatch x%s out%s" % (tuple(x.shape), tuple(out.shape)))
+        a = _lib.BfsrConvArgs()
+        a.x, a.x_bs, a.Cin = xp, xbs, Cin
+        a.w = pw.data.data_ptr()
+        a.y, a.y_bs, a.Cout = yp, ybs, Cout
+        a.B, a.H, a.W, a.KS, a.mtile = out.shape[0], H, W, 3, pw.mtile
+        a.epi, a.act, a.slope = _ptr(epi), act, slope
+        if pre_add is not None:
+            pp, bs, c, hh, ww = _view(pre_add, "conv_up2.pre_add")
+            assert (c, hh, ww) == (Cout, H, W)
+            a.pre_add, a.pre_add_bs = pp, bs
+        key = ("conv_up2", pw.mtile, Cin, Cout, out.shape[0], H, W)
+        _lib.check(self._launch(key, lambda: self.lib.bfsr_conv2d_up2(C.byref(a), self._stream())), "conv2d_up2")
+        return out
+
     def vec(self, t):
         """A per-channel parameter vector on the device."""
         return t.detach().reshape(-1).to(device=self.device, dtype=torch.float32).contiguous()

@@ -197,9 +197,18 @@ class SRFlowEngine(object):
             sh = torch.cat([self.steps[i].ft0_shift for i in idxs], 0)
             sc = torch.cat([self.steps[i].ft0_scale for i in idxs], 0)
             wa = torch.cat([self.steps[i].aff0_ft_w for i in idxs], 0)
-            self.hoist[level] = dict(idxs=idxs,
-                                     ft0=_ConvP(ops, wf, aff_shift=sh, aff_scale=sc, mtile=2),
-                                     aff0=_ConvP(ops, wa, mtile=2))
+            hz = dict(idxs=idxs, up2=False)
+            if self._taps_up2(level):
+                # the 256 stacked-RRDB channels of this level are the LR-resolution taps upsampled x2: their share of the
+                # 3x3 conv runs on the LR grid with parity pre-summed weights (4/9 of the MACs, nothing materialised);
+                # the 64 native-resolution key channels go through the normal conv, which adds the partial sum.
+                hz.update(up2=True,
+                          ft0_taps=ops.pack_conv_up2(wf[:, 64:].contiguous()), aff0_taps=ops.pack_conv_up2(wa[:, 64:].contiguous()),
+                          ft0=_ConvP(ops, wf[:, :64].contiguous(), aff_shift=sh, aff_scale=sc, mtile=2),
+                          aff0=_ConvP(ops, wa[:, :64].contiguous(), mtile=2))
+            else:
+                hz.update(ft0=_ConvP(ops, wf, aff_shift=sh, aff_scale=sc, mtile=2), aff0=_ConvP(ops, wa, mtile=2))
+            self.hoist[level] = hz
             for i in idxs:
                 del self.steps[i].ft0_w, self.steps[i].aff0_ft_w
 
@@ -211,6 +220,19 @@ class SRFlowEngine(object):
         c.rrdb = self.rrdb.fork()
         c._cond_key, c._cond = None, None
         return c
+
+    def _level_shift(self, level):
+        return _KEY_SHIFT.get(self.level_names[level])
+
+    def _lr_level(self):
+        """The flow level whose conditional lives at LR resolution (holds the block taps un-resized), or None."""
+        for l in range(1, self.L + 1):
+            if self._level_shift(l) == 0:
+                return l
+        return None
+
+    def _taps_up2(self, level):
+        return bool(self.concat and self.block_idxs and self._level_shift(level) == 1 and self._lr_level() is not None)
 
     # ------------------------------------------------------------------------------------------
     def _level_hw(self, level, h, w):
@@ -231,7 +253,8 @@ class SRFlowEngine(object):
         ft = {}
         for level in range(1, self.L + 1):
             hl, wl = self._level_hw(level, h, w)
-            ft[level] = ws.get("ft%d" % level, B, self.n_cond, hl, wl)
+            # levels whose taps are consumed through conv_up2 only keep their 64 key channels
+            ft[level] = ws.get("ft%d" % level, B, 64 if self._taps_up2(level) else self.n_cond, hl, wl)
         name2level = {self.level_names[l]: l for l in range(1, self.L + 1)}
 
         def key_view(name):
@@ -245,6 +268,8 @@ class SRFlowEngine(object):
             if idx in self.block_idxs and self.concat:
                 k = self.block_idxs.index(idx)
                 for level in range(1, self.L + 1):
+                    if self._taps_up2(level):
+                        continue
                     dst = ft[level][:, 64 * (k + 1): 64 * (k + 2)]
                     ops.resize(fea, dst, MODE_NEAREST, float(h) / dst.shape[2], float(w) / dst.shape[3])
 
@@ -269,8 +294,15 @@ class SRFlowEngine(object):
             hid = ws.get("hoist_hid%d" % level, B, K * 64, hl, wl)
             pre_aff = ws.get("pre_aff%d" % level, B, K * 64, hl, wl)
             h_ft = ws.get("h_ft%d" % level, B, K * 2 * Cz, hl, wl)
-            hz["ft0"].run(ops, f, hid, act=ACT_RELU)
-            hz["aff0"].run(ops, f, pre_aff)
+            if hz["up2"]:
+                taps = ft[self._lr_level()][:, 64:]
+                ops.conv_up2(taps, hz["ft0_taps"], hid)
+                hz["ft0"].run(ops, f, hid, pre_add=hid, act=ACT_RELU)
+                ops.conv_up2(taps, hz["aff0_taps"], pre_aff)
+                hz["aff0"].run(ops, f, pre_aff, pre_add=pre_aff)
+            else:
+                hz["ft0"].run(ops, f, hid, act=ACT_RELU)
+                hz["aff0"].run(ops, f, pre_aff)
             for k, i in enumerate(hz["idxs"]):
                 st = self.steps[i]
                 hk = hid[:, 64 * k: 64 * (k + 1)]

@@ -72,6 +72,16 @@ long long bfsr_conv_packed_size(int Cout, int Cin, int KS, int mtile);
 int bfsr_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int KS, int mtile, float* packed);
 int bfsr_conv2d(const BfsrConvArgs* a, void* stream);
 
+/* 3x3 'same' conv of nearest_up2(x) computed on the SOURCE resolution at 4/9 of the MACs: x is [B,Cin,H/2,W/2], y is
+ * [B,Cout,H,W]; `w` holds the 16 pre-summed [Cout x Cin] matrices, one per (output parity a,b; source offset i,j),
+ * tap index t = (a*2+b)*4 + i*2+j, packed with bfsr_pack_conv_weight_taps(T=16).  Row rule (same for columns):
+ * a=0: i=0 <- w[dy=-1], i=1 <- w[0]+w[+1];  a=1: i=0 <- w[-1]+w[0], i=1 <- w[+1].  Same epilogue as bfsr_conv2d.
+ * Replaces conv(F.interpolate(x, scale_factor=2, mode='nearest')) patterns: the x2-upsampled stacked RRDB taps in the
+ * level conditionals (SRFlowNet_arch.py:137 + FlowAffineCouplingsAblation.py:108-119), RRDBNet_arch.py:105-117. */
+int bfsr_conv2d_up2(const BfsrConvArgs* a, void* stream);
+long long bfsr_conv_packed_size_taps(int Cout, int Cin, int T, int mtile);
+int bfsr_pack_conv_weight_taps(const float* w_oit, int Cout, int Cin, int T, int mtile, float* packed);
+
 /* ---- fused flow-step pointwise chain -----------------------------------------------------------
  * One read of z / h_aff / h_ft, one write of z (the HBM-roofline "coupling inverse" kernel of
  * BASELINE.json).  replaces, per FlowStep (SRFlow-LP/code/models/modules/):

@@ -44,6 +44,13 @@ class CpuOps(object):
             w = w[torch.as_tensor(out_perm)].contiguous()
         return PackedConv(w, mtile)
 
+    def pack_conv_up2(self, w, mtile=2):
+        return PackedConv(w.detach().to(torch.float32).contiguous().clone(), mtile)
+
+    def conv_up2(self, x, pw, out, epi=None, pre_add=None, act=ACT_NONE, slope=0.2):
+        """Semantics: the plain 3x3 conv over the materialised nearest-x2 upsample (original weights)."""
+        return self.conv(F.interpolate(x, scale_factor=2, mode="nearest"), pw, out, epi=epi, pre_add=pre_add, act=act, slope=slope)
+
     def pack_epilogue(self, Cout, bias=None, aff_shift=None, aff_scale=None, aff_post=None, post_scale=None):
         vs = dict(bias=bias, aff_shift=aff_shift, aff_scale=aff_scale, aff_post=aff_post, post_scale=post_scale)
         if all(v is None for v in vs.values()):

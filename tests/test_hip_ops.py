@@ -224,3 +224,20 @@ def test_conv_fused_1x1_second_stage(hip, case):
                    aff_shift=sh1, aff_scale=sc1, act=1,
                    stage2=(hip.pack_conv(w2, 2), hip.pack_epilogue(C2, aff_shift=sh2, aff_scale=sc2), 1))
     close(out, ref, 2e-5, "fused 3x3+1x1 %s" % (case,))
+
+
+@pytest.mark.parametrize("case", [(2, 70, 64, 9, 21, 2), (1, 256, 128, 12, 40, 2), (1, 16, 24, 5, 33, 1), (2, 64, 64, 16, 32, 2)])
+def test_conv_up2_parity_decomposition(hip, case):
+    """conv3x3(nearest_up2(x)) computed on the source grid with pre-summed weights == the materialised computation."""
+    B, Cin, Cout, h, w_, mt = case
+    x, w = rnd(110, B, Cin, h, w_), rnd(111, Cout, Cin, 3, 3, scale=1.0 / np.sqrt(Cin * 9))
+    pre = rnd(112, B, Cout, 2 * h, 2 * w_)
+    sh, sc = rnd(113, Cout, scale=0.2), torch.exp(rnd(114, Cout, scale=0.2))
+    ref = CPU.conv_up2(x, CPU.pack_conv_up2(w, mt), torch.empty(B, Cout, 2 * h, 2 * w_))
+    out = hip.conv_up2(hip.to_device(x), hip.pack_conv_up2(w, mt), hip.empty(B, Cout, 2 * h, 2 * w_))
+    close(out, ref, 2e-5, "conv_up2 plain %s" % (case,))
+    epi_c = CPU.pack_epilogue(Cout, aff_shift=sh, aff_scale=sc)
+    ref = CPU.conv_up2(x, CPU.pack_conv_up2(w, mt), torch.empty(B, Cout, 2 * h, 2 * w_), epi=epi_c, pre_add=pre, act=1)
+    out = hip.conv_up2(hip.to_device(x), hip.pack_conv_up2(w, mt), hip.empty(B, Cout, 2 * h, 2 * w_),
+                       epi=hip.pack_epilogue(Cout, aff_shift=sh, aff_scale=sc), pre_add=hip.to_device(pre), act=1)
+    close(out, ref, 2e-5, "conv_up2 epilogue %s" % (case,))

@@ -26,6 +26,7 @@ class BfsrConvArgs(C.Structure):
         ("res2", C.c_void_p), ("res2_bs", C.c_longlong), ("alpha2", C.c_float),
         ("tune", C.c_int),
         ("w2", C.c_void_p), ("C2", C.c_int), ("epi2", C.c_void_p), ("act2", C.c_int),
+        ("x2", C.c_void_p), ("x2_bs", C.c_longlong), ("Cin2", C.c_int), ("w_x2", C.c_void_p),
     ]
 
 

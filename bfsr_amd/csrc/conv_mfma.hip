@@ -436,6 +436,96 @@ __global__ __launch_bounds__(256, 2) void conv_up2_kernel(BfsrConvArgs p, int ti
                         }
         }
     }
+    // ---- optional second K loop: `p.x2` = channels that live at OUTPUT resolution (the level's own 64 key
+    // channels), ordinary 3x3 taps with weights `p.w_x2` ([cin_pad2][9][MW]); they accumulate into the same
+    // parity accumulators, so the whole conv over cat[key, nearest_up2(taps)] is one kernel and one store.
+    if (p.x2) {
+        constexpr int KIH = 2 * TH + 2, KPW = 2 * TW + 2, KNPOS = KIH * KPW, KPPT = (KNPOS + 255) / 256;
+        constexpr int KW = CK * 9 * MW;                           // floats of key weights per chunk
+        float* kW = smem;                                         // [CK][9][MW]
+        float* kIn = smem + KW;                                   // [CK][KIH][KPW]
+        const int C2 = p.Cin2;
+        const int cin2_pad = (C2 + CIN_ALIGN - 1) / CIN_ALIGN * CIN_ALIGN, cin2_loop = (C2 + CK - 1) / CK * CK;
+        const long long cs2 = (long long)H * W;
+        const float* __restrict__ x2 = p.x2 + (long long)b * p.x2_bs;
+        const float* __restrict__ wk = p.w_x2 + (long long)cg * cin2_pad * 9 * MW;
+        const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x2), 0,
+                                                                              (unsigned)((long long)C2 * cs2 * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_wk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wk), 0,
+                                                                               (unsigned)(cin2_pad * 9 * MW * 4), 0x00020000);
+        unsigned kvoff[KPPT];
+#pragma unroll
+        for (int i = 0; i < KPPT; ++i) {
+            const int pos = tid + i * 256;
+            const int r = pos / KPW, c = pos - r * KPW;
+            const int gy = 2 * y0 + r - 1, gx = 2 * x0 + c - 1;
+            const bool ok = pos < KNPOS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            kvoff[i] = ok ? (unsigned)(gy * W + gx) * 4u : OOB;
+        }
+        const unsigned cs2_bytes = (unsigned)(cs2 * 4);
+        constexpr int KWV = (KW / 4 + 255) / 256;
+        float kin[KPPT][CK];
+        float4 kw[KWV];
+        auto kload = [&](int c0) {
+#pragma unroll
+            for (int c = 0; c < CK; ++c)
+#pragma unroll
+                for (int i = 0; i < KPPT; ++i)
+                    kin[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_k, kvoff[i], (unsigned)(c0 + c) * cs2_bytes, 0));
+#pragma unroll
+            for (int i = 0; i < KWV; ++i)
+                kw[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_wk, (unsigned)(tid + i * 256) * 16u,
+                                                                                        (unsigned)c0 * (9 * MW * 4), 0));
+        };
+        kload(0);
+        for (int c0 = 0; c0 < cin2_loop; c0 += CK) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < KPPT; ++i) {
+                const int pos = tid + i * 256;
+                if (i < KPPT - 1 || pos < KNPOS) {
+#pragma unroll
+                    for (int c = 0; c < CK; ++c) kIn[c * KNPOS + pos] = kin[i][c];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < KWV; ++i) {
+                const int idx = tid + i * 256;
+                if (i < KWV - 1 || idx < KW / 4) reinterpret_cast<float4*>(kW)[idx] = kw[i];
+            }
+            __syncthreads();
+            if (c0 + CK < cin2_loop) kload(c0 + CK);
+#pragma unroll
+            for (int kk = 0; kk < CK / 2; ++kk) {
+                const int c = 2 * kk + lhi;
+                // this wave's source row `wave` covers output rows 2*wave, 2*wave+1: tile rows 2*wave .. 2*wave+3
+                const float* inC = kIn + c * KNPOS + (2 * wave) * KPW + 2 * l31;
+                const float* wC = kW + c * 9 * MW + l31;
+                float bk[4][4];                                   // [tile row][column offset], stride-2 lanes
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) bk[r][d] = inC[r * KPW + d];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        float aw[MR];
+#pragma unroll
+                        for (int m = 0; m < MR; ++m) aw[m] = wC[(dy * 3 + dx) * MW + m * 32];
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                                for (int m = 0; m < MR; ++m)
+                                    acc[a * 2 + bb][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[m], bk[a + dy][bb + dx],
+                                                                                           acc[a * 2 + bb][m], 0, 0, 0);
+                    }
+            }
+        }
+    }
+
     // ---- epilogue (same stage order as conv_mfma_kernel)
     const int sx = x0 + l31, sy = y0 + wave;
     if (sx >= Ws || sy >= Hs) return;
@@ -480,7 +570,8 @@ __global__ __launch_bounds__(256, 2) void conv_up2_kernel(BfsrConvArgs p, int ti
 template <int MR>
 int launch_conv_up2(const BfsrConvArgs& a, hipStream_t st)
 {
-    constexpr int LDS = (8 * 16 * MR * 32 + 8 * 6 * 34) * 4;
+    constexpr int LDS_T = (8 * 16 * MR * 32 + 8 * 6 * 34) * 4, LDS_K = (8 * 9 * MR * 32 + 8 * 10 * 66) * 4;
+    constexpr int LDS = LDS_T > LDS_K ? LDS_T : LDS_K;
     const int Hs = a.H / 2, Ws = a.W / 2;
     const int tiles_x = (Ws + 31) / 32, tiles_y = (Hs + 3) / 4;
     const int groups = ((a.Cout + 31) / 32 + MR - 1) / MR;

@@ -135,8 +135,10 @@ class HipOps(object):
         _lib.check(self.lib.bfsr_pack_conv_weight_taps(w16.data_ptr(), Cout, Cin, 16, mtile, packed.data_ptr()), "pack_taps")
         return PackedConv(packed.to(self.device), Cout, Cin, 3, mtile, fixed=True)
 
-    def conv_up2(self, x, pw, out, epi=None, pre_add=None, act=ACT_NONE, slope=0.2):
-        """out [B,Cout,2h,2w] = epilogue(conv3x3(nearest_up2(x [B,Cin,h,w])))."""
+    def conv_up2(self, x, pw, out, epi=None, pre_add=None, act=ACT_NONE, slope=0.2, key=None):
+        """out [B,Cout,2h,2w] = epilogue(conv3x3(nearest_up2(x [B,Cin,h,w]))).
+        key = (x2 [B,Cin2,2h,2w], PackedConv 3x3 with the same mtile): extra input channels at output resolution,
+        i.e. the conv over cat[x2, nearest_up2(x)] in one kernel."""
         xp, xbs, Cin, h, w = _view(x, "conv_up2.x")
         yp, ybs, Cout, H, W = _view(out, "conv_up2.out")
         if (Cin, Cout, 2 * h, 2 * w) != (pw.Cin, pw.Cout, H, W) or x.shape[0] != out.shape[0]:
@@ -151,7 +153,14 @@ class HipOps(object):
             pp, bs, c, hh, ww = _view(pre_add, "conv_up2.pre_add")
             assert (c, hh, ww) == (Cout, H, W)
             a.pre_add, a.pre_add_bs = pp, bs
-        key = ("conv_up2", pw.mtile, Cin, Cout, out.shape[0], H, W)
+        cin2 = 0
+        if key is not None:
+            x2, pk = key
+            a.x2, a.x2_bs, cin2, h2, w2 = _view(x2, "conv_up2.x2")
+            if (h2, w2) != (H, W) or pk.Cin != cin2 or pk.Cout != Cout or pk.KS != 3 or pk.mtile != pw.mtile:
+                raise ValueError("conv_up2: bad key input")
+            a.Cin2, a.w_x2 = cin2, pk.data.data_ptr()
+        key = ("conv_up2", pw.mtile, Cin, Cout, out.shape[0], H, W, cin2)
         _lib.check(self._launch(key, lambda: self.lib.bfsr_conv2d_up2(C.byref(a), self._stream())), "conv2d_up2")
         return out
 

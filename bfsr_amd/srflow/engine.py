@@ -201,11 +201,11 @@ class SRFlowEngine(object):
             if self._taps_up2(level):
                 # the 256 stacked-RRDB channels of this level are the LR-resolution taps upsampled x2: their share of the
                 # 3x3 conv runs on the LR grid with parity pre-summed weights (4/9 of the MACs, nothing materialised);
-                # the 64 native-resolution key channels go through the normal conv, which adds the partial sum.
+                # the 64 native-resolution key channels are convolved into the same accumulators by the same kernel.
                 hz.update(up2=True,
                           ft0_taps=ops.pack_conv_up2(wf[:, 64:].contiguous()), aff0_taps=ops.pack_conv_up2(wa[:, 64:].contiguous()),
-                          ft0=_ConvP(ops, wf[:, :64].contiguous(), aff_shift=sh, aff_scale=sc, mtile=2),
-                          aff0=_ConvP(ops, wa[:, :64].contiguous(), mtile=2))
+                          ft0_key=ops.pack_conv(wf[:, :64].contiguous(), 2), aff0_key=ops.pack_conv(wa[:, :64].contiguous(), 2),
+                          ft0_epi=ops.pack_epilogue(wf.shape[0], aff_shift=sh, aff_scale=sc))
             else:
                 hz.update(ft0=_ConvP(ops, wf, aff_shift=sh, aff_scale=sc, mtile=2), aff0=_ConvP(ops, wa, mtile=2))
             self.hoist[level] = hz
@@ -296,10 +296,8 @@ class SRFlowEngine(object):
             h_ft = ws.get("h_ft%d" % level, B, K * 2 * Cz, hl, wl)
             if hz["up2"]:
                 taps = ft[self._lr_level()][:, 64:]
-                ops.conv_up2(taps, hz["ft0_taps"], hid)
-                hz["ft0"].run(ops, f, hid, pre_add=hid, act=ACT_RELU)
-                ops.conv_up2(taps, hz["aff0_taps"], pre_aff)
-                hz["aff0"].run(ops, f, pre_aff, pre_add=pre_aff)
+                ops.conv_up2(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, key=(f, hz["ft0_key"]))
+                ops.conv_up2(taps, hz["aff0_taps"], pre_aff, key=(f, hz["aff0_key"]))
             else:
                 hz["ft0"].run(ops, f, hid, act=ACT_RELU)
                 hz["aff0"].run(ops, f, pre_aff)

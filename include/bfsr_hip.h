@@ -63,6 +63,9 @@ typedef struct BfsrConvArgs {
      * bfsr_pack_conv_weight(KS=1, mtile=2).  Stage 1 keeps bias / pre_add / aff_* / act. */
     const float* w2; int C2;
     const float* epi2; int act2;      /* stage-2 per-channel parameters, same packing ([C2][8]) */
+    /* bfsr_conv2d_up2 only: optional extra input channels that live at OUTPUT resolution ([B,Cin2,H,W] view) with their
+     * own ordinary 3x3 weights (bfsr_pack_conv_weight, same mtile): y = epilogue(conv3x3(cat[x2, nearest_up2(x)])) */
+    const float* x2; long long x2_bs; int Cin2; const float* w_x2;
 } BfsrConvArgs;
 
 int bfsr_abi_version(void);
@@ -76,6 +79,8 @@ int bfsr_conv2d(const BfsrConvArgs* a, void* stream);
  * [B,Cout,H,W]; `w` holds the 16 pre-summed [Cout x Cin] matrices, one per (output parity a,b; source offset i,j),
  * tap index t = (a*2+b)*4 + i*2+j, packed with bfsr_pack_conv_weight_taps(T=16).  Row rule (same for columns):
  * a=0: i=0 <- w[dy=-1], i=1 <- w[0]+w[+1];  a=1: i=0 <- w[-1]+w[0], i=1 <- w[+1].  Same epilogue as bfsr_conv2d.
+ * With x2/w_x2 set, channels that already live at the output resolution are convolved (plain 3x3) into the same
+ * accumulators, i.e. the whole conv over cat[x2, nearest_up2(x)] in one kernel.
  * Replaces conv(F.interpolate(x, scale_factor=2, mode='nearest')) patterns: the x2-upsampled stacked RRDB taps in the
  * level conditionals (SRFlowNet_arch.py:137 + FlowAffineCouplingsAblation.py:108-119), RRDBNet_arch.py:105-117. */
 int bfsr_conv2d_up2(const BfsrConvArgs* a, void* stream);

@@ -47,9 +47,14 @@ class CpuOps(object):
     def pack_conv_up2(self, w, mtile=2):
         return PackedConv(w.detach().to(torch.float32).contiguous().clone(), mtile)
 
-    def conv_up2(self, x, pw, out, epi=None, pre_add=None, act=ACT_NONE, slope=0.2):
-        """Semantics: the plain 3x3 conv over the materialised nearest-x2 upsample (original weights)."""
-        return self.conv(F.interpolate(x, scale_factor=2, mode="nearest"), pw, out, epi=epi, pre_add=pre_add, act=act, slope=slope)
+    def conv_up2(self, x, pw, out, epi=None, pre_add=None, act=ACT_NONE, slope=0.2, key=None):
+        """Semantics: the plain 3x3 conv over cat[key channels, materialised nearest-x2 upsample] (original weights)."""
+        xin, w = F.interpolate(x, scale_factor=2, mode="nearest"), pw
+        if key is not None:
+            x2, pk = key
+            xin = torch.cat([x2, xin], 1)
+            w = PackedConv(torch.cat([pk.w, pw.w], 1), pw.mtile)
+        return self.conv(xin, w, out, epi=epi, pre_add=pre_add, act=act, slope=slope)
 
     def pack_epilogue(self, Cout, bias=None, aff_shift=None, aff_scale=None, aff_post=None, post_scale=None):
         vs = dict(bias=bias, aff_shift=aff_shift, aff_scale=aff_scale, aff_post=aff_post, post_scale=post_scale)

@@ -241,3 +241,19 @@ def test_conv_up2_parity_decomposition(hip, case):
     out = hip.conv_up2(hip.to_device(x), hip.pack_conv_up2(w, mt), hip.empty(B, Cout, 2 * h, 2 * w_),
                        epi=hip.pack_epilogue(Cout, aff_shift=sh, aff_scale=sc), pre_add=hip.to_device(pre), act=1)
     close(out, ref, 2e-5, "conv_up2 epilogue %s" % (case,))
+
+
+@pytest.mark.parametrize("case", [(2, 70, 64, 64, 9, 21), (1, 256, 64, 128, 12, 40), (1, 24, 10, 40, 7, 35)])
+def test_conv_up2_with_key_channels(hip, case):
+    """conv3x3(cat[key @ output res, nearest_up2(taps)]) in one kernel."""
+    B, Ct, Ck, Cout, h, w_ = case
+    taps, key = rnd(120, B, Ct, h, w_), rnd(121, B, Ck, 2 * h, 2 * w_)
+    w = rnd(122, Cout, Ck + Ct, 3, 3, scale=1.0 / np.sqrt((Ck + Ct) * 9))
+    sh, sc = rnd(123, Cout, scale=0.2), torch.exp(rnd(124, Cout, scale=0.2))
+    wk, wt = w[:, :Ck].contiguous(), w[:, Ck:].contiguous()
+    ref = CPU.conv_up2(taps, CPU.pack_conv_up2(wt, 2), torch.empty(B, Cout, 2 * h, 2 * w_),
+                       epi=CPU.pack_epilogue(Cout, aff_shift=sh, aff_scale=sc), act=1, key=(key, CPU.pack_conv(wk, 2)))
+    out = hip.conv_up2(hip.to_device(taps), hip.pack_conv_up2(wt, 2), hip.empty(B, Cout, 2 * h, 2 * w_),
+                       epi=hip.pack_epilogue(Cout, aff_shift=sh, aff_scale=sc), act=1,
+                       key=(hip.to_device(key), hip.pack_conv(wk, 2)))
+    close(out, ref, 2e-5, "conv_up2+key %s" % (case,))

@@ -47,6 +47,9 @@ def main():
         if k[0] == "conv":
             _, KS, mt, Cin, Cout, B, H, W = k
             extra = " %6.1f TF" % (2.0 * Cin * KS * KS * Cout * B * H * W * n / (t * 1e-3) / 1e12)
+        if k[0] == "conv_up2":
+            _, mt, Cin, Cout, B, H, W, c2 = k
+            extra = " %6.1f TF" % (2.0 * (Cin * 4 + c2 * 9) * Cout * B * H * W * n / (t * 1e-3) / 1e12)
         print("%8.2f ms %4d x %8.1f us  %s%s" % (t, n, t / n * 1e3, k, extra))
 
 

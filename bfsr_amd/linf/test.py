@@ -85,18 +85,43 @@ def calc_psnr(sr, hr, dataset=None, scale=1, rgb_range=1):
     return -10 * torch.log10(valid.pow(2).mean())
 
 
-def eval_psnr(loader, model, prior_model, eval_type=None, patch=True, temperature=0):
-    """Average PSNR over an iterable of batch dicts (LP branch of the reference's eval_psnr)."""
-    tot, n = 0.0, 0
+def eval_psnr(loader, model, prior_model=None, eval_type=None, patch=True, temperature=0, randomness=False, n_samples=5):
+    """Average PSNR over an iterable of batch dicts (LINF-LP/test.py:50-236, `eval_bsize` branch).
+    prior_model given: the LP path (encode -> prior -> decode).  prior_model None: the stochastic path, z ~ N(0, tau^2)
+    sampled on the device (linf.py:398).  randomness=True reproduces the `--randomness` loop (test.py:151-162, 203-208):
+    `n_samples` predictions per batch, mean PSNR and the diversity score (std over samples of the uint8 images)."""
+    ops = model.engine().ops
+    tot, div, n = 0.0, 0.0, 0
+
+    def one(batch, H, W):
+        if prior_model is not None:
+            return lp_infer(model, prior_model, batch, (H, W), temperature)
+        d = ops.to_device
+        inp01 = d(batch['inp'])
+        B, _, h, w = inp01.shape
+        inp = ops.axpb_clamp(inp01, ops.empty(B, 3, h, w), 2.0, -1.0)
+        full = batched_predict(model, inp, d(batch['coord']), d(batch['cell']), temperature)
+        pred = full[..., :H, :W].contiguous()
+        skip = ops.resize(inp, ops.empty(B, 3, H, W), MODE_BILINEAR, float(h) / H, float(w) / W)
+        raw = ops.axpb_clamp(pred, ops.empty(B, 3, H, W), 1.0, 0.0, r=skip)
+        return ops.axpb_clamp(raw, ops.empty(B, 3, H, W), 0.5, 0.5, 0.0, 1.0)
+
+    def psnr(pred, gt):
+        if eval_type is None:
+            return calc_psnr(pred, gt)
+        kind, s = eval_type.split('-')
+        return calc_psnr(pred, gt, dataset=kind, scale=int(s))
+
     for batch in loader:
         H, W = batch['gt'].shape[-2:]
-        pred = lp_infer(model, prior_model, batch, (H, W), temperature)
-        gt = batch['gt'].to(pred.device)
-        if eval_type is None:
-            p = calc_psnr(pred, gt)
-        else:
-            kind, s = eval_type.split('-')
-            p = calc_psnr(pred, gt, dataset=kind, scale=int(s))
-        tot += float(p) * pred.shape[0]
-        n += pred.shape[0]
+        preds = [one(batch, H, W) for _ in range(n_samples if randomness else 1)]
+        gt = batch['gt'].to(preds[0].device)
+        bsz = preds[0].shape[0]
+        tot += sum(float(psnr(p, gt)) for p in preds) / len(preds) * bsz
+        if randomness:
+            q = torch.stack([torch.round(p * 255.0) for p in preds], 1)
+            div += float(torch.std(q, dim=1).mean()) * bsz
+        n += bsz
+    if randomness:
+        return {'psnr': tot / max(n, 1), 'diversity': div / max(n, 1)}
     return tot / max(n, 1)

@@ -103,6 +103,8 @@ class SRFlowModel(object):
         C = fu.C
         H = int(self.opt['scale'] * lr_shape[2] // fu.scaleH)
         W = int(self.opt['scale'] * lr_shape[3] // fu.scaleW)
+        # generated directly on the device (the reference samples on the CPU and copies, SRFlow_model.py:229-231)
+        dev = self._net.engine().ops.device
         if heat and heat > 0:
-            return torch.normal(mean=0, std=heat, size=(batch_size, C, H, W))
-        return torch.zeros((batch_size, C, H, W))
+            return torch.randn(batch_size, C, H, W, device=dev) * heat
+        return torch.zeros((batch_size, C, H, W), device=dev)

@@ -212,8 +212,6 @@ def srflow_prior_schema(depth=3, dim=64, bilinear=True):
         t = OrderedDict()
         unet_body_schema(t, tag, depth, dim, bilinear, out_ch)
         parts[tag] = t
-    for grp in ("down_layers", "up_layers"):
-        pass
     # registration order in the reference: down_layers0, up_layers0, down_layers1, up_layers1, inc0, inc1, outc0, outc1
     for tag in ("0", "1"):
         for k, v in parts[tag].items():

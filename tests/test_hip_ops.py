@@ -257,3 +257,19 @@ def test_conv_up2_with_key_channels(hip, case):
                        epi=hip.pack_epilogue(Cout, aff_shift=sh, aff_scale=sc), act=1,
                        key=(hip.to_device(key), hip.pack_conv(wk, 2)))
     close(out, ref, 2e-5, "conv_up2+key %s" % (case,))
+
+
+def test_bad_arguments_fail_loudly(hip):
+    """Error behaviour of the boundary: shape / layout mistakes raise, unsupported configurations return an error code."""
+    x = hip.to_device(rnd(130, 1, 8, 8, 8))
+    pw = hip.pack_conv(rnd(131, 16, 8, 3, 3))
+    with pytest.raises(ValueError):
+        hip.conv(x, pw, hip.empty(1, 16, 9, 8))                              # spatial mismatch
+    with pytest.raises(ValueError):
+        hip.conv(hip.to_device(rnd(132, 1, 7, 8, 8)), pw, hip.empty(1, 16, 8, 8))   # channel mismatch
+    with pytest.raises(ValueError):
+        hip.conv(x.permute(0, 1, 3, 2), pw, hip.empty(1, 16, 8, 8))          # not plane-contiguous
+    with pytest.raises(RuntimeError):
+        hip.flow_pointwise(hip.to_device(rnd(133, 1, 7, 4, 4)), hip.empty(1, 7, 4, 4), 1)   # unsupported channel count
+    with pytest.raises(RuntimeError):
+        hip.squeeze2d(hip.to_device(rnd(134, 1, 3, 5, 6)), hip.empty(1, 12, 2, 3))     # odd height

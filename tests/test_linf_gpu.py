@@ -126,3 +126,19 @@ def test_vs_oracle_and_roundtrip_bigger(hip):
     z = m("query_log_p", feat=feat, coord=coord, cell=cell, gt=gt)[1]
     back = hip.patch_unfold(m("query_rgb", feat=feat, coord=coord, cell=cell, zmap=z), hip.empty(*gt.shape), 3)
     assert (back - gt).abs().max().item() <= 1e-4
+
+
+def test_stochastic_path_and_randomness_loop(hip):
+    """tau path (no prior): z ~ N(0, tau^2) on device; `--randomness`: 5 samples, PSNR + diversity."""
+    import oracle.linf_ref as O
+    from bfsr_amd.linf.models import make
+    from bfsr_amd.linf.test import eval_psnr
+    sd, psd = weights("edsr-baseline", 2025)
+    m = make(mspec("edsr-baseline"), args={"ops": hip}).eval()
+    m.load_state_dict(sd)
+    lr = synth.smooth_lr_batch(9, 1, 16, 16)
+    prep = dict(O.batch_prep(lr, (64, 64)), gt=torch.rand(1, 3, 64, 64))
+    zero = eval_psnr([prep], m, None, temperature=0.0)                      # tau = 0 is deterministic
+    assert zero == eval_psnr([prep], m, None, temperature=0.0)
+    r = eval_psnr([prep], m, None, temperature=0.8, randomness=True)
+    assert r["diversity"] > 0 and np.isfinite(r["psnr"])

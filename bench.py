@@ -152,6 +152,11 @@ def main():
                 "share_of_step": round(t / args.steps / step_ms_events, 4)}
 
     roofline = roof_entry(*totals[0]) if totals else None
+    # HBM bytes per launch of the dominant kernel from the committed PMC passes (separate --pmc runs, profiles/)
+    tp = os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")
+    if roofline and os.path.exists(tp) and totals[0][1] == ("conv_up2", 2, 256, 1024, 8, 320, 320, 64):
+        roofline["traffic"] = json.load(open(tp)).get("hbm_bytes_per_launch")
+        roofline["traffic_unit"] = "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_d_pmc_traffic.json)"
     roofline_next = [roof_entry(*x) for x in totals[1:4]]
     tail_ms, tail_n = avg_ms(key_tail)
     hw1 = (H // 2) * (H // 2)

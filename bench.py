@@ -67,8 +67,10 @@ def main():
     psd = synth.state_dict_from_schema(spec.srflow_prior_schema(), 4321)
     model = create_model(opt, ops=ops)
     model.load_network(sd)
-    prior = registry.make({"name": "unet", "args": {"depth": 3, "dim": 64, "bilinear": True, "ops": ops}, "sd": psd},
-                          load_sd=True).eval()
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):      # make_unet prints its arguments like the reference does; keep
+        prior = registry.make({"name": "unet", "args": {"depth": 3, "dim": 64, "bilinear": True, "ops": ops}, "sd": psd},
+                              load_sd=True).eval()    # stdout for the single JSON line
 
     B, h = args.batch, args.lr
     H = h * scale

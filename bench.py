@@ -36,7 +36,6 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8, help="LR crops per GPU")
     ap.add_argument("--lr", type=int, default=160, help="LR crop side")
-    ap.add_argument("--lanes", type=int, default=1, help="sub-batches run concurrently on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scale", type=int, default=4, choices=[4, 8], help="8 = the derived 8x config (BASELINE config 4)")
     ap.add_argument("--cpu-lr", type=int, default=160, help="LR side of the CPU-baseline sample (B=1)")
@@ -88,7 +87,7 @@ def main():
         nonlocal gathered
         x = batches[i % n_batches]
         x.add_(0.0)                       # bump the version so the conditioning cache never hits across steps
-        sr = lp_infer(model, prior, x, lanes=args.lanes)
+        sr = lp_infer(model, prior, x)
         if world > 1:
             gathered = bdist.all_gather_batch(sr, total=B * world)
         return sr
@@ -207,7 +206,7 @@ def main():
             "config": {"workload": "SRFlow-LP " + str(scale) + "x DF2K config (K=16,L=3,nb=23), batch=%d/GPU %dx%d LR synthetic -> %dx%d, "
                                    "LP path: RRDB + encode + standardise + prior UNet + decode + clamp%s"
                                    % (B, h, h, H, H, ", + RCCL all-gather of outputs" if world > 1 else ""),
-                       "parallelism": "dp%d" % world, "stream_lanes": args.lanes, "weights": "seeded synthetic (conditioned recipe)"},
+                       "parallelism": "dp%d" % world, "weights": "seeded synthetic (conditioned recipe)"},
             "roofline": roofline, "roofline_next_kernels": roofline_next, "roofline_coupling_inverse": roof_tail,
             "cpu_baseline": cpu_baseline,
             "parity": parity,

@@ -70,13 +70,6 @@ class RRDBEncoder(object):
         self.trunk_conv = _ConvP(ops, g("trunk_conv.weight"), g("trunk_conv.bias"))
         self.ws = _Workspace(ops)
 
-    def fork(self):
-        """Same packed weights, private scratch: lets several sub-batches run on different HIP streams."""
-        import copy
-        c = copy.copy(self)
-        c.ws = _Workspace(self.ops)
-        return c
-
     def forward(self, x, out, on_block=None):
         """x [B,3,h,w] -> out (a [B,nf,h,w] view) = fea + trunk_conv(fea).  `on_block(idx, fea_view)` is
         called after RRDB idx with a view that is only valid during the call."""
@@ -211,15 +204,6 @@ class SRFlowEngine(object):
             self.hoist[level] = hz
             for i in idxs:
                 del self.steps[i].ft0_w, self.steps[i].aff0_ft_w
-
-    def fork(self):
-        """A lane: shares every packed weight with `self`, owns its scratch buffers and conditioning cache."""
-        import copy
-        c = copy.copy(self)
-        c.ws = _Workspace(self.ops)
-        c.rrdb = self.rrdb.fork()
-        c._cond_key, c._cond = None, None
-        return c
 
     def _level_shift(self, level):
         return _KEY_SHIFT.get(self.level_names[level])

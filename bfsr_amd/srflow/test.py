@@ -44,7 +44,7 @@ def pad_lr_to_even(lr):
 
 
 def _lp_lane(eng, prior_eng, lr, scale, sr_out, keep=None):
-    """The LP block (test.py:126-151) for one sub-batch on the current stream; writes clamp(sr) into sr_out."""
+    """The LP block (test.py:126-151) on engine level; writes clamp(sr) into sr_out."""
     ops = eng.ops
     B, _, h, w = lr.shape
     lr_up = eng.ws.get("lr_up", B, 3, h * scale, w * scale)
@@ -58,28 +58,8 @@ def _lp_lane(eng, prior_eng, lr, scale, sr_out, keep=None):
         keep.update(lr_up=lr_up, epses=epses_lr, epses_norm=epses, epses_learned=epses_learned, sr_raw=sr_raw, sr=sr_out)
 
 
-_LANES = {}
-
-
-def _lanes(net, prior_model, n):
-    """n engine lanes (lane 0 = the model's own engines) with one side stream each."""
-    key = (id(net.engine()), id(prior_model.engine()), n)
-    if key not in _LANES:
-        e0, p0 = net.engine(), prior_model.engine()
-        engs = [e0] + [e0.fork() for _ in range(n - 1)]
-        pris = [p0] + [p0.fork() for _ in range(n - 1)]
-        streams = [torch.cuda.Stream(device=e0.ops.device) for _ in range(n)]
-        _LANES.clear()
-        _LANES[key] = (engs, pris, streams)
-    return _LANES[key]
-
-
-def lp_infer(model, prior_model, lr_t, return_all=False, lanes=1):
-    """lr_t [B,3,h,w] in [0,1] (h, w even) -> sr [B,3,s*h,s*w] clamped to [0,1].
-
-    lanes > 1 splits the batch into that many sub-batches and runs them on separate HIP streams (every op is
-    per-sample, so results are unchanged): kernels of one sub-batch fill the CUs left idle by the tail of the
-    other's, which removes most of the wave-quantisation loss of the small sequential launches."""
+def lp_infer(model, prior_model, lr_t, return_all=False):
+    """lr_t [B,3,h,w] in [0,1] (h, w even) -> sr [B,3,s*h,s*w] clamped to [0,1]."""
     net = model.netG.module
     eng = net.engine()
     ops = eng.ops
@@ -88,50 +68,9 @@ def lp_infer(model, prior_model, lr_t, return_all=False, lanes=1):
         lr = ops.to_device(lr_t)
         B, _, h, w = lr.shape
         sr = ops.empty(B, 3, h * scale, w * scale)
-        lanes = max(1, min(lanes, B))
-        if lanes == 1 or return_all:
-            keep = {} if return_all else None
-            _lp_lane(eng, prior_model.engine(), lr, scale, sr, keep)
-            return keep if return_all else sr
-        from ..dist import shard_bounds
-        engs, pris, streams = _lanes(net, prior_model, lanes)
-        main = torch.cuda.current_stream(ops.device)
-        for st in streams:
-            st.wait_stream(main)
-
-        def run(i):
-            lo, hi = shard_bounds(B, i, lanes)
-            with torch.no_grad(), torch.cuda.stream(streams[i]):
-                _lp_lane(engs[i], pris[i], lr[lo:hi], scale, sr[lo:hi])
-
-        # one host thread per lane so the launches of the lanes interleave (the C-ABI calls release the GIL); a short
-        # GIL switch interval keeps the two queues evenly fed
-        import sys
-        import threading
-        old = sys.getswitchinterval()
-        sys.setswitchinterval(5e-5)
-        try:
-            errs = []
-
-            def guard(i):
-                try:
-                    run(i)
-                except BaseException as e:      # noqa: BLE001 -- re-raised on the caller's thread
-                    errs.append(e)
-
-            ts = [threading.Thread(target=guard, args=(i,)) for i in range(1, lanes)]
-            for t in ts:
-                t.start()
-            guard(0)
-            for t in ts:
-                t.join()
-            if errs:
-                raise errs[0]
-        finally:
-            sys.setswitchinterval(old)
-        for st in streams:
-            main.wait_stream(st)
-    return sr
+        keep = {} if return_all else None
+        _lp_lane(eng, prior_model.engine(), lr, scale, sr, keep)
+    return keep if return_all else sr
 
 
 def main(argv=None):

@@ -115,12 +115,6 @@ class SRFlowPriorEngine(object):
         self.proj = [DenseBlock(ops, sd, "input_proj0"), DenseBlock(ops, sd, "input_proj1")]
         self.body = [UNetBody(ops, sd, "0", depth), UNetBody(ops, sd, "1", depth)]
 
-    def fork(self):
-        import copy
-        c = copy.copy(self)
-        c.ws = _Workspace(self.ops)
-        return c
-
     def forward(self, epses):
         outs = []
         for b in (0, 1):

@@ -625,8 +625,11 @@ extern "C" int bfsr_conv2d_up2(const BfsrConvArgs* a, void* stream)
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (!a || !a->x || !a->w || !a->y || a->w2) return -1;
     if (a->B <= 0 || a->H <= 0 || a->W <= 0 || (a->H & 1) || (a->W & 1) || a->Cin <= 0 || a->Cout <= 0) return -1;
+    // 32-bit buffer offsets: every view read through a buffer descriptor must be < 2 GiB per batch element (the output
+    // itself is written with 64-bit addressing and may be larger)
     if ((long long)a->Cin * (a->H / 2) * (a->W / 2) * 4 >= (1LL << 31)) return -1;
-    if ((long long)a->Cout * a->H * a->W * 4 >= (1LL << 31)) return -1;
+    if (a->x2 && (long long)a->Cin2 * a->H * a->W * 4 >= (1LL << 31)) return -1;
+    if ((a->pre_add || a->res1 || a->res2) && (long long)a->Cout * a->H * a->W * 4 >= (1LL << 31)) return -1;
     if (a->mtile == 2) return launch_conv_up2<2>(*a, st);
     if (a->mtile == 1) return launch_conv_up2<1>(*a, st);
     return -1;
@@ -655,8 +658,9 @@ extern "C" int bfsr_conv2d(const BfsrConvArgs* a, void* stream)
     if (!a || !a->x || !a->w || !a->y) return -1;
     if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cin <= 0 || a->Cout <= 0) return -1;
     if (a->in_shift < 0 || a->in_shift > 4) return -1;
-    if ((long long)a->Cin * (a->H >> a->in_shift) * (a->W >> a->in_shift) * 4 >= (1LL << 31)) return -1;   // buffer offsets
-    if ((long long)a->Cout * a->H * a->W * 4 >= (1LL << 31)) return -1;
+    // 32-bit buffer offsets: views read through a buffer descriptor must be < 2 GiB per batch element
+    if ((long long)a->Cin * (a->H >> a->in_shift) * (a->W >> a->in_shift) * 4 >= (1LL << 31)) return -1;
+    if ((a->pre_add || a->res1 || a->res2) && (long long)a->Cout * a->H * a->W * 4 >= (1LL << 31)) return -1;
     if (a->in_shift && (((a->H >> a->in_shift) << a->in_shift) != a->H || ((a->W >> a->in_shift) << a->in_shift) != a->W))
         return -1;
     // variant = (NR rows per wave, CK channels per LDS stage).  auto: NR=4 for big grids, NR=2 otherwise;

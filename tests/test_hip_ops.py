@@ -273,3 +273,15 @@ def test_bad_arguments_fail_loudly(hip):
         hip.flow_pointwise(hip.to_device(rnd(133, 1, 7, 4, 4)), hip.empty(1, 7, 4, 4), 1)   # unsupported channel count
     with pytest.raises(RuntimeError):
         hip.squeeze2d(hip.to_device(rnd(134, 1, 3, 5, 6)), hip.empty(1, 12, 2, 3))     # odd height
+
+
+def test_conv_output_larger_than_2gib(hip):
+    """Outputs are written with 64-bit addressing: a > 2 GiB result (full-image hoisted tensors) is fine."""
+    B, Cin, Cout, H, W = 1, 8, 1024, 736, 736            # 1024*736*736*4 B = 2.22 GB
+    x, w = rnd(140, B, Cin, H, W), rnd(141, Cout, Cin, 3, 3, scale=0.1)
+    out = hip.conv(hip.to_device(x), hip.pack_conv(w, 2), hip.empty(B, Cout, H, W))
+    for sl in (slice(0, 4), slice(1020, 1024)):
+        ref = torch.nn.functional.conv2d(x, w[sl], None, 1, 1)
+        close(out[:, sl], ref, 2e-5, "conv >2GiB out, channels %s" % (sl,))
+    del out
+    torch.cuda.empty_cache()

@@ -133,3 +133,20 @@ def test_tau_path_runs(model4, hip):
     sr, z = m.get_sr_with_z(lr, heat=0.5, seed=3)
     assert sr.shape == (1, 3, 64, 64) and torch.isfinite(sr).all()
     assert z.shape == (1, 96, 8, 8)
+
+
+def test_full_div2k_sized_image_roundtrip(model4, hip):
+    """Maximum-size case: a DIV2K-validation-sized LR image (340x510 -> 1360x2040, batch 1 like the reference's test.py).
+    The hoisted level-1 tensors exceed 2 GiB here; decode(encode(x)) must still return x."""
+    from bfsr_amd.ops import MODE_BILINEAR
+    m, prior, opt, sd, psd = model4
+    eng = m.netG.module.engine()
+    lr = hip.to_device(synth.smooth_lr_batch(51, 1, 340, 510))
+    lr_up = hip.resize(lr, hip.empty(1, 3, 1360, 2040), MODE_BILINEAR, 0.25, 0.25)
+    ep = eng.encode(lr_up, lr)
+    assert ep[0].shape == (1, 6, 680, 1020) and ep[1].shape == (1, 96, 170, 255)
+    rt = eng.decode(lr, epses=ep)
+    err = (rt - lr_up).abs().max().item()
+    assert torch.isfinite(rt).all() and err <= 1e-4, "round trip %.3e" % err
+    eng.ws.bufs.clear()
+    torch.cuda.empty_cache()

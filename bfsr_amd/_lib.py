@@ -87,6 +87,7 @@ SYMBOLS = {
     "bfsr_linf_flow": (_I, [C.POINTER(BfsrLinfFlowArgs), _VP]),
     "bfsr_patch_fold": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _I, _I, _I, _VP]),
     "bfsr_patch_unfold": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _I, _I, _I, _VP]),
+    "bfsr_grid_sample_add": (_I, [_VP, _LL, _VP, _VP, _LL, _VP, _LL, _I, _I, _I, _I, _I, _I, _VP]),
     "bfsr_conv2d_direct": (_I, [_VP, _LL, _VP, _VP, _VP, _LL, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _VP]),
 }
 

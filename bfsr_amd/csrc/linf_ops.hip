@@ -186,6 +186,36 @@ __global__ void conv2d_direct_kernel(const float* __restrict__ x, long long x_bs
     y[(long long)b * y_bs + i] = acc;
 }
 
+
+// F.grid_sample(x, coord.flip(-1), mode='bilinear', padding_mode='border', align_corners=False) added to `acc`
+// (LINF.query_rgb skip, LINF-LP/models/linf.py:193-194): coord [B,qh,qw,2] holds (y, x) in [-1,1].
+__global__ void grid_sample_add_kernel(const float* __restrict__ x, long long x_bs, const float* __restrict__ coord,
+                                       const float* __restrict__ acc, long long acc_bs, float* __restrict__ out,
+                                       long long out_bs, int C, int h, int w, long long NQ)
+{
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= NQ) return;
+    const int b = blockIdx.y;
+    const float cy = coord[((long long)b * NQ + q) * 2 + 0], cx = coord[((long long)b * NQ + q) * 2 + 1];
+    float ix = ((cx + 1.f) * (float)w - 1.f) / 2.f, iy = ((cy + 1.f) * (float)h - 1.f) / 2.f;
+    ix = fminf((float)(w - 1), fmaxf(ix, 0.f));                 // padding_mode='border': clip the coordinates
+    iy = fminf((float)(h - 1), fmaxf(iy, 0.f));
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float nw = ((float)x1 - ix) * ((float)y1 - iy), ne = (ix - (float)x0) * ((float)y1 - iy);
+    const float sw = ((float)x1 - ix) * (iy - (float)y0), se = (ix - (float)x0) * (iy - (float)y0);
+    const bool x1ok = x1 < w, y1ok = y1 < h;
+    for (int c = 0; c < C; ++c) {
+        const float* xc = x + (long long)b * x_bs + (long long)c * h * w;
+        float v = xc[(long long)y0 * w + x0] * nw;
+        if (x1ok) v += xc[(long long)y0 * w + x1] * ne;
+        if (y1ok) v += xc[(long long)y1 * w + x0] * sw;
+        if (x1ok && y1ok) v += xc[(long long)y1 * w + x1] * se;
+        const long long o = (long long)c * NQ + q;
+        out[(long long)b * out_bs + o] = acc[(long long)b * acc_bs + o] + v;
+    }
+}
+
 }  // namespace
 
 extern "C" int bfsr_linf_features(const BfsrLinfFeatArgs* a, void* stream)
@@ -243,5 +273,16 @@ extern "C" int bfsr_conv2d_direct(const float* x, long long x_bs, const float* w
     dim3 grid((unsigned)((n + 255) / 256), (unsigned)B);
     hipLaunchKernelGGL(conv2d_direct_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, x_bs, w, bias,
                        y, y_bs, Cin, Cout, H, W, OH, OW, KS, stride, pad, act, slope);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bfsr_grid_sample_add(const float* x, long long x_bs, const float* coord, const float* acc, long long acc_bs,
+                                    float* out, long long out_bs, int B, int C, int h, int w, int qh, int qw, void* stream)
+{
+    if (!x || !coord || !acc || !out) return -1;
+    const long long NQ = (long long)qh * qw;
+    dim3 grid((unsigned)((NQ + 255) / 256), (unsigned)B);
+    hipLaunchKernelGGL(grid_sample_add_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, x_bs, coord, acc,
+                       acc_bs, out, out_bs, C, h, w, NQ);
     return (int)hipGetLastError();
 }

@@ -116,13 +116,16 @@ class LINFEngine(object):
         z = self.ops.empty(*gt.shape)
         return self.ops.linf_flow(gt, ai, z, self.lin_w, self.lin_b, self.L, reverse=False)
 
-    def query_rgb(self, feat, coord, cell, zmap):
-        """-> folded prediction [B,3,ps*qh,ps*qw]."""
+    def query_rgb(self, feat, coord, cell, zmap, inp=None):
+        """patch model: -> folded prediction [B,3,ps*qh,ps*qw] (no skip; the harness adds it, LINF-LP/test.py:169-171).
+        pixel-wise model (ps=1): -> [B,3,qh,qw] WITH the bilinear grid_sample skip of `inp` (linf.py:193-194)."""
         ops = self.ops
         ai = self.affine_info(feat, coord, cell)
         B, _, qh, qw = zmap.shape
         p = self.ws.get("flow_out", B, self.D, qh, qw)
         ops.linf_flow(zmap, ai, p, self.lin_winv, self.lin_b, self.L, reverse=True)
+        if self.ps == 1:
+            return ops.grid_sample_add(inp, coord, p, ops.empty(B, 3, qh, qw))
         img = ops.empty(B, 3, self.ps * qh, self.ps * qw)
         return ops.patch_fold(p, img, self.ps)
 

@@ -66,7 +66,7 @@ class LINFPatch(nn.Module):
         if zmap is None:     # tau path (linf.py:398): z ~ N(0,1) * temperature, sampled on device (plumbing)
             B, qh, qw, _ = coord.shape
             zmap = torch.randn(B, e.D, qh, qw, device=coord.device) * temperature
-        return e.query_rgb(d(feat), coord, d(cell), d(zmap))
+        return e.query_rgb(d(feat), coord, d(cell), d(zmap), inp=None if inp is None else d(inp))
 
     def log_p(self, inp, coord, cell, gt):
         return self.query_log_p(inp, self.gen_feat(inp), coord, cell, gt)
@@ -91,8 +91,8 @@ class LINFPatch(nn.Module):
 
 @register('linf')
 class LINF(LINFPatch):
-    """Pixel-wise variant (patch_size 1, linf.py:11-216).  The engine supports D=3; the reference's in-method
-    bilinear `grid_sample` skip (linf.py:193-194) is the harness' job here (`bfsr_amd.linf.test`)."""
+    """Pixel-wise variant (patch_size 1, linf.py:11-216): D = 3 flow per query pixel, `query_rgb` adds the bilinear
+    `grid_sample` skip of `inp` itself (linf.py:193-194) and there is no fold."""
 
     def __init__(self, encoder_spec, imnet_spec=None, flow_layers=10, num_layer=3, hidden_dim=256, ops=None):
         super(LINF, self).__init__(encoder_spec, imnet_spec, flow_layers, num_layer, hidden_dim, patch_size=1, ops=ops)

@@ -30,6 +30,21 @@ def patch_grid(H, W, ps=3, always_pad=True):
     return _coord_cache[key]
 
 
+def prepare_batch_pixelwise(ops, inp01, hr_hw):
+    """The non-patch wrapper `SRImplicitPairedFast` (datasets/wrappers.py:92-152): coord = the full HR pixel grid,
+    gt_lr_up = the LR-upsample residual [B,3,H,W]."""
+    H, W = hr_hw
+    B, _, h, w = inp01.shape
+    inp_n = ops.axpb_clamp(inp01, ops.empty(B, 3, h, w), 2.0, -1.0)
+    lr_up = ops.resize(inp_n, ops.empty(B, 3, H, W), MODE_BILINEAR, float(h) / H, float(w) / W)
+    down = ops.resize(lr_up, ops.empty(B, 3, h, w), MODE_BILINEAR, float(H) / h, float(W) / w)
+    up2 = ops.resize(down, ops.empty(B, 3, H, W), MODE_BILINEAR, float(h) / H, float(w) / W)
+    res = ops.axpb_clamp(up2, up2, -1.0, 0.0, r=lr_up)
+    coord = ops.to_device(make_coord([H, W], flatten=False).unsqueeze(0).expand(B, H, W, 2).contiguous())
+    cell = ops.to_device(torch.tensor([[2 / H, 2 / W]], dtype=torch.float32).expand(B, 2).contiguous())
+    return dict(inp=inp01, coord=coord, cell=cell, gt_lr_up=res)
+
+
 def prepare_batch(ops, inp01, hr_hw, ps=3, always_pad=True):
     """inp01 [B,3,h,w] in [0,1] (device) -> dict(inp, coord, cell, gt_lr_up) on the device, as the DataLoader
     would deliver them (inp un-normalised)."""

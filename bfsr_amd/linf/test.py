@@ -41,6 +41,12 @@ def lp_infer(model, prior_model, batch, hr_hw, temperature=0, return_all=False):
             ops.resize(z_learned, t, MODE_BILINEAR, float(z_learned.shape[2]) / t.shape[2], float(z_learned.shape[3]) / t.shape[3])
             z_learned = t
         full = batched_predict(model, inp, coord, cell, temperature, z_learned)  # test.py:165
+        if model.patch_size == 1:        # pixel-wise LINF: the skip is already inside query_rgb, no fold (test.py:168, 217)
+            pred_raw = full[..., :H, :W].contiguous()
+            out = ops.axpb_clamp(pred_raw, ops.empty(B, 3, H, W), 0.5, 0.5, 0.0, 1.0)
+            if return_all:
+                return dict(z_lr=z_lr, z_learned=z_learned, pred_raw=pred_raw, pred=out)
+            return out
         pred = full[..., :H, :W]                                                 # test.py:168 (a view; planes stay contiguous only if W is full)
         if pred.shape[-1] != full.shape[-1]:
             c = ops.empty(B, 3, H, W)
@@ -62,7 +68,10 @@ def infer_from_lr(model, prior_model, inp01, scale, always_pad=True, **kw):
     inp01 = ops.to_device(inp01)
     h, w = inp01.shape[-2:]
     H, W = round(h * scale), round(w * scale)
-    batch = prep.prepare_batch(ops, inp01, (H, W), model.patch_size, always_pad)
+    if model.patch_size == 1:
+        batch = prep.prepare_batch_pixelwise(ops, inp01, (H, W))
+    else:
+        batch = prep.prepare_batch(ops, inp01, (H, W), model.patch_size, always_pad)
     return lp_infer(model, prior_model, batch, (H, W), **kw)
 
 

@@ -361,3 +361,13 @@ class HipOps(object):
         _lib.check(self._launch(("conv_direct",) + tuple(y.shape), lambda: self.lib.bfsr_conv2d_direct(xp, xbs, w.data_ptr(), _ptr(bias), yp, ybs, x.shape[0], Cin, Cout, H, W, KS,
                                                stride, pad, act, slope, self._stream())), "conv2d_direct")
         return y
+
+    def grid_sample_add(self, x, coord, acc, out):
+        """out = acc + grid_sample(x, coord(y,x), bilinear, border, align_corners=False); acc/out [B,C,qh,qw]."""
+        xp, xbs, Cc, h, w = _view(x)
+        ap, abs_, c2, qh, qw = _view(acc)
+        op, obs, _, _, _ = _view(out)
+        assert c2 == Cc and tuple(coord.shape) == (x.shape[0], qh, qw, 2) and coord.is_contiguous()
+        _lib.check(self._launch(("grid_sample_add",) + tuple(out.shape), lambda: self.lib.bfsr_grid_sample_add(
+            xp, xbs, coord.data_ptr(), ap, abs_, op, obs, x.shape[0], Cc, h, w, qh, qw, self._stream())), "grid_sample_add")
+        return out

@@ -189,6 +189,10 @@ int bfsr_patch_fold(const float* p, long long p_bs, float* img, long long img_bs
 /* zero-pad + unfold (datasets/wrappers.py:224-228): img [B,C,H,W] -> p [B,C*ps*ps,qh,qw] */
 int bfsr_patch_unfold(const float* img, long long img_bs, float* p, long long p_bs, int B, int C, int qh, int qw,
                       int H, int W, int ps, void* stream);
+/* out = acc + F.grid_sample(x, coord.flip(-1), bilinear, padding_mode='border', align_corners=False): the in-method
+ * LR skip of the pixel-wise LINF (LINF-LP/models/linf.py:193-194); x [B,C,h,w], coord [B,qh,qw,2] (y,x), acc/out [B,C,qh,qw] */
+int bfsr_grid_sample_add(const float* x, long long x_bs, const float* coord, const float* acc, long long acc_bs, float* out,
+                         long long out_bs, int B, int C, int h, int w, int qh, int qw, void* stream);
 /* small direct strided conv (+bias, +activation): LINF prior `lr_proj.0` (LINF-LP/models/unet.py:118) */
 int bfsr_conv2d_direct(const float* x, long long x_bs, const float* w, const float* bias, float* y, long long y_bs,
                        int B, int Cin, int Cout, int H, int W, int KS, int stride, int pad, int act, float slope,

@@ -53,7 +53,20 @@ def input_prep(lr, hr_hw, patch_size=3, always_pad=True):
     return dict(inp=lr, coord=coord.contiguous(), cell=cell, gt_lr_up=gt_lr_up)
 
 
+def input_prep_pixelwise(lr, hr_hw):
+    """SRImplicitPairedFast (wrappers.py:92-152): coord = full HR grid, gt_lr_up = residual [3,H,W]."""
+    H, W = hr_hw
+    x = ((lr - 0.5) / 0.5).unsqueeze(0)
+    lr_up = F.interpolate(x, (H, W), mode="bilinear", align_corners=False)
+    lr_up_down = F.interpolate(lr_up, lr.shape[1:], mode="bilinear", align_corners=False)
+    res = (lr_up - F.interpolate(lr_up_down, (H, W), mode="bilinear", align_corners=False)).squeeze(0)
+    return dict(inp=lr, coord=make_coord([H, W]), cell=torch.tensor([2 / H, 2 / W], dtype=torch.float32), gt_lr_up=res)
+
+
 def batch_prep(lr_batch, hr_hw, patch_size=3, always_pad=True):
+    if patch_size == 1:
+        items = [input_prep_pixelwise(lr_batch[i], hr_hw) for i in range(lr_batch.shape[0])]
+        return {k: torch.stack([it[k] for it in items]) for k in items[0]}
     items = [input_prep(lr_batch[i], hr_hw, patch_size, always_pad) for i in range(lr_batch.shape[0])]
     return {k: torch.stack([it[k] for it in items]) for k in items[0]}
 
@@ -203,6 +216,17 @@ def query_log_p(feat, coord, cell, gt, sd, n_layers=10):
     return z.reshape(bs, qh, qw, -1).permute(0, 3, 1, 2)
 
 
+def query_rgb_pixelwise(inp, feat, coord, cell, zmap, sd, n_layers=10):
+    """LINF.query_rgb (ps=1), linf.py:122-195: D=3 inverse flow per pixel + bilinear grid_sample skip of `inp`."""
+    ai = affine_info(feat, coord, cell, sd)
+    bs, qh, qw, _ = coord.shape
+    z = zmap.permute(0, 2, 3, 1).contiguous().view(-1, 3)
+    a = ai.permute(0, 2, 3, 1).contiguous().view(bs * qh * qw, -1)
+    pred = flow_inverse(z, a, sd, n_layers=n_layers)
+    pred = pred.clone().view(bs, qh, qw, -1).permute(0, 3, 1, 2).contiguous()
+    return pred + F.grid_sample(inp, coord.flip(-1), mode="bilinear", padding_mode="border", align_corners=False)
+
+
 def query_rgb(feat, coord, cell, zmap, sd, patch_size=3, n_layers=10):
     """LINFPatch.query_rgb, linf.py:324-407 -> folded pred [B,3,ps*qh,ps*qw]."""
     ai = affine_info(feat, coord, cell, sd)
@@ -286,11 +310,15 @@ def lp_pipeline(batch, sd, sd_prior, model_spec, hr_hw, patch_size=3, return_all
         feat = encoder(inp, sd, enc_spec)                                     # gen_feat again (test.py:22)
         ps = []
         for r in range(0, coord.shape[1], chunk):
-            ps.append(query_rgb(feat, coord[:, r:r + chunk], cell, z_learned[:, :, r:r + chunk], sd, patch_size, n_layers))
+            if patch_size == 1:
+                ps.append(query_rgb_pixelwise(inp, feat, coord[:, r:r + chunk], cell, z_learned[:, :, r:r + chunk], sd, n_layers))
+            else:
+                ps.append(query_rgb(feat, coord[:, r:r + chunk], cell, z_learned[:, :, r:r + chunk], sd, patch_size, n_layers))
         pred = torch.cat(ps, dim=2)
         H, W = hr_hw
         pred = pred[..., :H, :W]
-        pred = pred + F.interpolate(inp, pred.shape[-2:], mode="bilinear", align_corners=False)
+        if patch_size != 1:                                                   # `if patch:` (test.py:169-171)
+            pred = pred + F.interpolate(inp, pred.shape[-2:], mode="bilinear", align_corners=False)
         out = torch.clamp(pred * 0.5 + 0.5, 0, 1)
     if return_all:
         return dict(z_lr=z_lr, z_learned=z_learned, pred_raw=pred, pred=out)

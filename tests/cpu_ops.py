@@ -280,3 +280,7 @@ class CpuOps(object):
             v = F.leaky_relu(v, slope)
         y.copy_(v)
         return y
+
+    def grid_sample_add(self, x, coord, acc, out):
+        out.copy_(acc + F.grid_sample(x, coord.flip(-1), mode="bilinear", padding_mode="border", align_corners=False))
+        return out

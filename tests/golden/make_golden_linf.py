@@ -139,6 +139,44 @@ def gen_linf(MANIFEST):
                  weights_seed=np.int64(seed), prior_seed=np.int64(777))
             man["cfg1_eval_psnr"] = float(psnr)
 
+    # ---- pixel-wise LINF ('linf', patch_size 1) through the reference's non-patch wrapper and harness branch ----
+    mspec1 = {"name": "linf", "args": {"encoder_spec": {"name": "edsr-baseline", "args": {"no_upsampling": True}},
+                                        "imnet_spec": {"name": "flow", "args": {"name": "flow"}},
+                                        "flow_layers": 10, "num_layer": 3, "hidden_dim": 256}}
+    model1 = models.make(mspec1).eval()
+    sch1 = lspec.linf_schema(mspec1["args"]["encoder_spec"], patch_size=1)
+    assert [(k, tuple(v.shape)) for k, v in model1.state_dict().items()] == [(k, tuple(s_)) for k, (s_, _) in sch1.items()]
+    schema_out["linf_edsr"] = [[k, list(v.shape)] for k, v in model1.state_dict().items()]
+    sd1 = synth.state_dict_from_schema(sch1, 2026)
+    model1.load_state_dict(sd1, strict=True)
+    prior3 = models.make({"name": "unet", "args": {"in_chans": 3, "depth": 3, "dim": 64, "bilinear": True}}).eval()
+    psch3 = lspec.linf_prior_schema(3)
+    assert [(k, tuple(v.shape)) for k, v in prior3.state_dict().items()] == [(k, tuple(s_)) for k, (s_, _) in psch3.items()]
+    schema_out["prior_unet3"] = [[k, list(v.shape)] for k, v in prior3.state_dict().items()]
+    psd3 = synth.state_dict_from_schema(psch3, 778)
+    prior3.load_state_dict(psd3, strict=True)
+    for ctag, sc, (h, w) in (("s4", 4, (12, 10)), ("s3", 3, (9, 11))):
+        lr = synth.smooth_lr_batch(2026 + sc, 1, h, w)[0]
+        H, W = sc * h, sc * w
+        item = wrappers.SRImplicitPairedFast(Pair(lr, torch.rand(3, H, W)))[0]
+        mine = O.input_prep_pixelwise(lr, (H, W))
+        man["prep_pixelwise_%s" % ctag] = max(maxdiff(mine[k], item[k]) for k in ("coord", "cell", "gt_lr_up"))
+        batch = {k: v.unsqueeze(0) for k, v in item.items()}
+        inp = (batch["inp"] - 0.5) / 0.5
+        z_lr = test_mod.batched_predict_log_p(model1, inp, batch["coord"], batch["cell"], batch["gt_lr_up"]).contiguous()
+        z_learned = prior3(z_lr, inp)
+        if z_learned.shape != z_lr.shape:
+            z_learned = F.interpolate(z_learned, size=z_lr.shape[-2:], mode="bilinear", align_corners=False)
+        pred = test_mod.batched_predict(model1, inp, batch["coord"], batch["cell"], 0, z_learned)[..., :H, :W]
+        out = torch.clamp(pred * 0.5 + 0.5, 0, 1)
+        o = O.lp_pipeline({k: batch[k] for k in ("inp", "coord", "cell", "gt_lr_up")}, sd1, psd3, mspec1, (H, W),
+                          patch_size=1, return_all=True)
+        man["e2e_pixelwise_%s" % ctag] = dict(z_lr=maxdiff(o["z_lr"], z_lr), z_learned=maxdiff(o["z_learned"], z_learned),
+                                               pred_raw=maxdiff(o["pred_raw"], pred), pred=maxdiff(o["pred"], out))
+        save("linf_e2e_pixelwise_%s.npz" % ctag, lr=lr.unsqueeze(0), scale=np.int64(sc), coord=batch["coord"], cell=batch["cell"],
+             gt_lr_up=batch["gt_lr_up"], z_lr=z_lr, z_learned=z_learned, pred_raw=pred, pred=out,
+             weights_seed=np.int64(2026), prior_seed=np.int64(778))
+
     # downsampled-test wrapper padding rule (no pad when divisible)
     lr = synth.smooth_lr_batch(5, 1, 6, 9)[0]
     mine = O.input_prep(lr, (18, 27), 3, always_pad=False)

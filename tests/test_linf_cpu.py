@@ -124,3 +124,38 @@ def test_ops_golden(golden_dir):
     assert tuple(p["coord"].shape) == (6, 9, 2) and tuple(p["gt_lr_up"].shape) == (27, 6, 9)
     p = O.input_prep(torch.rand(3, 6, 9), (18, 27), 3, always_pad=True)
     assert tuple(p["coord"].shape) == (7, 10, 2)
+
+
+PIX_SPEC = {"name": "linf", "args": {"encoder_spec": {"name": "edsr-baseline", "args": {"no_upsampling": True}},
+                                      "imnet_spec": {"name": "flow", "args": {"name": "flow"}},
+                                      "flow_layers": 10, "num_layer": 3, "hidden_dim": 256}}
+
+
+def pixelwise_models(ops):
+    m = make(PIX_SPEC, args={"ops": ops}).eval()
+    m.load_state_dict(synth.state_dict_from_schema(lspec.linf_schema(PIX_SPEC["args"]["encoder_spec"], patch_size=1), 2026))
+    prior = make({"name": "unet", "args": {"in_chans": 3, "depth": 3, "dim": 64, "bilinear": True}}, args={"ops": ops}).eval()
+    prior.load_state_dict(synth.state_dict_from_schema(lspec.linf_prior_schema(3), 778))
+    return m, prior
+
+
+@pytest.mark.parametrize("c", ["s4", "s3"])
+def test_pixelwise_linf_on_cpu_double(golden_dir, c):
+    """Registry name 'linf' (patch_size 1): D=3 flow per pixel, grid_sample skip inside query_rgb, prior UNet(in_chans=3)."""
+    ref = json.load(open(os.path.join(golden_dir, "linf_schema.json")))
+    m, prior = pixelwise_models(CpuOps())
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == ref["linf_edsr"]
+    assert [[k, list(v.shape)] for k, v in prior.state_dict().items()] == ref["prior_unet3"]
+    g = np.load(os.path.join(golden_dir, "linf_e2e_pixelwise_%s.npz" % c))
+    s, lr = int(g["scale"]), T(g["lr"])
+    H, W = s * lr.shape[2], s * lr.shape[3]
+    batch = dict(inp=lr, coord=T(g["coord"]), cell=T(g["cell"]), gt_lr_up=T(g["gt_lr_up"]))
+    out = lp_infer(m, prior, batch, (H, W), return_all=True)
+    for k in ("z_lr", "z_learned", "pred_raw", "pred"):
+        assert (out[k] - T(g[k])).abs().max() <= 1e-4, k
+    assert (infer_from_lr(m, prior, lr, s) - T(g["pred"])).abs().max() <= 1e-4
+    # oracle against the same golden
+    sd = synth.state_dict_from_schema(lspec.linf_schema(PIX_SPEC["args"]["encoder_spec"], patch_size=1), 2026)
+    psd = synth.state_dict_from_schema(lspec.linf_prior_schema(3), 778)
+    o = O.lp_pipeline(O.batch_prep(lr, (H, W), patch_size=1), sd, psd, PIX_SPEC, (H, W), patch_size=1, return_all=True)
+    assert (o["pred"] - T(g["pred"])).abs().max() <= 2e-5

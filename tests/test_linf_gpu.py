@@ -142,3 +142,28 @@ def test_stochastic_path_and_randomness_loop(hip):
     assert zero == eval_psnr([prep], m, None, temperature=0.0)
     r = eval_psnr([prep], m, None, temperature=0.8, randomness=True)
     assert r["diversity"] > 0 and np.isfinite(r["psnr"])
+
+
+@pytest.mark.parametrize("c", ["s4", "s3"])
+def test_pixelwise_linf_golden(hip, golden_dir, c):
+    from bfsr_amd.linf.test import infer_from_lr, lp_infer
+    from test_linf_cpu import pixelwise_models
+    m, prior = pixelwise_models(hip)
+    g = np.load(os.path.join(golden_dir, "linf_e2e_pixelwise_%s.npz" % c))
+    s, lr = int(g["scale"]), T(g["lr"])
+    H, W = s * lr.shape[2], s * lr.shape[3]
+    batch = dict(inp=lr, coord=T(g["coord"]), cell=T(g["cell"]), gt_lr_up=T(g["gt_lr_up"]))
+    out = lp_infer(m, prior, batch, (H, W), return_all=True)
+    for k in ("z_lr", "z_learned", "pred_raw"):
+        close(out[k], T(g[k]), 1e-4, k)
+    assert (out["pred"].cpu() - T(g["pred"])).abs().max() <= 1e-4
+    assert (infer_from_lr(m, prior, lr, s).cpu() - T(g["pred"])).abs().max() <= 1e-4
+
+
+def test_grid_sample_add(hip):
+    import torch.nn.functional as F
+    x, acc = rnd(150, 2, 3, 7, 9), rnd(151, 2, 3, 11, 13)
+    coord = (torch.rand(2, 11, 13, 2) * 2.4 - 1.2).contiguous()        # includes out-of-range points (border padding)
+    ref = acc + F.grid_sample(x, coord.flip(-1), mode="bilinear", padding_mode="border", align_corners=False)
+    out = hip.grid_sample_add(hip.to_device(x), hip.to_device(coord), hip.to_device(acc), hip.empty(2, 3, 11, 13))
+    close(out, ref, 2e-6, "grid_sample_add")

@@ -1,15 +1,15 @@
-"""`make_coord` (reference LINF-LP/utils.py:105-120): pixel-centre coordinates in [-1,1]; same float arithmetic
-(`v0 + r + (2r) * arange(n).float()`) so nearest-cell lookups agree bit for bit."""
+"""`make_coord` (reference LINF-LP/utils.py:105-120): coordinates of the pixel centres of a grid in [-1, 1] (or in
+`ranges`).  The per-axis values are produced with the reference's float arithmetic -- python-double `v0 + r`, float32
+`(2r) * i` -- because nearest-cell lookups in the query kernels depend on their exact bits."""
 import torch
 
 
+def _axis_centres(n, lo=-1, hi=1):
+    half_step = (hi - lo) / (2 * n)
+    return lo + half_step + (2 * half_step) * torch.arange(n).float()
+
+
 def make_coord(shape, ranges=None, flatten=True):
-    coord_seqs = []
-    for i, n in enumerate(shape):
-        v0, v1 = (-1, 1) if ranges is None else ranges[i]
-        r = (v1 - v0) / (2 * n)
-        coord_seqs.append(v0 + r + (2 * r) * torch.arange(n).float())
-    ret = torch.stack(torch.meshgrid(*coord_seqs, indexing="ij"), dim=-1)
-    if flatten:
-        ret = ret.view(-1, ret.shape[-1])
-    return ret
+    axes = [_axis_centres(n, *((-1, 1) if ranges is None else ranges[i])) for i, n in enumerate(shape)]
+    grid = torch.stack(torch.meshgrid(*axes, indexing="ij"), dim=-1)
+    return grid.view(-1, grid.shape[-1]) if flatten else grid

@@ -72,6 +72,9 @@ SYMBOLS = {
     "bfsr_conv_packed_size": (_LL, [_I, _I, _I, _I]),
     "bfsr_pack_conv_weight": (_I, [_VP, _I, _I, _I, _I, _VP]),
     "bfsr_conv2d": (_I, [C.POINTER(BfsrConvArgs), _VP]),
+    "bfsr_conv2d_f16": (_I, [C.POINTER(BfsrConvArgs), _VP]),
+    "bfsr_conv_packed_size_f16": (_LL, [_I, _I, _I, _I]),
+    "bfsr_pack_conv_weight_f16": (_I, [_VP, _I, _I, _I, _I, _VP]),
     "bfsr_conv2d_up2": (_I, [C.POINTER(BfsrConvArgs), _VP]),
     "bfsr_conv_packed_size_taps": (_LL, [_I, _I, _I, _I]),
     "bfsr_pack_conv_weight_taps": (_I, [_VP, _I, _I, _I, _I, _VP]),

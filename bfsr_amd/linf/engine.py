@@ -20,13 +20,13 @@ class EDSREncoder(object):
     """EDSR with no_upsampling (LINF-LP/models/edsr.py:134-146): head conv, n ResBlocks (conv-ReLU-conv, *res_scale + x),
     body conv, + head output."""
 
-    def __init__(self, ops, sd, prefix, n_resblocks=16, res_scale=1.0):
+    def __init__(self, ops, sd, prefix, n_resblocks=16, res_scale=1.0, f16=False):
         self.ops, self.n, self.res_scale = ops, n_resblocks, float(res_scale)
         g = lambda n: sd[prefix + n]
-        self.head = _ConvP(ops, g("head.0.weight"), g("head.0.bias"))
-        self.blocks = [(_ConvP(ops, g("body.%d.body.0.weight" % i), g("body.%d.body.0.bias" % i)),
-                        _ConvP(ops, g("body.%d.body.2.weight" % i), g("body.%d.body.2.bias" % i))) for i in range(n_resblocks)]
-        self.tail = _ConvP(ops, g("body.%d.weight" % n_resblocks), g("body.%d.bias" % n_resblocks))
+        self.head = _ConvP(ops, g("head.0.weight"), g("head.0.bias"), f16=f16)
+        self.blocks = [(_ConvP(ops, g("body.%d.body.0.weight" % i), g("body.%d.body.0.bias" % i), f16=f16),
+                        _ConvP(ops, g("body.%d.body.2.weight" % i), g("body.%d.body.2.bias" % i), f16=f16)) for i in range(n_resblocks)]
+        self.tail = _ConvP(ops, g("body.%d.weight" % n_resblocks), g("body.%d.bias" % n_resblocks), f16=f16)
         self.nf = self.head.pw.Cout
         self.ws = _Workspace(ops)
 
@@ -46,30 +46,36 @@ class EDSREncoder(object):
         return out
 
 
-def make_encoder(ops, sd, encoder_spec):
+def make_encoder(ops, sd, encoder_spec, f16=False):
     name, args = encoder_spec["name"], dict(encoder_spec.get("args") or {})
     if name == "rrdb":
         return RRDBEncoder(ops, sd, "encoder.", args.get("nb", 23), nf=args.get("nf", 64), gc=args.get("gc", 32),
-                           skip_from_first=True), args.get("nf", 64)
+                           skip_from_first=True, f16=f16), args.get("nf", 64)
     if name == "edsr-baseline":
-        return EDSREncoder(ops, sd, "encoder.", args.get("n_resblocks", 16), args.get("res_scale", 1)), args.get("n_feats", 64)
+        return EDSREncoder(ops, sd, "encoder.", args.get("n_resblocks", 16), args.get("res_scale", 1), f16=f16), args.get("n_feats", 64)
     raise NotImplementedError("encoder '%s' is outside the hot-path scope" % name)
 
 
 class LINFEngine(object):
-    def __init__(self, sd, ops, encoder_spec, flow_layers=10, num_layer=3, hidden_dim=256, patch_size=3):
+    def __init__(self, sd, ops, encoder_spec, flow_layers=10, num_layer=3, hidden_dim=256, patch_size=3, precision="fp32"):
+        """precision: 'fp32' (parity path) or 'fp16' = BASELINE config 5: the conv contractions of the encoder, the
+        coef/freq conv and the shared MLP run on the fp16 MFMA (fp32 accumulation, fp32 tensors); the flow stays fp32."""
+        if precision not in ("fp32", "fp16"):
+            raise ValueError("precision must be 'fp32' or 'fp16'")
+        f16 = precision == "fp16"
+        self.precision = precision
         self.ops, self.ws = ops, _Workspace(ops)
         sd = {k: v.detach().to("cpu", torch.float32) for k, v in sd.items()}
         self.hidden, self.ps, self.L = hidden_dim, patch_size, flow_layers
         self.D = 3 * patch_size * patch_size
-        self.encoder, self.nf = make_encoder(ops, sd, encoder_spec)
+        self.encoder, self.nf = make_encoder(ops, sd, encoder_spec, f16=f16)
         # coef | freq as one conv (both read the same feat)
         self.cf = _ConvP(ops, torch.cat([sd["coef.weight"], sd["freq.weight"]], 0),
-                         torch.cat([sd["coef.bias"], sd["freq.bias"]], 0), mtile=2)
+                         torch.cat([sd["coef.bias"], sd["freq.bias"]], 0), mtile=2, f16=f16)
         self.phase = ops.vec(sd["phase.weight"])
         self.mlp = []
         for j in range(num_layer + 1):
-            self.mlp.append(_ConvP(ops, sd["layers.%d.weight" % (2 * j)], sd["layers.%d.bias" % (2 * j)], mtile=2))
+            self.mlp.append(_ConvP(ops, sd["layers.%d.weight" % (2 * j)], sd["layers.%d.bias" % (2 * j)], mtile=2, f16=f16))
         names = ["imnet.linears.%d" % i for i in range(flow_layers)] + ["imnet.last"]
         W = torch.stack([sd[n + "._weight"] for n in names])
         self.lin_b = ops.vec(torch.stack([sd[n + ".bias"] for n in names]))

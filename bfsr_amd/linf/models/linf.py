@@ -16,7 +16,8 @@ from .models import make as _make, register
 
 @register('linf-patch')
 class LINFPatch(nn.Module):
-    def __init__(self, encoder_spec, imnet_spec=None, flow_layers=10, num_layer=3, hidden_dim=256, patch_size=3, ops=None):
+    def __init__(self, encoder_spec, imnet_spec=None, flow_layers=10, num_layer=3, hidden_dim=256, patch_size=3, ops=None,
+                 precision="fp32"):
         super(LINFPatch, self).__init__()
         self.patch_size = patch_size
         self.encoder = _make(encoder_spec)
@@ -27,7 +28,7 @@ class LINFPatch(nn.Module):
         # keep the reference's key order: encoder.*, coef, freq, phase, layers.*, imnet.*
         self._modules["imnet"] = self._modules.pop("imnet")
         self._cfg = dict(encoder_spec=self.encoder.spec, flow_layers=flow_layers, num_layer=num_layer,
-                         hidden_dim=hidden_dim, patch_size=patch_size)
+                         hidden_dim=hidden_dim, patch_size=patch_size, precision=precision)
         self._ops, self._engine = ops, None
 
     def load_state_dict(self, state_dict, strict=True):
@@ -94,5 +95,6 @@ class LINF(LINFPatch):
     """Pixel-wise variant (patch_size 1, linf.py:11-216): D = 3 flow per query pixel, `query_rgb` adds the bilinear
     `grid_sample` skip of `inp` itself (linf.py:193-194) and there is no fold."""
 
-    def __init__(self, encoder_spec, imnet_spec=None, flow_layers=10, num_layer=3, hidden_dim=256, ops=None):
-        super(LINF, self).__init__(encoder_spec, imnet_spec, flow_layers, num_layer, hidden_dim, patch_size=1, ops=ops)
+    def __init__(self, encoder_spec, imnet_spec=None, flow_layers=10, num_layer=3, hidden_dim=256, ops=None, precision="fp32"):
+        super(LINF, self).__init__(encoder_spec, imnet_spec, flow_layers, num_layer, hidden_dim, patch_size=1, ops=ops,
+                                   precision=precision)

@@ -108,6 +108,41 @@ class HipOps(object):
         mtile = mtile or default_mtile(Cout)
         return PackedConv(self._pack_raw(w, mtile), Cout, Cin, KS, mtile, fixed=fixed, w=w, ops=self)
 
+    def pack_conv_f16(self, w, mtile=None):
+        """fp16 packing for conv_f16 (the reduced-precision MFMA path); rounding = RNE like the kernel's staging."""
+        w = w.detach().to("cpu", torch.float32).contiguous()
+        Cout, Cin, KS, _ = w.shape
+        mtile = mtile or (1 if Cout <= 32 else 2)
+        n = self.lib.bfsr_conv_packed_size_f16(Cout, Cin, KS, mtile)
+        packed = torch.empty(n, dtype=torch.int16)
+        _lib.check(self.lib.bfsr_pack_conv_weight_f16(w.data_ptr(), Cout, Cin, KS, mtile, packed.data_ptr()), "pack_f16")
+        return PackedConv(packed.to(self.device), Cout, Cin, KS, mtile, fixed=True)
+
+    def conv_f16(self, x, pw, out, in_shift=0, epi=None, pre_add=None, act=ACT_NONE, slope=0.2, res1=None, alpha1=1.0,
+                 res2=None, alpha2=1.0):
+        """Same contract as conv(), contraction in fp16 on the 16x faster MFMA (inputs/weights rounded to fp16)."""
+        xp, xbs, Cin, Hs, Ws = _view(x, "conv_f16.x")
+        yp, ybs, Cout, H, W = _view(out, "conv_f16.out")
+        if Cin != pw.Cin or Cout != pw.Cout or (Hs << in_shift) != H or (Ws << in_shift) != W or x.shape[0] != out.shape[0]:
+            raise ValueError("conv_f16: shape mismatch x%s out%s" % (tuple(x.shape), tuple(out.shape)))
+        a = _lib.BfsrConvArgs()
+        a.x, a.x_bs, a.Cin = xp, xbs, Cin
+        a.w = pw.data.data_ptr()
+        a.y, a.y_bs, a.Cout = yp, ybs, Cout
+        a.B, a.H, a.W, a.KS, a.in_shift, a.mtile = out.shape[0], H, W, pw.KS, in_shift, pw.mtile
+        a.epi, a.act, a.slope = _ptr(epi), act, slope
+        for name, t, al in (("pre_add", pre_add, None), ("res1", res1, alpha1), ("res2", res2, alpha2)):
+            if t is not None:
+                pp, bs, c, hh, ww = _view(t, "conv_f16." + name)
+                assert (c, hh, ww) == (Cout, H, W)
+                setattr(a, name, pp)
+                setattr(a, name + "_bs", bs)
+                if al is not None:
+                    setattr(a, "alpha" + name[-1], al)
+        key = ("conv_f16", pw.KS, pw.mtile, Cin, Cout, out.shape[0], H, W)
+        _lib.check(self._launch(key, lambda: self.lib.bfsr_conv2d_f16(C.byref(a), self._stream())), "conv2d_f16")
+        return out
+
     @staticmethod
     def presum_up2_weights(w):
         """[Cout,Cin,3,3] -> [Cout,Cin,16]: the 3x3 taps folded onto the 2x2 source pixels each output parity of a

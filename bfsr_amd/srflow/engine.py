@@ -27,11 +27,15 @@ _KEY_SHIFT = {"fea_up0": -1, "fea_up1": 0, "fea_up2": 1, "fea_up4": 2, "fea_up8"
 class _ConvP(object):
     """A packed conv + its per-channel epilogue vectors (all device tensors)."""
 
-    def __init__(self, ops, w, bias=None, aff_shift=None, aff_scale=None, aff_post=None, post_scale=None, mtile=None):
-        self.pw = ops.pack_conv(w, mtile)
+    def __init__(self, ops, w, bias=None, aff_shift=None, aff_scale=None, aff_post=None, post_scale=None, mtile=None,
+                 f16=False):
+        self.f16 = f16           # reduced-precision contraction (fp16 MFMA); epilogue and tensors stay fp32
+        self.pw = ops.pack_conv_f16(w, mtile) if f16 else ops.pack_conv(w, mtile)
         self.epi = ops.pack_epilogue(self.pw.Cout, bias, aff_shift, aff_scale, aff_post, post_scale)
 
     def run(self, ops, x, out, **kw):
+        if self.f16:
+            return ops.conv_f16(x, self.pw, out, epi=self.epi, **kw)
         return ops.conv(x, self.pw, out, epi=self.epi, **kw)
 
 
@@ -53,21 +57,21 @@ class RRDBEncoder(object):
     """RRDBNet trunk (RRDBNet_arch.py:67-148 / LINF-LP/models/rrdb.py:77-116): conv_first, nb x RRDB
     (3 x RDB of five 3x3 convs), trunk_conv + skip.  `taps` = RRDB indices whose output is wanted."""
 
-    def __init__(self, ops, sd, prefix, nb, nf=64, gc=32, skip_from_first=False):
+    def __init__(self, ops, sd, prefix, nb, nf=64, gc=32, skip_from_first=False, f16=False):
         # skip_from_first: LINF's RRDBNet adds the conv_first output (`fea = fea + trunk`, LINF-LP/models/rrdb.py:105-107)
         # whereas SRFlow's adds the trunk output (`last_lr_fea = fea + trunk` after the loop rebinds `fea`,
         # RRDBNet_arch.py:92-103)
         self.ops, self.nb, self.nf, self.gc, self.skip_from_first = ops, nb, nf, gc, skip_from_first
         g = lambda n: sd[prefix + n]
-        self.conv_first = _ConvP(ops, g("conv_first.weight"), g("conv_first.bias"))
+        self.conv_first = _ConvP(ops, g("conv_first.weight"), g("conv_first.bias"), f16=f16)
         self.blocks = []
         for b in range(nb):
             rdbs = []
             for r in (1, 2, 3):
                 p = "RRDB_trunk.%d.RDB%d." % (b, r)
-                rdbs.append([_ConvP(ops, g(p + "conv%d.weight" % i), g(p + "conv%d.bias" % i)) for i in range(1, 6)])
+                rdbs.append([_ConvP(ops, g(p + "conv%d.weight" % i), g(p + "conv%d.bias" % i), f16=f16) for i in range(1, 6)])
             self.blocks.append(rdbs)
-        self.trunk_conv = _ConvP(ops, g("trunk_conv.weight"), g("trunk_conv.bias"))
+        self.trunk_conv = _ConvP(ops, g("trunk_conv.weight"), g("trunk_conv.bias"), f16=f16)
         self.ws = _Workspace(ops)
 
     def forward(self, x, out, on_block=None):

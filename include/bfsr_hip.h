@@ -87,6 +87,14 @@ int bfsr_conv2d_up2(const BfsrConvArgs* a, void* stream);
 long long bfsr_conv_packed_size_taps(int Cout, int Cin, int T, int mtile);
 int bfsr_pack_conv_weight_taps(const float* w_oit, int Cout, int Cin, int T, int mtile, float* packed);
 
+/* Reduced-precision variant of bfsr_conv2d (BASELINE config 5, "fp16 MFMA path"): identical arguments and epilogue, but the
+ * contraction runs on v_mfma_f32_32x32x16_f16 -- inputs and weights are rounded to fp16 (RNE) as they are staged,
+ * accumulation / epilogue / HBM tensors stay fp32.  `w` = fp16 weights from bfsr_pack_conv_weight_f16; no fused second
+ * stage.  Outside the 1e-4 fp32 tolerance by construction (tests report the deviation). */
+int bfsr_conv2d_f16(const BfsrConvArgs* a, void* stream);
+long long bfsr_conv_packed_size_f16(int Cout, int Cin, int KS, int mtile);      /* in fp16 elements */
+int bfsr_pack_conv_weight_f16(const float* w_oihw, int Cout, int Cin, int KS, int mtile, unsigned short* packed);
+
 /* ---- fused flow-step pointwise chain -----------------------------------------------------------
  * One read of z / h_aff / h_ft, one write of z (the HBM-roofline "coupling inverse" kernel of
  * BASELINE.json).  replaces, per FlowStep (SRFlow-LP/code/models/modules/):

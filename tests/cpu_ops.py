@@ -44,6 +44,13 @@ class CpuOps(object):
             w = w[torch.as_tensor(out_perm)].contiguous()
         return PackedConv(w, mtile)
 
+    def pack_conv_f16(self, w, mtile=None):
+        return PackedConv(w.detach().to(torch.float32).half().float().contiguous().clone(), mtile)
+
+    def conv_f16(self, x, pw, out, **kw):
+        """Semantics: inputs and weights rounded to fp16 (RNE), fp32 accumulation and epilogue."""
+        return self.conv(x.half().float(), pw, out, **kw)
+
     def pack_conv_up2(self, w, mtile=2):
         return PackedConv(w.detach().to(torch.float32).contiguous().clone(), mtile)
 

@@ -167,3 +167,27 @@ def test_grid_sample_add(hip):
     ref = acc + F.grid_sample(x, coord.flip(-1), mode="bilinear", padding_mode="border", align_corners=False)
     out = hip.grid_sample_add(hip.to_device(x), hip.to_device(coord), hip.to_device(acc), hip.empty(2, 3, 11, 13))
     close(out, ref, 2e-6, "grid_sample_add")
+
+
+def test_fp16_mfma_path_config5(hip):
+    """BASELINE config 5 shape in miniature (rrdb-linf-LP, OOD x6, fp16 MFMA path): runs through the fp16 conv kernel and
+    stays close to the fp32 path; the deviation is REPORTED (no 1e-4 claim for reduced precision)."""
+    import oracle.linf_ref as O
+    from bfsr_amd.linf.models import make
+    from bfsr_amd.linf.test import lp_infer
+    sd, psd = weights("rrdb", 2024)
+    prior = make({"name": "unet", "args": {"in_chans": 27, "depth": 3, "dim": 64, "bilinear": True}}, args={"ops": hip}).eval()
+    prior.load_state_dict(psd)
+    outs = {}
+    lr = synth.smooth_lr_batch(13, 2, 32, 32)
+    H = W = 192
+    prep = O.batch_prep(lr, (H, W))
+    for prec in ("fp32", "fp16"):
+        m = make(mspec("rrdb"), args={"ops": hip, "precision": prec}).eval()
+        m.load_state_dict(sd)
+        outs[prec] = lp_infer(m, prior, prep, (H, W), return_all=True)
+    assert torch.isfinite(outs["fp16"]["pred"]).all()
+    dev = (outs["fp16"]["pred"] - outs["fp32"]["pred"]).abs().max().item()
+    dz = (outs["fp16"]["z_lr"] - outs["fp32"]["z_lr"]).abs().max().item()
+    print("fp16 MFMA path vs fp32: max-abs pred %.3e, z_lr %.3e" % (dev, dz))
+    assert 0 < dev < 5e-2

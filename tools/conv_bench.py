@@ -77,6 +77,18 @@ def main():
             torch.cuda.synchronize()
             us = s.elapsed_time(e) / n * 1e3
             row.append("%7.0fus %5.1fTF" % (us, flop / us / 1e6))
+        if "--f16" in sys.argv:
+            pf = ops.pack_conv_f16(w, min(mt, 2))
+            ops.conv_f16(x, pf, y)
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(10):
+                ops.conv_f16(x, pf, y)
+            e.record()
+            torch.cuda.synchronize()
+            us = s.elapsed_time(e) / 10 * 1e3
+            row.append("f16 %7.0fus %5.1fTF" % (us, flop / us / 1e6))
         print("%-26s | %s" % (name, " | ".join(row)), flush=True)
     print("tunes:", TUNES)
 

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--scales", default="2,3,4")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--encoder", default="rrdb")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"], help="fp16 = BASELINE config 5 MFMA path")
     ap.add_argument("--cpu", action="store_true", help="also time the oracle on one image")
     args = ap.parse_args()
     from bfsr_amd import synth
@@ -31,7 +32,7 @@ def main():
                                              "flow_layers": 10, "num_layer": 3, "hidden_dim": 256}}
     sd = synth.state_dict_from_schema(lspec.linf_schema(mspec["args"]["encoder_spec"]), 2024)
     psd = synth.state_dict_from_schema(lspec.linf_prior_schema(27), 777)
-    m = make(mspec, args={"ops": ops}).eval()
+    m = make(mspec, args={"ops": ops, "precision": args.precision}).eval()
     m.load_state_dict(sd)
     prior = make({"name": "unet", "args": {"in_chans": 27, "depth": 3, "dim": 64, "bilinear": True}}, args={"ops": ops}).eval()
     prior.load_state_dict(psd)
@@ -49,7 +50,7 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
         line = {"workload": "LINF-LP %s-linf-LP x%g, batch=%d %dx%d LR -> %dx%d" % (args.encoder, s, B, h, h, H, H),
-                "ms_per_step": round(dt * 1e3, 2), "HR_MPix_per_s": round(B * H * H / 1e6 / dt, 3)}
+                "precision": args.precision, "ms_per_step": round(dt * 1e3, 2), "HR_MPix_per_s": round(B * H * H / 1e6 / dt, 3)}
         if args.cpu:
             import oracle.linf_ref as O
             lr1 = synth.lr_batch(7, 1, h, h)

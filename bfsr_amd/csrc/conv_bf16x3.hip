@@ -1,0 +1,307 @@
+// conv_bf16x3.hip -- fp32-accurate conv on the bf16 matrix pipe ("3xBF16" split, as in the BLAS libraries' fp32-emulation
+// modes).  Every fp32 operand is split EXACTLY into three bf16 terms, x = xh + xm + xl (round-to-nearest at each level: 8+8+8
+// significant bits), and the product is evaluated as the six terms
+//        xh*wh + xh*wm + xm*wh + xm*wm + xh*wl + xl*wh        (each exact in the fp32 accumulator)
+// on v_mfma_f32_32x32x16_bf16; the three dropped terms are <= 2^-24 + 2^-24 + 2^-32 relative to |x*w|, i.e. at the level of
+// the one rounding an fp32 multiply makes anyway.  Accumulation and the whole epilogue are fp32, tensors in HBM are fp32.
+// Six bf16 MFMAs cost 6/16 of the fp32 MFMA (32x32x2) time for the same contraction: the effective peak of this scheme is
+// 2.5 PFLOP/s / 6 = 417 TFLOP/s of fp32-equivalent work against 157 TFLOP/s for the native fp32 MFMA.
+// Error against an fp64 conv is measured next to the native fp32 kernel in tests/test_hip_ops.py (same magnitude).
+//
+// Structure = conv_f16.hip: M = cout (MR tiles of 32), N = 32 pixels of a row, K = 16 input channels per MFMA; LDS holds the
+// three planes of the input tile ([plane][position][16 bf16]) and of the weight slab ([plane][tap][cout][16 bf16]); weights
+// are split once at pack time, activations while they are staged into LDS.
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "../../include/bfsr_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int CK = 16;
+
+__device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l)
+{
+    h = (__bf16)v;
+    const float r1 = v - (float)h;        // exact
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);          // exact residual, <= 8 significant bits
+}
+
+template <int KS, int MR, int NR, int MINB, int NW>
+__global__ __launch_bounds__(NW * 64, MINB) void conv_bf16x3_kernel(BfsrConvArgs p, int tiles_x, int tiles_xy, int groups)
+{
+    constexpr int NT = NW * 64;
+    constexpr int TH = NW * NR, TW = 32, HALO = KS - 1;
+    constexpr int IH = TH + HALO, PW = TW + HALO, NPOS = IH * PW, PPT = (NPOS + NT - 1) / NT;
+    constexpr int TAPS = KS * KS, MW = MR * 32;
+    constexpr int WPL = TAPS * MW * CK;              // bf16 elements of one weight plane per chunk
+    constexpr int WSLAB = 3 * WPL;
+    constexpr int WV = (WSLAB / 8 + NT - 1) / NT;      // 16-byte weight loads per thread
+    constexpr int IPL = NPOS * CK;                   // bf16 elements of one input plane
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* sW = reinterpret_cast<__bf16*>(smem_raw);                     // [3][TAPS][MW][16]
+    __bf16* sIn = sW + WSLAB;                                             // [3][NPOS][16]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int bid = blockIdx.x;
+    const int cg = bid % groups; bid /= groups;
+    const int tile = bid % tiles_xy; const int b = bid / tiles_xy;
+    const int x0 = (tile % tiles_x) * TW, y0 = (tile / tiles_x) * TH;
+
+    const int H = p.H, W = p.W, sh = p.in_shift, Ws = W >> sh;
+    const long long cs_in = (long long)(H >> sh) * Ws;
+    const float* __restrict__ xin = p.x + (long long)b * p.x_bs;
+    const int Cin = p.Cin;
+    const int nchunk = (Cin + CK - 1) / CK;
+    const __bf16* __restrict__ wg = reinterpret_cast<const __bf16*>(p.w) + (long long)cg * nchunk * WSLAB;
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0,
+                                                                           (unsigned)((long long)Cin * cs_in * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wg), 0,
+                                                                          (unsigned)((long long)nchunk * WSLAB * 2), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned voff[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int pos = tid + i * NT;
+        const int r = pos / PW, c = pos - r * PW;
+        const int gy = y0 + r - HALO / 2, gx = x0 + c - HALO / 2;
+        const bool ok = (pos < NPOS) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        voff[i] = ok ? (unsigned)((gy >> sh) * Ws + (gx >> sh)) * 4u : OOB;
+    }
+    const unsigned cs_bytes = (unsigned)(cs_in * 4);
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int n = 0; n < NR; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    float vin[PPT][CK];
+    uint4 vw[WV];
+    auto load_chunk = [&](int k) {
+        const unsigned sbase = (unsigned)(k * CK) * cs_bytes;
+#pragma unroll
+        for (int c = 0; c < CK; ++c)
+#pragma unroll
+            for (int i = 0; i < PPT; ++i)
+                vin[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff[i], sbase + (unsigned)c * cs_bytes, 0));
+        const unsigned wbase = (unsigned)k * (WSLAB * 2);
+#pragma unroll
+        for (int i = 0; i < WV; ++i)
+            vw[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(tid + i * NT) * 16u, wbase, 0));
+    };
+    load_chunk(0);
+
+    for (int k = 0; k < nchunk; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int pos = tid + i * NT;
+            if (i < PPT - 1 || pos < NPOS) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    bf16x8 h8, m8, l8;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        __bf16 h, m, l;
+                        split3(vin[i][hf * 8 + c], h, m, l);
+                        h8[c] = h; m8[c] = m; l8[c] = l;
+                    }
+                    *reinterpret_cast<bf16x8*>(sIn + pos * CK + hf * 8) = h8;
+                    *reinterpret_cast<bf16x8*>(sIn + IPL + pos * CK + hf * 8) = m8;
+                    *reinterpret_cast<bf16x8*>(sIn + 2 * IPL + pos * CK + hf * 8) = l8;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int idx = tid + i * NT;
+            if (i < WV - 1 || idx < WSLAB / 8) reinterpret_cast<uint4*>(sW)[idx] = vw[i];
+        }
+        __syncthreads();
+        if (k + 1 < nchunk) load_chunk(k + 1);
+        const __bf16* inB = sIn + ((wave * NR) * PW + l31) * CK + lhi * 8;
+        const __bf16* wA = sW + l31 * CK + lhi * 8;
+        // software pipeline over the taps (dx-major so a B row set serves the KS vertical taps): the A fragments of tap t+1
+        // and, at a column change, the B fragments of column dx+1 are requested from LDS before the MFMAs of tap t issue
+        constexpr bool PFB = (MINB == 1 && NW == 4);     // room for a second B row set only with the 512-register budget
+        bf16x8 bfr[PFB ? 2 : 1][3][NR + HALO], afr[2][3][MR];
+        auto load_b = [&](int buf, int dx) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int r = 0; r < NR + HALO; ++r)
+                    bfr[buf][pl][r] = *reinterpret_cast<const bf16x8*>(inB + pl * IPL + (r * PW + dx) * CK);
+        };
+        auto load_a = [&](int buf, int dx, int dy) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int m = 0; m < MR; ++m)
+                    afr[buf][pl][m] = *reinterpret_cast<const bf16x8*>(wA + pl * WPL + ((dy * KS + dx) * MW + m * 32) * CK);
+        };
+        load_b(0, 0);
+        load_a(0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            const int dx = t / KS, dy = t % KS;
+            const int ab = t & 1, bb = PFB ? (dx & 1) : 0;
+            if (!PFB && t > 0 && dy == 0) load_b(0, dx);
+            if (t + 1 < TAPS) {
+                load_a(ab ^ 1, (t + 1) / KS, (t + 1) % KS);
+                if (PFB && dy == KS - 1) load_b(bb ^ 1, dx + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);          // keep the prefetch ahead of this tap's MFMAs
+            // small terms first, the leading term last; MR*NR independent accumulators between dependent MFMAs
+#define BFSR_TERM(PA_, PB_)                                                                                            \
+    _Pragma("unroll") for (int m = 0; m < MR; ++m) _Pragma("unroll") for (int n = 0; n < NR; ++n)                       \
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ab][PA_][m], bfr[bb][PB_][n + dy], acc[m][n], 0, 0, 0);
+            BFSR_TERM(2, 0) BFSR_TERM(0, 2) BFSR_TERM(1, 1) BFSR_TERM(1, 0) BFSR_TERM(0, 1) BFSR_TERM(0, 0)
+#undef BFSR_TERM
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- epilogue (fp32, identical stage order to conv_mfma_kernel)
+    const long long HW = (long long)H * W;
+    const int gx = x0 + l31;
+    if (gx >= W) return;
+    const float slope = p.act == BFSR_ACT_NONE ? 1.f : (p.act == BFSR_ACT_RELU ? 0.f : p.slope);
+    const float4* __restrict__ epi = reinterpret_cast<const float4*>(p.epi);
+    const unsigned out_bytes = (unsigned)((long long)p.Cout * HW * 4);
+    auto tensor_rsrc = [&](const float* t, long long bs) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(t ? t + (long long)b * bs : p.y), 0, t ? out_bytes : 0u, 0x00020000);
+    };
+    const bool tensors = p.pre_add || p.res1 || p.res2;
+    auto run_epilogue = [&](auto with_tensors) {
+        constexpr bool T = decltype(with_tensors)::value;
+        const __amdgpu_buffer_rsrc_t rs_pre = tensor_rsrc(p.pre_add, p.pre_add_bs);
+        const __amdgpu_buffer_rsrc_t rs_r1 = tensor_rsrc(p.res1, p.res1_bs);
+        const __amdgpu_buffer_rsrc_t rs_r2 = tensor_rsrc(p.res2, p.res2_bs);
+        const float a1 = p.res1 ? p.alpha1 : 1.f, a2 = p.res2 ? p.alpha2 : 1.f;
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (cg * MR + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (co >= p.Cout) continue;
+                float4 q0 = make_float4(0.f, 0.f, 1.f, 0.f); float q1 = 1.f;
+                if (epi) { q0 = epi[co * 2]; q1 = epi[co * 2 + 1].x; }
+                const long long cbase = (long long)co * HW;
+#pragma unroll
+                for (int n = 0; n < NR; ++n) {
+                    const int gy = y0 + wave * NR + n;
+                    if (gy >= H) continue;
+                    const long long o = cbase + (long long)gy * W + gx;
+                    float v = acc[m][n][r];
+                    v += q0.x;
+                    if constexpr (T) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_pre, (unsigned)o * 4u, 0, 0));
+                    v += q0.y; v *= q0.z; v += q0.w;
+                    v = v > 0.f ? v : v * slope;
+                    v *= q1;
+                    if constexpr (T) {
+                        v = a1 * v + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r1, (unsigned)o * 4u, 0, 0));
+                        v = a2 * v + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r2, (unsigned)o * 4u, 0, 0));
+                    }
+                    p.y[(long long)b * p.y_bs + o] = v;
+                }
+            }
+    };
+    if (tensors) run_epilogue(std::true_type{});
+    else run_epilogue(std::false_type{});
+}
+
+template <int KS, int MR, int NR, int MINB, int NW>
+int launch_x3(const BfsrConvArgs& a, hipStream_t st)
+{
+    constexpr int TH = NW * NR, HALO = KS - 1;
+    constexpr int LDS = 3 * (KS * KS * MR * 32 * CK + (TH + HALO) * (32 + HALO) * CK) * 2;
+    static bool attr_set = false;
+    if (!attr_set && LDS > 65536) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<KS, MR, NR, MINB, NW>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
+        attr_set = true;
+    }
+    const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + TH - 1) / TH;
+    const int groups = ((a.Cout + 31) / 32 + MR - 1) / MR;
+    const long long nblk = (long long)tiles_x * tiles_y * groups * a.B;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return -1;
+    hipLaunchKernelGGL((conv_bf16x3_kernel<KS, MR, NR, MINB, NW>), dim3((unsigned)nblk), dim3(NW * 64), LDS, st, a, tiles_x, tiles_x * tiles_y, groups);
+    return (int)hipGetLastError();
+}
+
+inline void split3_host(float v, unsigned short out[3])
+{
+    float r = v;
+    for (int i = 0; i < 3; ++i) {
+        const __bf16 h = (__bf16)r;               // round-to-nearest-even, the conversion the kernel applies to activations
+        __builtin_memcpy(&out[i], &h, 2);
+        r -= (float)h;
+    }
+}
+
+}  // namespace
+
+extern "C" long long bfsr_conv_packed_size_bf16x3(int Cout, int Cin, int KS, int mtile)
+{
+    const int nchunk = (Cin + CK - 1) / CK;
+    const int groups = ((Cout + 31) / 32 + mtile - 1) / mtile;
+    return (long long)groups * nchunk * 3 * KS * KS * mtile * 32 * CK;      // number of bf16 elements
+}
+
+extern "C" int bfsr_pack_conv_weight_bf16x3(const float* w, int Cout, int Cin, int KS, int mtile, unsigned short* packed)
+{
+    // w [Cout][Cin][KS][KS] fp32 -> bf16 [cout_group][chunk][plane h,m,l][tap][mtile*32][16], zero padded
+    if ((KS != 1 && KS != 3) || mtile < 1) return -1;
+    const int nchunk = (Cin + CK - 1) / CK, MW = mtile * 32, T = KS * KS;
+    const int groups = ((Cout + 31) / 32 + mtile - 1) / mtile;
+    const long long n = (long long)groups * nchunk * 3 * T * MW * CK;
+    for (long long i = 0; i < n; ++i) packed[i] = 0;
+    for (int co = 0; co < Cout; ++co) {
+        const int g = co / MW, m = co % MW;
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int t = 0; t < T; ++t) {
+                unsigned short s3[3];
+                split3_host(w[((long long)co * Cin + ci) * T + t], s3);
+                for (int pl = 0; pl < 3; ++pl)
+                    packed[(((((long long)g * nchunk + ci / CK) * 3 + pl) * T + t) * MW + m) * CK + ci % CK] = s3[pl];
+            }
+    }
+    return 0;
+}
+
+extern "C" int bfsr_conv2d_bf16x3(const BfsrConvArgs* a, void* stream)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!a || !a->x || !a->w || !a->y || a->w2 || a->x2) return -1;
+    if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cin <= 0 || a->Cout <= 0 || a->in_shift < 0 || a->in_shift > 4) return -1;
+    if (a->in_shift && (((a->H >> a->in_shift) << a->in_shift) != a->H || ((a->W >> a->in_shift) << a->in_shift) != a->W)) return -1;
+    if ((long long)a->Cin * (a->H >> a->in_shift) * (a->W >> a->in_shift) * 4 >= (1LL << 31)) return -1;
+    if ((a->pre_add || a->res1 || a->res2) && (long long)a->Cout * a->H * a->W * 4 >= (1LL << 31)) return -1;
+    // 3x3: 8-wave workgroups (2 waves per SIMD hide each other's LDS latency); one tile row per wave for 32-cout layers
+    // (2 workgroups per CU) and for small grids, two rows otherwise.  1x1: 4 waves x 4 rows.
+    int NR, NW = 8;
+    if (a->KS == 1) { NR = 4; NW = 4; }
+    else if (a->mtile == 1) NR = 1;
+    else {
+        const long long groups_ = ((a->Cout + 31) / 32 + 1) / 2;
+        NR = (long long)((a->W + 31) / 32) * ((a->H + 15) / 16) * a->B * groups_ >= 160 ? 2 : 1;
+    }
+    if (a->tune) { NR = a->tune / 100; NW = (a->tune % 100) ? a->tune % 100 : 4; }
+    const int key = a->KS * 1000 + a->mtile * 100 + NR * 10 + NW;
+    switch (key) {
+#define V(KS_, MR_, NR_, MB_, NW_) case KS_ * 1000 + MR_ * 100 + NR_ * 10 + NW_: return launch_x3<KS_, MR_, NR_, MB_, NW_>(*a, st);
+        V(3, 1, 2, 2, 4) V(3, 2, 2, 2, 4) V(3, 1, 4, 1, 4) V(3, 2, 4, 1, 4) V(1, 1, 4, 2, 4) V(1, 2, 4, 2, 4) V(1, 1, 2, 2, 4) V(1, 2, 2, 2, 4)
+        V(3, 1, 2, 1, 8) V(3, 2, 2, 1, 8) V(3, 2, 1, 1, 8) V(3, 1, 1, 2, 8)
+#undef V
+        default: return -1;
+    }
+}

@@ -6,6 +6,7 @@ libbfsr_hip.so.  `HipOps` is the only ops backend of the product; tests may subs
 test double with the same interface to exercise the host-side schedule without a GPU.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -60,6 +61,11 @@ class HipOps(object):
         # optional in-situ timing: launches whose key is in `profile_keys` are bracketed by HIP events on the
         # launch stream; bench.py reads `profile` (key -> [(start, end), ...]) after synchronising.
         self.profile_keys, self.profile = None, {}
+        # contraction mode the engines pick for their large 3x3 convs: "x3" = fp32-accurate 3xBF16 split on the bf16
+        # MFMA (default), "f32" = native fp32 MFMA everywhere (BFSR_CONV=f32)
+        self.conv_mode = os.environ.get("BFSR_CONV", "x3")
+        if self.conv_mode not in ("x3", "f32"):
+            raise ValueError("BFSR_CONV must be 'x3' or 'f32'")
 
     def _launch(self, key, fn):
         if self.profile_keys is None or (self.profile_keys != "ALL" and key not in self.profile_keys):
@@ -108,18 +114,27 @@ class HipOps(object):
         mtile = mtile or default_mtile(Cout)
         return PackedConv(self._pack_raw(w, mtile), Cout, Cin, KS, mtile, fixed=fixed, w=w, ops=self)
 
-    def pack_conv_f16(self, w, mtile=None):
+    def pack_conv_f16(self, w, mtile=None, kind="f16"):
         """fp16 packing for conv_f16 (the reduced-precision MFMA path); rounding = RNE like the kernel's staging."""
         w = w.detach().to("cpu", torch.float32).contiguous()
         Cout, Cin, KS, _ = w.shape
-        mtile = mtile or (1 if Cout <= 32 else 2)
-        n = self.lib.bfsr_conv_packed_size_f16(Cout, Cin, KS, mtile)
-        packed = torch.empty(n, dtype=torch.int16)
-        _lib.check(self.lib.bfsr_pack_conv_weight_f16(w.data_ptr(), Cout, Cin, KS, mtile, packed.data_ptr()), "pack_f16")
+        mtile = min(mtile or 2, 2) if Cout > 32 else 1
+        size_fn = getattr(self.lib, "bfsr_conv_packed_size_" + kind)
+        pack_fn = getattr(self.lib, "bfsr_pack_conv_weight_" + kind)
+        packed = torch.empty(size_fn(Cout, Cin, KS, mtile), dtype=torch.int16)
+        _lib.check(pack_fn(w.data_ptr(), Cout, Cin, KS, mtile, packed.data_ptr()), "pack_" + kind)
         return PackedConv(packed.to(self.device), Cout, Cin, KS, mtile, fixed=True)
 
+    def pack_conv_x3(self, w, mtile=None):
+        """3xBF16 split packing for conv_x3 (fp32-accurate contraction on the bf16 MFMA)."""
+        return self.pack_conv_f16(w, mtile, kind="bf16x3")
+
+    def conv_x3(self, x, pw, out, **kw):
+        """Same contract as conv(); fp32 operands split exactly into 3 bf16 terms, 6 cross products accumulated in fp32."""
+        return self.conv_f16(x, pw, out, _kind="bf16x3", **kw)
+
     def conv_f16(self, x, pw, out, in_shift=0, epi=None, pre_add=None, act=ACT_NONE, slope=0.2, res1=None, alpha1=1.0,
-                 res2=None, alpha2=1.0):
+                 res2=None, alpha2=1.0, tune=0, _kind="f16"):
         """Same contract as conv(), contraction in fp16 on the 16x faster MFMA (inputs/weights rounded to fp16)."""
         xp, xbs, Cin, Hs, Ws = _view(x, "conv_f16.x")
         yp, ybs, Cout, H, W = _view(out, "conv_f16.out")
@@ -139,8 +154,10 @@ class HipOps(object):
                 setattr(a, name + "_bs", bs)
                 if al is not None:
                     setattr(a, "alpha" + name[-1], al)
-        key = ("conv_f16", pw.KS, pw.mtile, Cin, Cout, out.shape[0], H, W)
-        _lib.check(self._launch(key, lambda: self.lib.bfsr_conv2d_f16(C.byref(a), self._stream())), "conv2d_f16")
+        a.tune = tune
+        key = ("conv_" + _kind, pw.KS, pw.mtile, Cin, Cout, out.shape[0], H, W)
+        fn = getattr(self.lib, "bfsr_conv2d_" + _kind)
+        _lib.check(self._launch(key, lambda: fn(C.byref(a), self._stream())), "conv2d_" + _kind)
         return out
 
     @staticmethod

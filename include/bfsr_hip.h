@@ -95,6 +95,14 @@ int bfsr_conv2d_f16(const BfsrConvArgs* a, void* stream);
 long long bfsr_conv_packed_size_f16(int Cout, int Cin, int KS, int mtile);      /* in fp16 elements */
 int bfsr_pack_conv_weight_f16(const float* w_oihw, int Cout, int Cin, int KS, int mtile, unsigned short* packed);
 
+/* fp32-accurate variant of bfsr_conv2d on the bf16 matrix pipe ("3xBF16" split): every operand is split exactly into three
+ * bf16 terms and six of the nine cross products are accumulated in fp32 on v_mfma_f32_32x32x16_bf16; the dropped terms are
+ * below one fp32 rounding of the product (error vs an fp64 conv = that of the native fp32 kernel, see tests).  Identical
+ * arguments / epilogue; `w` from bfsr_pack_conv_weight_bf16x3; tune = NR*100 selects the tile height (0 = default). */
+int bfsr_conv2d_bf16x3(const BfsrConvArgs* a, void* stream);
+long long bfsr_conv_packed_size_bf16x3(int Cout, int Cin, int KS, int mtile);   /* in bf16 elements */
+int bfsr_pack_conv_weight_bf16x3(const float* w_oihw, int Cout, int Cin, int KS, int mtile, unsigned short* packed);
+
 /* ---- fused flow-step pointwise chain -----------------------------------------------------------
  * One read of z / h_aff / h_ft, one write of z (the HBM-roofline "coupling inverse" kernel of
  * BASELINE.json).  replaces, per FlowStep (SRFlow-LP/code/models/modules/):

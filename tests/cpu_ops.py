@@ -51,6 +51,14 @@ class CpuOps(object):
         """Semantics: inputs and weights rounded to fp16 (RNE), fp32 accumulation and epilogue."""
         return self.conv(x.half().float(), pw, out, **kw)
 
+    conv_mode = "f32"
+
+    def pack_conv_x3(self, w, mtile=None):
+        return self.pack_conv(w, mtile)
+
+    def conv_x3(self, x, pw, out, **kw):
+        return self.conv(x, pw, out, **kw)
+
     def pack_conv_up2(self, w, mtile=2):
         return PackedConv(w.detach().to(torch.float32).contiguous().clone(), mtile)
 

@@ -305,3 +305,32 @@ def test_conv_f16_path(hip, case):
     full = CPU.conv(x, CPU.pack_conv(w, mt), torch.empty(B, Cout, H, W), bias=b, act=2, res1=r1, alpha1=0.2)
     dev = (out.cpu() - full).abs().max().item()
     assert dev < 2e-2, "fp16 path deviates %.3e from fp32" % dev          # reported, not a 1e-4 claim
+
+
+X3_CASES = [(2, 64, 32, 40, 72, 3, 1), (1, 192, 64, 20, 36, 3, 2), (1, 70, 50, 17, 65, 3, 2), (1, 3, 64, 16, 16, 3, 2),
+            (1, 1024, 256, 9, 40, 1, 2), (2, 100, 27, 9, 31, 1, 1), (1, 320, 128, 48, 64, 3, 2)]
+
+
+@pytest.mark.parametrize("case", X3_CASES)
+def test_conv_bf16x3_is_fp32_accurate(hip, case):
+    """The 3xBF16 split conv: error against an fp64 conv is at the level of the native fp32 MFMA kernel (and of the CPU
+    fp32 conv the oracle uses) -- i.e. it is an fp32 conv, not a reduced-precision one."""
+    B, Cin, Cout, H, W, KS, mt = case
+    x = rnd(170, B, Cin, H, W) * 3.0
+    x[:, :, ::3] *= 1e-3                                        # wide dynamic range
+    w = rnd(171, Cout, Cin, KS, KS, scale=1.0 / np.sqrt(Cin * KS * KS))
+    b, r1 = rnd(172, Cout, scale=0.2), rnd(173, B, Cout, H, W)
+    truth = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=KS // 2)
+    truth = torch.nn.functional.leaky_relu(truth, 0.2) * 0.2 + r1.double()
+    kw = dict(act=2, res1=hip.to_device(r1), alpha1=0.2)
+    xd = hip.to_device(x)
+    o32 = hip.conv(xd, hip.pack_conv(w, mt), hip.empty(B, Cout, H, W), epi=hip.pack_epilogue(Cout, bias=b), **kw)
+    for tune in ([0] if KS == 1 else [200, 400]):
+        ox3 = hip.conv_x3(xd, hip.pack_conv_x3(w, mt), hip.empty(B, Cout, H, W), epi=hip.pack_epilogue(Cout, bias=b), tune=tune, **kw)
+        e32 = (o32.cpu().double() - truth).abs().max().item()
+        ex3 = (ox3.cpu().double() - truth).abs().max().item()
+        cpu = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x, w, b, padding=KS // 2), 0.2) * 0.2 + r1
+        ecpu = (cpu.double() - truth).abs().max().item()
+        print("case %s tune %d: max-abs err vs fp64: bf16x3 %.2e, fp32 MFMA %.2e, torch CPU fp32 %.2e" % (case, tune, ex3, e32, ecpu))
+        assert ex3 <= 2.0 * max(e32, ecpu) + 1e-7, (ex3, e32, ecpu)
+        close(ox3, o32.cpu(), 1e-5, "bf16x3 vs fp32 %s" % (case,))

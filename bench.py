@@ -15,6 +15,7 @@ hoisted level-1 3x3 conv on fp32 MFMA, timed in situ with HIP events on the laun
 `roofline_coupling_inverse` (the HBM-bound fused FlowStep-inverse kernel) and `cpu_baseline` (the oracle =
 reference-faithful torch-CPU port, bounded sample: one 160x160 image)."""
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -27,6 +28,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix peak (dense)
 PEAK_HBM_GBS = 8000.0            # HBM3E 8 TB/s spec
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # same guide: bf16 matrix peak (dense, no sparsity)
+PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0   # fp32-equivalent peak of the 3xBF16 split (6 bf16 MFMAs per fp32 product)
+CONV_KINDS = ("conv", "conv_up2", "conv_bf16x3", "conv_up2_x3")
 
 
 def parse_args():
@@ -37,6 +41,7 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=8, help="LR crops per GPU")
     ap.add_argument("--lr", type=int, default=160, help="LR crop side")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-line", action="store_true", help="skip the secondary all-native-fp32-MFMA timing")
     ap.add_argument("--scale", type=int, default=4, choices=[4, 8], help="8 = the derived 8x config (BASELINE config 4)")
     ap.add_argument("--cpu-lr", type=int, default=160, help="LR side of the CPU-baseline sample (B=1)")
     return ap.parse_args()
@@ -66,7 +71,6 @@ def main():
     psd = synth.state_dict_from_schema(spec.srflow_prior_schema(), 4321)
     model = create_model(opt, ops=ops)
     model.load_network(sd)
-    import contextlib
     with contextlib.redirect_stdout(sys.stderr):      # make_unet prints its arguments like the reference does; keep
         prior = registry.make({"name": "unet", "args": {"depth": 3, "dim": 64, "bilinear": True, "ops": ops}, "sd": psd},
                               load_sd=True).eval()    # stdout for the single JSON line
@@ -100,7 +104,7 @@ def main():
         step(i)
     torch.cuda.synchronize()
     ranked = sorted(((sum(s_.elapsed_time(e_) for s_, e_ in ev), k) for k, ev in ops.profile.items()
-                     if k[0] in ("conv", "conv_up2")), reverse=True)
+                     if k[0] in CONV_KINDS), reverse=True)
     warm_total_ms = sum(sum(s_.elapsed_time(e_) for s_, e_ in ev) for ev in ops.profile.values())
     ops.profile_keys = set([k for _, k in ranked[:4]] + [key_tail]) if args.warmup > 0 else "ALL"
     ops.profile = {}
@@ -127,10 +131,10 @@ def main():
 
     def launch_flop(k):
         """algorithmic flops of one launch of the result-preserving schedule"""
-        if k[0] == "conv":
+        if k[0] in ("conv", "conv_bf16x3"):
             _, KS, _, Cin, Cout, b_, hh, ww = k
             return 2.0 * Cin * KS * KS * Cout * b_ * hh * ww
-        if k[0] == "conv_up2":          # 2x2 source taps per output pixel (parity pre-summed weights)
+        if k[0] in ("conv_up2", "conv_up2_x3"):          # 2x2 source taps per output pixel (parity pre-summed weights)
             _, _, Cin, Cout, b_, hh, ww, cin2 = k       # + cin2 key channels at output resolution (9 taps)
             return 2.0 * (Cin * 4 + cin2 * 9) * Cout * b_ * hh * ww
         return None
@@ -146,18 +150,25 @@ def main():
 
     def roof_entry(t, k, f, n):
         a = f / (t / n * 1e-3) / 1e12
-        name = {"conv": "conv_mfma_kernel", "conv_up2": "conv_up2_kernel"}[k[0]]
-        return {"bound": "mfma", "kernel": "%s %s" % (name, list(k)), "achieved": round(a, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(a / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        name = {"conv": "conv_mfma_kernel", "conv_up2": "conv_up2_kernel", "conv_bf16x3": "conv_bf16x3_kernel",
+                "conv_up2_x3": "conv_up2_bf16x3_kernel"}[k[0]]
+        x3 = k[0] in ("conv_bf16x3", "conv_up2_x3")
+        peak = PEAK_BF16X3_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
+        return {"bound": "mfma", "kernel": "%s %s" % (name, list(k)), "achieved": round(a, 2), "peak": round(peak, 1),
+                "peak_basis": ("2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per fp32 product (3xBF16 split, fp32-accurate)" if x3
+                               else "157.3 TFLOP/s fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
+                "unit": "TFLOP/s", "frac": round(a / peak, 4), "traffic": None,
                 "algorithmic_flop_per_launch": f, "avg_launch_ms": round(t / n, 4), "launches": n,
                 "share_of_step": round(t / args.steps / step_ms_events, 4)}
 
     roofline = roof_entry(*totals[0]) if totals else None
     # HBM bytes per launch of the dominant kernel from the committed PMC passes (separate --pmc runs, profiles/)
-    tp = os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")
-    if roofline and os.path.exists(tp) and totals[0][1] == ("conv_up2", 2, 256, 1024, 8, 320, 320, 64):
-        roofline["traffic"] = json.load(open(tp)).get("hbm_bytes_per_launch")
-        roofline["traffic_unit"] = "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_d_pmc_traffic.json)"
+    tp = os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")
+    if roofline and os.path.exists(tp):
+        ent = json.load(open(tp)).get("kernels", {}).get(json.dumps(list(totals[0][1])))
+        if ent:
+            roofline["traffic"] = ent["hbm_bytes_per_launch"]
+            roofline["traffic_unit"] = "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_f_pmc_traffic.json)"
     roofline_next = [roof_entry(*x) for x in totals[1:4]]
     tail_ms, tail_n = avg_ms(key_tail)
     hw1 = (H // 2) * (H // 2)
@@ -168,6 +179,31 @@ def main():
         roof_tail = {"bound": "hbm", "kernel": "flow_pointwise_kernel<12,4> reverse (level-1 FlowStep inverse tail)",
                      "achieved": round(a, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(a / PEAK_HBM_GBS, 4),
                      "traffic": None, "avg_launch_ms": round(tail_ms, 4), "launches": tail_n}
+
+    # the same workload with every contraction on the native fp32 MFMA (BFSR_CONV=f32 engines), reported beside `value`
+    fp32_only = None
+    if rank == 0 and world == 1 and ops.conv_mode != "f32" and not args.no_fp32_line:
+        ops32 = HipOps(dev)
+        ops32.conv_mode = "f32"
+        m32 = create_model(opt, ops=ops32)
+        m32.load_network(sd)
+        with contextlib.redirect_stdout(sys.stderr):
+            p32 = registry.make({"name": "unet", "args": {"depth": 3, "dim": 64, "bilinear": True, "ops": ops32}, "sd": psd},
+                                load_sd=True).eval()
+        for i in range(max(1, min(args.warmup, 2))):
+            batches[i % n_batches].add_(0.0)
+            lp_infer(m32, p32, batches[i % n_batches])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            batches[i % n_batches].add_(0.0)
+            lp_infer(m32, p32, batches[i % n_batches])
+        torch.cuda.synchronize()
+        d32 = time.perf_counter() - t1
+        fp32_only = {"value": round(B * H * H / 1e6 * args.steps / d32, 4), "unit": "MPix/s", "ms_per_step": round(d32 / args.steps * 1e3, 3),
+                     "note": "same workload and steps, all convs on v_mfma_f32_32x32x2_f32 (BFSR_CONV=f32)"}
+        del m32, p32, ops32
+        torch.cuda.empty_cache()
 
     cpu_baseline, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -203,6 +239,11 @@ def main():
             "value": round(value, 4), "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "arithmetic": ("fp32 tensors and accumulation; 3x3 convs with >=32 input channels contract on the bf16 MFMA with the "
+                           "exact 3-term bf16 split of both operands (6 cross products, error vs fp64 = native fp32 MFMA's, "
+                           "tests/test_hip_ops.py::test_conv_bf16x3_is_fp32_accurate); everything else native fp32"
+                           if ops.conv_mode == "x3" else "native fp32 MFMA / fp32 VALU"),
+            "value_native_fp32_mfma": fp32_only,
             "config": {"workload": "SRFlow-LP " + str(scale) + "x DF2K config (K=16,L=3,nb=23), batch=%d/GPU %dx%d LR synthetic -> %dx%d, "
                                    "LP path: RRDB + encode + standardise + prior UNet + decode + clamp%s"
                                    % (B, h, h, H, H, ", + RCCL all-gather of outputs" if world > 1 else ""),

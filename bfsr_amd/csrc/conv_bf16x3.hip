@@ -43,8 +43,8 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_bf16x3_kernel(BfsrConvArgs
     constexpr int IPL = NPOS * CK;                   // bf16 elements of one input plane
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __bf16* sW = reinterpret_cast<__bf16*>(smem_raw);                     // [3][TAPS][MW][16]
-    __bf16* sIn = sW + WSLAB;                                             // [3][NPOS][16]
+    __bf16* sW = reinterpret_cast<__bf16*>(smem_raw);                     // [3][TAPS][k half][MW][8]
+    __bf16* sIn = sW + WSLAB;                                             // [3][k half][NPOS][8]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -115,9 +115,9 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_bf16x3_kernel(BfsrConvArgs
                         split3(vin[i][hf * 8 + c], h, m, l);
                         h8[c] = h; m8[c] = m; l8[c] = l;
                     }
-                    *reinterpret_cast<bf16x8*>(sIn + pos * CK + hf * 8) = h8;
-                    *reinterpret_cast<bf16x8*>(sIn + IPL + pos * CK + hf * 8) = m8;
-                    *reinterpret_cast<bf16x8*>(sIn + 2 * IPL + pos * CK + hf * 8) = l8;
+                    *reinterpret_cast<bf16x8*>(sIn + (hf * NPOS + pos) * 8) = h8;
+                    *reinterpret_cast<bf16x8*>(sIn + IPL + (hf * NPOS + pos) * 8) = m8;
+                    *reinterpret_cast<bf16x8*>(sIn + 2 * IPL + (hf * NPOS + pos) * 8) = l8;
                 }
             }
         }
@@ -128,8 +128,8 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_bf16x3_kernel(BfsrConvArgs
         }
         __syncthreads();
         if (k + 1 < nchunk) load_chunk(k + 1);
-        const __bf16* inB = sIn + ((wave * NR) * PW + l31) * CK + lhi * 8;
-        const __bf16* wA = sW + l31 * CK + lhi * 8;
+        const __bf16* inB = sIn + (lhi * NPOS + (wave * NR) * PW + l31) * 8;
+        const __bf16* wA = sW + (lhi * MW + l31) * 8;
         // software pipeline over the taps (dx-major so a B row set serves the KS vertical taps): the A fragments of tap t+1
         // and, at a column change, the B fragments of column dx+1 are requested from LDS before the MFMAs of tap t issue
         constexpr bool PFB = (MINB == 1 && NW == 4);     // room for a second B row set only with the 512-register budget
@@ -139,14 +139,14 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_bf16x3_kernel(BfsrConvArgs
             for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
                 for (int r = 0; r < NR + HALO; ++r)
-                    bfr[buf][pl][r] = *reinterpret_cast<const bf16x8*>(inB + pl * IPL + (r * PW + dx) * CK);
+                    bfr[buf][pl][r] = *reinterpret_cast<const bf16x8*>(inB + pl * IPL + (r * PW + dx) * 8);
         };
         auto load_a = [&](int buf, int dx, int dy) {
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
                 for (int m = 0; m < MR; ++m)
-                    afr[buf][pl][m] = *reinterpret_cast<const bf16x8*>(wA + pl * WPL + ((dy * KS + dx) * MW + m * 32) * CK);
+                    afr[buf][pl][m] = *reinterpret_cast<const bf16x8*>(wA + pl * WPL + ((dy * KS + dx) * 2 * MW + m * 32) * 8);
         };
         load_b(0, 0);
         load_a(0, 0, 0);
@@ -238,6 +238,207 @@ int launch_x3(const BfsrConvArgs& a, hipStream_t st)
     return (int)hipGetLastError();
 }
 
+
+// ---- conv over nearest_up2(x) with the 16 parity-pre-summed matrices (see conv_up2_kernel in conv_mfma.hip), 3xBF16 split.
+// x [B,Cin,H/2,W/2] -> y [B,Cout,H,W]; tap index t = (a*2+b)*4 + i*2+j (output row/column parity a,b; source offset i,j).
+// A workgroup produces the output rows of ONE row parity `a` (8 of the 16 matrices -> half the weight slab in LDS, two
+// workgroups per CU): NW waves, source tile (NW*NR) rows x 32 columns, 32 output channels; each wave owns NR source rows:
+// acc[column parity][row].  Column offset d = b+j is the outer loop so one set of B rows serves every (b,j) with that d.
+// The two column parities of a source pixel are adjacent output pixels: the epilogue moves float2 (fully coalesced rows).
+// Channels that already live at the output resolution go through the plain kernel first and arrive here as `pre_add`.
+template <int NW, int NR>
+__global__ __launch_bounds__(NW * 64, 2) void conv_up2_bf16x3_kernel(BfsrConvArgs p, int tiles_x, int tiles_xy, int groups)
+{
+    constexpr int NT = NW * 64, SR = NW * NR, PW = 34, NPOS = (SR + 1) * PW, PPT = (NPOS + NT - 1) / NT;
+    constexpr int TAPS = 16, MW = 32, HT = 8;                            // HT = matrices of one row parity
+    constexpr int WPL = HT * MW * CK, WSLAB = 3 * WPL, WV = (WSLAB / 8 + NT - 1) / NT, IPL = NPOS * CK;
+    constexpr int GPL = TAPS * MW * CK;                                  // one plane of all 16 matrices in global memory
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* sW = reinterpret_cast<__bf16*>(smem_raw);                     // [3][8][k half][32][8]
+    __bf16* sIn = sW + WSLAB;                                             // [3][k half][NPOS][8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int bid = blockIdx.x;
+    const int pa = bid & 1; bid >>= 1;                                    // output row parity of this workgroup
+    const int cg = bid % groups; bid /= groups;
+    const int tile = bid % tiles_xy; const int b = bid / tiles_xy;
+    const int x0 = (tile % tiles_x) * 32, y0 = (tile / tiles_x) * SR;     // source coordinates
+    const int H = p.H, W = p.W, Hs = H >> 1, Ws = W >> 1;
+    const long long cs_in = (long long)Hs * Ws;
+    const float* __restrict__ xin = p.x + (long long)b * p.x_bs;
+    const int Cin = p.Cin, nchunk = (Cin + CK - 1) / CK;
+    const __bf16* __restrict__ wg = reinterpret_cast<const __bf16*>(p.w) + (long long)cg * nchunk * 3 * GPL;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0,
+                                                                           (unsigned)((long long)Cin * cs_in * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wg), 0,
+                                                                          (unsigned)((long long)nchunk * 3 * GPL * 2), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned voff[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int pos = tid + i * NT;
+        const int r = pos / PW, c = pos - r * PW;
+        const int gy = y0 + r - 1 + pa, gx = x0 + c - 1;                  // parity a needs source rows sy-1+a, sy+a
+        const bool ok = pos < NPOS && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
+        voff[i] = ok ? (unsigned)(gy * Ws + gx) * 4u : OOB;
+    }
+    // weight slab of this parity: per plane the 8 matrices t = pa*8 .. pa*8+7 are contiguous in global memory
+    unsigned woff[WV];
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+        const int idx = tid + i * NT;                                     // 16-byte unit inside [3][8][32][16]
+        const int pl = idx / (WPL / 8), rem = idx - pl * (WPL / 8);
+        woff[i] = idx < WSLAB / 8 ? (unsigned)((pl * GPL + pa * WPL) * 2 + rem * 16) : OOB;
+    }
+    const unsigned cs_bytes = (unsigned)(cs_in * 4);
+    f32x16 acc[2][NR];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int n = 0; n < NR; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][n][r] = 0.f;
+
+    float vin[PPT][CK];
+    uint4 vw[WV];
+    auto load_chunk = [&](int k) {
+        const unsigned sbase = (unsigned)(k * CK) * cs_bytes;
+#pragma unroll
+        for (int c = 0; c < CK; ++c)
+#pragma unroll
+            for (int i = 0; i < PPT; ++i)
+                vin[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff[i], sbase + (unsigned)c * cs_bytes, 0));
+        const unsigned wbase = (unsigned)k * (3 * GPL * 2);
+#pragma unroll
+        for (int i = 0; i < WV; ++i)
+            vw[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff[i], wbase, 0));
+    };
+    load_chunk(0);
+    for (int k = 0; k < nchunk; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int pos = tid + i * NT;
+            if (i < PPT - 1 || pos < NPOS) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    bf16x8 h8, m8, l8;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        __bf16 h, m, l;
+                        split3(vin[i][hf * 8 + c], h, m, l);
+                        h8[c] = h; m8[c] = m; l8[c] = l;
+                    }
+                    *reinterpret_cast<bf16x8*>(sIn + (hf * NPOS + pos) * 8) = h8;
+                    *reinterpret_cast<bf16x8*>(sIn + IPL + (hf * NPOS + pos) * 8) = m8;
+                    *reinterpret_cast<bf16x8*>(sIn + 2 * IPL + (hf * NPOS + pos) * 8) = l8;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int idx = tid + i * NT;
+            if (i < WV - 1 || idx < WSLAB / 8) reinterpret_cast<uint4*>(sW)[idx] = vw[i];
+        }
+        __syncthreads();
+        if (k + 1 < nchunk) load_chunk(k + 1);
+        const __bf16* inB = sIn + (lhi * NPOS + (wave * NR) * PW + l31) * 8;
+        const __bf16* wA = sW + (lhi * MW + l31) * 8;
+        bf16x8 bfr[3][NR + 1], afr[2][3];
+        auto load_b = [&](int d) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int e = 0; e < NR + 1; ++e)
+                    bfr[pl][e] = *reinterpret_cast<const bf16x8*>(inB + pl * IPL + (e * PW + d) * 8);
+        };
+        // step s = 0..7 in the order (d; bq,j with bq+j = d; i); local matrix index = bq*4 + i*2 + j
+        auto load_a = [&](int buf, int s_) {
+            const int blk = s_ >> 1, bq = blk >> 1, j = blk & 1, i = s_ & 1;
+            const int t = bq * 4 + i * 2 + j;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) afr[buf][pl] = *reinterpret_cast<const bf16x8*>(wA + pl * WPL + t * 2 * MW * 8);
+        };
+        load_a(0, 0);
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            const int blk = s_ >> 1, bq = blk >> 1, j = blk & 1, i = s_ & 1, d = bq + j;
+            const int ab = s_ & 1;
+            if (s_ == 0 || s_ == 2 || s_ == 6) load_b(d);
+            if (s_ + 1 < 8) load_a(ab ^ 1, s_ + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#define BFSR_TERM(PA_, PB_)                                                                                            \
+    _Pragma("unroll") for (int n = 0; n < NR; ++n)                                                                      \
+        acc[bq][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ab][PA_], bfr[PB_][n + i], acc[bq][n], 0, 0, 0);
+            BFSR_TERM(2, 0) BFSR_TERM(0, 2) BFSR_TERM(1, 1) BFSR_TERM(1, 0) BFSR_TERM(0, 1) BFSR_TERM(0, 0)
+#undef BFSR_TERM
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- epilogue (same stage order as conv_mfma_kernel); lane = source column -> two adjacent output pixels
+    const int sx = x0 + l31;
+    if (sx >= Ws) return;
+    const long long HW = (long long)H * W;
+    const float slope = p.act == BFSR_ACT_NONE ? 1.f : (p.act == BFSR_ACT_RELU ? 0.f : p.slope);
+    const float4* __restrict__ epi = reinterpret_cast<const float4*>(p.epi);
+    const bool tensors = p.pre_add || p.res1 || p.res2;
+    auto run_epilogue = [&](auto with_tensors) {
+        constexpr bool T = decltype(with_tensors)::value;
+        const float a1 = p.res1 ? p.alpha1 : 1.f, a2 = p.res2 ? p.alpha2 : 1.f;
+        const float* pre = p.pre_add ? p.pre_add + (long long)b * p.pre_add_bs : nullptr;
+        const float* r1 = p.res1 ? p.res1 + (long long)b * p.res1_bs : nullptr;
+        const float* r2 = p.res2 ? p.res2 + (long long)b * p.res2_bs : nullptr;
+        float* yb = p.y + (long long)b * p.y_bs;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (co >= p.Cout) continue;
+            float4 q0 = make_float4(0.f, 0.f, 1.f, 0.f); float q1 = 1.f;
+            if (epi) { q0 = epi[co * 2]; q1 = epi[co * 2 + 1].x; }
+#pragma unroll
+            for (int n = 0; n < NR; ++n) {
+                const int sy = y0 + wave * NR + n;
+                if (sy >= Hs) continue;
+                const long long o = (long long)co * HW + (long long)(2 * sy + pa) * W + 2 * sx;
+                float2 v = make_float2(acc[0][n][r], acc[1][n][r]);
+                v.x += q0.x; v.y += q0.x;
+                if constexpr (T) if (pre) { const float2 t = *reinterpret_cast<const float2*>(pre + o); v.x += t.x; v.y += t.y; }
+                v.x = (v.x + q0.y) * q0.z + q0.w; v.y = (v.y + q0.y) * q0.z + q0.w;
+                v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+                v.x *= q1; v.y *= q1;
+                if constexpr (T) {
+                    if (r1) { const float2 t = *reinterpret_cast<const float2*>(r1 + o); v.x = a1 * v.x + t.x; v.y = a1 * v.y + t.y; }
+                    if (r2) { const float2 t = *reinterpret_cast<const float2*>(r2 + o); v.x = a2 * v.x + t.x; v.y = a2 * v.y + t.y; }
+                }
+                *reinterpret_cast<float2*>(yb + o) = v;
+            }
+        }
+    };
+    if (tensors) run_epilogue(std::true_type{});
+    else run_epilogue(std::false_type{});
+}
+
+template <int NW, int NR>
+int launch_up2_x3(const BfsrConvArgs& a, hipStream_t st)
+{
+    constexpr int SR = NW * NR;
+    constexpr int LDS = 3 * (8 * 32 * CK + (SR + 1) * 34 * CK) * 2;
+    static bool attr_set = false;
+    if (!attr_set && LDS > 65536) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up2_bf16x3_kernel<NW, NR>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
+        attr_set = true;
+    }
+    const int Hs = a.H / 2, Ws = a.W / 2;
+    const int tiles_x = (Ws + 31) / 32, tiles_y = (Hs + SR - 1) / SR;
+    const int groups = (a.Cout + 31) / 32;
+    const long long nblk = 2LL * tiles_x * tiles_y * groups * a.B;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return -1;
+    hipLaunchKernelGGL((conv_up2_bf16x3_kernel<NW, NR>), dim3((unsigned)nblk), dim3(NW * 64), LDS, st, a, tiles_x, tiles_x * tiles_y, groups);
+    return (int)hipGetLastError();
+}
+
 inline void split3_host(float v, unsigned short out[3])
 {
     float r = v;
@@ -250,18 +451,19 @@ inline void split3_host(float v, unsigned short out[3])
 
 }  // namespace
 
-extern "C" long long bfsr_conv_packed_size_bf16x3(int Cout, int Cin, int KS, int mtile)
+extern "C" long long bfsr_conv_packed_size_taps_bf16x3(int Cout, int Cin, int T, int mtile)
 {
     const int nchunk = (Cin + CK - 1) / CK;
     const int groups = ((Cout + 31) / 32 + mtile - 1) / mtile;
-    return (long long)groups * nchunk * 3 * KS * KS * mtile * 32 * CK;      // number of bf16 elements
+    return (long long)groups * nchunk * 3 * T * mtile * 32 * CK;            // number of bf16 elements
 }
 
-extern "C" int bfsr_pack_conv_weight_bf16x3(const float* w, int Cout, int Cin, int KS, int mtile, unsigned short* packed)
+extern "C" int bfsr_pack_conv_weight_taps_bf16x3(const float* w, int Cout, int Cin, int T, int mtile, unsigned short* packed)
 {
-    // w [Cout][Cin][KS][KS] fp32 -> bf16 [cout_group][chunk][plane h,m,l][tap][mtile*32][16], zero padded
-    if ((KS != 1 && KS != 3) || mtile < 1) return -1;
-    const int nchunk = (Cin + CK - 1) / CK, MW = mtile * 32, T = KS * KS;
+    // w [Cout][Cin][T] fp32 -> bf16 [cout_group][chunk][plane h,m,l][tap][k half][mtile*32][8], zero padded
+    // (k-half-major so the 64 lanes of an MFMA operand read 2 x 512 contiguous bytes of LDS: no bank conflicts)
+    if (T < 1 || mtile < 1) return -1;
+    const int nchunk = (Cin + CK - 1) / CK, MW = mtile * 32;
     const int groups = ((Cout + 31) / 32 + mtile - 1) / mtile;
     const long long n = (long long)groups * nchunk * 3 * T * MW * CK;
     for (long long i = 0; i < n; ++i) packed[i] = 0;
@@ -272,10 +474,41 @@ extern "C" int bfsr_pack_conv_weight_bf16x3(const float* w, int Cout, int Cin, i
                 unsigned short s3[3];
                 split3_host(w[((long long)co * Cin + ci) * T + t], s3);
                 for (int pl = 0; pl < 3; ++pl)
-                    packed[(((((long long)g * nchunk + ci / CK) * 3 + pl) * T + t) * MW + m) * CK + ci % CK] = s3[pl];
+                    packed[((((((long long)g * nchunk + ci / CK) * 3 + pl) * T + t) * 2 + (ci % CK) / 8) * MW + m) * 8 + ci % 8] = s3[pl];
             }
     }
     return 0;
+}
+
+extern "C" long long bfsr_conv_packed_size_bf16x3(int Cout, int Cin, int KS, int mtile)
+{
+    return bfsr_conv_packed_size_taps_bf16x3(Cout, Cin, KS * KS, mtile);
+}
+
+extern "C" int bfsr_pack_conv_weight_bf16x3(const float* w, int Cout, int Cin, int KS, int mtile, unsigned short* packed)
+{
+    if (KS != 1 && KS != 3) return -1;
+    return bfsr_pack_conv_weight_taps_bf16x3(w, Cout, Cin, KS * KS, mtile, packed);
+}
+
+extern "C" int bfsr_conv2d_up2_bf16x3(const BfsrConvArgs* a, void* stream)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!a || !a->x || !a->w || !a->y || a->w2 || a->x2 || a->mtile != 1) return -1;
+    if (a->B <= 0 || a->H <= 0 || a->W <= 0 || (a->H & 1) || (a->W & 1) || a->Cin <= 0 || a->Cout <= 0) return -1;
+    if ((long long)a->Cin * (a->H / 2) * (a->W / 2) * 4 >= (1LL << 31)) return -1;
+    // the float2 epilogue needs 8-byte aligned rows: even W and even plane/batch strides are given by H,W even + NCHW views
+    if ((reinterpret_cast<unsigned long long>(a->y) & 7) || (a->y_bs & 1)) return -1;
+    if (a->pre_add && ((reinterpret_cast<unsigned long long>(a->pre_add) & 7) || (a->pre_add_bs & 1))) return -1;
+    if (a->res1 && ((reinterpret_cast<unsigned long long>(a->res1) & 7) || (a->res1_bs & 1))) return -1;
+    if (a->res2 && ((reinterpret_cast<unsigned long long>(a->res2) & 7) || (a->res2_bs & 1))) return -1;
+    const int v = a->tune ? a->tune : 801;
+    switch (v) {
+        case 402: return launch_up2_x3<4, 2>(*a, st);
+        case 401: return launch_up2_x3<4, 1>(*a, st);
+        case 801: return launch_up2_x3<8, 1>(*a, st);
+        default: return -1;
+    }
 }
 
 extern "C" int bfsr_conv2d_bf16x3(const BfsrConvArgs* a, void* stream)
@@ -300,7 +533,7 @@ extern "C" int bfsr_conv2d_bf16x3(const BfsrConvArgs* a, void* stream)
     switch (key) {
 #define V(KS_, MR_, NR_, MB_, NW_) case KS_ * 1000 + MR_ * 100 + NR_ * 10 + NW_: return launch_x3<KS_, MR_, NR_, MB_, NW_>(*a, st);
         V(3, 1, 2, 2, 4) V(3, 2, 2, 2, 4) V(3, 1, 4, 1, 4) V(3, 2, 4, 1, 4) V(1, 1, 4, 2, 4) V(1, 2, 4, 2, 4) V(1, 1, 2, 2, 4) V(1, 2, 2, 2, 4)
-        V(3, 1, 2, 1, 8) V(3, 2, 2, 1, 8) V(3, 2, 1, 1, 8) V(3, 1, 1, 2, 8)
+        V(3, 1, 2, 1, 8) V(3, 2, 2, 1, 8) V(3, 2, 1, 1, 8) V(3, 1, 1, 2, 8) V(3, 2, 1, 2, 4) V(3, 1, 1, 2, 4)
 #undef V
         default: return -1;
     }

@@ -63,11 +63,21 @@ class HipOps(object):
         self.profile_keys, self.profile = None, {}
         # contraction mode the engines pick for their large 3x3 convs: "x3" = fp32-accurate 3xBF16 split on the bf16
         # MFMA (default), "f32" = native fp32 MFMA everywhere (BFSR_CONV=f32)
+        # BFSR_KEYLOG=<path>: record the key of every launch, in order, and dump them at exit (tools/pmc_traffic.py aligns
+        # them with the dispatch order of a rocprofv3 --pmc run to attribute counters to launch shapes)
+        self._keylog = None
+        if os.environ.get("BFSR_KEYLOG"):
+            import atexit
+            import json
+            self._keylog = []
+            atexit.register(lambda path=os.environ["BFSR_KEYLOG"], log=self._keylog: json.dump(log, open(path, "w")))
         self.conv_mode = os.environ.get("BFSR_CONV", "x3")
         if self.conv_mode not in ("x3", "f32"):
             raise ValueError("BFSR_CONV must be 'x3' or 'f32'")
 
     def _launch(self, key, fn):
+        if self._keylog is not None:
+            self._keylog.append(list(key))
         if self.profile_keys is None or (self.profile_keys != "ALL" and key not in self.profile_keys):
             return fn()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -214,6 +224,34 @@ class HipOps(object):
             a.Cin2, a.w_x2 = cin2, pk.data.data_ptr()
         key = ("conv_up2", pw.mtile, Cin, Cout, out.shape[0], H, W, cin2)
         _lib.check(self._launch(key, lambda: self.lib.bfsr_conv2d_up2(C.byref(a), self._stream())), "conv2d_up2")
+        return out
+
+    def pack_conv_up2_x3(self, w):
+        """conv_up2 weights (16 parity-pre-summed matrices) in the 3xBF16 split layout."""
+        w16 = self.presum_up2_weights(w)
+        Cout, Cin, _ = w16.shape
+        packed = torch.empty(self.lib.bfsr_conv_packed_size_taps_bf16x3(Cout, Cin, 16, 1), dtype=torch.int16)
+        _lib.check(self.lib.bfsr_pack_conv_weight_taps_bf16x3(w16.data_ptr(), Cout, Cin, 16, 1, packed.data_ptr()), "pack_taps_x3")
+        return PackedConv(packed.to(self.device), Cout, Cin, 3, 1, fixed=True)
+
+    def conv_up2_x3(self, x, pw, out, epi=None, pre_add=None, act=ACT_NONE, slope=0.2, tune=0):
+        """conv_up2 on the 3xBF16 split (fp32-accurate); channels at output resolution enter through pre_add (may be `out`)."""
+        xp, xbs, Cin, h, w = _view(x, "conv_up2_x3.x")
+        yp, ybs, Cout, H, W = _view(out, "conv_up2_x3.out")
+        if (Cin, Cout, 2 * h, 2 * w) != (pw.Cin, pw.Cout, H, W) or x.shape[0] != out.shape[0]:
+            raise ValueError("conv_up2_x3: shape mismatch x%s out%s" % (tuple(x.shape), tuple(out.shape)))
+        a = _lib.BfsrConvArgs()
+        a.x, a.x_bs, a.Cin = xp, xbs, Cin
+        a.w = pw.data.data_ptr()
+        a.y, a.y_bs, a.Cout = yp, ybs, Cout
+        a.B, a.H, a.W, a.KS, a.mtile, a.tune = out.shape[0], H, W, 3, 1, tune
+        a.epi, a.act, a.slope = _ptr(epi), act, slope
+        if pre_add is not None:
+            pp, bs, c, hh, ww = _view(pre_add, "conv_up2_x3.pre_add")
+            assert (c, hh, ww) == (Cout, H, W)
+            a.pre_add, a.pre_add_bs = pp, bs
+        key = ("conv_up2_x3", 1, Cin, Cout, out.shape[0], H, W, 0)
+        _lib.check(self._launch(key, lambda: self.lib.bfsr_conv2d_up2_bf16x3(C.byref(a), self._stream())), "conv2d_up2_bf16x3")
         return out
 
     def vec(self, t):

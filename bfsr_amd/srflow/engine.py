@@ -206,10 +206,16 @@ class SRFlowEngine(object):
                 # the 256 stacked-RRDB channels of this level are the LR-resolution taps upsampled x2: their share of the
                 # 3x3 conv runs on the LR grid with parity pre-summed weights (4/9 of the MACs, nothing materialised);
                 # the 64 native-resolution key channels are convolved into the same accumulators by the same kernel.
-                hz.update(up2=True,
-                          ft0_taps=ops.pack_conv_up2(wf[:, 64:].contiguous()), aff0_taps=ops.pack_conv_up2(wa[:, 64:].contiguous()),
-                          ft0_key=ops.pack_conv(wf[:, :64].contiguous(), 2), aff0_key=ops.pack_conv(wa[:, :64].contiguous(), 2),
+                hz.update(up2=True, x3=getattr(ops, "conv_mode", "f32") == "x3",
                           ft0_epi=ops.pack_epilogue(wf.shape[0], aff_shift=sh, aff_scale=sc))
+                if hz["x3"]:
+                    # 3xBF16 kernels: key channels by the plain conv (no epilogue) into the output buffer, then the taps
+                    # kernel adds them back through pre_add and applies the epilogue
+                    hz.update(ft0_taps=ops.pack_conv_up2_x3(wf[:, 64:].contiguous()), aff0_taps=ops.pack_conv_up2_x3(wa[:, 64:].contiguous()),
+                              ft0_key=ops.pack_conv_x3(wf[:, :64].contiguous(), 2), aff0_key=ops.pack_conv_x3(wa[:, :64].contiguous(), 2))
+                else:
+                    hz.update(ft0_taps=ops.pack_conv_up2(wf[:, 64:].contiguous()), aff0_taps=ops.pack_conv_up2(wa[:, 64:].contiguous()),
+                              ft0_key=ops.pack_conv(wf[:, :64].contiguous(), 2), aff0_key=ops.pack_conv(wa[:, :64].contiguous(), 2))
             else:
                 hz.update(ft0=_ConvP(ops, wf, aff_shift=sh, aff_scale=sc, mtile=2), aff0=_ConvP(ops, wa, mtile=2))
             self.hoist[level] = hz
@@ -291,8 +297,14 @@ class SRFlowEngine(object):
             h_ft = ws.get("h_ft%d" % level, B, K * 2 * Cz, hl, wl)
             if hz["up2"]:
                 taps = ft[self._lr_level()][:, 64:]
-                ops.conv_up2(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, key=(f, hz["ft0_key"]))
-                ops.conv_up2(taps, hz["aff0_taps"], pre_aff, key=(f, hz["aff0_key"]))
+                if hz["x3"]:
+                    ops.conv_x3(f, hz["ft0_key"], hid)
+                    ops.conv_up2_x3(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, pre_add=hid)
+                    ops.conv_x3(f, hz["aff0_key"], pre_aff)
+                    ops.conv_up2_x3(taps, hz["aff0_taps"], pre_aff, pre_add=pre_aff)
+                else:
+                    ops.conv_up2(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, key=(f, hz["ft0_key"]))
+                    ops.conv_up2(taps, hz["aff0_taps"], pre_aff, key=(f, hz["aff0_key"]))
             else:
                 hz["ft0"].run(ops, f, hid, act=ACT_RELU)
                 hz["aff0"].run(ops, f, pre_aff)

@@ -102,6 +102,12 @@ int bfsr_pack_conv_weight_f16(const float* w_oihw, int Cout, int Cin, int KS, in
 int bfsr_conv2d_bf16x3(const BfsrConvArgs* a, void* stream);
 long long bfsr_conv_packed_size_bf16x3(int Cout, int Cin, int KS, int mtile);   /* in bf16 elements */
 int bfsr_pack_conv_weight_bf16x3(const float* w_oihw, int Cout, int Cin, int KS, int mtile, unsigned short* packed);
+/* bfsr_conv2d_up2 on the same 3xBF16 scheme: x [B,Cin,H/2,W/2] -> y [B,Cout,H,W] with the 16 parity-pre-summed matrices
+ * (bfsr_pack_conv_weight_taps_bf16x3, T=16, mtile=1).  No x2/w_x2: channels at output resolution are convolved by
+ * bfsr_conv2d_bf16x3 first and enter through `pre_add` (which may alias y).  tune = NW*100+NR (0 = default). */
+int bfsr_conv2d_up2_bf16x3(const BfsrConvArgs* a, void* stream);
+long long bfsr_conv_packed_size_taps_bf16x3(int Cout, int Cin, int T, int mtile);
+int bfsr_pack_conv_weight_taps_bf16x3(const float* w_oit, int Cout, int Cin, int T, int mtile, unsigned short* packed);
 
 /* ---- fused flow-step pointwise chain -----------------------------------------------------------
  * One read of z / h_aff / h_ft, one write of z (the HBM-roofline "coupling inverse" kernel of

@@ -59,6 +59,12 @@ class CpuOps(object):
     def conv_x3(self, x, pw, out, **kw):
         return self.conv(x, pw, out, **kw)
 
+    def pack_conv_up2_x3(self, w):
+        return self.pack_conv_up2(w, 1)
+
+    def conv_up2_x3(self, x, pw, out, epi=None, pre_add=None, act=0, slope=0.2, tune=0):
+        return self.conv_up2(x, pw, out, epi=epi, pre_add=pre_add.clone() if pre_add is not None else None, act=act, slope=slope)
+
     def pack_conv_up2(self, w, mtile=2):
         return PackedConv(w.detach().to(torch.float32).contiguous().clone(), mtile)
 

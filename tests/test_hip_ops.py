@@ -334,3 +334,28 @@ def test_conv_bf16x3_is_fp32_accurate(hip, case):
         print("case %s tune %d: max-abs err vs fp64: bf16x3 %.2e, fp32 MFMA %.2e, torch CPU fp32 %.2e" % (case, tune, ex3, e32, ecpu))
         assert ex3 <= 2.0 * max(e32, ecpu) + 1e-7, (ex3, e32, ecpu)
         close(ox3, o32.cpu(), 1e-5, "bf16x3 vs fp32 %s" % (case,))
+
+
+@pytest.mark.parametrize("case", [(2, 70, 64, 64, 9, 21), (1, 256, 64, 128, 12, 40), (1, 24, 10, 40, 7, 35), (1, 48, 16, 96, 33, 50)])
+@pytest.mark.parametrize("tune", [402, 401, 801])
+def test_conv_up2_bf16x3_with_key_channels(hip, case, tune):
+    """The 3xBF16 pair (plain conv over the key channels -> taps kernel with pre_add aliasing the output) == the conv over
+    cat[key, nearest_up2(taps)], at fp32 accuracy."""
+    B, Ct, Ck, Cout, h, w_ = case
+    taps, key = rnd(180, B, Ct, h, w_), rnd(181, B, Ck, 2 * h, 2 * w_)
+    w = rnd(182, Cout, Ck + Ct, 3, 3, scale=1.0 / np.sqrt((Ck + Ct) * 9))
+    sh, sc = rnd(183, Cout, scale=0.2), torch.exp(rnd(184, Cout, scale=0.2))
+    wk, wt = w[:, :Ck].contiguous(), w[:, Ck:].contiguous()
+    xin = torch.cat([key, torch.nn.functional.interpolate(taps, scale_factor=2, mode="nearest")], 1)
+    truth = torch.relu((torch.nn.functional.conv2d(xin.double(), w.double(), padding=1) + sh.double().view(1, -1, 1, 1))
+                       * sc.double().view(1, -1, 1, 1))
+    out = hip.empty(B, Cout, 2 * h, 2 * w_)
+    hip.conv_x3(hip.to_device(key), hip.pack_conv_x3(wk, 2), out)
+    hip.conv_up2_x3(hip.to_device(taps), hip.pack_conv_up2_x3(wt), out, epi=hip.pack_epilogue(Cout, aff_shift=sh, aff_scale=sc),
+                    act=1, pre_add=out, tune=tune)
+    o32 = hip.conv_up2(hip.to_device(taps), hip.pack_conv_up2(wt, 2), hip.empty(B, Cout, 2 * h, 2 * w_),
+                       epi=hip.pack_epilogue(Cout, aff_shift=sh, aff_scale=sc), act=1, key=(hip.to_device(key), hip.pack_conv(wk, 2)))
+    ex3 = (out.cpu().double() - truth).abs().max().item()
+    e32 = (o32.cpu().double() - truth).abs().max().item()
+    assert ex3 <= 2.0 * e32 + 1e-7, (ex3, e32)
+    close(out, o32.cpu(), 1e-5, "conv_up2_x3 %s" % (case,))

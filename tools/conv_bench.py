@@ -44,8 +44,40 @@ SHAPES = [
 TUNES = [0, 208, 408, 216, 416]
 
 
+def up2_bench(ops):
+    """the dominant launch: conv over cat[64 key @320^2, up2(256 taps @160^2)] -> 1024, B=8"""
+    B, h = 8, 160
+    taps, key = torch.randn(B, 256, h, h, device="cuda"), torch.randn(B, 64, 2 * h, 2 * h, device="cuda")
+    w = torch.randn(1024, 320, 3, 3) * 0.02
+    out = ops.empty(B, 1024, 2 * h, 2 * h)
+    flop_t, flop_k = 2.0 * 256 * 4 * 1024 * B * 4 * h * h, 2.0 * 64 * 9 * 1024 * B * 4 * h * h
+
+    def timeit(fn, n=5):
+        fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(n):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / n * 1e3
+    pt, pk = ops.pack_conv_up2(w[:, 64:].contiguous()), ops.pack_conv(w[:, :64].contiguous(), 2)
+    us = timeit(lambda: ops.conv_up2(taps, pt, out, key=(key, pk)))
+    print("conv_up2 fp32 (taps+key)      %8.0fus %6.1fTF" % (us, (flop_t + flop_k) / us / 1e6))
+    ptx, pkx = ops.pack_conv_up2_x3(w[:, 64:].contiguous()), ops.pack_conv_x3(w[:, :64].contiguous(), 2)
+    usk = timeit(lambda: ops.conv_x3(key, pkx, out))
+    print("x3 key conv 64->1024 @320     %8.0fus %6.1fTF" % (usk, flop_k / usk / 1e6))
+    for t in (402, 401, 801):
+        us = timeit(lambda: ops.conv_up2_x3(taps, ptx, out, pre_add=out, tune=t))
+        print("x3 taps kernel tune %d       %8.0fus %6.1fTF   (pair: %.0fus %.1fTF)" % (t, us, flop_t / us / 1e6, us + usk,
+                                                                                   (flop_t + flop_k) / (us + usk) / 1e6), flush=True)
+
+
 def main():
     ops = HipOps("cuda:0")
+    if "--up2" in sys.argv:
+        return up2_bench(ops)
     quick = "--quick" in sys.argv
     only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
     tunes = [int(t) for a in sys.argv if a.startswith("--tunes=") for t in a.split("=", 1)[1].split(",")] or TUNES

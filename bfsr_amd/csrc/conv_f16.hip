@@ -4,8 +4,8 @@
 // fp32 (drop-in for bfsr_conv2d; NOT within the 1e-4 fp32 tolerance -- parity tests report the max-abs vs fp32).
 //
 // GEMM view: M = cout (MR tiles of 32), N = 32 pixels of a row, K = 16 input channels per MFMA.  LDS holds the input tile
-// channel-innermost ([position][16 halfs] = 32 B per pixel) so a B fragment (8 consecutive channels of one pixel) is one
-// ds_read_b128, and the weight slab as [tap][cout][16 halfs] so an A fragment is one ds_read_b128.
+// k-half-major ([k half][position][8 halfs]) and the weight slab as [tap][k half][cout][8 halfs]: each MFMA operand is one
+// ds_read_b128 per lane and the 64 lanes read 2 x 512 contiguous bytes (no bank conflicts).
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "../../include/bfsr_hip.h"
@@ -28,8 +28,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(BfsrConvArgs p, int ti
     constexpr int WV = (WSLAB / 8 + 255) / 256;      // 16-byte weight loads per thread
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    _Float16* sW = reinterpret_cast<_Float16*>(smem_raw);                 // [TAPS][MW][16]
-    _Float16* sIn = sW + WSLAB;                                           // [NPOS][16]
+    _Float16* sW = reinterpret_cast<_Float16*>(smem_raw);                 // [TAPS][k half][MW][8]
+    _Float16* sIn = sW + WSLAB;                                           // [k half][NPOS][8]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -94,9 +94,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(BfsrConvArgs p, int ti
                 half8 lo, hi;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) { lo[c] = (_Float16)vin[i][c]; hi[c] = (_Float16)vin[i][8 + c]; }
-                half8* dst = reinterpret_cast<half8*>(sIn + pos * CK);
-                dst[0] = lo;
-                dst[1] = hi;
+                *reinterpret_cast<half8*>(sIn + pos * 8) = lo;                 // k-half-major: conflict-free b128 accesses
+                *reinterpret_cast<half8*>(sIn + (NPOS + pos) * 8) = hi;
             }
         }
 #pragma unroll
@@ -106,18 +105,18 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(BfsrConvArgs p, int ti
         }
         __syncthreads();
         if (k + 1 < nchunk) load_chunk(k + 1);
-        const _Float16* inB = sIn + ((wave * NR) * PW + l31) * CK + lhi * 8;
-        const _Float16* wA = sW + l31 * CK + lhi * 8;
+        const _Float16* inB = sIn + (lhi * NPOS + (wave * NR) * PW + l31) * 8;
+        const _Float16* wA = sW + (lhi * MW + l31) * 8;
 #pragma unroll
         for (int dx = 0; dx < KS; ++dx) {
             half8 brow[NR + HALO];
 #pragma unroll
-            for (int r = 0; r < NR + HALO; ++r) brow[r] = *reinterpret_cast<const half8*>(inB + (r * PW + dx) * CK);
+            for (int r = 0; r < NR + HALO; ++r) brow[r] = *reinterpret_cast<const half8*>(inB + (r * PW + dx) * 8);
 #pragma unroll
             for (int dy = 0; dy < KS; ++dy) {
                 half8 a[MR];
 #pragma unroll
-                for (int m = 0; m < MR; ++m) a[m] = *reinterpret_cast<const half8*>(wA + ((dy * KS + dx) * MW + m * 32) * CK);
+                for (int m = 0; m < MR; ++m) a[m] = *reinterpret_cast<const half8*>(wA + ((dy * KS + dx) * 2 * MW + m * 32) * 8);
 #pragma unroll
                 for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -208,7 +207,7 @@ extern "C" long long bfsr_conv_packed_size_f16(int Cout, int Cin, int KS, int mt
 
 extern "C" int bfsr_pack_conv_weight_f16(const float* w, int Cout, int Cin, int KS, int mtile, unsigned short* packed)
 {
-    // w [Cout][Cin][KS][KS] fp32 -> fp16 [cout_group][chunk][tap][mtile*32][16], zero padded
+    // w [Cout][Cin][KS][KS] fp32 -> fp16 [cout_group][chunk][tap][k half][mtile*32][8], zero padded
     if ((KS != 1 && KS != 3) || mtile < 1) return -1;
     const int nchunk = (Cin + CK - 1) / CK, MW = mtile * 32, T = KS * KS;
     const int groups = ((Cout + 31) / 32 + mtile - 1) / mtile;
@@ -218,7 +217,7 @@ extern "C" int bfsr_pack_conv_weight_f16(const float* w, int Cout, int Cin, int 
         const int g = co / MW, m = co % MW;
         for (int ci = 0; ci < Cin; ++ci)
             for (int t = 0; t < T; ++t)
-                packed[((((long long)g * nchunk + ci / CK) * T + t) * MW + m) * CK + ci % CK] =
+                packed[(((((long long)g * nchunk + ci / CK) * T + t) * 2 + (ci % CK) / 8) * MW + m) * 8 + ci % 8] =
                     f32_to_f16_bits(w[((long long)co * Cin + ci) * T + t]);
     }
     return 0;

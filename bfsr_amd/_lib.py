@@ -62,6 +62,7 @@ class BfsrLinfFlowArgs(C.Structure):
         ("lin_w", C.c_void_p), ("lin_b", C.c_void_p),
         ("B", C.c_int), ("D", C.c_int), ("layers", C.c_int), ("qh", C.c_int), ("qw", C.c_int), ("reverse", C.c_int),
         ("eps", C.c_float),
+        ("log_p", C.c_void_p), ("logdet_const", C.c_float),
     ]
 
 
@@ -93,6 +94,8 @@ SYMBOLS = {
     "bfsr_maxpool2": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
     "bfsr_axpb_clamp": (_I, [_VP, _LL, _VP, _LL, _VP, _LL, _I, _I, _I, _I, _F, _F, _F, _F, _VP]),
     "bfsr_linf_features": (_I, [C.POINTER(BfsrLinfFeatArgs), _VP]),
+    "bfsr_logscale_sum": (_I, [_VP, _LL, _I, _I, _LL, _F, C.c_double, _VP, _VP]),
+    "bfsr_gaussian_logp": (_I, [_VP, _LL, _VP, _LL, _I, _I, _LL, C.c_double, _VP, _VP]),
     "bfsr_linf_flow": (_I, [C.POINTER(BfsrLinfFlowArgs), _VP]),
     "bfsr_patch_fold": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _I, _I, _I, _VP]),
     "bfsr_patch_unfold": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _I, _I, _I, _VP]),

@@ -355,7 +355,83 @@ __global__ void standardize_kernel(const float* __restrict__ x, long long x_bs, 
     for (int c = 0; c < C; ++c) yo[(long long)c * HW] = (xi[(long long)c * HW] - mean) / sd;
 }
 
+// ---- likelihood reductions (per-sample sums into double accumulators) --------------------------------------------
+__device__ __forceinline__ void block_atomic_add(double v, double* dst)
+{
+    __shared__ double part[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dst, part[0] + part[1] + part[2] + part[3]);
+}
+
+// h [B, 2*Cs, HW] cross split: scale raw = odd channels.  grid (blocks, B); a thread walks pixels with a grid stride.
+__global__ __launch_bounds__(256) void logscale_sum_kernel(const float* __restrict__ h, long long h_bs, int Cs, long long HW,
+                                                           float eps, double coef, double* __restrict__ out)
+{
+    const int b = blockIdx.y;
+    const float* hb = h + (long long)b * h_bs;
+    double acc = 0.0;
+    for (int j = 0; j < Cs; ++j) {
+        const float* hc = hb + (long long)(2 * j + 1) * HW;
+        float s = 0.f;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long long)gridDim.x * 256)
+            s += logf(1.f / (1.f + expf(-(hc[i] + 2.f))) + eps);
+        acc += (double)s;
+    }
+    block_atomic_add(acc * coef, out + b);
+}
+
+__global__ __launch_bounds__(256) void gaussian_logp_kernel(const float* __restrict__ x, long long x_bs, const float* __restrict__ h,
+                                                            long long h_bs, int C, long long HW, double coef, double* __restrict__ out)
+{
+    constexpr float LOG2PI = 1.8378770664093453f;
+    const int b = blockIdx.y;
+    const float* xb = x + (long long)b * x_bs;
+    const float* hb = h ? h + (long long)b * h_bs : nullptr;
+    double acc = 0.0;
+    for (int c = 0; c < C; ++c) {
+        float s = 0.f;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long long)gridDim.x * 256) {
+            const float v = xb[(long long)c * HW + i];
+            if (hb) {
+                const float mean = hb[(long long)(2 * c) * HW + i], logs = hb[(long long)(2 * c + 1) * HW + i];
+                const float d = v - mean;
+                s += -0.5f * (logs * 2.f + d * d / expf(logs * 2.f) + LOG2PI);
+            } else {
+                s += -0.5f * (v * v + LOG2PI);
+            }
+        }
+        acc += (double)s;
+    }
+    block_atomic_add(acc * coef, out + b);
+}
+
 }  // namespace
+
+extern "C" int bfsr_logscale_sum(const float* h, long long h_bs, int B, int Cs, long long HW, float eps, double coef, double* out,
+                                 void* stream)
+{
+    if (!h || !out || B <= 0 || Cs <= 0 || HW <= 0) return -1;
+    long long blocks = (HW + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(logscale_sum_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       h, h_bs, Cs, HW, eps, coef, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bfsr_gaussian_logp(const float* x, long long x_bs, const float* h, long long h_bs, int B, int C, long long HW,
+                                  double coef, double* out, void* stream)
+{
+    if (!x || !out || B <= 0 || C <= 0 || HW <= 0) return -1;
+    long long blocks = (HW + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(gaussian_logp_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       x, x_bs, h, h_bs, C, HW, coef, out);
+    return (int)hipGetLastError();
+}
+
 
 extern "C" int bfsr_flow_pointwise(const BfsrFlowArgs* a, void* stream)
 {

@@ -105,15 +105,25 @@ __global__ __launch_bounds__(256) void linf_flow_kernel(BfsrLinfFlowArgs a)
     };
 
     if (!a.reverse) {
+        float ld = a.logdet_const;
+        const bool want_lp = a.log_p != nullptr;
         for (int i = 0; i < L; ++i) {
             linear(i, false);
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 const float sr = ai[(long long)(2 * D * i + d) * NQ], sh = ai[(long long)(2 * D * i + D + d) * NQ];
-                x[d] = x[d] * (1.f / (1.f + expf(-(sr + 2.f))) + a.eps) + sh;
+                const float sc = 1.f / (1.f + expf(-(sr + 2.f))) + a.eps;
+                x[d] = x[d] * sc + sh;
+                if (want_lp) ld += logf(sc);
             }
         }
         linear(L, false);
+        if (want_lp) {
+            float base = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) base += -0.5f * (x[d] * x[d] + 1.8378770664093453f);
+            a.log_p[(long long)b * NQ + q] = ld + base;
+        }
     } else {
         linear(L, true);
         for (int i = L - 1; i >= 0; --i) {

@@ -81,6 +81,7 @@ class LINFEngine(object):
         self.lin_b = ops.vec(torch.stack([sd[n + ".bias"] for n in names]))
         self.lin_w = ops.vec(W)
         self.lin_winv = ops.vec(torch.inverse(W.double()).float())
+        self.logdet_const = float(sum(torch.slogdet(w.detach().cpu().float())[1] for w in W))     # NaiveLinear logabsdet, flow.py:66-70
         self._feat_key = self._feat = None
         self._cond_key = self._cond = None
 
@@ -116,11 +117,16 @@ class LINFEngine(object):
         self._cond_key, self._cond = key, x
         return x
 
-    def query_log_p(self, feat, coord, cell, gt):
-        """-> z [B,D,qh,qw] (log_p is not computed)."""
+    def query_log_p(self, feat, coord, cell, gt, with_logp=False):
+        """-> z [B,D,qh,qw]; with_logp: (log_p [B*qh*qw], z) = the reference's return pair (linf.py:319-322; per point
+        sum of slogdet(W) + sum log(scale) over the layers + the standard-normal log-prob of z, flow.py:44-55)."""
         ai = self.affine_info(feat, coord, cell)
         z = self.ops.empty(*gt.shape)
-        return self.ops.linf_flow(gt, ai, z, self.lin_w, self.lin_b, self.L, reverse=False)
+        if not with_logp:
+            return self.ops.linf_flow(gt, ai, z, self.lin_w, self.lin_b, self.L, reverse=False)
+        lp = self.ops.empty(gt.shape[0] * gt.shape[2] * gt.shape[3])
+        self.ops.linf_flow(gt, ai, z, self.lin_w, self.lin_b, self.L, reverse=False, log_p=lp, logdet_const=self.logdet_const)
+        return lp, z
 
     def query_rgb(self, feat, coord, cell, zmap, inp=None):
         """patch model: -> folded prediction [B,3,ps*qh,ps*qw] (no skip; the harness adds it, LINF-LP/test.py:169-171).

@@ -3,8 +3,8 @@
 `forward(op, inp, feat, coord, cell, gt, temperature, zmap)` with op in {"gen_feat", "query_log_p", "query_rgb",
 "log_p", "rgb"}; nested `encoder_spec` / `imnet_spec` are resolved through the registry like the reference
 (linf.py:225,242); state_dict keys are the reference's (`encoder.*`, `coef`, `freq`, `phase`, `layers.{0,2,4,6}`,
-`imnet.linears.{i}.{bias,_weight}`, `imnet.last.*`).  `log_p` values are not computed (None is returned in their
-place; the LP harness discards them, LINF-LP/test.py:43)."""
+`imnet.linears.{i}.{bias,_weight}`, `imnet.last.*`).  `query_log_p` returns the reference's pair (log_p per query point, z);
+the LP harness only uses z (LINF-LP/test.py:43)."""
 import torch
 from torch import nn
 
@@ -58,7 +58,7 @@ class LINFPatch(nn.Module):
     def query_log_p(self, inp, feat, coord, cell, gt):
         e = self.engine()
         d = e.ops.to_device
-        return None, e.query_log_p(d(feat), d(coord), d(cell), d(gt))
+        return e.query_log_p(d(feat), d(coord), d(cell), d(gt), with_logp=True)
 
     def query_rgb(self, inp, feat, coord, cell, temperature=0, zmap=None):
         e = self.engine()

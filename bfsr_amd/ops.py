@@ -415,8 +415,36 @@ class HipOps(object):
         _lib.check(self._launch(("linf_features",) + tuple(out.shape), lambda: self.lib.bfsr_linf_features(C.byref(a), self._stream())), "linf_features")
         return out
 
-    def linf_flow(self, x, ai, y, lin_w, lin_b, layers, reverse, eps=1e-4):
+    def logscale_sum(self, h, acc, coef=1.0, eps=1e-4):
+        """acc[b] (float64 [B]) += coef * sum log(sigmoid(h[:, 1::2] + 2) + eps): an affine coupling's get_logdet(scale)."""
+        hp, hbs, c2, H, W = _view(h, "logscale_sum.h")
+        assert c2 % 2 == 0 and acc.dtype == torch.float64 and acc.numel() == h.shape[0] and acc.is_contiguous()
+        _lib.check(self._launch(("logscale_sum", c2, h.shape[0], H, W),
+                                lambda: self.lib.bfsr_logscale_sum(hp, hbs, h.shape[0], c2 // 2, H * W, eps, coef, acc.data_ptr(), self._stream())),
+                   "logscale_sum")
+        return acc
+
+    def gaussian_logp(self, x, acc, h=None, coef=1.0):
+        """acc[b] += coef * GaussianDiag.logp(mean, logs, x) with mean,logs = h[:, 0::2], h[:, 1::2] (standard normal if h is None)."""
+        xp, xbs, Cx, H, W = _view(x, "gaussian_logp.x")
+        hp, hbs = 0, 0
+        if h is not None:
+            hp, hbs, c2, hh, ww = _view(h, "gaussian_logp.h")
+            assert (c2, hh, ww) == (2 * Cx, H, W)
+        assert acc.dtype == torch.float64 and acc.numel() == x.shape[0] and acc.is_contiguous()
+        _lib.check(self._launch(("gaussian_logp", Cx, x.shape[0], H, W),
+                                lambda: self.lib.bfsr_gaussian_logp(xp, xbs, hp, hbs, x.shape[0], Cx, H * W, coef, acc.data_ptr(), self._stream())),
+                   "gaussian_logp")
+        return acc
+
+    def zeros_f64(self, n):
+        return torch.zeros(n, dtype=torch.float64, device=self.device)
+
+    def linf_flow(self, x, ai, y, lin_w, lin_b, layers, reverse, eps=1e-4, log_p=None, logdet_const=0.0):
         a = _lib.BfsrLinfFlowArgs()
+        if log_p is not None:
+            assert not reverse and log_p.is_contiguous() and log_p.numel() == x.shape[0] * x.shape[2] * x.shape[3]
+            a.log_p, a.logdet_const = log_p.data_ptr(), float(logdet_const)
         a.x, a.x_bs, D, qh, qw = _view(x, "linf_flow.x")
         a.ai, a.ai_bs, ca, _, _ = _view(ai, "linf_flow.ai")
         a.y, a.y_bs, _, _, _ = _view(y, "linf_flow.y")

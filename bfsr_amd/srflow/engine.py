@@ -168,6 +168,8 @@ class SRFlowEngine(object):
                 st.an_bias = ops.vec(sd[p + "actnorm.bias"])
                 st.an_exp = ops.vec(torch.exp(logs))
                 st.an_expneg = ops.vec(torch.exp(-logs))
+                # per-pixel logdet of actnorm + invconv (FlowActNorms.py:85-91, Permutations.py:37)
+                st.ld_const = float(logs.double().sum()) + float(torch.slogdet(W.detach().cpu().double())[1])
                 if ly.coupled:
                     cn = C // 2
                     a = p + "affine.fAffine."
@@ -331,13 +333,16 @@ class SRFlowEngine(object):
         st.aff4.run(ops, hid, h_aff)
         return h_aff
 
-    def encode(self, gt, lr):
-        """normal flow (FlowUpsamplerNet.encode :217-251): gt [B,3,H,W] -> [eps_split..., z_final]."""
+    def encode(self, gt, lr, logdet=None):
+        """normal flow (FlowUpsamplerNet.encode :217-251): gt [B,3,H,W] -> [eps_split..., z_final].
+        logdet: optional float64 [B] accumulator that receives the flow's log-determinant (actnorm + invconv constants,
+        sum log(scale) of both couplings per step, Split2d log-likelihood) -- the reference's `logdet` return value."""
         ops, ws = self.ops, self.ws
         cond = self.conditioning(lr)
         z = gt
         epses = []
         pending = None           # h_aff of the previous coupled step, applied lazily by the next head
+        ld_const, ld_levels = 0.0, set()
         for ly in self.layers:
             B, _, H, W = z.shape
             if ly.type == "squeeze":
@@ -354,9 +359,15 @@ class SRFlowEngine(object):
                     ops.flow_pointwise(z, z, False, h_aff=pending, an_bias=st.an_bias, an_escale=st.an_exp,
                                        w=st.w_fwd, wt=st.w_fwd_t, h_ft=cnd["h_ft"][:, 2 * ly.C * k: 2 * ly.C * (k + 1)])
                     pending = self._self_cond(st, z, cnd, k, "enc%d" % ly.level)
+                    if logdet is not None:
+                        ops.logscale_sum(pending, logdet, 1.0)
+                        if ly.level not in ld_levels:           # the hoisted h_ft holds the scaleFt of all K steps of the level
+                            ld_levels.add(ly.level)
+                            ops.logscale_sum(cnd["h_ft"], logdet, 1.0)
                 else:
                     ops.flow_pointwise(z, z, False, h_aff=pending, an_bias=st.an_bias, an_escale=st.an_exp, w=st.w_fwd, wt=st.w_fwd_t)
                     pending = None
+                ld_const += st.ld_const * H * W
             else:   # split
                 if pending is not None:
                     ops.flow_pointwise(z, z, False, h_aff=pending)
@@ -365,6 +376,8 @@ class SRFlowEngine(object):
                 self.splits[ly.index].run(ops, z[:, :ly.C_pass], h)
                 e = ops.empty(B, ly.C_consume, H, W)
                 ops.split2d(h, z[:, ly.C_pass:], e, False)
+                if logdet is not None:
+                    ops.gaussian_logp(z[:, ly.C_pass:], logdet, h=h, coef=1.0)
                 epses.append(e)
                 z = z[:, :ly.C_pass]
         if pending is not None:
@@ -372,12 +385,16 @@ class SRFlowEngine(object):
         zf = ops.empty(*z.shape)
         ops.axpb_clamp(z, zf)               # detach the result from the workspace
         epses.append(zf)
+        if logdet is not None:
+            logdet += ld_const
         return epses
 
-    def decode(self, lr, epses=None, z=None, eps_std=None):
-        """reverse flow (FlowUpsamplerNet.decode :267-296): [eps_split..., z_final] -> sr [B,3,H,W]."""
+    def decode(self, lr, epses=None, z=None, eps_std=None, logdet=None):
+        """reverse flow (FlowUpsamplerNet.decode :267-296): [eps_split..., z_final] -> sr [B,3,H,W].
+        logdet: optional float64 [B] accumulator (every term of encode() enters with the opposite sign)."""
         ops, ws = self.ops, self.ws
         cond = self.conditioning(lr)
+        ld_const, ld_levels = 0.0, set()
         epses = list(epses) if epses is not None else None
         zin = epses.pop() if epses is not None else z
         B = zin.shape[0]
@@ -394,10 +411,16 @@ class SRFlowEngine(object):
                     cnd = cond[ly.level]
                     k = cnd["slot"][ly.index]
                     h_aff = self._self_cond(st, z, cnd, k, "dec%d" % ly.level)
+                    if logdet is not None:
+                        ops.logscale_sum(h_aff, logdet, -1.0)
+                        if ly.level not in ld_levels:
+                            ld_levels.add(ly.level)
+                            ops.logscale_sum(cnd["h_ft"], logdet, -1.0)
                     ops.flow_pointwise(z, z, True, h_aff=h_aff, h_ft=cnd["h_ft"][:, 2 * C * k: 2 * C * (k + 1)],
                                        w=st.w_inv, wt=st.w_inv_t, an_bias=st.an_bias, an_escale=st.an_expneg)
                 else:
                     ops.flow_pointwise(z, z, True, w=st.w_inv, wt=st.w_inv_t, an_bias=st.an_bias, an_escale=st.an_expneg)
+                ld_const -= st.ld_const * H * W
             elif ly.type == "squeeze":
                 Co = C // 4
                 nxt = self.layers[pos - 1] if pos > 0 else None
@@ -420,5 +443,9 @@ class SRFlowEngine(object):
                 else:   # tau path: eps ~ N(0, eps_std) sampled on device (plumbing)
                     e = torch.randn(B, ly.C_consume, H, W, device=z.device, dtype=torch.float32) * float(eps_std or 1)
                 ops.split2d(h, e, full[:, ly.C_pass:], True)
+                if logdet is not None:
+                    ops.gaussian_logp(full[:, ly.C_pass:], logdet, h=h, coef=-1.0)
                 z = full
+        if logdet is not None:
+            logdet += ld_const
         return z

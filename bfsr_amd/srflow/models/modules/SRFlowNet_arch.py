@@ -7,8 +7,11 @@ Constructor and `forward` signatures, the `epses` list convention (encode append
 and the state_dict key names are the reference's.  The computation is scheduled by
 `bfsr_amd.srflow.engine.SRFlowEngine` on the HIP kernels.
 
-Not reproduced: `logdet` / `nll` values -- the LP inference path discards them
-(test.py:139, SRFlow_model.py:199); zeros of the right shape are returned."""
+`forward(reverse=False)` returns `(epses | z, nll, logdet)` and `forward(reverse=True)` `(sr, logdet)` with the reference's
+values (SRFlowNet_arch.py:83-116,145-158): the flow's log-determinant is accumulated per sample in float64 on the device
+(`bfsr_logscale_sum`, `bfsr_gaussian_logp`) and returned as float32.  The LP harness (`test.py`) calls the engine directly
+and skips these reductions, as the reference discards the values there (test.py:139)."""
+import numpy as np
 import torch
 from torch import nn
 
@@ -70,7 +73,7 @@ class SRFlowNet(nn.Module):
             if not reverse:
                 return self.normal_flow(dev(gt), dev(lr), epses=epses, add_gt_noise=add_gt_noise)
             assert lr.shape[1] == 3
-            return self.reverse_flow(dev(lr), z, eps_std=eps_std, epses=epses)
+            return self.reverse_flow(dev(lr), z, eps_std=eps_std, epses=epses, add_gt_noise=add_gt_noise)
 
     def normal_flow(self, gt, lr, y_onehot=None, epses=None, lr_enc=None, add_gt_noise=True, step=None):
         eng = self.engine()
@@ -78,17 +81,27 @@ class SRFlowNet(nn.Module):
         if add_gt_noise:    # SRFlowNet_arch.py:93-99 (training-time dequantisation noise; plumbing on torch)
             if opt_get(self.opt, ['network_G', 'flow', 'augmentation', 'noiseQuant'], True):
                 z = z + ((torch.rand(z.shape, device=z.device) - 0.5) / self.quant)
-        out = eng.encode(z, lr)
-        zeros = torch.zeros(gt.shape[0], device=gt.device)
+        ops = eng.ops
+        pixels = int(gt.shape[2] * gt.shape[3])
+        acc = ops.zeros_f64(gt.shape[0])
+        if add_gt_noise:
+            acc += float(-np.log(self.quant) * pixels)
+        out = eng.encode(z, lr, logdet=acc)
+        objective = ops.gaussian_logp(out[-1], acc.clone())            # + GaussianDiag.logp(None, None, z), :108
+        nll = ((-objective) / float(np.log(2.) * pixels)).float()
+        logdet = acc.float()
         if isinstance(epses, list):
             epses.extend(out)
-            return epses, zeros, zeros.clone()
-        return out[-1], zeros, zeros.clone()
+            return epses, nll, logdet
+        return out[-1], nll, logdet
 
     def reverse_flow(self, lr, z, y_onehot=None, eps_std=None, epses=None, lr_enc=None, add_gt_noise=True):
         eng = self.engine()
+        acc = eng.ops.zeros_f64(lr.shape[0])
+        if add_gt_noise:       # SRFlowNet_arch.py:149-150
+            acc -= float(-np.log(self.quant) * int(lr.shape[2] * lr.shape[3]) * self.opt['scale'] ** 2)
         if isinstance(epses, list):
-            sr = eng.decode(lr, epses=[eng.ops.to_device(e) for e in epses])
+            sr = eng.decode(lr, epses=[eng.ops.to_device(e) for e in epses], logdet=acc)
         else:
-            sr = eng.decode(lr, z=eng.ops.to_device(z), eps_std=eps_std)
-        return sr, torch.zeros(lr.shape[0], device=sr.device)
+            sr = eng.decode(lr, z=eng.ops.to_device(z), eps_std=eps_std, logdet=acc)
+        return sr, acc.float()

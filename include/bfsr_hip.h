@@ -153,6 +153,17 @@ int bfsr_unsqueeze2d(const float* x, long long x_bs, float* y, long long y_bs, i
 int bfsr_split2d(const float* h, long long h_bs, const float* src, long long src_bs, float* dst,
                  long long dst_bs, int B, int Cc, int H, int W, int reverse, void* stream);
 
+/* likelihood terms of the flow (parity with the `logdet` / `nll` return values, SRFlowNet_arch.py:83-116,145-158).
+ * Both add coef * (per-sample sum) into out[b] (double, atomically; zero it before the first call):
+ *   bfsr_logscale_sum : sum over j < Cs and pixels of log(sigmoid(h[2j+1] + 2) + eps)   -- the affine couplings'
+ *                       get_logdet(scale) (FlowAffineCouplingsAblation.py:66,75,86,92); h = Conv2dZeros output, cross split
+ *   bfsr_gaussian_logp: GaussianDiag.logp (flow.py:86-107): h == NULL: sum -0.5*(x^2 + log 2pi); else mean,logs =
+ *                       h[2c], h[2c+1]: sum -0.5*(2*logs + (x-mean)^2/exp(2*logs) + log 2pi)   (Split.py:56,74,77-80) */
+int bfsr_logscale_sum(const float* h, long long h_bs, int B, int Cs, long long HW, float eps, double coef, double* out,
+                      void* stream);
+int bfsr_gaussian_logp(const float* x, long long x_bs, const float* h, long long h_bs, int B, int C, long long HW,
+                       double coef, double* out, void* stream);
+
 /* per-pixel channel standardisation (SRFlow-LP/code/test.py:141-145): (e-mean_c)/(std_c(unbiased)+1e-8) */
 int bfsr_standardize(const float* x, long long x_bs, float* y, long long y_bs, int B, int C, int H, int W,
                      void* stream);
@@ -202,6 +213,9 @@ typedef struct BfsrLinfFlowArgs {
     const float* lin_w; const float* lin_b;
     int B, D, layers, qh, qw, reverse;
     float eps;
+    float* log_p;              /* optional (forward only): [B][qh*qw] total log-det + base log-prob per query point
+                                * (flow.py:44-55); logdet_const = sum over the layers+1 linears of slogdet(W)[1] */
+    float logdet_const;
 } BfsrLinfFlowArgs;
 int bfsr_linf_flow(const BfsrLinfFlowArgs* a, void* stream);
 

@@ -179,15 +179,22 @@ def _flow_affine(ai, i, D):
     return torch.sigmoid(s + 2.0) + 1e-4, shift
 
 
-def flow_forward(x, ai, sd, p="imnet", n_layers=10):
-    """Flow.forward, models/flow.py:44-55 (log-det discarded by the caller)."""
+def flow_forward(x, ai, sd, p="imnet", n_layers=10, with_logp=False):
+    """Flow.forward, models/flow.py:44-55.  with_logp: also return total_log_det_J + base log-prob per point
+    (NaiveLinear logabsdet = slogdet(W)[1] :66-70,:106; affine sum(log scale) :28-36; -0.5*(z^2 + log 2pi) :54)."""
     D = x.shape[1]
     z = x
+    tot = x.new_zeros(x.shape[0])
     for i in range(n_layers):
         z = F.linear(z, sd[f"{p}.linears.{i}._weight"], sd[f"{p}.linears.{i}.bias"])
+        tot += torch.slogdet(sd[f"{p}.linears.{i}._weight"])[1] * z.new_ones(z.shape[0])
         scale, shift = _flow_affine(ai, i, D)
         z = z * scale + shift
-    return F.linear(z, sd[f"{p}.last._weight"], sd[f"{p}.last.bias"])
+        tot += torch.sum(torch.log(scale), dim=-1)
+    z = F.linear(z, sd[f"{p}.last._weight"], sd[f"{p}.last.bias"])
+    tot += torch.slogdet(sd[f"{p}.last._weight"])[1] * z.new_ones(z.shape[0])
+    tot += torch.sum(-0.5 * (z ** 2 + float(np.log(2 * np.pi))), -1)
+    return (z, tot) if with_logp else z
 
 
 def flow_inverse(z, ai, sd, p="imnet", n_layers=10):
@@ -206,12 +213,15 @@ def flow_inverse(z, ai, sd, p="imnet", n_layers=10):
     return x
 
 
-def query_log_p(feat, coord, cell, gt, sd, n_layers=10):
-    """LINFPatch.query_log_p, linf.py:248-322 -> z [B,D,qh,qw]."""
+def query_log_p(feat, coord, cell, gt, sd, n_layers=10, with_logp=False):
+    """LINFPatch.query_log_p, linf.py:248-322 -> z [B,D,qh,qw]  (with_logp: (log_p [B*qh*qw], z) like the reference)."""
     ai = affine_info(feat, coord, cell, sd)
     bs, qh, qw, _ = coord.shape
     x = gt.permute(0, 2, 3, 1).contiguous().view(bs * qh * qw, -1)
     a = ai.permute(0, 2, 3, 1).contiguous().view(bs * qh * qw, -1)
+    if with_logp:
+        z, lp = flow_forward(x, a, sd, n_layers=n_layers, with_logp=True)
+        return lp, z.reshape(bs, qh, qw, -1).permute(0, 3, 1, 2)
     z = flow_forward(x, a, sd, n_layers=n_layers)
     return z.reshape(bs, qh, qw, -1).permute(0, 3, 1, 2)
 

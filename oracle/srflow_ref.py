@@ -120,8 +120,16 @@ def cross_split(h):
     return h[:, 0::2], h[:, 1::2]
 
 
-def coupling(z, ft, sd, p, reverse, eps=1e-4):
-    """CondAffineSeparatedAndCond.forward, FlowAffineCouplingsAblation.py:57-97."""
+def _sum123(t):
+    """thops.sum(t, dim=[1,2,3]) (thops.py:4-18: the dims are reduced one at a time, last first)."""
+    for d in (3, 2, 1):
+        t = t.sum(dim=d)
+    return t
+
+
+def coupling(z, ft, sd, p, reverse, eps=1e-4, ld=None):
+    """CondAffineSeparatedAndCond.forward, FlowAffineCouplingsAblation.py:57-97.
+    `ld` (optional one-element list) carries the running logdet [B]: += sum log(scale) forward (:66,:75), -= reverse (:86,:92)."""
     C = z.shape[1]
     cn = C // 2
     if not reverse:
@@ -129,11 +137,15 @@ def coupling(z, ft, sd, p, reverse, eps=1e-4):
         scaleFt = torch.sigmoid(scaleFt + 2.0) + eps
         z = z + shiftFt
         z = z * scaleFt
+        if ld is not None:
+            ld[0] = ld[0] + _sum123(torch.log(scaleFt))
         z1, z2 = z[:, :cn], z[:, cn:]
         shift, scale = cross_split(coupling_net(torch.cat([z1, ft], 1), sd, p + ".fAffine"))
         scale = torch.sigmoid(scale + 2.0) + eps
         z2 = z2 + shift
         z2 = z2 * scale
+        if ld is not None:
+            ld[0] = ld[0] + _sum123(torch.log(scale))
         return torch.cat((z1, z2), 1)
     z1, z2 = z[:, :cn], z[:, cn:]
     shift, scale = cross_split(coupling_net(torch.cat([z1, ft], 1), sd, p + ".fAffine"))
@@ -141,25 +153,45 @@ def coupling(z, ft, sd, p, reverse, eps=1e-4):
     z2 = z2 / scale
     z2 = z2 - shift
     z = torch.cat((z1, z2), 1)
+    if ld is not None:
+        ld[0] = ld[0] - _sum123(torch.log(scale))
     shiftFt, scaleFt = cross_split(coupling_net(ft, sd, p + ".fFeatures"))
     scaleFt = torch.sigmoid(scaleFt + 2.0) + eps
     z = z / scaleFt
     z = z - shiftFt
+    if ld is not None:
+        ld[0] = ld[0] - _sum123(torch.log(scaleFt))
     return z
 
 
-def flow_step(z, ft, sd, p, coupled, reverse):
-    """FlowStep.normal_flow :88-111 / reverse_flow :113-129."""
+def _pixels(t):
+    return int(t.shape[2] * t.shape[3])          # thops.pixels, thops.py:67-68
+
+
+def flow_step(z, ft, sd, p, coupled, reverse, ld=None):
+    """FlowStep.normal_flow :88-111 / reverse_flow :113-129.  logdet terms: actnorm sum(logs)*pixels
+    (FlowActNorms.py:85-91), invconv slogdet(W)[1]*pixels (Permutations.py:37,51-57)."""
+    if ld is not None:
+        d_an = sd[p + ".actnorm.logs"].sum() * _pixels(z)
+        d_w = torch.slogdet(sd[p + ".invconv.weight"])[1] * _pixels(z)
     if not reverse:
         z = actnorm(z, sd[p + ".actnorm.bias"], sd[p + ".actnorm.logs"], False)
+        if ld is not None:
+            ld[0] = ld[0] + d_an
         z = invconv(z, sd[p + ".invconv.weight"], False)
+        if ld is not None:
+            ld[0] = ld[0] + d_w
         if coupled:
-            z = coupling(z, ft, sd, p + ".affine", False)
+            z = coupling(z, ft, sd, p + ".affine", False, ld=ld)
         return z
     if coupled:
-        z = coupling(z, ft, sd, p + ".affine", True)
+        z = coupling(z, ft, sd, p + ".affine", True, ld=ld)
     z = invconv(z, sd[p + ".invconv.weight"], True)
+    if ld is not None:
+        ld[0] = ld[0] - d_w
     z = actnorm(z, sd[p + ".actnorm.bias"], sd[p + ".actnorm.logs"], True)
+    if ld is not None:
+        ld[0] = ld[0] + d_an * -1
     return z
 
 
@@ -180,16 +212,30 @@ def unsqueeze2d(x, factor=2):
     return x.view(B, C // f2, H * factor, W * factor)
 
 
-def split2d(z, sd, p, C_pass, reverse, eps=None):
-    """Split.py:48-77 (position=None => no ft; logs_eps=0)."""
+LOG2PI = float(np.log(2 * np.pi))
+
+
+def gaussian_logp(mean, logs, x):
+    """flow.py:86-107 GaussianDiag.logp."""
+    if mean is None and logs is None:
+        return _sum123(-0.5 * (x ** 2 + LOG2PI))
+    return _sum123(-0.5 * (logs * 2. + ((x - mean) ** 2) / torch.exp(logs * 2.) + LOG2PI))
+
+
+def split2d(z, sd, p, C_pass, reverse, eps=None, ld=None):
+    """Split.py:48-77 (position=None => no ft; logs_eps=0).  logdet += / -= GaussianDiag.logp(mean, logs, z2) (:56,:74)."""
     if not reverse:
         z1, z2 = z[:, :C_pass], z[:, C_pass:]
         mean, logs = cross_split(conv2d_zeros(z1, sd, p + ".conv"))
         e = (z2 - mean) / torch.exp(logs)
+        if ld is not None:
+            ld[0] = ld[0] + gaussian_logp(mean, logs, z2)
         return z1, e
     z1 = z
     mean, logs = cross_split(conv2d_zeros(z1, sd, p + ".conv"))
     z2 = mean + torch.exp(logs) * eps
+    if ld is not None:
+        ld[0] = ld[0] - gaussian_logp(mean, logs, z2)
     return torch.cat((z1, z2), 1)
 
 
@@ -278,7 +324,7 @@ def _level(size):
     return int(np.log(160 / size) / np.log(2))
 
 
-def flow_encode(gt, lr_enc, sd, opt, p="flowUpsamplerNet"):
+def flow_encode(gt, lr_enc, sd, opt, p="flowUpsamplerNet", ld=None):
     """FlowUpsamplerNet.encode :217-251 with epses=[] => returns [eps_split..., z_final]."""
     names = level_to_name(opt["scale"])
     z = gt
@@ -288,15 +334,15 @@ def flow_encode(gt, lr_enc, sd, opt, p="flowUpsamplerNet"):
         if ly["type"] == "squeeze":
             z = squeeze2d(z)
         elif ly["type"] == "step":
-            z = flow_step(z, ft, sd, f"{p}.layers.{i}", ly["coupled"], False)
+            z = flow_step(z, ft, sd, f"{p}.layers.{i}", ly["coupled"], False, ld=ld)
         else:
-            z, e = split2d(z, sd, f"{p}.layers.{i}", ly["C_pass"], False)
+            z, e = split2d(z, sd, f"{p}.layers.{i}", ly["C_pass"], False, ld=ld)
             epses.append(e)
     epses.append(z)
     return epses
 
 
-def flow_decode(epses, lr_enc, sd, opt, p="flowUpsamplerNet"):
+def flow_decode(epses, lr_enc, sd, opt, p="flowUpsamplerNet", ld=None):
     """FlowUpsamplerNet.decode :267-296 (epses copied then popped from the end)."""
     names = level_to_name(opt["scale"])
     epses = list(epses)
@@ -308,9 +354,9 @@ def flow_decode(epses, lr_enc, sd, opt, p="flowUpsamplerNet"):
         if ly["type"] == "squeeze":
             z = unsqueeze2d(z)
         elif ly["type"] == "step":
-            z = flow_step(z, ft, sd, f"{p}.layers.{i}", ly["coupled"], True)
+            z = flow_step(z, ft, sd, f"{p}.layers.{i}", ly["coupled"], True, ld=ld)
         else:
-            z = split2d(z, sd, f"{p}.layers.{i}", ly["C_pass"], True, eps=epses.pop())
+            z = split2d(z, sd, f"{p}.layers.{i}", ly["C_pass"], True, eps=epses.pop(), ld=ld)
     return z
 
 
@@ -318,6 +364,23 @@ def srflow_encode(gt, lr, sd, opt, nb):
     """SRFlowNet.normal_flow (add_gt_noise=False), SRFlowNet_arch.py:83-116; logdet/nll discarded
     by the caller (test.py:139)."""
     return flow_encode(gt, rrdb_preprocessing(lr, sd, opt, nb), sd, opt)
+
+
+def srflow_normal_flow(gt, lr, sd, opt, nb):
+    """SRFlowNet.normal_flow with add_gt_noise=False and epses=[] (SRFlowNet_arch.py:83-116): -> (epses, nll, logdet)."""
+    ld = [torch.zeros_like(gt[:, 0, 0, 0])]
+    pixels = _pixels(gt)
+    epses = flow_encode(gt, rrdb_preprocessing(lr, sd, opt, nb), sd, opt, ld=ld)
+    objective = ld[0].clone() + gaussian_logp(None, None, epses[-1])
+    nll = (-objective) / float(np.log(2.) * pixels)
+    return epses, nll, ld[0]
+
+
+def srflow_reverse_flow(lr, epses, sd, opt, nb):
+    """SRFlowNet.reverse_flow with add_gt_noise=False (SRFlowNet_arch.py:145-158): -> (sr, logdet)."""
+    ld = [torch.zeros_like(lr[:, 0, 0, 0])]
+    x = flow_decode(epses, rrdb_preprocessing(lr, sd, opt, nb), sd, opt, ld=ld)
+    return x, ld[0]
 
 
 def srflow_decode(lr, epses, sd, opt, nb):

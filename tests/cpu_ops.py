@@ -4,6 +4,7 @@ Two uses: (1) `-m "not gpu"` tests run the product's host-side schedule (hoistin
 packing order, split/squeeze plumbing) on CPU against the oracle and the golden vectors; (2) `-m gpu` tests
 compare every HIP op against the same semantics on seeded inputs.  Never imported by the product.
 """
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -259,7 +260,23 @@ class CpuOps(object):
         out.copy_(torch.cat([((areas[i] / tot).unsqueeze(1) * coefs[i]) * freqs[i] for i in range(4)], 1))
         return out
 
-    def linf_flow(self, x, ai, y, lin_w, lin_b, layers, reverse, eps=1e-4):
+    def zeros_f64(self, n):
+        return torch.zeros(n, dtype=torch.float64)
+
+    def logscale_sum(self, h, acc, coef=1.0, eps=1e-4):
+        acc += coef * torch.log(torch.sigmoid(h[:, 1::2] + 2.0) + eps).double().sum(dim=(1, 2, 3))
+        return acc
+
+    def gaussian_logp(self, x, acc, h=None, coef=1.0):
+        l2pi = float(np.log(2 * np.pi))
+        if h is None:
+            acc += coef * (-0.5 * (x ** 2 + l2pi)).double().sum(dim=(1, 2, 3))
+        else:
+            mean, logs = h[:, 0::2], h[:, 1::2]
+            acc += coef * (-0.5 * (logs * 2.0 + (x - mean) ** 2 / torch.exp(logs * 2.0) + l2pi)).double().sum(dim=(1, 2, 3))
+        return acc
+
+    def linf_flow(self, x, ai, y, lin_w, lin_b, layers, reverse, eps=1e-4, log_p=None, logdet_const=0.0):
         B, D, qh, qw = x.shape
         v = x.permute(0, 2, 3, 1).reshape(-1, D)
         a = ai.permute(0, 2, 3, 1).reshape(-1, 2 * D * layers)
@@ -267,10 +284,14 @@ class CpuOps(object):
         sc = lambda i: torch.sigmoid(a[:, 2 * D * i: 2 * D * i + D] + 2.0) + eps
         sh = lambda i: a[:, 2 * D * i + D: 2 * D * (i + 1)]
         if not reverse:
+            ld = torch.full((v.shape[0],), float(logdet_const))
             for i in range(layers):
                 v = F.linear(v, Wm[i], bb[i])
                 v = v * sc(i) + sh(i)
+                ld = ld + torch.log(sc(i)).sum(-1)
             v = F.linear(v, Wm[layers], bb[layers])
+            if log_p is not None:
+                log_p.copy_((ld + (-0.5 * (v ** 2 + float(np.log(2 * np.pi)))).sum(-1)).reshape(log_p.shape))
         else:
             v = F.linear(v - bb[layers], Wm[layers])
             for i in reversed(range(layers)):

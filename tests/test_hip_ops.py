@@ -359,3 +359,24 @@ def test_conv_up2_bf16x3_with_key_channels(hip, case, tune):
     e32 = (o32.cpu().double() - truth).abs().max().item()
     assert ex3 <= 2.0 * e32 + 1e-7, (ex3, e32)
     close(out, o32.cpu(), 1e-5, "conv_up2_x3 %s" % (case,))
+
+
+def test_likelihood_reductions(hip):
+    """bfsr_logscale_sum / bfsr_gaussian_logp: per-sample float64 sums == torch float64 reference, coef and accumulation."""
+    h = rnd(190, 3, 24, 37, 53)
+    acc = hip.zeros_f64(3)
+    hip.logscale_sum(hip.to_device(h), acc, 1.0)
+    ref = torch.log(torch.sigmoid(h[:, 1::2].double() + 2.0) + 1e-4).sum(dim=(1, 2, 3))
+    assert ((acc.cpu() - ref).abs() / ref.abs()).max() < 1e-6
+    hip.logscale_sum(hip.to_device(h)[:, 4:12], acc, -2.0)             # channel-slice view, accumulate on top
+    ref2 = ref - 2.0 * torch.log(torch.sigmoid(h[:, 5:12:2].double() + 2.0) + 1e-4).sum(dim=(1, 2, 3))
+    assert ((acc.cpu() - ref2).abs() / ref2.abs()).max() < 1e-6
+    x, hh = rnd(191, 3, 6, 37, 53), rnd(192, 3, 12, 37, 53, scale=0.3)
+    l2pi = float(np.log(2 * np.pi))
+    a0 = hip.gaussian_logp(hip.to_device(x), hip.zeros_f64(3))
+    r0 = (-0.5 * (x.double() ** 2 + l2pi)).sum(dim=(1, 2, 3))
+    assert ((a0.cpu() - r0).abs() / r0.abs()).max() < 1e-6
+    a1 = hip.gaussian_logp(hip.to_device(x), hip.zeros_f64(3), h=hip.to_device(hh), coef=-1.0)
+    mean, logs = hh[:, 0::2].double(), hh[:, 1::2].double()
+    r1 = -(-0.5 * (logs * 2 + (x.double() - mean) ** 2 / torch.exp(logs * 2) + l2pi)).sum(dim=(1, 2, 3))
+    assert ((a1.cpu() - r1).abs() / r1.abs()).max() < 1e-6

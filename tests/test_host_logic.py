@@ -150,3 +150,29 @@ def test_conditioning_cache_is_keyed_on_tensor_identity():
     b = a.clone()                                          # different object with equal content: recomputed, equal
     h2 = c2[1]["h_ft"].clone()
     assert torch.equal(eng.conditioning(b)[1]["h_ft"], h2)
+
+
+@pytest.mark.parametrize("tag,scale", [("a", 4), ("c", 8)])
+def test_nll_and_logdet_vs_reference_golden(golden_dir, tag, scale):
+    """SRFlowNet.forward return values (epses, nll, logdet) / (sr, logdet) == the genuine reference's (srflow_logdet.npz),
+    through the engine's schedule on the CPU double of the ops."""
+    import torch.nn.functional as F
+    from bfsr_amd.srflow.models import create_model
+    ops = CpuOps()
+    opt = options.load(options.DEFAULT_CONF)
+    if scale == 8:
+        opt = options.derive_scale(opt, 8)
+    m = create_model(opt, ops=ops)
+    m.load_network(synth.state_dict_from_schema(spec.srflownet_schema(opt), 1234))
+    net = m.netG.module
+    g = np.load(os.path.join(golden_dir, "srflow_logdet.npz"))
+    lr = T(g["lr_" + tag])
+    lr_up = F.interpolate(lr, scale_factor=scale, mode="bilinear", align_corners=False)
+    epses, nll, logdet = net(gt=lr_up, lr=lr, reverse=False, epses=[], add_gt_noise=False)
+    assert nll.dtype == torch.float32 and logdet.shape == (lr.shape[0],)
+    rel = lambda a, b: float(((a - b).abs() / b.abs().clamp_min(1.0)).max())
+    assert rel(nll, T(g["nll_" + tag])) <= 1e-5
+    assert rel(logdet, T(g["logdet_" + tag])) <= 1e-5
+    sr, logdet_rev = net(lr=lr, reverse=True, epses=list(epses))
+    assert rel(logdet_rev, T(g["logdet_rev_" + tag])) <= 1e-5
+    assert rel(logdet_rev, -logdet) <= 1e-5                      # the inverse undoes every term

@@ -159,3 +159,24 @@ def test_pixelwise_linf_on_cpu_double(golden_dir, c):
     psd = synth.state_dict_from_schema(lspec.linf_prior_schema(3), 778)
     o = O.lp_pipeline(O.batch_prep(lr, (H, W), patch_size=1), sd, psd, PIX_SPEC, (H, W), patch_size=1, return_all=True)
     assert (o["pred"] - T(g["pred"])).abs().max() <= 2e-5
+
+
+def _logp_case(golden_dir, ops):
+    import oracle.linf_ref as OR
+    g = np.load(os.path.join(golden_dir, "linf_logp.npz"))
+    sd, _ = weights("edsr-baseline", 2025)
+    m = make(mspec("edsr-baseline"), args={"ops": ops}).eval()
+    m.load_state_dict(sd)
+    lr = T(g["lr"])
+    prep = OR.batch_prep(lr, (int(g["H"]), int(g["W"])))
+    inp = (prep["inp"] - 0.5) / 0.5
+    log_p, z = m("query_log_p", feat=m("gen_feat", inp=inp), coord=prep["coord"], cell=prep["cell"], gt=prep["gt_lr_up"])
+    return log_p, z, T(g["log_p"]), T(g["z"])
+
+
+def test_query_log_p_values_vs_reference_golden(golden_dir):
+    """LINFPatch.query_log_p returns the reference's (log_p per query point, z) pair (linf_logp.npz)."""
+    log_p, z, ref_lp, ref_z = _logp_case(golden_dir, CpuOps())
+    assert log_p.shape == ref_lp.shape
+    assert (z - ref_z).abs().max() <= 1e-4
+    assert ((log_p - ref_lp).abs() / ref_lp.abs().clamp_min(1.0)).max() <= 1e-5

@@ -191,3 +191,11 @@ def test_fp16_mfma_path_config5(hip):
     dz = (outs["fp16"]["z_lr"] - outs["fp32"]["z_lr"]).abs().max().item()
     print("fp16 MFMA path vs fp32: max-abs pred %.3e, z_lr %.3e" % (dev, dz))
     assert 0 < dev < 5e-2
+
+
+def test_query_log_p_values_golden(hip, golden_dir):
+    """log_p per query point from the flow kernel == the genuine reference's (tests/golden/linf_logp.npz)."""
+    from test_linf_cpu import _logp_case
+    log_p, z, ref_lp, ref_z = _logp_case(golden_dir, hip)
+    close(z, ref_z, 1e-4, "z")
+    assert ((log_p.cpu() - ref_lp).abs() / ref_lp.abs().clamp_min(1.0)).max() <= 1e-5

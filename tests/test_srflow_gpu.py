@@ -150,3 +150,34 @@ def test_full_div2k_sized_image_roundtrip(model4, hip):
     assert torch.isfinite(rt).all() and err <= 1e-4, "round trip %.3e" % err
     eng.ws.bufs.clear()
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_nll_and_logdet_golden(model4, golden_dir, tag):
+    """forward(reverse=False) -> (epses, nll, logdet), forward(reverse=True) -> (sr, logdet): the reference's values
+    (tests/golden/srflow_logdet.npz, generated from the genuine SRFlowNet), relative tolerance 1e-5."""
+    import torch.nn.functional as F
+    m, prior, opt, sd, psd = model4
+    net = m.netG.module
+    g = np.load(os.path.join(golden_dir, "srflow_logdet.npz"))
+    lr = torch.from_numpy(g["lr_" + tag])
+    lr_up = F.interpolate(lr, scale_factor=4, mode="bilinear", align_corners=False)
+    epses, nll, logdet = net(gt=lr_up, lr=lr, reverse=False, epses=[], add_gt_noise=False)
+    rel = lambda a, b: float(((a.cpu() - b).abs() / b.abs().clamp_min(1.0)).max())
+    assert rel(nll, torch.from_numpy(g["nll_" + tag])) <= 1e-5, (nll, g["nll_" + tag])
+    assert rel(logdet, torch.from_numpy(g["logdet_" + tag])) <= 1e-5, (logdet, g["logdet_" + tag])
+    sr, logdet_rev = net(lr=lr, reverse=True, epses=list(epses))
+    assert rel(logdet_rev, torch.from_numpy(g["logdet_rev_" + tag])) <= 1e-5
+
+
+def test_nll_vs_oracle_fresh_input(model4):
+    import oracle.srflow_ref as O
+    import torch.nn.functional as F
+    m, prior, opt, sd, psd = model4
+    lr = synth.smooth_lr_batch(77, 2, 24, 16)
+    lr_up = F.interpolate(lr, scale_factor=4, mode="bilinear", align_corners=False)
+    z, nll, logdet = m.netG.module(gt=lr_up, lr=lr, reverse=False, add_gt_noise=False)
+    oe, onll, old = O.srflow_normal_flow(lr_up, lr, sd, opt, 23)
+    _chk("z", z, oe[-1])
+    assert ((nll.cpu() - onll).abs() / onll.abs()).max() <= 1e-5
+    assert ((logdet.cpu() - old).abs() / old.abs()).max() <= 1e-5

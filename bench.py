@@ -44,6 +44,9 @@ def parse_args():
     ap.add_argument("--no-fp32-line", action="store_true", help="skip the secondary all-native-fp32-MFMA timing")
     ap.add_argument("--scale", type=int, default=4, choices=[4, 8], help="8 = the derived 8x config (BASELINE config 4)")
     ap.add_argument("--cpu-lr", type=int, default=160, help="LR side of the CPU-baseline sample (B=1)")
+    ap.add_argument("--mode", default="lp", choices=["lp", "tau"],
+                    help="lp = the learned-prior pipeline (headline); tau = sampling path: decode eps ~ 0.9*N(0,1) without "
+                         "encode/prior (SURVEY 8d secondary workload)")
     return ap.parse_args()
 
 
@@ -87,11 +90,24 @@ def main():
     key_tail = ("flow", 1, C1, B, H // 2, H // 2, True, True, True)
     gathered = None
 
+    tau_eps = None
+    if args.mode == "tau":                # eps resident before timing: 0.9*N(0,1) from the same PCG64 stream family
+        import numpy as np
+        tau_eps = []
+        for i in range(n_batches):
+            g = np.random.Generator(np.random.PCG64(5000 + 1000 * rank + i))
+            tau_eps.append([ops.to_device(torch.from_numpy((0.9 * g.standard_normal((B, 6, H // 2, H // 2))).astype(np.float32))),
+                            ops.to_device(torch.from_numpy((0.9 * g.standard_normal((B, 96, H // 8, H // 8))).astype(np.float32)))])
+
     def step(i):
         nonlocal gathered
         x = batches[i % n_batches]
         x.add_(0.0)                       # bump the version so the conditioning cache never hits across steps
-        sr = lp_infer(model, prior, x)
+        if tau_eps is not None:
+            sr = model.netG.module.engine().decode(x, epses=tau_eps[i % n_batches])
+            sr = ops.axpb_clamp(sr, ops.empty(*sr.shape), 1.0, 0.0, 0.0, 1.0)
+        else:
+            sr = lp_infer(model, prior, x)
         if world > 1:
             gathered = bdist.all_gather_batch(sr, total=B * world)
         return sr
@@ -182,7 +198,7 @@ def main():
 
     # the same workload with every contraction on the native fp32 MFMA (BFSR_CONV=f32 engines), reported beside `value`
     fp32_only = None
-    if rank == 0 and world == 1 and ops.conv_mode != "f32" and not args.no_fp32_line:
+    if rank == 0 and world == 1 and ops.conv_mode != "f32" and not args.no_fp32_line and args.mode == "lp":
         ops32 = HipOps(dev)
         ops32.conv_mode = "f32"
         m32 = create_model(opt, ops=ops32)
@@ -206,7 +222,26 @@ def main():
         torch.cuda.empty_cache()
 
     cpu_baseline, parity = None, None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "tau":
+        import numpy as np
+        import oracle.srflow_ref as O          # checker / baseline only
+        cl = args.cpu_lr
+        x = synth.lr_batch(99, 1, cl, cl)
+        g = np.random.Generator(np.random.PCG64(4999))
+        ep = [torch.from_numpy((0.9 * g.standard_normal((1, 6, cl * scale // 2, cl * scale // 2))).astype(np.float32)),
+              torch.from_numpy((0.9 * g.standard_normal((1, 96, cl * scale // 8, cl * scale // 8))).astype(np.float32))]
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        t1 = time.perf_counter()
+        ref = O.srflow_decode(x, ep, sd, opt, opt["network_G"]["nb"])
+        cdt = time.perf_counter() - t1
+        cpu_baseline = {"value": round((cl * scale) ** 2 / 1e6 / cdt, 5), "unit": "MPix/s", "cores": torch.get_num_threads(),
+                        "kind": "port", "sample": "1 image %dx%d->%dx%d, oracle srflow_decode (RRDB + reverse flow), %.1f s"
+                                                  % (cl, cl, cl * scale, cl * scale, cdt)}
+        out = model.netG.module.engine().decode(ops.to_device(x), epses=[ops.to_device(e) for e in ep])
+        torch.cuda.synchronize()
+        parity = {"max_abs_sr_raw": float((out.cpu() - ref).abs().max()), "ref_absmax_sr_raw": float(ref.abs().max()),
+                  "sample": "same %dx%d image and eps vs oracle" % (cl, cl)}
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle.srflow_ref as O          # checker / baseline only
         cl = args.cpu_lr
         x = synth.lr_batch(99, 1, cl, cl)
@@ -235,7 +270,8 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "HR MPix/s, SRFlow-LP %dx flow-inverse SR (%d->%d), LP pipeline" % (scale, h, H),
+            "metric": "HR MPix/s, SRFlow-LP %dx flow-inverse SR (%d->%d), %s" % (
+                scale, h, H, "LP pipeline" if args.mode == "lp" else "tau=0.9 sampling path (RRDB + decode, no encode/prior)"),
             "value": round(value, 4), "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

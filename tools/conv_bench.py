@@ -81,7 +81,9 @@ def main():
     quick = "--quick" in sys.argv
     only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
     tunes = [int(t) for a in sys.argv if a.startswith("--tunes=") for t in a.split("=", 1)[1].split(",")] or TUNES
-    for name, B, Cin, Cout, H, W, KS, mt in SHAPES:
+    extra = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--shape=")]       # --shape=name,B,Cin,Cout,H,W,KS,mt
+    shapes = [(e[0],) + tuple(int(v) for v in e[1:]) for e in extra] or SHAPES
+    for name, B, Cin, Cout, H, W, KS, mt in shapes:
         if only and not any(o in name for o in only):
             continue
         x = torch.randn(B, Cin, H, W, device="cuda")

@@ -100,6 +100,10 @@ SYMBOLS = {
     "bfsr_patch_fold": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _I, _I, _I, _VP]),
     "bfsr_patch_unfold": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _I, _I, _I, _VP]),
     "bfsr_grid_sample_add": (_I, [_VP, _LL, _VP, _VP, _LL, _VP, _LL, _I, _I, _I, _I, _I, _I, _VP]),
+    "bfsr_resample_taps": (_I, [_VP, _LL, _VP, _LL, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _VP]),
+    "bfsr_sqdiff_sum": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _I, _I, _F, _VP, _VP]),
+    "bfsr_ssim_sum": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, C.c_double, _VP, _VP, _VP]),
+    "bfsr_to_uint8": (_I, [_VP, _LL, _VP, _I, _LL, _VP]),
     "bfsr_conv2d_direct": (_I, [_VP, _LL, _VP, _VP, _VP, _LL, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _VP]),
 }
 

@@ -94,13 +94,16 @@ def calc_psnr(sr, hr, dataset=None, scale=1, rgb_range=1):
     return -10 * torch.log10(valid.pow(2).mean())
 
 
-def eval_psnr(loader, model, prior_model=None, eval_type=None, patch=True, temperature=0, randomness=False, n_samples=5):
+def eval_psnr(loader, model, prior_model=None, eval_type=None, patch=True, temperature=0, randomness=False, n_samples=5,
+              detail=False):
     """Average PSNR over an iterable of batch dicts (LINF-LP/test.py:50-236, `eval_bsize` branch).
     prior_model given: the LP path (encode -> prior -> decode).  prior_model None: the stochastic path, z ~ N(0, tau^2)
     sampled on the device (linf.py:398).  randomness=True reproduces the `--randomness` loop (test.py:151-162, 203-208):
     `n_samples` predictions per batch, mean PSNR and the diversity score (std over samples of the uint8 images)."""
+    from . import metrics
     ops = model.engine().ops
     tot, div, n = 0.0, 0.0, 0
+    tot_ssim, tot_lr = 0.0, 0.0
 
     def one(batch, H, W):
         if prior_model is not None:
@@ -130,7 +133,17 @@ def eval_psnr(loader, model, prior_model=None, eval_type=None, patch=True, tempe
         if randomness:
             q = torch.stack([torch.round(p * 255.0) for p in preds], 1)
             div += float(torch.std(q, dim=1).mean()) * bsz
+        if detail:      # test.py:172-200: SSIM on [0,255] images and LR-consistency PSNR through imresize(pred, 1/scale), on device
+            sc = int(eval_type.split('-')[1]) if eval_type else round(H / batch['inp'].shape[-2])
+            inp01 = ops.to_device(batch['inp'])
+            tot_ssim += sum(float(metrics.ssim(ops, p, gt).mean()) for p in preds) / len(preds) * bsz
+            tot_lr += sum(metrics.lr_consistency_psnr(ops, p, inp01, sc) for p in preds) / len(preds) * bsz
         n += bsz
+    res = {'psnr': tot / max(n, 1)}
+    if detail:
+        res.update({'ssim': tot_ssim / max(n, 1), 'LR recon': tot_lr / max(n, 1)})      # 'lpips' (pretrained AlexNet) is outside the path
     if randomness:
-        return {'psnr': tot / max(n, 1), 'diversity': div / max(n, 1)}
+        res['diversity'] = div / max(n, 1)
+    if randomness or detail:
+        return res
     return tot / max(n, 1)

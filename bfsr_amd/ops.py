@@ -440,6 +440,46 @@ class HipOps(object):
     def zeros_f64(self, n):
         return torch.zeros(n, dtype=torch.float64, device=self.device)
 
+    # ---- metrics / output formatting (metrics.hip) ----------------------------------------------------
+    def resample_taps(self, x, y, idx, w, dim):
+        """one separable-resampler pass along dim (0 rows / 1 cols) with tap tables idx int32 [O,P], w fp32 [O,P]."""
+        xp, xbs, Cc, H, W = _view(x, "resample_taps.x")
+        yp, ybs, _, OH, OW = _view(y, "resample_taps.y")
+        O, P = idx.shape
+        assert idx.dtype == torch.int32 and w.dtype == torch.float32 and w.shape == idx.shape and idx.is_contiguous() and w.is_contiguous()
+        assert (OH, OW) == ((O, W) if dim == 0 else (H, O))
+        _lib.check(self._launch(("resample_taps", dim) + tuple(x.shape) + (O, P), lambda: self.lib.bfsr_resample_taps(
+            xp, xbs, yp, ybs, idx.data_ptr(), w.data_ptr(), x.shape[0], Cc, H, W, O, P, dim, self._stream())), "resample_taps")
+        return y
+
+    def sqdiff_sum(self, a, b, shave=0, luma=False, rgb_range=1.0):
+        """float64 [B]: sum of ((a-b)/rgb_range)^2 over the window shaved by `shave` (luma: 3 channels -> Y first)."""
+        ap, abs_, Cc, H, W = _view(a, "sqdiff_sum.a")
+        bp, bbs, c2, h2, w2 = _view(b, "sqdiff_sum.b")
+        assert (Cc, H, W) == (c2, h2, w2) and a.shape[0] == b.shape[0]
+        out = self.zeros_f64(a.shape[0])
+        _lib.check(self._launch(("sqdiff_sum",) + tuple(a.shape), lambda: self.lib.bfsr_sqdiff_sum(
+            ap, abs_, bp, bbs, a.shape[0], Cc, H, W, int(shave), int(bool(luma)), float(rgb_range), out.data_ptr(), self._stream())), "sqdiff_sum")
+        return out
+
+    def ssim_sum(self, a, b, window121, scale=255.0):
+        """float64 [B,C]: sum of the SSIM map over the valid region (11x11 window given as float64 [121] on the device)."""
+        ap, abs_, Cc, H, W = _view(a, "ssim_sum.a")
+        bp, bbs, c2, h2, w2 = _view(b, "ssim_sum.b")
+        assert (Cc, H, W) == (c2, h2, w2) and window121.dtype == torch.float64 and window121.numel() == 121
+        out = self.zeros_f64(a.shape[0] * Cc)
+        _lib.check(self._launch(("ssim_sum",) + tuple(a.shape), lambda: self.lib.bfsr_ssim_sum(
+            ap, abs_, bp, bbs, a.shape[0], Cc, H, W, float(scale), window121.data_ptr(), out.data_ptr(), self._stream())), "ssim_sum")
+        return out.view(a.shape[0], Cc)
+
+    def to_uint8(self, x):
+        """uint8 [B,C,H,W] = round(clamp(x,0,1)*255), half-to-even."""
+        xp, xbs, Cc, H, W = _view(x, "to_uint8.x")
+        y = torch.empty(x.shape, dtype=torch.uint8, device=self.device)
+        _lib.check(self._launch(("to_uint8",) + tuple(x.shape), lambda: self.lib.bfsr_to_uint8(
+            xp, xbs, y.data_ptr(), x.shape[0], Cc * H * W, self._stream())), "to_uint8")
+        return y
+
     def linf_flow(self, x, ai, y, lin_w, lin_b, layers, reverse, eps=1e-4, log_p=None, logdet_const=0.0):
         a = _lib.BfsrLinfFlowArgs()
         if log_p is not None:

@@ -234,6 +234,22 @@ int bfsr_conv2d_direct(const float* x, long long x_bs, const float* w, const flo
                        int B, int Cin, int Cout, int H, int W, int KS, int stride, int pad, int act, float slope,
                        void* stream);
 
+/* ---- evaluation metrics / output formatting on the device (LINF-LP/test.py:172-225) -------------
+ * bfsr_resample_taps: one pass of a separable resampler, y = sum_p w[o][p] * x[..idx[o][p]..] along dim (0 = rows, 1 = cols);
+ *   idx/w [O][P] are the host-built tables of MATLAB-style `imresize` (imresize.py:64-88 `contributions`, :110-121).
+ * bfsr_sqdiff_sum: out[b] += sum over the window shaved by `shave` of ((a-b)/rgb_range)^2; luma != 0 first reduces the
+ *   3 channels with [65.738,129.057,25.064]/256 (calc_psnr 'benchmark', utils.py:132-149).  Zero `out` before the call.
+ * bfsr_ssim_sum: out[b*C+c] += sum of the SSIM map over the 'valid' (H-10)x(W-10) region, 11x11 window `window121`
+ *   (outer product of the Gaussian sigma 1.5), images multiplied by `scale` first (255 for [0,1] data), fp64 (utils.py:152-171).
+ * bfsr_to_uint8: y[b][i] = uint8(rint(clamp(x,0,1)*255)) for i < n (test.py:210-212). */
+int bfsr_resample_taps(const float* x, long long x_bs, float* y, long long y_bs, const int* idx, const float* w,
+                       int B, int C, int H, int W, int O, int P, int dim, void* stream);
+int bfsr_sqdiff_sum(const float* a, long long a_bs, const float* b, long long b_bs, int B, int C, int H, int W, int shave,
+                    int luma, float rgb_range, double* out, void* stream);
+int bfsr_ssim_sum(const float* a, long long a_bs, const float* b, long long b_bs, int B, int C, int H, int W, double scale,
+                  const double* window121, double* out, void* stream);
+int bfsr_to_uint8(const float* x, long long x_bs, unsigned char* y, int B, long long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -263,6 +263,33 @@ class CpuOps(object):
     def zeros_f64(self, n):
         return torch.zeros(n, dtype=torch.float64)
 
+    def resample_taps(self, x, y, idx, w, dim):
+        g = x[:, :, idx.long(), :] if dim == 0 else x[:, :, :, idx.long()]          # [B,C,O,P,W] / [B,C,H,O,P]
+        y.copy_((g * w.view(1, 1, *w.shape, 1)).sum(3) if dim == 0 else (g * w.view(1, 1, 1, *w.shape)).sum(4))
+        return y
+
+    def sqdiff_sum(self, a, b, shave=0, luma=False, rgb_range=1.0):
+        d = (a - b) / rgb_range
+        if luma:
+            d = (d * torch.tensor([65.738, 129.057, 25.064]).view(1, 3, 1, 1) / 256).sum(1, keepdim=True)
+        if shave:
+            d = d[..., shave:-shave, shave:-shave]
+        return d.double().pow(2).sum(dim=(1, 2, 3))
+
+    def ssim_sum(self, a, b, window121, scale=255.0):
+        k = window121.view(1, 1, 11, 11)
+        B, Cc, H, W = a.shape
+        p, q = (a.double() * scale).reshape(B * Cc, 1, H, W), (b.double() * scale).reshape(B * Cc, 1, H, W)
+        f = lambda t: F.conv2d(t, k)
+        m1, m2 = f(p), f(q)
+        v1, v2, cv = f(p * p) - m1 * m1, f(q * q) - m2 * m2, f(p * q) - m1 * m2
+        C1, C2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+        smap = ((2 * m1 * m2 + C1) * (2 * cv + C2)) / ((m1 * m1 + m2 * m2 + C1) * (v1 + v2 + C2))
+        return smap.sum(dim=(1, 2, 3)).view(B, Cc)
+
+    def to_uint8(self, x):
+        return torch.round(torch.clamp(x, 0, 1) * 255.0).to(torch.uint8)
+
     def logscale_sum(self, h, acc, coef=1.0, eps=1e-4):
         acc += coef * torch.log(torch.sigmoid(h[:, 1::2] + 2.0) + eps).double().sum(dim=(1, 2, 3))
         return acc

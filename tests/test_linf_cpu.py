@@ -110,6 +110,15 @@ def test_cfg1_eval_psnr_scalar(golden_dir):
     psnr = eval_psnr([batch], m, prior, eval_type="div2k-4")
     assert abs(psnr - float(g["psnr"])) <= 1e-3
     assert (lp_infer(m, prior, batch, (192, 192)) - T(g["pred"])).abs().max() <= 1e-4
+    # detail=True (test.py:172-200): SSIM and LR-consistency PSNR of the same prediction, computed by the metric ops; checked
+    # against the oracle's restatements on the golden prediction
+    import oracle.metrics_ref as MO
+    d = eval_psnr([batch], m, prior, eval_type="div2k-4", detail=True)
+    assert abs(d["psnr"] - float(g["psnr"])) <= 1e-3
+    pred = g["pred"][0].transpose(1, 2, 0).astype(np.float64)
+    assert abs(d["ssim"] - MO.calculate_ssim(pred * 255.0, hr[0].permute(1, 2, 0).numpy().astype(np.float64) * 255.0)) <= 1e-4
+    lr_rec = MO.imresize(g["pred"][0].transpose(1, 2, 0), 0.25).transpose(2, 0, 1)[None]
+    assert abs(d["LR recon"] - MO.calc_psnr(lr_rec.astype(np.float32), lr.numpy())) <= 1e-2
 
 
 def test_ops_golden(golden_dir):

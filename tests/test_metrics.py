@@ -1,0 +1,70 @@
+"""Evaluation metrics after the hot path: oracle vs the genuine reference's goldens (imresize,
+calc_psnr), the product's device metrics (on the CPU double here, on the HIP kernels under -m gpu) vs the same goldens, and
+known-answer properties for SSIM (the reference's cv2-based SSIM cannot run in this image: unpinned)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle.metrics_ref as O
+from bfsr_amd.linf import metrics
+from cpu_ops import CpuOps
+
+T = torch.from_numpy
+
+
+def _g(golden_dir):
+    return np.load(os.path.join(golden_dir, "metrics.npz"))
+
+
+def test_oracle_vs_reference_golden(golden_dir):
+    g = _g(golden_dir)
+    for tag in "abc":
+        assert np.abs(O.imresize(g["img_" + tag], 1.0 / int(g["scale_" + tag])) - g["lr_" + tag]).max() <= 1e-12
+    sr, hr = g["psnr_sr"], g["psnr_hr"]
+    assert abs(O.calc_psnr(sr, hr) - float(g["psnr_plain"])) <= 1e-5
+    assert abs(O.calc_psnr(sr, hr, dataset="div2k", scale=4) - float(g["psnr_div2k4"])) <= 1e-5
+    assert abs(O.calc_psnr(sr, hr, dataset="benchmark", scale=3) - float(g["psnr_bench3"])) <= 1e-5
+
+
+def _check_product(ops, g):
+    dev = ops.to_device
+    for tag in "abc":
+        img = T(g["img_" + tag]).permute(2, 0, 1).unsqueeze(0).contiguous()
+        out = metrics.imresize(ops, dev(img), 1.0 / int(g["scale_" + tag]))
+        ref = T(g["lr_" + tag]).permute(2, 0, 1).unsqueeze(0).float()
+        assert tuple(out.shape) == tuple(ref.shape)
+        assert (out.cpu() - ref).abs().max() <= 2e-6, tag
+    sr, hr = dev(T(g["psnr_sr"])), dev(T(g["psnr_hr"]))
+    assert abs(metrics.psnr(ops, sr, hr) - float(g["psnr_plain"])) <= 1e-4
+    assert abs(metrics.psnr(ops, sr, hr, dataset="div2k", scale=4) - float(g["psnr_div2k4"])) <= 1e-4
+    assert abs(metrics.psnr(ops, sr, hr, dataset="benchmark", scale=3) - float(g["psnr_bench3"])) <= 1e-4
+    # SSIM: identical images -> 1; vs the oracle's restatement on a noisy pair; symmetric
+    a, b = T(g["psnr_sr"]), T(g["psnr_hr"])
+    s_same = metrics.ssim(ops, dev(a), dev(a)).cpu()
+    assert (s_same - 1.0).abs().max() <= 1e-9
+    s_ab = metrics.ssim(ops, dev(a), dev(b)).cpu()
+    s_ba = metrics.ssim(ops, dev(b), dev(a)).cpu()
+    assert (s_ab - s_ba).abs().max() <= 1e-9
+    for i in range(a.shape[0]):
+        ref = O.calculate_ssim(a[i].permute(1, 2, 0).numpy() * 255.0, b[i].permute(1, 2, 0).numpy() * 255.0)
+        assert abs(float(s_ab[i]) - ref) <= 1e-6
+    # uint8 formatting: round half to even like numpy
+    x = torch.tensor([0.0, 0.5 / 255, 1.5 / 255, 2.5 / 255, 0.999, 1.2, -0.3, 100.4 / 255]).view(1, 1, 2, 4)
+    q = ops.to_uint8(dev(x)).cpu()
+    assert q.flatten().tolist() == np.round(np.clip(x.numpy().astype(np.float32), 0, 1) * np.float32(255.0)).astype(np.uint8).flatten().tolist()
+    # LR consistency of an exact bicubic-downscale pair is (numerically) perfect
+    img = dev(T(g["img_a"]).permute(2, 0, 1).unsqueeze(0).contiguous())
+    lr = metrics.imresize(ops, img, 0.5)
+    assert metrics.lr_consistency_psnr(ops, img, lr, 2) > 120
+
+
+def test_product_metrics_on_cpu_double(golden_dir):
+    _check_product(CpuOps(), _g(golden_dir))
+
+
+@pytest.mark.gpu
+def test_product_metrics_on_hip(golden_dir):
+    from bfsr_amd.ops import HipOps
+    _check_product(HipOps("cuda:0"), _g(golden_dir))

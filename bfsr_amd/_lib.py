@@ -80,6 +80,7 @@ SYMBOLS = {
     "bfsr_conv_packed_size_bf16x3": (_LL, [_I, _I, _I, _I]),
     "bfsr_pack_conv_weight_bf16x3": (_I, [_VP, _I, _I, _I, _I, _VP]),
     "bfsr_conv2d_up2_bf16x3": (_I, [C.POINTER(BfsrConvArgs), _VP]),
+    "bfsr_conv2d_up4_bf16x3": (_I, [C.POINTER(BfsrConvArgs), _VP]),
     "bfsr_conv_packed_size_taps_bf16x3": (_LL, [_I, _I, _I, _I]),
     "bfsr_pack_conv_weight_taps_bf16x3": (_I, [_VP, _I, _I, _I, _I, _VP]),
     "bfsr_conv2d_up2": (_I, [C.POINTER(BfsrConvArgs), _VP]),

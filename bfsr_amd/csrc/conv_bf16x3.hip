@@ -439,6 +439,205 @@ int launch_up2_x3(const BfsrConvArgs& a, hipStream_t st)
     return (int)hipGetLastError();
 }
 
+// ---- conv over nearest_up4(x): x [B,Cin,H/4,W/4] -> y [B,Cout,H,W] (the level-1 conditional of the 8x model: LR-resolution
+// RRDB taps under a 4x finer flow level).  Along each axis the 3x3 window of output phase p = 0..3 touches the source offsets
+//   p=0: {-1 <- w[-1], 0 <- w[0]+w[+1]}     p=1,2: {0 <- w[-1]+w[0]+w[+1]}     p=3: {0 <- w[-1]+w[0], +1 <- w[+1]}
+// i.e. 5 pre-summed "entries" per axis in 3 classes (phases 1 and 2 see the same window): 25 matrices produce the 9 distinct
+// outputs of a source pixel (25 vs 144 tap products of the materialised conv), which the epilogue replicates to the 16 pixels.
+// entry e = 0..4 -> (class, staged offset): (0,0) (0,1) (1,1) (2,1) (2,2) with staged offset 0,1,2 = source offset -1,0,+1.
+// A workgroup handles one ROW class rc (10, 5 or 10 matrices in LDS; staged rows start at y0-1 for rc=0, y0 otherwise, so row
+// entry ie of the class reads staged row n+ie) and keeps acc[column class][row]; lane = source column -> float4 of 4 output px.
+template <int NW, int NR, int RC>
+__global__ __launch_bounds__(NW * 64, 4) void conv_up4_bf16x3_kernel(BfsrConvArgs p, int tiles_x, int tiles_xy, int groups)
+{
+    constexpr int NT = NW * 64, SR = NW * NR, PW = 34, NPOS = (SR + 1) * PW, PPT = (NPOS + NT - 1) / NT;
+    constexpr int MW = 32, MAXM = 10, MEL = 2 * MW * 8;                   // MEL = bf16 elements of one matrix chunk
+    constexpr int WPL = MAXM * MEL, WSLAB = 3 * WPL, WV = (WSLAB / 8 + NT - 1) / NT, IPL = NPOS * CK;
+    constexpr int GPL = 25 * MEL;                                         // one plane of all 25 matrices in global memory
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* sW = reinterpret_cast<__bf16*>(smem_raw);                     // [3][<=10][k half][32][8]
+    __bf16* sIn = sW + WSLAB;                                             // [3][k half][NPOS][8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int bid = blockIdx.x;
+    constexpr int rc = RC;                                                // row class of this launch
+    const int cg = bid % groups; bid /= groups;
+    const int tile = bid % tiles_xy; const int b = bid / tiles_xy;
+    const int x0 = (tile % tiles_x) * 32, y0 = (tile / tiles_x) * SR;     // source coordinates
+    const int H = p.H, W = p.W, Hs = H >> 2, Ws = W >> 2;
+    constexpr int nrt = rc == 1 ? 1 : 2, e0 = rc == 0 ? 0 : (rc == 1 ? 2 : 3), nm = nrt * 5;
+    const long long cs_in = (long long)Hs * Ws;
+    const float* __restrict__ xin = p.x + (long long)b * p.x_bs;
+    const int Cin = p.Cin, nchunk = (Cin + CK - 1) / CK;
+    const __bf16* __restrict__ wg = reinterpret_cast<const __bf16*>(p.w) + (long long)cg * nchunk * 3 * GPL;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0,
+                                                                           (unsigned)((long long)Cin * cs_in * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wg), 0,
+                                                                          (unsigned)((long long)nchunk * 3 * GPL * 2), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned voff[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int pos = tid + i * NT;
+        const int r = pos / PW, c = pos - r * PW;
+        const int gy = y0 + r - (rc == 0 ? 1 : 0), gx = x0 + c - 1;
+        const bool ok = pos < NPOS && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
+        voff[i] = ok ? (unsigned)(gy * Ws + gx) * 4u : OOB;
+    }
+    unsigned woff[WV];
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+        const int idx = tid + i * NT;                                     // 16-byte unit inside [3][MAXM][MEL]
+        const int pl = idx / (WPL / 8), rem = idx - pl * (WPL / 8);
+        woff[i] = (idx < WSLAB / 8 && rem < nm * (MEL / 8)) ? (unsigned)((pl * GPL + e0 * 5 * MEL) * 2 + rem * 16) : OOB;
+    }
+    const unsigned cs_bytes = (unsigned)(cs_in * 4);
+    f32x16 acc[3][NR];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int n = 0; n < NR; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][n][r] = 0.f;
+
+    float vin[PPT][CK];
+    uint4 vw[WV];
+    auto load_chunk = [&](int k) {
+        const unsigned sbase = (unsigned)(k * CK) * cs_bytes;
+#pragma unroll
+        for (int c = 0; c < CK; ++c)
+#pragma unroll
+            for (int i = 0; i < PPT; ++i)
+                vin[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff[i], sbase + (unsigned)c * cs_bytes, 0));
+        const unsigned wbase = (unsigned)k * (3 * GPL * 2);
+#pragma unroll
+        for (int i = 0; i < WV; ++i)
+            vw[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff[i], wbase, 0));
+    };
+    // one chunk of MFMAs for a row class with NRT row entries; column entries in staged-offset order d = 0 | 1,1,1 | 2
+    auto mfma_chunk = [&](auto nrt_tag) {
+        constexpr int NRT = decltype(nrt_tag)::value;
+        constexpr int STEPS = 5 * NRT;
+        const __bf16* inB = sIn + (lhi * NPOS + (wave * NR) * PW + l31) * 8;
+        const __bf16* wA = sW + (lhi * MW + l31) * 8;
+        bf16x8 bfr[3][NR + 1], afr[2][3];
+        auto load_b = [&](int d) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int e = 0; e < NR + NRT - 1; ++e)
+                    bfr[pl][e] = *reinterpret_cast<const bf16x8*>(inB + pl * IPL + (e * PW + d) * 8);
+        };
+        auto load_a = [&](int buf, int s_) {                              // step s_ -> (column entry ce, row entry ie)
+            const int ce = s_ / NRT, ie = s_ % NRT;
+            const int t = ie * 5 + ce;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) afr[buf][pl] = *reinterpret_cast<const bf16x8*>(wA + pl * WPL + t * MEL);
+        };
+        load_a(0, 0);
+#pragma unroll
+        for (int s_ = 0; s_ < STEPS; ++s_) {
+            const int ce = s_ / NRT, ie = s_ % NRT;
+            const int d = ce == 0 ? 0 : (ce == 4 ? 2 : 1), cc = ce == 0 ? 0 : (ce <= 1 ? 0 : (ce == 2 ? 1 : 2));
+            const int ab = s_ & 1;
+            if (ie == 0 && (ce == 0 || ce == 1 || ce == 4)) load_b(d);
+            if (s_ + 1 < STEPS) load_a(ab ^ 1, s_ + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#define BFSR_TERM(PA_, PB_)                                                                                            \
+    _Pragma("unroll") for (int n = 0; n < NR; ++n)                                                                      \
+        acc[cc][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ab][PA_], bfr[PB_][n + ie], acc[cc][n], 0, 0, 0);
+            BFSR_TERM(2, 0) BFSR_TERM(0, 2) BFSR_TERM(1, 1) BFSR_TERM(1, 0) BFSR_TERM(0, 1) BFSR_TERM(0, 0)
+#undef BFSR_TERM
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    load_chunk(0);
+    for (int k = 0; k < nchunk; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int pos = tid + i * NT;
+            if (i < PPT - 1 || pos < NPOS) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    bf16x8 h8, m8, l8;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        __bf16 h, m, l;
+                        split3(vin[i][hf * 8 + c], h, m, l);
+                        h8[c] = h; m8[c] = m; l8[c] = l;
+                    }
+                    *reinterpret_cast<bf16x8*>(sIn + (hf * NPOS + pos) * 8) = h8;
+                    *reinterpret_cast<bf16x8*>(sIn + IPL + (hf * NPOS + pos) * 8) = m8;
+                    *reinterpret_cast<bf16x8*>(sIn + 2 * IPL + (hf * NPOS + pos) * 8) = l8;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int idx = tid + i * NT;
+            if (i < WV - 1 || idx < WSLAB / 8) reinterpret_cast<uint4*>(sW)[idx] = vw[i];
+        }
+        __syncthreads();
+        if (k + 1 < nchunk) load_chunk(k + 1);
+        mfma_chunk(std::integral_constant<int, nrt>{});
+    }
+
+    // ---- epilogue: lane = source column -> float4 of output columns 4sx..4sx+3 = classes (0, 1, 1, 2); rows of this class
+    const int sx = x0 + l31;
+    if (sx >= Ws) return;
+    const long long HW = (long long)H * W;
+    const float slope = p.act == BFSR_ACT_NONE ? 1.f : (p.act == BFSR_ACT_RELU ? 0.f : p.slope);
+    const float4* __restrict__ epi = reinterpret_cast<const float4*>(p.epi);
+    const float* pre = p.pre_add ? p.pre_add + (long long)b * p.pre_add_bs : nullptr;
+    float* yb = p.y + (long long)b * p.y_bs;
+    constexpr int row0 = rc == 0 ? 0 : (rc == 1 ? 1 : 3), nrow = rc == 1 ? 2 : 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (co >= p.Cout) continue;
+        float4 q0 = make_float4(0.f, 0.f, 1.f, 0.f); float q1 = 1.f;
+        if (epi) { q0 = epi[co * 2]; q1 = epi[co * 2 + 1].x; }
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+            const int sy = y0 + wave * NR + n;
+            if (sy >= Hs) continue;
+            for (int rr = 0; rr < nrow; ++rr) {
+                const long long o = (long long)co * HW + (long long)(4 * sy + row0 + rr) * W + 4 * sx;
+                float v[4] = {acc[0][n][r], acc[1][n][r], acc[1][n][r], acc[2][n][r]};
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pre) t = *reinterpret_cast<const float4*>(pre + o);
+                const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float u = v[j] + q0.x + tv[j];
+                    u = (u + q0.y) * q0.z + q0.w;
+                    u = u > 0.f ? u : u * slope;
+                    v[j] = u * q1;
+                }
+                *reinterpret_cast<float4*>(yb + o) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+template <int NW, int NR>
+int launch_up4_x3(const BfsrConvArgs& a, hipStream_t st)
+{
+    constexpr int SR = NW * NR;
+    constexpr int LDS = 3 * (10 * 2 * 32 * 8 + (SR + 1) * 34 * CK) * 2;
+    const int Hs = a.H / 4, Ws = a.W / 4;
+    const int tiles_x = (Ws + 31) / 32, tiles_y = (Hs + SR - 1) / SR;
+    const int groups = (a.Cout + 31) / 32;
+    const long long nblk = (long long)tiles_x * tiles_y * groups * a.B;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return -1;
+    // one launch per row class (phase 0 | phases 1,2 | phase 3): they write disjoint output rows
+    hipLaunchKernelGGL((conv_up4_bf16x3_kernel<NW, NR, 0>), dim3((unsigned)nblk), dim3(NW * 64), LDS, st, a, tiles_x, tiles_x * tiles_y, groups);
+    hipLaunchKernelGGL((conv_up4_bf16x3_kernel<NW, NR, 1>), dim3((unsigned)nblk), dim3(NW * 64), LDS, st, a, tiles_x, tiles_x * tiles_y, groups);
+    hipLaunchKernelGGL((conv_up4_bf16x3_kernel<NW, NR, 2>), dim3((unsigned)nblk), dim3(NW * 64), LDS, st, a, tiles_x, tiles_x * tiles_y, groups);
+    return (int)hipGetLastError();
+}
+
 inline void split3_host(float v, unsigned short out[3])
 {
     float r = v;
@@ -509,6 +708,17 @@ extern "C" int bfsr_conv2d_up2_bf16x3(const BfsrConvArgs* a, void* stream)
         case 801: return launch_up2_x3<8, 1>(*a, st);
         default: return -1;
     }
+}
+
+extern "C" int bfsr_conv2d_up4_bf16x3(const BfsrConvArgs* a, void* stream)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!a || !a->x || !a->w || !a->y || a->w2 || a->x2 || a->res1 || a->res2 || a->mtile != 1) return -1;
+    if (a->B <= 0 || a->H <= 0 || a->W <= 0 || (a->H & 3) || (a->W & 3) || a->Cin <= 0 || a->Cout <= 0) return -1;
+    if ((long long)a->Cin * (a->H / 4) * (a->W / 4) * 4 >= (1LL << 31)) return -1;
+    if ((reinterpret_cast<unsigned long long>(a->y) & 15) || (a->y_bs & 3)) return -1;           // float4 rows
+    if (a->pre_add && ((reinterpret_cast<unsigned long long>(a->pre_add) & 15) || (a->pre_add_bs & 3))) return -1;
+    return launch_up4_x3<8, 1>(*a, st);
 }
 
 extern "C" int bfsr_conv2d_bf16x3(const BfsrConvArgs* a, void* stream)

@@ -234,12 +234,39 @@ class HipOps(object):
         _lib.check(self.lib.bfsr_pack_conv_weight_taps_bf16x3(w16.data_ptr(), Cout, Cin, 16, 1, packed.data_ptr()), "pack_taps_x3")
         return PackedConv(packed.to(self.device), Cout, Cin, 3, 1, fixed=True)
 
-    def conv_up2_x3(self, x, pw, out, epi=None, pre_add=None, act=ACT_NONE, slope=0.2, tune=0):
+    @staticmethod
+    def presum_up4_weights(w):
+        """[Cout,Cin,3,3] -> [Cout,Cin,25]: per axis 5 entries (phase class, source offset) <- kernel taps:
+        (0,-1)<-{-1}  (0,0)<-{0,+1}  (12,0)<-{-1,0,+1}  (3,0)<-{-1,0}  (3,+1)<-{+1}; index = row_entry*5 + col_entry."""
+        S = [(0,), (1, 2), (0, 1, 2), (0, 1), (2,)]
+        w = w.detach().to("cpu", torch.float32)
+        out = torch.zeros(w.shape[0], w.shape[1], 25, dtype=torch.float32)
+        for er in range(5):
+            for ec in range(5):
+                acc = None
+                for dy in S[er]:
+                    for dx in S[ec]:
+                        acc = w[:, :, dy, dx].clone() if acc is None else acc + w[:, :, dy, dx]
+                out[:, :, er * 5 + ec] = acc
+        return out.contiguous()
+
+    def pack_conv_up4_x3(self, w):
+        w25 = self.presum_up4_weights(w)
+        Cout, Cin, _ = w25.shape
+        packed = torch.empty(self.lib.bfsr_conv_packed_size_taps_bf16x3(Cout, Cin, 25, 1), dtype=torch.int16)
+        _lib.check(self.lib.bfsr_pack_conv_weight_taps_bf16x3(w25.data_ptr(), Cout, Cin, 25, 1, packed.data_ptr()), "pack_taps_x3")
+        return PackedConv(packed.to(self.device), Cout, Cin, 3, 1, fixed=True)
+
+    def conv_up4_x3(self, x, pw, out, epi=None, pre_add=None, act=ACT_NONE, slope=0.2):
+        """out [B,Cout,4h,4w] = epilogue(conv3x3(nearest_up4(x)) + pre_add) on the 3xBF16 split (25 pre-summed matrices)."""
+        return self.conv_up2_x3(x, pw, out, epi=epi, pre_add=pre_add, act=act, slope=slope, _factor=4)
+
+    def conv_up2_x3(self, x, pw, out, epi=None, pre_add=None, act=ACT_NONE, slope=0.2, tune=0, _factor=2):
         """conv_up2 on the 3xBF16 split (fp32-accurate); channels at output resolution enter through pre_add (may be `out`)."""
         xp, xbs, Cin, h, w = _view(x, "conv_up2_x3.x")
         yp, ybs, Cout, H, W = _view(out, "conv_up2_x3.out")
-        if (Cin, Cout, 2 * h, 2 * w) != (pw.Cin, pw.Cout, H, W) or x.shape[0] != out.shape[0]:
-            raise ValueError("conv_up2_x3: shape mismatch x%s out%s" % (tuple(x.shape), tuple(out.shape)))
+        if (Cin, Cout, _factor * h, _factor * w) != (pw.Cin, pw.Cout, H, W) or x.shape[0] != out.shape[0]:
+            raise ValueError("conv_up%d_x3: shape mismatch x%s out%s" % (_factor, tuple(x.shape), tuple(out.shape)))
         a = _lib.BfsrConvArgs()
         a.x, a.x_bs, a.Cin = xp, xbs, Cin
         a.w = pw.data.data_ptr()
@@ -250,6 +277,10 @@ class HipOps(object):
             pp, bs, c, hh, ww = _view(pre_add, "conv_up2_x3.pre_add")
             assert (c, hh, ww) == (Cout, H, W)
             a.pre_add, a.pre_add_bs = pp, bs
+        if _factor == 4:
+            key = ("conv_up4_x3", 1, Cin, Cout, out.shape[0], H, W, 0)
+            _lib.check(self._launch(key, lambda: self.lib.bfsr_conv2d_up4_bf16x3(C.byref(a), self._stream())), "conv2d_up4_bf16x3")
+            return out
         key = ("conv_up2_x3", 1, Cin, Cout, out.shape[0], H, W, 0)
         _lib.check(self._launch(key, lambda: self.lib.bfsr_conv2d_up2_bf16x3(C.byref(a), self._stream())), "conv2d_up2_bf16x3")
         return out

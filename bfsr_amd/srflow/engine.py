@@ -208,9 +208,12 @@ class SRFlowEngine(object):
                 # the 256 stacked-RRDB channels of this level are the LR-resolution taps upsampled x2: their share of the
                 # 3x3 conv runs on the LR grid with parity pre-summed weights (4/9 of the MACs, nothing materialised);
                 # the 64 native-resolution key channels are convolved into the same accumulators by the same kernel.
-                hz.update(up2=True, x3=getattr(ops, "conv_mode", "f32") == "x3",
+                hz.update(up2=True, up=self._taps_up2(level), x3=getattr(ops, "conv_mode", "f32") == "x3",
                           ft0_epi=ops.pack_epilogue(wf.shape[0], aff_shift=sh, aff_scale=sc))
-                if hz["x3"]:
+                if hz["up"] == 2:       # x4: 25 pre-summed matrices (25 instead of 144 tap products per source pixel)
+                    hz.update(ft0_taps=ops.pack_conv_up4_x3(wf[:, 64:].contiguous()), aff0_taps=ops.pack_conv_up4_x3(wa[:, 64:].contiguous()),
+                              ft0_key=ops.pack_conv_x3(wf[:, :64].contiguous(), 2), aff0_key=ops.pack_conv_x3(wa[:, :64].contiguous(), 2))
+                elif hz["x3"]:
                     # 3xBF16 kernels: key channels by the plain conv (no epilogue) into the output buffer, then the taps
                     # kernel adds them back through pre_add and applies the epilogue
                     hz.update(ft0_taps=ops.pack_conv_up2_x3(wf[:, 64:].contiguous()), aff0_taps=ops.pack_conv_up2_x3(wa[:, 64:].contiguous()),
@@ -235,7 +238,14 @@ class SRFlowEngine(object):
         return None
 
     def _taps_up2(self, level):
-        return bool(self.concat and self.block_idxs and self._level_shift(level) == 1 and self._lr_level() is not None)
+        """shift (1 = x2, 2 = x4) if this level's stacked RRDB taps are the LR-resolution taps nearest-upsampled by 2^shift and
+        can be consumed in place through a parity-decomposed conv kernel, else 0.  x4 exists on the 3xBF16 path only."""
+        sh = self._level_shift(level)
+        if not (self.concat and self.block_idxs and self._lr_level() is not None):
+            return 0
+        if sh == 1 or (sh == 2 and getattr(self.ops, "conv_mode", "f32") == "x3"):
+            return sh
+        return 0
 
     # ------------------------------------------------------------------------------------------
     def _level_hw(self, level, h, w):
@@ -300,10 +310,11 @@ class SRFlowEngine(object):
             if hz["up2"]:
                 taps = ft[self._lr_level()][:, 64:]
                 if hz["x3"]:
+                    up = ops.conv_up4_x3 if hz["up"] == 2 else ops.conv_up2_x3
                     ops.conv_x3(f, hz["ft0_key"], hid)
-                    ops.conv_up2_x3(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, pre_add=hid)
+                    up(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, pre_add=hid)
                     ops.conv_x3(f, hz["aff0_key"], pre_aff)
-                    ops.conv_up2_x3(taps, hz["aff0_taps"], pre_aff, pre_add=pre_aff)
+                    up(taps, hz["aff0_taps"], pre_aff, pre_add=pre_aff)
                 else:
                     ops.conv_up2(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, key=(f, hz["ft0_key"]))
                     ops.conv_up2(taps, hz["aff0_taps"], pre_aff, key=(f, hz["aff0_key"]))

@@ -106,6 +106,12 @@ int bfsr_pack_conv_weight_bf16x3(const float* w_oihw, int Cout, int Cin, int KS,
  * (bfsr_pack_conv_weight_taps_bf16x3, T=16, mtile=1).  No x2/w_x2: channels at output resolution are convolved by
  * bfsr_conv2d_bf16x3 first and enter through `pre_add` (which may alias y).  tune = NW*100+NR (0 = default). */
 int bfsr_conv2d_up2_bf16x3(const BfsrConvArgs* a, void* stream);
+/* the same for a nearest-x4-upsampled input (level-1 conditional of the 8x model, SRFlowNet_arch.py:137 with scale 8):
+ * x [B,Cin,H/4,W/4] -> y [B,Cout,H,W]; w = 25 pre-summed matrices, index = row_entry*5 + col_entry, entry e = 0..4 per axis:
+ * (phase 0, offset -1) <- w[-1]; (phase 0, offset 0) <- w[0]+w[+1]; (phases 1,2, offset 0) <- w[-1]+w[0]+w[+1];
+ * (phase 3, offset 0) <- w[-1]+w[0]; (phase 3, offset +1) <- w[+1]   (bfsr_pack_conv_weight_taps_bf16x3, T=25, mtile=1).
+ * Epilogue: bias/affine/act + pre_add only (no residuals). */
+int bfsr_conv2d_up4_bf16x3(const BfsrConvArgs* a, void* stream);
 long long bfsr_conv_packed_size_taps_bf16x3(int Cout, int Cin, int T, int mtile);
 int bfsr_pack_conv_weight_taps_bf16x3(const float* w_oit, int Cout, int Cin, int T, int mtile, unsigned short* packed);
 

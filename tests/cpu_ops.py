@@ -60,6 +60,13 @@ class CpuOps(object):
     def conv_x3(self, x, pw, out, **kw):
         return self.conv(x, pw, out, **kw)
 
+    def pack_conv_up4_x3(self, w):
+        return self.pack_conv_up2(w, 1)
+
+    def conv_up4_x3(self, x, pw, out, epi=None, pre_add=None, act=0, slope=0.2):
+        xin = F.interpolate(x, scale_factor=4, mode="nearest")
+        return self.conv(xin, pw, out, epi=epi, pre_add=pre_add.clone() if pre_add is not None else None, act=act, slope=slope)
+
     def pack_conv_up2_x3(self, w):
         return self.pack_conv_up2(w, 1)
 

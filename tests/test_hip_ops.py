@@ -380,3 +380,27 @@ def test_likelihood_reductions(hip):
     mean, logs = hh[:, 0::2].double(), hh[:, 1::2].double()
     r1 = -(-0.5 * (logs * 2 + (x.double() - mean) ** 2 / torch.exp(logs * 2) + l2pi)).sum(dim=(1, 2, 3))
     assert ((a1.cpu() - r1).abs() / r1.abs()).max() < 1e-6
+
+
+@pytest.mark.parametrize("case", [(2, 70, 64, 64, 9, 21), (1, 256, 64, 96, 12, 40), (1, 24, 10, 40, 7, 35)])
+def test_conv_up4_bf16x3_with_key_channels(hip, case):
+    """x4 parity kernel (25 pre-summed matrices, 3 row-class launches) + key conv == conv over cat[key, nearest_up4(taps)]."""
+    B, Ct, Ck, Cout, h, w_ = case
+    taps, key = rnd(200, B, Ct, h, w_), rnd(201, B, Ck, 4 * h, 4 * w_)
+    w = rnd(202, Cout, Ck + Ct, 3, 3, scale=1.0 / np.sqrt((Ck + Ct) * 9))
+    sh, sc = rnd(203, Cout, scale=0.2), torch.exp(rnd(204, Cout, scale=0.2))
+    wk, wt = w[:, :Ck].contiguous(), w[:, Ck:].contiguous()
+    xin = torch.cat([key, torch.nn.functional.interpolate(taps, scale_factor=4, mode="nearest")], 1)
+    truth = torch.relu((torch.nn.functional.conv2d(xin.double(), w.double(), padding=1) + sh.double().view(1, -1, 1, 1))
+                       * sc.double().view(1, -1, 1, 1))
+    out = hip.empty(B, Cout, 4 * h, 4 * w_)
+    hip.conv_x3(hip.to_device(key), hip.pack_conv_x3(wk, 2), out)
+    hip.conv_up4_x3(hip.to_device(taps), hip.pack_conv_up4_x3(wt), out, epi=hip.pack_epilogue(Cout, aff_shift=sh, aff_scale=sc),
+                    act=1, pre_add=out)
+    ref32 = torch.relu((torch.nn.functional.conv2d(xin, w, padding=1) + sh.view(1, -1, 1, 1)) * sc.view(1, -1, 1, 1))
+    o32 = hip.conv(hip.to_device(xin), hip.pack_conv(w, 2), hip.empty(B, Cout, 4 * h, 4 * w_),
+                   epi=hip.pack_epilogue(Cout, aff_shift=sh, aff_scale=sc), act=1)        # native fp32 MFMA on the materialised input
+    ex3 = (out.cpu().double() - truth).abs().max().item()
+    e32 = max((ref32.double() - truth).abs().max().item(), (o32.cpu().double() - truth).abs().max().item())
+    assert ex3 <= 2.0 * e32 + 1e-7, (ex3, e32)
+    close(out, ref32, 1e-5, "conv_up4_x3 %s" % (case,))

@@ -125,7 +125,7 @@ def main():
             row.append("f16 %7.0fus %5.1fTF" % (us, flop / us / 1e6))
         if "--x3" in sys.argv:
             px = ops.pack_conv_x3(w, min(mt, 2))
-            for t in ([0] if KS == 1 else [int(v) for a in sys.argv if a.startswith('--x3tunes=') for v in a.split('=')[1].split(',')] or [200, 400]):
+            for t in ([int(v) for a in sys.argv if a.startswith('--x3tunes=') for v in a.split('=')[1].split(',')] or ([0] if KS == 1 else [200, 400])):
                 ops.conv_x3(x, px, y, tune=t)
                 torch.cuda.synchronize()
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

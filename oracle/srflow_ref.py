@@ -91,7 +91,9 @@ def invconv(x, weight, reverse):
     if not reverse:
         w = weight.view(C, C, 1, 1)
     else:
-        w = torch.inverse(weight.double()).float().view(C, C, 1, 1)
+        # `.float()` in the reference; `.to(x.dtype)` is the same for fp32 inputs and lets the tests run this restatement in
+        # fp64 (weights and inputs cast to double) as the ground truth for error measurements
+        w = torch.inverse(weight.double()).to(x.dtype).view(C, C, 1, 1)
     return F.conv2d(x, w)
 
 

@@ -181,3 +181,36 @@ def test_nll_vs_oracle_fresh_input(model4):
     _chk("z", z, oe[-1])
     assert ((nll.cpu() - onll).abs() / onll.abs()).max() <= 1e-5
     assert ((logdet.cpu() - old).abs() / old.abs()).max() <= 1e-5
+
+
+def test_default_contraction_is_fp32_accurate_end_to_end(hip):
+    """Pipeline-level evidence for the 3xBF16 default: against an fp64 run of the oracle (ground truth) the HIP pipeline's
+    error with the x3 kernels is at the level of the native-fp32-MFMA pipeline's and of the CPU fp32 oracle's own error."""
+    import oracle.srflow_ref as O
+    from bfsr_amd.ops import HipOps
+    from bfsr_amd.srflow.models import create_model, models as registry
+    from bfsr_amd.srflow.test import lp_infer
+    opt = options.load(options.DEFAULT_CONF)
+    sd = synth.state_dict_from_schema(spec.srflownet_schema(opt), 1234)
+    psd = synth.state_dict_from_schema(spec.srflow_prior_schema(), 4321)
+    lr = synth.smooth_lr_batch(3, 1, 32, 32)
+    dbl = lambda m: {k: (v.double() if v.is_floating_point() else v) for k, v in m.items()}
+    truth = O.lp_pipeline(lr.double(), dbl(sd), dbl(psd), opt, 23, return_all=True)
+    cpu32 = O.lp_pipeline(lr, sd, psd, opt, 23, return_all=True)
+    errs = {}
+    for mode in ("x3", "f32"):
+        ops = HipOps("cuda:0")
+        ops.conv_mode = mode
+        m = create_model(opt, ops=ops)
+        m.load_network(sd)
+        prior = registry.make({"name": "unet", "args": {"depth": 3, "dim": 64, "bilinear": True, "ops": ops}, "sd": psd},
+                              load_sd=True).eval()
+        out = lp_infer(m, prior, lr, return_all=True)
+        errs[mode] = {k: float((out[k].cpu().double() - truth[k]).abs().max()) for k in ("sr_raw", "sr")}
+        errs[mode]["z"] = float((out["epses"][1].cpu().double() - truth["epses"][1]).abs().max())
+    errs["cpu32"] = {k: float((cpu32[k].double() - truth[k]).abs().max()) for k in ("sr_raw", "sr")}
+    errs["cpu32"]["z"] = float((cpu32["epses"][1].double() - truth["epses"][1]).abs().max())
+    print("max-abs error vs fp64 oracle:", errs)
+    for k in ("sr_raw", "sr", "z"):
+        assert errs["x3"][k] <= 2.0 * max(errs["f32"][k], errs["cpu32"][k]) + 1e-7, (k, errs)
+        assert errs["x3"][k] <= 1e-4

@@ -274,7 +274,10 @@ int dispatch_flow_vec(const BfsrFlowArgs& a, hipStream_t st, int maxvec)
               (a.z_out_bs % 4 == 0);
     if (a.h_aff) v4 = v4 && aligned16(a.h_aff) && (a.h_aff_bs % 4 == 0);
     if (a.h_ft) v4 = v4 && aligned16(a.h_ft) && (a.h_ft_bs % 4 == 0);
-    if (v4) return launch_flow<C, 4>(a, st);
+    // 16-byte accesses only when the grid still has >= 2 blocks per CU; below that 8-byte accesses double the number of
+    // waves in flight, which is what a ~35 us latency-bound launch needs (measured: C=24 @ 8x160x160 +10 %)
+    if (v4 && (HW / 4 + 255) / 256 * a.B >= 512) return launch_flow<C, 4>(a, st);
+    if (v4) return launch_flow<C, 2>(a, st);
     return launch_flow<C, 1>(a, st);
 }
 

@@ -41,9 +41,9 @@ class PackedConv(object):
         self.data, self.Cout, self.Cin, self.KS, self.mtile, self.fixed = data, Cout, Cin, KS, mtile, fixed
         self._w, self._alts, self._ops = w, {mtile: data}, ops
 
-    def variant(self, mtile):
+    def variant(self, mtile, packer=None):
         if mtile not in self._alts:
-            self._alts[mtile] = self._ops._pack_raw(self._w, mtile)
+            self._alts[mtile] = (packer or self._ops._pack_raw)(self._w, mtile)
         return self._alts[mtile]
 
 
@@ -128,12 +128,17 @@ class HipOps(object):
         """fp16 packing for conv_f16 (the reduced-precision MFMA path); rounding = RNE like the kernel's staging."""
         w = w.detach().to("cpu", torch.float32).contiguous()
         Cout, Cin, KS, _ = w.shape
+        fixed = mtile is not None or Cout <= 32
         mtile = min(mtile or 2, 2) if Cout > 32 else 1
+        return PackedConv(self._pack_raw_16(w, mtile, kind), Cout, Cin, KS, mtile, fixed=fixed, w=w, ops=self)
+
+    def _pack_raw_16(self, w, mtile, kind):
+        Cout, Cin, KS, _ = w.shape
         size_fn = getattr(self.lib, "bfsr_conv_packed_size_" + kind)
         pack_fn = getattr(self.lib, "bfsr_pack_conv_weight_" + kind)
         packed = torch.empty(size_fn(Cout, Cin, KS, mtile), dtype=torch.int16)
         _lib.check(pack_fn(w.data_ptr(), Cout, Cin, KS, mtile, packed.data_ptr()), "pack_" + kind)
-        return PackedConv(packed.to(self.device), Cout, Cin, KS, mtile, fixed=True)
+        return packed.to(self.device)
 
     def pack_conv_x3(self, w, mtile=None):
         """3xBF16 split packing for conv_x3 (fp32-accurate contraction on the bf16 MFMA)."""
@@ -152,9 +157,16 @@ class HipOps(object):
             raise ValueError("conv_f16: shape mismatch x%s out%s" % (tuple(x.shape), tuple(out.shape)))
         a = _lib.BfsrConvArgs()
         a.x, a.x_bs, a.Cin = xp, xbs, Cin
-        a.w = pw.data.data_ptr()
+        mtile, wdata = pw.mtile, pw.data
+        if not pw.fixed and mtile == 2 and pw.KS == 3 and _kind == "bf16x3":
+            # small grids: 32-cout workgroups (two per CU, more of them) beat the 64-cout tile (measured on MI355X:
+            # 64->96 @ 8x80x80 59 -> 49 us, 64->48 @ 8x160x160 106 -> 97 us, RDB conv5 @ 8x160x160 ~ -8 %)
+            if ((W + 31) // 32) * ((H + 7) // 8) * out.shape[0] * ((Cout + 31) // 32) < 2000:
+                mtile = 1
+                wdata = pw.variant(1, lambda w_, m_: self._pack_raw_16(w_, m_, _kind))
+        a.w = wdata.data_ptr()
         a.y, a.y_bs, a.Cout = yp, ybs, Cout
-        a.B, a.H, a.W, a.KS, a.in_shift, a.mtile = out.shape[0], H, W, pw.KS, in_shift, pw.mtile
+        a.B, a.H, a.W, a.KS, a.in_shift, a.mtile = out.shape[0], H, W, pw.KS, in_shift, mtile
         a.epi, a.act, a.slope = _ptr(epi), act, slope
         for name, t, al in (("pre_add", pre_add, None), ("res1", res1, alpha1), ("res2", res2, alpha2)):
             if t is not None:
@@ -165,7 +177,7 @@ class HipOps(object):
                 if al is not None:
                     setattr(a, "alpha" + name[-1], al)
         a.tune = tune
-        key = ("conv_" + _kind, pw.KS, pw.mtile, Cin, Cout, out.shape[0], H, W)
+        key = ("conv_" + _kind, pw.KS, mtile, Cin, Cout, out.shape[0], H, W)
         fn = getattr(self.lib, "bfsr_conv2d_" + _kind)
         _lib.check(self._launch(key, lambda: fn(C.byref(a), self._stream())), "conv2d_" + _kind)
         return out

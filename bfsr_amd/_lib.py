@@ -79,6 +79,9 @@ SYMBOLS = {
     "bfsr_conv2d_bf16x3": (_I, [C.POINTER(BfsrConvArgs), _VP]),
     "bfsr_conv_packed_size_bf16x3": (_LL, [_I, _I, _I, _I]),
     "bfsr_pack_conv_weight_bf16x3": (_I, [_VP, _I, _I, _I, _I, _VP]),
+    "bfsr_conv1x1": (_I, [C.POINTER(BfsrConvArgs), _I, _VP]),
+    "bfsr_conv1x1_packed_size": (_LL, [_I, _I, _I]),
+    "bfsr_pack_conv1x1_weight": (_I, [_VP, _I, _I, _I, _VP]),
     "bfsr_conv2d_up2_bf16x3": (_I, [C.POINTER(BfsrConvArgs), _VP]),
     "bfsr_conv2d_up4_bf16x3": (_I, [C.POINTER(BfsrConvArgs), _VP]),
     "bfsr_conv_packed_size_taps_bf16x3": (_LL, [_I, _I, _I, _I]),

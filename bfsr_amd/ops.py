@@ -182,6 +182,39 @@ class HipOps(object):
         _lib.check(self._launch(key, lambda: fn(C.byref(a), self._stream())), "conv2d_" + _kind)
         return out
 
+    def pack_conv1x1(self, w, x3=True):
+        """Wide 1x1 conv weights ([Cout,Cin,1,1] or [Cout,Cin]) for conv1x1: x3 = exact bf16 triple, else fp16."""
+        w = w.detach().to("cpu", torch.float32).reshape(w.shape[0], w.shape[1]).contiguous()
+        Cout, Cin = w.shape
+        packed = torch.empty(self.lib.bfsr_conv1x1_packed_size(Cout, Cin, int(x3)), dtype=torch.int16)
+        _lib.check(self.lib.bfsr_pack_conv1x1_weight(w.data_ptr(), Cout, Cin, int(x3), packed.data_ptr()), "pack_conv1x1")
+        return PackedConv(packed.to(self.device), Cout, Cin, 1, 8, fixed=True)
+
+    def conv1x1(self, x, pw, out, x3=True, epi=None, pre_add=None, act=ACT_NONE, slope=0.2, res1=None, alpha1=1.0, res2=None,
+                alpha2=1.0):
+        """1x1 conv as a GEMM over the flattened pixels, 256 output channels per workgroup (conv1x1.hip)."""
+        xp, xbs, Cin, H, W = _view(x, "conv1x1.x")
+        yp, ybs, Cout, H2, W2 = _view(out, "conv1x1.out")
+        if (Cin, Cout, H, W) != (pw.Cin, pw.Cout, H2, W2) or x.shape[0] != out.shape[0] or pw.KS != 1:
+            raise ValueError("conv1x1: shape mismatch x%s out%s" % (tuple(x.shape), tuple(out.shape)))
+        a = _lib.BfsrConvArgs()
+        a.x, a.x_bs, a.Cin = xp, xbs, Cin
+        a.w = pw.data.data_ptr()
+        a.y, a.y_bs, a.Cout = yp, ybs, Cout
+        a.B, a.H, a.W, a.KS, a.mtile = out.shape[0], H, W, 1, pw.mtile
+        a.epi, a.act, a.slope = _ptr(epi), act, slope
+        for name, t, al in (("pre_add", pre_add, None), ("res1", res1, alpha1), ("res2", res2, alpha2)):
+            if t is not None:
+                pp, bs, c, hh, ww = _view(t, "conv1x1." + name)
+                assert (c, hh, ww) == (Cout, H, W)
+                setattr(a, name, pp)
+                setattr(a, name + "_bs", bs)
+                if al is not None:
+                    setattr(a, "alpha" + name[-1], al)
+        key = ("conv1x1_x3" if x3 else "conv1x1_f16", Cin, Cout, out.shape[0], H, W)
+        _lib.check(self._launch(key, lambda: self.lib.bfsr_conv1x1(C.byref(a), int(x3), self._stream())), "conv1x1")
+        return out
+
     @staticmethod
     def presum_up2_weights(w):
         """[Cout,Cin,3,3] -> [Cout,Cin,16]: the 3x3 taps folded onto the 2x2 source pixels each output parity of a

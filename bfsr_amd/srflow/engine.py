@@ -32,13 +32,22 @@ class _ConvP(object):
         """Contraction mode: 'f32' = native fp32 MFMA; 'x3' = fp32-accurate 3xBF16 split on the bf16 MFMA (the default
         for 3x3 convs with >= 32 input channels, where it is 1.4-1.7x faster; x3=False pins fp32, e.g. for the fused
         two-stage kernel); 'f16' = reduced precision (LINF precision='fp16' only).  Epilogue and tensors are fp32."""
+        pinned_f32 = x3 is False
         if x3 is None:
             x3 = getattr(ops, "conv_mode", "f32") == "x3" and w.shape[2] == 3 and w.shape[1] >= 32
         self.mode = "f16" if f16 else ("x3" if x3 else "f32")
-        self.pw = {"f16": ops.pack_conv_f16, "x3": ops.pack_conv_x3, "f32": ops.pack_conv}[self.mode](w, mtile)
+        # wide 1x1 convs (the LINF MLP): GEMM kernel with 256 output channels per workgroup, in the fp16 or the x3 arithmetic
+        # (x3 mode only for the fp16-precision models for now: the x3 arithmetic of this kernel is not faster than the fp32 MFMA)
+        self.wide1x1 = (w.shape[2] == 1 and w.shape[0] >= 128 and w.shape[1] >= 64 and not pinned_f32 and f16)
+        if self.wide1x1:
+            self.pw = ops.pack_conv1x1(w, x3=not f16)
+        else:
+            self.pw = {"f16": ops.pack_conv_f16, "x3": ops.pack_conv_x3, "f32": ops.pack_conv}[self.mode](w, mtile)
         self.epi = ops.pack_epilogue(self.pw.Cout, bias, aff_shift, aff_scale, aff_post, post_scale)
 
     def run(self, ops, x, out, **kw):
+        if self.wide1x1:
+            return ops.conv1x1(x, self.pw, out, x3=self.mode != "f16", epi=self.epi, **kw)
         if self.mode == "f16":
             return ops.conv_f16(x, self.pw, out, epi=self.epi, **kw)
         if self.mode == "x3":

@@ -115,6 +115,14 @@ int bfsr_conv2d_up4_bf16x3(const BfsrConvArgs* a, void* stream);
 long long bfsr_conv_packed_size_taps_bf16x3(int Cout, int Cin, int T, int mtile);
 int bfsr_pack_conv_weight_taps_bf16x3(const float* w_oit, int Cout, int Cin, int T, int mtile, unsigned short* packed);
 
+/* Wide 1x1 convolutions as a GEMM over the flattened pixel axis (the LINF shared MLP, linf.py:313-314): a workgroup owns
+ * 128 pixels x 256 output channels, so activations are read once per 256 couts.  x3 != 0: exact 3-term bf16 split (fp32
+ * accurate); x3 == 0: operands rounded to fp16 (LINF precision='fp16').  Same BfsrConvArgs / epilogue as bfsr_conv2d with
+ * KS = 1, no in_shift, no fused second stage; `w` from bfsr_pack_conv1x1_weight (16-bit elements). */
+int bfsr_conv1x1(const BfsrConvArgs* a, int x3, void* stream);
+long long bfsr_conv1x1_packed_size(int Cout, int Cin, int x3);
+int bfsr_pack_conv1x1_weight(const float* w_oi, int Cout, int Cin, int x3, unsigned short* packed);
+
 /* ---- fused flow-step pointwise chain -----------------------------------------------------------
  * One read of z / h_aff / h_ft, one write of z (the HBM-roofline "coupling inverse" kernel of
  * BASELINE.json).  replaces, per FlowStep (SRFlow-LP/code/models/modules/):

@@ -60,6 +60,13 @@ class CpuOps(object):
     def conv_x3(self, x, pw, out, **kw):
         return self.conv(x, pw, out, **kw)
 
+    def pack_conv1x1(self, w, x3=True):
+        w = w.detach().to(torch.float32).reshape(w.shape[0], w.shape[1], 1, 1)
+        return PackedConv((w if x3 else w.half().float()).contiguous().clone(), 8)
+
+    def conv1x1(self, x, pw, out, x3=True, **kw):
+        return self.conv(x if x3 else x.half().float(), pw, out, **kw)
+
     def pack_conv_up4_x3(self, w):
         return self.pack_conv_up2(w, 1)
 

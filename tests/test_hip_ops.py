@@ -404,3 +404,24 @@ def test_conv_up4_bf16x3_with_key_channels(hip, case):
     e32 = max((ref32.double() - truth).abs().max().item(), (o32.cpu().double() - truth).abs().max().item())
     assert ex3 <= 2.0 * e32 + 1e-7, (ex3, e32)
     close(out, ref32, 1e-5, "conv_up4_x3 %s" % (case,))
+
+
+@pytest.mark.parametrize("case", [(2, 1024, 256, 9, 40), (1, 256, 540, 17, 33), (3, 100, 130, 5, 7), (1, 256, 256, 64, 64)])
+@pytest.mark.parametrize("x3", [True, False])
+def test_wide_conv1x1(hip, case, x3):
+    """conv1x1.hip (128 px x 256 couts per workgroup): x3 mode is fp32-accurate, f16 mode == fp16-rounded operands."""
+    B, Cin, Cout, H, W = case
+    x = rnd(210, B, Cin, H, W)
+    w = rnd(211, Cout, Cin, 1, 1, scale=1.0 / np.sqrt(Cin))
+    b, r1 = rnd(212, Cout, scale=0.2), rnd(213, B, Cout, H, W)
+    out = hip.conv1x1(hip.to_device(x), hip.pack_conv1x1(w, x3=x3), hip.empty(B, Cout, H, W), x3=x3,
+                      epi=hip.pack_epilogue(Cout, bias=b), act=1, res1=hip.to_device(r1), alpha1=0.5)
+    ref = CPU.conv1x1(x, CPU.pack_conv1x1(w, x3=x3), torch.empty(B, Cout, H, W), x3=x3, bias=b, act=1, res1=r1, alpha1=0.5)
+    close(out, ref, 1e-5 if x3 else 2e-5, "conv1x1 %s x3=%s" % (case, x3))
+    if x3:
+        truth = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double())) * 0.5 + r1.double()
+        o32 = hip.conv(hip.to_device(x), hip.pack_conv(w, 2), hip.empty(B, Cout, H, W), epi=hip.pack_epilogue(Cout, bias=b), act=1,
+                       res1=hip.to_device(r1), alpha1=0.5)                      # native fp32 MFMA kernel
+        e = (out.cpu().double() - truth).abs().max().item()
+        e32 = max((ref.double() - truth).abs().max().item(), (o32.cpu().double() - truth).abs().max().item())
+        assert e <= 2.0 * e32 + 1e-7, (e, e32)

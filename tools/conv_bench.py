@@ -136,6 +136,19 @@ def main():
                 torch.cuda.synchronize()
                 us = s.elapsed_time(e) / 10 * 1e3
                 row.append("x3/%d %7.0fus %5.1fTF" % (t, us, flop / us / 1e6))
+        if "--wide" in sys.argv and KS == 1:
+            for x3 in (True, False):
+                pw1 = ops.pack_conv1x1(w, x3=x3)
+                ops.conv1x1(x, pw1, y, x3=x3)
+                torch.cuda.synchronize()
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                for _ in range(10):
+                    ops.conv1x1(x, pw1, y, x3=x3)
+                e.record()
+                torch.cuda.synchronize()
+                us = s.elapsed_time(e) / 10 * 1e3
+                row.append("wide/%s %7.0fus %5.1fTF" % ("x3" if x3 else "f16", us, flop / us / 1e6))
         print("%-26s | %s" % (name, " | ".join(row)), flush=True)
     print("tunes:", TUNES)
 

@@ -113,16 +113,17 @@ def main():
             row.append("%7.0fus %5.1fTF" % (us, flop / us / 1e6))
         if "--f16" in sys.argv:
             pf = ops.pack_conv_f16(w, min(mt, 2))
-            ops.conv_f16(x, pf, y)
-            torch.cuda.synchronize()
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            for _ in range(10):
-                ops.conv_f16(x, pf, y)
-            e.record()
-            torch.cuda.synchronize()
-            us = s.elapsed_time(e) / 10 * 1e3
-            row.append("f16 %7.0fus %5.1fTF" % (us, flop / us / 1e6))
+            for t in ([int(v) for a in sys.argv if a.startswith('--f16tunes=') for v in a.split('=')[1].split(',')] or [0]):
+                ops.conv_f16(x, pf, y, tune=t)
+                torch.cuda.synchronize()
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                for _ in range(10):
+                    ops.conv_f16(x, pf, y, tune=t)
+                e.record()
+                torch.cuda.synchronize()
+                us = s.elapsed_time(e) / 10 * 1e3
+                row.append("f16/%d %7.0fus %5.1fTF" % (t, us, flop / us / 1e6))
         if "--x3" in sys.argv:
             px = ops.pack_conv_x3(w, min(mt, 2))
             for t in ([int(v) for a in sys.argv if a.startswith('--x3tunes=') for v in a.split('=')[1].split(',')] or ([0] if KS == 1 else [200, 400])):

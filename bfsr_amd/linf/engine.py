@@ -145,14 +145,18 @@ class LINFEngine(object):
 class LINFPriorEngine(object):
     """LINF-LP prior `UNet.forward(x, lr)` (LINF-LP/models/unet.py:144-167)."""
 
-    def __init__(self, sd, ops, in_chans, depth=3, dim=64):
+    def __init__(self, sd, ops, in_chans, depth=3, dim=64, precision="fp32"):
+        """precision='fp16': the prior's 3x3 convs contract on the fp16 MFMA like the LINF model's (BASELINE config 5)."""
+        if precision not in ("fp32", "fp16"):
+            raise ValueError("precision must be 'fp32' or 'fp16'")
+        f16 = precision == "fp16"
         sd = {k: v.detach().to("cpu", torch.float32) for k, v in sd.items() if v.dtype.is_floating_point}
         self.ops, self.ws, self.in_chans, self.dim = ops, _Workspace(ops), in_chans, dim
-        self.input_proj = DenseBlock(ops, sd, "input_proj")
+        self.input_proj = DenseBlock(ops, sd, "input_proj", f16=f16)
         self.lr_w = ops.to_device(sd["lr_proj.0.weight"])
         self.lr_b = ops.vec(sd["lr_proj.0.bias"])
-        self.lr_dense = DenseBlock(ops, sd, "lr_proj.2")
-        self.body = UNetBody(ops, sd, "", depth)
+        self.lr_dense = DenseBlock(ops, sd, "lr_proj.2", f16=f16)
+        self.body = UNetBody(ops, sd, "", depth, f16=f16)
 
     def forward(self, x, lr):
         ops, ws = self.ops, self.ws

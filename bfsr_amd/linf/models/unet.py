@@ -10,9 +10,9 @@ from .models import register
 
 
 class UNet(nn.Module):
-    def __init__(self, in_chans, depth=3, dim=64, bilinear=False, ops=None):
+    def __init__(self, in_chans, depth=3, dim=64, bilinear=False, ops=None, precision="fp32"):
         super(UNet, self).__init__()
-        self.in_chans, self.depth, self.dim, self.bilinear = in_chans, depth, dim, bilinear
+        self.in_chans, self.depth, self.dim, self.bilinear, self.precision = in_chans, depth, dim, bilinear, precision
         paramtree.attach(self, spec.linf_prior_schema(in_chans, depth, dim, bilinear), paramtree.default_init(15))
         self._ops, self._engine = ops, None
 
@@ -32,7 +32,7 @@ class UNet(nn.Module):
                 from ...ops import HipOps
                 p = next(self.parameters())
                 self._ops = HipOps(p.device if p.is_cuda else None)
-            self._engine = LINFPriorEngine(self.state_dict(), self._ops, self.in_chans, self.depth, self.dim)
+            self._engine = LINFPriorEngine(self.state_dict(), self._ops, self.in_chans, self.depth, self.dim, precision=self.precision)
         return self._engine
 
     def forward(self, x, lr):
@@ -44,6 +44,6 @@ class UNet(nn.Module):
 
 
 @register('unet')
-def make_unet(in_chans, depth=3, dim=64, bilinear=True, cell_input=None, ops=None):
+def make_unet(in_chans, depth=3, dim=64, bilinear=True, cell_input=None, ops=None, precision="fp32"):
     print('UNet: depth={}, dim={}, bilinear={}'.format(depth, dim, bilinear))
-    return UNet(in_chans=in_chans, depth=depth, dim=dim, bilinear=bilinear, ops=ops)
+    return UNet(in_chans=in_chans, depth=depth, dim=dim, bilinear=bilinear, ops=ops, precision=precision)

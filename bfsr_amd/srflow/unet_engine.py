@@ -13,15 +13,15 @@ from ..ops import ACT_LRELU, ACT_NONE, MODE_BILINEAR_AC
 from .engine import _ConvP, _Workspace
 
 
-def _bn_conv(ops, sd, wkey, bnp, eps=1e-5):
+def _bn_conv(ops, sd, wkey, bnp, eps=1e-5, f16=False):
     s = sd[bnp + ".weight"] / torch.sqrt(sd[bnp + ".running_var"] + eps)
-    return _ConvP(ops, sd[wkey], aff_shift=-sd[bnp + ".running_mean"], aff_scale=s, aff_post=sd[bnp + ".bias"])
+    return _ConvP(ops, sd[wkey], aff_shift=-sd[bnp + ".running_mean"], aff_scale=s, aff_post=sd[bnp + ".bias"], f16=f16)
 
 
 class _DoubleConv(object):
-    def __init__(self, ops, sd, p):
-        self.c1 = _bn_conv(ops, sd, p + ".double_conv.0.weight", p + ".double_conv.1")
-        self.c2 = _bn_conv(ops, sd, p + ".double_conv.3.weight", p + ".double_conv.4")
+    def __init__(self, ops, sd, p, f16=False):
+        self.c1 = _bn_conv(ops, sd, p + ".double_conv.0.weight", p + ".double_conv.1", f16=f16)
+        self.c2 = _bn_conv(ops, sd, p + ".double_conv.3.weight", p + ".double_conv.4", f16=f16)
         self.mid = self.c1.pw.Cout
         self.out = self.c2.pw.Cout
 
@@ -36,8 +36,8 @@ class _DoubleConv(object):
 class DenseBlock(object):
     """DenseBlock_5C (unet.py:10-36): five 3x3 convs over a growing concat, no residual."""
 
-    def __init__(self, ops, sd, p):
-        self.convs = [_ConvP(ops, sd["%s.conv%d.weight" % (p, i)], sd["%s.conv%d.bias" % (p, i)]) for i in range(1, 6)]
+    def __init__(self, ops, sd, p, f16=False):
+        self.convs = [_ConvP(ops, sd["%s.conv%d.weight" % (p, i)], sd["%s.conv%d.bias" % (p, i)], f16=f16) for i in range(1, 6)]
         self.nf = self.convs[0].pw.Cin
         self.gc = self.convs[0].pw.Cout
         self.out = self.convs[4].pw.Cout
@@ -56,11 +56,11 @@ class DenseBlock(object):
 class UNetBody(object):
     """inc -> downs -> ups -> outc, parameter names with a branch suffix `tag` ('' for LINF, '0'/'1' SRFlow)."""
 
-    def __init__(self, ops, sd, tag, depth):
+    def __init__(self, ops, sd, tag, depth, f16=False):
         self.ops, self.depth, self.tag = ops, depth, tag
-        self.inc = _DoubleConv(ops, sd, "inc%s" % tag)
-        self.downs = [_DoubleConv(ops, sd, "down_layers%s.%d.maxpool_conv.1" % (tag, i)) for i in range(depth)]
-        self.ups = [_DoubleConv(ops, sd, "up_layers%s.%d.conv" % (tag, i)) for i in range(depth)]
+        self.inc = _DoubleConv(ops, sd, "inc%s" % tag, f16=f16)
+        self.downs = [_DoubleConv(ops, sd, "down_layers%s.%d.maxpool_conv.1" % (tag, i), f16=f16) for i in range(depth)]
+        self.ups = [_DoubleConv(ops, sd, "up_layers%s.%d.conv" % (tag, i), f16=f16) for i in range(depth)]
         self.outc = _ConvP(ops, sd["outc%s.conv.weight" % tag], sd["outc%s.conv.bias" % tag])
 
     def run(self, ws, x, out, name):

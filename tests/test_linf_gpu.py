@@ -176,13 +176,14 @@ def test_fp16_mfma_path_config5(hip):
     from bfsr_amd.linf.models import make
     from bfsr_amd.linf.test import lp_infer
     sd, psd = weights("rrdb", 2024)
-    prior = make({"name": "unet", "args": {"in_chans": 27, "depth": 3, "dim": 64, "bilinear": True}}, args={"ops": hip}).eval()
-    prior.load_state_dict(psd)
     outs = {}
     lr = synth.smooth_lr_batch(13, 2, 32, 32)
     H = W = 192
     prep = O.batch_prep(lr, (H, W))
     for prec in ("fp32", "fp16"):
+        prior = make({"name": "unet", "args": {"in_chans": 27, "depth": 3, "dim": 64, "bilinear": True}},
+                     args={"ops": hip, "precision": prec}).eval()
+        prior.load_state_dict(psd)
         m = make(mspec("rrdb"), args={"ops": hip, "precision": prec}).eval()
         m.load_state_dict(sd)
         outs[prec] = lp_infer(m, prior, prep, (H, W), return_all=True)

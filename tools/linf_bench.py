@@ -34,7 +34,7 @@ def main():
     psd = synth.state_dict_from_schema(lspec.linf_prior_schema(27), 777)
     m = make(mspec, args={"ops": ops, "precision": args.precision}).eval()
     m.load_state_dict(sd)
-    prior = make({"name": "unet", "args": {"in_chans": 27, "depth": 3, "dim": 64, "bilinear": True}}, args={"ops": ops}).eval()
+    prior = make({"name": "unet", "args": {"in_chans": 27, "depth": 3, "dim": 64, "bilinear": True}}, args={"ops": ops, "precision": args.precision}).eval()
     prior.load_state_dict(psd)
     B, h = args.batch, args.lr
     xs = [ops.to_device(synth.lr_batch(100 + i, B, h, h)) for i in range(2)]

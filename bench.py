@@ -179,12 +179,12 @@ def main():
 
     roofline = roof_entry(*totals[0]) if totals else None
     # HBM bytes per launch of the dominant kernel from the committed PMC passes (separate --pmc runs, profiles/)
-    tp = os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")
+    tp = os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")
     if roofline and os.path.exists(tp):
         ent = json.load(open(tp)).get("kernels", {}).get(json.dumps(list(totals[0][1])))
         if ent:
             roofline["traffic"] = ent["hbm_bytes_per_launch"]
-            roofline["traffic_unit"] = "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_f_pmc_traffic.json)"
+            roofline["traffic_unit"] = "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_g_pmc_traffic.json)"
     roofline_next = [roof_entry(*x) for x in totals[1:4]]
     tail_ms, tail_n = avg_ms(key_tail)
     hw1 = (H // 2) * (H // 2)

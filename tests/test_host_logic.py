@@ -176,3 +176,52 @@ def test_nll_and_logdet_vs_reference_golden(golden_dir, tag, scale):
     sr, logdet_rev = net(lr=lr, reverse=True, epses=list(epses))
     assert rel(logdet_rev, T(g["logdet_rev_" + tag])) <= 1e-5
     assert rel(logdet_rev, -logdet) <= 1e-5                      # the inverse undoes every term
+
+
+def test_split_packing_is_exact_and_laid_out_as_documented():
+    """Host-side packers of the 16-bit kernels (no GPU needed): the 3xBF16 triple sums EXACTLY to the fp32 weight and sits at
+    [group][chunk][plane][tap][k half][cout][8]; the fp16 / wide-1x1 packers round to nearest-even at the documented slots."""
+    from bfsr_amd import _lib
+    lib = _lib.load()
+    Cout, Cin, KS, mt = 70, 37, 3, 2
+    g = np.random.Generator(np.random.PCG64(5))
+    w = torch.from_numpy((g.standard_normal((Cout, Cin, KS, KS)) * np.exp(g.uniform(-12, 4, (Cout, Cin, KS, KS)))).astype(np.float32))
+    n = lib.bfsr_conv_packed_size_bf16x3(Cout, Cin, KS, mt)
+    nchunk, groups = 3, 2
+    assert n == groups * nchunk * 3 * 9 * 2 * 64 * 8
+    packed = torch.zeros(n, dtype=torch.int16)
+    assert lib.bfsr_pack_conv_weight_bf16x3(w.data_ptr(), Cout, Cin, KS, mt, packed.data_ptr()) == 0
+    P = packed.view(groups, nchunk, 3, 9, 2, 64, 8)
+    as_f32 = lambda t: (t.to(torch.int32) << 16).view(torch.float32)          # bf16 bits -> float
+    full = torch.zeros(Cout, Cin, 9)
+    for co in range(Cout):
+        blk = P[co // 64, :, :, :, :, co % 64, :]                             # [chunk, plane, tap, khalf, 8]
+        v = as_f32(blk).double().sum(1)                                       # h + m + l  -> [chunk, tap, khalf, 8]
+        full[co] = v.permute(0, 2, 3, 1).reshape(nchunk * 16, 9)[:Cin].float()
+    assert torch.equal(full.view(Cout, Cin, 3, 3), w)                         # exact, bit for bit
+    assert int(P[1, :, :, :, :, 6:, :].abs().sum()) == 0                      # cout padding of the second group
+    assert int(P[:, 2, :, :, 0, :, 5:].abs().sum()) == 0 and int(P[:, 2, :, :, 1].abs().sum()) == 0    # cin 37..47 padding
+    # fp16 packer: RNE of the weight at [group][chunk][tap][k half][cout][8]
+    n16 = lib.bfsr_conv_packed_size_f16(Cout, Cin, KS, mt)
+    p16 = torch.zeros(n16, dtype=torch.int16)
+    w16 = torch.randn(Cout, Cin, KS, KS)
+    assert lib.bfsr_pack_conv_weight_f16(w16.data_ptr(), Cout, Cin, KS, mt, p16.data_ptr()) == 0
+    Q = p16.view(groups, nchunk, 9, 2, 64, 8).view(torch.float16)
+    for co, ci, t in ((0, 0, 0), (69, 36, 8), (64, 17, 4), (33, 7, 2)):
+        assert Q[co // 64, ci // 16, t, (ci % 16) // 8, co % 64, ci % 8] == w16[co, ci, t // 3, t % 3].half()
+    # wide 1x1 packers
+    Co1, Ci1 = 300, 70
+    w1 = torch.randn(Co1, Ci1)
+    for x3, CK, PL in ((1, 32, 3), (0, 64, 1)):
+        n1 = lib.bfsr_conv1x1_packed_size(Co1, Ci1, x3)
+        nch = (Ci1 + CK - 1) // CK
+        assert n1 == 2 * nch * PL * (CK // 8) * 256 * 8
+        p1 = torch.zeros(n1, dtype=torch.int16)
+        assert lib.bfsr_pack_conv1x1_weight(w1.data_ptr(), Co1, Ci1, x3, p1.data_ptr()) == 0
+        R = p1.view(2, nch, PL, CK // 8, 256, 8)
+        for co, ci in ((0, 0), (299, 69), (256, 33), (17, 64)):
+            cell = R[co // 256, ci // CK, :, (ci % CK) // 8, co % 256, ci % 8]
+            if x3:
+                assert float(as_f32(cell).double().sum()) == float(w1[co, ci])
+            else:
+                assert cell.view(torch.float16)[0] == w1[co, ci].half()

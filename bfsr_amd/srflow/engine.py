@@ -14,6 +14,9 @@ reference):
 
 `ops` is the kernel backend (bfsr_amd.ops.HipOps).  No arithmetic happens in this file.
 """
+import contextlib
+import os
+
 import torch
 
 from . import spec
@@ -142,6 +145,7 @@ class SRFlowEngine(object):
                                       "(FlowAffineCouplingsAblation.py:30); got %d" % self.n_cond)
         self.ws = _Workspace(ops)
         self._cond_key, self._cond = None, None
+        self._side_stream = None
         self._load(sd)
 
     # ------------------------------------------------------------------------------------------
@@ -307,37 +311,63 @@ class SRFlowEngine(object):
             dst = key_view("fea_up0")       # bilinear 1/2, align_corners=False, recompute_scale_factor=True
             ops.resize(last, dst, MODE_BILINEAR, float(h) / dst.shape[2], float(w) / dst.shape[3])
 
+        # Levels >= 2 are not needed before the level-1 steps of encode() are through, and those steps (short kernels, matrix
+        # pipe ~40 % busy) leave room on the chip: their hoisted convs go to a side stream that forks here, after the level-1
+        # hoists have been enqueued, and joins at the first use of the level (`_await`).  BFSR_OVERLAP=0 disables it.
+        use_side = (getattr(getattr(ops, "device", None), "type", "cpu") == "cuda" and os.environ.get("BFSR_OVERLAP", "1") != "0")
+        main_stream = torch.cuda.current_stream(ops.device) if use_side else None
         cond = {}
-        for level, hz in self.hoist.items():
-            K = len(hz["idxs"])
-            f = ft[level]
-            hl, wl = f.shape[2], f.shape[3]
-            Cz = [ly.C for ly in self.layers if ly.index == hz["idxs"][0]][0]
-            hid = ws.get("hoist_hid%d" % level, B, K * 64, hl, wl)
-            pre_aff = ws.get("pre_aff%d" % level, B, K * 64, hl, wl)
-            h_ft = ws.get("h_ft%d" % level, B, K * 2 * Cz, hl, wl)
-            if hz["up2"]:
-                taps = ft[self._lr_level()][:, 64:]
-                if hz["x3"]:
-                    up = ops.conv_up4_x3 if hz["up"] == 2 else ops.conv_up2_x3
-                    ops.conv_x3(f, hz["ft0_key"], hid)
-                    up(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, pre_add=hid)
-                    ops.conv_x3(f, hz["aff0_key"], pre_aff)
-                    up(taps, hz["aff0_taps"], pre_aff, pre_add=pre_aff)
-                else:
-                    ops.conv_up2(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, key=(f, hz["ft0_key"]))
-                    ops.conv_up2(taps, hz["aff0_taps"], pre_aff, key=(f, hz["aff0_key"]))
-            else:
-                hz["ft0"].run(ops, f, hid, act=ACT_RELU)
-                hz["aff0"].run(ops, f, pre_aff)
-            for k, i in enumerate(hz["idxs"]):
-                st = self.steps[i]
-                hk = hid[:, 64 * k: 64 * (k + 1)]
-                st.ft2.run(ops, hk, hk, act=ACT_RELU)            # 1x1, in place (disjoint pixel tiles)
-                st.ft4.run(ops, hk, h_ft[:, 2 * Cz * k: 2 * Cz * (k + 1)])
-            cond[level] = dict(pre_aff=pre_aff, h_ft=h_ft, slot={i: k for k, i in enumerate(hz["idxs"])}, C=Cz)
+        for level, hz in sorted(self.hoist.items()):
+            side = None
+            if use_side and level >= 2:
+                if self._side_stream is None:
+                    self._side_stream = torch.cuda.Stream(device=ops.device)
+                side = self._side_stream
+                side.wait_stream(main_stream)
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                cond[level] = self._hoist_level(level, hz, ft, B)
+                if side is not None:
+                    cond[level]["ready"] = side.record_event()
         self._cond_key, self._cond = key, cond
         return cond
+
+    def _await(self, cnd):
+        """Join the side stream that produced this level's hoisted tensors (once per consumer stream)."""
+        ev = cnd.get("ready")
+        if ev is not None:
+            torch.cuda.current_stream(self.ops.device).wait_event(ev)
+            cnd["ready"] = None
+        return cnd
+
+    def _hoist_level(self, level, hz, ft, B):
+        ops, ws = self.ops, self.ws
+        K = len(hz["idxs"])
+        f = ft[level]
+        hl, wl = f.shape[2], f.shape[3]
+        Cz = [ly.C for ly in self.layers if ly.index == hz["idxs"][0]][0]
+        hid = ws.get("hoist_hid%d" % level, B, K * 64, hl, wl)
+        pre_aff = ws.get("pre_aff%d" % level, B, K * 64, hl, wl)
+        h_ft = ws.get("h_ft%d" % level, B, K * 2 * Cz, hl, wl)
+        if hz["up2"]:
+            taps = ft[self._lr_level()][:, 64:]
+            if hz["x3"]:
+                up = ops.conv_up4_x3 if hz["up"] == 2 else ops.conv_up2_x3
+                ops.conv_x3(f, hz["ft0_key"], hid)
+                up(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, pre_add=hid)
+                ops.conv_x3(f, hz["aff0_key"], pre_aff)
+                up(taps, hz["aff0_taps"], pre_aff, pre_add=pre_aff)
+            else:
+                ops.conv_up2(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, key=(f, hz["ft0_key"]))
+                ops.conv_up2(taps, hz["aff0_taps"], pre_aff, key=(f, hz["aff0_key"]))
+        else:
+            hz["ft0"].run(ops, f, hid, act=ACT_RELU)
+            hz["aff0"].run(ops, f, pre_aff)
+        for k, i in enumerate(hz["idxs"]):
+            st = self.steps[i]
+            hk = hid[:, 64 * k: 64 * (k + 1)]
+            st.ft2.run(ops, hk, hk, act=ACT_RELU)            # 1x1, in place (disjoint pixel tiles)
+            st.ft4.run(ops, hk, h_ft[:, 2 * Cz * k: 2 * Cz * (k + 1)])
+        return dict(pre_aff=pre_aff, h_ft=h_ft, slot={i: k for k, i in enumerate(hz["idxs"])}, C=Cz)
 
     # ------------------------------------------------------------------------------------------
     def _self_cond(self, st, z, cnd, k, tag):
@@ -374,7 +404,7 @@ class SRFlowEngine(object):
             elif ly.type == "step":
                 st = self.steps[ly.index]
                 if ly.coupled:
-                    cnd = cond[ly.level]
+                    cnd = self._await(cond[ly.level])
                     k = cnd["slot"][ly.index]
                     ops.flow_pointwise(z, z, False, h_aff=pending, an_bias=st.an_bias, an_escale=st.an_exp,
                                        w=st.w_fwd, wt=st.w_fwd_t, h_ft=cnd["h_ft"][:, 2 * ly.C * k: 2 * ly.C * (k + 1)])
@@ -428,7 +458,7 @@ class SRFlowEngine(object):
             if ly.type == "step":
                 st = self.steps[ly.index]
                 if ly.coupled:
-                    cnd = cond[ly.level]
+                    cnd = self._await(cond[ly.level])
                     k = cnd["slot"][ly.index]
                     h_aff = self._self_cond(st, z, cnd, k, "dec%d" % ly.level)
                     if logdet is not None:

@@ -265,8 +265,9 @@ class SRFlowEngine(object):
         """spatial size of flow level `level` for an LR of h x w: HR / 2^level."""
         return (h * self.scale) >> level, (w * self.scale) >> level
 
-    def conditioning(self, lr):
-        """RRDB features + hoisted ft-only coupling activations for an LR batch (cached per tensor)."""
+    def conditioning(self, lr, reverse=False):
+        """RRDB features + hoisted ft-only coupling activations for an LR batch (cached per tensor).
+        reverse: the caller walks the levels from L down to 1 (decode), which decides which level is needed first."""
         # the cache holds a reference to the keyed tensor, so its storage cannot be recycled for another input
         # while the entry is alive; a new tensor object or an in-place update (version bump) is a miss
         key = (lr, lr._version)
@@ -311,15 +312,17 @@ class SRFlowEngine(object):
             dst = key_view("fea_up0")       # bilinear 1/2, align_corners=False, recompute_scale_factor=True
             ops.resize(last, dst, MODE_BILINEAR, float(h) / dst.shape[2], float(w) / dst.shape[3])
 
-        # Levels >= 2 are not needed before the level-1 steps of encode() are through, and those steps (short kernels, matrix
-        # pipe ~40 % busy) leave room on the chip: their hoisted convs go to a side stream that forks here, after the level-1
-        # hoists have been enqueued, and joins at the first use of the level (`_await`).  BFSR_OVERLAP=0 disables it.
+        # Only the level the caller starts with is needed right away (level 1 for encode, level L for decode); its steps are
+        # short kernels with the matrix pipe ~40 % busy and leave room on the chip, so the hoisted convs of the other levels go
+        # to a side stream that forks after the first level's hoists have been enqueued and joins at the first use of a level
+        # (`_await`).  BFSR_OVERLAP=0 disables it.
         use_side = (getattr(getattr(ops, "device", None), "type", "cpu") == "cuda" and os.environ.get("BFSR_OVERLAP", "1") != "0")
         main_stream = torch.cuda.current_stream(ops.device) if use_side else None
         cond = {}
-        for level, hz in sorted(self.hoist.items()):
+        order = sorted(self.hoist.items(), reverse=bool(reverse))
+        for n, (level, hz) in enumerate(order):
             side = None
-            if use_side and level >= 2:
+            if use_side and n >= 1:
                 if self._side_stream is None:
                     self._side_stream = torch.cuda.Stream(device=ops.device)
                 side = self._side_stream
@@ -443,7 +446,7 @@ class SRFlowEngine(object):
         """reverse flow (FlowUpsamplerNet.decode :267-296): [eps_split..., z_final] -> sr [B,3,H,W].
         logdet: optional float64 [B] accumulator (every term of encode() enters with the opposite sign)."""
         ops, ws = self.ops, self.ws
-        cond = self.conditioning(lr)
+        cond = self.conditioning(lr, reverse=True)
         ld_const, ld_levels = 0.0, set()
         epses = list(epses) if epses is not None else None
         zin = epses.pop() if epses is not None else z

@@ -1,14 +1,15 @@
 #!/bin/bash
-# Build libbfsr_hip.so for gfx950 (cross-compiles without a GPU).  Usage: bfsr_amd/csrc/build.sh
+# Build libbfsr_hip.so for gfx950 (cross-compiles without a GPU).  Usage: bfsr_amd/csrc/build.sh [--clean]
 set -e
 cd "$(dirname "$0")"
 OUT=../lib
+if [ "$1" = "--clean" ]; then rm -rf build "$OUT"/libbfsr_hip.so; fi
 mkdir -p "$OUT" build
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off"
 pids=()
 for f in conv_mfma conv_f16 conv_bf16x3 conv1x1 flow_ops resample linf_ops metrics; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ ../../include/bfsr_hip.h -nt build/$f.o ]; then
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ ../../include/bfsr_hip.h -nt build/$f.o ] || [ launch_util.h -nt build/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)
   fi

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "../../include/bfsr_hip.h"
+#include "launch_util.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -168,12 +169,8 @@ int launch_1x1(const BfsrConvArgs& a, hipStream_t st)
 {
     constexpr int PL = Mode<X3>::PL, CK = Mode<X3>::CK;
     constexpr int LDS = PL * (CK / 8) * (MWG + NPX) * 8 * 2;
-    static bool attr_set = false;
-    if (!attr_set && LDS > 65536) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_kernel<X3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-            return -1;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_done{0};
+    if (LDS > 65536 && bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv1x1_kernel<X3>), LDS, lds_done) != 0) return -1;
     const long long P = (long long)a.H * a.W;
     const long long ptiles = (P + NPX - 1) / NPX;
     const int groups = (a.Cout + MWG - 1) / MWG;

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "../../include/bfsr_hip.h"
+#include "launch_util.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -224,12 +225,9 @@ int launch_x3(const BfsrConvArgs& a, hipStream_t st)
 {
     constexpr int TH = NW * NR, HALO = KS - 1;
     constexpr int LDS = 3 * (KS * KS * MR * 32 * CK + (TH + HALO) * (32 + HALO) * CK) * 2;
-    static bool attr_set = false;
-    if (!attr_set && LDS > 65536) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<KS, MR, NR, MINB, NW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_done{0};
+    if (LDS > 65536 && bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_bf16x3_kernel<KS, MR, NR, MINB, NW>), LDS, lds_done) != 0)
+        return -1;
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + TH - 1) / TH;
     const int groups = ((a.Cout + 31) / 32 + MR - 1) / MR;
     const long long nblk = (long long)tiles_x * tiles_y * groups * a.B;
@@ -424,12 +422,8 @@ int launch_up2_x3(const BfsrConvArgs& a, hipStream_t st)
 {
     constexpr int SR = NW * NR;
     constexpr int LDS = 3 * (8 * 32 * CK + (SR + 1) * 34 * CK) * 2;
-    static bool attr_set = false;
-    if (!attr_set && LDS > 65536) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up2_bf16x3_kernel<NW, NR>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_done{0};
+    if (LDS > 65536 && bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_up2_bf16x3_kernel<NW, NR>), LDS, lds_done) != 0) return -1;
     const int Hs = a.H / 2, Ws = a.W / 2;
     const int tiles_x = (Ws + 31) / 32, tiles_y = (Hs + SR - 1) / SR;
     const int groups = (a.Cout + 31) / 32;

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "../../include/bfsr_hip.h"
+#include "launch_util.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -319,12 +320,9 @@ int launch_conv(const BfsrConvArgs& a, hipStream_t st)
     const int groups = ((a.Cout + 31) / 32 + MR - 1) / MR;
     const long long nblk = (long long)tiles_x * tiles_y * groups * a.B;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return -1;
-    static bool attr_set = false;
-    if (!attr_set && LDS > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<KS, MR, NR, CK, FUSE2>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_done{0};
+    if (LDS > 48 * 1024 && bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_mfma_kernel<KS, MR, NR, CK, FUSE2>), LDS, lds_done) != 0)
+        return -1;
     hipLaunchKernelGGL((conv_mfma_kernel<KS, MR, NR, CK, FUSE2>), dim3((unsigned)nblk), dim3(256), LDS, st, a, tiles_x,
                        tiles_x * tiles_y, groups);
     return (int)hipGetLastError();
@@ -577,11 +575,8 @@ int launch_conv_up2(const BfsrConvArgs& a, hipStream_t st)
     const int groups = ((a.Cout + 31) / 32 + MR - 1) / MR;
     const long long nblk = (long long)tiles_x * tiles_y * groups * a.B;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return -1;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_up2_kernel<MR>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_done{0};
+    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_up2_kernel<MR>), LDS, lds_done) != 0) return -1;
     hipLaunchKernelGGL((conv_up2_kernel<MR>), dim3((unsigned)nblk), dim3(256), LDS, st, a, tiles_x, tiles_x * tiles_y, groups);
     return (int)hipGetLastError();
 }

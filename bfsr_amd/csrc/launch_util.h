@@ -1,0 +1,32 @@
+// launch_util.h -- host-side helpers shared by the launchers, and the XCD-aware workgroup order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <atomic>
+
+namespace bfsr {
+
+// Raise a kernel's dynamic-LDS limit once per DEVICE (hipFuncSetAttribute is per device).  `done` is a per-kernel bit mask of
+// devices already configured: an idempotent cache, safe under concurrent callers (a racing second call repeats the same
+// attribute write), so the library stays re-entrant across host threads, streams and devices.
+inline int ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<unsigned long long>& done)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return 0;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return -1;
+    done.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
+
+// XCD-aware workgroup order (MI355X: block b runs on XCD b % 8, each XCD has a private L2): returns the logical work index of
+// hardware block `bid` such that every XCD walks one CONTIGUOUS range of logical indices -- neighbouring tiles (shared halo
+// rows, the cout groups of one input tile) then hit the same L2.  Bijective for any grid size.
+__device__ __forceinline__ unsigned xcd_order(unsigned bid, unsigned nblk)
+{
+    const unsigned xcd = bid & 7u, slot = bid >> 3;
+    const unsigned q = nblk >> 3, r = nblk & 7u;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+}  // namespace bfsr

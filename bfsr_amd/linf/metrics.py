@@ -80,6 +80,8 @@ def ssim(ops, img1, img2):
     return (s / float((H - 10) * (W - 10))).mean(dim=1)          # [B]
 
 
-def lr_consistency_psnr(ops, pred01, inp01, scale):
-    """LR-consistency (test.py:183-187,197-200): PSNR between imresize(pred, 1/scale) and the LR input."""
-    return psnr(ops, imresize(ops, pred01, 1.0 / scale), inp01)
+def lr_consistency_psnr(ops, pred01, inp01, scale, dataset=None):
+    """LR-consistency (test.py:183-187,197-200): `psnr_fn(imresize(pred, 1/scale), batch['inp'])` -- `psnr_fn` is the SAME
+    partial the HR PSNR uses (test.py:66-75), so with an eval_type it shaves `scale` border pixels of the LR image and, for
+    'benchmark', compares luma."""
+    return psnr(ops, imresize(ops, pred01, 1.0 / scale), inp01, dataset=dataset, scale=scale if dataset is not None else 1)

@@ -137,7 +137,8 @@ def eval_psnr(loader, model, prior_model=None, eval_type=None, patch=True, tempe
             sc = int(eval_type.split('-')[1]) if eval_type else round(H / batch['inp'].shape[-2])
             inp01 = ops.to_device(batch['inp'])
             tot_ssim += sum(float(metrics.ssim(ops, p, gt).mean()) for p in preds) / len(preds) * bsz
-            tot_lr += sum(metrics.lr_consistency_psnr(ops, p, inp01, sc) for p in preds) / len(preds) * bsz
+            kind = eval_type.split('-')[0] if eval_type else None
+            tot_lr += sum(metrics.lr_consistency_psnr(ops, p, inp01, sc, dataset=kind) for p in preds) / len(preds) * bsz
         n += bsz
     res = {'psnr': tot / max(n, 1)}
     if detail:

@@ -274,6 +274,10 @@ class SRFlowEngine(object):
         if self._cond_key is not None and self._cond_key[0] is lr and self._cond_key[1] == lr._version:
             return self._cond
         ops, ws = self.ops, self.ws
+        if self._side_stream is not None:
+            # hoists of the previous conditioning may still be in flight on the side stream (e.g. a level that was never
+            # consumed after an exception): they write the workspaces this call is about to rewrite
+            torch.cuda.current_stream(ops.device).wait_stream(self._side_stream)
         B, _, h, w = lr.shape
         if (h * self.scale) % (1 << self.L) or (w * self.scale) % (1 << self.L):
             raise ValueError("HR size must be divisible by 2^L (LR %dx%d, scale %d, L %d)" % (h, w, self.scale, self.L))
@@ -320,6 +324,8 @@ class SRFlowEngine(object):
         main_stream = torch.cuda.current_stream(ops.device) if use_side else None
         cond = {}
         order = sorted(self.hoist.items(), reverse=bool(reverse))
+        for level, hz in order:
+            self._hoist_buffers(level, hz, ft, B)       # allocate on the main stream (see _hoist_buffers)
         for n, (level, hz) in enumerate(order):
             side = None
             if use_side and n >= 1:
@@ -330,27 +336,36 @@ class SRFlowEngine(object):
             with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
                 cond[level] = self._hoist_level(level, hz, ft, B)
                 if side is not None:
-                    cond[level]["ready"] = side.record_event()
+                    cond[level]["ready"], cond[level]["joined"] = side.record_event(), set()
         self._cond_key, self._cond = key, cond
         return cond
 
     def _await(self, cnd):
-        """Join the side stream that produced this level's hoisted tensors (once per consumer stream)."""
+        """Join the side stream that produced this level's hoisted tensors.  Idempotent per CONSUMER stream: the event is kept
+        (the conditioning is cached across encode/decode and may be consumed from another torch stream later), and a stream
+        that has already waited is remembered so the wait is enqueued once per stream."""
         ev = cnd.get("ready")
         if ev is not None:
-            torch.cuda.current_stream(self.ops.device).wait_event(ev)
-            cnd["ready"] = None
+            st = torch.cuda.current_stream(self.ops.device)
+            if st.cuda_stream not in cnd["joined"]:
+                st.wait_event(ev)
+                cnd["joined"].add(st.cuda_stream)
         return cnd
 
-    def _hoist_level(self, level, hz, ft, B):
-        ops, ws = self.ops, self.ws
+    def _hoist_buffers(self, level, hz, ft, B):
+        """The workspace tensors of a level's hoists (allocated on the CALLER's stream: buffers that are later filled on the
+        side stream must not be owned by it, or the caching allocator could recycle them without a join)."""
+        ws = self.ws
         K = len(hz["idxs"])
-        f = ft[level]
-        hl, wl = f.shape[2], f.shape[3]
+        hl, wl = ft[level].shape[2], ft[level].shape[3]
         Cz = [ly.C for ly in self.layers if ly.index == hz["idxs"][0]][0]
-        hid = ws.get("hoist_hid%d" % level, B, K * 64, hl, wl)
-        pre_aff = ws.get("pre_aff%d" % level, B, K * 64, hl, wl)
-        h_ft = ws.get("h_ft%d" % level, B, K * 2 * Cz, hl, wl)
+        return (ws.get("hoist_hid%d" % level, B, K * 64, hl, wl), ws.get("pre_aff%d" % level, B, K * 64, hl, wl),
+                ws.get("h_ft%d" % level, B, K * 2 * Cz, hl, wl), Cz)
+
+    def _hoist_level(self, level, hz, ft, B):
+        ops = self.ops
+        f = ft[level]
+        hid, pre_aff, h_ft, Cz = self._hoist_buffers(level, hz, ft, B)
         if hz["up2"]:
             taps = ft[self._lr_level()][:, 64:]
             if hz["x3"]:

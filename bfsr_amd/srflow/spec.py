@@ -43,9 +43,44 @@ class LayerSpec(object):
             self.index, self.type, self.C, self.level, self.coupled)
 
 
+POINTWISE_CHANNELS = (3, 6, 12, 24, 48, 96)     # channel counts bfsr_flow_pointwise is instantiated for (flow_ops.hip)
+
+
+def check_supported(opt):
+    """Fail at construction time on every reference option that changes the maths and that this engine does not implement
+    (the reference would build a different network; silently ignoring the key would produce wrong images)."""
+    g = lambda *k, default=None: opt_get(opt, ["network_G", "flow"] + list(k), default)
+    if g("coupling") != "CondAffineSeparatedAndCond":
+        raise NotImplementedError("only flow.coupling=CondAffineSeparatedAndCond is on the hot path (FlowStep.py:77-83)")
+    bad = []
+    if g("split", "conditional"):
+        bad.append("split.conditional (Split2d conv conditioned on ft, FlowUpsamplerNet.py:156)")
+    if g("split", "cond_channels"):
+        bad.append("split.cond_channels (FlowUpsamplerNet.py:157)")
+    if g("split", "logs_eps"):
+        bad.append("split.logs_eps (exp(logs)+logs_eps, Split.py:46)")
+    if g("split", "type", default="Split2d") != "Split2d":
+        bad.append("split.type != Split2d (FlowUpsamplerNet.py:160)")
+    if g("levelConditional", "conditional") is True or g("levelConditional", "n_channels"):
+        bad.append("levelConditional (FlowUpsamplerNet.py:83,274)")
+    if g("condAff") or g("condFtAffine"):
+        bad.append("condAff / condFtAffine (FlowUpsamplerNet.py:144-147)")
+    if g("norm"):
+        bad.append("norm (FlowUpsamplerNet.py:79)")
+    if g("CondAffineSeparatedAndCond", "hidden_channels") not in (None, HIDDEN):
+        bad.append("CondAffineSeparatedAndCond.hidden_channels != 64 (FlowAffineCouplingsAblation.py:34-35)")
+    if g("CondAffineSeparatedAndCond", "eps", default=1e-4) != 1e-4:
+        bad.append("CondAffineSeparatedAndCond.eps != 1e-4 (FlowAffineCouplingsAblation.py:37)")
+    if g("fea_up-1"):
+        bad.append("fea_up-1 (RRDBNet_arch.py:139)")
+    if bad:
+        raise NotImplementedError("reference options outside the accelerated path: " + "; ".join(bad))
+
+
 def flow_layers(opt):
     """The `FlowUpsamplerNet.layers` list as LayerSpec objects; `level` is the level the
     reference derives from the construction-time size (log2(160/size), :230,:280)."""
+    check_supported(opt)
     flow = opt["network_G"]["flow"]
     L = flow["L"]
     K = flow["K"]
@@ -54,8 +89,6 @@ def flow_layers(opt):
     split_on = bool(opt_get(opt, ["network_G", "flow", "split", "enable"]))
     correction = 0 if opt_get(opt, ["network_G", "flow", "split", "correct_splits"], False) else 1
     ratio = opt_get(opt, ["network_G", "flow", "split", "consume_ratio"]) or 0.5
-    if opt_get(opt, ["network_G", "flow", "coupling"]) != "CondAffineSeparatedAndCond":
-        raise NotImplementedError("only flow.coupling=CondAffineSeparatedAndCond is on the hot path")
     C = 3
     out = []
     for level in range(1, L + 1):
@@ -69,6 +102,10 @@ def flow_layers(opt):
             consume = int(round(C * ratio))
             out.append(LayerSpec(len(out), "split", C, level, C_pass=C - consume, C_consume=consume))
             C -= consume
+    for ly in out:
+        if ly.type == "step" and ly.C not in POINTWISE_CHANNELS:
+            raise NotImplementedError("FlowStep with C=%d channels (L=%d): bfsr_flow_pointwise supports C in %s" %
+                                      (ly.C, L, POINTWISE_CHANNELS))
     return out
 
 

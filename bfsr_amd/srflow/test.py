@@ -16,25 +16,42 @@ from .options import load as load_opt, opt_get
 from ..ops import MODE_BILINEAR
 
 
-def load_model(conf_path, ops=None):
-    """test.py:41-49: parse conf, build the model, load `model_path` into netG."""
+def load_model(conf_path, ops=None, allow_uninitialised=False):
+    """test.py:41-49: parse conf, build the model, load `model_path` into netG.  Like the reference (which calls
+    `load_network` unconditionally) a missing checkpoint is an error, not a silent run on default-initialised weights;
+    `allow_uninitialised=True` is the explicit opt-out for callers that load a state_dict themselves."""
     opt = load_opt(conf_path)
     model = create_model(opt, ops=ops)
     model_path = opt_get(opt, ['model_path'], None)
-    if model_path and os.path.exists(model_path):
+    if model_path is None:
+        if not allow_uninitialised:
+            raise FileNotFoundError("%s: `model_path` is not set" % conf_path)
+    elif not os.path.exists(model_path):
+        raise FileNotFoundError("%s: model_path %r does not exist" % (conf_path, model_path))
+    else:
         model.load_network(load_path=model_path, network=model.netG)
     return model, opt
 
 
 def load_prior(opt, ops=None):
     """test.py:90-91: `models.make(torch.load(prior_model_path)['prior_model'], load_sd=True)`."""
-    spec = torch.load(opt['prior_model_path'], map_location='cpu')['prior_model']
+    path = opt_get(opt, ['prior_model_path'], None)
+    if not path or not os.path.exists(path):
+        raise FileNotFoundError("prior_model_path %r does not exist" % (path,))
+    spec = torch.load(path, map_location='cpu')['prior_model']
     args = dict(spec['args'])
     if ops is not None:
         args['ops'] = ops
     prior = registry.make({'name': spec['name'], 'args': args, 'sd': spec['sd']}, load_sd=True)
     prior.eval()
     return prior
+
+
+def natsorted(paths):
+    """Natural (numeric-aware) ordering like `natsort.natsorted` (test.py:37-38): 2.png sorts before 10.png, so the output
+    index `{idx:06d}.png` maps to the same input as upstream."""
+    import re
+    return sorted(paths, key=lambda p: [int(t) if t.isdigit() else t.lower() for t in re.split(r'(\d+)', p)])
 
 
 def pad_lr_to_even(lr):
@@ -81,7 +98,7 @@ def main(argv=None):
     model, opt = load_model(argv[0])
     prior = load_prior(opt)
     scale = opt['scale']
-    lr_paths = sorted(glob.glob(os.path.join(opt['dataroot_LR'], '*.png')))
+    lr_paths = natsorted(glob.glob(os.path.join(opt['dataroot_LR'], '*.png')))     # test.py:37-38 uses natsort
     out_dir = os.path.join(os.path.dirname(os.path.abspath(argv[0])), '..', 'results', 'SRFlow-LP')
     os.makedirs(out_dir, exist_ok=True)
     for idx, p in enumerate(lr_paths):

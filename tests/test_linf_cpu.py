@@ -118,6 +118,11 @@ def test_cfg1_eval_psnr_scalar(golden_dir):
     pred = g["pred"][0].transpose(1, 2, 0).astype(np.float64)
     assert abs(d["ssim"] - MO.calculate_ssim(pred * 255.0, hr[0].permute(1, 2, 0).numpy().astype(np.float64) * 255.0)) <= 1e-4
     lr_rec = MO.imresize(g["pred"][0].transpose(1, 2, 0), 0.25).transpose(2, 0, 1)[None]
+    # the reference's psnr_fn carries dataset and scale into the LR-consistency PSNR too (LINF-LP/test.py:66-75,186,199)
+    assert abs(d["LR recon"] - MO.calc_psnr(lr_rec.astype(np.float32), lr.numpy(), dataset="div2k", scale=4)) <= 1e-2
+    d = eval_psnr([batch], m, prior, eval_type="benchmark-4", detail=True)
+    assert abs(d["LR recon"] - MO.calc_psnr(lr_rec.astype(np.float32), lr.numpy(), dataset="benchmark", scale=4)) <= 1e-2
+    d = eval_psnr([batch], m, prior, eval_type=None, detail=True)
     assert abs(d["LR recon"] - MO.calc_psnr(lr_rec.astype(np.float32), lr.numpy())) <= 1e-2
 
 

@@ -30,6 +30,19 @@ class BfsrConvArgs(C.Structure):
     ]
 
 
+class BfsrConvX3Args(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("x_bs", C.c_longlong), ("Cin", C.c_int),
+        ("w", C.c_void_p),
+        ("y", C.c_void_p), ("y_bs", C.c_longlong), ("Cout", C.c_int), ("y_fmt", C.c_int),
+        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("epi", C.c_void_p), ("act", C.c_int), ("slope", C.c_float),
+        ("res1", C.c_void_p), ("res1_bs", C.c_longlong), ("alpha1", C.c_float),
+        ("res2", C.c_void_p), ("res2_bs", C.c_longlong), ("alpha2", C.c_float),
+        ("tune", C.c_int),
+    ]
+
+
 class BfsrFlowArgs(C.Structure):
     _fields_ = [
         ("z_in", C.c_void_p), ("z_in_bs", C.c_longlong),
@@ -79,6 +92,9 @@ SYMBOLS = {
     "bfsr_conv2d_bf16x3": (_I, [C.POINTER(BfsrConvArgs), _VP]),
     "bfsr_conv_packed_size_bf16x3": (_LL, [_I, _I, _I, _I]),
     "bfsr_pack_conv_weight_bf16x3": (_I, [_VP, _I, _I, _I, _I, _VP]),
+    "bfsr_conv3x3_x3s": (_I, [C.POINTER(BfsrConvX3Args), _VP]),
+    "bfsr_x3_pack": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
+    "bfsr_x3_unpack": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
     "bfsr_conv1x1": (_I, [C.POINTER(BfsrConvArgs), _I, _VP]),
     "bfsr_conv1x1_packed_size": (_LL, [_I, _I, _I]),
     "bfsr_pack_conv1x1_weight": (_I, [_VP, _I, _I, _I, _VP]),

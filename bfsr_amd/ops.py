@@ -330,6 +330,66 @@ class HipOps(object):
         _lib.check(self._launch(key, lambda: self.lib.bfsr_conv2d_up2_bf16x3(C.byref(a), self._stream())), "conv2d_up2_bf16x3")
         return out
 
+    # ---- x3 tensors (activations stored as the exact 3-term bf16 split) + the LDS-DMA conv over them (conv_x3s.hip) ----------
+    def x3_empty(self, B, Cc, H, W):
+        """[B, C/8, 3, H, W, 8] bf16: x = h + m + l exactly; channel slices `t[:, a//8:b//8]` are views."""
+        if Cc % 8:
+            raise ValueError("x3 tensors need a multiple of 8 channels")
+        return torch.empty(B, Cc // 8, 3, H, W, 8, dtype=torch.bfloat16, device=self.device)
+
+    @staticmethod
+    def _x3view(t, name="x3"):
+        """(ptr, batch stride in bf16 elements, C, H, W) of an x3 view."""
+        if t.dtype != torch.bfloat16 or t.dim() != 6 or t.shape[2] != 3 or t.shape[5] != 8:
+            raise ValueError("%s: need a [B,C/8,3,H,W,8] bfloat16 tensor" % name)
+        B, C8, _, H, W, _ = t.shape
+        st = t.stride()
+        if not (st[5] == 1 and st[4] == 8 and st[3] == 8 * W and st[2] == 8 * W * H and (C8 == 1 or st[1] == 24 * W * H)):
+            raise ValueError("%s: not an x3 view (shape %s stride %s)" % (name, tuple(t.shape), st))
+        return t.data_ptr(), (st[0] if B > 1 else C8 * 24 * H * W), C8 * 8, H, W
+
+    def x3_pack(self, x, out):
+        xp, xbs, Cc, H, W = _view(x, "x3_pack.x")
+        yp, ybs, c2, h2, w2 = self._x3view(out, "x3_pack.out")
+        assert (Cc, H, W) == (c2, h2, w2) and x.shape[0] == out.shape[0]
+        _lib.check(self._launch(("x3_pack",) + tuple(x.shape), lambda: self.lib.bfsr_x3_pack(xp, xbs, yp, ybs, x.shape[0], Cc, H, W, self._stream())), "x3_pack")
+        return out
+
+    def x3_unpack(self, x, out):
+        xp, xbs, Cc, H, W = self._x3view(x, "x3_unpack.x")
+        yp, ybs, c2, h2, w2 = _view(out, "x3_unpack.out")
+        assert (Cc, H, W) == (c2, h2, w2) and x.shape[0] == out.shape[0]
+        _lib.check(self._launch(("x3_unpack",) + tuple(out.shape), lambda: self.lib.bfsr_x3_unpack(xp, xbs, yp, ybs, x.shape[0], Cc, H, W, self._stream())), "x3_unpack")
+        return out
+
+    def conv_x3s(self, x, pw, out, epi=None, act=ACT_NONE, slope=0.2, res1=None, alpha1=1.0, res2=None, alpha2=1.0, tune=0):
+        """3x3 conv over an x3 tensor `x` (weights: pack_conv_x3(w, 1)); `out` is an x3 view or an fp32 NCHW view; residuals
+        are x3 views.  Same epilogue contract as conv()."""
+        a = _lib.BfsrConvX3Args()
+        a.x, a.x_bs, Cin, H, W = self._x3view(x, "conv_x3s.x")
+        if out.dtype == torch.bfloat16:
+            a.y, a.y_bs, Cout, H2, W2 = self._x3view(out, "conv_x3s.out")
+            a.y_fmt = 1
+        else:
+            a.y, a.y_bs, Cout, H2, W2 = _view(out, "conv_x3s.out")
+            a.y_fmt = 0
+        if (Cin, Cout, H, W) != (pw.Cin, pw.Cout, H2, W2) or pw.KS != 3 or x.shape[0] != out.shape[0]:
+            raise ValueError("conv_x3s: shape mismatch x%s out%s weight(Cout=%d,Cin=%d)" % (tuple(x.shape), tuple(out.shape), pw.Cout, pw.Cin))
+        a.Cin, a.Cout = Cin, Cout
+        a.w = pw.variant(1, lambda w_, m_: self._pack_raw_16(w_, m_, "bf16x3")).data_ptr()
+        a.B, a.H, a.W = out.shape[0], H, W
+        a.epi, a.act, a.slope, a.tune = _ptr(epi), act, slope, tune
+        for name, t, al in (("res1", res1, alpha1), ("res2", res2, alpha2)):
+            if t is not None:
+                pp, bs, c, hh, ww = self._x3view(t, "conv_x3s." + name)
+                assert (c, hh, ww) == (Cout, H, W)
+                setattr(a, name, pp)
+                setattr(a, name + "_bs", bs)
+                setattr(a, "alpha" + name[-1], al)
+        key = ("conv_x3s", Cin, Cout, out.shape[0], H, W, a.y_fmt)
+        _lib.check(self._launch(key, lambda: self.lib.bfsr_conv3x3_x3s(C.byref(a), self._stream())), "conv3x3_x3s")
+        return out
+
     def vec(self, t):
         """A per-channel parameter vector on the device."""
         return t.detach().reshape(-1).to(device=self.device, dtype=torch.float32).contiguous()

@@ -74,28 +74,38 @@ class _Workspace(object):
 
 class RRDBEncoder(object):
     """RRDBNet trunk (RRDBNet_arch.py:67-148 / LINF-LP/models/rrdb.py:77-116): conv_first, nb x RRDB
-    (3 x RDB of five 3x3 convs), trunk_conv + skip.  `taps` = RRDB indices whose output is wanted."""
+    (3 x RDB of five 3x3 convs), trunk_conv + skip.  `taps` = RRDB indices whose output is wanted.
+
+    Default path (3xBF16 contraction): the dense blocks live in HBM as x3 tensors (exact 3-term bf16 split, ops.x3_empty) and
+    every RDB conv runs on conv_x3s (LDS-DMA staging by dedicated loader waves, conv_x3s.hip); conv_first's output is packed
+    once, tapped block outputs and the trunk output are unpacked / written as fp32.  `BFSR_RRDB=fp32` (or a backend without
+    conv_x3s, or precision='fp16') keeps fp32 NCHW block buffers and the register-staged kernels."""
 
     def __init__(self, ops, sd, prefix, nb, nf=64, gc=32, skip_from_first=False, f16=False):
         # skip_from_first: LINF's RRDBNet adds the conv_first output (`fea = fea + trunk`, LINF-LP/models/rrdb.py:105-107)
         # whereas SRFlow's adds the trunk output (`last_lr_fea = fea + trunk` after the loop rebinds `fea`,
         # RRDBNet_arch.py:92-103)
         self.ops, self.nb, self.nf, self.gc, self.skip_from_first = ops, nb, nf, gc, skip_from_first
+        self.x3s = (not f16 and getattr(ops, "conv_mode", "f32") == "x3" and hasattr(ops, "conv_x3s") and nf % 16 == 0 and gc % 16 == 0
+                    and os.environ.get("BFSR_RRDB", "x3") != "fp32")
         g = lambda n: sd[prefix + n]
+        mk = (lambda w, b: _ConvX3S(ops, w, b)) if self.x3s else (lambda w, b: _ConvP(ops, w, b, f16=f16))
         self.conv_first = _ConvP(ops, g("conv_first.weight"), g("conv_first.bias"), f16=f16)
         self.blocks = []
         for b in range(nb):
             rdbs = []
             for r in (1, 2, 3):
                 p = "RRDB_trunk.%d.RDB%d." % (b, r)
-                rdbs.append([_ConvP(ops, g(p + "conv%d.weight" % i), g(p + "conv%d.bias" % i), f16=f16) for i in range(1, 6)])
+                rdbs.append([mk(g(p + "conv%d.weight" % i), g(p + "conv%d.bias" % i)) for i in range(1, 6)])
             self.blocks.append(rdbs)
-        self.trunk_conv = _ConvP(ops, g("trunk_conv.weight"), g("trunk_conv.bias"), f16=f16)
+        self.trunk_conv = mk(g("trunk_conv.weight"), g("trunk_conv.bias"))
         self.ws = _Workspace(ops)
 
-    def forward(self, x, out, on_block=None):
-        """x [B,3,h,w] -> out (a [B,nf,h,w] view) = fea + trunk_conv(fea).  `on_block(idx, fea_view)` is
-        called after RRDB idx with a view that is only valid during the call."""
+    def forward(self, x, out, on_block=None, taps=None):
+        """x [B,3,h,w] -> out (a [B,nf,h,w] view) = fea + trunk_conv(fea).  `on_block(idx, fea_view)` is called after RRDB idx
+        (only for idx in `taps` when given) with an fp32 view that is only valid during the call."""
+        if self.x3s:
+            return self._forward_x3(x, out, on_block, taps)
         ops, nf, gc = self.ops, self.nf, self.gc
         B, _, h, w = x.shape
         ring = [self.ws.get("dense%d" % i, B, nf + 4 * gc, h, w) for i in range(4)]
@@ -117,11 +127,56 @@ class RRDBEncoder(object):
                 else:                       # (x5*0.2 + x)*0.2 + x_rrdb
                     convs[4].run(ops, D, ring[nxt][:, :nf], res1=D[:, :nf], alpha1=0.2, res2=x_rrdb, alpha2=0.2)
                 cur = nxt
-            if on_block is not None:
+            if on_block is not None and (taps is None or idx in taps):
                 on_block(idx, ring[cur][:, :nf])
         fea = ring[cur][:, :nf]
         self.trunk_conv.run(ops, fea, out, res1=first if first is not None else fea, alpha1=1.0)   # skip + trunk
         return out
+
+    def _forward_x3(self, x, out, on_block, taps):
+        ops, nf, gc = self.ops, self.nf, self.gc
+        B, _, h, w = x.shape
+        o = lambda c: c // 8                                           # channel -> octet index of an x3 tensor
+        key = (B, h, w)
+        if getattr(self, "_x3key", None) != key:                       # x3 block buffers (not fp32: kept outside _Workspace)
+            self._x3key = key
+            self._ring = [ops.x3_empty(B, nf + 4 * gc, h, w) for _ in range(4)]
+            self._first = ops.x3_empty(B, nf, h, w) if self.skip_from_first else None
+        ring = self._ring
+        tmp = self.ws.get("x3_io", B, nf, h, w)                        # fp32 staging at the two ends of the x3 region
+        cur = 0
+        self.conv_first.run(ops, x, tmp)
+        ops.x3_pack(tmp, ring[cur][:, :o(nf)])
+        if self.skip_from_first:
+            ops.x3_pack(tmp, self._first)
+        for idx, rdbs in enumerate(self.blocks):
+            x_rrdb = ring[cur][:, :o(nf)]
+            for r, convs in enumerate(rdbs):
+                D = ring[cur]
+                for i in range(4):
+                    convs[i].run(ops, D[:, :o(nf + i * gc)], D[:, o(nf + i * gc): o(nf + (i + 1) * gc)], act=ACT_LRELU, slope=0.2)
+                nxt = (cur + 1) % 4
+                if r < 2:
+                    convs[4].run(ops, D, ring[nxt][:, :o(nf)], res1=D[:, :o(nf)], alpha1=0.2)
+                else:
+                    convs[4].run(ops, D, ring[nxt][:, :o(nf)], res1=D[:, :o(nf)], alpha1=0.2, res2=x_rrdb, alpha2=0.2)
+                cur = nxt
+            if on_block is not None and (taps is None or idx in taps):
+                on_block(idx, ops.x3_unpack(ring[cur][:, :o(nf)], tmp))
+        fea = ring[cur][:, :o(nf)]
+        self.trunk_conv.run(ops, fea, out, res1=self._first if self.skip_from_first else fea, alpha1=1.0)
+        return out
+
+
+class _ConvX3S(object):
+    """A 3x3 conv over x3 tensors (ops.conv_x3s): 3xBF16 weights packed for 32-cout workgroup tiles + bias epilogue."""
+
+    def __init__(self, ops, w, bias=None):
+        self.pw = ops.pack_conv_x3(w, 1)
+        self.epi = ops.pack_epilogue(self.pw.Cout, bias)
+
+    def run(self, ops, x, out, **kw):
+        return ops.conv_x3s(x, self.pw, out, epi=self.epi, **kw)
 
 
 class _CouplingStep(object):
@@ -305,7 +360,7 @@ class SRFlowEngine(object):
                     ops.resize(fea, dst, MODE_NEAREST, float(h) / dst.shape[2], float(w) / dst.shape[3])
 
         last = key_view("fea_up1")
-        self.rrdb.forward(lr, last, on_block)
+        self.rrdb.forward(lr, last, on_block, taps=set(self.block_idxs) if self.concat else set())
         prev = last
         for name in ("fea_up2", "fea_up4", "fea_up8"):       # lrelu is in-place in the reference => stored post-act
             if name in self.upconvs:

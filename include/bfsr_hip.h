@@ -123,6 +123,34 @@ int bfsr_conv1x1(const BfsrConvArgs* a, int x3, void* stream);
 long long bfsr_conv1x1_packed_size(int Cout, int Cin, int x3);
 int bfsr_pack_conv1x1_weight(const float* w_oi, int Cout, int Cin, int x3, unsigned short* packed);
 
+/* ---- x3 tensors: activations stored as the exact 3-term bf16 split -----------------------------------------------------
+ * Layout [B][C/8][3 planes h,m,l][H][W][8] bf16 with x = h + m + l exactly (round-to-nearest at each level, 8+8+8 significant
+ * bits: a lossless 48-bit encoding of an fp32 value).  A view = (pointer, batch stride in bf16 elements, C); channel slices at
+ * multiples of 8 are views.  bfsr_x3_pack / bfsr_x3_unpack convert from / to an fp32 NCHW view.
+ *
+ * bfsr_conv3x3_x3s: the 3x3 'same' conv of bfsr_conv2d_bf16x3 (same six-product arithmetic, same packed weights with mtile=1)
+ * for inputs that are x3 tensors: tiles are staged by LDS-DMA straight from HBM (no split at staging time), the LDS stage is
+ * double-buffered and the workgroups are persistent (one per CU).  Used for the dense blocks of the RRDB encoder
+ * (SRFlow-LP/code/models/modules/RRDBNet_arch.py:25-65, LINF-LP/models/rrdb.py:38-76): conv1..4 write their 32-channel slice of
+ * the block buffer as x3, conv5 applies `x5*0.2 + x` (and `*0.2 + x_rrdb`) with x3 residuals.
+ * epilogue: v = acc + bias; v = (v + aff_shift)*aff_scale + aff_post; v = act(v); v *= post_scale;
+ *           v = alpha1*v + res1; v = alpha2*v + res2;   y_fmt 0: fp32 NCHW view (y_bs in floats), 1: x3 view (y_bs in bf16 elements).
+ * Cin must be a multiple of 16; Cout a multiple of 8 when the output or a residual is x3.  tune > 0 overrides the number of
+ * persistent workgroups (default: one per CU). */
+typedef struct BfsrConvX3Args {
+    const unsigned short* x; long long x_bs; int Cin;
+    const unsigned short* w;                       /* bfsr_pack_conv_weight_bf16x3(KS=3, mtile=1) */
+    void* y; long long y_bs; int Cout; int y_fmt;
+    int B, H, W;
+    const float* epi; int act; float slope;        /* [Cout][8] packed per-channel parameters (see bfsr_conv2d), or NULL */
+    const unsigned short* res1; long long res1_bs; float alpha1;
+    const unsigned short* res2; long long res2_bs; float alpha2;
+    int tune;
+} BfsrConvX3Args;
+int bfsr_conv3x3_x3s(const BfsrConvX3Args* a, void* stream);
+int bfsr_x3_pack(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int C, int H, int W, void* stream);
+int bfsr_x3_unpack(const unsigned short* x, long long x_bs, float* y, long long y_bs, int B, int C, int H, int W, void* stream);
+
 /* ---- fused flow-step pointwise chain -----------------------------------------------------------
  * One read of z / h_aff / h_ft, one write of z (the HBM-roofline "coupling inverse" kernel of
  * BASELINE.json).  replaces, per FlowStep (SRFlow-LP/code/models/modules/):

@@ -60,6 +60,41 @@ class CpuOps(object):
     def conv_x3(self, x, pw, out, **kw):
         return self.conv(x, pw, out, **kw)
 
+    # ---- x3 tensors: [B, C/8, 3, H, W, 8] bf16, x = h + m + l exactly (HipOps.x3_empty)
+    def x3_empty(self, B, Cc, H, W):
+        assert Cc % 8 == 0
+        return torch.full((B, Cc // 8, 3, H, W, 8), float("nan"), dtype=torch.bfloat16)
+
+    @staticmethod
+    def _x3_to_f32(t):
+        B, C8, _, H, W, _ = t.shape
+        v = (t[:, :, 0].float() + t[:, :, 1].float()) + t[:, :, 2].float()          # [B, C8, H, W, 8]
+        return v.permute(0, 1, 4, 2, 3).reshape(B, C8 * 8, H, W)
+
+    def x3_pack(self, x, out):
+        B, Cc, H, W = x.shape
+        v = x.reshape(B, Cc // 8, 8, H, W).permute(0, 1, 3, 4, 2)
+        h = v.bfloat16()
+        r1 = v - h.float()
+        m = r1.bfloat16()
+        l = (r1 - m.float()).bfloat16()
+        out[:, :, 0], out[:, :, 1], out[:, :, 2] = h, m, l
+        assert torch.equal(self._x3_to_f32(out), x), "x3 split is not lossless"
+        return out
+
+    def x3_unpack(self, x, out):
+        out.copy_(self._x3_to_f32(x))
+        return out
+
+    def conv_x3s(self, x, pw, out, epi=None, act=0, slope=0.2, res1=None, alpha1=1.0, res2=None, alpha2=1.0, tune=0):
+        f = self._x3_to_f32
+        tmp = torch.empty(out.shape[0], pw.Cout, x.shape[3], x.shape[4]) if out.dtype == torch.bfloat16 else out
+        self.conv(f(x), pw, tmp, epi=epi, act=act, slope=slope, res1=None if res1 is None else f(res1), alpha1=alpha1,
+                  res2=None if res2 is None else f(res2), alpha2=alpha2)
+        if out.dtype == torch.bfloat16:
+            self.x3_pack(tmp, out)
+        return out
+
     def pack_conv1x1(self, w, x3=True):
         w = w.detach().to(torch.float32).reshape(w.shape[0], w.shape[1], 1, 1)
         return PackedConv((w if x3 else w.half().float()).contiguous().clone(), 8)

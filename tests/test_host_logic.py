@@ -86,6 +86,34 @@ def test_engine_schedule_on_cpu_double_vs_reference_golden(golden_dir, fx, scale
     assert (rt - out["lr_up"]).abs().max() <= 1e-4
 
 
+class CpuOpsX3(CpuOps):
+    """the test double in the product's default contraction mode: the engines then take the x3 paths (x3-tensor RRDB blocks on
+    conv_x3s, parity-decomposed hoists) -- on the double these are exact fp32 restatements, so the goldens still apply"""
+    conv_mode = "x3"
+
+
+@pytest.mark.parametrize("fx,scale", [("srflow_e2e_4x_b", 4), ("srflow_e2e_8x", 8)])
+def test_engine_schedule_x3_mode_on_cpu_double(golden_dir, fx, scale):
+    """Host logic of the default (x3) schedule: RRDB dense blocks as x3 tensors (pack after conv_first, octet-sliced views,
+    x3 residuals, unpack at the taps, fp32 trunk output) + conv_up2/up4 hoists, against the genuine reference's golden."""
+    from bfsr_amd.srflow.models import create_model, models as registry
+    from bfsr_amd.srflow.test import lp_infer
+    ops = CpuOpsX3()
+    opt = options.load(options.DEFAULT_CONF)
+    if scale == 8:
+        opt = options.derive_scale(opt, 8)
+    m = create_model(opt, ops=ops)
+    m.load_network(synth.state_dict_from_schema(spec.srflownet_schema(opt), 1234))
+    prior = registry.make({"name": "unet", "args": {"depth": 3, "dim": 64, "bilinear": True, "ops": ops},
+                           "sd": synth.state_dict_from_schema(spec.srflow_prior_schema(), 4321)}, load_sd=True).eval()
+    g = np.load(os.path.join(golden_dir, fx + ".npz"))
+    out = lp_infer(m, prior, T(g["lr"]), return_all=True)
+    assert m.netG.module.engine().rrdb.x3s
+    for i in (0, 1):
+        assert (out["epses"][i] - T(g["eps%d" % i])).abs().max() <= 5e-5
+    assert (out["sr"] - T(g["sr"])).abs().max() <= 1e-4
+
+
 def test_library_exports_every_declared_symbol():
     from bfsr_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "bfsr_hip.h")).read()

@@ -6,6 +6,8 @@
 `imnet.linears.{i}.{bias,_weight}`, `imnet.last.*`).  `query_log_p` returns the reference's pair (log_p per query point, z);
 the LP harness only uses z (LINF-LP/test.py:43)."""
 import torch
+
+from ... import rng
 from torch import nn
 
 from ... import paramtree
@@ -66,7 +68,7 @@ class LINFPatch(nn.Module):
         coord = d(coord)
         if zmap is None:     # tau path (linf.py:398): z ~ N(0,1) * temperature, sampled on device (plumbing)
             B, qh, qw, _ = coord.shape
-            zmap = torch.randn(B, e.D, qh, qw, device=coord.device) * temperature
+            zmap = rng.randn((B, qh * qw, e.D), coord.device).view(B, qh, qw, e.D).permute(0, 3, 1, 2).contiguous() * temperature
         return e.query_rgb(d(feat), coord, d(cell), d(zmap), inp=None if inp is None else d(inp))
 
     def log_p(self, inp, coord, cell, gt):

@@ -20,6 +20,7 @@ import os
 import torch
 
 from . import spec
+from .. import rng
 from .options import opt_get
 from ..ops import ACT_LRELU, ACT_NONE, ACT_RELU, MODE_BILINEAR, MODE_BILINEAR_AC, MODE_NEAREST
 
@@ -564,7 +565,7 @@ class SRFlowEngine(object):
                 if epses is not None:
                     e = epses.pop()
                 else:   # tau path: eps ~ N(0, eps_std) sampled on device (plumbing)
-                    e = torch.randn(B, ly.C_consume, H, W, device=z.device, dtype=torch.float32) * float(eps_std or 1)
+                    e = rng.randn((B, ly.C_consume, H, W), z.device) * float(eps_std or 1)
                 ops.split2d(h, e, full[:, ly.C_pass:], True)
                 if logdet is not None:
                     ops.gaussian_logp(full[:, ly.C_pass:], logdet, h=h, coef=-1.0)

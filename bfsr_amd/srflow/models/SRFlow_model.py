@@ -10,6 +10,7 @@ from collections import OrderedDict
 import torch
 
 from ..options import opt_get
+from ... import rng
 from . import networks
 
 
@@ -106,5 +107,5 @@ class SRFlowModel(object):
         # generated directly on the device (the reference samples on the CPU and copies, SRFlow_model.py:229-231)
         dev = self._net.engine().ops.device
         if heat and heat > 0:
-            return torch.randn(batch_size, C, H, W, device=dev) * heat
+            return rng.randn((batch_size, C, H, W), dev) * heat
         return torch.zeros((batch_size, C, H, W), device=dev)

@@ -36,7 +36,23 @@ def _stub(name, **attrs):
 def install_stubs():
     import torch
 
-    _stub("cv2")
+    # cv2 is not installed.  The reference calls exactly two OpenCV functions on the path to its SSIM (LINF-LP/utils.py:158-166):
+    #   cv2.getGaussianKernel(ksize, sigma) -> [ksize,1] float64 column, exp(-(i-(ksize-1)/2)^2 / (2 sigma^2)) normalised to sum 1
+    #   cv2.filter2D(img, -1, kernel)       -> same-size CORRELATION with the kernel anchored at its centre, BORDER_REFLECT_101
+    # (OpenCV documentation); both are restated here so that the reference's own calculate_ssim runs unmodified.
+    import numpy as _np
+
+    def _get_gaussian_kernel(ksize, sigma):
+        i = _np.arange(ksize, dtype=_np.float64) - (ksize - 1) / 2.0
+        g = _np.exp(-(i * i) / (2.0 * sigma * sigma))
+        return (g / g.sum()).reshape(-1, 1)
+
+    def _filter2d(img, ddepth, kernel):
+        from scipy.ndimage import correlate
+        assert ddepth == -1
+        return correlate(_np.asarray(img, dtype=_np.float64), _np.asarray(kernel, dtype=_np.float64), mode="mirror")
+
+    _stub("cv2", getGaussianKernel=_get_gaussian_kernel, filter2D=_filter2d)
     ns = _stub("natsort", natsorted=sorted)
     ns.natsort = ns
     tv = _stub("torchvision")
@@ -44,11 +60,35 @@ def install_stubs():
     tv.transforms = _stub("torchvision.transforms")
     tv.transforms.InterpolationMode = types.SimpleNamespace(BICUBIC="bicubic", BILINEAR="bilinear")
     tv.models = _stub("torchvision.models")
-    _stub("lpips")
+    # LPIPS needs pretrained AlexNet weights (no network): a stand-in that returns zeros keeps `eval_psnr(detail=True)` runnable;
+    # its 'lpips' entry is NOT a golden value and is never stored
+    class _LPIPS(object):
+        def __init__(self, net="alex"):
+            pass
+
+        def to(self, *a, **k):
+            return self
+
+        cuda = to
+
+        def __call__(self, a, b):
+            return torch.zeros(a.shape[0], 1, 1, 1)
+
+        forward = __call__
+
+    _stub("lpips", LPIPS=_LPIPS)
     _stub("tensorboardX", SummaryWriter=object)
     _stub("imageio")
     sk = _stub("skimage")
-    sk.metrics = _stub("skimage.metrics")
+
+    def _psnr(a, b, data_range=None):
+        """skimage.metrics.peak_signal_noise_ratio: 10 log10(data_range^2 / mse); data_range from the dtype (255 for uint8)"""
+        if data_range is None:
+            data_range = 255.0 if a.dtype == _np.uint8 else 1.0
+        err = _np.mean((a.astype(_np.float64) - b.astype(_np.float64)) ** 2)
+        return 10.0 * _np.log10(data_range ** 2 / err)
+
+    sk.metrics = _stub("skimage.metrics", peak_signal_noise_ratio=_psnr, structural_similarity=None)
     timm = _stub("timm")
     timm.models = _stub("timm.models")
     timm.models.layers = _stub(

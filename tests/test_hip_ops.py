@@ -61,6 +61,56 @@ def test_conv_large_tile_path(hip):
     close(out, ref, 2e-5, "conv NR=4")
 
 
+X3S_CASES = [
+    # (B, Cin, Cout, H, W): single tile; ragged edges + two cout groups; many items per persistent workgroup; Cout not a multiple of 32
+    (1, 16, 32, 8, 32), (2, 64, 32, 19, 45), (1, 192, 64, 33, 65), (3, 96, 32, 160, 160), (2, 48, 24, 9, 33), (1, 32, 40, 70, 70),
+]
+
+
+@pytest.mark.parametrize("case", X3S_CASES)
+@pytest.mark.parametrize("fp32_out", [False, True])
+def test_conv_x3s_and_x3_tensors(hip, case, fp32_out):
+    """conv_x3s (LDS-DMA staged 3x3 conv over x3 tensors, conv_x3s.hip) vs the fp32 conv semantics; x3 pack/unpack lossless."""
+    B, Cin, Cout, H, W = case
+    x, w, b = rnd(31, B, Cin, H, W), rnd(32, Cout, Cin, 3, 3, scale=1.0 / np.sqrt(Cin * 9)), rnd(33, Cout, scale=0.3)
+    xd = hip.to_device(x)
+    x3 = hip.x3_pack(xd, hip.x3_empty(B, Cin, H, W))
+    assert torch.equal(hip.x3_unpack(x3, hip.empty(B, Cin, H, W)), xd), "x3 encoding is not lossless"
+    planes = x3.float()
+    assert torch.equal((planes[:, :, 0] + planes[:, :, 1]) + planes[:, :, 2], xd.view(B, Cin // 8, 8, H, W).permute(0, 1, 3, 4, 2))
+    ref = CPU.conv(x, CPU.pack_conv(w, 1), torch.empty(B, Cout, H, W), bias=b, act=2, slope=0.2)
+    pw, epi = hip.pack_conv_x3(w, 1), hip.pack_epilogue(Cout, bias=b)
+    if fp32_out:
+        out = hip.conv_x3s(x3, pw, hip.empty(B, Cout, H, W), epi=epi, act=2, slope=0.2)
+    else:
+        out = hip.x3_unpack(hip.conv_x3s(x3, pw, hip.x3_empty(B, Cout, H, W), epi=epi, act=2, slope=0.2), hip.empty(B, Cout, H, W))
+    close(out, ref, 2e-5, "conv_x3s%s" % (case,))
+    # bit-identical to the register-staged 3xBF16 kernel (same six products, same order)
+    same = hip.conv_x3(xd, pw, hip.empty(B, Cout, H, W), epi=epi, act=2, slope=0.2)
+    assert torch.equal(out, same), "conv_x3s differs from conv_x3"
+
+
+def test_conv_x3s_dense_block_views_and_residuals(hip):
+    """The RDB pattern (RRDBNet_arch.py:39-45): octet-sliced views of one x3 block buffer, conv5 with `x5*0.2 + x` and the
+    RRDB-level `*0.2 + x_rrdb`, all residuals x3."""
+    B, H, W = 2, 21, 37
+    D = rnd(41, B, 192, H, W)
+    xr = rnd(42, B, 64, H, W)
+    D3 = hip.x3_pack(hip.to_device(D), hip.x3_empty(B, 192, H, W))
+    xr3 = hip.x3_pack(hip.to_device(xr), hip.x3_empty(B, 64, H, W))
+    ref = D.clone()
+    w2, b2 = rnd(43, 32, 96, 3, 3, scale=0.04), rnd(44, 32, scale=0.1)
+    CPU.conv(ref[:, :96].clone(), CPU.pack_conv(w2, 1), ref[:, 96:128], bias=b2, act=2, slope=0.2)
+    hip.conv_x3s(D3[:, :12], hip.pack_conv_x3(w2, 1), D3[:, 12:16], epi=hip.pack_epilogue(32, bias=b2), act=2, slope=0.2)
+    close(hip.x3_unpack(D3, hip.empty(B, 192, H, W)), ref, 2e-5, "x3 slice views")
+    w5, b5 = rnd(45, 64, 192, 3, 3, scale=0.03), rnd(46, 64, scale=0.1)
+    out_ref = CPU.conv(ref.clone(), CPU.pack_conv(w5, 1), torch.empty(B, 64, H, W), bias=b5, res1=ref[:, :64].clone(), alpha1=0.2,
+                       res2=xr, alpha2=0.2)
+    nxt = hip.x3_empty(B, 192, H, W)
+    hip.conv_x3s(D3, hip.pack_conv_x3(w5, 1), nxt[:, :8], epi=hip.pack_epilogue(64, bias=b5), res1=D3[:, :8], alpha1=0.2, res2=xr3, alpha2=0.2)
+    close(hip.x3_unpack(nxt[:, :8], hip.empty(B, 64, H, W)), out_ref, 2e-5, "x3 conv5 residuals")
+
+
 def test_conv_epilogue_all_stages(hip):
     B, Cin, Cout, H, W = 2, 40, 48, 21, 35
     x, w = rnd(5, B, Cin, H, W), rnd(6, Cout, Cin, 3, 3, scale=0.08)

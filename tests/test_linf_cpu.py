@@ -17,7 +17,7 @@ from cpu_ops import CpuOps
 
 T = torch.from_numpy
 torch.set_grad_enabled(False)
-CASES = [("rrdb", "rrdb", 2024, "s4"), ("rrdb", "rrdb", 2024, "s3"), ("rrdb", "rrdb", 2024, "s2"),
+CASES = [("rrdb", "rrdb", 2024, "s4"), ("rrdb", "rrdb", 2024, "s3"), ("rrdb", "rrdb", 2024, "s2"), ("rrdb", "rrdb", 2024, "s6"),
          ("edsr", "edsr-baseline", 2025, "s4"), ("edsr", "edsr-baseline", 2025, "s6")]
 
 
@@ -118,6 +118,14 @@ def test_cfg1_eval_psnr_scalar(golden_dir):
     pred = g["pred"][0].transpose(1, 2, 0).astype(np.float64)
     assert abs(d["ssim"] - MO.calculate_ssim(pred * 255.0, hr[0].permute(1, 2, 0).numpy().astype(np.float64) * 255.0)) <= 1e-4
     lr_rec = MO.imresize(g["pred"][0].transpose(1, 2, 0), 0.25).transpose(2, 0, 1)[None]
+    # the genuine reference's eval_psnr(detail=True) dict for the same batch (tests/golden/linf_detail.npz)
+    rd = np.load(os.path.join(golden_dir, "linf_detail.npz"))
+    for et in ("div2k-4", "benchmark-4"):
+        dd = eval_psnr([batch], m, prior, eval_type=et, detail=True)
+        k = et.replace("-", "")
+        assert abs(dd["psnr"] - float(rd[k + "_psnr"])) <= 1e-3
+        assert abs(dd["ssim"] - float(rd[k + "_ssim"])) <= 1e-4
+        assert abs(dd["LR recon"] - float(rd[k + "_LR_recon"])) <= 1e-2
     # the reference's psnr_fn carries dataset and scale into the LR-consistency PSNR too (LINF-LP/test.py:66-75,186,199)
     assert abs(d["LR recon"] - MO.calc_psnr(lr_rec.astype(np.float32), lr.numpy(), dataset="div2k", scale=4)) <= 1e-2
     d = eval_psnr([batch], m, prior, eval_type="benchmark-4", detail=True)

@@ -169,29 +169,109 @@ def test_grid_sample_add(hip):
     close(out, ref, 2e-6, "grid_sample_add")
 
 
-def test_fp16_mfma_path_config5(hip):
-    """BASELINE config 5 shape in miniature (rrdb-linf-LP, OOD x6, fp16 MFMA path): runs through the fp16 conv kernel and
-    stays close to the fp32 path; the deviation is REPORTED (no 1e-4 claim for reduced precision)."""
-    import oracle.linf_ref as O
+FP16_TOL_PRED = 1e-3      # stated tolerance of the fp16-MFMA path against the fp32 REFERENCE on the [0,1] output image
+FP16_TOL_LATENT = 2e-3    # ... and on the latents, relative to max(1, |ref|)
+
+
+@pytest.mark.parametrize("c", ["s6", "s4"])
+def test_fp16_mfma_path_vs_reference_golden(hip, golden_dir, c):
+    """BASELINE config 5 in miniature (rrdb-linf-LP, fp16 MFMA path; s6 = the out-of-distribution x6 scale) against the GENUINE
+    reference's fp32 result.  Reduced precision is outside the 1e-4 fp32 bar by construction; the bar for this path is
+    FP16_TOL_PRED on `pred` (north_star states no number for fp16; measured 1-3e-4, asserted at 1e-3)."""
     from bfsr_amd.linf.models import make
     from bfsr_amd.linf.test import lp_infer
+    g = np.load(os.path.join(golden_dir, "linf_e2e_rrdb_%s.npz" % c))
     sd, psd = weights("rrdb", 2024)
-    outs = {}
-    lr = synth.smooth_lr_batch(13, 2, 32, 32)
-    H = W = 192
-    prep = O.batch_prep(lr, (H, W))
-    for prec in ("fp32", "fp16"):
-        prior = make({"name": "unet", "args": {"in_chans": 27, "depth": 3, "dim": 64, "bilinear": True}},
-                     args={"ops": hip, "precision": prec}).eval()
-        prior.load_state_dict(psd)
-        m = make(mspec("rrdb"), args={"ops": hip, "precision": prec}).eval()
-        m.load_state_dict(sd)
-        outs[prec] = lp_infer(m, prior, prep, (H, W), return_all=True)
-    assert torch.isfinite(outs["fp16"]["pred"]).all()
-    dev = (outs["fp16"]["pred"] - outs["fp32"]["pred"]).abs().max().item()
-    dz = (outs["fp16"]["z_lr"] - outs["fp32"]["z_lr"]).abs().max().item()
-    print("fp16 MFMA path vs fp32: max-abs pred %.3e, z_lr %.3e" % (dev, dz))
-    assert 0 < dev < 5e-2
+    prior = make({"name": "unet", "args": {"in_chans": 27, "depth": 3, "dim": 64, "bilinear": True}},
+                 args={"ops": hip, "precision": "fp16"}).eval()
+    prior.load_state_dict(psd)
+    m = make(mspec("rrdb"), args={"ops": hip, "precision": "fp16"}).eval()
+    m.load_state_dict(sd)
+    s, lr = int(g["scale"]), T(g["lr"])
+    H, W = s * lr.shape[2], s * lr.shape[3]
+    batch = dict(inp=lr, coord=T(g["coord"]), cell=T(g["cell"]), gt_lr_up=T(g["gt_lr_up"]))
+    out = lp_infer(m, prior, batch, (H, W), return_all=True)
+    dev = (out["pred"].cpu() - T(g["pred"])).abs().max().item()
+    dz = (out["z_lr"].cpu() - T(g["z_lr"])).abs().max().item() / max(1.0, float(np.abs(g["z_lr"]).max()))
+    dzl = (out["z_learned"].cpu() - T(g["z_learned"])).abs().max().item() / max(1.0, float(np.abs(g["z_learned"]).max()))
+    print("fp16 MFMA path vs reference (%s): max-abs pred %.3e, rel z_lr %.3e, rel z_learned %.3e" % (c, dev, dz, dzl))
+    assert torch.isfinite(out["pred"]).all()
+    assert 0 < dev <= FP16_TOL_PRED and dz <= FP16_TOL_LATENT and dzl <= FP16_TOL_LATENT
+
+
+def _bench_size_models(hip, precision):
+    from bfsr_amd.linf.models import make
+    sd, psd = weights("rrdb", 2024)
+    m = make(mspec("rrdb"), args={"ops": hip, "precision": precision}).eval()
+    m.load_state_dict(sd)
+    prior = make({"name": "unet", "args": {"in_chans": 27, "depth": 3, "dim": 64, "bilinear": True}},
+                 args={"ops": hip, "precision": precision}).eval()
+    prior.load_state_dict(psd)
+    return m, prior, sd, psd
+
+
+@pytest.mark.parametrize("cfg", ["cfg3_x2", "cfg3_x3", "cfg3_x4", "cfg5_x6_fp16"])
+def test_bench_size_properties(hip, cfg):
+    """BASELINE configs 3 and 5 at FULL size (config 3: B=16, 256x256 LR, x2/x3/x4; config 5 per GPU: B=16, 128x128 LR, x6, fp16
+    MFMA path): size-independent properties -- query_rgb(query_log_p(x)) == x within 1e-4 (the flow is inverted exactly on the
+    shared conditioning), bit-identical results under batch sharding, the re-fold branch when the HR width is not a multiple
+    of 3 -- plus an oracle comparison on a B=1 crop of the SAME input (fp32 configs)."""
+    import oracle.linf_ref as O
+    from bfsr_amd.linf import prep
+    from bfsr_amd.linf.test import lp_infer
+    scale = int(cfg.split("_x")[1].split("_")[0])
+    fp16 = cfg.endswith("fp16")
+    B, n = (16, 128) if cfg.startswith("cfg5") else (16, 256)
+    m, prior, sd, psd = _bench_size_models(hip, "fp16" if fp16 else "fp32")
+    lr = hip.to_device(synth.smooth_lr_batch(40 + scale, B, n, n))
+    H = W = n * scale
+    batch = prep.prepare_batch(hip, lr, (H, W), 3, True)
+    Q = batch["coord"].shape[1]
+    assert Q == (H + (3 - H % 3)) // 3                      # wrappers.py:218-219: pad = ps - H % ps even when divisible
+    inp = hip.axpb_clamp(lr, hip.empty(B, 3, n, n), 2.0, -1.0)
+    feat = m("gen_feat", inp=inp)
+    z = m("query_log_p", feat=feat, coord=batch["coord"], cell=batch["cell"], gt=batch["gt_lr_up"])[1]
+    back = hip.patch_unfold(m("query_rgb", feat=feat, coord=batch["coord"], cell=batch["cell"], zmap=z), hip.empty(*batch["gt_lr_up"].shape), 3)
+    rt = (back - batch["gt_lr_up"]).abs().max().item()
+    assert rt <= 1e-4, "round trip %.3e" % rt
+    out = lp_infer(m, prior, batch, (H, W), return_all=True)
+    assert out["pred"].shape == (B, 3, H, W) and torch.isfinite(out["pred"]).all()
+    # batch sharding: samples 5..6 alone give bit-identical latents and images
+    sub = {k: v[5:7].contiguous() for k, v in batch.items()}
+    out2 = lp_infer(m, prior, sub, (H, W), return_all=True)
+    for k in ("z_lr", "z_learned", "pred"):
+        assert torch.equal(out[k][5:7], out2[k]), "batch sharding changed %s" % k
+    if not fp16:    # oracle on a 24x20 crop of sample 3 of the same input
+        crop = lr[3:4, :, 100:124, 60:80].contiguous().cpu()
+        h, w = crop.shape[-2:]
+        pb = O.batch_prep(crop, (h * scale, w * scale))
+        ref = O.lp_pipeline(pb, sd, psd, mspec("rrdb"), (h * scale, w * scale), return_all=True)
+        got = lp_infer(m, prior, pb, (h * scale, w * scale), return_all=True)
+        close(got["z_lr"], ref["z_lr"], 1e-4, "crop z_lr")
+        assert (got["pred"].cpu() - ref["pred"]).abs().max() <= 1e-4
+    m.engine().ws.bufs.clear()
+    torch.cuda.empty_cache()
+
+
+def test_eval_psnr_detail_vs_reference(hip, golden_dir):
+    """`eval_psnr(detail=True)` on the HIP path == the genuine reference's dict (psnr / ssim / LR recon), eval_type div2k-4 and
+    benchmark-4 (tests/golden/linf_detail.npz)."""
+    import oracle.linf_ref as O
+    from bfsr_amd.linf.models import make
+    from bfsr_amd.linf.test import eval_psnr
+    rd = np.load(os.path.join(golden_dir, "linf_detail.npz"))
+    sd, psd = weights("edsr-baseline", 2025)
+    m = make(mspec("edsr-baseline"), args={"ops": hip}).eval()
+    m.load_state_dict(sd)
+    prior = make({"name": "unet", "args": {"in_chans": 27, "depth": 3, "dim": 64, "bilinear": True}}, args={"ops": hip}).eval()
+    prior.load_state_dict(psd)
+    batch = dict(O.batch_prep(T(rd["lr"]), (192, 192)), gt=T(rd["hr"]))
+    for et in ("div2k-4", "benchmark-4"):
+        d = eval_psnr([batch], m, prior, eval_type=et, detail=True)
+        k = et.replace("-", "")
+        assert abs(d["psnr"] - float(rd[k + "_psnr"])) <= 1e-3
+        assert abs(d["ssim"] - float(rd[k + "_ssim"])) <= 1e-4
+        assert abs(d["LR recon"] - float(rd[k + "_LR_recon"])) <= 1e-2
 
 
 def test_query_log_p_values_golden(hip, golden_dir):

@@ -1,6 +1,8 @@
 """Evaluation metrics after the hot path: oracle vs the genuine reference's goldens (imresize,
 calc_psnr), the product's device metrics (on the CPU double here, on the HIP kernels under -m gpu) vs the same goldens, and
-known-answer properties for SSIM (the reference's cv2-based SSIM cannot run in this image: unpinned)."""
+SSIM pinned to the reference's own `utils.calculate_ssim` / `eval_psnr(detail=True)` (tests/golden/linf_detail.npz, generated
+with numpy/scipy restatements of the two OpenCV calls the reference makes, see tests/golden/ref_import.py), and the SRFlow
+harness' `Measure.psnr` (tests/golden/srflow_measure.npz)."""
 import os
 
 import numpy as np
@@ -58,6 +60,34 @@ def _check_product(ops, g):
     img = dev(T(g["img_a"]).permute(2, 0, 1).unsqueeze(0).contiguous())
     lr = metrics.imresize(ops, img, 0.5)
     assert metrics.lr_consistency_psnr(ops, img, lr, 2) > 120
+
+
+def test_ssim_oracle_pinned_to_reference(golden_dir):
+    """oracle/metrics_ref.calculate_ssim == the genuine LINF-LP/utils.py:152-193 on a random pair and on a real prediction"""
+    d = np.load(os.path.join(golden_dir, "linf_detail.npz"))
+    assert abs(O.calculate_ssim(d["rand_a"], d["rand_b"]) - float(d["ssim_rand"])) <= 1e-9
+    man = __import__("json").load(open(os.path.join(golden_dir, "MANIFEST.json")))
+    assert man["extra_r2"]["ssim_oracle_vs_reference"] <= 1e-8
+
+
+def _check_ssim_and_measure(ops, golden_dir):
+    d = np.load(os.path.join(golden_dir, "linf_detail.npz"))
+    f = lambda a: ops.to_device(T(np.ascontiguousarray(a.transpose(2, 0, 1)[None] / 255.0)).float())
+    s = float(metrics.ssim(ops, f(d["rand_a"]), f(d["rand_b"]))[0])
+    assert abs(s - float(d["ssim_rand"])) <= 1e-5               # inputs pass through fp32 [0,1] images on the product side
+    from bfsr_amd.srflow.Measure import Measure
+    m = np.load(os.path.join(golden_dir, "srflow_measure.npz"))
+    assert abs(Measure(ops).psnr(m["a"], m["b"]) - float(m["psnr"])) <= 1e-6
+
+
+def test_ssim_and_measure_on_cpu_double(golden_dir):
+    _check_ssim_and_measure(CpuOps(), golden_dir)
+
+
+@pytest.mark.gpu
+def test_ssim_and_measure_on_hip(golden_dir):
+    from bfsr_amd.ops import HipOps
+    _check_ssim_and_measure(HipOps("cuda:0"), golden_dir)
 
 
 def test_product_metrics_on_cpu_double(golden_dir):

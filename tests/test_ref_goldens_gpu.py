@@ -1,0 +1,134 @@
+"""-m gpu: the per-op / per-FlowStep golden vectors emitted from the GENUINE reference (tests/golden/srflow_ops.npz,
+srflow_steps.npz; generator tests/golden/make_golden.py) fed straight to the HIP kernels through the C ABI -- no engine
+schedule, no CPU test double in between.  Tolerance: 1e-5 * max(1, |ref|) per op (fp32), 2e-5 for a whole FlowStep."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from bfsr_amd import synth                      # noqa: E402
+from bfsr_amd.srflow import options, spec       # noqa: E402
+
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from bfsr_amd.ops import HipOps
+    return HipOps("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, "srflow_ops.npz"))
+
+
+def close(got, ref, tol, what):
+    got = got.detach().cpu()
+    assert not torch.isnan(got).any(), what + " NaN"
+    err = (got - ref).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), "%s: %.3e" % (what, err)
+
+
+def test_actnorm_and_invconv_goldens(hip, g):
+    """FlowActNorms.py:61-113 and Permutations.py:34-58 through bfsr_flow_pointwise."""
+    x, bias, logs = T(g["actnorm_x"]), T(g["actnorm_bias"]).reshape(-1), T(g["actnorm_logs"]).reshape(-1)
+    d = hip.to_device
+    fwd = hip.flow_pointwise(d(x), hip.empty(*x.shape), False, an_bias=hip.vec(bias), an_escale=hip.vec(torch.exp(logs)))
+    close(fwd, T(g["actnorm_fwd"]), 1e-6, "actnorm fwd")
+    rev = hip.flow_pointwise(d(x), hip.empty(*x.shape), True, an_bias=hip.vec(bias), an_escale=hip.vec(torch.exp(-logs)))
+    close(rev, T(g["actnorm_rev"]), 1e-6, "actnorm rev")
+    for C in (12, 24, 96):
+        w, x = T(g["invconv%d_w" % C]), T(g["invconv%d_x" % C])
+        winv = torch.inverse(w.double()).float()                     # Permutations.py:41
+        y = hip.flow_pointwise(d(x), hip.empty(*x.shape), False, w=hip.vec(w), wt=hip.vec(w.t().contiguous()))
+        close(y, T(g["invconv%d_fwd" % C]), 1e-5, "invconv%d fwd" % C)
+        y = hip.flow_pointwise(d(x), hip.empty(*x.shape), True, w=hip.vec(winv), wt=hip.vec(winv.t().contiguous()))
+        close(y, T(g["invconv%d_rev" % C]), 1e-5, "invconv%d rev" % C)
+
+
+def test_flow_conv_goldens(hip, g):
+    """flow.Conv2d (conv + ActNorm, flow.py:26-65) and Conv2dZeros (flow.py:68-83) through bfsr_conv2d's fused epilogue."""
+    d = hip.to_device
+    for k in (3, 1):
+        w, x = T(g["fconv%d_w" % k]), T(g["fconv%d_x" % k])
+        y = hip.conv(d(x), hip.pack_conv(w), hip.empty(*g["fconv%d_y" % k].shape), aff_shift=T(g["fconv%d_b" % k]).reshape(-1),
+                     aff_scale=torch.exp(T(g["fconv%d_logs" % k]).reshape(-1)))
+        close(y, T(g["fconv%d_y" % k]), 1e-5, "flow.Conv2d %dx%d" % (k, k))
+    y = hip.conv(d(T(g["czero_x"])), hip.pack_conv(T(g["czero_w"])), hip.empty(*g["czero_y"].shape), bias=T(g["czero_b"]),
+                 post_scale=torch.exp(T(g["czero_logs"]).reshape(-1) * 3))
+    close(y, T(g["czero_y"]), 1e-5, "Conv2dZeros")
+
+
+def test_squeeze_split_standardize_goldens(hip, g):
+    d = hip.to_device
+    x = T(g["squeeze_x"])
+    y = hip.squeeze2d(d(x), hip.empty(*g["squeeze_y"].shape))
+    assert torch.equal(y.cpu(), T(g["squeeze_y"]))                   # pure permutation: bit exact (flow.py:122-134)
+    assert torch.equal(hip.unsqueeze2d(y, hip.empty(*x.shape)).cpu(), T(g["unsqueeze_y"]))
+    # Split2d (Split.py:48-77): h = Conv2dZeros(z1); eps = (z2 - mean) / exp(logs); reverse z2 = mean + exp(logs) * eps
+    xs = d(T(g["split_x"]))
+    h = hip.conv(xs[:, :6], hip.pack_conv(T(g["split_w"])), hip.empty(2, 12, 6, 6), bias=T(g["split_b"]),
+                 post_scale=torch.exp(T(g["split_logs"]).reshape(-1) * 3))
+    eps = hip.split2d(h, xs[:, 6:], hip.empty(2, 6, 6, 6), False)
+    close(eps, T(g["split_eps"]), 1e-5, "split eps")
+    full = hip.empty(2, 12, 6, 6)
+    full[:, :6].copy_(xs[:, :6])
+    hip.split2d(h, eps, full[:, 6:], True)
+    close(full, T(g["split_rev"]), 1e-5, "split reverse")
+    close(hip.standardize(d(T(g["std_x"])), hip.empty(*g["std_x"].shape)), T(g["std_y"]), 1e-5, "eps standardisation")
+
+
+def _coupling_net(hip, sd, p, x, cout):
+    """F() of FlowAffineCouplingsAblation.py:127-135: Conv2d 3x3 + ActNorm, ReLU, Conv2d 1x1 + ActNorm, ReLU, Conv2dZeros."""
+    B, _, H, W = x.shape
+    h = hip.conv(x, hip.pack_conv(sd[p + "0.weight"]), hip.empty(B, 64, H, W), aff_shift=sd[p + "0.actnorm.bias"].reshape(-1),
+                 aff_scale=torch.exp(sd[p + "0.actnorm.logs"].reshape(-1)), act=1)
+    h = hip.conv(h, hip.pack_conv(sd[p + "2.weight"]), hip.empty(B, 64, H, W), aff_shift=sd[p + "2.actnorm.bias"].reshape(-1),
+                 aff_scale=torch.exp(sd[p + "2.actnorm.logs"].reshape(-1)), act=1)
+    return hip.conv(h, hip.pack_conv(sd[p + "4.weight"]), hip.empty(B, cout, H, W), bias=sd[p + "4.bias"],
+                    post_scale=torch.exp(sd[p + "4.logs"].reshape(-1) * 3))
+
+
+@pytest.mark.parametrize("li", [3, 23, 42, 1])
+def test_flowstep_goldens(hip, golden_dir, li):
+    """One whole FlowStep (FlowStep.py:88-129) of the reference, forward and reverse, composed from the HIP kernels in the
+    reference's UN-hoisted form: coupling nets on cat[z1, ft] / ft, then the fused pointwise chain."""
+    opt = options.load(options.DEFAULT_CONF)
+    sd = synth.state_dict_from_schema(spec.srflownet_schema(opt), 1234)
+    g = np.load(os.path.join(golden_dir, "srflow_steps.npz"))
+    if bytes(g["weights_sha256"]).decode() != synth.digest(sd):
+        pytest.skip("synthetic weights differ on this machine (numpy/LAPACK build)")
+    p = "flowUpsamplerNet.layers.%d." % li
+    d = hip.to_device
+    z0 = T(g["step%d_z" % li])
+    B, C, H, W = z0.shape
+    Wm = sd[p + "invconv.weight"]
+    Winv = torch.inverse(Wm.double()).float()
+    logs = sd[p + "actnorm.logs"].reshape(-1)
+    an = dict(an_bias=hip.vec(sd[p + "actnorm.bias"]))
+    coupled = li != 1
+    ft = d(T(g["step%d_ft" % li])) if coupled else None
+    cn = C // 2
+
+    def h_aff(z):
+        cat = hip.empty(B, cn + 320, H, W)
+        cat[:, :cn].copy_(z[:, :cn])
+        cat[:, cn:].copy_(ft)
+        return _coupling_net(hip, sd, p + "affine.fAffine.", cat, 2 * (C - cn))
+
+    # ---- forward: actnorm -> invconv -> feature-conditional affine -> self-conditional affine
+    z = d(z0).clone()
+    h_ft = _coupling_net(hip, sd, p + "affine.fFeatures.", ft, 2 * C) if coupled else None
+    hip.flow_pointwise(z, z, False, an_escale=hip.vec(torch.exp(logs)), w=hip.vec(Wm), wt=hip.vec(Wm.t().contiguous()), h_ft=h_ft, **an)
+    if coupled:
+        hip.flow_pointwise(z, z, False, h_aff=h_aff(z))
+    close(z, T(g["step%d_fwd" % li]), 2e-5, "FlowStep %d forward" % li)
+    # ---- reverse: self-conditional^-1 -> feature-conditional^-1 -> invconv^-1 -> actnorm^-1
+    z = d(z0).clone()
+    hip.flow_pointwise(z, z, True, h_aff=h_aff(z) if coupled else None, h_ft=h_ft, w=hip.vec(Winv), wt=hip.vec(Winv.t().contiguous()),
+                       an_escale=hip.vec(torch.exp(-logs)), **an)
+    close(z, T(g["step%d_rev" % li]), 2e-5, "FlowStep %d reverse" % li)

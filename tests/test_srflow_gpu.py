@@ -62,6 +62,32 @@ def test_golden_e2e_4x(model4, golden_dir, fx):
     _chk("sr", out["sr"], T("sr"), 1e-4)       # north_star: <= 1e-4 max-abs on the [0,1] output
 
 
+def test_reference_caller_sequence_through_srflowmodel(model4, golden_dir):
+    """The LP block exactly as SRFlow-LP/code/test.py:139-148 drives it -- `model.get_encode_z(lr, lr_up, epses=[],
+    add_gt_noise=False)` -> per-pixel standardisation -> `prior_model(epses)` -> `model.get_sr(lq=lr, epses=...)` -- through the
+    SRFlowModel wrapper (not the engine-level `lp_infer`), against the reference golden."""
+    import torch.nn.functional as F
+    m, prior, opt, sd, psd = model4
+    g = np.load(os.path.join(golden_dir, "srflow_e2e_4x_a.npz"))
+    T = lambda k: torch.from_numpy(g[k])
+    lr = T("lr")
+    lr_up = F.interpolate(lr, scale_factor=opt["scale"], mode="bilinear", align_corners=False)      # test.py:137
+    epses_lr = m.get_encode_z(lr, lr_up, epses=[], add_gt_noise=False)                                # test.py:139
+    assert isinstance(epses_lr, list) and len(epses_lr) == 2
+    for i in (0, 1):
+        _chk("eps%d" % i, epses_lr[i], T("eps%d" % i))
+    for idx, eps in enumerate(epses_lr):                                                              # test.py:141-145
+        eps_mean = eps.mean(dim=1, keepdim=True)
+        eps_std = eps.std(dim=1, keepdim=True)
+        epses_lr[idx] = (eps - eps_mean) / (eps_std + 1e-8)
+        _chk("epsn%d" % idx, epses_lr[idx], T("epsn%d" % idx))
+    epses_learned = prior(epses_lr)                                                                   # test.py:147
+    sr = m.get_sr(lq=lr, epses=epses_learned)                                                         # test.py:148
+    assert len(epses_learned) == 2                          # decode copies the list, the caller's is not consumed
+    _chk("sr_raw", sr, T("sr_raw"))
+    _chk("sr", sr.clamp(0, 1), T("sr"), 1e-4)
+
+
 def test_golden_e2e_8x(hip, golden_dir):
     from bfsr_amd.srflow.test import lp_infer
     m, prior, opt, sd, psd = build(hip, 8)

@@ -1,23 +1,33 @@
 #!/usr/bin/env python
-"""bench.py -- HR MPix/s of the SRFlow-LP 4x learned-prior pipeline on MI355X.
+"""bench.py -- HR MPix/s of the BFSR hot path on MI355X, one JSON line per run (contract in the task statement).
 
-A "step" = one pass of the hot path (RRDB conditioning encoder -> flow encode -> eps standardise -> prior
-UNet -> flow decode -> clamp) over one synthetic LR batch already resident in HBM.  Workload at every N:
-BASELINE.json configs[1] per GPU (SRFlow-LP 4x DF2K config, batch 8 of 160x160 LR -> 640x640), i.e. weak
-scaling; for N > 1 the step ends with the RCCL all-gather of the SR outputs.
+A "step" = one pass of the hot path over one synthetic LR batch already resident in HBM.  `--config` names the BASELINE.json
+configuration (default 2 = the headline, the one the metric is quoted on and that fits one GPU):
 
-  python bench.py --gpus 1 --steps 5 --warmup 2
+  2  SRFlow-LP 4x DF2K config, batch 8 of 160x160 LR per GPU -> 640x640 (weak scaling: 8 crops per GPU at every N)
+  3  LINF-LP rrdb-linf-LP, batch 16 of 256x256 LR per GPU, arbitrary scale x2/x3/x4 (`--linf-scale`, default 4)
+  4  SRFlow-LP 8x config (scale 8, L=3), the NAMED batch of 64 crops of 96x96 LR sharded over the N GPUs (strong scaling)
+  5  LINF-LP rrdb-linf-LP, out-of-distribution x6, the NAMED batch of 128 crops of 128x128 LR sharded over the N GPUs,
+     fp16 MFMA path (strong scaling)
+
+SRFlow step: RRDB conditioning encoder -> flow encode -> eps standardise -> prior UNet -> flow decode -> clamp.
+LINF step:   device-side input prep -> encoder -> query_log_p -> prior UNet -> query_rgb -> fold + skip -> clamp.
+For N > 1 (one process per GPU, `torch.distributed` / RCCL) every step's outputs are all-gathered; the gather of step i is
+double-buffered and runs while step i+1 computes (bfsr_amd.dist.AsyncGatherer), the timed region ends when the last gather has.
+
+  python bench.py [--config 2] --gpus 1 --steps 5 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
-         bench.py --gpus N --steps K --warmup W
+         bench.py --gpus N --steps K --warmup W [--config C]
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel: the
-hoisted level-1 3x3 conv on fp32 MFMA, timed in situ with HIP events on the launch stream),
-`roofline_coupling_inverse` (the HBM-bound fused FlowStep-inverse kernel) and `cpu_baseline` (the oracle =
-reference-faithful torch-CPU port, bounded sample: one 160x160 image)."""
+JSON: `roofline` = the launch shape with the largest total time in the timed region (HIP events on the launch stream around
+every launch of the top shapes), `roofline_by_symbol` = the same ranking by kernel family, `roofline_coupling_inverse` = the
+HBM-bound fused FlowStep-inverse kernel (SRFlow configs), `cpu_baseline` = the oracle (reference-faithful torch-CPU port) on a
+bounded sample: 1 warm-up + median of 3, thread count and host core count stated, `parity` = HIP vs oracle on that sample."""
 import argparse
 import contextlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -26,11 +36,23 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix peak (dense)
-PEAK_HBM_GBS = 8000.0            # HBM3E 8 TB/s spec
-PEAK_BF16_MFMA_TFLOPS = 2500.0   # same guide: bf16 matrix peak (dense, no sparsity)
-PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0   # fp32-equivalent peak of the 3xBF16 split (6 bf16 MFMAs per fp32 product)
-CONV_KINDS = ("conv", "conv_up2", "conv_bf16x3", "conv_up2_x3")
+# /opt/skills/guides/MI355X_MICROARCH.md (dense peaks, no sparsity)
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_16BIT_MFMA_TFLOPS = 2500.0
+PEAK_HBM_GBS = 8000.0
+# family -> (kernel symbol, hardware peak TFLOP/s, MFMA instructions per fp32-equivalent product, arithmetic)
+FAMILIES = {
+    "conv": ("conv_mfma_kernel", PEAK_F32_MFMA_TFLOPS, 1, "native fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
+    "conv+1x1": ("conv_mfma_kernel<FUSE2>", PEAK_F32_MFMA_TFLOPS, 1, "native fp32 MFMA, fused 3x3 + 1x1"),
+    "conv_up2": ("conv_up2_kernel", PEAK_F32_MFMA_TFLOPS, 1, "native fp32 MFMA"),
+    "conv_bf16x3": ("conv_bf16x3_kernel", PEAK_16BIT_MFMA_TFLOPS, 6, "3xBF16 split on v_mfma_f32_32x32x16_bf16"),
+    "conv_x3s": ("conv3x3_x3s_kernel", PEAK_16BIT_MFMA_TFLOPS, 6, "3xBF16 split on v_mfma_f32_32x32x16_bf16, x3-tensor input by LDS-DMA"),
+    "conv_up2_x3": ("conv_up2_bf16x3_kernel", PEAK_16BIT_MFMA_TFLOPS, 6, "3xBF16 split, parity-decomposed conv over nearest-x2 input"),
+    "conv_up4_x3": ("conv_up4_bf16x3_kernel", PEAK_16BIT_MFMA_TFLOPS, 6, "3xBF16 split, phase-decomposed conv over nearest-x4 input"),
+    "conv_f16": ("conv_f16_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, "fp16 MFMA (v_mfma_f32_32x32x16_f16), fp32 accumulate"),
+    "conv1x1_f16": ("conv1x1_kernel<fp16>", PEAK_16BIT_MFMA_TFLOPS, 1, "fp16 MFMA GEMM over pixels"),
+    "conv1x1_x3": ("conv1x1_kernel<x3>", PEAK_16BIT_MFMA_TFLOPS, 6, "3xBF16 split GEMM over pixels"),
+}
 
 
 def parse_args():
@@ -38,25 +60,90 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8, help="LR crops per GPU")
-    ap.add_argument("--lr", type=int, default=160, help="LR crop side")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json configuration (see module docstring)")
+    ap.add_argument("--linf-scale", type=float, default=4.0, help="config 3: the arbitrary scale (2, 3 or 4)")
+    ap.add_argument("--batch", type=int, default=None, help="override: LR crops per GPU")
+    ap.add_argument("--lr", type=int, default=None, help="override: LR crop side")
+    ap.add_argument("--scale", type=int, default=None, choices=[4, 8], help="override: SRFlow scale (8 = config 4's model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fp32-line", action="store_true", help="skip the secondary all-native-fp32-MFMA timing")
-    ap.add_argument("--scale", type=int, default=4, choices=[4, 8], help="8 = the derived 8x config (BASELINE config 4)")
-    ap.add_argument("--cpu-lr", type=int, default=160, help="LR side of the CPU-baseline sample (B=1)")
+    ap.add_argument("--no-fp32-line", action="store_true", help="config 2: skip the secondary all-native-fp32-MFMA timing")
+    ap.add_argument("--cpu-lr", type=int, default=None, help="LR side of the CPU-baseline sample (B=1)")
     ap.add_argument("--mode", default="lp", choices=["lp", "tau"],
-                    help="lp = the learned-prior pipeline (headline); tau = sampling path: decode eps ~ 0.9*N(0,1) without "
-                         "encode/prior (SURVEY 8d secondary workload)")
+                    help="SRFlow configs: lp = the learned-prior pipeline (headline); tau = sampling path: decode eps ~ 0.9*N(0,1) "
+                         "without encode/prior (SURVEY 8d secondary workload)")
     return ap.parse_args()
 
 
+# ----------------------------------------------------------------------------------------------------------------------------
+def launch_flop(k):
+    """algorithmic flops of one launch (result-preserving schedule) from its ops.py profile key, or None"""
+    f = k[0]
+    if f in ("conv", "conv_bf16x3", "conv_f16"):
+        _, KS, _, Cin, Cout, b_, hh, ww = k
+        return 2.0 * Cin * KS * KS * Cout * b_ * hh * ww
+    if f == "conv+1x1":
+        _, Cin, Cout, b_, hh, ww = k
+        return 2.0 * (Cin * 9 + 64) * Cout * b_ * hh * ww
+    if f == "conv_x3s":
+        _, Cin, Cout, b_, hh, ww, _fmt = k
+        return 2.0 * Cin * 9 * Cout * b_ * hh * ww
+    if f in ("conv1x1_f16", "conv1x1_x3"):
+        _, Cin, Cout, b_, hh, ww = k
+        return 2.0 * Cin * Cout * b_ * hh * ww
+    if f in ("conv_up2", "conv_up2_x3"):               # 2x2 source taps per output pixel (parity pre-summed weights)
+        _, _, Cin, Cout, b_, hh, ww, cin2 = k          # + cin2 key channels at output resolution (9 taps)
+        return 2.0 * (Cin * 4 + cin2 * 9) * Cout * b_ * hh * ww
+    if f == "conv_up4_x3":                             # 25 pre-summed matrices per 16 output pixels
+        _, _, Cin, Cout, b_, hh, ww, _ = k
+        return 2.0 * Cin * 25.0 / 16.0 * Cout * b_ * hh * ww
+    return None
+
+
+def roof_entry(t, k, f, n, steps, step_ms, traffic_db):
+    sym, hw_peak, per_prod, arith = FAMILIES[k[0]]
+    a = f / (t / n * 1e-3) / 1e12
+    peak = hw_peak / per_prod
+    e = {"bound": "mfma", "kernel": "%s %s" % (sym, list(k)), "achieved": round(a, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+         "frac": round(a / peak, 4), "traffic": None,
+         "peak_equiv_fp32": round(peak, 1), "peak_hw": hw_peak, "achieved_hw": round(a * per_prod, 1),
+         "peak_basis": ("%s: hardware peak %.0f TFLOP/s dense, %d MFMA(s) per fp32-equivalent product -> `peak` = %.1f is a DERIVED "
+                        "fp32-equivalent figure, not a hardware peak; frac = achieved/peak = achieved_hw/peak_hw"
+                        % (arith, hw_peak, per_prod, peak)),
+         "algorithmic_flop_per_launch": f, "avg_launch_ms": round(t / n, 4), "launches": n,
+         "share_of_step": round(t / steps / step_ms, 4)}
+    ent = traffic_db.get(json.dumps(list(k)))
+    if ent:
+        e["traffic"] = ent["hbm_bytes_per_launch"]
+        e["traffic_unit"] = ent.get("unit", "HBM-side bytes per launch (rocprofv3 FETCH_SIZE raw + WRITE_SIZE, profiles/)")
+    return e
+
+
+def load_traffic():
+    """per-launch HBM-side bytes from the committed PMC passes of this round (separate --pmc runs, profiles/), keyed by launch shape"""
+    db = {}
+    for name in ("r02_pmc_traffic.json",):
+        p = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(p):
+            db.update(json.load(open(p)).get("kernels", {}))
+    return db
+
+
+def median_time(fn, warm=1, reps=3):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t = time.perf_counter()
+        r = fn()
+        ts.append(time.perf_counter() - t)
+    return statistics.median(ts), ts, r
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
     from bfsr_amd import dist as bdist, synth
     from bfsr_amd.ops import HipOps
-    from bfsr_amd.srflow import options, spec
-    from bfsr_amd.srflow.models import create_model, models as registry
-    from bfsr_amd.srflow.test import lp_infer
 
     rank, world, local = bdist.init()
     if world != args.gpus:
@@ -65,33 +152,71 @@ def main():
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
     ops = HipOps(dev)
+    cfg = args.config
+    srflow = cfg in (2, 4)
 
-    opt = options.load(options.DEFAULT_CONF)
-    if args.scale != 4:
-        opt = options.derive_scale(opt, args.scale)
-    scale = opt["scale"]
-    sd = synth.state_dict_from_schema(spec.srflownet_schema(opt), 1234)
-    psd = synth.state_dict_from_schema(spec.srflow_prior_schema(), 4321)
-    model = create_model(opt, ops=ops)
-    model.load_network(sd)
-    with contextlib.redirect_stdout(sys.stderr):      # make_unet prints its arguments like the reference does; keep
-        prior = registry.make({"name": "unet", "args": {"depth": 3, "dim": 64, "bilinear": True, "ops": ops}, "sd": psd},
-                              load_sd=True).eval()    # stdout for the single JSON line
+    # ---- workload ----------------------------------------------------------------------------------------------------------
+    if srflow:
+        scale = args.scale or (4 if cfg == 2 else 8)
+        h = args.lr or (160 if cfg == 2 else 96)
+        if cfg == 2:
+            B, total, scaling = args.batch or 8, None, "weak"
+        else:
+            total = 64
+            if total % world:
+                raise SystemExit("config 4 shards a batch of 64 crops: --gpus must divide 64")
+            B, scaling = args.batch or total // world, "strong"
+    else:
+        scale = float(args.linf_scale) if cfg == 3 else 6.0
+        h = args.lr or (256 if cfg == 3 else 128)
+        precision = "fp32" if cfg == 3 else "fp16"
+        if cfg == 3:
+            B, total, scaling = args.batch or 16, None, "weak"
+        else:
+            total = 128
+            if total % world:
+                raise SystemExit("config 5 shards a batch of 128 crops: --gpus must divide 128")
+            B, scaling = args.batch or total // world, "strong"
+    H = int(round(h * scale))
+    global_B = B * world
 
-    B, h = args.batch, args.lr
-    H = h * scale
+    # ---- models ------------------------------------------------------------------------------------------------------------
+    if srflow:
+        from bfsr_amd.srflow import options, spec
+        from bfsr_amd.srflow.models import create_model, models as registry
+        from bfsr_amd.srflow.test import lp_infer
+        opt = options.load(options.DEFAULT_CONF)
+        if scale != 4:
+            opt = options.derive_scale(opt, scale)
+        sd = synth.state_dict_from_schema(spec.srflownet_schema(opt), 1234)
+        psd = synth.state_dict_from_schema(spec.srflow_prior_schema(), 4321)
+        model = create_model(opt, ops=ops)
+        model.load_network(sd)
+        with contextlib.redirect_stdout(sys.stderr):      # make_unet prints its arguments like the reference does; keep
+            prior = registry.make({"name": "unet", "args": {"depth": 3, "dim": 64, "bilinear": True, "ops": ops}, "sd": psd},
+                                  load_sd=True).eval()    # stdout for the single JSON line
+    else:
+        from bfsr_amd.linf import spec as lspec
+        from bfsr_amd.linf.models import make
+        from bfsr_amd.linf.test import infer_from_lr
+        mspec = {"name": "linf-patch", "args": {"encoder_spec": {"name": "rrdb", "args": {"no_upsampling": True}},
+                                                 "imnet_spec": {"name": "flow", "args": {"name": "flow"}},
+                                                 "flow_layers": 10, "num_layer": 3, "hidden_dim": 256}}
+        sd = synth.state_dict_from_schema(lspec.linf_schema(mspec["args"]["encoder_spec"]), 2024)
+        psd = synth.state_dict_from_schema(lspec.linf_prior_schema(27), 777)
+        with contextlib.redirect_stdout(sys.stderr):
+            model = make(mspec, args={"ops": ops, "precision": precision}).eval()
+            model.load_state_dict(sd)
+            prior = make({"name": "unet", "args": {"in_chans": 27, "depth": 3, "dim": 64, "bilinear": True}},
+                         args={"ops": ops, "precision": precision}).eval()
+            prior.load_state_dict(psd)
+
     # distinct seeded batches per rank and step (global sample index = seed), resident in HBM before timing
     n_batches = max(2, min(args.steps + args.warmup, 4))
     batches = [ops.to_device(synth.lr_batch(1000 * rank + i, B, h, h)) for i in range(n_batches)]
 
-    # in-situ timing: every launch of the timed region is bracketed by HIP events on the launch stream (host cost
-    # ~2 us per launch, the loop stays GPU-bound); the dominant kernel is picked from the totals afterwards
-    C1 = 12
-    key_tail = ("flow", 1, C1, B, H // 2, H // 2, True, True, True)
-    gathered = None
-
     tau_eps = None
-    if args.mode == "tau":                # eps resident before timing: 0.9*N(0,1) from the same PCG64 stream family
+    if srflow and args.mode == "tau":     # eps resident before timing: 0.9*N(0,1) from the same PCG64 stream family
         import numpy as np
         tau_eps = []
         for i in range(n_batches):
@@ -99,36 +224,51 @@ def main():
             tau_eps.append([ops.to_device(torch.from_numpy((0.9 * g.standard_normal((B, 6, H // 2, H // 2))).astype(np.float32))),
                             ops.to_device(torch.from_numpy((0.9 * g.standard_normal((B, 96, H // 8, H // 8))).astype(np.float32)))])
 
-    def step(i):
-        nonlocal gathered
-        x = batches[i % n_batches]
-        x.add_(0.0)                       # bump the version so the conditioning cache never hits across steps
+    gatherer = bdist.AsyncGatherer(global_B)
+
+    def infer(x, i):
+        if not srflow:
+            return infer_from_lr(model, prior, x, scale)
         if tau_eps is not None:
             sr = model.netG.module.engine().decode(x, epses=tau_eps[i % n_batches])
-            sr = ops.axpb_clamp(sr, ops.empty(*sr.shape), 1.0, 0.0, 0.0, 1.0)
-        else:
-            sr = lp_infer(model, prior, x)
+            return ops.axpb_clamp(sr, ops.empty(*sr.shape), 1.0, 0.0, 0.0, 1.0)
+        return lp_infer(model, prior, x)
+
+    def step(i):
+        x = batches[i % n_batches]
+        x.add_(0.0)                       # bump the version so the conditioning cache never hits across steps
+        sr = infer(x, i)
         if world > 1:
-            gathered = bdist.all_gather_batch(sr, total=B * world)
+            gatherer.submit(sr)           # gather of step i overlaps the compute of step i+1
         return sr
 
-    # warm-up: the last warm-up step brackets EVERY launch with HIP events to rank the kernels; the timed region
-    # then only brackets the launches of the top kernels (+ the inverse tail), keeping the host overhead negligible
+    # warm-up: the last warm-up step brackets EVERY launch with HIP events to rank the launch shapes; the timed region then
+    # only brackets the launches of the top shapes (+ the inverse tail), keeping the host overhead negligible
+    C1 = 12
+    key_tail = ("flow", 1, C1, B, H // 2, H // 2, True, True, True) if srflow else None
     for i in range(args.warmup):
         if i == args.warmup - 1:
             ops.profile_keys, ops.profile = "ALL", {}
         step(i)
+    gatherer.finish()
     torch.cuda.synchronize()
     ranked = sorted(((sum(s_.elapsed_time(e_) for s_, e_ in ev), k) for k, ev in ops.profile.items()
-                     if k[0] in CONV_KINDS), reverse=True)
-    warm_total_ms = sum(sum(s_.elapsed_time(e_) for s_, e_ in ev) for ev in ops.profile.values())
-    ops.profile_keys = set([k for _, k in ranked[:4]] + [key_tail]) if args.warmup > 0 else "ALL"
+                     if k[0] in FAMILIES), reverse=True)
+    warm_by_family = {}
+    warm_total_ms = 0.0
+    for k, ev in ops.profile.items():
+        t = sum(s_.elapsed_time(e_) for s_, e_ in ev)
+        warm_total_ms += t
+        fam = FAMILIES[k[0]][0] if k[0] in FAMILIES else k[0]
+        warm_by_family[fam] = warm_by_family.get(fam, 0.0) + t
+    ops.profile_keys = set([k for _, k in ranked[:4]] + ([key_tail] if key_tail else [])) if args.warmup > 0 else "ALL"
     ops.profile = {}
     bdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    gatherer.finish()
     torch.cuda.synchronize()
     bdist.barrier()
     dt = time.perf_counter() - t0
@@ -137,68 +277,35 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-
-    mpix = world * B * H * H / 1e6
+    mpix = global_B * H * H / 1e6
     value = mpix * args.steps / dt
+    step_ms = dt / args.steps * 1e3
 
-    def avg_ms(key):
-        ev = ops.profile.get(key, [])
-        return (sum(s.elapsed_time(e) for s, e in ev) / len(ev), len(ev)) if ev else (None, 0)
-
-    def launch_flop(k):
-        """algorithmic flops of one launch of the result-preserving schedule"""
-        if k[0] in ("conv", "conv_bf16x3"):
-            _, KS, _, Cin, Cout, b_, hh, ww = k
-            return 2.0 * Cin * KS * KS * Cout * b_ * hh * ww
-        if k[0] in ("conv_up2", "conv_up2_x3"):          # 2x2 source taps per output pixel (parity pre-summed weights)
-            _, _, Cin, Cout, b_, hh, ww, cin2 = k       # + cin2 key channels at output resolution (9 taps)
-            return 2.0 * (Cin * 4 + cin2 * 9) * Cout * b_ * hh * ww
-        return None
-
+    # ---- roofline ----------------------------------------------------------------------------------------------------------
+    traffic_db = load_traffic()
     totals = []
     for k, ev in ops.profile.items():
         f = launch_flop(k)
         if f is not None:
-            t = sum(s_.elapsed_time(e_) for s_, e_ in ev)
-            totals.append((t, k, f, len(ev)))
+            totals.append((sum(s_.elapsed_time(e_) for s_, e_ in ev), k, f, len(ev)))
     totals.sort(reverse=True)
-    step_ms_events = dt / args.steps * 1e3          # share_of_step is relative to the measured step time
-
-    def roof_entry(t, k, f, n):
-        a = f / (t / n * 1e-3) / 1e12
-        name = {"conv": "conv_mfma_kernel", "conv_up2": "conv_up2_kernel", "conv_bf16x3": "conv_bf16x3_kernel",
-                "conv_up2_x3": "conv_up2_bf16x3_kernel"}[k[0]]
-        x3 = k[0] in ("conv_bf16x3", "conv_up2_x3")
-        peak = PEAK_BF16X3_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
-        return {"bound": "mfma", "kernel": "%s %s" % (name, list(k)), "achieved": round(a, 2), "peak": round(peak, 1),
-                "peak_basis": ("2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per fp32 product (3xBF16 split, fp32-accurate)" if x3
-                               else "157.3 TFLOP/s fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
-                "unit": "TFLOP/s", "frac": round(a / peak, 4), "traffic": None,
-                "algorithmic_flop_per_launch": f, "avg_launch_ms": round(t / n, 4), "launches": n,
-                "share_of_step": round(t / args.steps / step_ms_events, 4)}
-
-    roofline = roof_entry(*totals[0]) if totals else None
-    # HBM bytes per launch of the dominant kernel from the committed PMC passes (separate --pmc runs, profiles/)
-    tp = os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")
-    if roofline and os.path.exists(tp):
-        ent = json.load(open(tp)).get("kernels", {}).get(json.dumps(list(totals[0][1])))
-        if ent:
-            roofline["traffic"] = ent["hbm_bytes_per_launch"]
-            roofline["traffic_unit"] = "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_g_pmc_traffic.json)"
-    roofline_next = [roof_entry(*x) for x in totals[1:4]]
-    tail_ms, tail_n = avg_ms(key_tail)
-    hw1 = (H // 2) * (H // 2)
-    tail_bytes = 20.0 * C1 * B * hw1                                 # read z,h_aff,h_ft + write z (SURVEY 8d)
+    roofline = roof_entry(*totals[0], args.steps, step_ms, traffic_db) if totals else None
+    roofline_next = [roof_entry(*x, args.steps, step_ms, traffic_db) for x in totals[1:4]]
+    by_symbol = [{"kernel": fam, "ms_per_step": round(t, 3), "share_of_event_time": round(t / warm_total_ms, 4)}
+                 for fam, t in sorted(warm_by_family.items(), key=lambda kv: -kv[1])[:8]] if warm_total_ms else None
     roof_tail = None
-    if tail_ms:
+    if key_tail and ops.profile.get(key_tail):
+        ev = ops.profile[key_tail]
+        tail_ms = sum(s.elapsed_time(e) for s, e in ev) / len(ev)
+        tail_bytes = 20.0 * C1 * B * (H // 2) * (H // 2)                 # read z,h_aff,h_ft + write z
         a = tail_bytes / (tail_ms * 1e-3) / 1e9
         roof_tail = {"bound": "hbm", "kernel": "flow_pointwise_kernel<12,4> reverse (level-1 FlowStep inverse tail)",
                      "achieved": round(a, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(a / PEAK_HBM_GBS, 4),
-                     "traffic": None, "avg_launch_ms": round(tail_ms, 4), "launches": tail_n}
+                     "traffic": None, "algorithmic_bytes_per_launch": tail_bytes, "avg_launch_ms": round(tail_ms, 4), "launches": len(ev)}
 
-    # the same workload with every contraction on the native fp32 MFMA (BFSR_CONV=f32 engines), reported beside `value`
+    # ---- config 2: the same workload with every contraction on the native fp32 MFMA, reported beside `value` --------------
     fp32_only = None
-    if rank == 0 and world == 1 and ops.conv_mode != "f32" and not args.no_fp32_line and args.mode == "lp":
+    if cfg == 2 and rank == 0 and world == 1 and ops.conv_mode != "f32" and not args.no_fp32_line and args.mode == "lp":
         ops32 = HipOps(dev)
         ops32.conv_mode = "f32"
         m32 = create_model(opt, ops=ops32)
@@ -221,73 +328,93 @@ def main():
         del m32, p32, ops32
         torch.cuda.empty_cache()
 
+    # ---- CPU baseline (rank 0, N = 1 only) + parity of the HIP path on the same sample -------------------------------------
     cpu_baseline, parity = None, None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "tau":
-        import numpy as np
-        import oracle.srflow_ref as O          # checker / baseline only
-        cl = args.cpu_lr
-        x = synth.lr_batch(99, 1, cl, cl)
-        g = np.random.Generator(np.random.PCG64(4999))
-        ep = [torch.from_numpy((0.9 * g.standard_normal((1, 6, cl * scale // 2, cl * scale // 2))).astype(np.float32)),
-              torch.from_numpy((0.9 * g.standard_normal((1, 96, cl * scale // 8, cl * scale // 8))).astype(np.float32))]
-        torch.set_num_threads(min(16, os.cpu_count() or 1))
-        t1 = time.perf_counter()
-        ref = O.srflow_decode(x, ep, sd, opt, opt["network_G"]["nb"])
-        cdt = time.perf_counter() - t1
-        cpu_baseline = {"value": round((cl * scale) ** 2 / 1e6 / cdt, 5), "unit": "MPix/s", "cores": torch.get_num_threads(),
-                        "kind": "port", "sample": "1 image %dx%d->%dx%d, oracle srflow_decode (RRDB + reverse flow), %.1f s"
-                                                  % (cl, cl, cl * scale, cl * scale, cdt)}
-        out = model.netG.module.engine().decode(ops.to_device(x), epses=[ops.to_device(e) for e in ep])
-        torch.cuda.synchronize()
-        parity = {"max_abs_sr_raw": float((out.cpu() - ref).abs().max()), "ref_absmax_sr_raw": float(ref.abs().max()),
-                  "sample": "same %dx%d image and eps vs oracle" % (cl, cl)}
-    elif rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import oracle.srflow_ref as O          # checker / baseline only
-        cl = args.cpu_lr
-        x = synth.lr_batch(99, 1, cl, cl)
-        # the oracle is a torch-CPU program: with all 128+ hardware threads MKL-DNN is badly oversubscribed on the
-        # small convs, so the sample is timed at two pool sizes and the faster one is reported (threads stated)
-        best = None
-        for nt in sorted(set([min(16, os.cpu_count() or 1), min(32, os.cpu_count() or 1)])):
-            torch.set_num_threads(nt)
-            t1 = time.perf_counter()
-            ref = O.lp_pipeline(x, sd, psd, opt, opt["network_G"]["nb"], return_all=True)
-            cdt = time.perf_counter() - t1
-            if best is None or cdt < best[0]:
-                best = (cdt, nt)
-        cdt, nt = best
-        cpu_baseline = {"value": round((cl * scale) ** 2 / 1e6 / cdt, 5), "unit": "MPix/s",
-                        "cores": nt, "kind": "port",
-                        "sample": "1 image %dx%d->%dx%d, oracle lp_pipeline (reference op order, RRDB twice), best of "
-                                  "16/32 threads on a %d-thread host, %.1f s" % (cl, cl, cl * scale, cl * scale,
-                                                                                 os.cpu_count() or 0, cdt)}
-        out = lp_infer(model, prior, x, return_all=True)
-        torch.cuda.synchronize()
-        parity = {"max_abs_sr": float((out["sr"].cpu() - ref["sr"]).abs().max()),
-                  "max_abs_sr_raw": float((out["sr_raw"].cpu() - ref["sr_raw"]).abs().max()),
-                  "ref_absmax_sr_raw": float(ref["sr_raw"].abs().max()),
-                  "sample": "same %dx%d image vs oracle" % (cl, cl)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        ncpu = os.cpu_count() or 1
+        nt = min(32, ncpu)        # the oracle is a torch-CPU program: beyond ~32 threads MKL-DNN is oversubscribed on these convs
+        torch.set_num_threads(nt)
+        if srflow:
+            import numpy as np
+            import oracle.srflow_ref as O          # checker / baseline only
+            cl = args.cpu_lr or (160 if cfg == 2 else 96)
+            x = synth.lr_batch(99, 1, cl, cl)
+            nb = opt["network_G"]["nb"]
+            if args.mode == "tau":
+                g = np.random.Generator(np.random.PCG64(4999))
+                ep = [torch.from_numpy((0.9 * g.standard_normal((1, 6, cl * scale // 2, cl * scale // 2))).astype(np.float32)),
+                      torch.from_numpy((0.9 * g.standard_normal((1, 96, cl * scale // 8, cl * scale // 8))).astype(np.float32))]
+                med, ts, ref = median_time(lambda: O.srflow_decode(x, ep, sd, opt, nb))
+                what = "oracle srflow_decode (RRDB + reverse flow)"
+                out = model.netG.module.engine().decode(ops.to_device(x), epses=[ops.to_device(e) for e in ep])
+                torch.cuda.synchronize()
+                parity = {"max_abs_sr_raw": float((out.cpu() - ref).abs().max()), "ref_absmax_sr_raw": float(ref.abs().max()),
+                          "sample": "same %dx%d image and eps vs oracle" % (cl, cl)}
+            else:
+                med, ts, ref = median_time(lambda: O.lp_pipeline(x, sd, psd, opt, nb, return_all=True))
+                what = "oracle lp_pipeline (reference op order, RRDB twice)"
+                out = lp_infer(model, prior, x, return_all=True)
+                torch.cuda.synchronize()
+                parity = {"max_abs_sr": float((out["sr"].cpu() - ref["sr"]).abs().max()),
+                          "max_abs_sr_raw": float((out["sr_raw"].cpu() - ref["sr_raw"]).abs().max()),
+                          "ref_absmax_sr_raw": float(ref["sr_raw"].abs().max()), "sample": "same %dx%d image vs oracle" % (cl, cl)}
+            hr = cl * scale
+        else:
+            import oracle.linf_ref as O            # checker / baseline only
+            cl = args.cpu_lr or 96                 # bounded sample (the full 256x256 crop takes > 30 s per run on the host)
+            hr = int(round(cl * scale))
+            x = synth.lr_batch(99, 1, cl, cl)
+
+            def run():
+                return O.lp_pipeline(O.batch_prep(x, (hr, hr)), sd, psd, mspec, (hr, hr), return_all=True)
+            med, ts, ref = median_time(run)
+            what = "oracle LINF lp_pipeline (input prep + encoder + query_log_p + prior + query_rgb, 256-row chunks)"
+            out = infer_from_lr(model, prior, x, scale, return_all=True)
+            torch.cuda.synchronize()
+            parity = {"max_abs_pred": float((out["pred"].cpu() - ref["pred"]).abs().max()),
+                      "max_abs_z_lr": float((out["z_lr"].cpu() - ref["z_lr"]).abs().max()),
+                      "ref_absmax_z_lr": float(ref["z_lr"].abs().max()), "precision": "fp32" if cfg == 3 else "fp16 MFMA path vs fp32 oracle",
+                      "sample": "same %dx%d image vs oracle" % (cl, cl)}
+        cpu_baseline = {"value": round(hr * hr / 1e6 / med, 5), "unit": "MPix/s", "cores": nt, "host_cpu_count": ncpu, "kind": "port",
+                        "sample": "1 image %dx%d->%dx%d, %s; 1 warm-up + median of 3 runs (%s s) at torch.set_num_threads(%d)"
+                                  % (cl, cl, hr, hr, what, ", ".join("%.1f" % t for t in ts), nt)}
 
     if rank == 0:
+        if srflow:
+            name = "SRFlow-LP %dx flow-inverse SR (%d->%d)" % (scale, h, H)
+            path = ("LP path: RRDB + encode + standardise + prior UNet + decode + clamp" if args.mode == "lp"
+                    else "tau=0.9 sampling path (RRDB + decode, no encode/prior)")
+            wl = "SRFlow-LP %dx %s (K=16,L=3,nb=23), " % (scale, "DF2K config" if scale == 4 else "config derived from the 4X yml (scale 8, L 3)")
+            arithmetic = ("fp32 tensors and accumulation; 3x3 convs with >=32 input channels contract on the bf16 MFMA with the exact 3-term "
+                          "bf16 split of both operands (6 cross products, error vs fp64 = native fp32 MFMA's, "
+                          "tests/test_hip_ops.py::test_conv_bf16x3_is_fp32_accurate; RRDB block activations are STORED as that exact split "
+                          "= lossless); everything else native fp32" if ops.conv_mode == "x3" else "native fp32 MFMA / fp32 VALU")
+            dtype = "f32"
+        else:
+            name = "LINF-LP rrdb-linf-LP x%g arbitrary-scale SR (%d->%d)" % (scale, h, H)
+            path = "LP path: input prep + RRDB encoder + query_log_p + prior UNet + query_rgb + fold + skip + clamp"
+            wl = "LINF-LP rrdb-linf-LP, "
+            arithmetic = ("fp32-accurate 3xBF16 contraction (see config 2)" if cfg == 3 else
+                          "fp16 MFMA path (BASELINE config 5): encoder / coef|freq / MLP / prior contractions round their operands to fp16, "
+                          "fp32 accumulation, fp32 tensors, the flow itself in fp32; tolerance vs the fp32 reference 1e-3 on the output "
+                          "(tests/test_linf_gpu.py::test_fp16_mfma_path_vs_reference_golden)")
+            dtype = "f32" if cfg == 3 else "f16"
+        batch_txt = ("batch=%d/GPU" % B) if scaling == "weak" else ("named batch of %d crops sharded over %d GPU(s) = %d/GPU" % (global_B, world, B))
         line = {
-            "metric": "HR MPix/s, SRFlow-LP %dx flow-inverse SR (%d->%d), %s" % (
-                scale, h, H, "LP pipeline" if args.mode == "lp" else "tau=0.9 sampling path (RRDB + decode, no encode/prior)"),
+            "metric": "HR MPix/s, %s, %s" % (name, "LP pipeline" if args.mode == "lp" or not srflow else path),
             "value": round(value, 4), "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "arithmetic": ("fp32 tensors and accumulation; 3x3 convs with >=32 input channels contract on the bf16 MFMA with the "
-                           "exact 3-term bf16 split of both operands (6 cross products, error vs fp64 = native fp32 MFMA's, "
-                           "tests/test_hip_ops.py::test_conv_bf16x3_is_fp32_accurate); everything else native fp32"
-                           if ops.conv_mode == "x3" else "native fp32 MFMA / fp32 VALU"),
-            "value_native_fp32_mfma": fp32_only,
-            "config": {"workload": "SRFlow-LP " + str(scale) + "x DF2K config (K=16,L=3,nb=23), batch=%d/GPU %dx%d LR synthetic -> %dx%d, "
-                                   "LP path: RRDB + encode + standardise + prior UNet + decode + clamp%s"
-                                   % (B, h, h, H, H, ", + RCCL all-gather of outputs" if world > 1 else ""),
-                       "parallelism": "dp%d" % world, "weights": "seeded synthetic (conditioned recipe)"},
-            "roofline": roofline, "roofline_next_kernels": roofline_next, "roofline_coupling_inverse": roof_tail,
-            "cpu_baseline": cpu_baseline,
-            "parity": parity,
+            "ms_per_step": round(step_ms, 3), "higher_is_better": True, "scaling": scaling,
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic", "arithmetic": arithmetic,
+            "config": {"baseline_config": cfg,
+                       "workload": wl + "%s %dx%d LR synthetic -> %dx%d, %s%s" % (
+                           batch_txt, h, h, H, H, path, ", + double-buffered RCCL all-gather of outputs" if world > 1 else ""),
+                       "parallelism": "dp%d" % world, "global_batch": global_B, "weights": "seeded synthetic (conditioned recipe)"},
+            "roofline": roofline, "roofline_next_kernels": roofline_next, "roofline_by_symbol": by_symbol,
+            "roofline_coupling_inverse": roof_tail,
+            "cpu_baseline": cpu_baseline, "parity": parity,
         }
+        if fp32_only is not None or cfg == 2:
+            line["value_native_fp32_mfma"] = fp32_only
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -60,6 +60,46 @@ def all_gather_batch(local_out, total=None):
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0)
 
 
+class AsyncGatherer(object):
+    """Double-buffered all-gather of the per-step outputs: `submit(out_i)` starts the collective for
+    step i without blocking the compute stream, so the gather of step i runs over xGMI while step i+1 computes; it first
+    completes the gather of step i-1 (two output buffers alternate).  `finish()` completes whatever is in flight and returns
+    the last gathered batch.  The collective is RCCL's all_gather_into_tensor on its own internal stream (`async_op=True`);
+    the local output is kept referenced until its gather has completed, so the caching allocator cannot recycle it early.
+    With one process (world 1) it degenerates to returning the local output."""
+
+    def __init__(self, total):
+        self.total, self.bufs, self.pending, self.n, self.last = total, [None, None], None, 0, None
+
+    def submit(self, local_out):
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            self.last = local_out
+            return
+        self._complete()
+        world = dist.get_world_size()
+        if self.total % world != 0 or local_out.shape[0] * world != self.total:
+            self.last = all_gather_batch(local_out, total=self.total)          # ragged shards: synchronous path
+            return
+        i = self.n & 1
+        shape = (self.total,) + tuple(local_out.shape[1:])
+        if self.bufs[i] is None or tuple(self.bufs[i].shape) != shape:
+            self.bufs[i] = local_out.new_empty(shape)
+        src = local_out.contiguous()
+        work = dist.all_gather_into_tensor(self.bufs[i], src, async_op=True)
+        self.pending = (work, self.bufs[i], src)
+        self.n += 1
+
+    def _complete(self):
+        if self.pending is not None:
+            work, buf, _src = self.pending
+            work.wait()                     # orders the current stream after the collective
+            self.last, self.pending = buf, None
+
+    def finish(self):
+        self._complete()
+        return self.last
+
+
 def barrier():
     if dist.is_initialized():
         dist.barrier()

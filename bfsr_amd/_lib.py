@@ -67,6 +67,19 @@ class BfsrLinfFeatArgs(C.Structure):
     ]
 
 
+class BfsrLinfMlpArgs(C.Structure):
+    _fields_ = [
+        ("cf", C.c_void_p), ("cf_bs", C.c_longlong),
+        ("coord", C.c_void_p), ("cell", C.c_void_p), ("phase", C.c_void_p),
+        ("wts", C.c_void_p), ("bias", C.c_void_p),
+        ("out", C.c_void_p), ("out_bs", C.c_longlong),
+        ("B", C.c_int), ("hidden", C.c_int), ("Cout", C.c_int), ("h", C.c_int), ("w", C.c_int), ("qh", C.c_int), ("qw", C.c_int),
+        ("dy_neg", C.c_float), ("dy_pos", C.c_float), ("dx_neg", C.c_float), ("dx_pos", C.c_float),
+        ("clamp_lo", C.c_float), ("clamp_hi", C.c_float),
+        ("cy0", C.c_float), ("cy1", C.c_float), ("cx0", C.c_float), ("cx1", C.c_float),
+    ]
+
+
 class BfsrLinfFlowArgs(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("x_bs", C.c_longlong),
@@ -114,6 +127,9 @@ SYMBOLS = {
     "bfsr_maxpool2": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
     "bfsr_axpb_clamp": (_I, [_VP, _LL, _VP, _LL, _VP, _LL, _I, _I, _I, _I, _F, _F, _F, _F, _VP]),
     "bfsr_linf_features": (_I, [C.POINTER(BfsrLinfFeatArgs), _VP]),
+    "bfsr_linf_mlp": (_I, [C.POINTER(BfsrLinfMlpArgs), _I, _VP]),
+    "bfsr_linf_mlp_packed_size": (_LL, [_I, _I, _I]),
+    "bfsr_pack_linf_mlp": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
     "bfsr_logscale_sum": (_I, [_VP, _LL, _I, _I, _LL, _F, C.c_double, _VP, _VP]),
     "bfsr_gaussian_logp": (_I, [_VP, _LL, _VP, _LL, _I, _I, _LL, C.c_double, _VP, _VP]),
     "bfsr_linf_flow": (_I, [C.POINTER(BfsrLinfFlowArgs), _VP]),

@@ -1,0 +1,370 @@
+// linf_mlp.hip -- fused per-point conditioning of LINF-LP: local-ensemble Fourier features -> shared MLP -> affine_info
+// (LINF-LP/models/linf.py:324-391: the K12 prologue + K13 MLP of SURVEY section 7 item 6), one kernel.
+//
+//   features[1024] = cat_k ( w_k * coef_k (.) [cos(pi f_k) | sin(pi f_k)] ),  f_k = freq_k . rel_k + phase(rel_cell)   (k = 4 neighbours)
+//   affine_info    = W4 relu(W3 relu(W2 relu(W1 features + b1) + b2) + b3) + b4        (1024 -> 256 -> 256 -> 256 -> 2*D*L = 540)
+//
+// Before this kernel the 1024-channel feature tensor ([B,1024,Q,Q] fp32, 7.7 GB at BASELINE config 3 x4) and the three 256-channel
+// hidden tensors went through HBM between five launches; here a workgroup keeps a tile of P = 64 query points on chip from the
+// coef|freq gather to the 540 conditioning channels:
+//   * 8 waves; wave w owns output rows 32w..32w+31 of every layer (M = 256 = 8 x 32; the 540-row last layer = 17 tiles, waves take
+//     tiles w, w+8, w+16), N = 64 points = 2 MFMA column tiles, accumulators stay in registers across the whole K loop;
+//   * activations live in LDS as MFMA B fragments ([16-channel chunk][plane][k half][64 points][8]): layer 1 consumes the features
+//     in 8 intervals of 128 channels (wave w generates chunk w of an interval with lane = point: 32 gathers from the coef|freq map,
+//     8 sincosf, split, 6 ds_write_b128), double-buffered so the VALU work of interval t+1 sits next to the MFMAs of interval t;
+//     layers 2-4 read the previous layer's output, which the epilogue wrote back into the same LDS region (98 KB in the 3xBF16
+//     arithmetic) after a v_permlane32_swap transposition to channel octets;
+//   * weights are NOT staged: every wave needs different rows, so its A fragments (16 B per lane) are loaded straight from
+//     global/L2 into registers, three chunks ahead (3.1 MB of packed weights, L2-resident, read once per workgroup);
+//   * arithmetic: X3 = fp32-accurate 3xBF16 split (six v_mfma_f32_32x32x16_bf16 per operand pair, the default); otherwise operands
+//     rounded to fp16 (precision='fp16', BASELINE config 5).  Features are computed in fp32 with exactly the operation order of
+//     linf_features_kernel (linf_ops.hip), accumulation / bias / ReLU in fp32.
+// affine_info [B, 540, Q, Q] fp32 is still written to HBM once: it is read twice (query_log_p and query_rgb, linf_flow_kernel).
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "../../include/bfsr_hip.h"
+#include "launch_util.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int NW = 8, P = 64, HID = 256, KC = 16;
+constexpr int K1 = 4 * HID;                    // 1024 feature channels
+constexpr int NCH_HID = HID / KC;              // 16 chunks of 16 channels in a hidden activation
+
+template <bool X3> struct Mode;
+template <> struct Mode<true> {
+    static constexpr int PL = 3;
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mode<false> {
+    static constexpr int PL = 1;
+    typedef f16x8 frag;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+__device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l)
+{
+    h = (__bf16)v;
+    const float r1 = v - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+
+// 8 fp32 values of one point (8 consecutive channels of a chunk half) -> PL fragments of 16 B
+template <bool X3>
+__device__ __forceinline__ void encode8(const float (&v)[8], typename Mode<X3>::frag (&out)[Mode<X3>::PL])
+{
+    if constexpr (X3) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { __bf16 h, m, l; split3(v[e], h, m, l); out[0][e] = h; out[1][e] = m; out[2][e] = l; }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[0][e] = (_Float16)v[e];
+    }
+}
+
+template <bool X3>
+__global__ __launch_bounds__(NW * 64, 1) void linf_mlp_kernel(BfsrLinfMlpArgs a, int tiles_per_image)
+{
+    typedef Mode<X3> MD;
+    typedef typename MD::frag frag;
+    constexpr int PL = MD::PL;
+    constexpr int CHUNK = PL * 2 * P * 16;            // bytes of one 16-channel activation chunk: [plane][k half][64 points][8]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 16 chunks: stage A = chunks 0-7, stage B = 8-15
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int b = blockIdx.x / tiles_per_image;
+    const long long NQ = (long long)a.qh * a.qw;
+    const long long q0 = (long long)(blockIdx.x - b * tiles_per_image) * P;
+    const long long q = q0 + lane;                     // this lane's query point during feature generation
+    const bool qok = q < NQ;
+
+    // ---- per-point geometry, identical arithmetic to linf_features_kernel (linf.py:332-383) ------------------------------
+    const int h = a.h, w = a.w;
+    const float fh = (float)h, fw = (float)w;
+    float rel_y[4], rel_x[4], wk[4];
+    int off[4];
+    {
+        const long long qq = qok ? q : NQ - 1;
+        const float cy = a.coord[((long long)b * NQ + qq) * 2 + 0];
+        const float cx = a.coord[((long long)b * NQ + qq) * 2 + 1];
+        float area[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float y = cy + ((j & 2) ? a.dy_pos : a.dy_neg);
+            float x = cx + ((j & 1) ? a.dx_pos : a.dx_neg);
+            y = fminf(fmaxf(y, a.clamp_lo), a.clamp_hi);
+            x = fminf(fmaxf(x, a.clamp_lo), a.clamp_hi);
+            int jy = (int)nearbyintf(((y + 1.f) * fh - 1.f) / 2.f);
+            int jx = (int)nearbyintf(((x + 1.f) * fw - 1.f) / 2.f);
+            jy = min(max(jy, 0), h - 1);
+            jx = min(max(jx, 0), w - 1);
+            const float qy = a.cy0 + a.cy1 * (float)jy;
+            const float qx = a.cx0 + a.cx1 * (float)jx;
+            rel_y[j] = (cy - qy) * fh; rel_x[j] = (cx - qx) * fw;
+            area[j] = fabsf(rel_y[j] * rel_x[j]) + 1e-9f;
+            off[j] = jy * w + jx;
+        }
+        const float tot = ((area[0] + area[1]) + area[2]) + area[3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wk[j] = area[3 - j] / tot;
+    }
+    const float cell_y = a.cell[b * 2 + 0] * fh, cell_x = a.cell[b * 2 + 1] * fw;
+    const long long hw = (long long)h * w;
+    const float* __restrict__ cfb = a.cf + (long long)b * a.cf_bs;
+    const float PI = 3.14159274101257324f;
+
+    // chunk kc (0..63) of the feature vector: neighbour k = kc / 16, pairs c0 = (kc % 16) * 8 .. +7;
+    // k half 0 = cos features (channel k*256 + c), k half 1 = sin features (channel k*256 + 128 + c): W1 is packed in this order
+    // k is wave-uniform but not a compile-time constant: the four per-neighbour values are picked with selects (an array
+    // indexed by a run-time k would be demoted to scratch memory)
+    auto gen_chunk = [&](int k, int c0, unsigned char* dst) {
+        const float ry = k == 0 ? rel_y[0] : (k == 1 ? rel_y[1] : (k == 2 ? rel_y[2] : rel_y[3]));
+        const float rx = k == 0 ? rel_x[0] : (k == 1 ? rel_x[1] : (k == 2 ? rel_x[2] : rel_x[3]));
+        const float wgt = k == 0 ? wk[0] : (k == 1 ? wk[1] : (k == 2 ? wk[2] : wk[3]));
+        const int ofs = k == 0 ? off[0] : (k == 1 ? off[1] : (k == 2 ? off[2] : off[3]));
+        const float* cfp = cfb + ofs;
+        float vc[8], vs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            const float co0 = cfp[(long long)c * hw], co1 = cfp[(long long)(HID / 2 + c) * hw];
+            const float f0 = cfp[(long long)(HID + c) * hw], f1 = cfp[(long long)(HID + HID / 2 + c) * hw];
+            float f = f0 * ry + f1 * rx;
+            f = f + (cell_y * a.phase[c * 2 + 0] + cell_x * a.phase[c * 2 + 1]);
+            float s, cs;
+            sincosf(PI * f, &s, &cs);
+            vc[e] = (wgt * co0) * cs;
+            vs[e] = (wgt * co1) * s;
+        }
+        frag fc[PL], fs[PL];
+        encode8<X3>(vc, fc);
+        encode8<X3>(vs, fs);
+#pragma unroll
+        for (int pl = 0; pl < PL; ++pl) {
+            *reinterpret_cast<frag*>(dst + ((pl * 2 + 0) * P + lane) * 16) = fc[pl];
+            *reinterpret_cast<frag*>(dst + ((pl * 2 + 1) * P + lane) * 16) = fs[pl];
+        }
+    };
+
+    // ---- weights: packed [layer][m tile][k chunk][plane][64 lanes][8]; this lane's fragment of (tile, chunk, plane) is 16 B
+    const unsigned short* __restrict__ wbase = a.wts;
+    auto load_a = [&](const unsigned short* wl, int nchunk, int mt, int kc, frag (&dst)[PL]) {
+        const unsigned short* p = wl + (((long long)mt * nchunk + kc) * PL * 64 + lane) * 8;
+#pragma unroll
+        for (int pl = 0; pl < PL; ++pl) dst[pl] = *reinterpret_cast<const frag*>(p + pl * 64 * 8);
+    };
+    auto load_b = [&](const unsigned char* chunk, frag (&dst)[PL][2]) {
+#pragma unroll
+        for (int pl = 0; pl < PL; ++pl)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                dst[pl][nt] = *reinterpret_cast<const frag*>(chunk + ((pl * 2 + lhi) * P + nt * 32 + l31) * 16);
+    };
+    // acc[nt] += A(tile) x B(chunk): X3 = six cross products, small terms first
+    auto mma = [&](f32x16 (&acc)[2], const frag (&af)[PL], const frag (&bf)[PL][2]) {
+        if constexpr (X3) {
+#define BFSR_T(PA_, PB_) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) acc[nt] = MD::mfma(af[PA_], bf[PB_][nt], acc[nt]);
+            BFSR_T(2, 0) BFSR_T(0, 2) BFSR_T(1, 1) BFSR_T(1, 0) BFSR_T(0, 1) BFSR_T(0, 0)
+#undef BFSR_T
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[nt] = MD::mfma(af[0], bf[0][nt], acc[nt]);
+        }
+    };
+    // one output tile of a hidden layer -> bias, ReLU, channel-octet transposition, re-encode, write as activation chunks
+    auto store_hidden = [&](const f32x16 (&acc)[2], const float* __restrict__ bias, int mt) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            float v[2][8];
+            asm volatile("s_nop 11" ::: "memory");                 // MFMA result -> VALU read inside the asm below
+#pragma unroll
+            for (int qd = 0; qd < 2; ++qd)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float lo = acc[nt][8 * qd + i], hi = acc[nt][8 * qd + 4 + i];
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+                    v[qd][i] = lo; v[qd][4 + i] = hi;
+                }
+#pragma unroll
+            for (int qd = 0; qd < 2; ++qd) {
+                const int oct = qd * 2 + lhi;                        // channel octet inside the 32-row tile
+                const int ch0 = mt * 32 + oct * 8;
+                float u[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float t = v[qd][e] + bias[ch0 + e]; u[e] = t > 0.f ? t : 0.f; }
+                frag fr[PL];
+                encode8<X3>(u, fr);
+                unsigned char* dst = smem + (ch0 >> 4) * CHUNK;
+#pragma unroll
+                for (int pl = 0; pl < PL; ++pl)
+                    *reinterpret_cast<frag*>(dst + ((pl * 2 + (oct & 1)) * P + nt * 32 + l31) * 16) = fr[pl];
+            }
+        }
+    };
+
+    // =============================== layer 1: features (K = 1024) -> 256, feature generation interleaved =================
+    const unsigned short* w1 = wbase;
+    constexpr long long WSZ1 = (long long)(HID / 32) * (K1 / KC) * PL * 64 * 8;
+    constexpr long long WSZH = (long long)(HID / 32) * NCH_HID * PL * 64 * 8;
+    f32x16 acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    gen_chunk(0, wave * 8, smem + wave * CHUNK);                      // interval 0 (chunk kc = wave) -> stage A
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < 8; ++t) {
+        // interval t+1: chunk kc = (t+1)*8 + wave -> neighbour (t+1)/2, pair block kc % 16
+        if (t + 1 < 8) gen_chunk((t + 1) >> 1, ((((t + 1) & 1) * 8) + wave) * 8, smem + (((t + 1) & 1) * 8 + wave) * CHUNK);
+        const unsigned char* stage = smem + (t & 1) * 8 * CHUNK;
+        frag af[2][PL], bf[PL][2];
+        load_a(w1, K1 / KC, wave, t * 8, af[0]);
+#pragma unroll 2
+        for (int c = 0; c < 8; ++c) {
+            if (c + 1 < 8) load_a(w1, K1 / KC, wave, t * 8 + c + 1, af[(c + 1) & 1]);
+            load_b(stage + c * CHUNK, bf);
+            mma(acc, af[c & 1], bf);
+        }
+        __syncthreads();
+    }
+    store_hidden(acc, a.bias, wave);                                 // all waves are past the last interval's reads (barrier above)
+    __syncthreads();
+
+    // =============================== layers 2, 3: 256 -> 256 ==============================================================
+    for (int layer = 1; layer <= 2; ++layer) {
+        const unsigned short* wl = wbase + WSZ1 + (layer - 1) * WSZH;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        frag af[2][PL], bf[PL][2];
+        load_a(wl, NCH_HID, wave, 0, af[0]);
+#pragma unroll 2
+        for (int c = 0; c < NCH_HID; ++c) {
+            if (c + 1 < NCH_HID) load_a(wl, NCH_HID, wave, c + 1, af[(c + 1) & 1]);
+            load_b(smem + c * CHUNK, bf);
+            mma(acc, af[c & 1], bf);
+        }
+        __syncthreads();                                             // everybody has read the layer input
+        store_hidden(acc, a.bias + layer * HID, wave);
+        __syncthreads();
+    }
+
+    // =============================== layer 4: 256 -> Cout (540), fp32 to HBM ==============================================
+    {
+        const unsigned short* wl = wbase + WSZ1 + 2 * WSZH;
+        const float* __restrict__ b4 = a.bias + 3 * HID;
+        const int mtiles = (a.Cout + 31) / 32;
+        float* __restrict__ outb = a.out + (long long)b * a.out_bs;
+        for (int mt = wave; mt < mtiles; mt += NW) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+            frag af[2][PL], bf[PL][2];
+            load_a(wl, NCH_HID, mt, 0, af[0]);
+#pragma unroll 2
+            for (int c = 0; c < NCH_HID; ++c) {
+                if (c + 1 < NCH_HID) load_a(wl, NCH_HID, mt, c + 1, af[(c + 1) & 1]);
+                load_b(smem + c * CHUNK, bf);
+                mma(acc, af[c & 1], bf);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const long long qq = q0 + nt * 32 + l31;
+                if (qq >= NQ) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    if (co < a.Cout) outb[(long long)co * NQ + qq] = acc[nt][r] + b4[co];
+                }
+            }
+        }
+    }
+}
+
+template <bool X3>
+int launch_mlp(const BfsrLinfMlpArgs& a, hipStream_t st)
+{
+    constexpr int LDS = 16 * Mode<X3>::PL * 2 * P * 16;              // 98 304 B (x3) / 32 768 B (fp16)
+    static std::atomic<unsigned long long> lds_done{0};
+    if (LDS > 65536 && bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&linf_mlp_kernel<X3>), LDS, lds_done) != 0) return -1;
+    const long long NQ = (long long)a.qh * a.qw;
+    const long long tiles = (NQ + P - 1) / P;
+    const long long nblk = tiles * a.B;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return -1;
+    hipLaunchKernelGGL(linf_mlp_kernel<X3>, dim3((unsigned)nblk), dim3(NW * 64), LDS, st, a, (int)tiles);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" long long bfsr_linf_mlp_packed_size(int hidden, int Cout, int x3)
+{
+    if (hidden != HID || Cout <= 0) return -1;
+    const long long PL = x3 ? 3 : 1;
+    const long long mt4 = (Cout + 31) / 32;
+    return ((long long)(HID / 32) * (K1 / KC) + 2LL * (HID / 32) * NCH_HID + mt4 * NCH_HID) * PL * 64 * 8;      // 16-bit elements
+}
+
+// w1 [256][1024], w2, w3 [256][256], w4 [Cout][256] (row-major fp32, the nn.Conv2d 1x1 weights of linf.py:231-240) -> the
+// per-lane fragment order of linf_mlp_kernel: [layer][m tile][k chunk][plane][lane = k half*32 + row][8].  Layer 1's K axis is
+// regrouped per neighbour into (cos | sin) halves: chunk kc = k*16 + cb, half 0 -> channel k*256 + cb*8 + e, half 1 -> k*256 + 128 + cb*8 + e.
+extern "C" int bfsr_pack_linf_mlp(const float* w1, const float* w2, const float* w3, const float* w4, int hidden, int Cout, int x3,
+                                  unsigned short* packed)
+{
+    if (hidden != HID || Cout <= 0 || !w1 || !w2 || !w3 || !w4 || !packed) return -1;
+    const int PL = x3 ? 3 : 1;
+    long long o = 0;
+    auto encode = [&](float v, unsigned short (&out)[3]) {
+        if (x3) {
+            float r = v;
+            for (int i = 0; i < 3; ++i) { const __bf16 hb = (__bf16)r; __builtin_memcpy(&out[i], &hb, 2); r -= (float)hb; }
+        } else {
+            const _Float16 hf = (_Float16)v;
+            __builtin_memcpy(&out[0], &hf, 2);
+        }
+    };
+    auto pack_layer = [&](const float* W, int rows, int K, bool feature_order) {
+        const int mtiles = (rows + 31) / 32, nchunk = K / KC;
+        for (int mt = 0; mt < mtiles; ++mt)
+            for (int kc = 0; kc < nchunk; ++kc) {
+                unsigned short* dst = packed + o + ((long long)mt * nchunk + kc) * PL * 64 * 8;
+                for (int ln = 0; ln < 64; ++ln) {
+                    const int row = mt * 32 + (ln & 31), half = ln >> 5;
+                    for (int e = 0; e < 8; ++e) {
+                        int kidx;
+                        if (feature_order) { const int k = kc >> 4, cb = kc & 15; kidx = k * HID + half * (HID / 2) + cb * 8 + e; }
+                        else kidx = kc * KC + half * 8 + e;
+                        unsigned short s3[3] = {0, 0, 0};
+                        if (row < rows) encode(W[(long long)row * K + kidx], s3);
+                        for (int pl = 0; pl < PL; ++pl) dst[(pl * 64 + ln) * 8 + e] = s3[pl];
+                    }
+                }
+            }
+        o += (long long)mtiles * nchunk * PL * 64 * 8;
+    };
+    pack_layer(w1, HID, K1, true);
+    pack_layer(w2, HID, HID, false);
+    pack_layer(w3, HID, HID, false);
+    pack_layer(w4, Cout, HID, false);
+    return 0;
+}
+
+extern "C" int bfsr_linf_mlp(const BfsrLinfMlpArgs* a, int x3, void* stream)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!a || !a->cf || !a->coord || !a->cell || !a->phase || !a->wts || !a->bias || !a->out) return -1;
+    if (a->hidden != HID || a->Cout <= 0 || a->Cout > 24 * 32 || a->B <= 0 || a->h <= 0 || a->w <= 0 || a->qh <= 0 || a->qw <= 0) return -1;
+    BfsrLinfMlpArgs c = *a;
+    return x3 ? launch_mlp<true>(c, st) : launch_mlp<false>(c, st);
+}

@@ -73,9 +73,18 @@ class LINFEngine(object):
         self.cf = _ConvP(ops, torch.cat([sd["coef.weight"], sd["freq.weight"]], 0),
                          torch.cat([sd["coef.bias"], sd["freq.bias"]], 0), mtile=2, f16=f16)
         self.phase = ops.vec(sd["phase.weight"])
+        # Fourier features + shared MLP as ONE kernel (linf_mlp.hip) when the MLP has the reference's shape (3 hidden layers of
+        # 256); otherwise, with BFSR_LINF_MLP=unfused, or on the all-native-fp32 backend (BFSR_CONV=f32): features kernel + 1x1 convs
+        import os
+        self.fused_mlp = (hidden_dim == 256 and num_layer == 3 and hasattr(ops, "linf_mlp")
+                          and (f16 or getattr(ops, "conv_mode", "f32") == "x3") and os.environ.get("BFSR_LINF_MLP", "fused") != "unfused")
         self.mlp = []
-        for j in range(num_layer + 1):
-            self.mlp.append(_ConvP(ops, sd["layers.%d.weight" % (2 * j)], sd["layers.%d.bias" % (2 * j)], mtile=2, f16=f16))
+        if self.fused_mlp:
+            names_ = ["layers.%d" % (2 * j) for j in range(num_layer + 1)]
+            self.mlp_packed = ops.pack_linf_mlp([sd[n + ".weight"] for n in names_], [sd[n + ".bias"] for n in names_], x3=not f16)
+        else:
+            for j in range(num_layer + 1):
+                self.mlp.append(_ConvP(ops, sd["layers.%d.weight" % (2 * j)], sd["layers.%d.bias" % (2 * j)], mtile=2, f16=f16))
         names = ["imnet.linears.%d" % i for i in range(flow_layers)] + ["imnet.last"]
         W = torch.stack([sd[n + "._weight"] for n in names])
         self.lin_b = ops.vec(torch.stack([sd[n + ".bias"] for n in names]))
@@ -106,6 +115,11 @@ class LINFEngine(object):
         _, qh, qw, _ = coord.shape
         cf = ws.get("cf", B, 2 * HD, h, w)
         self.cf.run(ops, feat, cf)
+        if self.fused_mlp:
+            x = ops.linf_mlp(cf, coord, cell, self.phase, self.mlp_packed, ws.get("affine_info", B, self.mlp_packed[2], qh, qw), HD,
+                             x3=self.precision != "fp16")
+            self._cond_key, self._cond = key, x
+            return x
         feats = ws.get("fourier", B, 4 * HD, qh, qw)
         ops.linf_features(cf, coord, cell, self.phase, feats, HD)
         x = feats

@@ -551,6 +551,37 @@ class HipOps(object):
         _lib.check(self._launch(("linf_features",) + tuple(out.shape), lambda: self.lib.bfsr_linf_features(C.byref(a), self._stream())), "linf_features")
         return out
 
+    def pack_linf_mlp(self, ws, bs, x3=True):
+        """ws = [w1 [256,1024(,1,1)], w2, w3 [256,256], w4 [Cout,256]], bs = the four biases -> (packed weights, bias vector, Cout)."""
+        w = [t.detach().to("cpu", torch.float32).reshape(t.shape[0], t.shape[1]).contiguous() for t in ws]
+        hidden, Cout = w[1].shape[0], w[3].shape[0]
+        n = self.lib.bfsr_linf_mlp_packed_size(hidden, Cout, int(x3))
+        if n <= 0 or w[0].shape != (hidden, 4 * hidden) or w[2].shape != (hidden, hidden) or w[3].shape[1] != hidden:
+            raise ValueError("pack_linf_mlp: unsupported MLP shape (hidden must be 256)")
+        packed = torch.empty(n, dtype=torch.int16)
+        _lib.check(self.lib.bfsr_pack_linf_mlp(w[0].data_ptr(), w[1].data_ptr(), w[2].data_ptr(), w[3].data_ptr(), hidden, Cout, int(x3),
+                                               packed.data_ptr()), "pack_linf_mlp")
+        bias = torch.cat([b.detach().to("cpu", torch.float32).reshape(-1) for b in bs])
+        return packed.to(self.device), bias.to(self.device), Cout
+
+    def linf_mlp(self, cf, coord, cell, phase, packed, out, hidden, x3=True):
+        """fused Fourier features + shared MLP: cf [B,2*hidden,h,w], coord [B,qh,qw,2], cell [B,2] -> out = affine_info [B,Cout,qh,qw]."""
+        wts, bias, Cout = packed
+        a = _lib.BfsrLinfMlpArgs()
+        a.cf, a.cf_bs, c2, h, w = _view(cf, "linf_mlp.cf")
+        a.out, a.out_bs, co, qh, qw = _view(out, "linf_mlp.out")
+        assert c2 == 2 * hidden and co == Cout and tuple(coord.shape) == (cf.shape[0], qh, qw, 2)
+        assert coord.is_contiguous() and cell.is_contiguous() and phase.is_contiguous()
+        a.coord, a.cell, a.phase, a.wts, a.bias = coord.data_ptr(), cell.data_ptr(), phase.data_ptr(), wts.data_ptr(), bias.data_ptr()
+        a.B, a.hidden, a.Cout, a.h, a.w, a.qh, a.qw = cf.shape[0], hidden, Cout, h, w, qh, qw
+        rx, ry, e = 2 / h / 2, 2 / w / 2, 1e-6            # linf.py:332-341 (python doubles -> float32 at the add)
+        a.dy_neg, a.dy_pos, a.dx_neg, a.dx_pos = -1 * rx + e, 1 * rx + e, -1 * ry + e, 1 * ry + e
+        a.clamp_lo, a.clamp_hi = -1 + 1e-6, 1 - 1e-6
+        a.cy0, a.cy1, a.cx0, a.cx1 = -1 + 1.0 / h, 2 * (1.0 / h), -1 + 1.0 / w, 2 * (1.0 / w)
+        key = ("linf_mlp_x3" if x3 else "linf_mlp_f16", hidden, Cout, cf.shape[0], qh, qw)
+        _lib.check(self._launch(key, lambda: self.lib.bfsr_linf_mlp(C.byref(a), int(x3), self._stream())), "linf_mlp")
+        return out
+
     def logscale_sum(self, h, acc, coef=1.0, eps=1e-4):
         """acc[b] (float64 [B]) += coef * sum log(sigmoid(h[:, 1::2] + 2) + eps): an affine coupling's get_logdet(scale)."""
         hp, hbs, c2, H, W = _view(h, "logscale_sum.h")

@@ -245,6 +245,26 @@ typedef struct BfsrLinfFeatArgs {
 } BfsrLinfFeatArgs;
 int bfsr_linf_features(const BfsrLinfFeatArgs* a, void* stream);
 
+/* Fused per-point conditioning (LINF-LP/models/linf.py:324-391): the Fourier features of bfsr_linf_features feed the shared MLP
+ * (`self.layers`: 1x1 convs 4*hidden -> hidden -> hidden -> hidden -> Cout with ReLU, linf.py:231-240,313-314) inside one kernel;
+ * the 4*hidden-channel feature tensor and the hidden activations never leave the chip.  out = affine_info [B, Cout, qh, qw].
+ * hidden must be 256; Cout = 2*D*layers (540).  `wts` from bfsr_pack_linf_mlp (x3 != 0: exact 3-term bf16 split of the weights and
+ * activations = fp32-accurate; x3 == 0: operands rounded to fp16, LINF precision='fp16'); bias = [b1 | b2 | b3 | b4] (3*hidden + Cout).
+ * Geometry fields as in BfsrLinfFeatArgs. */
+typedef struct BfsrLinfMlpArgs {
+    const float* cf; long long cf_bs;
+    const float* coord; const float* cell; const float* phase;
+    const unsigned short* wts; const float* bias;
+    float* out; long long out_bs;
+    int B, hidden, Cout, h, w, qh, qw;
+    float dy_neg, dy_pos, dx_neg, dx_pos, clamp_lo, clamp_hi;
+    float cy0, cy1, cx0, cx1;
+} BfsrLinfMlpArgs;
+int bfsr_linf_mlp(const BfsrLinfMlpArgs* a, int x3, void* stream);
+long long bfsr_linf_mlp_packed_size(int hidden, int Cout, int x3);          /* in 16-bit elements */
+int bfsr_pack_linf_mlp(const float* w1, const float* w2, const float* w3, const float* w4, int hidden, int Cout, int x3,
+                       unsigned short* packed);
+
 /* local implicit coupling flow (LINF-LP/models/flow.py:44-63) over D = 3*ps*ps vectors on the query grid:
  * x,y [B,D,qh,qw]; ai = affine_info [B, 2*D*layers, qh, qw]; lin_w [layers+1][D][D] holds W (forward) or
  * inv(W) (reverse, precomputed by the caller), lin_b [layers+1][D]; last entry = `last` linear. */

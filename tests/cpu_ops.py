@@ -309,6 +309,24 @@ class CpuOps(object):
         out.copy_(torch.cat([((areas[i] / tot).unsqueeze(1) * coefs[i]) * freqs[i] for i in range(4)], 1))
         return out
 
+    def pack_linf_mlp(self, ws, bs, x3=True):
+        rnd = (lambda t: t) if x3 else (lambda t: t.half().float())
+        return ([rnd(t.detach().to(torch.float32).reshape(t.shape[0], t.shape[1], 1, 1)).clone() for t in ws],
+                [b.detach().to(torch.float32).reshape(-1).clone() for b in bs], ws[3].shape[0])
+
+    def linf_mlp(self, cf, coord, cell, phase, packed, out, hidden, x3=True):
+        """Semantics of the fused kernel: Fourier features -> 1x1 MLP (ReLU between layers); fp16 mode rounds every layer's
+        operands to fp16, accumulation fp32."""
+        ws, bs, _ = packed
+        rnd = (lambda t: t) if x3 else (lambda t: t.half().float())
+        x = self.linf_features(cf, coord, cell, phase, torch.empty(cf.shape[0], 4 * hidden, coord.shape[1], coord.shape[2]), hidden)
+        for j, (w, b) in enumerate(zip(ws, bs)):
+            x = F.conv2d(rnd(x), w, b)
+            if j < len(ws) - 1:
+                x = F.relu(x)
+        out.copy_(x)
+        return out
+
     def zeros_f64(self, n):
         return torch.zeros(n, dtype=torch.float64)
 
@@ -402,3 +420,10 @@ class CpuOps(object):
     def grid_sample_add(self, x, coord, acc, out):
         out.copy_(acc + F.grid_sample(x, coord.flip(-1), mode="bilinear", padding_mode="border", align_corners=False))
         return out
+
+
+class CpuOpsX3(CpuOps):
+    """the test double in the product's default contraction mode: the engines then take the x3 paths (x3-tensor RRDB blocks on
+    conv_x3s, parity-decomposed hoists, the fused LINF conditioning kernel) -- on the double these are exact fp32 restatements,
+    so the reference goldens still apply"""
+    conv_mode = "x3"

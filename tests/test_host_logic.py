@@ -11,7 +11,7 @@ import torch
 
 from bfsr_amd import synth
 from bfsr_amd.srflow import options, spec
-from cpu_ops import CpuOps
+from cpu_ops import CpuOps, CpuOpsX3
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 T = torch.from_numpy
@@ -84,12 +84,6 @@ def test_engine_schedule_on_cpu_double_vs_reference_golden(golden_dir, fx, scale
     rt = eng.decode(T(g["lr"]), epses=out["epses"])
     assert len(out["epses"]) == n
     assert (rt - out["lr_up"]).abs().max() <= 1e-4
-
-
-class CpuOpsX3(CpuOps):
-    """the test double in the product's default contraction mode: the engines then take the x3 paths (x3-tensor RRDB blocks on
-    conv_x3s, parity-decomposed hoists) -- on the double these are exact fp32 restatements, so the goldens still apply"""
-    conv_mode = "x3"
 
 
 @pytest.mark.parametrize("fx,scale", [("srflow_e2e_4x_b", 4), ("srflow_e2e_8x", 8)])

@@ -52,6 +52,30 @@ def test_linf_features(hip, hw, q):
     close(out, ref, 5e-6, "linf_features")
 
 
+@pytest.mark.parametrize("hw,q", [((8, 12), (21, 33)), ((16, 16), (22, 22)), ((5, 7), (30, 9)), ((24, 20), (65, 55))])
+@pytest.mark.parametrize("x3", [True, False])
+def test_linf_mlp_fused(hip, hw, q, x3):
+    """The fused conditioning kernel (linf_mlp.hip: Fourier features -> 1024-256-256-256-540 MLP) against the unfused semantics
+    (features + 1x1 convs): fp32-accurate in the 3xBF16 mode; in fp16 mode against the same chain with every layer's operands
+    rounded to fp16.  Tiles of 64 query points: sizes with ragged last tiles and several tiles per image."""
+    import oracle.linf_ref as O
+    h, w = hw
+    qh, qw = q
+    B, HD, Cout = 2, 256, 540
+    cf = rnd(1, B, 2 * HD, h, w)
+    phase = rnd(2, HD // 2, 2, scale=0.5)
+    ws = [rnd(11, HD, 4 * HD, scale=1.0 / 32), rnd(12, HD, HD, scale=1.0 / 16), rnd(13, HD, HD, scale=1.0 / 16), rnd(14, Cout, HD, scale=1.0 / 16)]
+    bs = [rnd(15, HD, scale=0.1), rnd(16, HD, scale=0.1), rnd(17, HD, scale=0.1), rnd(18, Cout, scale=0.1)]
+    H, W = qh * 3 - 1, qw * 3 - 2
+    prep = O.batch_prep(torch.rand(B, 3, h, w), (H, W))
+    coord, cell = prep["coord"], prep["cell"]
+    assert coord.shape[1:3] == (qh, qw)
+    ref = CPU.linf_mlp(cf, coord, cell, phase.reshape(-1), CPU.pack_linf_mlp(ws, bs, x3=x3), torch.empty(B, Cout, qh, qw), HD, x3=x3)
+    out = hip.linf_mlp(hip.to_device(cf), hip.to_device(coord), hip.to_device(cell), hip.vec(phase), hip.pack_linf_mlp(ws, bs, x3=x3),
+                       hip.empty(B, Cout, qh, qw), HD, x3=x3)
+    close(out, ref, 2e-5 if x3 else 3e-3, "linf_mlp x3=%s" % x3)
+
+
 @pytest.mark.parametrize("D", [27, 3])
 @pytest.mark.parametrize("reverse", [0, 1])
 def test_linf_flow(hip, D, reverse):

@@ -55,6 +55,29 @@ class BfsrFlowArgs(C.Structure):
     ]
 
 
+class BfsrCouplingHeadArgs(C.Structure):
+    _fields_ = [
+        ("z", C.c_void_p), ("z_bs", C.c_longlong), ("Cz", C.c_int),
+        ("pre_aff", C.c_void_p), ("pre_aff_bs", C.c_longlong),
+        ("w", C.c_void_p), ("epi0", C.c_void_p), ("epi2", C.c_void_p),
+        ("hid", C.c_void_p), ("hid_bs", C.c_longlong),
+        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
+    ]
+
+
+class BfsrCouplingTailArgs(C.Structure):
+    _fields_ = [
+        ("hid", C.c_void_p), ("hid_bs", C.c_longlong), ("Cin", C.c_int),
+        ("w", C.c_void_p), ("bias", C.c_void_p), ("post_scale", C.c_void_p),
+        ("z_in", C.c_void_p), ("z_in_bs", C.c_longlong),
+        ("z_out", C.c_void_p), ("z_out_bs", C.c_longlong),
+        ("h_ft", C.c_void_p), ("h_ft_bs", C.c_longlong),
+        ("wmat", C.c_void_p), ("an_bias", C.c_void_p), ("an_escale", C.c_void_p),
+        ("B", C.c_int), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("reverse", C.c_int),
+        ("eps", C.c_float),
+    ]
+
+
 class BfsrLinfFeatArgs(C.Structure):
     _fields_ = [
         ("cf", C.c_void_p), ("cf_bs", C.c_longlong),
@@ -119,6 +142,12 @@ SYMBOLS = {
     "bfsr_conv_packed_size_taps": (_LL, [_I, _I, _I, _I]),
     "bfsr_pack_conv_weight_taps": (_I, [_VP, _I, _I, _I, _I, _VP]),
     "bfsr_flow_pointwise": (_I, [C.POINTER(BfsrFlowArgs), _VP]),
+    "bfsr_coupling_head": (_I, [C.POINTER(BfsrCouplingHeadArgs), _VP]),
+    "bfsr_coupling_tail": (_I, [C.POINTER(BfsrCouplingTailArgs), _VP]),
+    "bfsr_coupling_head_packed_size": (_LL, [_I]),
+    "bfsr_pack_coupling_head": (_I, [_VP, _VP, _I, _VP]),
+    "bfsr_coupling_tail_packed_size": (_LL, [_I, _I]),
+    "bfsr_pack_coupling_tail": (_I, [_VP, _I, _I, _VP]),
     "bfsr_squeeze2d": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
     "bfsr_unsqueeze2d": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
     "bfsr_split2d": (_I, [_VP, _LL, _VP, _LL, _VP, _LL, _I, _I, _I, _I, _I, _VP]),

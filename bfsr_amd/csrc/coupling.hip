@@ -1,0 +1,535 @@
+// coupling.hip -- the sequential part of a conditional-affine FlowStep (FlowAffineCouplingsAblation.py:57-135, FlowStep.py:88-129)
+// as TWO kernels per step instead of four (fused 3x3+1x1 on fp32 MFMA, 3x3 Conv2dZeros on 32-row tiles, pointwise chain):
+//
+//   bfsr_coupling_head : t2 = relu(AN2(W2 . relu(AN0(conv3x3(z1; W0z) + pre_aff))))            -> hid [B,64,H,W]
+//       3xBF16 arithmetic (exact 3-term split, six v_mfma_f32_32x32x16_bf16 per operand pair).  The 3x3 conv has K = 9 taps x
+//       ceil(Cz/8) channel octets (54 real channels at level 1): a k-chunk of 16 = two (tap, octet) units, lanes 0-31 read the B
+//       operand of the first unit, lanes 32-63 of the second, straight from the x3 z1 tile in LDS.  The 1x1 is CHAINED IN REGISTERS:
+//       the accumulator layout of stage 1 (lane = pixel; half-wave h holds channels (r&3)+8(r>>2)+4h) is already a valid B operand
+//       for the next GEMM if W2's K axis is packed in that order, so t1 never goes to LDS (no transposition, no barrier).
+//   bfsr_coupling_tail : h_aff = Conv2dZeros(hid) (64 -> 2*(C - C/2) channels); then the FlowStep's pointwise chain with h_aff
+//       taken from LDS instead of HBM.  The conv runs on v_mfma_f32_16x16x4_f32 (exact fp32, M = 16): Cout = 12 / 24 wastes 25 % of
+//       a 16-row tile instead of 62 % of the 32-row tiles of the generic kernels.  Tail semantics = bfsr_flow_pointwise:
+//         reverse: z2 = z2/scale - shift; z = z/scaleFt - shiftFt; z = Winv z; z = z*exp(-logs) - bias          (this step)
+//         forward: z2 = (z2 + shift)*scale   (this step's self-conditional)   then, if given, the NEXT step's head:
+//                  z = (z + bias)*exp(logs); z = W z; z = (z + shiftFt)*scaleFt
+// Measured motivation (profiles/r02_c_keys_x3.txt, level 1 of BASELINE config 2, per step): fused 3x3+1x1 on fp32 MFMA 407 us
+// (matrix pipe 38 % busy: the fp32 MFMA is 16x slower than bf16), Conv2dZeros 64->12 322 us, pointwise 50 us.
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "../../include/bfsr_hip.h"
+#include "launch_util.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int TH = 8, TW = 32, PW = TW + 2, NPOS = (TH + 2) * PW;      // 8 x 32 pixel tile, 340 staged positions
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ float sigmoid_scale(float raw, float eps) { return 1.f / (1.f + expf(-(raw + 2.f))) + eps; }
+
+__device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l)
+{
+    h = (__bf16)v;
+    const float r1 = v - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+
+// =====================================================================================================================
+// tail: conv3x3 64 -> CO2 = 2*(C - C/2) on 16x16x4 fp32 MFMA + pointwise chain.  8 waves, wave w = tile row w, 2 column
+// tiles of 16 pixels, MT = ceil(CO2/16) row tiles.  K walked 16 input channels per LDS stage (register-staged pipeline).
+template <int C, int CIN>
+__global__ __launch_bounds__(512, 2) void coupling_tail_kernel(BfsrCouplingTailArgs p, int tiles_x, int tiles_xy)
+{
+    constexpr int CN = C / 2, CC = C - CN, CO2 = 2 * CC, MT = (CO2 + 15) / 16, MW = MT * 16;
+    constexpr int CK = 16, NCHUNK = CIN / CK;
+    constexpr int WCH = CK * 9 * MW;                       // weight floats per chunk: [ch][tap][MW]
+    constexpr int PPT = (NPOS + 511) / 512;
+    constexpr int WV = (WCH / 4 + 511) / 512;
+    static_assert(CIN % CK == 0, "hidden width must be a multiple of 16");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    float* sW = smem;                                      // [CK][9][MW]
+    float* sIn = smem + WCH;                               // [CK][NPOS]
+    float* sH = smem;                                      // after the K loop: h_aff [CO2][TH*TW]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    int bid = (int)bfsr::xcd_order(blockIdx.x, gridDim.x);
+    const int tile = bid % tiles_xy, b = bid / tiles_xy;
+    const int x0 = (tile % tiles_x) * TW, y0 = (tile / tiles_x) * TH;
+    const int H = p.H, W = p.W;
+    const long long HW = (long long)H * W;
+
+    const float* __restrict__ hid = p.hid + (long long)b * p.hid_bs;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hid), 0, (unsigned)((long long)CIN * HW * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (unsigned)(NCHUNK * WCH * 4), 0x00020000);
+    unsigned voff[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int pos = tid + i * 512;
+        const int r = pos / PW, c = pos - r * PW;
+        const int gy = y0 + r - 1, gx = x0 + c - 1;
+        const bool ok = pos < NPOS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        voff[i] = ok ? (unsigned)(gy * W + gx) * 4u : OOB;
+    }
+    const unsigned cs_bytes = (unsigned)(HW * 4);
+
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[m][n][r] = 0.f;
+
+    float vin[PPT][CK];
+    float4 vw[WV];
+    auto load_chunk = [&](int k) {
+        const unsigned sbase = (unsigned)(k * CK) * cs_bytes;
+#pragma unroll
+        for (int c = 0; c < CK; ++c)
+#pragma unroll
+            for (int i = 0; i < PPT; ++i)
+                vin[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff[i], sbase + (unsigned)c * cs_bytes, 0));
+#pragma unroll
+        for (int i = 0; i < WV; ++i)
+            vw[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(tid + i * 512) * 16u, (unsigned)k * (WCH * 4), 0));
+    };
+    load_chunk(0);
+    for (int k = 0; k < NCHUNK; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int pos = tid + i * 512;
+            if (i < PPT - 1 || pos < NPOS) {
+#pragma unroll
+                for (int c = 0; c < CK; ++c) sIn[c * NPOS + pos] = vin[i][c];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int idx = tid + i * 512;
+            if (i < WV - 1 || idx < WCH / 4) reinterpret_cast<float4*>(sW)[idx] = vw[i];
+        }
+        __syncthreads();
+        if (k + 1 < NCHUNK) load_chunk(k + 1);
+        // lane (l15, lq): A = weight row l15 of channel 4*ks + lq; B = pixel column l15 (+16 for the second tile) of that channel
+#pragma unroll
+        for (int ks = 0; ks < CK / 4; ++ks) {
+            const float* inC = sIn + (ks * 4 + lq) * NPOS + wave * PW + l15;
+            const float* wC = sW + (ks * 4 + lq) * 9 * MW + l15;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                float brow[2][3];
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) brow[n][r] = inC[r * PW + n * 16 + dx];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const float a = wC[(dy * 3 + dx) * MW + m * 16];
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, brow[n][dy], acc[m][n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();                                       // every wave is done with the last stage: LDS becomes the h_aff tile
+    // accumulator layout of 16x16x4: lane (l15, lq) holds rows 4*lq + i (i = 0..3) of column l15
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = m * 16 + lq * 4 + i;
+            if (co < CO2) {
+                const float bias = p.bias[co], ps = p.post_scale[co];
+#pragma unroll
+                for (int n = 0; n < 2; ++n) sH[co * (TH * TW) + wave * TW + n * 16 + l15] = (acc[m][n][i] + bias) * ps;
+            }
+        }
+    __syncthreads();
+
+    // ---- pointwise chain, one thread per pixel (tile row = tid / 32): identical arithmetic to flow_pointwise_kernel
+    if (tid >= TH * TW) return;
+    const int py = y0 + (tid >> 5), px = x0 + (tid & 31);
+    if (py >= H || px >= W) return;
+    const long long pix = (long long)py * W + px;
+    const float eps = p.eps;
+    float x[C];
+    {
+        const float* zi = p.z_in + (long long)b * p.z_in_bs + pix;
+#pragma unroll
+        for (int c = 0; c < C; ++c) x[c] = zi[(long long)c * HW];
+    }
+    const float* hf = p.h_ft ? p.h_ft + (long long)b * p.h_ft_bs + pix : nullptr;
+    const float* ha = sH + tid;
+    float* zo = p.z_out + (long long)b * p.z_out_bs + pix;
+    // feature-conditional (shift, raw scale) of every channel, loaded up front so that all 2C loads are in flight together
+    float fsh[C], fsr[C];
+    if (hf) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) { fsh[c] = hf[(long long)(2 * c) * HW]; fsr[c] = hf[(long long)(2 * c + 1) * HW]; }
+    }
+    if (p.reverse) {
+#pragma unroll
+        for (int j = 0; j < CC; ++j) x[CN + j] = x[CN + j] / sigmoid_scale(ha[(2 * j + 1) * (TH * TW)], eps) - ha[(2 * j) * (TH * TW)];
+        if (hf) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) x[c] = x[c] / sigmoid_scale(fsr[c], eps) - fsh[c];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < CC; ++j) x[CN + j] = (x[CN + j] + ha[(2 * j) * (TH * TW)]) * sigmoid_scale(ha[(2 * j + 1) * (TH * TW)], eps);
+        if (p.an_bias) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) x[c] = (x[c] + p.an_bias[c]) * p.an_escale[c];
+        }
+    }
+    if (p.wmat) {
+        const float* __restrict__ w = p.wmat;
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            float y = 0.f;
+#pragma unroll
+            for (int j = 0; j < C; ++j) y = fmaf(w[i * C + j], x[j], y);
+            if (p.reverse) {
+                if (p.an_bias) y = y * p.an_escale[i] - p.an_bias[i];
+            } else if (hf) {
+                y = (y + fsh[i]) * sigmoid_scale(fsr[i], eps);
+            }
+            zo[(long long)i * HW] = y;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float y = x[c];
+            if (p.reverse) {
+                if (p.an_bias) y = y * p.an_escale[c] - p.an_bias[c];
+            } else if (hf) {
+                y = (y + fsh[c]) * sigmoid_scale(fsr[c], eps);
+            }
+            zo[(long long)c * HW] = y;
+        }
+    }
+}
+
+template <int C, int CIN>
+int launch_tail(const BfsrCouplingTailArgs& a, hipStream_t st)
+{
+    constexpr int CO2 = 2 * (C - C / 2), MW = (CO2 + 15) / 16 * 16;
+    constexpr int LDS_K = (16 * 9 * MW + 16 * NPOS) * 4, LDS_H = CO2 * TH * TW * 4;
+    constexpr int LDS = LDS_K > LDS_H ? LDS_K : LDS_H;
+    static std::atomic<unsigned long long> lds_done{0};
+    if (LDS > 65536 && bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&coupling_tail_kernel<C, CIN>), LDS, lds_done) != 0) return -1;
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const long long nblk = (long long)tiles_x * tiles_y * a.B;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return -1;
+    hipLaunchKernelGGL((coupling_tail_kernel<C, CIN>), dim3((unsigned)nblk), dim3(512), LDS, st, a, tiles_x, tiles_x * tiles_y);
+    return (int)hipGetLastError();
+}
+
+// =====================================================================================================================
+// head: conv3x3(z1) + pre_aff + ActNorm + ReLU -> 1x1 + ActNorm + ReLU, 3xBF16, register-chained.  NO = ceil(Cz/8) z1 octets.
+// 8 waves, wave w = tile row w, M = 64 = 2 row tiles, N = 32 pixels.  PERSISTENT: one workgroup per CU stages the packed weights
+// once and walks its tiles in an XCD-aware order; the z1 values and the hoisted partial of tile t+1 are loaded into registers
+// while tile t is in the matrix pipe (the kernel moves 420 MB per launch at level 1 and has ~5 us of MFMA per tile, so without the
+// prefetch it is a chain of exposed HBM latencies: 410 us measured for the non-persistent form against a 105 us traffic bound).
+template <int NO>
+__global__ __launch_bounds__(512, 1) void coupling_head_kernel(BfsrCouplingHeadArgs p, int tiles_x, int tiles_xy, int ntiles)
+{
+    constexpr int NU = 9 * NO, NC1 = (NU + 1) / 2;          // (tap, octet) units and 16-wide k-chunks of the 3x3
+    constexpr int ZT = NO * 3 * NPOS * 16;                  // bytes of the x3 z1 tile: [octet][plane][pos][8]
+    constexpr int W0B = NC1 * 3 * 2 * 64 * 16;              // [chunk][plane][k half][64 rows][8]
+    constexpr int W2B = 4 * 3 * 2 * 64 * 16;
+    constexpr int ZU = (NO * NPOS + 511) / 512;             // staged (octet, position) units per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned char* smem = smem_raw;
+    unsigned char* sZ = smem;
+    unsigned char* sW0 = smem + ZT;
+    unsigned char* sW2 = sW0 + W0B;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int G = gridDim.x;
+    const int slot = (int)bfsr::xcd_order(blockIdx.x, (unsigned)G);
+    if (slot >= ntiles) return;
+    const int H = p.H, W = p.W, Cz = p.Cz;
+    const long long HW = (long long)H * W;
+    {
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(p.w);
+        uint4* dst = reinterpret_cast<uint4*>(sW0);
+        for (int i = tid; i < (W0B + W2B) / 16; i += 512) dst[i] = src[i];
+    }
+
+    // ---- per-tile register prefetch: this thread's z1 units (8 channels of one staged position) and its 32 pre_aff values
+    float zr[ZU][8], pre[2][16];
+    auto prefetch_z = [&](int t) {
+        const int tile = t % tiles_xy, b = t / tiles_xy;
+        const int x0 = (tile % tiles_x) * TW, y0 = (tile / tiles_x) * TH;
+        const float* __restrict__ zb = p.z + (long long)b * p.z_bs;
+#pragma unroll
+        for (int i = 0; i < ZU; ++i) {
+            const int u = tid + i * 512;
+            const int o = u / NPOS, pos = u - o * NPOS;
+            const int r = pos / PW, c = pos - r * PW;
+            const int gy = y0 + r - 1, gx = x0 + c - 1;
+            const bool ok = u < NO * NPOS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ch = o * 8 + e;
+                zr[i][e] = (ok && ch < Cz) ? zb[(long long)ch * HW + (long long)gy * W + gx] : 0.f;
+            }
+        }
+    };
+    auto prefetch_pre = [&](int t) {
+        const int tile = t % tiles_xy, b = t / tiles_xy;
+        const int x0 = (tile % tiles_x) * TW, y0 = (tile / tiles_x) * TH;
+        const int gy = y0 + wave, gx = x0 + l31;
+        const bool pok = gy < H && gx < W;
+        // raw buffer loads: one VGPR offset (pixel + the half-wave's 4-channel shift), the channel as a scalar offset
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pre_aff + (long long)b * p.pre_aff_bs), 0,
+                                                                            (unsigned)(64 * HW * 4), 0x00020000);
+        const unsigned vo = pok ? (unsigned)(((long long)gy * W + gx + 4LL * lhi * HW) * 4) : OOB;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                pre[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (unsigned)((m * 32 + (r & 3) + 8 * (r >> 2)) * HW * 4), 0));
+    };
+    prefetch_z(slot);
+    prefetch_pre(slot);
+
+    for (int t = slot; t < ntiles; t += G) {
+        const int tile = t % tiles_xy, b = t / tiles_xy;
+        const int x0 = (tile % tiles_x) * TW, y0 = (tile / tiles_x) * TH;
+        // ---- registers -> x3 tile in LDS (exact 3-term bf16 split)
+#pragma unroll
+        for (int i = 0; i < ZU; ++i) {
+            const int u = tid + i * 512;
+            if (u < NO * NPOS) {
+                const int o = u / NPOS, pos = u - o * NPOS;
+                bf16x8 h8, m8, l8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { __bf16 h, m, l; split3(zr[i][e], h, m, l); h8[e] = h; m8[e] = m; l8[e] = l; }
+                *reinterpret_cast<bf16x8*>(sZ + ((o * 3 + 0) * NPOS + pos) * 16) = h8;
+                *reinterpret_cast<bf16x8*>(sZ + ((o * 3 + 1) * NPOS + pos) * 16) = m8;
+                *reinterpret_cast<bf16x8*>(sZ + ((o * 3 + 2) * NPOS + pos) * 16) = l8;
+            }
+        }
+        __syncthreads();
+        if (t + G < ntiles) prefetch_z(t + G);              // next tile's z1 loads fly under this tile's MFMAs and stores
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#define BFSR_SIX(ACC_, A_, B_)                                                                                 \
+    ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[2], B_[0], ACC_, 0, 0, 0);                                \
+    ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[0], B_[2], ACC_, 0, 0, 0);                                \
+    ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[1], B_[1], ACC_, 0, 0, 0);                                \
+    ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[1], B_[0], ACC_, 0, 0, 0);                                \
+    ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[0], B_[1], ACC_, 0, 0, 0);                                \
+    ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[0], B_[0], ACC_, 0, 0, 0);
+        // ---- 3x3: chunk j = units (2j, 2j+1); unit u = (tap u / NO, octet u % NO); lanes 0-31 take unit 2j, lanes 32-63 unit 2j+1
+        // (not unrolled: a fully unrolled loop lets the compiler hoist every chunk's 9 fragment reads and spill)
+#pragma unroll 1
+        for (int j = 0; j < NC1; ++j) {
+            const int u0 = 2 * j, u1 = (2 * j + 1 < NU) ? 2 * j + 1 : 2 * j;  // a missing second unit re-reads the first (its weights are 0)
+            const int t0 = u0 / NO, o0 = u0 % NO, t1 = u1 / NO, o1 = u1 % NO;
+            const int a0 = (o0 * 3 * NPOS + (t0 / 3) * PW + (t0 % 3)) * 16, a1 = (o1 * 3 * NPOS + (t1 / 3) * PW + (t1 % 3)) * 16;
+            const unsigned char* bp = sZ + (lhi ? a1 : a0) + (wave * PW + l31) * 16;
+            bf16x8 bf[3], af[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bf[pl] = *reinterpret_cast<const bf16x8*>(bp + pl * NPOS * 16);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    af[m][pl] = *reinterpret_cast<const bf16x8*>(sW0 + (((j * 3 + pl) * 2 + lhi) * 64 + m * 32 + l31) * 16);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) { BFSR_SIX(acc[m], af[m], bf) }
+        }
+        __syncthreads();                                    // the z1 tile may be overwritten by the next iteration
+        // ---- epilogue 1 in registers: + pre_aff, ActNorm, ReLU; the result IS the B operand of the 1x1 (K order = accumulator order)
+        const float4* __restrict__ e0 = reinterpret_cast<const float4*>(p.epi0);    // [64] {shift, scale, 0, 0}
+        bf16x8 b2[4][3];                                    // chunk c = (m, half): registers 8*half .. 8*half+7 of tile m
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int r = hf * 8 + e;
+                    const int ch = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const float4 q = e0[ch];
+                    float v = ((acc[m][r] + pre[m][r]) + q.x) * q.y;
+                    v = v > 0.f ? v : 0.f;
+                    __bf16 h, mm, l;
+                    split3(v, h, mm, l);
+                    b2[m * 2 + hf][0][e] = h; b2[m * 2 + hf][1][e] = mm; b2[m * 2 + hf][2][e] = l;
+                }
+        if (t + G < ntiles) prefetch_pre(t + G);            // ... and its hoisted partial under the 1x1 and the stores
+        f32x16 acc2[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[m][r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bf16x8 af[2][3];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    af[m][pl] = *reinterpret_cast<const bf16x8*>(sW2 + (((c * 3 + pl) * 2 + lhi) * 64 + m * 32 + l31) * 16);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) { BFSR_SIX(acc2[m], af[m], b2[c]) }
+            __builtin_amdgcn_sched_barrier(0);              // keep the fragment reads of chunk c+1 behind this chunk's MFMAs
+        }
+#undef BFSR_SIX
+        const int gy = y0 + wave, gx = x0 + l31;
+        {
+            const float4* __restrict__ e2 = reinterpret_cast<const float4*>(p.epi2);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.hid + (long long)b * p.hid_bs, 0, (unsigned)(64 * HW * 4), 0x00020000);
+            const unsigned vo = (gy < H && gx < W) ? (unsigned)(((long long)gy * W + gx + 4LL * lhi * HW) * 4) : OOB;     // out-of-image lanes: dropped
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const float4 q = e2[ch];
+                    const float v = (acc2[m][r] + q.x) * q.y;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v > 0.f ? v : 0.f), rs, vo,
+                                                          (unsigned)((m * 32 + (r & 3) + 8 * (r >> 2)) * HW * 4), 0);
+                }
+        }
+    }
+}
+
+template <int NO>
+int launch_head(const BfsrCouplingHeadArgs& a, hipStream_t st)
+{
+    constexpr int NC1 = (9 * NO + 1) / 2;
+    constexpr int LDS = NO * 3 * NPOS * 16 + NC1 * 3 * 2 * 64 * 16 + 4 * 3 * 2 * 64 * 16;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    static std::atomic<unsigned long long> lds_done{0};
+    if (LDS > 65536 && bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&coupling_head_kernel<NO>), LDS, lds_done) != 0) return -1;
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const long long ntiles = (long long)tiles_x * tiles_y * a.B;
+    if (ntiles <= 0 || ntiles > 0x7fffffffLL) return -1;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const long long grid = ntiles < cus ? ntiles : cus;     // one persistent workgroup per CU
+    hipLaunchKernelGGL(coupling_head_kernel<NO>, dim3((unsigned)grid), dim3(512), LDS, st, a, tiles_x, tiles_x * tiles_y, (int)ntiles);
+    return (int)hipGetLastError();
+}
+
+inline void split3_host(float v, unsigned short out[3])
+{
+    float r = v;
+    for (int i = 0; i < 3; ++i) {
+        const __bf16 h = (__bf16)r;
+        __builtin_memcpy(&out[i], &h, 2);
+        r -= (float)h;
+    }
+}
+
+}  // namespace
+
+// ---- host-side packing -----------------------------------------------------------------------------------------------
+extern "C" long long bfsr_coupling_head_packed_size(int Cz)
+{
+    if (Cz <= 0 || Cz > 16) return -1;
+    const int NO = (Cz + 7) / 8, NC1 = (9 * NO + 1) / 2;
+    return (long long)(NC1 + 4) * 3 * 2 * 64 * 8;             // bf16 elements
+}
+
+// w0 [64][Cz][3][3] (fAffine.0 rows restricted to z1), w2 [64][64] (fAffine.2, 1x1) -> the LDS image of coupling_head_kernel:
+// [chunk][plane][k half][64 rows][8]; 3x3 chunks: k half h of chunk j = unit u = 2j+h = (tap u / NO, octet u % NO), element e =
+// channel 8*octet + e (zero beyond Cz / beyond the last unit); 1x1 chunks: chunk c = (m, half): k half h, element e = input channel
+// m*32 + (r&3) + 8*(r>>2) + 4*h with r = 8*half + e  (the accumulator order of the 3x3's output, see the kernel).
+extern "C" int bfsr_pack_coupling_head(const float* w0, const float* w2, int Cz, unsigned short* packed)
+{
+    if (!w0 || !w2 || !packed || Cz <= 0 || Cz > 16) return -1;
+    const int NO = (Cz + 7) / 8, NU = 9 * NO, NC1 = (NU + 1) / 2;
+    const long long n = bfsr_coupling_head_packed_size(Cz);
+    for (long long i = 0; i < n; ++i) packed[i] = 0;
+    auto put = [&](long long chunk, int half, int row, int e, float v) {
+        unsigned short s3[3];
+        split3_host(v, s3);
+        for (int pl = 0; pl < 3; ++pl) packed[((((chunk * 3 + pl) * 2 + half) * 64 + row) * 8) + e] = s3[pl];
+    };
+    for (int j = 0; j < NC1; ++j)
+        for (int half = 0; half < 2; ++half) {
+            const int u = 2 * j + half;
+            if (u >= NU) continue;
+            const int tap = u / NO, o = u % NO;
+            for (int row = 0; row < 64; ++row)
+                for (int e = 0; e < 8; ++e) {
+                    const int ch = o * 8 + e;
+                    if (ch < Cz) put(j, half, row, e, w0[((long long)row * Cz + ch) * 9 + tap]);
+                }
+        }
+    for (int c = 0; c < 4; ++c) {
+        const int m = c >> 1, hf = c & 1;
+        for (int half = 0; half < 2; ++half)
+            for (int row = 0; row < 64; ++row)
+                for (int e = 0; e < 8; ++e) {
+                    const int r = hf * 8 + e;
+                    const int ch = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    put(NC1 + c, half, row, e, w2[(long long)row * 64 + ch]);
+                }
+    }
+    return 0;
+}
+
+extern "C" long long bfsr_coupling_tail_packed_size(int Cin, int Cout)
+{
+    if (Cin <= 0 || (Cin & 15) || Cout <= 0) return -1;
+    return (long long)Cin * 9 * ((Cout + 15) / 16 * 16);        // floats
+}
+
+// w [Cout][Cin][3][3] (Conv2dZeros weight) -> [Cin][tap][MW] fp32, rows zero padded to a multiple of 16
+extern "C" int bfsr_pack_coupling_tail(const float* w, int Cin, int Cout, float* packed)
+{
+    if (!w || !packed || Cin <= 0 || (Cin & 15) || Cout <= 0) return -1;
+    const int MW = (Cout + 15) / 16 * 16;
+    for (long long i = 0; i < (long long)Cin * 9 * MW; ++i) packed[i] = 0.f;
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int t = 0; t < 9; ++t) packed[((long long)ci * 9 + t) * MW + co] = w[((long long)co * Cin + ci) * 9 + t];
+    return 0;
+}
+
+extern "C" int bfsr_coupling_head(const BfsrCouplingHeadArgs* a, void* stream)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!a || !a->z || !a->pre_aff || !a->w || !a->epi0 || !a->epi2 || !a->hid) return -1;
+    if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cz <= 0 || a->Cz > 16) return -1;
+    return a->Cz <= 8 ? launch_head<1>(*a, st) : launch_head<2>(*a, st);
+}
+
+extern "C" int bfsr_coupling_tail(const BfsrCouplingTailArgs* a, void* stream)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!a || !a->hid || !a->w || !a->bias || !a->post_scale || !a->z_in || !a->z_out) return -1;
+    if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cin != 64) return -1;
+    if (a->an_bias && !a->an_escale) return -1;
+    if ((long long)a->Cin * a->H * a->W * 4 >= (1LL << 31)) return -1;
+    switch (a->C) {
+        case 12: return launch_tail<12, 64>(*a, st);
+        case 24: return launch_tail<24, 64>(*a, st);
+        default: return -1;
+    }
+}

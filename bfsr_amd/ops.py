@@ -478,6 +478,68 @@ class HipOps(object):
                    "flow_pointwise(C=%d)" % Cc)
         return z_out
 
+    # ---- the sequential part of a coupled FlowStep in two kernels (coupling.hip) -----------------------------------------------
+    def pack_coupling_head(self, w0_z1, w2, shift0, scale0, shift2, scale2):
+        """fAffine.0 restricted to the z1 rows [64,Cz,3,3] + fAffine.2 [64,64(,1,1)] and their ActNorm (bias, exp(logs)) vectors."""
+        w0 = w0_z1.detach().to("cpu", torch.float32).contiguous()
+        w2 = w2.detach().to("cpu", torch.float32).reshape(64, 64).contiguous()
+        Cz = w0.shape[1]
+        n = self.lib.bfsr_coupling_head_packed_size(Cz)
+        if n <= 0 or w0.shape[0] != 64:
+            raise ValueError("pack_coupling_head: unsupported shape %s" % (tuple(w0.shape),))
+        packed = torch.empty(n, dtype=torch.int16)
+        _lib.check(self.lib.bfsr_pack_coupling_head(w0.data_ptr(), w2.data_ptr(), Cz, packed.data_ptr()), "pack_coupling_head")
+
+        def epi(shift, scale):
+            e = torch.zeros(64, 4, dtype=torch.float32)
+            e[:, 0] = shift.detach().reshape(-1).to("cpu", torch.float32)
+            e[:, 1] = scale.detach().reshape(-1).to("cpu", torch.float32)
+            return e.to(self.device)
+        return packed.to(self.device), epi(shift0, scale0), epi(shift2, scale2), Cz
+
+    def coupling_head(self, z, packed, pre_aff, hid):
+        """hid [B,64,H,W] = relu(AN2(W2 . relu(AN0(conv3x3(z[:, :Cz]) + pre_aff)))) on the 3xBF16 split, 1x1 chained in registers."""
+        wts, e0, e2, Cz = packed
+        a = _lib.BfsrCouplingHeadArgs()
+        a.z, a.z_bs, Cc, H, W = _view(z, "coupling_head.z")
+        a.pre_aff, a.pre_aff_bs, c1, h1, w1 = _view(pre_aff, "coupling_head.pre_aff")
+        a.hid, a.hid_bs, c2, h2, w2 = _view(hid, "coupling_head.hid")
+        assert Cc >= Cz and (c1, h1, w1) == (64, H, W) and (c2, h2, w2) == (64, H, W)
+        a.Cz, a.w, a.epi0, a.epi2 = Cz, wts.data_ptr(), e0.data_ptr(), e2.data_ptr()
+        a.B, a.H, a.W = z.shape[0], H, W
+        key = ("coupling_head", Cz, z.shape[0], H, W)
+        _lib.check(self._launch(key, lambda: self.lib.bfsr_coupling_head(C.byref(a), self._stream())), "coupling_head")
+        return hid
+
+    def pack_coupling_tail(self, w4, bias, post_scale):
+        """fAffine.4 (Conv2dZeros) [Cout,64,3,3] for 16-row fp32 MFMA tiles + its bias and exp(3*logs)."""
+        w = w4.detach().to("cpu", torch.float32).contiguous()
+        Cout, Cin = w.shape[0], w.shape[1]
+        n = self.lib.bfsr_coupling_tail_packed_size(Cin, Cout)
+        if n <= 0:
+            raise ValueError("pack_coupling_tail: unsupported shape %s" % (tuple(w.shape),))
+        packed = torch.empty(n, dtype=torch.float32)
+        _lib.check(self.lib.bfsr_pack_coupling_tail(w.data_ptr(), Cin, Cout, packed.data_ptr()), "pack_coupling_tail")
+        return packed.to(self.device), self.vec(bias), self.vec(post_scale), Cout
+
+    def coupling_tail(self, hid, packed, z_in, z_out, reverse, h_ft=None, w=None, an_bias=None, an_escale=None, eps=1e-4):
+        """h_aff = Conv2dZeros(hid), then the pointwise chain of flow_pointwise(z_in, z_out, reverse, h_aff=h_aff, h_ft, w, an_*)."""
+        wts, bias, ps, Cout = packed
+        a = _lib.BfsrCouplingTailArgs()
+        a.hid, a.hid_bs, a.Cin, H, W = _view(hid, "coupling_tail.hid")
+        a.z_in, a.z_in_bs, Cc, h1, w1 = _view(z_in, "coupling_tail.z_in")
+        a.z_out, a.z_out_bs, c2, h2, w2 = _view(z_out, "coupling_tail.z_out")
+        assert (Cc, h1, w1) == (c2, h2, w2) == (Cc, H, W) and Cout == 2 * (Cc - Cc // 2)
+        if h_ft is not None:
+            a.h_ft, a.h_ft_bs, c, h, ww = _view(h_ft, "coupling_tail.h_ft")
+            assert (c, h, ww) == (2 * Cc, H, W)
+        a.w, a.bias, a.post_scale = wts.data_ptr(), bias.data_ptr(), ps.data_ptr()
+        a.wmat, a.an_bias, a.an_escale = _ptr(w), _ptr(an_bias), _ptr(an_escale)
+        a.B, a.C, a.H, a.W, a.reverse, a.eps = z_in.shape[0], Cc, H, W, int(bool(reverse)), eps
+        key = ("coupling_tail", int(bool(reverse)), Cc, z_in.shape[0], H, W)
+        _lib.check(self._launch(key, lambda: self.lib.bfsr_coupling_tail(C.byref(a), self._stream())), "coupling_tail(C=%d)" % Cc)
+        return z_out
+
     def squeeze2d(self, x, y):
         xp, xbs, Cc, H, W = _view(x)
         yp, ybs, c2, h2, w2 = _view(y)

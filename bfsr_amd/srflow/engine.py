@@ -24,6 +24,7 @@ from .. import rng
 from .options import opt_get
 from ..ops import ACT_LRELU, ACT_NONE, ACT_RELU, MODE_BILINEAR, MODE_BILINEAR_AC, MODE_NEAREST
 
+FUSED_COUPLING_C = tuple(int(v) for v in os.environ.get("BFSR_COUPLING_C", "12").split(",") if v)
 # fea_up{k} lives at LR resolution * 2^shift
 _KEY_SHIFT = {"fea_up0": -1, "fea_up1": 0, "fea_up2": 1, "fea_up4": 2, "fea_up8": 3}
 
@@ -250,6 +251,18 @@ class SRFlowEngine(object):
                                      aff_scale=torch.exp(sd[a + "2.actnorm.logs"]), mtile=2)
                     st.aff4 = _ConvP(ops, sd[a + "4.weight"], bias=sd[a + "4.bias"],
                                      post_scale=torch.exp(sd[a + "4.logs"] * 3))
+                    # levels with 12 / 24 flow channels: the whole sequential part of the step as two kernels (coupling.hip):
+                    # 3xBF16 head (3x3 on z1 + hoisted partial, 1x1 chained in registers) and a 16-row-tile Conv2dZeros with
+                    # the pointwise chain as its tail.  BFSR_COUPLING=unfused keeps the four generic launches.
+                    # (measured without side-stream overlap, per step at BASELINE config 2: C = 12 @ 8x320^2: 467 -> 363 us;
+                    #  C = 24 @ 8x160^2: 200 -> 219 us, i.e. no gain on the smaller planes -> fused at the 12-channel level only)
+                    st.fused = (C in FUSED_COUPLING_C and w0.shape[0] == 64 and hasattr(ops, "coupling_head")
+                                and getattr(ops, "conv_mode", "f32") == "x3" and os.environ.get("BFSR_COUPLING", "fused") != "unfused")
+                    if st.fused:
+                        st.head = ops.pack_coupling_head(w0[:, :cn].contiguous(), sd[a + "2.weight"], sd[a + "0.actnorm.bias"],
+                                                         torch.exp(sd[a + "0.actnorm.logs"]), sd[a + "2.actnorm.bias"],
+                                                         torch.exp(sd[a + "2.actnorm.logs"]))
+                        st.tail = ops.pack_coupling_tail(sd[a + "4.weight"], sd[a + "4.bias"], torch.exp(sd[a + "4.logs"] * 3))
                     f = p + "affine.fFeatures."
                     st.ft0_w = sd[f + "0.weight"]
                     st.ft0_shift = sd[f + "0.actnorm.bias"].reshape(-1)
@@ -467,7 +480,9 @@ class SRFlowEngine(object):
         epses = []
         pending = None           # h_aff of the previous coupled step, applied lazily by the next head
         ld_const, ld_levels = 0.0, set()
-        for ly in self.layers:
+        head_done = False        # the current step's head (actnorm, W, feature-conditional affine) was already applied by the
+                                 # previous step's fused tail kernel
+        for pos, ly in enumerate(self.layers):
             B, _, H, W = z.shape
             if ly.type == "squeeze":
                 if pending is not None:
@@ -480,17 +495,37 @@ class SRFlowEngine(object):
                 if ly.coupled:
                     cnd = self._await(cond[ly.level])
                     k = cnd["slot"][ly.index]
-                    ops.flow_pointwise(z, z, False, h_aff=pending, an_bias=st.an_bias, an_escale=st.an_exp,
-                                       w=st.w_fwd, wt=st.w_fwd_t, h_ft=cnd["h_ft"][:, 2 * ly.C * k: 2 * ly.C * (k + 1)])
-                    pending = self._self_cond(st, z, cnd, k, "enc%d" % ly.level)
-                    if logdet is not None:
-                        ops.logscale_sum(pending, logdet, 1.0)
-                        if ly.level not in ld_levels:           # the hoisted h_ft holds the scaleFt of all K steps of the level
-                            ld_levels.add(ly.level)
-                            ops.logscale_sum(cnd["h_ft"], logdet, 1.0)
+                    if not head_done:
+                        ops.flow_pointwise(z, z, False, h_aff=pending, an_bias=st.an_bias, an_escale=st.an_exp,
+                                           w=st.w_fwd, wt=st.w_fwd_t, h_ft=cnd["h_ft"][:, 2 * ly.C * k: 2 * ly.C * (k + 1)])
+                        pending = None
+                    head_done = False
+                    if getattr(st, "fused", False) and logdet is None:
+                        hid = ws.get("hid_enc%d" % ly.level, B, 64, H, W)
+                        ops.coupling_head(z, st.head, cnd["pre_aff"][:, 64 * k: 64 * (k + 1)], hid)
+                        # the tail applies this step's self-conditional affine and, when the next layer is another step of this
+                        # level, that step's head (what the generic path does lazily through `pending`)
+                        nxt = self.layers[pos + 1] if pos + 1 < len(self.layers) else None
+                        kw = {}
+                        if nxt is not None and nxt.type == "step":
+                            sn = self.steps[nxt.index]
+                            kw = dict(an_bias=sn.an_bias, an_escale=sn.an_exp, w=sn.w_fwd)
+                            if nxt.coupled:
+                                kn = cnd["slot"][nxt.index]
+                                kw["h_ft"] = cnd["h_ft"][:, 2 * ly.C * kn: 2 * ly.C * (kn + 1)]
+                            head_done = True
+                        ops.coupling_tail(hid, st.tail, z, z, False, **kw)
+                    else:
+                        pending = self._self_cond(st, z, cnd, k, "enc%d" % ly.level)
+                        if logdet is not None:
+                            ops.logscale_sum(pending, logdet, 1.0)
+                            if ly.level not in ld_levels:           # the hoisted h_ft holds the scaleFt of all K steps of the level
+                                ld_levels.add(ly.level)
+                                ops.logscale_sum(cnd["h_ft"], logdet, 1.0)
                 else:
-                    ops.flow_pointwise(z, z, False, h_aff=pending, an_bias=st.an_bias, an_escale=st.an_exp, w=st.w_fwd, wt=st.w_fwd_t)
-                    pending = None
+                    if not head_done:
+                        ops.flow_pointwise(z, z, False, h_aff=pending, an_bias=st.an_bias, an_escale=st.an_exp, w=st.w_fwd, wt=st.w_fwd_t)
+                    pending, head_done = None, False
                 ld_const += st.ld_const * H * W
             else:   # split
                 if pending is not None:
@@ -534,14 +569,20 @@ class SRFlowEngine(object):
                 if ly.coupled:
                     cnd = self._await(cond[ly.level])
                     k = cnd["slot"][ly.index]
-                    h_aff = self._self_cond(st, z, cnd, k, "dec%d" % ly.level)
-                    if logdet is not None:
-                        ops.logscale_sum(h_aff, logdet, -1.0)
-                        if ly.level not in ld_levels:
-                            ld_levels.add(ly.level)
-                            ops.logscale_sum(cnd["h_ft"], logdet, -1.0)
-                    ops.flow_pointwise(z, z, True, h_aff=h_aff, h_ft=cnd["h_ft"][:, 2 * C * k: 2 * C * (k + 1)],
-                                       w=st.w_inv, wt=st.w_inv_t, an_bias=st.an_bias, an_escale=st.an_expneg)
+                    if getattr(st, "fused", False) and logdet is None:
+                        hid = ws.get("hid_dec%d" % ly.level, z.shape[0], 64, H, W)
+                        ops.coupling_head(z, st.head, cnd["pre_aff"][:, 64 * k: 64 * (k + 1)], hid)
+                        ops.coupling_tail(hid, st.tail, z, z, True, h_ft=cnd["h_ft"][:, 2 * C * k: 2 * C * (k + 1)],
+                                          w=st.w_inv, an_bias=st.an_bias, an_escale=st.an_expneg)
+                    else:
+                        h_aff = self._self_cond(st, z, cnd, k, "dec%d" % ly.level)
+                        if logdet is not None:
+                            ops.logscale_sum(h_aff, logdet, -1.0)
+                            if ly.level not in ld_levels:
+                                ld_levels.add(ly.level)
+                                ops.logscale_sum(cnd["h_ft"], logdet, -1.0)
+                        ops.flow_pointwise(z, z, True, h_aff=h_aff, h_ft=cnd["h_ft"][:, 2 * C * k: 2 * C * (k + 1)],
+                                           w=st.w_inv, wt=st.w_inv_t, an_bias=st.an_bias, an_escale=st.an_expneg)
                 else:
                     ops.flow_pointwise(z, z, True, w=st.w_inv, wt=st.w_inv_t, an_bias=st.an_bias, an_escale=st.an_expneg)
                 ld_const -= st.ld_const * H * W

@@ -183,6 +183,39 @@ typedef struct BfsrFlowArgs {
 } BfsrFlowArgs;
 int bfsr_flow_pointwise(const BfsrFlowArgs* a, void* stream);
 
+/* ---- the sequential part of a conditional-affine FlowStep in two kernels (coupling.hip) -------------------------------------
+ * replaces, per coupled step of a level with C in {12, 24} flow channels (FlowAffineCouplingsAblation.py:57-135):
+ *   bfsr_coupling_head: hid = relu(AN2(W2 . relu(AN0(conv3x3(z[:, :Cz]; W0z) + pre_aff))))     (fAffine.0 on the z1 rows + the hoisted
+ *                       ft partial, fAffine.2; flow.Conv2d = conv without bias + ActNorm, flow.py:26-65); 3xBF16 arithmetic, the 1x1
+ *                       chained in registers.  epi0 / epi2: [64][4] floats {ActNorm bias, exp(logs), 0, 0}.
+ *   bfsr_coupling_tail: h_aff = (conv3x3(hid; W4) + b4) * exp(3*logs4)  (fAffine.4 = Conv2dZeros, flow.py:68-83) on 16-row fp32 MFMA
+ *                       tiles, then the pointwise chain of bfsr_flow_pointwise with that h_aff (same argument meaning: h_ft, wmat,
+ *                       an_bias / an_escale, reverse, eps; z_in and z_out may alias). */
+typedef struct BfsrCouplingHeadArgs {
+    const float* z; long long z_bs; int Cz;
+    const float* pre_aff; long long pre_aff_bs;
+    const unsigned short* w;                          /* bfsr_pack_coupling_head */
+    const float* epi0; const float* epi2;
+    float* hid; long long hid_bs;
+    int B, H, W;
+} BfsrCouplingHeadArgs;
+typedef struct BfsrCouplingTailArgs {
+    const float* hid; long long hid_bs; int Cin;      /* Cin = 64 */
+    const float* w; const float* bias; const float* post_scale;      /* bfsr_pack_coupling_tail; [2*(C-C/2)] each */
+    const float* z_in; long long z_in_bs;
+    float* z_out; long long z_out_bs;
+    const float* h_ft; long long h_ft_bs;
+    const float* wmat; const float* an_bias; const float* an_escale;
+    int B, C, H, W, reverse;
+    float eps;
+} BfsrCouplingTailArgs;
+int bfsr_coupling_head(const BfsrCouplingHeadArgs* a, void* stream);
+int bfsr_coupling_tail(const BfsrCouplingTailArgs* a, void* stream);
+long long bfsr_coupling_head_packed_size(int Cz);                                   /* bf16 elements */
+int bfsr_pack_coupling_head(const float* w0_z1, const float* w2, int Cz, unsigned short* packed);
+long long bfsr_coupling_tail_packed_size(int Cin, int Cout);                        /* floats */
+int bfsr_pack_coupling_tail(const float* w, int Cin, int Cout, float* packed);
+
 /* squeeze2d / unsqueeze2d, factor 2 (flow.py:122-152): x [B,C,H,W] <-> y [B,4C,H/2,W/2] */
 int bfsr_squeeze2d(const float* x, long long x_bs, float* y, long long y_bs, int B, int C, int H, int W,
                    void* stream);

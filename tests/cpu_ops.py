@@ -309,6 +309,26 @@ class CpuOps(object):
         out.copy_(torch.cat([((areas[i] / tot).unsqueeze(1) * coefs[i]) * freqs[i] for i in range(4)], 1))
         return out
 
+    def pack_coupling_head(self, w0_z1, w2, shift0, scale0, shift2, scale2):
+        f = lambda t: t.detach().to(torch.float32).clone()
+        return (f(w0_z1), f(w2).reshape(64, 64, 1, 1), f(shift0).reshape(-1), f(scale0).reshape(-1), f(shift2).reshape(-1),
+                f(scale2).reshape(-1))
+
+    def coupling_head(self, z, packed, pre_aff, hid):
+        w0, w2, s0, c0, s2, c2 = packed
+        t = F.relu((F.conv2d(z[:, :w0.shape[1]], w0, None, 1, 1) + pre_aff + _cv(s0)) * _cv(c0))
+        hid.copy_(F.relu((F.conv2d(t, w2) + _cv(s2)) * _cv(c2)))
+        return hid
+
+    def pack_coupling_tail(self, w4, bias, post_scale):
+        f = lambda t: t.detach().to(torch.float32).clone()
+        return f(w4), f(bias).reshape(-1), f(post_scale).reshape(-1), w4.shape[0]
+
+    def coupling_tail(self, hid, packed, z_in, z_out, reverse, h_ft=None, w=None, an_bias=None, an_escale=None, eps=1e-4):
+        w4, b4, ps, _ = packed
+        h_aff = (F.conv2d(hid, w4, None, 1, 1) + _cv(b4)) * _cv(ps)
+        return self.flow_pointwise(z_in, z_out, reverse, h_aff=h_aff, h_ft=h_ft, w=w, an_bias=an_bias, an_escale=an_escale, eps=eps)
+
     def pack_linf_mlp(self, ws, bs, x3=True):
         rnd = (lambda t: t) if x3 else (lambda t: t.half().float())
         return ([rnd(t.detach().to(torch.float32).reshape(t.shape[0], t.shape[1], 1, 1)).clone() for t in ws],

@@ -153,6 +153,41 @@ def test_conv_nearest_upsample_on_read(hip):
     close(out, ref, 2e-5, "conv in_shift")
 
 
+@pytest.mark.parametrize("Cz", [6, 12])
+@pytest.mark.parametrize("hw", [(16, 40), (9, 33), (70, 70)])
+def test_coupling_head(hip, Cz, hw):
+    """coupling.hip head: 3x3 on z1 (+ hoisted partial, ActNorm, ReLU) -> register-chained 1x1 (+ ActNorm, ReLU), 3xBF16."""
+    H, W = hw
+    B = 2
+    z, pre = rnd(61, B, 2 * Cz, H, W), rnd(62, B, 64, H, W, scale=0.5)
+    w0, w2 = rnd(63, 64, Cz, 3, 3, scale=0.1), rnd(64, 64, 64, 1, 1, scale=0.1)
+    s0, c0, s2, c2 = rnd(65, 64, scale=0.1), torch.exp(rnd(66, 64, scale=0.1)), rnd(67, 64, scale=0.1), torch.exp(rnd(68, 64, scale=0.1))
+    ref = CPU.coupling_head(z, CPU.pack_coupling_head(w0, w2, s0, c0, s2, c2), pre, torch.empty(B, 64, H, W))
+    out = hip.coupling_head(hip.to_device(z), hip.pack_coupling_head(w0, w2, s0, c0, s2, c2), hip.to_device(pre), hip.empty(B, 64, H, W))
+    close(out, ref, 2e-5, "coupling_head Cz=%d" % Cz)
+
+
+@pytest.mark.parametrize("C", [12, 24])
+@pytest.mark.parametrize("reverse", [0, 1])
+@pytest.mark.parametrize("hw", [(16, 40), (9, 33), (70, 70)])
+def test_coupling_tail(hip, C, reverse, hw):
+    """coupling.hip tail: Conv2dZeros 64 -> 2*(C - C/2) on 16-row fp32 MFMA tiles + the FlowStep pointwise chain, in place."""
+    H, W = hw
+    B, cc2 = 2, 2 * (C - C // 2)
+    hid, z = rnd(71, B, 64, H, W), rnd(72, B, C, H, W)
+    w4, b4, ps = rnd(73, cc2, 64, 3, 3, scale=0.02), rnd(74, cc2, scale=0.2), torch.exp(rnd(75, cc2, scale=0.2))
+    h_ft = rnd(76, B, 2 * C, H, W, scale=0.5)
+    Wm = torch.from_numpy(np.linalg.qr(np.random.Generator(np.random.PCG64(7)).standard_normal((C, C)))[0].astype(np.float32))
+    bias, es = rnd(77, C, scale=0.1), torch.exp(rnd(78, C, scale=0.1))
+    for kw in (dict(h_ft=h_ft, w=Wm, an_bias=bias, an_escale=es), dict()) if not reverse else (dict(h_ft=h_ft, w=Wm, an_bias=bias, an_escale=es),):
+        ref = CPU.coupling_tail(hid, CPU.pack_coupling_tail(w4, b4, ps), z, torch.empty_like(z), reverse,
+                                **{k: (v.reshape(-1) if k == "w" else v) for k, v in kw.items()})
+        zd = hip.to_device(z).clone()
+        dkw = {k: (hip.vec(v) if v.dim() <= 2 else hip.to_device(v)) for k, v in kw.items()}
+        hip.coupling_tail(hip.to_device(hid), hip.pack_coupling_tail(w4, b4, ps), zd, zd, reverse, **dkw)
+        close(zd, ref, 2e-5, "coupling_tail C=%d rev=%d" % (C, reverse))
+
+
 @pytest.mark.parametrize("C", [12, 24, 96])
 @pytest.mark.parametrize("reverse", [0, 1])
 @pytest.mark.parametrize("hw", [(16, 24), (7, 9)])

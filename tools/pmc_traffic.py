@@ -10,8 +10,13 @@ import glob
 import json
 import sys
 
-LIB = ("conv_", "flow_pointwise", "squeeze2d", "unsqueeze2d", "split2d", "standardize", "resize_kernel", "maxpool2",
-       "axpb_clamp", "linf_", "patch_", "grid_sample")
+LIB = ("conv_", "conv3x3_x3s", "x3_pack", "x3_unpack", "coupling_", "flow_pointwise", "squeeze2d", "unsqueeze2d", "split2d",
+       "standardize", "resize_kernel", "maxpool2", "axpb_clamp", "linf_", "patch_", "grid_sample")
+# FETCH_SIZE on gfx950 counts 64 B per 128-B request (MI355X_MICROARCH.md, HBM; documented there for 16-B-per-lane streaming reads).
+# Calibration for THIS library's access patterns, from the same PMC run (profiles/r02_pmc_traffic.json "calibration"): the plain 1x1
+# conv 64->64 @ 8x320x320 reads its 209.7 MB input exactly once with 4-byte-per-lane row loads and reports 105.3 MB raw = 0.502, so the
+# x2 reading holds for the 4-byte row loads of the conv kernels as well as for the 16-byte LDS-DMA of conv_x3s: x2 for every family.
+WIDE_READERS = ("conv", "coupling", "linf", "flow")     # calibrated in r02: the 1x1 conv 64->64 reads its input once, raw FETCH_SIZE = 0.50 of it -> x2 everywhere
 
 
 def per_key(d, keylog, counter):
@@ -36,15 +41,18 @@ fetch = per_key(sys.argv[1], sys.argv[2], "FETCH_SIZE")
 write = per_key(sys.argv[3], sys.argv[4], "WRITE_SIZE")
 out = {"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python bench.py --steps 1 --warmup 1 "
                   "--no-cpu-baseline --no-fp32-line (one pass per counter, BFSR_KEYLOG to map dispatches to launch shapes)",
-       "units": "rocprofv3 reports KB; bytes = KB * 1024; fetch corrected x2 (gfx950)", "kernels": collections.OrderedDict()}
+       "units": "rocprofv3 reports KB; bytes = KB * 1024; hbm_bytes_per_launch = fetch (x2 only for 16-B-per-lane readers, see fetch_correction) + write",
+       "kernels": collections.OrderedDict()}
 rows = []
 for k, fa in fetch.items():
     wa = write.get(k)
-    if not wa or not k.startswith('["conv'):
+    if not wa or not (k.startswith('["conv') or k.startswith('["coupling') or k.startswith('["linf_mlp') or k.startswith('["flow')):
         continue
     fb, wb = fa["sum"] / fa["n"] * 1024.0, wa["sum"] / wa["n"] * 1024.0
-    rows.append((fa["n"] * (2 * fb + wb), k, {"kernel": fa["kernel"], "launches": fa["n"], "fetch_bytes_raw": fb, "write_bytes": wb,
-                                             "fetch_bytes_corrected_x2": 2 * fb, "hbm_bytes_per_launch": 2 * fb + wb}))
-for _, k, v in sorted(rows, reverse=True)[:12]:
+    corr = 2.0 if any(k.startswith('["%s"' % w) for w in WIDE_READERS) else 1.0
+    rows.append((fa["n"] * (corr * fb + wb), k, {"kernel": fa["kernel"], "launches": fa["n"], "fetch_bytes_raw": fb, "write_bytes": wb,
+                                                "fetch_correction": corr, "hbm_bytes_per_launch": corr * fb + wb,
+                                                "unit": "HBM-side bytes per launch: rocprofv3 FETCH_SIZE x %g + WRITE_SIZE" % corr}))
+for _, k, v in sorted(rows, reverse=True)[:16]:
     out["kernels"][k] = v
 print(json.dumps(out, indent=1))

@@ -242,14 +242,18 @@ def main():
             gatherer.submit(sr)           # gather of step i overlaps the compute of step i+1
         return sr
 
-    # warm-up: the last warm-up step brackets EVERY launch with HIP events to rank the launch shapes; the timed region then
-    # only brackets the launches of the top shapes (+ the inverse tail), keeping the host overhead negligible
+    # warm-up, then ONE untimed ranking step that brackets EVERY launch with HIP events to rank the launch shapes; the timed region
+    # then only brackets the launches of the top shapes (+ the inverse tail), keeping the host overhead negligible
     C1 = 12
     key_tail = ("flow", 1, C1, B, H // 2, H // 2, True, True, True) if srflow else None
     for i in range(args.warmup):
-        if i == args.warmup - 1:
-            ops.profile_keys, ops.profile = "ALL", {}
         step(i)
+    gatherer.finish()
+    torch.cuda.synchronize()
+    # one extra UNTIMED ranking step after the warm-up (allocator and caches are warm, so no first-touch stalls leak into the event
+    # times): every launch bracketed by HIP events
+    ops.profile_keys, ops.profile = "ALL", {}
+    step(args.warmup)
     gatherer.finish()
     torch.cuda.synchronize()
     ranked = sorted(((sum(s_.elapsed_time(e_) for s_, e_ in ev), k) for k, ev in ops.profile.items()
@@ -261,13 +265,13 @@ def main():
         warm_total_ms += t
         fam = FAMILIES[k[0]][0] if k[0] in FAMILIES else k[0]
         warm_by_family[fam] = warm_by_family.get(fam, 0.0) + t
-    ops.profile_keys = set([k for _, k in ranked[:4]] + ([key_tail] if key_tail else [])) if args.warmup > 0 else "ALL"
+    ops.profile_keys = set([k for _, k in ranked[:4]] + ([key_tail] if key_tail else []))
     ops.profile = {}
     bdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i)
+        step(args.warmup + 1 + i)
     gatherer.finish()
     torch.cuda.synchronize()
     bdist.barrier()

@@ -55,6 +55,32 @@ __device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l)
     l = (__bf16)(r1 - (float)m);
 }
 
+// sin(x), cos(x) for the Fourier features (x = fl(pi * f), the product the reference forms before torch.cos / torch.sin).  The
+// libdevice sincosf costs ~250 VALU instructions per call (generic argument reduction, special cases) and made the fused kernel
+// VALU-bound (512 calls per query point).  For |x| < 200 (always, unless a checkpoint has enormous frequencies) a three-term
+// Cody-Waite reduction by pi/2 with FMAs and the classic single-precision minimax polynomials on [-pi/4, pi/4] give <= 2 ulp
+// (checked against fp64 over the argument range in tests/test_linf_gpu.py::test_linf_mlp_fused); larger arguments take the
+// library path.
+__device__ __forceinline__ void sincos_feat(float x, float& s, float& c)
+{
+    if (!(fabsf(x) < 200.f)) { sincosf(x, &s, &c); return; }
+    const float kf = rintf(x * 0.636619772367581343f);               // nearest multiple of pi/2
+    float r = fmaf(-kf, 1.57079637050628662109375f, x);              // pi/2 = C1 + C2 + C3
+    r = fmaf(-kf, -4.37113900018624283e-8f, r);
+    r = fmaf(-kf, -1.71512451306013e-15f, r);
+    const float r2 = r * r;
+    float ps = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = fmaf(r2, ps, -1.6666654611e-1f);
+    const float sr = fmaf(r * r2, ps, r);                            // sin(r)
+    float pc = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = fmaf(r2, pc, 4.166664568298827e-2f);
+    const float cr = fmaf(r2 * r2, pc, fmaf(r2, -0.5f, 1.f));        // cos(r)
+    const int k = (int)kf;
+    const float s0 = (k & 1) ? cr : sr, c0 = (k & 1) ? sr : cr;
+    s = (k & 2) ? -s0 : s0;
+    c = ((k + 1) & 2) ? -c0 : c0;
+}
+
 // 8 fp32 values of one point (8 consecutive channels of a chunk half) -> PL fragments of 16 B
 template <bool X3>
 __device__ __forceinline__ void encode8(const float (&v)[8], typename Mode<X3>::frag (&out)[Mode<X3>::PL])
@@ -69,7 +95,7 @@ __device__ __forceinline__ void encode8(const float (&v)[8], typename Mode<X3>::
 }
 
 template <bool X3>
-__global__ __launch_bounds__(NW * 64, 1) void linf_mlp_kernel(BfsrLinfMlpArgs a, int tiles_per_image)
+__global__ __launch_bounds__(NW * 64, X3 ? 2 : 4) void linf_mlp_kernel(BfsrLinfMlpArgs a, int tiles_per_image)
 {
     typedef Mode<X3> MD;
     typedef typename MD::frag frag;
@@ -125,24 +151,33 @@ __global__ __launch_bounds__(NW * 64, 1) void linf_mlp_kernel(BfsrLinfMlpArgs a,
     // k half 0 = cos features (channel k*256 + c), k half 1 = sin features (channel k*256 + 128 + c): W1 is packed in this order
     // k is wave-uniform but not a compile-time constant: the four per-neighbour values are picked with selects (an array
     // indexed by a run-time k would be demoted to scratch memory)
-    auto gen_chunk = [&](int k, int c0, unsigned char* dst) {
+    struct Gather { float co0[8], co1[8], f0[8], f1[8]; };
+    auto gen_load = [&](int k, int c0, Gather& g) {
+        const int ofs = k == 0 ? off[0] : (k == 1 ? off[1] : (k == 2 ? off[2] : off[3]));
+        const float* cfp = cfb + ofs;
+        // all 32 gathers of a chunk back to back; they are consumed by gen_finish AFTER the MFMAs of the current interval, so the
+        // gather latency (PMC: the waves were 65 % parked in s_waitcnt when each pair's loads were waited for separately) is hidden
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            g.co0[e] = cfp[(long long)c * hw]; g.co1[e] = cfp[(long long)(HID / 2 + c) * hw];
+            g.f0[e] = cfp[(long long)(HID + c) * hw]; g.f1[e] = cfp[(long long)(HID + HID / 2 + c) * hw];
+        }
+    };
+    auto gen_finish = [&](int k, int c0, const Gather& g, unsigned char* dst) {
         const float ry = k == 0 ? rel_y[0] : (k == 1 ? rel_y[1] : (k == 2 ? rel_y[2] : rel_y[3]));
         const float rx = k == 0 ? rel_x[0] : (k == 1 ? rel_x[1] : (k == 2 ? rel_x[2] : rel_x[3]));
         const float wgt = k == 0 ? wk[0] : (k == 1 ? wk[1] : (k == 2 ? wk[2] : wk[3]));
-        const int ofs = k == 0 ? off[0] : (k == 1 ? off[1] : (k == 2 ? off[2] : off[3]));
-        const float* cfp = cfb + ofs;
         float vc[8], vs[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = c0 + e;
-            const float co0 = cfp[(long long)c * hw], co1 = cfp[(long long)(HID / 2 + c) * hw];
-            const float f0 = cfp[(long long)(HID + c) * hw], f1 = cfp[(long long)(HID + HID / 2 + c) * hw];
-            float f = f0 * ry + f1 * rx;
+            float f = g.f0[e] * ry + g.f1[e] * rx;
             f = f + (cell_y * a.phase[c * 2 + 0] + cell_x * a.phase[c * 2 + 1]);
             float s, cs;
-            sincosf(PI * f, &s, &cs);
-            vc[e] = (wgt * co0) * cs;
-            vs[e] = (wgt * co1) * s;
+            sincos_feat(PI * f, s, cs);
+            vc[e] = (wgt * g.co0[e]) * cs;
+            vs[e] = (wgt * g.co1[e]) * s;
         }
         frag fc[PL], fs[PL];
         encode8<X3>(vc, fc);
@@ -177,6 +212,21 @@ __global__ __launch_bounds__(NW * 64, 1) void linf_mlp_kernel(BfsrLinfMlpArgs a,
         } else {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[nt] = MD::mfma(af[0], bf[0][nt], acc[nt]);
+        }
+    };
+    // K loop of one output tile over n chunks of 16 channels whose B operands sit at chunk0, chunk0 + CHUNK, ...: the A fragments
+    // (weights, straight from global / L2: ~1 us away) run THREE chunks ahead in a ring of four -- with one chunk of lookahead
+    // the loop was bound by the weight-load latency (12 MFMAs = 384 cycles per chunk vs > 1000 cycles of L2 latency)
+    auto k_loop = [&](f32x16 (&acc_)[2], const unsigned short* wl, int nchunk_total, int mt, int kc0, int n, const unsigned char* chunk0) {
+        frag af[4][PL], bf[PL][2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < n) load_a(wl, nchunk_total, mt, kc0 + i, af[i]);
+#pragma unroll 4
+        for (int c = 0; c < n; ++c) {
+            if (c + 3 < n) load_a(wl, nchunk_total, mt, kc0 + c + 3, af[(c + 3) & 3]);
+            load_b(chunk0 + c * CHUNK, bf);
+            mma(acc_, af[c & 3], bf);
         }
     };
     // one output tile of a hidden layer -> bias, ReLU, channel-octet transposition, re-encode, write as activation chunks
@@ -219,21 +269,21 @@ __global__ __launch_bounds__(NW * 64, 1) void linf_mlp_kernel(BfsrLinfMlpArgs a,
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-    gen_chunk(0, wave * 8, smem + wave * CHUNK);                      // interval 0 (chunk kc = wave) -> stage A
+    {
+        Gather g0;
+        gen_load(0, wave * 8, g0);
+        gen_finish(0, wave * 8, g0, smem + wave * CHUNK);             // interval 0 (chunk kc = wave) -> stage A
+    }
     __syncthreads();
 #pragma unroll 1
     for (int t = 0; t < 8; ++t) {
-        // interval t+1: chunk kc = (t+1)*8 + wave -> neighbour (t+1)/2, pair block kc % 16
-        if (t + 1 < 8) gen_chunk((t + 1) >> 1, ((((t + 1) & 1) * 8) + wave) * 8, smem + (((t + 1) & 1) * 8 + wave) * CHUNK);
-        const unsigned char* stage = smem + (t & 1) * 8 * CHUNK;
-        frag af[2][PL], bf[PL][2];
-        load_a(w1, K1 / KC, wave, t * 8, af[0]);
-#pragma unroll 2
-        for (int c = 0; c < 8; ++c) {
-            if (c + 1 < 8) load_a(w1, K1 / KC, wave, t * 8 + c + 1, af[(c + 1) & 1]);
-            load_b(stage + c * CHUNK, bf);
-            mma(acc, af[c & 1], bf);
-        }
+        // interval t+1: chunk kc = (t+1)*8 + wave -> neighbour (t+1)/2, pair block kc % 16: gathers issued, then the MFMAs of
+        // interval t (which read stage t), then the arithmetic of interval t+1 into the other stage
+        const int nk = (t + 1) >> 1, nc0 = ((((t + 1) & 1) * 8) + wave) * 8;
+        Gather g;
+        if (t + 1 < 8) gen_load(nk, nc0, g);
+        k_loop(acc, w1, K1 / KC, wave, t * 8, 8, smem + (t & 1) * 8 * CHUNK);
+        if (t + 1 < 8) gen_finish(nk, nc0, g, smem + (((t + 1) & 1) * 8 + wave) * CHUNK);
         __syncthreads();
     }
     store_hidden(acc, a.bias, wave);                                 // all waves are past the last interval's reads (barrier above)
@@ -246,14 +296,7 @@ __global__ __launch_bounds__(NW * 64, 1) void linf_mlp_kernel(BfsrLinfMlpArgs a,
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-        frag af[2][PL], bf[PL][2];
-        load_a(wl, NCH_HID, wave, 0, af[0]);
-#pragma unroll 2
-        for (int c = 0; c < NCH_HID; ++c) {
-            if (c + 1 < NCH_HID) load_a(wl, NCH_HID, wave, c + 1, af[(c + 1) & 1]);
-            load_b(smem + c * CHUNK, bf);
-            mma(acc, af[c & 1], bf);
-        }
+        k_loop(acc, wl, NCH_HID, wave, 0, NCH_HID, smem);
         __syncthreads();                                             // everybody has read the layer input
         store_hidden(acc, a.bias + layer * HID, wave);
         __syncthreads();
@@ -270,14 +313,7 @@ __global__ __launch_bounds__(NW * 64, 1) void linf_mlp_kernel(BfsrLinfMlpArgs a,
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-            frag af[2][PL], bf[PL][2];
-            load_a(wl, NCH_HID, mt, 0, af[0]);
-#pragma unroll 2
-            for (int c = 0; c < NCH_HID; ++c) {
-                if (c + 1 < NCH_HID) load_a(wl, NCH_HID, mt, c + 1, af[(c + 1) & 1]);
-                load_b(smem + c * CHUNK, bf);
-                mma(acc, af[c & 1], bf);
-            }
+            k_loop(acc, wl, NCH_HID, mt, 0, NCH_HID, smem);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const long long qq = q0 + nt * 32 + l31;

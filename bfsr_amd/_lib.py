@@ -131,6 +131,11 @@ SYMBOLS = {
     "bfsr_conv3x3_x3s": (_I, [C.POINTER(BfsrConvX3Args), _VP]),
     "bfsr_x3_pack": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
     "bfsr_x3_unpack": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
+    "bfsr_conv3x3_h2s": (_I, [C.POINTER(BfsrConvX3Args), _VP]),
+    "bfsr_conv_packed_size_h2s": (_LL, [_I, _I]),
+    "bfsr_pack_conv_weight_h2s": (_I, [_VP, _I, _I, _VP]),
+    "bfsr_h2_pack": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
+    "bfsr_h2_unpack": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
     "bfsr_conv1x1": (_I, [C.POINTER(BfsrConvArgs), _I, _VP]),
     "bfsr_conv1x1_packed_size": (_LL, [_I, _I, _I]),
     "bfsr_pack_conv1x1_weight": (_I, [_VP, _I, _I, _I, _VP]),

@@ -1,0 +1,328 @@
+// conv_h2s.hip -- 3x3 'same' conv on the fp16 matrix pipe (v_mfma_f32_32x32x16_f16, fp32 accumulation) over activations that are
+// STORED in fp16, for the dense blocks of the RRDB encoder on the reduced-precision path (LINF precision='fp16', BASELINE
+// config 5; LINF-LP/models/rrdb.py:38-76).
+//
+// Why: conv_f16_kernel reads fp32 NCHW activations and rounds them to fp16 while staging (global load -> VALU -> ds_write,
+// two barriers per 16-channel chunk); on the RDB shapes it is bound by that staging, not by the matrix pipe (one product per
+// operand pair instead of the six of the 3xBF16 path, yet only 1.6x faster per pixel than conv3x3_x3s_kernel).  Here the
+// producer's epilogue writes fp16 once and the tiles are staged by LDS-DMA (`buffer_load ... lds`), like conv_x3s.hip.
+//
+// h2 tensor layout: [B][C/8][2 planes hi,lo][H][W][8] fp16 with hi = fp16(x), lo = fp16(x - hi): x ~ hi + lo to 22 significant
+// bits.  A conv reads ONLY the hi plane (= exactly the operand conv_f16_kernel forms by rounding at staging time, so the two
+// kernels contract identical numbers); the lo plane exists for the tensors that are residual operands (the RDB / RRDB trunk:
+// `x5*0.2 + x`), whose sum must not be re-rounded to 11 bits at each of the 69 dense blocks.  Outputs that only ever feed
+// convs (x1..x4 of a dense block) are written hi-only (y_fmt 2).
+//
+// GEMM view per workgroup: M = 32 output channels, N = 16 rows x 32 pixels (compute wave w owns rows 2w, 2w+1: every weight
+// fragment feeds two MFMAs and the four input rows of a tap column feed six), K = 16 channels per chunk x 9 taps.
+// LDS stage = input [2 k halves][640 positions][8] (18 x 34 tile, padded to 10 x 64 positions) + weights [9 taps][2][32][8]
+// = 20 480 + 9 216 B; FOUR stages (118 784 B): a chunk is only 576 MFMA cycles per wave, shorter than an HBM round trip, so the
+// four dedicated loader waves run up to three chunks ahead (across tile boundaries) and park on `s_waitcnt vmcnt(N)` with N =
+// the pieces of the later stages.  One barrier per chunk; the eight compute waves issue nothing but ds_read_b128 + MFMA
+// (21 reads per 18 MFMAs: 58 % of the LDS read rate at full matrix rate).  Persistent workgroups, XCD-aware order.
+#include <hip/hip_runtime.h>
+#include "../../include/bfsr_hip.h"
+#include "launch_util.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+namespace {
+
+constexpr int NW = 8, NL = 4, NS = 4;
+constexpr int TH = 16, PW = 34, NPOS = (TH + 2) * PW, NG = 10, NPOSP = NG * 64;
+constexpr int SUB = NPOSP * 16;                 // bytes of one k-half sub-image (8 channels of every tile position)
+constexpr int IN_BYTES = 2 * SUB;               // 20 480
+constexpr int W_BYTES = 9 * 1024;               // 9 216: one 1-KiB piece per tap
+constexpr int STAGE = IN_BYTES + W_BYTES;
+constexpr int LDS_TOTAL = NS * STAGE;           // 118 784
+constexpr unsigned OOB = 0x80000000u;
+
+struct Item { int cg, b, x0, y0; };
+
+__device__ __forceinline__ void split2(float v, _Float16& h, _Float16& l)
+{
+    h = (_Float16)v;
+    l = (_Float16)(v - (float)h);
+}
+
+__global__ __launch_bounds__((NW + NL) * 64, 1) void conv3x3_h2s_kernel(BfsrConvX3Args p, int tiles_x, int tiles_y, int groups, int nitems)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int G = gridDim.x;
+    const int slot = (int)bfsr::xcd_order(blockIdx.x, (unsigned)G);      // see conv_x3s.hip: one XCD walks neighbouring tiles
+    if (slot >= nitems) return;
+    const int H = p.H, W = p.W;
+    const unsigned HW16 = (unsigned)(H * W) * 16u;                       // bytes of one (octet, plane) image
+    const int nchunk = p.Cin >> 4;
+
+    auto decode = [&](int it) {
+        Item r;
+        r.cg = it % groups; int t = it / groups;
+        const int ty = t % tiles_y; t /= tiles_y;
+        r.x0 = (t % tiles_x) * 32; r.y0 = ty * TH; r.b = t / tiles_x;
+        return r;
+    };
+
+    if (wave >= NW) {
+        // ---- loader waves.  29 pieces of 1 KiB per stage: loader ld owns input k half (ld & 1), position groups (ld>>1) + 2j
+        // (j = 0..4), and weight taps ld, ld+4, ld+8 (< 9): 8 pieces for loader 0, 7 for the others -- the same count for every
+        // chunk, which is what lets `vmcnt(N)` stand for "everything but the youngest N/np stages has landed".
+        const int ld = wave - NW, oc = ld & 1, g0 = ld >> 1;
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w), 0,
+                                                                              (unsigned)((long long)groups * nchunk * W_BYTES), 0x00020000);
+        __amdgpu_buffer_rsrc_t rs_in;
+        unsigned vg[5];
+        int cg_ = 0;
+        auto lsetup = [&](const Item& it) {
+            const unsigned short* xb = p.x + (long long)it.b * p.x_bs;
+            rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xb), 0, (unsigned)(p.Cin >> 3) * 2u * HW16, 0x00020000);
+            cg_ = it.cg;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int pos = (g0 + 2 * j) * 64 + lane;
+                const int r = pos / PW, c = pos - r * PW;
+                const int gy = it.y0 + r - 1, gx = it.x0 + c - 1;
+                const bool ok = pos < NPOS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                vg[j] = ok ? (unsigned)(gy * W + gx) * 16u : OOB;        // out of range -> the DMA writes zeros (= the padding)
+            }
+        };
+        auto lstage = [&](int k, int buf) {
+            unsigned char* base = smem + buf * STAGE;
+            const unsigned soff = (unsigned)(2 * k + oc) * 2u * HW16;    // hi plane of channel octet 2k + oc
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(base + oc * SUB + (g0 + 2 * j) * 1024), 16, vg[j], soff, 0, 0);
+            const unsigned wsoff = (unsigned)(cg_ * nchunk + k) * (unsigned)W_BYTES;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                if (ld + 4 * t < 9)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(base + IN_BYTES + (ld + 4 * t) * 1024), 16,
+                                                             (unsigned)lane * 16u + (unsigned)(ld + 4 * t) * 1024u, wsoff, 0, 0);
+        };
+        const int n_mine = (nitems - slot + G - 1) / G;
+        const int T = n_mine * nchunk;                                   // chunks this workgroup consumes
+        int issued = 0, iss_it = slot, iss_k = 0;
+        auto issue = [&]() {
+            if (iss_k == 0) lsetup(decode(iss_it));
+            lstage(iss_k, issued & (NS - 1));
+            ++issued;
+            if (++iss_k == nchunk) { iss_k = 0; iss_it += G; }
+        };
+        for (int i = 0; i < NS - 1 && issued < T; ++i) issue();
+        for (int c = 0; c < T; ++c) {
+            const int ahead = issued - c - 1;                            // stages issued after chunk c's
+            if (ahead >= 2) { if (ld == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
+            else if (ahead == 1) { if (ld == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                // chunk c is in LDS; stage (c-1) % NS is free again
+            if (issued < T) issue();
+        }
+        return;
+    }
+
+    // ---- compute waves -------------------------------------------------------------------------------------------------
+    int c = 0;
+    const float slope = p.act == BFSR_ACT_NONE ? 1.f : (p.act == BFSR_ACT_RELU ? 0.f : p.slope);
+    const float4* __restrict__ epi = reinterpret_cast<const float4*>(p.epi);
+    const long long HW = (long long)H * W;
+    for (int it = slot; it < nitems; it += G) {
+        const Item cur = decode(it);
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        for (int k = 0; k < nchunk; ++k) {
+            __builtin_amdgcn_s_barrier();
+            const unsigned char* sIn = smem + (c & (NS - 1)) * STAGE;
+            ++c;
+            const unsigned char* inB = sIn + (lhi * NPOSP + 2 * wave * PW + l31) * 16;
+            const unsigned char* wA = sIn + IN_BYTES + (lhi * 32 + l31) * 16;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                half8 b[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b[r] = *reinterpret_cast<const half8*>(inB + (r * PW + dx) * 16);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const half8 a = *reinterpret_cast<const half8*>(wA + (dy * 3 + dx) * 1024);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[dy], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[dy + 1], acc1, 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- epilogue (the loaders are already staging the next item).  acc[r] = channel (r&3) + 8(r>>2) + 4*lhi of pixel
+        // (row, x0 + l31); v_permlane32_swap pairs the half-waves so that each lane holds two complete channel octets.
+        // Inline asm for the reason given in conv_x3s.hip (the builtin is folded on MFMA results); the pads cover the
+        // MFMA -> VALU-read and VALU-write -> permlane hazards the compiler does not see around asm.
+        asm volatile("s_nop 11" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v[2][8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float lo = j ? acc1[8 * q + i] : acc0[8 * q + i], hi = j ? acc1[8 * q + 4 + i] : acc0[8 * q + 4 + i];
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+                    v[q][i] = lo;
+                    v[q][4 + i] = hi;
+                }
+            const int gy = cur.y0 + 2 * wave + j, gx = cur.x0 + l31;
+            if (gy >= H || gx >= W) continue;
+            const long long pix = (long long)gy * W + gx;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int oct = cur.cg * 4 + q * 2 + lhi;
+                if (oct * 8 >= p.Cout) continue;
+                float o8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int co = oct * 8 + i;
+                    float4 q0 = make_float4(0.f, 0.f, 1.f, 0.f); float q1 = 1.f;
+                    if (epi && co < p.Cout) { q0 = epi[co * 2]; q1 = epi[co * 2 + 1].x; }
+                    float u = v[q][i] + q0.x;
+                    u = (u + q0.y) * q0.z + q0.w;
+                    u = u > 0.f ? u : u * slope;
+                    o8[i] = u * q1;
+                }
+                auto add_res = [&](const unsigned short* res, long long bs, float alpha) {
+                    const unsigned short* rb = res + (long long)cur.b * bs + ((long long)oct * 2 * HW + pix) * 8;
+                    const half8 h = *reinterpret_cast<const half8*>(rb);
+                    const half8 l = *reinterpret_cast<const half8*>(rb + HW * 8);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o8[i] = alpha * o8[i] + ((float)h[i] + (float)l[i]);
+                };
+                if (p.res1) add_res(p.res1, p.res1_bs, p.alpha1);
+                if (p.res2) add_res(p.res2, p.res2_bs, p.alpha2);
+                if (p.y_fmt != 0) {
+                    half8 h8, l8;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { _Float16 h, l; split2(o8[i], h, l); h8[i] = h; l8[i] = l; }
+                    unsigned short* yb = reinterpret_cast<unsigned short*>(p.y) + (long long)cur.b * p.y_bs + ((long long)oct * 2 * HW + pix) * 8;
+                    *reinterpret_cast<half8*>(yb) = h8;
+                    if (p.y_fmt == 1) *reinterpret_cast<half8*>(yb + HW * 8) = l8;
+                } else {
+                    float* yb = reinterpret_cast<float*>(p.y) + (long long)cur.b * p.y_bs + pix;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (oct * 8 + i < p.Cout) yb[(long long)(oct * 8 + i) * HW] = o8[i];
+                }
+            }
+        }
+    }
+}
+
+// ---- fp32 NCHW view <-> h2 tensor (the two ends of the fp16-stored region: conv_first's output, the trunk output) -------------
+__global__ void h2_pack_kernel(const float* __restrict__ x, long long x_bs, unsigned short* __restrict__ y, long long y_bs,
+                               int C, long long HW, long long total)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int C8 = C >> 3;
+    const long long pix = i % HW; const long long t = i / HW;
+    const int oct = (int)(t % C8); const int b = (int)(t / C8);
+    const float* xb = x + (long long)b * x_bs + (long long)oct * 8 * HW + pix;
+    half8 h8, l8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { _Float16 h, l; split2(xb[(long long)j * HW], h, l); h8[j] = h; l8[j] = l; }
+    unsigned short* yb = y + (long long)b * y_bs + ((long long)oct * 2 * HW + pix) * 8;
+    *reinterpret_cast<half8*>(yb) = h8;
+    *reinterpret_cast<half8*>(yb + HW * 8) = l8;
+}
+
+__global__ void h2_unpack_kernel(const unsigned short* __restrict__ x, long long x_bs, float* __restrict__ y, long long y_bs,
+                                 int C, long long HW, long long total)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int C8 = C >> 3;
+    const long long pix = i % HW; const long long t = i / HW;
+    const int oct = (int)(t % C8); const int b = (int)(t / C8);
+    const unsigned short* xb = x + (long long)b * x_bs + ((long long)oct * 2 * HW + pix) * 8;
+    const half8 h = *reinterpret_cast<const half8*>(xb);
+    const half8 l = *reinterpret_cast<const half8*>(xb + HW * 8);
+    float* yb = y + (long long)b * y_bs + (long long)oct * 8 * HW + pix;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) yb[(long long)j * HW] = (float)h[j] + (float)l[j];
+}
+
+inline unsigned short f32_to_f16_bits(float v)
+{
+    const _Float16 h = (_Float16)v;              // round to nearest even, like the device conversion
+    unsigned short u;
+    __builtin_memcpy(&u, &h, 2);
+    return u;
+}
+
+}  // namespace
+
+extern "C" long long bfsr_conv_packed_size_h2s(int Cout, int Cin)
+{
+    if (Cout <= 0 || Cin <= 0 || (Cin & 15)) return -1;
+    return (long long)((Cout + 31) / 32) * (Cin / 16) * (W_BYTES / 2);          // fp16 elements
+}
+
+extern "C" int bfsr_pack_conv_weight_h2s(const float* w, int Cout, int Cin, unsigned short* packed)
+{
+    // w [Cout][Cin][3][3] fp32 -> fp16 [cout group of 32][16-channel chunk][tap = dy*3+dx][k half][32][8], zero padded
+    if (!w || !packed || Cout <= 0 || Cin <= 0 || (Cin & 15)) return -1;
+    const int nchunk = Cin / 16;
+    const long long n = bfsr_conv_packed_size_h2s(Cout, Cin);
+    for (long long i = 0; i < n; ++i) packed[i] = 0;
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int t = 0; t < 9; ++t)
+                packed[(((((long long)(co / 32) * nchunk + ci / 16) * 9 + t) * 2 + (ci % 16) / 8) * 32 + co % 32) * 8 + ci % 8] =
+                    f32_to_f16_bits(w[((long long)co * Cin + ci) * 9 + t]);
+    return 0;
+}
+
+extern "C" int bfsr_conv3x3_h2s(const BfsrConvX3Args* a, void* stream)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!a || !a->x || !a->w || !a->y) return -1;
+    if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cin <= 0 || (a->Cin & 15) || a->Cout <= 0) return -1;
+    if (a->y_fmt < 0 || a->y_fmt > 2) return -1;
+    if ((a->y_fmt != 0 || a->res1 || a->res2) && (a->Cout & 7)) return -1;
+    if ((long long)(a->Cin / 8) * 2 * a->H * a->W * 16 >= (1LL << 31)) return -1;      // 32-bit byte offsets inside one batch item
+    if ((reinterpret_cast<unsigned long long>(a->x) & 15) || (a->x_bs & 7)) return -1;
+    if (a->y_fmt != 0 && ((reinterpret_cast<unsigned long long>(a->y) & 15) || (a->y_bs & 7))) return -1;
+    if (a->res1 && ((reinterpret_cast<unsigned long long>(a->res1) & 15) || (a->res1_bs & 7))) return -1;
+    if (a->res2 && ((reinterpret_cast<unsigned long long>(a->res2) & 15) || (a->res2_bs & 7))) return -1;
+    const int tiles_x = (a->W + 31) / 32, tiles_y = (a->H + TH - 1) / TH;
+    const int groups = (a->Cout + 31) / 32;
+    const long long nitems = (long long)tiles_x * tiles_y * groups * a->B;
+    if (nitems > 0x7fffffffLL) return -1;
+    if ((long long)groups * (a->Cin / 16) * W_BYTES >= (1LL << 32)) return -1;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (a->tune > 0) cus = a->tune;
+    const long long grid = nitems < cus ? nitems : cus;                  // one persistent workgroup per CU
+    static std::atomic<unsigned long long> lds_done{0};
+    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2s_kernel), LDS_TOTAL, lds_done) != 0) return -1;
+    hipLaunchKernelGGL(conv3x3_h2s_kernel, dim3((unsigned)grid), dim3((NW + NL) * 64), LDS_TOTAL, st, *a, tiles_x, tiles_y, groups, (int)nitems);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bfsr_h2_pack(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int C, int H, int W, void* stream)
+{
+    if (!x || !y || B <= 0 || C <= 0 || (C & 7) || H <= 0 || W <= 0) return -1;
+    if ((reinterpret_cast<unsigned long long>(y) & 15) || (y_bs & 7)) return -1;
+    const long long HW = (long long)H * W, total = (long long)B * (C / 8) * HW;
+    hipLaunchKernelGGL(h2_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, x_bs, y, y_bs, C, HW, total);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bfsr_h2_unpack(const unsigned short* x, long long x_bs, float* y, long long y_bs, int B, int C, int H, int W, void* stream)
+{
+    if (!x || !y || B <= 0 || C <= 0 || (C & 7) || H <= 0 || W <= 0) return -1;
+    if ((reinterpret_cast<unsigned long long>(x) & 15) || (x_bs & 7)) return -1;
+    const long long HW = (long long)H * W, total = (long long)B * (C / 8) * HW;
+    hipLaunchKernelGGL(h2_unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, x_bs, y, y_bs, C, HW, total);
+    return (int)hipGetLastError();
+}

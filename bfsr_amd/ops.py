@@ -390,6 +390,76 @@ class HipOps(object):
         _lib.check(self._launch(key, lambda: self.lib.bfsr_conv3x3_x3s(C.byref(a), self._stream())), "conv3x3_x3s")
         return out
 
+    # ---- h2 tensors (activations stored in fp16: hi + lo planes) + the LDS-DMA fp16 conv over them (conv_h2s.hip) ---------------
+    def h2_empty(self, B, Cc, H, W):
+        """[B, C/8, 2, H, W, 8] fp16: x ~ hi + lo; channel slices `t[:, a//8:b//8]` are views."""
+        if Cc % 8:
+            raise ValueError("h2 tensors need a multiple of 8 channels")
+        return torch.empty(B, Cc // 8, 2, H, W, 8, dtype=torch.float16, device=self.device)
+
+    @staticmethod
+    def _h2view(t, name="h2"):
+        """(ptr, batch stride in fp16 elements, C, H, W) of an h2 view."""
+        if t.dtype != torch.float16 or t.dim() != 6 or t.shape[2] != 2 or t.shape[5] != 8:
+            raise ValueError("%s: need a [B,C/8,2,H,W,8] float16 tensor" % name)
+        B, C8, _, H, W, _ = t.shape
+        st = t.stride()
+        if not (st[5] == 1 and st[4] == 8 and st[3] == 8 * W and st[2] == 8 * W * H and (C8 == 1 or st[1] == 16 * W * H)):
+            raise ValueError("%s: not an h2 view (shape %s stride %s)" % (name, tuple(t.shape), st))
+        return t.data_ptr(), (st[0] if B > 1 else C8 * 16 * H * W), C8 * 8, H, W
+
+    def h2_pack(self, x, out):
+        xp, xbs, Cc, H, W = _view(x, "h2_pack.x")
+        yp, ybs, c2, h2, w2 = self._h2view(out, "h2_pack.out")
+        assert (Cc, H, W) == (c2, h2, w2) and x.shape[0] == out.shape[0]
+        _lib.check(self._launch(("h2_pack",) + tuple(x.shape), lambda: self.lib.bfsr_h2_pack(xp, xbs, yp, ybs, x.shape[0], Cc, H, W, self._stream())), "h2_pack")
+        return out
+
+    def h2_unpack(self, x, out):
+        xp, xbs, Cc, H, W = self._h2view(x, "h2_unpack.x")
+        yp, ybs, c2, h2, w2 = _view(out, "h2_unpack.out")
+        assert (Cc, H, W) == (c2, h2, w2) and x.shape[0] == out.shape[0]
+        _lib.check(self._launch(("h2_unpack",) + tuple(out.shape), lambda: self.lib.bfsr_h2_unpack(xp, xbs, yp, ybs, x.shape[0], Cc, H, W, self._stream())), "h2_unpack")
+        return out
+
+    def pack_conv_h2s(self, w):
+        """OIHW 3x3 fp32 weights -> fp16 packing of conv_h2s (32-cout workgroup tiles, 16-channel chunks)."""
+        w = w.detach().to("cpu", torch.float32).contiguous()
+        Cout, Cin, KS, _ = w.shape
+        if KS != 3 or Cin % 16:
+            raise ValueError("conv_h2s: 3x3 weights with Cin % 16 == 0 only")
+        packed = torch.empty(self.lib.bfsr_conv_packed_size_h2s(Cout, Cin), dtype=torch.int16)
+        _lib.check(self.lib.bfsr_pack_conv_weight_h2s(w.data_ptr(), Cout, Cin, packed.data_ptr()), "pack_h2s")
+        return PackedConv(packed.to(self.device), Cout, Cin, 3, 1, fixed=True, w=None, ops=self)
+
+    def conv_h2s(self, x, pw, out, epi=None, act=ACT_NONE, slope=0.2, res1=None, alpha1=1.0, res2=None, alpha2=1.0, hi_only=False, tune=0):
+        """3x3 conv over an h2 tensor `x` (weights: pack_conv_h2s); `out` is an h2 view (hi_only: the lo plane is not written --
+        for outputs that only feed convs) or an fp32 NCHW view; residuals are h2 views.  Same epilogue contract as conv()."""
+        a = _lib.BfsrConvX3Args()
+        a.x, a.x_bs, Cin, H, W = self._h2view(x, "conv_h2s.x")
+        if out.dtype == torch.float16:
+            a.y, a.y_bs, Cout, H2, W2 = self._h2view(out, "conv_h2s.out")
+            a.y_fmt = 2 if hi_only else 1
+        else:
+            a.y, a.y_bs, Cout, H2, W2 = _view(out, "conv_h2s.out")
+            a.y_fmt = 0
+        if (Cin, Cout, H, W) != (pw.Cin, pw.Cout, H2, W2) or pw.KS != 3 or x.shape[0] != out.shape[0]:
+            raise ValueError("conv_h2s: shape mismatch x%s out%s weight(Cout=%d,Cin=%d)" % (tuple(x.shape), tuple(out.shape), pw.Cout, pw.Cin))
+        a.Cin, a.Cout = Cin, Cout
+        a.w = pw.data.data_ptr()
+        a.B, a.H, a.W = out.shape[0], H, W
+        a.epi, a.act, a.slope, a.tune = _ptr(epi), act, slope, tune
+        for name, t, al in (("res1", res1, alpha1), ("res2", res2, alpha2)):
+            if t is not None:
+                pp, bs, c, hh, ww = self._h2view(t, "conv_h2s." + name)
+                assert (c, hh, ww) == (Cout, H, W)
+                setattr(a, name, pp)
+                setattr(a, name + "_bs", bs)
+                setattr(a, "alpha" + name[-1], al)
+        key = ("conv_h2s", Cin, Cout, out.shape[0], H, W, a.y_fmt)
+        _lib.check(self._launch(key, lambda: self.lib.bfsr_conv3x3_h2s(C.byref(a), self._stream())), "conv3x3_h2s")
+        return out
+
     def vec(self, t):
         """A per-channel parameter vector on the device."""
         return t.detach().reshape(-1).to(device=self.device, dtype=torch.float32).contiguous()

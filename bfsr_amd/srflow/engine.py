@@ -88,10 +88,12 @@ class RRDBEncoder(object):
         # whereas SRFlow's adds the trunk output (`last_lr_fea = fea + trunk` after the loop rebinds `fea`,
         # RRDBNet_arch.py:92-103)
         self.ops, self.nb, self.nf, self.gc, self.skip_from_first = ops, nb, nf, gc, skip_from_first
-        self.x3s = (not f16 and getattr(ops, "conv_mode", "f32") == "x3" and hasattr(ops, "conv_x3s") and nf % 16 == 0 and gc % 16 == 0
-                    and os.environ.get("BFSR_RRDB", "x3") != "fp32")
+        packed_ok = nf % 16 == 0 and gc % 16 == 0 and os.environ.get("BFSR_RRDB", "x3") != "fp32"
+        self.x3s = not f16 and getattr(ops, "conv_mode", "f32") == "x3" and hasattr(ops, "conv_x3s") and packed_ok
+        self.h2s = f16 and hasattr(ops, "conv_h2s") and packed_ok
         g = lambda n: sd[prefix + n]
-        mk = (lambda w, b: _ConvX3S(ops, w, b)) if self.x3s else (lambda w, b: _ConvP(ops, w, b, f16=f16))
+        mk = ((lambda w, b: _ConvX3S(ops, w, b)) if self.x3s else (lambda w, b: _ConvH2S(ops, w, b)) if self.h2s
+              else (lambda w, b: _ConvP(ops, w, b, f16=f16)))
         self.conv_first = _ConvP(ops, g("conv_first.weight"), g("conv_first.bias"), f16=f16)
         self.blocks = []
         for b in range(nb):
@@ -106,8 +108,8 @@ class RRDBEncoder(object):
     def forward(self, x, out, on_block=None, taps=None):
         """x [B,3,h,w] -> out (a [B,nf,h,w] view) = fea + trunk_conv(fea).  `on_block(idx, fea_view)` is called after RRDB idx
         (only for idx in `taps` when given) with an fp32 view that is only valid during the call."""
-        if self.x3s:
-            return self._forward_x3(x, out, on_block, taps)
+        if self.x3s or self.h2s:
+            return self._forward_packed(x, out, on_block, taps)
         ops, nf, gc = self.ops, self.nf, self.gc
         B, _, h, w = x.shape
         ring = [self.ws.get("dense%d" % i, B, nf + 4 * gc, h, w) for i in range(4)]
@@ -135,28 +137,32 @@ class RRDBEncoder(object):
         self.trunk_conv.run(ops, fea, out, res1=first if first is not None else fea, alpha1=1.0)   # skip + trunk
         return out
 
-    def _forward_x3(self, x, out, on_block, taps):
+    def _forward_packed(self, x, out, on_block, taps):
+        """The dense blocks on packed 16-bit tensors: x3 (exact 3-term bf16 split, conv_x3s) or, for precision='fp16', h2 (fp16
+        hi + lo planes, conv_h2s: convs read hi, the residual chain reads hi + lo; x1..x4 are written hi-only)."""
         ops, nf, gc = self.ops, self.nf, self.gc
         B, _, h, w = x.shape
-        o = lambda c: c // 8                                           # channel -> octet index of an x3 tensor
+        o = lambda c: c // 8                                           # channel -> octet index of a packed tensor
+        empty, pack, unpack = (ops.x3_empty, ops.x3_pack, ops.x3_unpack) if self.x3s else (ops.h2_empty, ops.h2_pack, ops.h2_unpack)
+        inner = {"hi_only": True} if self.h2s else {}
         key = (B, h, w)
-        if getattr(self, "_x3key", None) != key:                       # x3 block buffers (not fp32: kept outside _Workspace)
-            self._x3key = key
-            self._ring = [ops.x3_empty(B, nf + 4 * gc, h, w) for _ in range(4)]
-            self._first = ops.x3_empty(B, nf, h, w) if self.skip_from_first else None
+        if getattr(self, "_pkkey", None) != key:                       # packed block buffers (not fp32: kept outside _Workspace)
+            self._pkkey = key
+            self._ring = [empty(B, nf + 4 * gc, h, w) for _ in range(4)]
+            self._first = empty(B, nf, h, w) if self.skip_from_first else None
         ring = self._ring
-        tmp = self.ws.get("x3_io", B, nf, h, w)                        # fp32 staging at the two ends of the x3 region
+        tmp = self.ws.get("x3_io", B, nf, h, w)                        # fp32 staging at the two ends of the packed region
         cur = 0
         self.conv_first.run(ops, x, tmp)
-        ops.x3_pack(tmp, ring[cur][:, :o(nf)])
+        pack(tmp, ring[cur][:, :o(nf)])
         if self.skip_from_first:
-            ops.x3_pack(tmp, self._first)
+            pack(tmp, self._first)
         for idx, rdbs in enumerate(self.blocks):
             x_rrdb = ring[cur][:, :o(nf)]
             for r, convs in enumerate(rdbs):
                 D = ring[cur]
                 for i in range(4):
-                    convs[i].run(ops, D[:, :o(nf + i * gc)], D[:, o(nf + i * gc): o(nf + (i + 1) * gc)], act=ACT_LRELU, slope=0.2)
+                    convs[i].run(ops, D[:, :o(nf + i * gc)], D[:, o(nf + i * gc): o(nf + (i + 1) * gc)], act=ACT_LRELU, slope=0.2, **inner)
                 nxt = (cur + 1) % 4
                 if r < 2:
                     convs[4].run(ops, D, ring[nxt][:, :o(nf)], res1=D[:, :o(nf)], alpha1=0.2)
@@ -164,7 +170,7 @@ class RRDBEncoder(object):
                     convs[4].run(ops, D, ring[nxt][:, :o(nf)], res1=D[:, :o(nf)], alpha1=0.2, res2=x_rrdb, alpha2=0.2)
                 cur = nxt
             if on_block is not None and (taps is None or idx in taps):
-                on_block(idx, ops.x3_unpack(ring[cur][:, :o(nf)], tmp))
+                on_block(idx, unpack(ring[cur][:, :o(nf)], tmp))
         fea = ring[cur][:, :o(nf)]
         self.trunk_conv.run(ops, fea, out, res1=self._first if self.skip_from_first else fea, alpha1=1.0)
         return out
@@ -179,6 +185,17 @@ class _ConvX3S(object):
 
     def run(self, ops, x, out, **kw):
         return ops.conv_x3s(x, self.pw, out, epi=self.epi, **kw)
+
+
+class _ConvH2S(object):
+    """A 3x3 conv over h2 tensors (ops.conv_h2s): fp16 weights packed for 32-cout workgroup tiles + bias epilogue."""
+
+    def __init__(self, ops, w, bias=None):
+        self.pw = ops.pack_conv_h2s(w)
+        self.epi = ops.pack_epilogue(self.pw.Cout, bias)
+
+    def run(self, ops, x, out, **kw):
+        return ops.conv_h2s(x, self.pw, out, epi=self.epi, **kw)
 
 
 class _CouplingStep(object):

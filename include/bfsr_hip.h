@@ -151,6 +151,23 @@ int bfsr_conv3x3_x3s(const BfsrConvX3Args* a, void* stream);
 int bfsr_x3_pack(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int C, int H, int W, void* stream);
 int bfsr_x3_unpack(const unsigned short* x, long long x_bs, float* y, long long y_bs, int B, int C, int H, int W, void* stream);
 
+/* ---- h2 tensors: activations stored in fp16 for the reduced-precision path (LINF precision='fp16', BASELINE config 5) ----------
+ * Layout [B][C/8][2 planes hi,lo][H][W][8] fp16 with hi = fp16(x), lo = fp16(x - hi) (x ~ hi + lo to 22 significant bits).  A
+ * view = (pointer, batch stride in fp16 elements, C); channel slices at multiples of 8 are views.  bfsr_h2_pack / bfsr_h2_unpack
+ * convert from / to an fp32 NCHW view.
+ *
+ * bfsr_conv3x3_h2s: the 3x3 'same' conv of bfsr_conv2d_f16 (operands rounded to fp16, fp32 accumulation -- the hi plane IS that
+ * rounding, so both kernels contract the same numbers) for inputs that are h2 tensors: LDS-DMA staging by dedicated loader waves
+ * through a 4-stage LDS ring, persistent workgroups.  Same argument struct and epilogue as bfsr_conv3x3_x3s; residuals are h2
+ * views read as hi + lo;  y_fmt 0: fp32 NCHW view, 1: h2 view (both planes), 2: h2 view, hi plane only (outputs that only feed
+ * convs).  Weights from bfsr_pack_conv_weight_h2s (OIHW 3x3 fp32 -> fp16 [cout group of 32][16-channel chunk][tap][k half][32][8]).
+ * Dense blocks of the RRDB encoder: LINF-LP/models/rrdb.py:38-76. */
+int bfsr_conv3x3_h2s(const BfsrConvX3Args* a, void* stream);
+long long bfsr_conv_packed_size_h2s(int Cout, int Cin);
+int bfsr_pack_conv_weight_h2s(const float* w_oihw, int Cout, int Cin, unsigned short* packed);
+int bfsr_h2_pack(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int C, int H, int W, void* stream);
+int bfsr_h2_unpack(const unsigned short* x, long long x_bs, float* y, long long y_bs, int B, int C, int H, int W, void* stream);
+
 /* ---- fused flow-step pointwise chain -----------------------------------------------------------
  * One read of z / h_aff / h_ft, one write of z (the HBM-roofline "coupling inverse" kernel of
  * BASELINE.json).  replaces, per FlowStep (SRFlow-LP/code/models/modules/):

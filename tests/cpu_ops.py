@@ -95,6 +95,42 @@ class CpuOps(object):
             self.x3_pack(tmp, out)
         return out
 
+    # ---- h2 tensors: [B, C/8, 2, H, W, 8] fp16, hi = fp16(x), lo = fp16(x - hi) (HipOps.h2_empty); convs read hi only
+    def h2_empty(self, B, Cc, H, W):
+        assert Cc % 8 == 0
+        return torch.full((B, Cc // 8, 2, H, W, 8), float("nan"), dtype=torch.float16)
+
+    @staticmethod
+    def _h2_planes(t):
+        B, C8, _, H, W, _ = t.shape
+        f = lambda p: p.float().permute(0, 1, 4, 2, 3).reshape(B, C8 * 8, H, W)
+        return f(t[:, :, 0]), f(t[:, :, 1])
+
+    def h2_pack(self, x, out, hi_only=False):
+        B, Cc, H, W = x.shape
+        v = x.reshape(B, Cc // 8, 8, H, W).permute(0, 1, 3, 4, 2)
+        h = v.half()
+        out[:, :, 0] = h
+        if not hi_only:                          # hi-only outputs keep their NaN lo plane: a residual read of one would show
+            out[:, :, 1] = (v - h.float()).half()
+        return out
+
+    def h2_unpack(self, x, out):
+        hi, lo = self._h2_planes(x)
+        out.copy_(hi + lo)
+        return out
+
+    def pack_conv_h2s(self, w):
+        return PackedConv(w.detach().to(torch.float32).half().float().contiguous().clone(), 1)
+
+    def conv_h2s(self, x, pw, out, epi=None, act=0, slope=0.2, res1=None, alpha1=1.0, res2=None, alpha2=1.0, hi_only=False, tune=0):
+        full = lambda t: None if t is None else sum(self._h2_planes(t))
+        tmp = torch.empty(out.shape[0], pw.Cout, x.shape[3], x.shape[4]) if out.dtype == torch.float16 else out
+        self.conv(self._h2_planes(x)[0], pw, tmp, epi=epi, act=act, slope=slope, res1=full(res1), alpha1=alpha1, res2=full(res2), alpha2=alpha2)
+        if out.dtype == torch.float16:
+            self.h2_pack(tmp, out, hi_only=hi_only)
+        return out
+
     def pack_conv1x1(self, w, x3=True):
         w = w.detach().to(torch.float32).reshape(w.shape[0], w.shape[1], 1, 1)
         return PackedConv((w if x3 else w.half().float()).contiguous().clone(), 8)

@@ -111,6 +111,69 @@ def test_conv_x3s_dense_block_views_and_residuals(hip):
     close(hip.x3_unpack(nxt[:, :8], hip.empty(B, 64, H, W)), out_ref, 2e-5, "x3 conv5 residuals")
 
 
+H2S_CASES = [
+    # (B, Cin, Cout, H, W): one tile; ragged edges + two cout groups + many chunks (the loaders run 3 stages ahead across items);
+    # many items per persistent workgroup; Cout not a multiple of 32; more tiles than the ring is deep with ONE chunk each
+    (1, 16, 32, 16, 32), (2, 64, 32, 19, 45), (1, 192, 64, 33, 65), (3, 96, 32, 128, 128), (2, 48, 24, 9, 33), (1, 32, 40, 70, 70),
+    (5, 16, 32, 40, 40),
+]
+
+
+@pytest.mark.parametrize("case", H2S_CASES)
+@pytest.mark.parametrize("mode", ["f32_out", "h2_out", "hi_only"])
+def test_conv_h2s_and_h2_tensors(hip, case, mode):
+    """conv_h2s (LDS-DMA staged fp16 3x3 conv over h2 tensors, conv_h2s.hip) vs the fp16-operand conv semantics (operands rounded
+    to fp16, fp32 accumulation) and vs conv_f16 on the fp32 tensor (the hi plane is that kernel's staging-time rounding)."""
+    B, Cin, Cout, H, W = case
+    x, w, b = rnd(31, B, Cin, H, W), rnd(32, Cout, Cin, 3, 3, scale=1.0 / np.sqrt(Cin * 9)), rnd(33, Cout, scale=0.3)
+    xd = hip.to_device(x)
+    xh = hip.h2_pack(xd, hip.h2_empty(B, Cin, H, W))
+    planes = xh.float()
+    want_hi = xd.view(B, Cin // 8, 8, H, W).permute(0, 1, 3, 4, 2).half()
+    assert torch.equal(xh[:, :, 0], want_hi), "hi plane != fp16(x)"
+    close(hip.h2_unpack(xh, hip.empty(B, Cin, H, W)), x, 1e-6, "h2 round trip (22 bits)")
+    ref = CPU.conv(x.half().float(), CPU.pack_conv(w.half().float(), 1), torch.empty(B, Cout, H, W), bias=b, act=2, slope=0.2)
+    pw, epi = hip.pack_conv_h2s(w), hip.pack_epilogue(Cout, bias=b)
+    if mode == "f32_out":
+        out = hip.conv_h2s(xh, pw, hip.empty(B, Cout, H, W), epi=epi, act=2, slope=0.2)
+        close(out, ref, 2e-5, "conv_h2s%s" % (case,))
+        same = hip.conv_f16(xd, hip.pack_conv_f16(w, 1), hip.empty(B, Cout, H, W), epi=epi, act=2, slope=0.2)
+        close(out, same.cpu(), 2e-6, "conv_h2s vs conv_f16 (same operands, different summation order)")
+    elif Cout % 8 == 0:
+        yh = hip.h2_empty(B, Cout, H, W)
+        yh.fill_(float("nan"))
+        hip.conv_h2s(xh, pw, yh, epi=epi, act=2, slope=0.2, hi_only=mode == "hi_only")
+        if mode == "hi_only":
+            assert torch.isnan(yh[:, :, 1]).all(), "hi_only wrote the lo plane"
+            o = yh[:, :, 0].float().permute(0, 1, 4, 2, 3).reshape(B, Cout, H, W)
+            close(o, ref.half().float(), 2e-3, "conv_h2s hi plane")           # 1 fp16 ulp where the fp32 sums straddle a rounding boundary
+        else:
+            close(hip.h2_unpack(yh, hip.empty(B, Cout, H, W)), ref, 2e-5, "conv_h2s h2 out")
+
+
+def test_conv_h2s_dense_block_views_and_residuals(hip):
+    """The RDB pattern (LINF-LP/models/rrdb.py:52-58) on h2 tensors: octet-sliced views of one block buffer, conv5 with
+    `x5*0.2 + x` and the RRDB-level `*0.2 + x_rrdb`; the residual operands are read as hi + lo (22 bits), not hi."""
+    B, H, W = 2, 21, 37
+    D = rnd(41, B, 192, H, W)
+    xr = rnd(42, B, 64, H, W)
+    Dh = hip.h2_pack(hip.to_device(D), hip.h2_empty(B, 192, H, W))
+    xrh = hip.h2_pack(hip.to_device(xr), hip.h2_empty(B, 64, H, W))
+    Dq = D.half().float()                                              # what the convs see
+    w2, b2 = rnd(43, 32, 96, 3, 3, scale=0.04), rnd(44, 32, scale=0.1)
+    x3ref = CPU.conv(Dq[:, :96].clone(), CPU.pack_conv(w2.half().float(), 1), torch.empty(B, 32, H, W), bias=b2, act=2, slope=0.2)
+    hip.conv_h2s(Dh[:, :12], hip.pack_conv_h2s(w2), Dh[:, 12:16], epi=hip.pack_epilogue(32, bias=b2), act=2, slope=0.2, hi_only=True)
+    got = Dh[:, 12:16, 0].float().permute(0, 1, 4, 2, 3).reshape(B, 32, H, W)
+    close(got, x3ref.half().float(), 2e-3, "h2 slice view, hi plane")
+    Dq[:, 96:128] = got.cpu()
+    w5, b5 = rnd(45, 64, 192, 3, 3, scale=0.03), rnd(46, 64, scale=0.1)
+    out_ref = CPU.conv(Dq.clone(), CPU.pack_conv(w5.half().float(), 1), torch.empty(B, 64, H, W), bias=b5, res1=D[:, :64].clone(), alpha1=0.2,
+                       res2=xr, alpha2=0.2)
+    nxt = hip.h2_empty(B, 192, H, W)
+    hip.conv_h2s(Dh, hip.pack_conv_h2s(w5), nxt[:, :8], epi=hip.pack_epilogue(64, bias=b5), res1=Dh[:, :8], alpha1=0.2, res2=xrh, alpha2=0.2)
+    close(hip.h2_unpack(nxt[:, :8], hip.empty(B, 64, H, W)), out_ref, 2e-5, "h2 conv5 residuals")
+
+
 def test_conv_epilogue_all_stages(hip):
     B, Cin, Cout, H, W = 2, 40, 48, 21, 35
     x, w = rnd(5, B, Cin, H, W), rnd(6, Cout, Cin, 3, 3, scale=0.08)

@@ -116,6 +116,26 @@ def test_engine_schedule_x3_mode_on_cpu_double(golden_dir, c):
     assert (out["pred"] - T(g["pred"])).abs().max() <= 1e-4
 
 
+def test_engine_schedule_fp16_h2_mode_on_cpu_double(golden_dir):
+    """Host logic of precision='fp16' (BASELINE config 5): the RRDB dense blocks on h2 tensors (fp16 hi + lo planes, conv_h2s; the
+    double leaves NaN in every plane a hi-only conv does not write, so a residual read of one would poison the output) against the
+    reference golden at the stated fp16 tolerance."""
+    ops = CpuOps()
+    g = np.load(os.path.join(golden_dir, "linf_e2e_rrdb_s6.npz"))
+    sd, psd = weights("rrdb", 2024)
+    m = make(mspec("rrdb"), args={"ops": ops, "precision": "fp16"}).eval()
+    m.load_state_dict(sd)
+    prior = make({"name": "unet", "args": {"in_chans": 27, "depth": 3, "dim": 64, "bilinear": True}}, args={"ops": ops}).eval()
+    prior.load_state_dict(psd)
+    s, lr = int(g["scale"]), T(g["lr"])
+    H, W = s * lr.shape[2], s * lr.shape[3]
+    batch = dict(inp=lr, coord=T(g["coord"]), cell=T(g["cell"]), gt_lr_up=T(g["gt_lr_up"]))
+    out = lp_infer(m, prior, batch, (H, W), return_all=True)
+    assert m.engine().encoder.h2s
+    assert not torch.isnan(out["pred"]).any()
+    assert (out["pred"] - T(g["pred"])).abs().max() <= 1e-3           # = FP16_TOL_PRED of tests/test_linf_gpu.py
+
+
 def test_cfg1_eval_psnr_scalar(golden_dir):
     """BASELINE config 1: LINF-LP edsr-baseline, 1 x 48x48 LR crop, 4x -- the reference's own eval_psnr value."""
     ops = CpuOps()

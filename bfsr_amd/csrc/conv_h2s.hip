@@ -21,6 +21,7 @@
 // the pieces of the later stages.  One barrier per chunk; the eight compute waves issue nothing but ds_read_b128 + MFMA
 // (21 reads per 18 MFMAs: 58 % of the LDS read rate at full matrix rate).  Persistent workgroups, XCD-aware order.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "../../include/bfsr_hip.h"
 #include "launch_util.h"
 
@@ -30,14 +31,22 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 namespace {
 
-constexpr int NW = 8, NL = 4, NS = 4;
+constexpr int NW = 8, NLW = 4;                  // compute waves, loader waves
 constexpr int TH = 16, PW = 34, NPOS = (TH + 2) * PW, NG = 10, NPOSP = NG * 64;
 constexpr int SUB = NPOSP * 16;                 // bytes of one k-half sub-image (8 channels of every tile position)
 constexpr int IN_BYTES = 2 * SUB;               // 20 480
-constexpr int W_BYTES = 9 * 1024;               // 9 216: one 1-KiB piece per tap
-constexpr int STAGE = IN_BYTES + W_BYTES;
-constexpr int LDS_TOTAL = NS * STAGE;           // 118 784
 constexpr unsigned OOB = 0x80000000u;
+
+// MT = 32-cout M tiles per workgroup (1: Cout <= 32, 2: wider -- the input fragments then feed twice the MFMAs and the input tile
+// is staged once for 64 output channels)
+template <int MT> struct Cfg {
+    static constexpr int W_BYTES = 9 * 2 * MT * 32 * 16;                 // weights of one chunk: [9 taps][2 k halves][MT*32][8] fp16
+    static constexpr int STAGE = IN_BYTES + W_BYTES;                     // 29 696 / 38 912
+    static constexpr int NS = MT == 1 ? 5 : 4;                           // LDS ring: 148 480 / 155 648 B
+    static constexpr int LDS_TOTAL = NS * STAGE;
+    static constexpr int NPIECE = 20 + W_BYTES / 1024;                   // 1-KiB LDS-DMA pieces per stage: 29 / 38
+    static constexpr int NJ = (NPIECE + NLW - 1) / NLW;
+};
 
 struct Item { int cg, b, x0, y0; };
 
@@ -47,8 +56,24 @@ __device__ __forceinline__ void split2(float v, _Float16& h, _Float16& l)
     l = (_Float16)(v - (float)h);
 }
 
-__global__ __launch_bounds__((NW + NL) * 64, 1) void conv3x3_h2s_kernel(BfsrConvX3Args p, int tiles_x, int tiles_y, int groups, int nitems)
+// `s_waitcnt vmcnt(n)` for a wave-uniform run-time n (the instruction takes an immediate); n = stages in flight x pieces per stage
+__device__ __forceinline__ void wait_vmcnt(int n)
 {
+    switch (n) {
+#define W_(N_) case N_: asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory"); break;
+        W_(7) W_(8) W_(9) W_(10) W_(14) W_(16)
+#undef W_
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// abl = ablation switches, honoured only in -DBFSR_H2S_ABL builds (tools/exp/h2s_bench.py): 1 = no input DMA after the first
+// stages, 2 = no weight DMA after them, 4 = no ds_read/MFMA
+template <int MT>
+__global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrConvX3Args p, int tiles_x, int tiles_y, int groups, int nitems, int abl)
+{
+    typedef Cfg<MT> CF;
+    constexpr int NS = CF::NS, STAGE = CF::STAGE, W_BYTES = CF::W_BYTES, NPIECE = CF::NPIECE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -59,6 +84,8 @@ __global__ __launch_bounds__((NW + NL) * 64, 1) void conv3x3_h2s_kernel(BfsrConv
     const int H = p.H, W = p.W;
     const unsigned HW16 = (unsigned)(H * W) * 16u;                       // bytes of one (octet, plane) image
     const int nchunk = p.Cin >> 4;
+    const int n_mine = (nitems - slot + G - 1) / G;
+    const int T = n_mine * nchunk;                                       // chunks this workgroup consumes = barriers every wave passes
 
     auto decode = [&](int it) {
         Item r;
@@ -69,14 +96,16 @@ __global__ __launch_bounds__((NW + NL) * 64, 1) void conv3x3_h2s_kernel(BfsrConv
     };
 
     if (wave >= NW) {
-        // ---- loader waves.  29 pieces of 1 KiB per stage: loader ld owns input k half (ld & 1), position groups (ld>>1) + 2j
-        // (j = 0..4), and weight taps ld, ld+4, ld+8 (< 9): 8 pieces for loader 0, 7 for the others -- the same count for every
-        // chunk, which is what lets `vmcnt(N)` stand for "everything but the youngest N/np stages has landed".
-        const int ld = wave - NW, oc = ld & 1, g0 = ld >> 1;
+        // ---- loader waves.  Piece i of a stage (i < 20: input position group i>>1, k half i&1; else weight piece i-20) belongs to
+        // loader i % NLW: the same count np for every chunk, which is what lets `vmcnt(N)` stand for "everything but the youngest
+        // N/np stages has landed".  Barrier c = "chunk c is in LDS, and every compute wave is past its reads of chunk c-2" (they
+        // arrive one pipeline step early, see below), so the stage of chunk c-2 is refilled with chunk c+NS-2.
+        const int ld = wave - NW;
+        const int np = (NPIECE - ld + NLW - 1) / NLW;
         const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w), 0,
                                                                               (unsigned)((long long)groups * nchunk * W_BYTES), 0x00020000);
         __amdgpu_buffer_rsrc_t rs_in;
-        unsigned vg[5];
+        unsigned vg[5];                                                  // 20 input pieces / 4 loaders (a dependent bound here makes hipcc 7.2 drop the HOST stub silently)
         int cg_ = 0;
         auto lsetup = [&](const Item& it) {
             const unsigned short* xb = p.x + (long long)it.b * p.x_bs;
@@ -84,75 +113,122 @@ __global__ __launch_bounds__((NW + NL) * 64, 1) void conv3x3_h2s_kernel(BfsrConv
             cg_ = it.cg;
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
-                const int pos = (g0 + 2 * j) * 64 + lane;
+                const int i = ld + j * NLW;
+                const int pos = (i >> 1) * 64 + lane;
                 const int r = pos / PW, c = pos - r * PW;
                 const int gy = it.y0 + r - 1, gx = it.x0 + c - 1;
                 const bool ok = pos < NPOS && gy >= 0 && gy < H && gx >= 0 && gx < W;
                 vg[j] = ok ? (unsigned)(gy * W + gx) * 16u : OOB;        // out of range -> the DMA writes zeros (= the padding)
             }
         };
-        auto lstage = [&](int k, int buf) {
+        auto lstage = [&](int k, int buf, int skip) {
             unsigned char* base = smem + buf * STAGE;
-            const unsigned soff = (unsigned)(2 * k + oc) * 2u * HW16;    // hi plane of channel octet 2k + oc
-#pragma unroll
-            for (int j = 0; j < 5; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(base + oc * SUB + (g0 + 2 * j) * 1024), 16, vg[j], soff, 0, 0);
             const unsigned wsoff = (unsigned)(cg_ * nchunk + k) * (unsigned)W_BYTES;
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
-                if (ld + 4 * t < 9)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(base + IN_BYTES + (ld + 4 * t) * 1024), 16,
-                                                             (unsigned)lane * 16u + (unsigned)(ld + 4 * t) * 1024u, wsoff, 0, 0);
+            for (int j = 0; j < CF::NJ; ++j) {
+                const int i = ld + j * NLW;
+                if (j < 5) {
+                    if (skip & 1) continue;
+                    const unsigned soff = (unsigned)(2 * k + (i & 1)) * 2u * HW16;                  // hi plane of channel octet 2k + (i&1)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(base + (i & 1) * SUB + (i >> 1) * 1024), 16, vg[j], soff, 0, 0);
+                } else if (i < NPIECE) {
+                    if (skip & 2) continue;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(base + IN_BYTES + (i - 20) * 1024), 16,
+                                                             (unsigned)lane * 16u + (unsigned)(i - 20) * 1024u, wsoff, 0, 0);
+                }
+            }
         };
-        const int n_mine = (nitems - slot + G - 1) / G;
-        const int T = n_mine * nchunk;                                   // chunks this workgroup consumes
-        int issued = 0, iss_it = slot, iss_k = 0;
+        int issued = 0, iss_it = slot, iss_k = 0, iss_buf = 0;
         auto issue = [&]() {
             if (iss_k == 0) lsetup(decode(iss_it));
-            lstage(iss_k, issued & (NS - 1));
+#ifdef BFSR_H2S_ABL
+            lstage(iss_k, iss_buf, issued >= NS - 2 ? abl & 3 : 0);
+#else
+            lstage(iss_k, iss_buf, 0);
+#endif
             ++issued;
+            iss_buf = iss_buf + 1 == NS ? 0 : iss_buf + 1;
             if (++iss_k == nchunk) { iss_k = 0; iss_it += G; }
         };
-        for (int i = 0; i < NS - 1 && issued < T; ++i) issue();
+        for (int i = 0; i < NS - 2 && issued < T; ++i) issue();
         for (int c = 0; c < T; ++c) {
-            const int ahead = issued - c - 1;                            // stages issued after chunk c's
-            if (ahead >= 2) { if (ld == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
-            else if (ahead == 1) { if (ld == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                                // chunk c is in LDS; stage (c-1) % NS is free again
+#ifdef BFSR_H2S_ABL
+            if (abl & 3) wait_vmcnt(0); else
+#endif
+            wait_vmcnt((issued - c - 1) * np);                           // all but the stages issued after chunk c's
+            __builtin_amdgcn_s_barrier();
             if (issued < T) issue();
         }
         return;
     }
 
-    // ---- compute waves -------------------------------------------------------------------------------------------------
-    int c = 0;
+    // ---- compute waves: a software pipeline of (chunk, dx) steps.  A step = the 4 input rows of tap column dx (B fragments) and the
+    // 3*MT weight fragments of that column -> 6*MT MFMAs; the fragments of step s+1 are read from LDS while the MFMAs of step s run,
+    // across chunk and tile boundaries: barrier c+1 is passed BEFORE the last step of chunk c so that the first fragments of chunk
+    // c+1 are in flight under it.  Register double buffer: chunk parity P (compile-time, two instantiations of the body).
+    half8 bq[2][4], aq[2][3 * MT];
+    auto load_step = [&](auto buf_, int st, int dx) {
+        constexpr int BUF = decltype(buf_)::value;
+        const unsigned char* sIn = smem + st * STAGE;
+        const unsigned char* inB = sIn + (lhi * NPOSP + 2 * wave * PW + l31 + dx) * 16;
+        const unsigned char* wA = sIn + IN_BYTES + (lhi * MT * 32 + l31) * 16 + dx * 3 * (MT * 1024);   // tap = dx*3 + dy
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bq[BUF][r] = *reinterpret_cast<const half8*>(inB + r * PW * 16);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) aq[BUF][dy * MT + m] = *reinterpret_cast<const half8*>(wA + dy * (MT * 1024) + m * 512);
+    };
+    f32x16 acc[MT][2];
+    auto mfma_step = [&](auto buf_) {
+        constexpr int BUF = decltype(buf_)::value;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][dy * MT + m], bq[BUF][dy], acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][dy * MT + m], bq[BUF][dy + 1], acc[m][1], 0, 0, 0);
+            }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    int c = 0, st = 0;                                                   // chunk counter, its LDS stage
+    auto chunk_body = [&](auto p_, auto q_) {                            // p_ = parity of this chunk's first step, q_ = the other buffer
+        const int nst = st + 1 == NS ? 0 : st + 1;
+        load_step(q_, st, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(p_);
+        __builtin_amdgcn_sched_barrier(0);
+        load_step(p_, st, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(q_);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < T) {
+            __builtin_amdgcn_s_barrier();
+            load_step(q_, nst, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(p_);
+        __builtin_amdgcn_sched_barrier(0);
+        st = nst; ++c;
+    };
     const float slope = p.act == BFSR_ACT_NONE ? 1.f : (p.act == BFSR_ACT_RELU ? 0.f : p.slope);
     const float4* __restrict__ epi = reinterpret_cast<const float4*>(p.epi);
     const long long HW = (long long)H * W;
+    __builtin_amdgcn_s_barrier();                                        // barrier 0
+    load_step(I0(), 0, 0);
     for (int it = slot; it < nitems; it += G) {
         const Item cur = decode(it);
-        f32x16 acc0, acc1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-        for (int k = 0; k < nchunk; ++k) {
-            __builtin_amdgcn_s_barrier();
-            const unsigned char* sIn = smem + (c & (NS - 1)) * STAGE;
-            ++c;
-            const unsigned char* inB = sIn + (lhi * NPOSP + 2 * wave * PW + l31) * 16;
-            const unsigned char* wA = sIn + IN_BYTES + (lhi * 32 + l31) * 16;
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                half8 b[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) b[r] = *reinterpret_cast<const half8*>(inB + (r * PW + dx) * 16);
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    const half8 a = *reinterpret_cast<const half8*>(wA + (dy * 3 + dx) * 1024);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[dy], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[dy + 1], acc1, 0, 0, 0);
-                }
-            }
+            for (int r = 0; r < 16; ++r) { acc[m][0][r] = 0.f; acc[m][1][r] = 0.f; }
+#ifdef BFSR_H2S_ABL
+        if (abl & 4) { for (int k = 0; k < nchunk; ++k) { if (c + 1 < T) __builtin_amdgcn_s_barrier(); ++c; } } else
+#endif
+        for (int k = 0; k < nchunk; k += 2) {                            // Cin % 32 == 0: the register-buffer parity is static
+            chunk_body(I0(), I1());
+            chunk_body(I1(), I0());
         }
 
         // ---- epilogue (the loaders are already staging the next item).  acc[r] = channel (r&3) + 8(r>>2) + 4*lhi of pixel
@@ -161,13 +237,15 @@ __global__ __launch_bounds__((NW + NL) * 64, 1) void conv3x3_h2s_kernel(BfsrConv
         // MFMA -> VALU-read and VALU-write -> permlane hazards the compiler does not see around asm.
         asm volatile("s_nop 11" ::: "memory");
 #pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
         for (int j = 0; j < 2; ++j) {
             float v[2][8];
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float lo = j ? acc1[8 * q + i] : acc0[8 * q + i], hi = j ? acc1[8 * q + 4 + i] : acc0[8 * q + 4 + i];
+                    float lo = acc[m][j][8 * q + i], hi = acc[m][j][8 * q + 4 + i];
                     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
                     v[q][i] = lo;
                     v[q][4 + i] = hi;
@@ -177,7 +255,7 @@ __global__ __launch_bounds__((NW + NL) * 64, 1) void conv3x3_h2s_kernel(BfsrConv
             const long long pix = (long long)gy * W + gx;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int oct = cur.cg * 4 + q * 2 + lhi;
+                const int oct = (cur.cg * MT + m) * 4 + q * 2 + lhi;
                 if (oct * 8 >= p.Cout) continue;
                 float o8[8];
 #pragma unroll
@@ -212,6 +290,7 @@ __global__ __launch_bounds__((NW + NL) * 64, 1) void conv3x3_h2s_kernel(BfsrConv
                     for (int i = 0; i < 8; ++i)
                         if (oct * 8 + i < p.Cout) yb[(long long)(oct * 8 + i) * HW] = o8[i];
                 }
+                __builtin_amdgcn_sched_barrier(0);                       // one octet at a time: keeps the epilogue's live ranges short
             }
         }
     }
@@ -261,24 +340,29 @@ inline unsigned short f32_to_f16_bits(float v)
 
 }  // namespace
 
+static inline int h2s_mtile(int Cout) { return Cout > 32 ? 2 : 1; }
+
 extern "C" long long bfsr_conv_packed_size_h2s(int Cout, int Cin)
 {
-    if (Cout <= 0 || Cin <= 0 || (Cin & 15)) return -1;
-    return (long long)((Cout + 31) / 32) * (Cin / 16) * (W_BYTES / 2);          // fp16 elements
+    if (Cout <= 0 || Cin <= 0 || (Cin & 31)) return -1;
+    const int MW = h2s_mtile(Cout) * 32;
+    return (long long)((Cout + MW - 1) / MW) * (Cin / 16) * 9 * 2 * MW * 8;      // fp16 elements
 }
 
 extern "C" int bfsr_pack_conv_weight_h2s(const float* w, int Cout, int Cin, unsigned short* packed)
 {
-    // w [Cout][Cin][3][3] fp32 -> fp16 [cout group of 32][16-channel chunk][tap = dy*3+dx][k half][32][8], zero padded
-    if (!w || !packed || Cout <= 0 || Cin <= 0 || (Cin & 15)) return -1;
-    const int nchunk = Cin / 16;
+    // w [Cout][Cin][3][3] fp32 -> fp16 [cout group of MW = 32 (Cout <= 32) or 64][16-channel chunk][tap = dx*3 + dy][k half][MW][8],
+    // zero padded (tap-column-major: the kernel consumes one tap column dx per pipeline step)
+    if (!w || !packed || Cout <= 0 || Cin <= 0 || (Cin & 31)) return -1;
+    const int nchunk = Cin / 16, MW = h2s_mtile(Cout) * 32;
     const long long n = bfsr_conv_packed_size_h2s(Cout, Cin);
     for (long long i = 0; i < n; ++i) packed[i] = 0;
     for (int co = 0; co < Cout; ++co)
         for (int ci = 0; ci < Cin; ++ci)
-            for (int t = 0; t < 9; ++t)
-                packed[(((((long long)(co / 32) * nchunk + ci / 16) * 9 + t) * 2 + (ci % 16) / 8) * 32 + co % 32) * 8 + ci % 8] =
-                    f32_to_f16_bits(w[((long long)co * Cin + ci) * 9 + t]);
+            for (int dy = 0; dy < 3; ++dy)
+                for (int dx = 0; dx < 3; ++dx)
+                    packed[(((((long long)(co / MW) * nchunk + ci / 16) * 9 + dx * 3 + dy) * 2 + (ci % 16) / 8) * MW + co % MW) * 8 + ci % 8] =
+                        f32_to_f16_bits(w[((long long)co * Cin + ci) * 9 + dy * 3 + dx]);
     return 0;
 }
 
@@ -286,7 +370,7 @@ extern "C" int bfsr_conv3x3_h2s(const BfsrConvX3Args* a, void* stream)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (!a || !a->x || !a->w || !a->y) return -1;
-    if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cin <= 0 || (a->Cin & 15) || a->Cout <= 0) return -1;
+    if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cin <= 0 || (a->Cin & 31) || a->Cout <= 0) return -1;
     if (a->y_fmt < 0 || a->y_fmt > 2) return -1;
     if ((a->y_fmt != 0 || a->res1 || a->res2) && (a->Cout & 7)) return -1;
     if ((long long)(a->Cin / 8) * 2 * a->H * a->W * 16 >= (1LL << 31)) return -1;      // 32-bit byte offsets inside one batch item
@@ -295,18 +379,30 @@ extern "C" int bfsr_conv3x3_h2s(const BfsrConvX3Args* a, void* stream)
     if (a->res1 && ((reinterpret_cast<unsigned long long>(a->res1) & 15) || (a->res1_bs & 7))) return -1;
     if (a->res2 && ((reinterpret_cast<unsigned long long>(a->res2) & 15) || (a->res2_bs & 7))) return -1;
     const int tiles_x = (a->W + 31) / 32, tiles_y = (a->H + TH - 1) / TH;
-    const int groups = (a->Cout + 31) / 32;
+    const int mt = h2s_mtile(a->Cout);
+    const int groups = (a->Cout + mt * 32 - 1) / (mt * 32);
     const long long nitems = (long long)tiles_x * tiles_y * groups * a->B;
     if (nitems > 0x7fffffffLL) return -1;
-    if ((long long)groups * (a->Cin / 16) * W_BYTES >= (1LL << 32)) return -1;
+    if (bfsr_conv_packed_size_h2s(a->Cout, a->Cin) * 2 >= (1LL << 32)) return -1;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (a->tune > 0) cus = a->tune;
     const long long grid = nitems < cus ? nitems : cus;                  // one persistent workgroup per CU
-    static std::atomic<unsigned long long> lds_done{0};
-    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2s_kernel), LDS_TOTAL, lds_done) != 0) return -1;
-    hipLaunchKernelGGL(conv3x3_h2s_kernel, dim3((unsigned)grid), dim3((NW + NL) * 64), LDS_TOTAL, st, *a, tiles_x, tiles_y, groups, (int)nitems);
-    return (int)hipGetLastError();
+    int abl = 0;
+#ifdef BFSR_H2S_ABL
+    abl = a->tune < 0 ? -a->tune : 0;
+#endif
+#define BFSR_LAUNCH(MT_)                                                                                                          \
+    {                                                                                                                             \
+        static std::atomic<unsigned long long> lds_done{0};                                                                       \
+        if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2s_kernel<MT_>), Cfg<MT_>::LDS_TOTAL, lds_done) != 0) return -1; \
+        hipLaunchKernelGGL(conv3x3_h2s_kernel<MT_>, dim3((unsigned)grid), dim3((NW + NLW) * 64), Cfg<MT_>::LDS_TOTAL, st, *a, tiles_x, tiles_y, \
+                           groups, (int)nitems, abl);                                                                             \
+        return (int)hipGetLastError();                                                                                            \
+    }
+    if (mt == 1) BFSR_LAUNCH(1)
+    BFSR_LAUNCH(2)
+#undef BFSR_LAUNCH
 }
 
 extern "C" int bfsr_h2_pack(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int C, int H, int W, void* stream)

@@ -423,11 +423,11 @@ class HipOps(object):
         return out
 
     def pack_conv_h2s(self, w):
-        """OIHW 3x3 fp32 weights -> fp16 packing of conv_h2s (32-cout workgroup tiles, 16-channel chunks)."""
+        """OIHW 3x3 fp32 weights -> fp16 packing of conv_h2s (32- or 64-cout workgroup tiles, 16-channel chunks)."""
         w = w.detach().to("cpu", torch.float32).contiguous()
         Cout, Cin, KS, _ = w.shape
-        if KS != 3 or Cin % 16:
-            raise ValueError("conv_h2s: 3x3 weights with Cin % 16 == 0 only")
+        if KS != 3 or Cin % 32:
+            raise ValueError("conv_h2s: 3x3 weights with Cin % 32 == 0 only")
         packed = torch.empty(self.lib.bfsr_conv_packed_size_h2s(Cout, Cin), dtype=torch.int16)
         _lib.check(self.lib.bfsr_pack_conv_weight_h2s(w.data_ptr(), Cout, Cin, packed.data_ptr()), "pack_h2s")
         return PackedConv(packed.to(self.device), Cout, Cin, 3, 1, fixed=True, w=None, ops=self)

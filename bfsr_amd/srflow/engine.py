@@ -90,7 +90,7 @@ class RRDBEncoder(object):
         self.ops, self.nb, self.nf, self.gc, self.skip_from_first = ops, nb, nf, gc, skip_from_first
         packed_ok = nf % 16 == 0 and gc % 16 == 0 and os.environ.get("BFSR_RRDB", "x3") != "fp32"
         self.x3s = not f16 and getattr(ops, "conv_mode", "f32") == "x3" and hasattr(ops, "conv_x3s") and packed_ok
-        self.h2s = f16 and hasattr(ops, "conv_h2s") and packed_ok
+        self.h2s = f16 and hasattr(ops, "conv_h2s") and packed_ok and nf % 32 == 0 and gc % 32 == 0
         g = lambda n: sd[prefix + n]
         mk = ((lambda w, b: _ConvX3S(ops, w, b)) if self.x3s else (lambda w, b: _ConvH2S(ops, w, b)) if self.h2s
               else (lambda w, b: _ConvP(ops, w, b, f16=f16)))

@@ -114,8 +114,8 @@ def test_conv_x3s_dense_block_views_and_residuals(hip):
 H2S_CASES = [
     # (B, Cin, Cout, H, W): one tile; ragged edges + two cout groups + many chunks (the loaders run 3 stages ahead across items);
     # many items per persistent workgroup; Cout not a multiple of 32; more tiles than the ring is deep with ONE chunk each
-    (1, 16, 32, 16, 32), (2, 64, 32, 19, 45), (1, 192, 64, 33, 65), (3, 96, 32, 128, 128), (2, 48, 24, 9, 33), (1, 32, 40, 70, 70),
-    (5, 16, 32, 40, 40),
+    (1, 32, 32, 16, 32), (2, 64, 32, 19, 45), (1, 192, 64, 33, 65), (3, 96, 32, 128, 128), (2, 64, 24, 9, 33), (1, 32, 40, 70, 70),
+    (5, 32, 32, 40, 40), (2, 64, 64, 50, 40), (1, 160, 104, 17, 31),
 ]
 
 

@@ -68,7 +68,7 @@ __device__ __forceinline__ void wait_vmcnt(int n)
 }
 
 // abl = ablation switches, honoured only in -DBFSR_H2S_ABL builds (tools/exp/h2s_bench.py): 1 = no input DMA after the first
-// stages, 2 = no weight DMA after them, 4 = no ds_read/MFMA
+// stages, 2 = no weight DMA after them, 4 = no ds_read/MFMA, 8 = no epilogue
 template <int MT>
 __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrConvX3Args p, int tiles_x, int tiles_y, int groups, int nitems, int abl)
 {
@@ -219,6 +219,13 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
     load_step(I0(), 0, 0);
     for (int it = slot; it < nitems; it += G) {
         const Item cur = decode(it);
+        float4 pm[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int idx = (cur.cg * MT + m) * 64 + lane;
+            pm[m] = (lane & 1) ? make_float4(1.f, 0.f, 0.f, 0.f) : make_float4(0.f, 0.f, 1.f, 0.f);
+            if (epi && (idx >> 1) < p.Cout) pm[m] = epi[idx];
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -235,60 +242,80 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
         // (row, x0 + l31); v_permlane32_swap pairs the half-waves so that each lane holds two complete channel octets.
         // Inline asm for the reason given in conv_x3s.hip (the builtin is folded on MFMA results); the pads cover the
         // MFMA -> VALU-read and VALU-write -> permlane hazards the compiler does not see around asm.
+        // Per-channel epilogue parameters: ONE coalesced load per lane (lane L holds float4 #L of this cout group's [32][8]
+        // block: channel L>>1, fields bias/shift/scale/post (L even) or post_scale (L odd)), handed to the lanes that need
+        // them by ds_bpermute.  (Reading epi[co] directly is 16 broadcast loads of 1 KiB per octet: 8 waves x 64 of them per
+        // tile kept the memory pipe busy for longer than the tile's MFMAs.)  Bias-only parameter sets skip the other fields.
+#ifdef BFSR_H2S_ABL
+        if (abl & 8) continue;
+#endif
+        bool plain = true;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) plain = plain && ((lane & 1) ? pm[m].x == 1.f : (pm[m].y == 0.f && pm[m].z == 1.f && pm[m].w == 0.f));
+        const bool bias_only = __all(plain);
+        auto fetch = [&](float val, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane * 4, __float_as_int(val))); };
         asm volatile("s_nop 11" ::: "memory");
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m) {
+            float v[2][2][8];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float v[2][8];
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
+                for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float lo = acc[m][j][8 * q + i], hi = acc[m][j][8 * q + 4 + i];
-                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
-                    v[q][i] = lo;
-                    v[q][4 + i] = hi;
-                }
-            const int gy = cur.y0 + 2 * wave + j, gx = cur.x0 + l31;
-            if (gy >= H || gx >= W) continue;
-            const long long pix = (long long)gy * W + gx;
+                    for (int i = 0; i < 4; ++i) {
+                        float lo = acc[m][j][8 * q + i], hi = acc[m][j][8 * q + 4 + i];
+                        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+                        v[j][q][i] = lo;
+                        v[j][q][4 + i] = hi;
+                    }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int oct = (cur.cg * MT + m) * 4 + q * 2 + lhi;
-                if (oct * 8 >= p.Cout) continue;
-                float o8[8];
+                float e0[8], e1[8], e2[8], e3[8], e4[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const int co = oct * 8 + i;
-                    float4 q0 = make_float4(0.f, 0.f, 1.f, 0.f); float q1 = 1.f;
-                    if (epi && co < p.Cout) { q0 = epi[co * 2]; q1 = epi[co * 2 + 1].x; }
-                    float u = v[q][i] + q0.x;
-                    u = (u + q0.y) * q0.z + q0.w;
-                    u = u > 0.f ? u : u * slope;
-                    o8[i] = u * q1;
+                    const int src = ((q * 2 + lhi) * 8 + i) * 2;         // lane holding this channel's first float4
+                    e0[i] = fetch(pm[m].x, src);
+                    e1[i] = 0.f; e2[i] = 1.f; e3[i] = 0.f; e4[i] = 1.f;
+                    if (!bias_only) { e1[i] = fetch(pm[m].y, src); e2[i] = fetch(pm[m].z, src); e3[i] = fetch(pm[m].w, src); e4[i] = fetch(pm[m].x, src + 1); }
                 }
-                auto add_res = [&](const unsigned short* res, long long bs, float alpha) {
-                    const unsigned short* rb = res + (long long)cur.b * bs + ((long long)oct * 2 * HW + pix) * 8;
-                    const half8 h = *reinterpret_cast<const half8*>(rb);
-                    const half8 l = *reinterpret_cast<const half8*>(rb + HW * 8);
+                if (oct * 8 >= p.Cout) continue;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) o8[i] = alpha * o8[i] + ((float)h[i] + (float)l[i]);
-                };
-                if (p.res1) add_res(p.res1, p.res1_bs, p.alpha1);
-                if (p.res2) add_res(p.res2, p.res2_bs, p.alpha2);
-                if (p.y_fmt != 0) {
-                    half8 h8, l8;
+                for (int j = 0; j < 2; ++j) {
+                    const int gy = cur.y0 + 2 * wave + j, gx = cur.x0 + l31;
+                    if (gy >= H || gx >= W) continue;
+                    const long long pix = (long long)gy * W + gx;
+                    float o8[8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) { _Float16 h, l; split2(o8[i], h, l); h8[i] = h; l8[i] = l; }
-                    unsigned short* yb = reinterpret_cast<unsigned short*>(p.y) + (long long)cur.b * p.y_bs + ((long long)oct * 2 * HW + pix) * 8;
-                    *reinterpret_cast<half8*>(yb) = h8;
-                    if (p.y_fmt == 1) *reinterpret_cast<half8*>(yb + HW * 8) = l8;
-                } else {
-                    float* yb = reinterpret_cast<float*>(p.y) + (long long)cur.b * p.y_bs + pix;
+                    for (int i = 0; i < 8; ++i) {
+                        float u = v[j][q][i] + e0[i];
+                        u = (u + e1[i]) * e2[i] + e3[i];
+                        u = u > 0.f ? u : u * slope;
+                        o8[i] = u * e4[i];
+                    }
+                    auto add_res = [&](const unsigned short* res, long long bs, float alpha) {
+                        const unsigned short* rb = res + (long long)cur.b * bs + ((long long)oct * 2 * HW + pix) * 8;
+                        const half8 h = *reinterpret_cast<const half8*>(rb);
+                        const half8 l = *reinterpret_cast<const half8*>(rb + HW * 8);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        if (oct * 8 + i < p.Cout) yb[(long long)(oct * 8 + i) * HW] = o8[i];
+                        for (int i = 0; i < 8; ++i) o8[i] = alpha * o8[i] + ((float)h[i] + (float)l[i]);
+                    };
+                    if (p.res1) add_res(p.res1, p.res1_bs, p.alpha1);
+                    if (p.res2) add_res(p.res2, p.res2_bs, p.alpha2);
+                    if (p.y_fmt != 0) {
+                        half8 h8, l8;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { _Float16 h, l; split2(o8[i], h, l); h8[i] = h; l8[i] = l; }
+                        unsigned short* yb = reinterpret_cast<unsigned short*>(p.y) + (long long)cur.b * p.y_bs + ((long long)oct * 2 * HW + pix) * 8;
+                        *reinterpret_cast<half8*>(yb) = h8;
+                        if (p.y_fmt == 1) *reinterpret_cast<half8*>(yb + HW * 8) = l8;
+                    } else {
+                        float* yb = reinterpret_cast<float*>(p.y) + (long long)cur.b * p.y_bs + pix;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            if (oct * 8 + i < p.Cout) yb[(long long)(oct * 8 + i) * HW] = o8[i];
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);                       // one octet at a time: keeps the epilogue's live ranges short
             }

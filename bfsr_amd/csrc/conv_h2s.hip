@@ -193,7 +193,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
     int c = 0, st = 0;                                                   // chunk counter, its LDS stage
-    auto chunk_body = [&](auto p_, auto q_) {                            // p_ = parity of this chunk's first step, q_ = the other buffer
+    auto chunk_body = [&](auto p_, auto q_, bool pf) {                   // p_ = buffer of this chunk's first step, q_ = the other; pf: prefetch the next chunk's first step
         const int nst = st + 1 == NS ? 0 : st + 1;
         load_step(q_, st, 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -205,7 +205,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < T) {
             __builtin_amdgcn_s_barrier();
-            load_step(q_, nst, 0);
+            if (pf) load_step(q_, nst, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         mfma_step(p_);
@@ -234,30 +234,41 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
         if (abl & 4) { for (int k = 0; k < nchunk; ++k) { if (c + 1 < T) __builtin_amdgcn_s_barrier(); ++c; } } else
 #endif
         for (int k = 0; k < nchunk; k += 2) {                            // Cin % 32 == 0: the register-buffer parity is static
-            chunk_body(I0(), I1());
-            chunk_body(I1(), I0());
+            chunk_body(I0(), I1(), true);
+            chunk_body(I1(), I0(), k + 2 < nchunk);                      // the last chunk of a tile leaves the registers to the epilogue
         }
 
         // ---- epilogue (the loaders are already staging the next item).  acc[r] = channel (r&3) + 8(r>>2) + 4*lhi of pixel
         // (row, x0 + l31); v_permlane32_swap pairs the half-waves so that each lane holds two complete channel octets.
         // Inline asm for the reason given in conv_x3s.hip (the builtin is folded on MFMA results); the pads cover the
         // MFMA -> VALU-read and VALU-write -> permlane hazards the compiler does not see around asm.
-        // Per-channel epilogue parameters: ONE coalesced load per lane (lane L holds float4 #L of this cout group's [32][8]
-        // block: channel L>>1, fields bias/shift/scale/post (L even) or post_scale (L odd)), handed to the lanes that need
-        // them by ds_bpermute.  (Reading epi[co] directly is 16 broadcast loads of 1 KiB per octet: 8 waves x 64 of them per
-        // tile kept the memory pipe busy for longer than the tile's MFMAs.)  Bias-only parameter sets skip the other fields.
+        // Per-channel parameters: the coalesced load issued at the top of the tile, handed to the lanes that need them by
+        // ds_bpermute (reading epi[co] directly = 16 broadcast loads of 1 KiB per octet, after the last MFMA).  Residual
+        // operands: ALL groups' loads are issued before the first is used -- one HBM round trip per residual and tile, not one
+        // per octet (measured: the serialised version cost more than the K loop of the 192-channel conv).
 #ifdef BFSR_H2S_ABL
-        if (abl & 8) continue;
+        if (abl & 8) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) { asm volatile("" :: "v"(acc[m][0])); asm volatile("" :: "v"(acc[m][1])); }
+#endif
+            if (c < T) load_step(I0(), st, 0);
+            continue;
+        }
 #endif
         bool plain = true;
 #pragma unroll
         for (int m = 0; m < MT; ++m) plain = plain && ((lane & 1) ? pm[m].x == 1.f : (pm[m].y == 0.f && pm[m].z == 1.f && pm[m].w == 0.f));
         const bool bias_only = __all(plain);
         auto fetch = [&](float val, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane * 4, __float_as_int(val))); };
+        float o[MT][2][2][8];                                            // [m tile][row][octet q][channel]
+        int lh = lhi, lx = l31;                                          // opaque copies: keeps the per-lane address arithmetic of the epilogue
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(lh), "+v"(lx));                           // INSIDE the tile loop (hoisted, it is spilled to scratch and reloaded here)
+#endif
         asm volatile("s_nop 11" ::: "memory");
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            float v[2][2][8];
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -266,60 +277,91 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
                     for (int i = 0; i < 4; ++i) {
                         float lo = acc[m][j][8 * q + i], hi = acc[m][j][8 * q + 4 + i];
                         asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
-                        v[j][q][i] = lo;
-                        v[j][q][4 + i] = hi;
+                        o[m][j][q][i] = lo;
+                        o[m][j][q][4 + i] = hi;
                     }
+        const int gx = cur.x0 + lx;
+        int goff[MT][2][2];                                              // element offset of the group's hi octet inside a batch item (< 2^31, checked by the launcher), or -1
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int oct = (cur.cg * MT + m) * 4 + q * 2 + lhi;
-                float e0[8], e1[8], e2[8], e3[8], e4[8];
+                const int oct = (cur.cg * MT + m) * 4 + q * 2 + lh;
+                float e0[8], e1[8], e2[8], e3[8], e4[8];                 // every lane takes part in the exchange (before any divergence)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const int src = ((q * 2 + lhi) * 8 + i) * 2;         // lane holding this channel's first float4
+                    const int src = ((q * 2 + lh) * 8 + i) * 2;         // lane holding this channel's first float4
                     e0[i] = fetch(pm[m].x, src);
                     e1[i] = 0.f; e2[i] = 1.f; e3[i] = 0.f; e4[i] = 1.f;
                     if (!bias_only) { e1[i] = fetch(pm[m].y, src); e2[i] = fetch(pm[m].z, src); e3[i] = fetch(pm[m].w, src); e4[i] = fetch(pm[m].x, src + 1); }
                 }
-                if (oct * 8 >= p.Cout) continue;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int gy = cur.y0 + 2 * wave + j, gx = cur.x0 + l31;
-                    if (gy >= H || gx >= W) continue;
-                    const long long pix = (long long)gy * W + gx;
-                    float o8[8];
+                    const int gy = cur.y0 + 2 * wave + j;
+                    goff[m][j][q] = (gy < H && gx < W && oct * 8 < p.Cout) ? (int)(((long long)oct * 2 * HW + (long long)gy * W + gx) * 8) : -1;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        float u = v[j][q][i] + e0[i];
+                        float u = o[m][j][q][i] + e0[i];
                         u = (u + e1[i]) * e2[i] + e3[i];
                         u = u > 0.f ? u : u * slope;
-                        o8[i] = u * e4[i];
+                        o[m][j][q][i] = u * e4[i];
                     }
-                    auto add_res = [&](const unsigned short* res, long long bs, float alpha) {
-                        const unsigned short* rb = res + (long long)cur.b * bs + ((long long)oct * 2 * HW + pix) * 8;
-                        const half8 h = *reinterpret_cast<const half8*>(rb);
-                        const half8 l = *reinterpret_cast<const half8*>(rb + HW * 8);
+                }
+                __builtin_amdgcn_sched_barrier(0);                       // one (M tile, octet) at a time: short live ranges
+            }
+        auto add_res = [&](const unsigned short* res, long long bs, float alpha) {
+            const unsigned short* rb = res + (long long)cur.b * bs;
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) o8[i] = alpha * o8[i] + ((float)h[i] + (float)l[i]);
-                    };
-                    if (p.res1) add_res(p.res1, p.res1_bs, p.alpha1);
-                    if (p.res2) add_res(p.res2, p.res2_bs, p.alpha2);
+            for (int m = 0; m < MT; ++m) {                               // one M tile (4 groups, 32 registers) per round trip
+                half8 rh[2][2], rl[2][2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int g = goff[m][j][q];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { rh[j][q][i] = (_Float16)0.f; rl[j][q][i] = (_Float16)0.f; }
+                        if (g >= 0) {
+                            rh[j][q] = *reinterpret_cast<const half8*>(rb + g);
+                            rl[j][q] = *reinterpret_cast<const half8*>(rb + g + HW * 8);
+                        }
+                    }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) o[m][j][q][i] = alpha * o[m][j][q][i] + ((float)rh[j][q][i] + (float)rl[j][q][i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (p.res1) add_res(p.res1, p.res1_bs, p.alpha1);
+        if (p.res2) add_res(p.res2, p.res2_bs, p.alpha2);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int g = goff[m][j][q];
+                    if (g < 0) continue;
                     if (p.y_fmt != 0) {
                         half8 h8, l8;
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) { _Float16 h, l; split2(o8[i], h, l); h8[i] = h; l8[i] = l; }
-                        unsigned short* yb = reinterpret_cast<unsigned short*>(p.y) + (long long)cur.b * p.y_bs + ((long long)oct * 2 * HW + pix) * 8;
+                        for (int i = 0; i < 8; ++i) { _Float16 h, l; split2(o[m][j][q][i], h, l); h8[i] = h; l8[i] = l; }
+                        unsigned short* yb = reinterpret_cast<unsigned short*>(p.y) + (long long)cur.b * p.y_bs + g;
                         *reinterpret_cast<half8*>(yb) = h8;
                         if (p.y_fmt == 1) *reinterpret_cast<half8*>(yb + HW * 8) = l8;
                     } else {
-                        float* yb = reinterpret_cast<float*>(p.y) + (long long)cur.b * p.y_bs + pix;
+                        const int oct = (cur.cg * MT + m) * 4 + q * 2 + lh;
+                        float* yb = reinterpret_cast<float*>(p.y) + (long long)cur.b * p.y_bs + (long long)(cur.y0 + 2 * wave + j) * W + gx;
 #pragma unroll
                         for (int i = 0; i < 8; ++i)
-                            if (oct * 8 + i < p.Cout) yb[(long long)(oct * 8 + i) * HW] = o8[i];
+                            if (oct * 8 + i < p.Cout) yb[(long long)(oct * 8 + i) * HW] = o[m][j][q][i];
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);                       // one octet at a time: keeps the epilogue's live ranges short
-            }
-        }
+        if (c < T) load_step(I0(), st, 0);                               // first fragments of the next tile (its barrier is already behind us)
     }
 }
 
@@ -367,7 +409,10 @@ inline unsigned short f32_to_f16_bits(float v)
 
 }  // namespace
 
-static inline int h2s_mtile(int Cout) { return Cout > 32 ? 2 : 1; }
+// M tiles per workgroup.  MT = 2 (64 couts per workgroup for the 192 -> 64 conv: one staging of the input tile instead of two) is
+// implemented by the kernel template but NOT used: its epilogue (64 accumulators + residual operands per lane) spills to scratch
+// and measured 1.05 ms against 0.61 ms for two 32-cout passes at 128 x 128x128 (tools/exp/h2s_bench.py).
+static inline int h2s_mtile(int Cout) { (void)Cout; return 1; }
 
 extern "C" long long bfsr_conv_packed_size_h2s(int Cout, int Cin)
 {
@@ -401,6 +446,7 @@ extern "C" int bfsr_conv3x3_h2s(const BfsrConvX3Args* a, void* stream)
     if (a->y_fmt < 0 || a->y_fmt > 2) return -1;
     if ((a->y_fmt != 0 || a->res1 || a->res2) && (a->Cout & 7)) return -1;
     if ((long long)(a->Cin / 8) * 2 * a->H * a->W * 16 >= (1LL << 31)) return -1;      // 32-bit byte offsets inside one batch item
+    if ((long long)((a->Cout + 7) / 8) * 2 * a->H * a->W * 8 >= (1LL << 31)) return -1;  // 32-bit element offsets in the epilogue
     if ((reinterpret_cast<unsigned long long>(a->x) & 15) || (a->x_bs & 7)) return -1;
     if (a->y_fmt != 0 && ((reinterpret_cast<unsigned long long>(a->y) & 15) || (a->y_bs & 7))) return -1;
     if (a->res1 && ((reinterpret_cast<unsigned long long>(a->res1) & 15) || (a->res1_bs & 7))) return -1;
@@ -427,8 +473,7 @@ extern "C" int bfsr_conv3x3_h2s(const BfsrConvX3Args* a, void* stream)
                            groups, (int)nitems, abl);                                                                             \
         return (int)hipGetLastError();                                                                                            \
     }
-    if (mt == 1) BFSR_LAUNCH(1)
-    BFSR_LAUNCH(2)
+    BFSR_LAUNCH(1)
 #undef BFSR_LAUNCH
 }
 

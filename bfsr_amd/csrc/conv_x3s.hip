@@ -188,6 +188,36 @@ __global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64
         f32x16 acc, acc2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+        // Per-channel epilogue parameters of this cout group: ONE coalesced load per lane, issued here so that it lands under the
+        // K loop (lane L holds float4 #L of the group's [32][8] block: channel L>>1; bias/shift/scale/post if L is even, post_scale
+        // if odd); the epilogue hands them to the lanes that need them with ds_bpermute.  Reading epi[co] directly costs 32
+        // broadcast loads of 1 KiB per wave and tile, issued after the last MFMA: measured (tools/exp/x3s_abl.py), the epilogue
+        // then took as long as the K loop of a 64-channel conv.
+        float4 pm = (lane & 1) ? make_float4(1.f, 0.f, 0.f, 0.f) : make_float4(0.f, 0.f, 1.f, 0.f);
+        {
+            const int idx = cur.cg * 64 + lane;
+            if (p.epi && (idx >> 1) < p.Cout) pm = reinterpret_cast<const float4*>(p.epi)[idx];
+        }
+        // ... and so are the operands of the first residual (`x5*0.2 + x`, 2 octets x 3 planes): the K loop hides their round trip
+        const int gy = cur.y0 + wave, gx = cur.x0 + l31;
+        const long long HW = (long long)H * W;
+        const long long pix = (long long)gy * W + gx;
+        bool valid[2];
+        bf16x8 r1[2][3];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int oct = cur.cg * 4 + q * 2 + lhi;             // channel octet of the output tensor
+            valid[q] = gy < H && gx < W && oct * 8 < p.Cout;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r1[q][pl][j] = (__bf16)0.f;
+            if (p.res1 && valid[q]) {
+                const unsigned short* rb = p.res1 + (long long)cur.b * p.res1_bs + ((long long)oct * 3 * HW + pix) * 8;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) r1[q][pl] = *reinterpret_cast<const bf16x8*>(rb + pl * HW * 8);
+            }
+        }
         const int nxt = it + G;
         const bool has_next = nxt < nitems;
         Item nitem = cur;
@@ -245,6 +275,11 @@ __global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64
         // ---- epilogue of item `cur` (the next item's first chunk is already in flight).  acc[r] = channel (r&3)+8(r>>2)+4*lhi
         // of pixel (y0+wave, x0+l31); v_permlane32_swap pairs the two half-waves so that every lane ends up with two complete
         // channel octets of its pixel: octet q*2+lhi in v[q][0..7]
+        if constexpr ((ABL & 128) != 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" :: "v"(acc));
+#endif
+            if (!has_next) break; it = nxt; cur = nitem; continue; }     // ablation: no epilogue (acc kept alive)
         float v[2][8];
         // inline asm: hipcc (ROCm 7.2) folds eight __builtin_amdgcn_permlane32_swap calls on MFMA result elements into ONE
         // swap of element 0 (every output channel became channel 0); asm statements are opaque to it.  The compiler pads
@@ -260,51 +295,71 @@ __global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64
                 v[q][i] = lo;
                 v[q][4 + i] = hi;
             }
-        const int gy = cur.y0 + wave, gx = cur.x0 + l31;
-        if (gy < H && gx < W) {
-            const float slope = p.act == BFSR_ACT_NONE ? 1.f : (p.act == BFSR_ACT_RELU ? 0.f : p.slope);
-            const float4* __restrict__ epi = reinterpret_cast<const float4*>(p.epi);
-            const long long pix = (long long)gy * W + gx;
-            const long long HW = (long long)H * W;
+        const bool bias_only = __all((lane & 1) ? pm.x == 1.f : (pm.y == 0.f && pm.z == 1.f && pm.w == 0.f));
+        auto fetch = [&](float val, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane * 4, __float_as_int(val))); };
+        const float slope = p.act == BFSR_ACT_NONE ? 1.f : (p.act == BFSR_ACT_RELU ? 0.f : p.slope);
+        float o[2][8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float e0[8], e1[8], e2[8], e3[8], e4[8];              // all lanes take part in the exchange (before any divergence)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int src = ((q * 2 + lhi) * 8 + j) * 2;      // lane holding this channel's first float4
+                e0[j] = fetch(pm.x, src);
+                e1[j] = 0.f; e2[j] = 1.f; e3[j] = 0.f; e4[j] = 1.f;
+                if (!bias_only) { e1[j] = fetch(pm.y, src); e2[j] = fetch(pm.z, src); e3[j] = fetch(pm.w, src); e4[j] = fetch(pm.x, src + 1); }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float u = v[q][j] + e0[j];
+                u = (u + e1[j]) * e2[j] + e3[j];
+                u = u > 0.f ? u : u * slope;
+                o[q][j] = u * e4[j];
+            }
+        }
+        if (p.res1) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[q][j] = p.alpha1 * o[q][j] + (((float)r1[q][0][j] + (float)r1[q][1][j]) + (float)r1[q][2][j]);
+        }
+        if (p.res2) {                                             // both octets' loads in flight before the first use: one round trip
+            bf16x8 r2[2][3];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int oct = cur.cg * 4 + q * 2 + lhi;             // channel octet of the output tensor
-                if (oct * 8 >= p.Cout) continue;
-                float o8[8];
+                const int oct = cur.cg * 4 + q * 2 + lhi;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int co = oct * 8 + j;
-                    float4 q0 = make_float4(0.f, 0.f, 1.f, 0.f); float q1 = 1.f;
-                    if (epi && co < p.Cout) { q0 = epi[co * 2]; q1 = epi[co * 2 + 1].x; }
-                    float u = v[q][j] + q0.x;
-                    u = (u + q0.y) * q0.z + q0.w;
-                    u = u > 0.f ? u : u * slope;
-                    o8[j] = u * q1;
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) r2[q][pl][j] = (__bf16)0.f;
+                if (valid[q]) {
+                    const unsigned short* rb = p.res2 + (long long)cur.b * p.res2_bs + ((long long)oct * 3 * HW + pix) * 8;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) r2[q][pl] = *reinterpret_cast<const bf16x8*>(rb + pl * HW * 8);
                 }
-                auto add_res = [&](const unsigned short* res, long long bs, float alpha) {
-                    const unsigned short* rb = res + (long long)cur.b * bs + ((long long)oct * 3 * HW + pix) * 8;
-                    const bf16x8 h = *reinterpret_cast<const bf16x8*>(rb);
-                    const bf16x8 m = *reinterpret_cast<const bf16x8*>(rb + HW * 8);
-                    const bf16x8 l = *reinterpret_cast<const bf16x8*>(rb + 2 * HW * 8);
+            }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) o8[j] = alpha * o8[j] + (((float)h[j] + (float)m[j]) + (float)l[j]);
-                };
-                if (p.res1) add_res(p.res1, p.res1_bs, p.alpha1);
-                if (p.res2) add_res(p.res2, p.res2_bs, p.alpha2);
-                if (p.y_fmt == 1) {
-                    bf16x8 h8, m8, l8;
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { __bf16 h, m, l; split3(o8[j], h, m, l); h8[j] = h; m8[j] = m; l8[j] = l; }
-                    unsigned short* yb = reinterpret_cast<unsigned short*>(p.y) + (long long)cur.b * p.y_bs + ((long long)oct * 3 * HW + pix) * 8;
-                    *reinterpret_cast<bf16x8*>(yb) = h8;
-                    *reinterpret_cast<bf16x8*>(yb + HW * 8) = m8;
-                    *reinterpret_cast<bf16x8*>(yb + 2 * HW * 8) = l8;
-                } else {
-                    float* yb = reinterpret_cast<float*>(p.y) + (long long)cur.b * p.y_bs + pix;
+                for (int j = 0; j < 8; ++j) o[q][j] = p.alpha2 * o[q][j] + (((float)r2[q][0][j] + (float)r2[q][1][j]) + (float)r2[q][2][j]);
+        }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (oct * 8 + j < p.Cout) yb[(long long)(oct * 8 + j) * HW] = o8[j];
-                }
+        for (int q = 0; q < 2; ++q) {
+            if (!valid[q]) continue;
+            const int oct = cur.cg * 4 + q * 2 + lhi;
+            if (p.y_fmt == 1) {
+                bf16x8 h8, m8, l8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { __bf16 h, m, l; split3(o[q][j], h, m, l); h8[j] = h; m8[j] = m; l8[j] = l; }
+                unsigned short* yb = reinterpret_cast<unsigned short*>(p.y) + (long long)cur.b * p.y_bs + ((long long)oct * 3 * HW + pix) * 8;
+                *reinterpret_cast<bf16x8*>(yb) = h8;
+                *reinterpret_cast<bf16x8*>(yb + HW * 8) = m8;
+                *reinterpret_cast<bf16x8*>(yb + 2 * HW * 8) = l8;
+            } else {
+                float* yb = reinterpret_cast<float*>(p.y) + (long long)cur.b * p.y_bs + pix;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (oct * 8 + j < p.Cout) yb[(long long)(oct * 8 + j) * HW] = o[q][j];
             }
         }
         if (!has_next) break;
@@ -386,6 +441,7 @@ extern "C" int bfsr_conv3x3_x3s(const BfsrConvX3Args* a, void* stream)
     switch (a->tune < 0 ? -a->tune : 0) {
         case 1: BFSR_LAUNCH(1) case 3: BFSR_LAUNCH(3) case 4: BFSR_LAUNCH(4) case 5: BFSR_LAUNCH(5) case 7: BFSR_LAUNCH(7)
         case 8: BFSR_LAUNCH(8) case 12: BFSR_LAUNCH(12) case 16: BFSR_LAUNCH(16) case 48: BFSR_LAUNCH(48) case 80: BFSR_LAUNCH(80)
+        case 17: BFSR_LAUNCH(17) case 144: BFSR_LAUNCH(144) case 145: BFSR_LAUNCH(145) case 20: BFSR_LAUNCH(20) case 148: BFSR_LAUNCH(148)
         default: break;
     }
 #endif

@@ -18,24 +18,23 @@ def timeit(fn, n=20):
     return s.elapsed_time(e) / n * 1e3
 
 
-NAMES = {0: "full", 16: "2 loaders", 48: "3 loaders", 80: "4 loaders", 1: "noDMA"}
-for B in (8, 32):
+NAMES = {16: "product", 144: "no epilogue", 20: "2 acc chains", 148: "2 chains, no epilogue"}
+for B, H, W in ((8, 160, 160), (16, 256, 256)):
+    tot = {k: 0.0 for k in NAMES}
     for Cin, Cout in ((64, 32), (96, 32), (128, 32), (160, 32), (192, 64)):
-        H = W = 160
         x = torch.randn(B, Cin, H, W, device="cuda")
         w = torch.randn(Cout, Cin, 3, 3) * 0.05
         pw = ops.pack_conv_x3(w, None)
+        epi = ops.pack_epilogue(Cout, bias=torch.zeros(Cout))
         x3 = ops.x3_pack(x, ops.x3_empty(B, Cin, H, W))
         y3 = ops.x3_empty(B, Cout, H, W)
+        r3 = ops.x3_pack(torch.randn(B, Cout, H, W, device="cuda"), ops.x3_empty(B, Cout, H, W))
+        kw = dict(epi=epi, act=ACT_LRELU) if Cout == 32 else dict(epi=epi, res1=r3, alpha1=0.2)
         flop = 2.0 * Cin * 9 * Cout * B * H * W
-        row = "B%-2d %3d->%2d:" % (B, Cin, Cout)
-        ref = ops.conv_x3s(x3, pw, ops.x3_empty(B, Cout, H, W), act=ACT_LRELU, tune=0).clone()
-        for abl in (16, 48, 80):
-            got = ops.conv_x3s(x3, pw, ops.x3_empty(B, Cout, H, W), act=ACT_LRELU, tune=-abl)
-            torch.cuda.synchronize()
-            if not torch.equal(got.view(torch.int16), ref.view(torch.int16)):
-                row += " [variant %d WRONG]" % abl
+        row = "B%-2d %dx%d %3d->%2d:" % (B, H, W, Cin, Cout)
         for abl, nm in NAMES.items():
-            t = timeit(lambda: ops.conv_x3s(x3, pw, y3, act=ACT_LRELU, tune=-abl))
+            t = timeit(lambda: ops.conv_x3s(x3, pw, y3, tune=-abl, **kw))
+            tot[abl] += t
             row += " %s %.0fus %.0fTF |" % (nm, t, flop / t / 1e6)
         print(row, flush=True)
+    print("   one RDB: " + ", ".join("%s %.0f us" % (NAMES[k], v) for k, v in tot.items()), flush=True)

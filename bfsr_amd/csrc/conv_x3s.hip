@@ -53,14 +53,14 @@ __device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l)
     l = (__bf16)(r1 - (float)m);          // exact residual, <= 8 significant bits
 }
 
-struct Item { int cg, b, x0, y0; };
+struct Item { int cg, b, x0, y0, th; };     // th = tile height: TH, or TH/2 for the split tiles of the last partial round
 
 // ABL: the product is ABL = 16: dedicated loader waves (2 + ((ABL >> 5) & 3) of them, waves 8..) issue every LDS-DMA piece.
 // The other values are the ablation switches of tools/exp/x3s_abl.py (built with -DBFSR_X3S_ABL only): 0 = the compute waves
 // issue the DMA themselves right after the barrier, 8 = one piece per tap between the MFMAs, 1 = no DMA after the first stage
 // (timing only), 2 = no barrier (timing only), 4 = two accumulator chains
 template <int ABL>
-__global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64, 1) void conv3x3_x3s_kernel(BfsrConvX3Args p, int tiles_x, int tiles_y, int groups, int nitems)
+__global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64, 1) void conv3x3_x3s_kernel(BfsrConvX3Args p, int tiles_x, int tiles_y, int groups, int nitems, int n_full)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -74,11 +74,17 @@ __global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64
     const unsigned HW16 = (unsigned)(H * W) * 16u;           // bytes of one (octet, plane) image
     const int nchunk = p.Cin >> 4;
 
-    auto decode = [&](int it) {
+    // items [0, n_full) are whole tiles; the tiles of the last partial round of persistent workgroups follow as two half-height
+    // items each (rows 0-3 / 4-7, computed by waves 0-3): 800 tiles on 256 CUs take 3.5 rounds instead of 4
+    auto decode = [&](int it_) {
         Item r;
+        const int half = it_ >= n_full ? (it_ - n_full) & 1 : -1;
+        const int it = it_ >= n_full ? n_full + ((it_ - n_full) >> 1) : it_;
         r.cg = it % groups; int t = it / groups;
         const int ty = t % tiles_y; t /= tiles_y;
         r.x0 = (t % tiles_x) * 32; r.y0 = ty * TH; r.b = t / tiles_x;
+        r.th = TH;
+        if (half >= 0) { r.th = TH / 2; r.y0 += half * (TH / 2); }
         return r;
     };
 
@@ -207,7 +213,7 @@ __global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int oct = cur.cg * 4 + q * 2 + lhi;             // channel octet of the output tensor
-            valid[q] = gy < H && gx < W && oct * 8 < p.Cout;
+            valid[q] = wave < cur.th && gy < H && gx < W && oct * 8 < p.Cout;
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
@@ -247,6 +253,7 @@ __global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64
                 for (int pl = 0; pl < 3; ++pl)
                     afr[b_][pl] = *reinterpret_cast<const bf16x8*>(wA + pl * WPL + (dy * 3 + dx) * 1024);
             };
+            if (wave >= cur.th) { buf ^= 1; continue; }            // upper waves of a half-height tile: barriers only
             load_b(0);
             load_a(0, 0, 0);
 #pragma unroll
@@ -429,12 +436,16 @@ extern "C" int bfsr_conv3x3_x3s(const BfsrConvX3Args* a, void* stream)
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (a->tune > 0) cus = a->tune;
     long long grid = nitems < cus ? nitems : cus;          // one persistent workgroup per CU
+    long long n_full = nitems, n_items = nitems;
+    const long long rem = nitems % grid;
+    if (nitems > grid && rem > 0 && 2 * rem <= grid) { n_full = nitems - rem; n_items = n_full + 2 * rem; }     // split the last partial round
+    if (n_items > 0x7fffffffLL) return -1;
 #define BFSR_LAUNCH(ABL_)                                                                                                            \
     {                                                                                                                                \
         static std::atomic<unsigned long long> lds_done{0};                                                                          \
         if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_x3s_kernel<ABL_>), LDS_TOTAL, lds_done) != 0) return -1; \
         hipLaunchKernelGGL(conv3x3_x3s_kernel<ABL_>, dim3((unsigned)grid), dim3((NW + (((ABL_) & 16) ? 2 + (((ABL_) >> 5) & 3) : 0)) * 64), LDS_TOTAL, st, *a, tiles_x, tiles_y, groups, \
-                           (int)nitems);                                                                                             \
+                           (int)n_items, (int)n_full);                                                                              \
         return (int)hipGetLastError();                                                                                               \
     }
 #ifdef BFSR_X3S_ABL

@@ -260,6 +260,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
 #pragma unroll
         for (int m = 0; m < MT; ++m) plain = plain && ((lane & 1) ? pm[m].x == 1.f : (pm[m].y == 0.f && pm[m].z == 1.f && pm[m].w == 0.f));
         const bool bias_only = __all(plain);
+        const bool fast = bias_only && slope >= 0.f && slope <= 1.f;
         auto fetch = [&](float val, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane * 4, __float_as_int(val))); };
         float o[MT][2][2][8];                                            // [m tile][row][octet q][channel]
         int lh = lhi, lx = l31;                                          // opaque copies: keeps the per-lane address arithmetic of the epilogue
@@ -299,12 +300,20 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
                 for (int j = 0; j < 2; ++j) {
                     const int gy = cur.y0 + 2 * wave + j;
                     goff[m][j][q] = (gy < H && gx < W && oct * 8 < p.Cout) ? (int)(((long long)oct * 2 * HW + (long long)gy * W + gx) * 8) : -1;
+                    if (fast) {                                          // bias + (leaky) ReLU only: 3 VALU ops per channel instead of 8
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        float u = o[m][j][q][i] + e0[i];
-                        u = (u + e1[i]) * e2[i] + e3[i];
-                        u = u > 0.f ? u : u * slope;
-                        o[m][j][q][i] = u * e4[i];
+                        for (int i = 0; i < 8; ++i) {
+                            const float u = o[m][j][q][i] + e0[i];
+                            o[m][j][q][i] = fmaxf(u, u * slope);         // = u > 0 ? u : u*slope for 0 <= slope <= 1
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            float u = o[m][j][q][i] + e0[i];
+                            u = (u + e1[i]) * e2[i] + e3[i];
+                            u = u > 0.f ? u : u * slope;
+                            o[m][j][q][i] = u * e4[i];
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);                       // one (M tile, octet) at a time: short live ranges
@@ -345,13 +354,18 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
                 for (int q = 0; q < 2; ++q) {
                     const int g = goff[m][j][q];
                     if (g < 0) continue;
-                    if (p.y_fmt != 0) {
+                    if (p.y_fmt == 2) {
+                        half8 h8;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) h8[i] = (_Float16)o[m][j][q][i];
+                        *reinterpret_cast<half8*>(reinterpret_cast<unsigned short*>(p.y) + (long long)cur.b * p.y_bs + g) = h8;
+                    } else if (p.y_fmt == 1) {
                         half8 h8, l8;
 #pragma unroll
                         for (int i = 0; i < 8; ++i) { _Float16 h, l; split2(o[m][j][q][i], h, l); h8[i] = h; l8[i] = l; }
                         unsigned short* yb = reinterpret_cast<unsigned short*>(p.y) + (long long)cur.b * p.y_bs + g;
                         *reinterpret_cast<half8*>(yb) = h8;
-                        if (p.y_fmt == 1) *reinterpret_cast<half8*>(yb + HW * 8) = l8;
+                        *reinterpret_cast<half8*>(yb + HW * 8) = l8;
                     } else {
                         const int oct = (cur.cg * MT + m) * 4 + q * 2 + lh;
                         float* yb = reinterpret_cast<float*>(p.y) + (long long)cur.b * p.y_bs + (long long)(cur.y0 + 2 * wave + j) * W + gx;

@@ -305,6 +305,7 @@ __global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64
         const bool bias_only = __all((lane & 1) ? pm.x == 1.f : (pm.y == 0.f && pm.z == 1.f && pm.w == 0.f));
         auto fetch = [&](float val, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane * 4, __float_as_int(val))); };
         const float slope = p.act == BFSR_ACT_NONE ? 1.f : (p.act == BFSR_ACT_RELU ? 0.f : p.slope);
+        const bool fast = bias_only && slope >= 0.f && slope <= 1.f;
         float o[2][8];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -316,12 +317,20 @@ __global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64
                 e1[j] = 0.f; e2[j] = 1.f; e3[j] = 0.f; e4[j] = 1.f;
                 if (!bias_only) { e1[j] = fetch(pm.y, src); e2[j] = fetch(pm.z, src); e3[j] = fetch(pm.w, src); e4[j] = fetch(pm.x, src + 1); }
             }
+            if (fast) {                                           // bias + (leaky) ReLU only: 3 VALU ops per channel instead of 8
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float u = v[q][j] + e0[j];
-                u = (u + e1[j]) * e2[j] + e3[j];
-                u = u > 0.f ? u : u * slope;
-                o[q][j] = u * e4[j];
+                for (int j = 0; j < 8; ++j) {
+                    const float u = v[q][j] + e0[j];
+                    o[q][j] = fmaxf(u, u * slope);                // = u > 0 ? u : u*slope for 0 <= slope <= 1
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float u = v[q][j] + e0[j];
+                    u = (u + e1[j]) * e2[j] + e3[j];
+                    u = u > 0.f ? u : u * slope;
+                    o[q][j] = u * e4[j];
+                }
             }
         }
         if (p.res1) {

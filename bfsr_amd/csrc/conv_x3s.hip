@@ -103,7 +103,7 @@ __global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64
             const int pos = wave * 64 + lane;
             const int r = pos / PW, c = pos - r * PW;
             const int gy = it.y0 + r - 1, gx = it.x0 + c - 1;
-            const bool ok = pos < NPOS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const bool ok = pos < (it.th + 2) * PW && gy >= 0 && gy < H && gx >= 0 && gx < W;
             voff_in = ok ? (unsigned)(gy * W + gx) * 16u : OOB;
         }
     };
@@ -145,7 +145,7 @@ __global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64
                     const int pos = g * 64 + lane;
                     const int r = pos / PW, c = pos - r * PW;
                     const int gy = itx.y0 + r - 1, gx = itx.x0 + c - 1;
-                    const bool ok = pos < NPOS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                    const bool ok = pos < (itx.th + 2) * PW && gy >= 0 && gy < H && gx >= 0 && gx < W;
                     vg[g] = ok ? (unsigned)(gy * W + gx) * 16u : OOB;
                 }
             };

@@ -106,9 +106,13 @@ __global__ __launch_bounds__(NW * 64, X3 ? 2 : 4) void linf_mlp_kernel(BfsrLinfM
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int b = blockIdx.x / tiles_per_image;
+    // XCD-aware tile order: the 4-neighbour gathers of nearby tiles (same and adjacent query rows) hit the same cf lines, so one
+    // XCD (= one L2) takes a contiguous range of tiles; with the default round-robin every L2 fetched every line (PMC: 20x the
+    // algorithmic bytes of cf at BASELINE config 5)
+    const int bid = (int)bfsr::xcd_order(blockIdx.x, gridDim.x);
+    const int b = bid / tiles_per_image;
     const long long NQ = (long long)a.qh * a.qw;
-    const long long q0 = (long long)(blockIdx.x - b * tiles_per_image) * P;
+    const long long q0 = (long long)(bid - b * tiles_per_image) * P;
     const long long q = q0 + lane;                     // this lane's query point during feature generation
     const bool qok = q < NQ;
 

@@ -10,8 +10,9 @@ import glob
 import json
 import sys
 
-LIB = ("conv_", "conv3x3_x3s", "x3_pack", "x3_unpack", "coupling_", "flow_pointwise", "squeeze2d", "unsqueeze2d", "split2d",
-       "standardize", "resize_kernel", "maxpool2", "axpb_clamp", "linf_", "patch_", "grid_sample")
+LIB = ("conv_", "conv3x3_x3s", "conv3x3_h2s", "conv2d_direct", "x3_pack", "x3_unpack", "h2_pack", "h2_unpack", "coupling_", "flow_pointwise", "squeeze2d", "unsqueeze2d", "split2d",
+       "standardize", "resize_kernel", "maxpool2", "axpb_clamp", "linf_", "patch_", "grid_sample", "conv1x1", "gaussian_logp", "logscale_sum",
+       "resample_taps", "sqdiff_sum", "ssim_sum", "to_uint8")
 # FETCH_SIZE on gfx950 counts 64 B per 128-B request (MI355X_MICROARCH.md, HBM; documented there for 16-B-per-lane streaming reads).
 # Calibration for THIS library's access patterns, from the same PMC run (profiles/r02_pmc_traffic.json "calibration"): the plain 1x1
 # conv 64->64 @ 8x320x320 reads its 209.7 MB input exactly once with 4-byte-per-lane row loads and reports 105.3 MB raw = 0.502, so the
@@ -41,7 +42,7 @@ fetch = per_key(sys.argv[1], sys.argv[2], "FETCH_SIZE")
 write = per_key(sys.argv[3], sys.argv[4], "WRITE_SIZE")
 out = {"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python bench.py --steps 1 --warmup 1 "
                   "--no-cpu-baseline --no-fp32-line (one pass per counter, BFSR_KEYLOG to map dispatches to launch shapes)",
-       "units": "rocprofv3 reports KB; bytes = KB * 1024; hbm_bytes_per_launch = fetch (x2 only for 16-B-per-lane readers, see fetch_correction) + write",
+       "units": "rocprofv3 reports KB; bytes = KB * 1024; hbm_bytes_per_launch = fetch x fetch_correction (x2 on gfx950, calibrated: see the comment in tools/pmc_traffic.py) + write",
        "kernels": collections.OrderedDict()}
 rows = []
 for k, fa in fetch.items():
@@ -49,7 +50,7 @@ for k, fa in fetch.items():
     if not wa or not (k.startswith('["conv') or k.startswith('["coupling') or k.startswith('["linf_mlp') or k.startswith('["flow')):
         continue
     fb, wb = fa["sum"] / fa["n"] * 1024.0, wa["sum"] / wa["n"] * 1024.0
-    corr = 2.0 if any(k.startswith('["%s"' % w) for w in WIDE_READERS) else 1.0
+    corr = 2.0 if any(k.startswith('["%s' % w) for w in WIDE_READERS) else 1.0
     rows.append((fa["n"] * (corr * fb + wb), k, {"kernel": fa["kernel"], "launches": fa["n"], "fetch_bytes_raw": fb, "write_bytes": wb,
                                                 "fetch_correction": corr, "hbm_bytes_per_launch": corr * fb + wb,
                                                 "unit": "HBM-side bytes per launch: rocprofv3 FETCH_SIZE x %g + WRITE_SIZE" % corr}))

@@ -9,12 +9,14 @@
 // (ONE barrier per chunk, the next chunk's DMA in flight under this chunk's MFMAs), the eight compute waves issue nothing but
 // ds_read_b128 + MFMA, and the workgroup is persistent (one per CU walks its tiles in an XCD-aware order; the loaders run ahead
 // across tile boundaries, so a tile's first chunk lands under the previous tile's epilogue).
-// Measured on MI355X at the RDB shapes (tools/exp/x3s_abl.py, profiles/r02_b_x3s_ablation.txt): the bare fragment-read + MFMA
-// loop of this tile shape tops out at 190-245 TFLOP/s; DMA issued by the compute waves costs 20-25 % of that (an LDS-DMA
-// instruction blocks its wave's issue for 60-185 cycles), dedicated loader waves give most of it back: 139-202 TFLOP/s at
-// B=8 x 160x160 and 185-220 at B=32, against 120-156 / 154-179 for conv_bf16x3_kernel.  A producer/consumer variant that kept
-// fp32 tensors (producer waves doing the split, tools/exp/conv_bf16x3_ps.hip) measured NO gain over conv_bf16x3_kernel: the
-// split's ds_write traffic and VALU issue compete with the consumers either way; only removing them (x3 tensors + DMA) pays.
+// Measured on MI355X at the RDB shapes (tools/exp/x3s_abl.py; current variants in profiles/r02_b_x3s_ablation.txt, the staging
+// variants were measured while the kernel was built and are quoted in DESIGN.md section 5): the bare fragment-read + MFMA loop of
+// this tile shape tops out at 190-245 TFLOP/s; DMA issued by the compute waves costs 20-25 % of that (an LDS-DMA instruction
+// blocks its wave's issue for 60-185 cycles), dedicated loader waves give most of it back: 139-202 TFLOP/s at B=8 x 160x160 and
+// 185-220 at B=32, against 120-156 / 154-179 for conv_bf16x3_kernel.  A producer/consumer variant that kept fp32 tensors (producer
+// waves doing the split, tools/exp/kernels/conv_bf16x3_ps.hip) measured NO gain over conv_bf16x3_kernel: the split's ds_write
+// traffic and VALU issue compete with the consumers either way; only removing them (x3 tensors + DMA) pays.  The epilogue is
+// 6-11 % of the kernel; a second accumulator chain changes nothing (the single chain is not what idles the pipe).
 //
 // x3 tensor layout: [B][C/8][3 planes h,m,l][H][W][8] bf16, x = h + m + l EXACTLY (8+8+8 significant bits: a lossless 48-bit
 // encoding of an fp32 value); a 16-byte unit = 8 consecutive channels of one pixel = half of an MFMA B operand, so a 64-lane

@@ -251,6 +251,9 @@ def main():
     # warm-up, then ONE untimed ranking step that brackets EVERY launch with HIP events to rank the launch shapes; the timed region
     # then only brackets the launches of the top shapes (+ the inverse tail), keeping the host overhead negligible
     C1 = 12
+    # the HBM-bound "coupling inverse" kernel of level 1: the fused tail (Conv2dZeros 64->12 on 16-wide MFMA tiles + the whole
+    # pointwise chain of the step) by default, the pointwise-only kernel with BFSR_COUPLING=unfused
+    key_tail_fused = ("coupling_tail", 1, C1, B, H // 2, H // 2) if srflow else None
     key_tail = ("flow", 1, C1, B, H // 2, H // 2, True, True, True) if srflow else None
     for i in range(args.warmup):
         step(i)
@@ -271,7 +274,7 @@ def main():
         warm_total_ms += t
         fam = FAMILIES[k[0]][0] if k[0] in FAMILIES else k[0]
         warm_by_family[fam] = warm_by_family.get(fam, 0.0) + t
-    ops.profile_keys = set([k for _, k in ranked[:4]] + ([key_tail] if key_tail else []))
+    ops.profile_keys = set([k for _, k in ranked[:4]] + ([key_tail, key_tail_fused] if key_tail else []))
     ops.profile = {}
     bdist.barrier()
     torch.cuda.synchronize()
@@ -304,14 +307,21 @@ def main():
     by_symbol = [{"kernel": fam, "ms_per_step": round(t, 3), "share_of_event_time": round(t / warm_total_ms, 4)}
                  for fam, t in sorted(warm_by_family.items(), key=lambda kv: -kv[1])[:8]] if warm_total_ms else None
     roof_tail = None
-    if key_tail and ops.profile.get(key_tail):
-        ev = ops.profile[key_tail]
+    if key_tail and (ops.profile.get(key_tail_fused) or ops.profile.get(key_tail)):
+        fused = bool(ops.profile.get(key_tail_fused))
+        ev = ops.profile[key_tail_fused if fused else key_tail]
         tail_ms = sum(s.elapsed_time(e) for s, e in ev) / len(ev)
-        tail_bytes = 20.0 * C1 * B * (H // 2) * (H // 2)                 # read z,h_aff,h_ft + write z
+        px = B * (H // 2) * (H // 2)
+        # unfused: read z, h_aff, h_ft + write z = 20*C B/px.  fused: h_aff never exists in HBM; the kernel reads the 64
+        # hidden channels of the coupling net instead, + h_ft (2C) + z (C) and writes z (C) = 4*(64 + 4C) B/px
+        tail_bytes = (4.0 * (64 + 4 * C1) if fused else 20.0 * C1) * px
         a = tail_bytes / (tail_ms * 1e-3) / 1e9
-        roof_tail = {"bound": "hbm", "kernel": "flow_pointwise_kernel<12,4> reverse (level-1 FlowStep inverse tail)",
+        roof_tail = {"bound": "hbm",
+                     "kernel": ("coupling_tail_kernel<12> reverse: Conv2dZeros 64->12 (3xBF16 on 16-wide MFMA tiles) + level-1 FlowStep inverse tail, fused" if fused
+                                else "flow_pointwise_kernel<12,4> reverse (level-1 FlowStep inverse tail)"),
                      "achieved": round(a, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(a / PEAK_HBM_GBS, 4),
-                     "traffic": None, "algorithmic_bytes_per_launch": tail_bytes, "avg_launch_ms": round(tail_ms, 4), "launches": len(ev)}
+                     "traffic": (traffic_db.get(json.dumps(list(key_tail_fused if fused else key_tail))) or {}).get("hbm_bytes_per_launch"),
+                     "algorithmic_bytes_per_launch": tail_bytes, "avg_launch_ms": round(tail_ms, 4), "launches": len(ev)}
 
     # ---- config 2: the same workload with every contraction on the native fp32 MFMA, reported beside `value` --------------
     fp32_only = None

@@ -8,8 +8,11 @@
 //       the accumulator layout of stage 1 (lane = pixel; half-wave h holds channels (r&3)+8(r>>2)+4h) is already a valid B operand
 //       for the next GEMM if W2's K axis is packed in that order, so t1 never goes to LDS (no transposition, no barrier).
 //   bfsr_coupling_tail : h_aff = Conv2dZeros(hid) (64 -> 2*(C - C/2) channels); then the FlowStep's pointwise chain with h_aff
-//       taken from LDS instead of HBM.  The conv runs on v_mfma_f32_16x16x4_f32 (exact fp32, M = 16): Cout = 12 / 24 wastes 25 % of
-//       a 16-row tile instead of 62 % of the 32-row tiles of the generic kernels.  Tail semantics = bfsr_flow_pointwise:
+//       taken from LDS instead of HBM.  The conv runs on 16-row MFMA tiles (v_mfma_f32_16x16x32_bf16, exact 3-term bf16 split, six
+//       products): Cout = 12 / 24 wastes 25 % of a 16-row tile instead of 62 % of the 32-row tiles of the generic kernels.  (The
+//       first version used the native fp32 MFMA 16x16x4: 96 us of matrix time at 8 x 320 x 320, more than the kernel's HBM traffic
+//       takes; 183 -> 163 us per launch with the split form and the pointwise operands prefetched under the last K chunk.)
+//       Tail semantics = bfsr_flow_pointwise:
 //         reverse: z2 = z2/scale - shift; z = z/scaleFt - shiftFt; z = Winv z; z = z*exp(-logs) - bias          (this step)
 //         forward: z2 = (z2 + shift)*scale   (this step's self-conditional)   then, if given, the NEXT step's head:
 //                  z = (z + bias)*exp(logs); z = W z; z = (z + shiftFt)*scaleFt
@@ -40,22 +43,28 @@ __device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l)
 }
 
 // =====================================================================================================================
-// tail: conv3x3 64 -> CO2 = 2*(C - C/2) on 16x16x4 fp32 MFMA + pointwise chain.  8 waves, wave w = tile row w, 2 column
-// tiles of 16 pixels, MT = ceil(CO2/16) row tiles.  K walked 16 input channels per LDS stage (register-staged pipeline).
+// tail: conv3x3 64 -> CO2 = 2*(C - C/2) + pointwise chain.  8 waves, wave w = tile row w, 2 column tiles of 16 pixels, MT =
+// ceil(CO2/16) row tiles.  The conv runs as the exact 3-term bf16 split on v_mfma_f32_16x16x32_bf16 (six products per operand
+// pair, fp32 accumulation: fp32-accurate like conv_bf16x3.hip): the native fp32 MFMA (16x16x4) needs 96 us for this conv at
+// 8 x 320 x 320 -- more than the kernel's HBM traffic takes -- the split form 36 us.  K = 16 hidden channels per LDS stage; one
+// MFMA spans 32 k = TWO taps x 16 channels (lane group lq = lane>>4: tap 2*tp + (lq>>1), channel octet lq&1; the tenth tap is zero
+// weights), so a stage is 5 tap pairs.  hid is fp32 in HBM and split while it is staged: LDS input tile [plane][octet][pos][8],
+// weights [plane][tap pair][lq][MW][8] (packed by bfsr_pack_coupling_tail), both conflict-free ds_read_b128 operands.
 template <int C, int CIN>
-__global__ __launch_bounds__(512, 2) void coupling_tail_kernel(BfsrCouplingTailArgs p, int tiles_x, int tiles_xy)
+__global__ __launch_bounds__(512, 4) void coupling_tail_kernel(BfsrCouplingTailArgs p, int tiles_x, int tiles_xy)
 {
     constexpr int CN = C / 2, CC = C - CN, CO2 = 2 * CC, MT = (CO2 + 15) / 16, MW = MT * 16;
-    constexpr int CK = 16, NCHUNK = CIN / CK;
-    constexpr int WCH = CK * 9 * MW;                       // weight floats per chunk: [ch][tap][MW]
-    constexpr int PPT = (NPOS + 511) / 512;
-    constexpr int WV = (WCH / 4 + 511) / 512;
+    constexpr int CK = 16, NCHUNK = CIN / CK, TP = 5;
+    constexpr int IN_B = 3 * 2 * NPOS * 16;                // bytes of the split input stage
+    constexpr int W_B = 3 * TP * 4 * MW * 16;              // bytes of one chunk's weights
+    constexpr int NU = 2 * NPOS;                           // (octet, position) staging units per chunk
+    constexpr int PPT = (NU + 511) / 512;
+    constexpr int WV = (W_B / 16 + 511) / 512;
     static_assert(CIN % CK == 0, "hidden width must be a multiple of 16");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float* smem = reinterpret_cast<float*>(smem_raw);
-    float* sW = smem;                                      // [CK][9][MW]
-    float* sIn = smem + WCH;                               // [CK][NPOS]
-    float* sH = smem;                                      // after the K loop: h_aff [CO2][TH*TW]
+    unsigned char* sIn = smem_raw;                         // [3 planes][2 octets][NPOS][8] bf16
+    unsigned char* sW = smem_raw + IN_B;                   // [3 planes][TP][4][MW][8] bf16
+    float* sH = reinterpret_cast<float*>(smem_raw);        // after the K loop: h_aff [CO2][TH*TW]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,14 +77,16 @@ __global__ __launch_bounds__(512, 2) void coupling_tail_kernel(BfsrCouplingTailA
 
     const float* __restrict__ hid = p.hid + (long long)b * p.hid_bs;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hid), 0, (unsigned)((long long)CIN * HW * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (unsigned)(NCHUNK * WCH * 4), 0x00020000);
-    unsigned voff[PPT];
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (unsigned)(NCHUNK * W_B), 0x00020000);
+    unsigned voff[PPT];                                    // pixel byte offset of this thread's staging units
+    int uoct[PPT], upos[PPT];
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-        const int pos = tid + i * 512;
-        const int r = pos / PW, c = pos - r * PW;
+        const int u = tid + i * 512;
+        uoct[i] = u / NPOS; upos[i] = u - uoct[i] * NPOS;
+        const int r = upos[i] / PW, c = upos[i] - r * PW;
         const int gy = y0 + r - 1, gx = x0 + c - 1;
-        const bool ok = pos < NPOS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const bool ok = u < NU && gy >= 0 && gy < H && gx >= 0 && gx < W;
         voff[i] = ok ? (unsigned)(gy * W + gx) * 4u : OOB;
     }
     const unsigned cs_bytes = (unsigned)(HW * 4);
@@ -88,59 +99,81 @@ __global__ __launch_bounds__(512, 2) void coupling_tail_kernel(BfsrCouplingTailA
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[m][n][r] = 0.f;
 
-    float vin[PPT][CK];
-    float4 vw[WV];
+    float vin[PPT][8];
+    uint4 vw[WV];
     auto load_chunk = [&](int k) {
-        const unsigned sbase = (unsigned)(k * CK) * cs_bytes;
 #pragma unroll
-        for (int c = 0; c < CK; ++c)
+        for (int i = 0; i < PPT; ++i)
 #pragma unroll
-            for (int i = 0; i < PPT; ++i)
-                vin[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff[i], sbase + (unsigned)c * cs_bytes, 0));
+            for (int e = 0; e < 8; ++e)
+                vin[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff[i], (unsigned)(k * CK + uoct[i] * 8 + e) * cs_bytes, 0));
 #pragma unroll
         for (int i = 0; i < WV; ++i)
-            vw[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(tid + i * 512) * 16u, (unsigned)k * (WCH * 4), 0));
+            vw[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(tid + i * 512) * 16u, (unsigned)k * (unsigned)W_B, 0));
+    };
+    // per-lane LDS offsets: B = this lane group's octet and tap (dy*PW + dx added per tap pair), A = row l15 of k group lq
+    const unsigned char* bBase = sIn + ((lq & 1) * NPOS + wave * PW + l15) * 16;
+    const unsigned char* aBase = sW + (lq * MW + l15) * 16;
+    const int th = lq >> 1;
+    // operands of the pointwise chain (one thread per pixel, tid < TH*TW): z and the feature-conditional (shift, raw scale) pairs are
+    // loaded while the LAST K chunk is in the matrix pipe (the staging registers are free by then), not after the conv
+    const int py = y0 + (tid >> 5), px = x0 + (tid & 31);
+    const bool pw_on = tid < TH * TW && py < H && px < W;
+    const long long pix = (long long)py * W + px;
+    float x[C], fsh[C], fsr[C];
+    auto prefetch_pw = [&]() {
+        if (!pw_on) return;
+        const float* zi = p.z_in + (long long)b * p.z_in_bs + pix;
+#pragma unroll
+        for (int c = 0; c < C; ++c) x[c] = zi[(long long)c * HW];
+        if (p.h_ft) {
+            const float* hf = p.h_ft + (long long)b * p.h_ft_bs + pix;
+#pragma unroll
+            for (int c = 0; c < C; ++c) { fsh[c] = hf[(long long)(2 * c) * HW]; fsr[c] = hf[(long long)(2 * c + 1) * HW]; }
+        }
     };
     load_chunk(0);
     for (int k = 0; k < NCHUNK; ++k) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
-            const int pos = tid + i * 512;
-            if (i < PPT - 1 || pos < NPOS) {
+            if (i < PPT - 1 || tid + i * 512 < NU) {
+                bf16x8 h8, m8, l8;
 #pragma unroll
-                for (int c = 0; c < CK; ++c) sIn[c * NPOS + pos] = vin[i][c];
+                for (int e = 0; e < 8; ++e) { __bf16 h, m, l; split3(vin[i][e], h, m, l); h8[e] = h; m8[e] = m; l8[e] = l; }
+                unsigned char* dst = sIn + (uoct[i] * NPOS + upos[i]) * 16;
+                *reinterpret_cast<bf16x8*>(dst) = h8;
+                *reinterpret_cast<bf16x8*>(dst + 2 * NPOS * 16) = m8;
+                *reinterpret_cast<bf16x8*>(dst + 4 * NPOS * 16) = l8;
             }
         }
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
             const int idx = tid + i * 512;
-            if (i < WV - 1 || idx < WCH / 4) reinterpret_cast<float4*>(sW)[idx] = vw[i];
+            if (i < WV - 1 || idx < W_B / 16) reinterpret_cast<uint4*>(sW)[idx] = vw[i];
         }
         __syncthreads();
-        if (k + 1 < NCHUNK) load_chunk(k + 1);
-        // lane (l15, lq): A = weight row l15 of channel 4*ks + lq; B = pixel column l15 (+16 for the second tile) of that channel
+        if (k + 1 < NCHUNK) load_chunk(k + 1); else prefetch_pw();
 #pragma unroll
-        for (int ks = 0; ks < CK / 4; ++ks) {
-            const float* inC = sIn + (ks * 4 + lq) * NPOS + wave * PW + l15;
-            const float* wC = sW + (ks * 4 + lq) * 9 * MW + l15;
+        for (int tp = 0; tp < TP; ++tp) {
+            const int t0 = 2 * tp, t1 = 2 * tp + 1 < 9 ? 2 * tp + 1 : 8;          // the tenth tap has zero weights: any finite B will do
+            const int toff = th ? (t1 / 3) * PW + (t1 % 3) : (t0 / 3) * PW + (t0 % 3);
+            bf16x8 bf[3][2], af[3][MT];
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                float brow[2][3];
+            for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+                for (int n = 0; n < 2; ++n) bf[pl][n] = *reinterpret_cast<const bf16x8*>(bBase + pl * (2 * NPOS * 16) + (toff + n * 16) * 16);
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) brow[n][r] = inC[r * PW + n * 16 + dx];
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        const float a = wC[(dy * 3 + dx) * MW + m * 16];
-#pragma unroll
-                        for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, brow[n][dy], acc[m][n], 0, 0, 0);
-                    }
-                }
+                for (int m = 0; m < MT; ++m) af[pl][m] = *reinterpret_cast<const bf16x8*>(aBase + (pl * TP + tp) * (4 * MW * 16) + m * 256);
             }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+#define BFSR_T(PA_, PB_) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[PA_][m], bf[PB_][n], acc[m][n], 0, 0, 0);
+                    BFSR_T(2, 0) BFSR_T(0, 2) BFSR_T(1, 1) BFSR_T(1, 0) BFSR_T(0, 1) BFSR_T(0, 0)
+#undef BFSR_T
+                }
         }
     }
     __syncthreads();                                       // every wave is done with the last stage: LDS becomes the h_aff tile
@@ -159,26 +192,11 @@ __global__ __launch_bounds__(512, 2) void coupling_tail_kernel(BfsrCouplingTailA
     __syncthreads();
 
     // ---- pointwise chain, one thread per pixel (tile row = tid / 32): identical arithmetic to flow_pointwise_kernel
-    if (tid >= TH * TW) return;
-    const int py = y0 + (tid >> 5), px = x0 + (tid & 31);
-    if (py >= H || px >= W) return;
-    const long long pix = (long long)py * W + px;
+    if (!pw_on) return;
     const float eps = p.eps;
-    float x[C];
-    {
-        const float* zi = p.z_in + (long long)b * p.z_in_bs + pix;
-#pragma unroll
-        for (int c = 0; c < C; ++c) x[c] = zi[(long long)c * HW];
-    }
-    const float* hf = p.h_ft ? p.h_ft + (long long)b * p.h_ft_bs + pix : nullptr;
+    const bool hf = p.h_ft != nullptr;
     const float* ha = sH + tid;
     float* zo = p.z_out + (long long)b * p.z_out_bs + pix;
-    // feature-conditional (shift, raw scale) of every channel, loaded up front so that all 2C loads are in flight together
-    float fsh[C], fsr[C];
-    if (hf) {
-#pragma unroll
-        for (int c = 0; c < C; ++c) { fsh[c] = hf[(long long)(2 * c) * HW]; fsr[c] = hf[(long long)(2 * c + 1) * HW]; }
-    }
     if (p.reverse) {
 #pragma unroll
         for (int j = 0; j < CC; ++j) x[CN + j] = x[CN + j] / sigmoid_scale(ha[(2 * j + 1) * (TH * TW)], eps) - ha[(2 * j) * (TH * TW)];
@@ -226,7 +244,7 @@ template <int C, int CIN>
 int launch_tail(const BfsrCouplingTailArgs& a, hipStream_t st)
 {
     constexpr int CO2 = 2 * (C - C / 2), MW = (CO2 + 15) / 16 * 16;
-    constexpr int LDS_K = (16 * 9 * MW + 16 * NPOS) * 4, LDS_H = CO2 * TH * TW * 4;
+    constexpr int LDS_K = 3 * 2 * NPOS * 16 + 3 * 5 * 4 * MW * 16, LDS_H = CO2 * TH * TW * 4;
     constexpr int LDS = LDS_K > LDS_H ? LDS_K : LDS_H;
     static std::atomic<unsigned long long> lds_done{0};
     if (LDS > 65536 && bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&coupling_tail_kernel<C, CIN>), LDS, lds_done) != 0) return -1;
@@ -497,18 +515,35 @@ extern "C" int bfsr_pack_coupling_head(const float* w0, const float* w2, int Cz,
 extern "C" long long bfsr_coupling_tail_packed_size(int Cin, int Cout)
 {
     if (Cin <= 0 || (Cin & 15) || Cout <= 0) return -1;
-    return (long long)Cin * 9 * ((Cout + 15) / 16 * 16);        // floats
+    return (long long)(Cin / 16) * 3 * 5 * 4 * ((Cout + 15) / 16 * 16) * 8 / 2;        // floats (the buffer holds bf16 pairs)
 }
 
-// w [Cout][Cin][3][3] (Conv2dZeros weight) -> [Cin][tap][MW] fp32, rows zero padded to a multiple of 16
+// w [Cout][Cin][3][3] (Conv2dZeros weight) -> exact 3-term bf16 split, [16-channel chunk][plane][tap pair][k group lq][MW][8]:
+// k group lq holds tap 2*tp + (lq>>1) (the tenth tap = zeros) of channels chunk*16 + (lq&1)*8 + j; rows zero padded to MW
 extern "C" int bfsr_pack_coupling_tail(const float* w, int Cin, int Cout, float* packed)
 {
     if (!w || !packed || Cin <= 0 || (Cin & 15) || Cout <= 0) return -1;
     const int MW = (Cout + 15) / 16 * 16;
-    for (long long i = 0; i < (long long)Cin * 9 * MW; ++i) packed[i] = 0.f;
+    unsigned short* out = reinterpret_cast<unsigned short*>(packed);
+    const long long n = bfsr_coupling_tail_packed_size(Cin, Cout) * 2;
+    for (long long i = 0; i < n; ++i) out[i] = 0;
+    auto bits = [](float v) { unsigned u; __builtin_memcpy(&u, &v, 4); return u; };
+    auto rne = [&](float v) {                             // fp32 -> bf16 round-to-nearest-even, returned as fp32
+        unsigned u = bits(v);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        u &= 0xffff0000u;
+        float r; __builtin_memcpy(&r, &u, 4); return r;
+    };
     for (int co = 0; co < Cout; ++co)
         for (int ci = 0; ci < Cin; ++ci)
-            for (int t = 0; t < 9; ++t) packed[((long long)ci * 9 + t) * MW + co] = w[((long long)co * Cin + ci) * 9 + t];
+            for (int t = 0; t < 9; ++t) {
+                const float v = w[((long long)co * Cin + ci) * 9 + t];
+                const float h = rne(v), m = rne(v - h), l = rne((v - h) - m);
+                const float pl3[3] = {h, m, l};
+                const int chunk = ci / 16, oct = (ci % 16) / 8, j = ci % 8, tp = t / 2, lq = (t & 1) * 2 + oct;
+                for (int pl = 0; pl < 3; ++pl)
+                    out[((((long long)(chunk * 3 + pl) * 5 + tp) * 4 + lq) * MW + co) * 8 + j] = (unsigned short)(bits(pl3[pl]) >> 16);
+            }
     return 0;
 }
 

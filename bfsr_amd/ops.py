@@ -582,7 +582,7 @@ class HipOps(object):
         return hid
 
     def pack_coupling_tail(self, w4, bias, post_scale):
-        """fAffine.4 (Conv2dZeros) [Cout,64,3,3] for 16-row fp32 MFMA tiles + its bias and exp(3*logs)."""
+        """fAffine.4 (Conv2dZeros) [Cout,64,3,3] as 3-term bf16 planes for 16-row MFMA tiles + its bias and exp(3*logs)."""
         w = w4.detach().to("cpu", torch.float32).contiguous()
         Cout, Cin = w.shape[0], w.shape[1]
         n = self.lib.bfsr_coupling_tail_packed_size(Cin, Cout)

@@ -205,7 +205,7 @@ int bfsr_flow_pointwise(const BfsrFlowArgs* a, void* stream);
  *   bfsr_coupling_head: hid = relu(AN2(W2 . relu(AN0(conv3x3(z[:, :Cz]; W0z) + pre_aff))))     (fAffine.0 on the z1 rows + the hoisted
  *                       ft partial, fAffine.2; flow.Conv2d = conv without bias + ActNorm, flow.py:26-65); 3xBF16 arithmetic, the 1x1
  *                       chained in registers.  epi0 / epi2: [64][4] floats {ActNorm bias, exp(logs), 0, 0}.
- *   bfsr_coupling_tail: h_aff = (conv3x3(hid; W4) + b4) * exp(3*logs4)  (fAffine.4 = Conv2dZeros, flow.py:68-83) on 16-row fp32 MFMA
+ *   bfsr_coupling_tail: h_aff = (conv3x3(hid; W4) + b4) * exp(3*logs4)  (fAffine.4 = Conv2dZeros, flow.py:68-83) on 16-row MFMA tiles (exact 3-term bf16 split, fp32-accurate)
  *                       tiles, then the pointwise chain of bfsr_flow_pointwise with that h_aff (same argument meaning: h_ft, wmat,
  *                       an_bias / an_escale, reverse, eps; z_in and z_out may alias). */
 typedef struct BfsrCouplingHeadArgs {

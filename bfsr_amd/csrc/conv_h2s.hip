@@ -16,10 +16,14 @@
 // GEMM view per workgroup: M = 32 output channels, N = 16 rows x 32 pixels (compute wave w owns rows 2w, 2w+1: every weight
 // fragment feeds two MFMAs and the four input rows of a tap column feed six), K = 16 channels per chunk x 9 taps.
 // LDS stage = input [2 k halves][640 positions][8] (18 x 34 tile, padded to 10 x 64 positions) + weights [9 taps][2][32][8]
-// = 20 480 + 9 216 B; FOUR stages (118 784 B): a chunk is only 576 MFMA cycles per wave, shorter than an HBM round trip, so the
-// four dedicated loader waves run up to three chunks ahead (across tile boundaries) and park on `s_waitcnt vmcnt(N)` with N =
-// the pieces of the later stages.  One barrier per chunk; the eight compute waves issue nothing but ds_read_b128 + MFMA
-// (21 reads per 18 MFMAs: 58 % of the LDS read rate at full matrix rate).  Persistent workgroups, XCD-aware order.
+// = 20 480 + 9 216 B; FIVE stages (148 480 B): a chunk is only 576 MFMA cycles per wave, shorter than an HBM round trip, so the
+// four dedicated loader waves run three chunks ahead (across tile boundaries) and park on `s_waitcnt vmcnt(N)` with N = the
+// pieces of the later stages.  One barrier per chunk, passed by the compute waves one pipeline step EARLY (before the last tap
+// column of the previous chunk) so that, with a register double buffer of fragments, LDS latency never shows at chunk or tile
+// boundaries; the eight compute waves issue nothing but ds_read_b128 + MFMA (21 reads per 18 MFMAs: 58 % of the LDS read rate at
+// full matrix rate).  Persistent workgroups, XCD-aware order.  Measured (tools/exp/h2s_bench.py, profiles/r02_d_h2s_*.txt):
+// K loop alone 1.2-1.45 PFLOP/s, whole kernel 0.6-0.8 PFLOP/s and ~3.2 TB/s algorithmic at 128 x 128x128 -- the epilogue
+// (VALU-issue bound, all compute waves in it at once) is the remaining 35 %.
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "../../include/bfsr_hip.h"
@@ -37,16 +41,13 @@ constexpr int SUB = NPOSP * 16;                 // bytes of one k-half sub-image
 constexpr int IN_BYTES = 2 * SUB;               // 20 480
 constexpr unsigned OOB = 0x80000000u;
 
-// MT = 32-cout M tiles per workgroup (1: Cout <= 32, 2: wider -- the input fragments then feed twice the MFMAs and the input tile
-// is staged once for 64 output channels)
-template <int MT> struct Cfg {
-    static constexpr int W_BYTES = 9 * 2 * MT * 32 * 16;                 // weights of one chunk: [9 taps][2 k halves][MT*32][8] fp16
-    static constexpr int STAGE = IN_BYTES + W_BYTES;                     // 29 696 / 38 912
-    static constexpr int NS = MT == 1 ? 5 : 4;                           // LDS ring: 148 480 / 155 648 B
-    static constexpr int LDS_TOTAL = NS * STAGE;
-    static constexpr int NPIECE = 20 + W_BYTES / 1024;                   // 1-KiB LDS-DMA pieces per stage: 29 / 38
-    static constexpr int NJ = (NPIECE + NLW - 1) / NLW;
-};
+constexpr int MT = 1;                           // 32-cout M tiles per workgroup (the loops below are written for MT tiles; see the launcher for why 1)
+constexpr int W_BYTES = 9 * 1024;               // weights of one chunk: [9 taps][2 k halves][32 couts][8] fp16, one 1-KiB piece per tap
+constexpr int STAGE = IN_BYTES + W_BYTES;       // 29 696
+constexpr int NS = 5;                           // LDS ring: 148 480 B
+constexpr int LDS_TOTAL = NS * STAGE;
+constexpr int NPIECE = 20 + W_BYTES / 1024;     // 1-KiB LDS-DMA pieces per stage: 29
+constexpr int NJ = (NPIECE + NLW - 1) / NLW;
 
 struct Item { int cg, b, x0, y0; };
 
@@ -69,11 +70,8 @@ __device__ __forceinline__ void wait_vmcnt(int n)
 
 // abl = ablation switches, honoured only in -DBFSR_H2S_ABL builds (tools/exp/h2s_bench.py): 1 = no input DMA after the first
 // stages, 2 = no weight DMA after them, 4 = no ds_read/MFMA, 8 = no epilogue
-template <int MT>
 __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrConvX3Args p, int tiles_x, int tiles_y, int groups, int nitems, int abl)
 {
-    typedef Cfg<MT> CF;
-    constexpr int NS = CF::NS, STAGE = CF::STAGE, W_BYTES = CF::W_BYTES, NPIECE = CF::NPIECE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -125,7 +123,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
             unsigned char* base = smem + buf * STAGE;
             const unsigned wsoff = (unsigned)(cg_ * nchunk + k) * (unsigned)W_BYTES;
 #pragma unroll
-            for (int j = 0; j < CF::NJ; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int i = ld + j * NLW;
                 if (j < 5) {
                     if (skip & 1) continue;
@@ -423,10 +421,10 @@ inline unsigned short f32_to_f16_bits(float v)
 
 }  // namespace
 
-// M tiles per workgroup.  MT = 2 (64 couts per workgroup for the 192 -> 64 conv: one staging of the input tile instead of two) is
-// implemented by the kernel template but NOT used: its epilogue (64 accumulators + residual operands per lane) spills to scratch
-// and measured 1.05 ms against 0.61 ms for two 32-cout passes at 128 x 128x128 (tools/exp/h2s_bench.py).
-static inline int h2s_mtile(int Cout) { (void)Cout; return 1; }
+// Wider convs (192 -> 64) run as two 32-cout passes over the input tile.  A 64-cout workgroup tile (MT = 2: one staging of the input,
+// twice the MFMAs per input fragment) was built and measured SLOWER: 64 accumulators + the residual operands spill to scratch in the
+// epilogue -- 1.05 ms against 0.61 ms at 128 x 128x128 (tools/exp/h2s_bench.py).
+static inline int h2s_mtile(int Cout) { (void)Cout; return MT; }
 
 extern "C" long long bfsr_conv_packed_size_h2s(int Cout, int Cin)
 {
@@ -479,16 +477,10 @@ extern "C" int bfsr_conv3x3_h2s(const BfsrConvX3Args* a, void* stream)
 #ifdef BFSR_H2S_ABL
     abl = a->tune < 0 ? -a->tune : 0;
 #endif
-#define BFSR_LAUNCH(MT_)                                                                                                          \
-    {                                                                                                                             \
-        static std::atomic<unsigned long long> lds_done{0};                                                                       \
-        if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2s_kernel<MT_>), Cfg<MT_>::LDS_TOTAL, lds_done) != 0) return -1; \
-        hipLaunchKernelGGL(conv3x3_h2s_kernel<MT_>, dim3((unsigned)grid), dim3((NW + NLW) * 64), Cfg<MT_>::LDS_TOTAL, st, *a, tiles_x, tiles_y, \
-                           groups, (int)nitems, abl);                                                                             \
-        return (int)hipGetLastError();                                                                                            \
-    }
-    BFSR_LAUNCH(1)
-#undef BFSR_LAUNCH
+    static std::atomic<unsigned long long> lds_done{0};
+    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2s_kernel), LDS_TOTAL, lds_done) != 0) return -1;
+    hipLaunchKernelGGL(conv3x3_h2s_kernel, dim3((unsigned)grid), dim3((NW + NLW) * 64), LDS_TOTAL, st, *a, tiles_x, tiles_y, groups, (int)nitems, abl);
+    return (int)hipGetLastError();
 }
 
 extern "C" int bfsr_h2_pack(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int C, int H, int W, void* stream)

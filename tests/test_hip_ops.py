@@ -90,6 +90,26 @@ def test_conv_x3s_and_x3_tensors(hip, case, fp32_out):
     assert torch.equal(out, same), "conv_x3s differs from conv_x3"
 
 
+@pytest.mark.parametrize("cus", [1, 7, 40, 100, 255])
+def test_persistent_convs_are_independent_of_the_workgroup_count(hip, cus):
+    """conv_x3s / conv_h2s walk their tiles with one persistent workgroup per CU (`tune` overrides the count, as a partitioned
+    GPU would): every split of the tile list -- incl. the half-height tiles of a last partial round and a ring that wraps
+    across many tiles -- must give the same bits as the default launch."""
+    B, Cin, Cout, H, W = 2, 64, 40, 75, 70
+    x, w, b = rnd(61, B, Cin, H, W), rnd(62, Cout, Cin, 3, 3, scale=0.05), rnd(63, Cout, scale=0.3)
+    xd = hip.to_device(x)
+    x3 = hip.x3_pack(xd, hip.x3_empty(B, Cin, H, W))
+    pw, epi = hip.pack_conv_x3(w, 1), hip.pack_epilogue(Cout, bias=b)
+    ref = hip.conv_x3s(x3, pw, hip.x3_empty(B, Cout, H, W), epi=epi, act=2, slope=0.2).clone()
+    got = hip.conv_x3s(x3, pw, hip.x3_empty(B, Cout, H, W), epi=epi, act=2, slope=0.2, tune=cus)
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), "conv_x3s depends on the number of workgroups"
+    xh = hip.h2_pack(xd, hip.h2_empty(B, Cin, H, W))
+    ph = hip.pack_conv_h2s(w)
+    refh = hip.conv_h2s(xh, ph, hip.h2_empty(B, Cout, H, W), epi=epi, act=2, slope=0.2).clone()
+    goth = hip.conv_h2s(xh, ph, hip.h2_empty(B, Cout, H, W), epi=epi, act=2, slope=0.2, tune=cus)
+    assert torch.equal(goth.view(torch.int16), refh.view(torch.int16)), "conv_h2s depends on the number of workgroups"
+
+
 def test_conv_x3s_dense_block_views_and_residuals(hip):
     """The RDB pattern (RRDBNet_arch.py:39-45): octet-sliced views of one x3 block buffer, conv5 with `x5*0.2 + x` and the
     RRDB-level `*0.2 + x_rrdb`, all residuals x3."""

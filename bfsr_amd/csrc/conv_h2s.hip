@@ -265,6 +265,38 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("" : "+v"(lh), "+v"(lx));                           // INSIDE the tile loop (hoisted, it is spilled to scratch and reloaded here)
 #endif
+        const int gx = cur.x0 + lx;
+        int goff[MT][2][2];                                              // element offset of the group's hi octet inside a batch item (< 2^31, checked by the launcher), or -1
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int oct = (cur.cg * MT + m) * 4 + q * 2 + lh;
+                    const int gy = cur.y0 + 2 * wave + j;
+                    goff[m][j][q] = (gy < H && gx < W && oct * 8 < p.Cout) ? (int)(((long long)oct * 2 * HW + (long long)gy * W + gx) * 8) : -1;
+                }
+        // operands of the first residual: issued NOW, consumed after the parameter stage (their HBM round trip runs under the swaps,
+        // the bpermute exchange and the bias/activation arithmetic instead of in front of the adds)
+        half8 r1h[MT][2][2], r1l[MT][2][2];
+        if (p.res1) {
+            const unsigned short* rb = p.res1 + (long long)cur.b * p.res1_bs;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int g = goff[m][j][q];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { r1h[m][j][q][i] = (_Float16)0.f; r1l[m][j][q][i] = (_Float16)0.f; }
+                        if (g >= 0) {
+                            r1h[m][j][q] = *reinterpret_cast<const half8*>(rb + g);
+                            r1l[m][j][q] = *reinterpret_cast<const half8*>(rb + g + HW * 8);
+                        }
+                    }
+        }
         asm volatile("s_nop 11" ::: "memory");
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -279,13 +311,10 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
                         o[m][j][q][i] = lo;
                         o[m][j][q][4 + i] = hi;
                     }
-        const int gx = cur.x0 + lx;
-        int goff[MT][2][2];                                              // element offset of the group's hi octet inside a batch item (< 2^31, checked by the launcher), or -1
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int oct = (cur.cg * MT + m) * 4 + q * 2 + lh;
                 float e0[8], e1[8], e2[8], e3[8], e4[8];                 // every lane takes part in the exchange (before any divergence)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -296,8 +325,6 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int gy = cur.y0 + 2 * wave + j;
-                    goff[m][j][q] = (gy < H && gx < W && oct * 8 < p.Cout) ? (int)(((long long)oct * 2 * HW + (long long)gy * W + gx) * 8) : -1;
                     if (fast) {                                          // bias + (leaky) ReLU only: 3 VALU ops per channel instead of 8
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
@@ -342,7 +369,16 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        if (p.res1) add_res(p.res1, p.res1_bs, p.alpha1);
+        if (p.res1) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) o[m][j][q][i] = p.alpha1 * o[m][j][q][i] + ((float)r1h[m][j][q][i] + (float)r1l[m][j][q][i]);
+        }
         if (p.res2) add_res(p.res2, p.res2_bs, p.alpha2);
 #pragma unroll
         for (int m = 0; m < MT; ++m)

@@ -124,6 +124,32 @@ __global__ __launch_bounds__(256) void linf_flow_kernel(BfsrLinfFlowArgs a)
             for (int d = 0; d < D; ++d) base += -0.5f * (x[d] * x[d] + 1.8378770664093453f);
             a.log_p[(long long)b * NQ + q] = ld + base;
         }
+    } else if (a.reverse == 2) {
+        // vector-Jacobian product of the INVERSE flow w.r.t. its input z (the conditioning is fixed, so the inverse is affine in z):
+        // J = Winv_0 D_0 ... Winv_{L-1} D_{L-1} Winv_L with D_i = diag(1/scale_i)  =>  g_z = Winv_L^T D_{L-1} Winv_{L-1}^T ... D_0 Winv_0^T g.
+        // The caller passes lin_w[i] = Winv_i^T; biases and shifts do not enter.  (LINF-LP/train.py:143: the image-space loss of the
+        // latent module back-propagates through query_rgb into z_lr_learned.)
+        auto matvec = [&](int layer) {
+            const float* __restrict__ W = a.lin_w + (long long)layer * D * D;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < D; ++j) s = fmaf(W[i * D + j], x[j], s);
+                y[i] = s;
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d) x[d] = y[d];
+        };
+        for (int i = 0; i < L; ++i) {
+            matvec(i);
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const float sr = ai[(long long)(2 * D * i + d) * NQ];
+                x[d] = x[d] / (1.f / (1.f + expf(-(sr + 2.f))) + a.eps);
+            }
+        }
+        matvec(L);
     } else {
         linear(L, true);
         for (int i = L - 1; i >= 0; --i) {

@@ -89,7 +89,9 @@ class LINFEngine(object):
         W = torch.stack([sd[n + "._weight"] for n in names])
         self.lin_b = ops.vec(torch.stack([sd[n + ".bias"] for n in names]))
         self.lin_w = ops.vec(W)
-        self.lin_winv = ops.vec(torch.inverse(W.double()).float())
+        Winv = torch.inverse(W.double()).float()
+        self.lin_winv = ops.vec(Winv)
+        self.lin_winv_t = ops.vec(Winv.transpose(1, 2).contiguous())      # for the VJP of the inverse (query_rgb_vjp)
         self.logdet_const = float(sum(torch.slogdet(w.detach().cpu().float())[1] for w in W))     # NaiveLinear logabsdet, flow.py:66-70
         self._feat_key = self._feat = None
         self._cond_key = self._cond = None
@@ -154,6 +156,21 @@ class LINFEngine(object):
             return ops.grid_sample_add(inp, coord, p, ops.empty(B, 3, qh, qw))
         img = ops.empty(B, 3, self.ps * qh, self.ps * qw)
         return ops.patch_fold(p, img, self.ps)
+
+
+    def query_rgb_vjp(self, feat, coord, cell, grad_out):
+        """Vector-Jacobian product of `query_rgb` w.r.t. `zmap`: grad_out [B,3,H,W] (patch model: H, W <= ps*qh, ps*qw; the
+        cropped part gets zero gradient) or [B,3,qh,qw] (pixel-wise) -> grad_zmap [B,D,qh,qw].  The conditioning is independent of
+        z, so the inverse flow is affine in z and its backward is a transposed flow (LINF-LP/train.py:143: the image-space loss
+        of the latent module back-propagates through query_rgb); fold's adjoint is the zero-padded unfold."""
+        ops = self.ops
+        ai = self.affine_info(feat, coord, cell)
+        B, qh, qw, _ = coord.shape
+        if self.ps == 1:
+            gp = grad_out
+        else:
+            gp = ops.patch_unfold(grad_out, self.ws.get("flow_grad", B, self.D, qh, qw), self.ps)
+        return ops.linf_flow(gp, ai, ops.empty(B, self.D, qh, qw), self.lin_winv_t, self.lin_b, self.L, reverse=2)
 
 
 class LINFPriorEngine(object):

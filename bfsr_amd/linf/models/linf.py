@@ -78,6 +78,9 @@ class LINFPatch(nn.Module):
         return self.query_rgb(inp, self.gen_feat(inp), coord, cell, temperature, zmap)
 
     def forward(self, op, inp=None, feat=None, coord=None, cell=None, gt=None, temperature=0, zmap=None):
+        if op == "query_rgb" and zmap is not None and torch.is_grad_enabled() and zmap.requires_grad:
+            # latent-module training (LINF-LP/train.py:143): the frozen model's query_rgb is differentiable w.r.t. zmap
+            return _QueryRGB.apply(zmap, self, inp, feat, coord, cell)
         with torch.no_grad():
             if op == "query_log_p":
                 return self.query_log_p(inp, feat, coord, cell, gt)
@@ -90,6 +93,26 @@ class LINFPatch(nn.Module):
             if op == "gen_feat":
                 return self.gen_feat(inp)
         raise ValueError("unknown op %r" % (op,))
+
+
+class _QueryRGB(torch.autograd.Function):
+    """`query_rgb` with a backward into `zmap` only (the model is frozen while the latent module trains): forward = the HIP inverse
+    flow, backward = its transposed flow (engine.query_rgb_vjp)."""
+
+    @staticmethod
+    def forward(ctx, zmap, model, inp, feat, coord, cell):
+        e = model.engine()
+        d = e.ops.to_device
+        feat, coord, cell = d(feat.detach()), d(coord), d(cell)
+        ctx.model, ctx.saved = model, (feat, coord, cell)
+        return e.query_rgb(feat, coord, cell, d(zmap.detach()), inp=None if inp is None else d(inp.detach()))
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        e = ctx.model.engine()
+        feat, coord, cell = ctx.saved
+        gz = e.query_rgb_vjp(feat, coord, cell, e.ops.to_device(grad_out.contiguous()))
+        return gz, None, None, None, None, None
 
 
 @register('linf')

@@ -789,8 +789,10 @@ class HipOps(object):
         a.y, a.y_bs, _, _, _ = _view(y, "linf_flow.y")
         assert ca == 2 * D * layers and lin_w.numel() == (layers + 1) * D * D and lin_b.numel() == (layers + 1) * D
         a.lin_w, a.lin_b = lin_w.data_ptr(), lin_b.data_ptr()
-        a.B, a.D, a.layers, a.qh, a.qw, a.reverse, a.eps = x.shape[0], D, layers, qh, qw, int(bool(reverse)), eps
-        key = ("linf_flow", int(bool(reverse)), D, x.shape[0], qh, qw)
+        mode = int(reverse)                      # 0 forward, 1 (True) inverse, 2 = VJP of the inverse w.r.t. its input
+        assert mode in (0, 1, 2)
+        a.B, a.D, a.layers, a.qh, a.qw, a.reverse, a.eps = x.shape[0], D, layers, qh, qw, mode, eps
+        key = ("linf_flow", mode, D, x.shape[0], qh, qw)
         _lib.check(self._launch(key, lambda: self.lib.bfsr_linf_flow(C.byref(a), self._stream())), "linf_flow(D=%d)" % D)
         return y
 

@@ -317,7 +317,9 @@ int bfsr_pack_linf_mlp(const float* w1, const float* w2, const float* w3, const 
 
 /* local implicit coupling flow (LINF-LP/models/flow.py:44-63) over D = 3*ps*ps vectors on the query grid:
  * x,y [B,D,qh,qw]; ai = affine_info [B, 2*D*layers, qh, qw]; lin_w [layers+1][D][D] holds W (forward) or
- * inv(W) (reverse, precomputed by the caller), lin_b [layers+1][D]; last entry = `last` linear. */
+ * inv(W) (reverse, precomputed by the caller), lin_b [layers+1][D]; last entry = `last` linear.
+ * reverse: 0 = forward, 1 = inverse, 2 = vector-Jacobian product of the inverse w.r.t. its input (x = upstream gradient
+ * [B,D,qh,qw], lin_w[i] = inv(W_i)^T, lin_b unused): the backward of query_rgb into the latent (LINF-LP/train.py:143). */
 typedef struct BfsrLinfFlowArgs {
     const float* x; long long x_bs;
     const float* ai; long long ai_bs;

@@ -442,6 +442,10 @@ class CpuOps(object):
             v = F.linear(v, Wm[layers], bb[layers])
             if log_p is not None:
                 log_p.copy_((ld + (-0.5 * (v ** 2 + float(np.log(2 * np.pi)))).sum(-1)).reshape(log_p.shape))
+        elif int(reverse) == 2:        # VJP of the inverse w.r.t. its input: Wm[i] = inv(W_i)^T, no biases / shifts
+            for i in range(layers):
+                v = F.linear(v, Wm[i]) / sc(i)
+            v = F.linear(v, Wm[layers])
         else:
             v = F.linear(v - bb[layers], Wm[layers])
             for i in reversed(range(layers)):

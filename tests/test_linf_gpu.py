@@ -304,3 +304,88 @@ def test_query_log_p_values_golden(hip, golden_dir):
     log_p, z, ref_lp, ref_z = _logp_case(golden_dir, hip)
     close(z, ref_z, 1e-4, "z")
     assert ((log_p.cpu() - ref_lp).abs() / ref_lp.abs().clamp_min(1.0)).max() <= 1e-5
+
+
+def test_linf_flow_vjp_of_inverse(hip):
+    """linf_flow mode 2 = vector-Jacobian product of the inverse flow w.r.t. its input, against torch.autograd through the fp32
+    torch semantics of the inverse (cpu_ops.linf_flow)."""
+    D, L, B, qh, qw = 27, 10, 2, 13, 17
+    q = np.stack([np.linalg.qr(np.random.Generator(np.random.PCG64(i)).standard_normal((D, D)))[0] for i in range(L + 1)])
+    Wm = torch.from_numpy(q.astype(np.float32)) * torch.from_numpy(np.random.Generator(np.random.PCG64(5)).uniform(0.8, 1.25, (L + 1, 1, D)).astype(np.float32))
+    Winv = torch.inverse(Wm.double()).float()
+    bb, ai, gy = rnd(6, L + 1, D, scale=0.1), rnd(7, B, 2 * D * L, qh, qw), rnd(8, B, D, qh, qw)
+    with torch.enable_grad():
+        z = rnd(9, B, D, qh, qw).requires_grad_(True)
+        v = z.permute(0, 2, 3, 1).reshape(-1, D)
+        a = ai.permute(0, 2, 3, 1).reshape(-1, 2 * D * L)
+        v = torch.nn.functional.linear(v - bb[L], Winv[L])
+        for i in reversed(range(L)):
+            v = (v - a[:, 2 * D * i + D: 2 * D * (i + 1)]) / (torch.sigmoid(a[:, 2 * D * i: 2 * D * i + D] + 2.0) + 1e-4)
+            v = torch.nn.functional.linear(v - bb[i], Winv[i])
+        (v.reshape(B, qh, qw, D).permute(0, 3, 1, 2) * gy).sum().backward()
+    out = hip.linf_flow(hip.to_device(gy), hip.to_device(ai), hip.empty(B, D, qh, qw), hip.vec(Winv.transpose(1, 2).contiguous()), hip.vec(bb), L, reverse=2)
+    close(out, z.grad, 1e-5, "linf_flow vjp")
+    close(CPU.linf_flow(gy, ai, torch.empty(B, D, qh, qw), Winv.transpose(1, 2).contiguous().reshape(-1), bb.reshape(-1), L, 2), z.grad, 1e-5, "cpu double vjp")
+
+
+def test_query_rgb_backward_vs_reference_autograd(hip, golden_dir):
+    """f4, the hot-path part of latent-module training: d/dzmap of the frozen model's query_rgb
+    (LINF-LP/train.py:143) on the HIP path against the genuine reference's autograd gradient (tests/golden/linf_vjp.npz)."""
+    from bfsr_amd.linf.models import make
+    g = np.load(os.path.join(golden_dir, "linf_vjp.npz"))
+    sd, _ = weights("edsr-baseline", int(g["weights_seed"]))
+    m = make(mspec("edsr-baseline"), args={"ops": hip}).eval()
+    m.load_state_dict(sd)
+    inp = hip.to_device((T(g["lr"]) - 0.5) / 0.5)
+    coord, cell = hip.to_device(T(g["coord"])), hip.to_device(T(g["cell"]))
+    feat = m("gen_feat", inp=inp)
+    with torch.enable_grad():
+        z = hip.to_device(T(g["zmap"])).clone().requires_grad_(True)
+        pred = m("query_rgb", inp=inp, feat=feat, coord=coord, cell=cell, zmap=z)
+        (pred * hip.to_device(T(g["cotangent"]))).sum().backward()
+    close(pred, T(g["pred"]), 1e-4, "query_rgb forward")
+    close(z.grad, T(g["grad_z"]), 1e-5, "d query_rgb / d zmap")
+
+
+def test_latent_module_train_step_gradients_vs_oracle(hip, golden_dir):
+    """linf/train.py::train_step on the HIP path (frozen model on the kernels, a small torch latent module on the GPU): loss and
+    parameter gradients against the same objective written on the oracle under CPU autograd (LINF-LP/train.py:118-160)."""
+    import oracle.linf_ref as O
+    import torch.nn.functional as F
+    from bfsr_amd.linf.models import make
+    from bfsr_amd.linf.train import train_step
+    g = np.load(os.path.join(golden_dir, "linf_vjp.npz"))
+    sd, _ = weights("edsr-baseline", int(g["weights_seed"]))
+    m = make(mspec("edsr-baseline"), args={"ops": hip}).eval()
+    m.load_state_dict(sd)
+    lr, coord, cell = T(g["lr"]), T(g["coord"]), T(g["cell"])
+    H, W = 48, 40
+    prep = O.batch_prep(lr, (H, W))
+    gt = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(3))
+    batch = dict(inp=lr, gt=gt, coord=coord, cell=cell, gt_lr_up=prep["gt_lr_up"], gt_patch=prep["gt_lr_up"] * 0.5 + 0.1)
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(11)
+            self.c = torch.nn.Conv2d(27, 27, 3, padding=1)
+
+        def forward(self, z, inp):
+            return z + 0.1 * self.c(z)
+
+    prior = Tiny().to(hip.device)
+    out = train_step(prior, m, batch, optimizer=None, latent_weight=0.7, image_weight=1.3)
+    ref_prior = Tiny()
+    espec = mspec("edsr-baseline")["args"]["encoder_spec"]
+    inp = (lr - 0.5) / 0.5
+    feat = O.encoder(inp, sd, espec)
+    z_lr, z_hr = O.query_log_p(feat, coord, cell, batch["gt_lr_up"], sd), O.query_log_p(feat, coord, cell, batch["gt_patch"], sd)
+    with torch.enable_grad():
+        zl = ref_prior(z_lr, inp)
+        pred = O.query_rgb(feat, coord, cell, zl, sd)[..., :H, :W] + F.interpolate(inp, (H, W), mode="bilinear", align_corners=False)
+        loss = 1.3 * F.l1_loss(torch.clamp(pred * 0.5 + 0.5, 0, 1), gt) + 0.7 * F.l1_loss(zl, z_hr)
+        loss.backward()
+    assert abs(out["loss"] - float(loss)) <= 1e-4 * max(1.0, abs(float(loss)))
+    for a, b in zip(prior.parameters(), ref_prior.parameters()):
+        err, ref = (a.grad.cpu() - b.grad).abs().max().item(), b.grad.abs().max().item()
+        assert ref > 0 and err <= 1e-3 * ref, "latent-module parameter gradient: %.3e of %.3e" % (err, ref)

@@ -27,6 +27,9 @@ def train_step(prior_model, linf_model, batch, optimizer=None, latent_weight=1.0
                           gt=d(batch["gt_patch" if patch else "gt_pixel"]))[1]    # train.py:131/135
     with torch.enable_grad():
         z_learned = prior_model(z_lr.detach().contiguous(), inp)                  # train.py:137-138
+        if not z_learned.requires_grad:
+            raise RuntimeError("train_step: prior_model returned a tensor without a graph -- the latent module must be a trainable "
+                               "torch.nn.Module (the engine-backed `unet` of this package is inference-only)")
         latent_l = F.l1_loss(z_learned, z_hr.detach()) if latent_weight > 0 else z_learned.new_zeros(())      # train.py:146
         image_l = z_learned.new_zeros(())
         if image_weight > 0:

@@ -24,7 +24,7 @@ from .. import rng
 from .options import opt_get
 from ..ops import ACT_LRELU, ACT_NONE, ACT_RELU, MODE_BILINEAR, MODE_BILINEAR_AC, MODE_NEAREST
 
-FUSED_COUPLING_C = tuple(int(v) for v in os.environ.get("BFSR_COUPLING_C", "12").split(",") if v)
+FUSED_COUPLING_C = tuple(int(v) for v in os.environ.get("BFSR_COUPLING_C", "12,24").split(",") if v)
 # fea_up{k} lives at LR resolution * 2^shift
 _KEY_SHIFT = {"fea_up0": -1, "fea_up1": 0, "fea_up2": 1, "fea_up4": 2, "fea_up8": 3}
 

@@ -443,8 +443,8 @@ extern "C" int bfsr_conv3x3_x3s(const BfsrConvX3Args* a, void* stream)
     const long long nitems = (long long)tiles_x * tiles_y * groups * a->B;
     if (nitems > 0x7fffffffLL) return -1;
     if ((long long)groups * (a->Cin / 16) * W_BYTES >= (1LL << 32)) return -1;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int cus = bfsr::cu_count();                             // cached per device; no silent default
+    if (cus <= 0) return -1;
     if (a->tune > 0) cus = a->tune;
     long long grid = nitems < cus ? nitems : cus;          // one persistent workgroup per CU
     long long n_full = nitems, n_items = nitems;

@@ -446,8 +446,8 @@ int launch_head(const BfsrCouplingHeadArgs& a, hipStream_t st)
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
     const long long ntiles = (long long)tiles_x * tiles_y * a.B;
     if (ntiles <= 0 || ntiles > 0x7fffffffLL) return -1;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int cus = bfsr::cu_count();                             // cached per device; no silent default
+    if (cus <= 0) return -1;
     const long long grid = ntiles < cus ? ntiles : cus;     // one persistent workgroup per CU
     hipLaunchKernelGGL(coupling_head_kernel<NO>, dim3((unsigned)grid), dim3(512), LDS, st, a, tiles_x, tiles_x * tiles_y, (int)ntiles);
     return (int)hipGetLastError();

@@ -19,6 +19,25 @@ inline int ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<unsigne
     return 0;
 }
 
+// Compute-unit count of the CURRENT device, queried once per device (the persistent kernels size their grids with it on every
+// launch: hundreds of RDB convs per step).  Returns -1 if the runtime cannot tell -- the caller fails the launch instead of
+// guessing a grid.
+inline int cu_count()
+{
+    static std::atomic<int> cache[64];              // zero-initialised; 0 = not queried yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (dev < 0 || dev >= 64) {                     // beyond the cache: ask every time
+        int n = 0;
+        return hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0 ? n : -1;
+    }
+    int n = cache[dev].load(std::memory_order_acquire);
+    if (n > 0) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return -1;
+    cache[dev].store(n, std::memory_order_release);
+    return n;
+}
+
 // XCD-aware workgroup order (MI355X: block b runs on XCD b % 8, each XCD has a private L2): returns the logical work index of
 // hardware block `bid` such that every XCD walks one CONTIGUOUS range of logical indices -- neighbouring tiles (shared halo
 // rows, the cout groups of one input tile) then hit the same L2.  Bijective for any grid size.

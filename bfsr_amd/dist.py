@@ -10,12 +10,17 @@ import torch
 import torch.distributed as dist
 
 
-def init(backend=None):
-    """Initialise from the torchrun environment; returns (rank, world_size, local_rank)."""
+def init(backend=None, force=None):
+    """Initialise from the torchrun environment; returns (rank, world_size, local_rank).  A single process does not need a process
+    group and gets none -- unless `force` (or BFSR_DIST_FORCE=1) asks for one: then even world_size 1 goes through
+    `init_process_group` and every gather below runs the real collective (RCCL on a GPU box), which is how the nccl code path is
+    exercised on the 1-GPU boxes of the test pool (tests/test_dist_rccl.py)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if force is None:
+        force = os.environ.get("BFSR_DIST_FORCE", "0") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -41,7 +46,7 @@ def shard(batch, rank, world):
 def all_gather_batch(local_out, total=None):
     """All-gather per-rank outputs along dim 0.  Equal shards use one all_gather_into_tensor (a single
     RCCL collective); ragged shards are padded to the largest shard."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return local_out
     world = dist.get_world_size()
     n_local = torch.tensor([local_out.shape[0]], device=local_out.device, dtype=torch.long)
@@ -61,43 +66,52 @@ def all_gather_batch(local_out, total=None):
 
 
 class AsyncGatherer(object):
-    """Double-buffered all-gather of the per-step outputs: `submit(out_i)` starts the collective for
-    step i without blocking the compute stream, so the gather of step i runs over xGMI while step i+1 computes; it first
-    completes the gather of step i-1 (two output buffers alternate).  `finish()` completes whatever is in flight and returns
-    the last gathered batch.  The collective is RCCL's all_gather_into_tensor on its own internal stream (`async_op=True`);
-    the local output is kept referenced until its gather has completed, so the caching allocator cannot recycle it early.
-    With one process (world 1) it degenerates to returning the local output."""
+    """Double-buffered all-gather of the per-step outputs.
+
+    `submit(out_i)` starts the collective for step i without blocking the compute stream, so the gather of step i runs over xGMI
+    while step i+1 computes.  It first completes the gather of step i-1 and RETURNS it (None on the first call); `finish()`
+    completes whatever is in flight and returns the last gathered batch.  `.last` is always the most recently COMPLETED gather,
+    i.e. after `submit(i)` it is step i-1 on every path (equal and ragged shards alike).
+
+    Buffer lifetime: the tensor returned for step i is one of two internal buffers and is overwritten by `submit(i+2)`; clone it
+    to keep it longer.  The local output is kept referenced until its gather has completed, so the caching allocator cannot
+    recycle it early.  The collective is RCCL's all_gather_into_tensor on its own internal stream (`async_op=True`);
+    `work.wait()` orders the CURRENT stream after it without a host sync.  Without a process group it degenerates to handing
+    the local output back one step late (the same contract)."""
 
     def __init__(self, total):
         self.total, self.bufs, self.pending, self.n, self.last = total, [None, None], None, 0, None
 
     def submit(self, local_out):
-        if not dist.is_initialized() or dist.get_world_size() == 1:
-            self.last = local_out
-            return
-        self._complete()
+        prev = self._complete()
+        if not dist.is_initialized():
+            self.pending = (None, local_out, None)
+            return prev
         world = dist.get_world_size()
         if self.total % world != 0 or local_out.shape[0] * world != self.total:
-            self.last = all_gather_batch(local_out, total=self.total)          # ragged shards: synchronous path
-            return
+            # ragged shards: synchronous padded gather, surfaced one step late like the asynchronous path
+            self.pending = (None, all_gather_batch(local_out, total=self.total), None)
+            return prev
         i = self.n & 1
         shape = (self.total,) + tuple(local_out.shape[1:])
-        if self.bufs[i] is None or tuple(self.bufs[i].shape) != shape:
+        if self.bufs[i] is None or tuple(self.bufs[i].shape) != shape or self.bufs[i].device != local_out.device:
             self.bufs[i] = local_out.new_empty(shape)
         src = local_out.contiguous()
         work = dist.all_gather_into_tensor(self.bufs[i], src, async_op=True)
         self.pending = (work, self.bufs[i], src)
         self.n += 1
+        return prev
 
     def _complete(self):
         if self.pending is not None:
             work, buf, _src = self.pending
-            work.wait()                     # orders the current stream after the collective
+            if work is not None:
+                work.wait()                 # orders the current stream after the collective
             self.last, self.pending = buf, None
+        return self.last
 
     def finish(self):
-        self._complete()
-        return self.last
+        return self._complete()
 
 
 def barrier():

@@ -13,7 +13,8 @@ import torch.nn.functional as F
 
 def train_step(prior_model, linf_model, batch, optimizer=None, latent_weight=1.0, image_weight=0.0, feat_fn=None, patch=True):
     """One iteration of train.py:118-160 on a batch dict (inp, gt, coord, cell, gt_lr_up, gt_patch | gt_pixel, [interpolate_coord]),
-    tensors in the reference's normalisation (inp, gt in [0,1]; sub = div = 0.5).  Returns dict(loss, latent, image) of floats;
+    tensors in the reference's normalisation (inp, gt in [0,1]; sub = div = 0.5).  `image_weight` / `feat_fn` are train.py's
+    `vgg_weight` / `vgg`.  Returns dict(loss, latent, image) of floats;
     with `optimizer` the step is applied."""
     eng = linf_model.engine()
     d = eng.ops.to_device
@@ -35,9 +36,21 @@ def train_step(prior_model, linf_model, batch, optimizer=None, latent_weight=1.0
         if image_weight > 0:
             pred = linf_model("query_rgb", inp=inp, feat=feat, coord=coord, cell=cell, zmap=z_learned)           # train.py:152
             gt = d(batch["gt"])
-            if patch:                                                             # train.py:154-155: + bilinear LR skip
+            if patch:
                 H, W = gt.shape[-2:]
-                pred = pred[..., :H, :W] + F.interpolate(inp, (H, W), mode="bilinear", align_corners=False)
+                if "interpolate_coord" in batch:
+                    # train.py:154: + F.grid_sample(inp, interpolate_coord.flip(-1), bilinear, border) -- the LR image sampled at
+                    # the coordinates of the random out_size x out_size HR sub-crop the training wrapper cut (wrappers.py:741-783).
+                    # `inp` carries no graph, so the skip runs on the resampling kernel outside autograd.
+                    ic = d(batch["interpolate_coord"]).contiguous()
+                    assert tuple(ic.shape[1:3]) == tuple(pred.shape[-2:]), "interpolate_coord must cover the folded prediction"
+                    with torch.no_grad():
+                        skip = eng.ops.grid_sample_add(inp, ic, torch.zeros_like(pred), torch.empty_like(pred))
+                    pred = pred + skip
+                else:
+                    # full-image batches of the eval wrapper (no sub-crop): the same skip is the plain bilinear resize of
+                    # LINF-LP/test.py:171; the reference's train() itself always receives interpolate_coord
+                    pred = pred[..., :H, :W] + F.interpolate(inp, (H, W), mode="bilinear", align_corners=False)
             img = torch.clamp(pred * 0.5 + 0.5, 0, 1)
             f = feat_fn if feat_fn is not None else (lambda t: t)
             image_l = F.l1_loss(f(img), f(gt))                                    # train.py:155/157 with vgg := feat_fn

@@ -17,6 +17,8 @@ class Measure(object):
         a, b = f(imgA), f(imgB)
         s = ops.sqdiff_sum(a, b, shave=0, luma=False, rgb_range=1.0)          # float64 sum of squared differences
         mse = float(s.sum()) / a.numel()
+        if mse == 0.0:                      # identical images: skimage's peak_signal_noise_ratio returns inf (divide warning), not an error
+            return float("inf")
         return float(10.0 * np.log10(255.0 ** 2 / mse))
 
     def measure(self, imgA, imgB):

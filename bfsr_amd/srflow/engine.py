@@ -271,8 +271,9 @@ class SRFlowEngine(object):
                     # levels with 12 / 24 flow channels: the whole sequential part of the step as two kernels (coupling.hip):
                     # 3xBF16 head (3x3 on z1 + hoisted partial, 1x1 chained in registers) and a 16-row-tile Conv2dZeros with
                     # the pointwise chain as its tail.  BFSR_COUPLING=unfused keeps the four generic launches.
-                    # (measured without side-stream overlap, per step at BASELINE config 2: C = 12 @ 8x320^2: 467 -> 363 us;
-                    #  C = 24 @ 8x160^2: 200 -> 219 us, i.e. no gain on the smaller planes -> fused at the 12-channel level only)
+                    # (measured without side-stream overlap, per step at BASELINE config 2: C = 12 @ 8x320^2: 467 -> 350 us;
+                    #  C = 24 @ 8x160^2 was slower, 200 -> 219 us, while the tail's conv ran on the fp32 MFMA; with the 3xBF16
+                    #  tail it is 0.6-1.0 ms faster per cfg2 step, A/B on one box -> FUSED_COUPLING_C = (12, 24))
                     st.fused = (C in FUSED_COUPLING_C and w0.shape[0] == 64 and hasattr(ops, "coupling_head")
                                 and getattr(ops, "conv_mode", "f32") == "x3" and os.environ.get("BFSR_COUPLING", "fused") != "unfused")
                     if st.fused:

@@ -50,6 +50,50 @@ def test_shard_allgather_world2(total):
     assert sum(s[0] for _, _, s in res) == total
 
 
+def _gatherer_worker(rank, world, port, total, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from bfsr_amd import dist as bdist
+    r, w, _ = bdist.init(backend="gloo")
+    fulls = [torch.arange(total * 4, dtype=torch.float32).view(total, 4) + 100 * s for s in range(4)]
+    gat = bdist.AsyncGatherer(total)
+    ok = True
+    kept = []
+    for s, full in enumerate(fulls):
+        prev = gat.submit(bdist.shard(full, r, w).contiguous())
+        # contract: submit(s) returns (and .last holds) the completed gather of step s-1 -- on the ragged path as well
+        ok &= (prev is None) if s == 0 else (prev is gat.last and torch.equal(prev, fulls[s - 1]))
+        kept.append(prev)
+    last = gat.finish()
+    ok &= torch.equal(last, fulls[-1]) and gat.finish() is last
+    bdist.barrier()
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [8, 5])
+def test_async_gatherer_contract_world2(total):
+    """AsyncGatherer over equal (8) and ragged (5) shards: every submit hands back the previous step's gathered batch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_gatherer_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(60)
+    assert all(ok for _, ok in res)
+
+
+def test_async_gatherer_without_process_group():
+    from bfsr_amd.dist import AsyncGatherer
+    gat = AsyncGatherer(2)
+    a, b = torch.ones(2, 3), torch.zeros(2, 3)
+    assert gat.submit(a) is None and gat.submit(b) is a and gat.last is a and gat.finish() is b
+
+
 def test_shard_bounds_cover_everything():
     from bfsr_amd.dist import shard_bounds
     for n in (1, 7, 8, 64, 129):
@@ -96,9 +140,9 @@ def _pipeline_worker_body(rank, world, port, q):
     got = []
     for s in range(2):
         mine = bdist.shard(fulls[s], r, w).contiguous()
-        gat.submit(lp_infer(m, prior, mine))
+        prev = gat.submit(lp_infer(m, prior, mine))                          # returns the completed gather of step s-1
         if s > 0:
-            got.append(gat.last.clone())                                     # submit(s) completed the gather of step s-1
+            got.append(prev.clone())
     got.append(gat.finish().clone())
     for s in range(2):
         errs.append(float((got[s] - refs[s]).abs().max()))

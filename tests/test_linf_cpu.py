@@ -324,3 +324,87 @@ def test_latent_module_train_step_on_cpu_double(golden_dir):
     assert abs(out["loss"] - float(loss)) <= 1e-5 * max(1.0, abs(float(loss)))
     for a, b in zip(got, [p.grad for p in ref_prior.parameters()]):
         assert (a - b).abs().max() <= 1e-5 * max(1e-3, b.abs().max()), (a - b).abs().max()
+
+
+# ---- the training iteration itself, pinned to the genuine reference's train() (tests/golden/make_golden_train.py) ----------------
+class TrainTiny(torch.nn.Module):
+    """the latent module of linf_train_step.npz (make_golden_train.py::Tiny), weights from the fixture"""
+
+    def __init__(self, g):
+        super().__init__()
+        self.c = torch.nn.Conv2d(27, 27, 3, padding=1)
+        self.i = torch.nn.Conv2d(3, 27, 1)
+        with torch.no_grad():
+            for n, prm in self.named_parameters():
+                prm.copy_(T(g["prior." + n]))
+
+    def forward(self, z, inp):
+        import torch.nn.functional as F
+        return z + 0.1 * self.c(z) + 0.05 * self.i(F.interpolate(inp, z.shape[-2:], mode="bilinear", align_corners=False))
+
+
+class TrainFeat(torch.nn.Module):
+    """the fixed 2-layer conv that stands in for VGG19 in linf_train_step.npz"""
+
+    def __init__(self, g):
+        super().__init__()
+        self.a = torch.nn.Conv2d(3, 8, 3, padding=1)
+        self.b = torch.nn.Conv2d(8, 8, 3, padding=1)
+        with torch.no_grad():
+            for n, prm in self.named_parameters():
+                prm.copy_(T(g["feat." + n]))
+        for prm in self.parameters():
+            prm.requires_grad_(False)
+
+    def forward(self, x):
+        return self.b(torch.relu(self.a(x)))
+
+
+def run_train_step_case(golden_dir, ops, device="cpu"):
+    """train_step on `ops` for the fixture batch -> (result dict, latent module, fixture)."""
+    from bfsr_amd.linf.train import train_step
+    g = np.load(os.path.join(golden_dir, "linf_train_step.npz"))
+    sd, _ = weights("edsr-baseline", int(g["weights_seed"]))
+    m = make(mspec("edsr-baseline"), args={"ops": ops}).eval()
+    m.load_state_dict(sd)
+    batch = {k: T(g[k]) for k in ("inp", "coord", "cell", "gt", "gt_patch", "gt_lr_up", "interpolate_coord")}
+    prior, feat = TrainTiny(g).to(device), TrainFeat(g).to(device)
+    out = train_step(prior, m, batch, optimizer=None, latent_weight=float(g["latent_weight"]), image_weight=float(g["vgg_weight"]),
+                     feat_fn=feat, patch=True)
+    return out, prior, g
+
+
+def check_train_step(out, prior, g, loss_tol, grad_tol):
+    assert abs(out["image"] - float(g["vgg_loss"])) <= loss_tol * max(1.0, abs(float(g["vgg_loss"]))), (out, float(g["vgg_loss"]))
+    assert abs(out["latent"] - float(g["latent_loss"])) <= loss_tol * max(1.0, abs(float(g["latent_loss"]))), (out, float(g["latent_loss"]))
+    total = float(g["vgg_weight"]) * float(g["vgg_loss"]) + float(g["latent_weight"]) * float(g["latent_loss"])
+    assert abs(out["loss"] - total) <= loss_tol * max(1.0, abs(total))
+    for n, prm in prior.named_parameters():
+        ref = T(g["grad." + n])
+        err = (prm.grad.detach().cpu() - ref).abs().max().item()
+        assert ref.abs().max().item() > 0 and err <= grad_tol * ref.abs().max().item(), "grad %s: %.3e of %.3e" % (n, err, ref.abs().max().item())
+
+
+def test_train_step_vs_reference_train_golden(golden_dir):
+    """f4: linf/train.py::train_step (host logic on the CPU double) against the losses and latent-module gradients that the GENUINE
+    reference's `train()` (LINF-LP/train.py:88-172) produced for a batch of its own training wrapper -- random sub-crop, s != 1,
+    `interpolate_coord` grid_sample skip (train.py:154), patch=True, vgg_weight and latent_weight > 0.  MANIFEST: the oracle's
+    restatement of the objective is within float rounding of it."""
+    man = json.load(open(os.path.join(golden_dir, "MANIFEST.json")))["train_step"]
+    assert max(man.values()) <= 1e-8
+    out, prior, g = run_train_step_case(golden_dir, CpuOps())
+    check_train_step(out, prior, g, 1e-5, 1e-4)
+
+
+def test_train_step_needs_interpolate_coord_for_subcrops(golden_dir):
+    """Without `interpolate_coord` the fallback (plain resize of the whole LR crop) is a DIFFERENT objective on a sub-crop batch:
+    the fixture must tell the two apart, i.e. the golden really exercises train.py:154."""
+    from bfsr_amd.linf.train import train_step
+    g = np.load(os.path.join(golden_dir, "linf_train_step.npz"))
+    sd, _ = weights("edsr-baseline", int(g["weights_seed"]))
+    m = make(mspec("edsr-baseline"), args={"ops": CpuOps()}).eval()
+    m.load_state_dict(sd)
+    batch = {k: T(g[k]) for k in ("inp", "coord", "cell", "gt", "gt_patch", "gt_lr_up")}
+    out = train_step(TrainTiny(g), m, batch, latent_weight=float(g["latent_weight"]), image_weight=float(g["vgg_weight"]),
+                     feat_fn=TrainFeat(g), patch=True)
+    assert abs(out["image"] - float(g["vgg_loss"])) > 1e-3 * float(g["vgg_loss"])

@@ -389,3 +389,12 @@ def test_latent_module_train_step_gradients_vs_oracle(hip, golden_dir):
     for a, b in zip(prior.parameters(), ref_prior.parameters()):
         err, ref = (a.grad.cpu() - b.grad).abs().max().item(), b.grad.abs().max().item()
         assert ref > 0 and err <= 1e-3 * ref, "latent-module parameter gradient: %.3e of %.3e" % (err, ref)
+
+
+def test_train_step_vs_reference_train_golden_gpu(hip, golden_dir):
+    """The training iteration on the HIP path (frozen model on the kernels incl. the `interpolate_coord` skip on
+    bfsr_grid_sample_add, latent module + feature net in torch on the GPU) against the GENUINE reference's `train()` output
+    (tests/golden/linf_train_step.npz, LINF-LP/train.py:88-172): losses within 1e-5 relative, gradients within 1e-3."""
+    from test_linf_cpu import check_train_step, run_train_step_case
+    out, prior, g = run_train_step_case(golden_dir, hip, device=hip.device)
+    check_train_step(out, prior, g, 1e-5, 1e-3)

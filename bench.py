@@ -352,7 +352,9 @@ def main():
     cpu_baseline, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ncpu = os.cpu_count() or 1
-        nt = min(32, ncpu)        # the oracle is a torch-CPU program: beyond ~32 threads MKL-DNN is oversubscribed on these convs
+        # the oracle is a torch-CPU (MKL-DNN) program: measured on the GPU box's 256-core host it is fastest at 16 threads
+        # (8/16/32/64/128 threads: 7.4 / 5.7 / 6.8 / 16.1 / 30.5 s per 160x160 crop, profiles/r03_cpu_thread_sweep.json)
+        nt = min(16, ncpu)
         torch.set_num_threads(nt)
         if srflow:
             import numpy as np

@@ -65,6 +65,21 @@ class BfsrCouplingHeadArgs(C.Structure):
     ]
 
 
+class BfsrCouplingStepArgs(C.Structure):
+    _fields_ = [
+        ("z_in", C.c_void_p), ("z_in_bs", C.c_longlong),
+        ("z_out", C.c_void_p), ("z_out_bs", C.c_longlong),
+        ("pre_aff", C.c_void_p), ("pre_aff_bs", C.c_longlong),
+        ("h_ft", C.c_void_p), ("h_ft_bs", C.c_longlong),
+        ("w_head", C.c_void_p), ("w_tail", C.c_void_p),
+        ("epi0", C.c_void_p), ("epi2", C.c_void_p),
+        ("bias", C.c_void_p), ("post_scale", C.c_void_p),
+        ("wmat", C.c_void_p), ("an_bias", C.c_void_p), ("an_escale", C.c_void_p),
+        ("B", C.c_int), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("reverse", C.c_int),
+        ("eps", C.c_float),
+    ]
+
+
 class BfsrCouplingTailArgs(C.Structure):
     _fields_ = [
         ("hid", C.c_void_p), ("hid_bs", C.c_longlong), ("Cin", C.c_int),
@@ -149,6 +164,9 @@ SYMBOLS = {
     "bfsr_flow_pointwise": (_I, [C.POINTER(BfsrFlowArgs), _VP]),
     "bfsr_coupling_head": (_I, [C.POINTER(BfsrCouplingHeadArgs), _VP]),
     "bfsr_coupling_tail": (_I, [C.POINTER(BfsrCouplingTailArgs), _VP]),
+    "bfsr_coupling_step": (_I, [C.POINTER(BfsrCouplingStepArgs), _VP]),
+    "bfsr_coupling_step_tail_packed_size": (_LL, [_I]),
+    "bfsr_pack_coupling_step_tail": (_I, [_VP, _I, _VP]),
     "bfsr_coupling_head_packed_size": (_LL, [_I]),
     "bfsr_pack_coupling_head": (_I, [_VP, _VP, _I, _VP]),
     "bfsr_coupling_tail_packed_size": (_LL, [_I, _I]),

@@ -610,6 +610,39 @@ class HipOps(object):
         _lib.check(self._launch(key, lambda: self.lib.bfsr_coupling_tail(C.byref(a), self._stream())), "coupling_tail(C=%d)" % Cc)
         return z_out
 
+    # ---- ... and in ONE kernel (coupling_step.hip): hid stays in LDS ------------------------------------------------------------
+    def pack_coupling_step(self, w0_z1, w2, shift0, scale0, shift2, scale2, w4, bias4, post_scale4):
+        """Everything bfsr_coupling_step needs of one step's fAffine net: the head pack (fAffine.0 z1 rows + fAffine.2 + ActNorms) and
+        fAffine.4 (Conv2dZeros [Cout,64,3,3]) in the fragment order of the fused kernel's last stage."""
+        wh, e0, e2, Cz = self.pack_coupling_head(w0_z1, w2, shift0, scale0, shift2, scale2)
+        w = w4.detach().to("cpu", torch.float32).contiguous()
+        Cout = w.shape[0]
+        n = self.lib.bfsr_coupling_step_tail_packed_size(Cout)
+        if n <= 0 or tuple(w.shape[1:]) != (64, 3, 3):
+            raise ValueError("pack_coupling_step: unsupported fAffine.4 shape %s" % (tuple(w.shape),))
+        packed = torch.empty(n, dtype=torch.int16)
+        _lib.check(self.lib.bfsr_pack_coupling_step_tail(w.data_ptr(), Cout, packed.data_ptr()), "pack_coupling_step_tail")
+        return wh, e0, e2, Cz, packed.to(self.device), self.vec(bias4), self.vec(post_scale4), Cout
+
+    def coupling_step(self, z_in, z_out, packed, pre_aff, reverse, h_ft=None, w=None, an_bias=None, an_escale=None, eps=1e-4):
+        """The sequential remainder of a coupled FlowStep in one launch: coupling_head + coupling_tail semantics, z_out != z_in."""
+        wh, e0, e2, Cz, wt, bias, ps, Cout = packed
+        a = _lib.BfsrCouplingStepArgs()
+        a.z_in, a.z_in_bs, Cc, H, W = _view(z_in, "coupling_step.z_in")
+        a.z_out, a.z_out_bs, c2, h2, w2 = _view(z_out, "coupling_step.z_out")
+        a.pre_aff, a.pre_aff_bs, c1, h1, w1 = _view(pre_aff, "coupling_step.pre_aff")
+        assert (c2, h2, w2) == (Cc, H, W) and (c1, h1, w1) == (64, H, W) and Cz == Cc // 2 and Cout == 2 * (Cc - Cc // 2)
+        if h_ft is not None:
+            a.h_ft, a.h_ft_bs, c, h, ww = _view(h_ft, "coupling_step.h_ft")
+            assert (c, h, ww) == (2 * Cc, H, W)
+        a.w_head, a.w_tail, a.epi0, a.epi2 = wh.data_ptr(), wt.data_ptr(), e0.data_ptr(), e2.data_ptr()
+        a.bias, a.post_scale = bias.data_ptr(), ps.data_ptr()
+        a.wmat, a.an_bias, a.an_escale = _ptr(w), _ptr(an_bias), _ptr(an_escale)
+        a.B, a.C, a.H, a.W, a.reverse, a.eps = z_in.shape[0], Cc, H, W, int(bool(reverse)), eps
+        key = ("coupling_step", int(bool(reverse)), Cc, z_in.shape[0], H, W)
+        _lib.check(self._launch(key, lambda: self.lib.bfsr_coupling_step(C.byref(a), self._stream())), "coupling_step(C=%d)" % Cc)
+        return z_out
+
     def squeeze2d(self, x, y):
         xp, xbs, Cc, H, W = _view(x)
         yp, ybs, c2, h2, w2 = _view(y)

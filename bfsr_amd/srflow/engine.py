@@ -276,7 +276,14 @@ class SRFlowEngine(object):
                     #  tail it is 0.6-1.0 ms faster per cfg2 step, A/B on one box -> FUSED_COUPLING_C = (12, 24))
                     st.fused = (C in FUSED_COUPLING_C and w0.shape[0] == 64 and hasattr(ops, "coupling_head")
                                 and getattr(ops, "conv_mode", "f32") == "x3" and os.environ.get("BFSR_COUPLING", "fused") != "unfused")
-                    if st.fused:
+                    # default: ONE kernel per step (coupling_step.hip, hid stays in LDS); BFSR_COUPLING=pair keeps head + tail
+                    st.step = None
+                    if st.fused and hasattr(ops, "coupling_step") and os.environ.get("BFSR_COUPLING", "fused") != "pair":
+                        st.step = ops.pack_coupling_step(w0[:, :cn].contiguous(), sd[a + "2.weight"], sd[a + "0.actnorm.bias"],
+                                                         torch.exp(sd[a + "0.actnorm.logs"]), sd[a + "2.actnorm.bias"],
+                                                         torch.exp(sd[a + "2.actnorm.logs"]), sd[a + "4.weight"], sd[a + "4.bias"],
+                                                         torch.exp(sd[a + "4.logs"] * 3))
+                    elif st.fused:
                         st.head = ops.pack_coupling_head(w0[:, :cn].contiguous(), sd[a + "2.weight"], sd[a + "0.actnorm.bias"],
                                                          torch.exp(sd[a + "0.actnorm.logs"]), sd[a + "2.actnorm.bias"],
                                                          torch.exp(sd[a + "2.actnorm.logs"]))
@@ -488,6 +495,12 @@ class SRFlowEngine(object):
         st.aff4.run(ops, hid, h_aff)
         return h_aff
 
+    def _pingpong(self, z, tag):
+        """A workspace tensor of z's shape that is not z: the fused step kernel reads the z1 halo of neighbouring tiles, so it
+        cannot run in place and the flow state alternates between two buffers per level."""
+        a = self.ws.get("pp_%s_a" % tag, *z.shape)
+        return a if a.data_ptr() != z.data_ptr() else self.ws.get("pp_%s_b" % tag, *z.shape)
+
     def encode(self, gt, lr, logdet=None):
         """normal flow (FlowUpsamplerNet.encode :217-251): gt [B,3,H,W] -> [eps_split..., z_final].
         logdet: optional float64 [B] accumulator that receives the flow's log-determinant (actnorm + invconv constants,
@@ -519,8 +532,6 @@ class SRFlowEngine(object):
                         pending = None
                     head_done = False
                     if getattr(st, "fused", False) and logdet is None:
-                        hid = ws.get("hid_enc%d" % ly.level, B, 64, H, W)
-                        ops.coupling_head(z, st.head, cnd["pre_aff"][:, 64 * k: 64 * (k + 1)], hid)
                         # the tail applies this step's self-conditional affine and, when the next layer is another step of this
                         # level, that step's head (what the generic path does lazily through `pending`)
                         nxt = self.layers[pos + 1] if pos + 1 < len(self.layers) else None
@@ -532,7 +543,13 @@ class SRFlowEngine(object):
                                 kn = cnd["slot"][nxt.index]
                                 kw["h_ft"] = cnd["h_ft"][:, 2 * ly.C * kn: 2 * ly.C * (kn + 1)]
                             head_done = True
-                        ops.coupling_tail(hid, st.tail, z, z, False, **kw)
+                        pre_k = cnd["pre_aff"][:, 64 * k: 64 * (k + 1)]
+                        if st.step is not None:
+                            z = ops.coupling_step(z, self._pingpong(z, "enc%d" % ly.level), st.step, pre_k, False, **kw)
+                        else:
+                            hid = ws.get("hid_enc%d" % ly.level, B, 64, H, W)
+                            ops.coupling_head(z, st.head, pre_k, hid)
+                            ops.coupling_tail(hid, st.tail, z, z, False, **kw)
                     else:
                         pending = self._self_cond(st, z, cnd, k, "enc%d" % ly.level)
                         if logdet is not None:
@@ -588,10 +605,14 @@ class SRFlowEngine(object):
                     cnd = self._await(cond[ly.level])
                     k = cnd["slot"][ly.index]
                     if getattr(st, "fused", False) and logdet is None:
-                        hid = ws.get("hid_dec%d" % ly.level, z.shape[0], 64, H, W)
-                        ops.coupling_head(z, st.head, cnd["pre_aff"][:, 64 * k: 64 * (k + 1)], hid)
-                        ops.coupling_tail(hid, st.tail, z, z, True, h_ft=cnd["h_ft"][:, 2 * C * k: 2 * C * (k + 1)],
-                                          w=st.w_inv, an_bias=st.an_bias, an_escale=st.an_expneg)
+                        pre_k = cnd["pre_aff"][:, 64 * k: 64 * (k + 1)]
+                        kw = dict(h_ft=cnd["h_ft"][:, 2 * C * k: 2 * C * (k + 1)], w=st.w_inv, an_bias=st.an_bias, an_escale=st.an_expneg)
+                        if st.step is not None:
+                            z = ops.coupling_step(z, self._pingpong(z, "dec%d" % ly.level), st.step, pre_k, True, **kw)
+                        else:
+                            hid = ws.get("hid_dec%d" % ly.level, z.shape[0], 64, H, W)
+                            ops.coupling_head(z, st.head, pre_k, hid)
+                            ops.coupling_tail(hid, st.tail, z, z, True, **kw)
                     else:
                         h_aff = self._self_cond(st, z, cnd, k, "dec%d" % ly.level)
                         if logdet is not None:

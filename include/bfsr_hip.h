@@ -233,6 +233,29 @@ int bfsr_pack_coupling_head(const float* w0_z1, const float* w2, int Cz, unsigne
 long long bfsr_coupling_tail_packed_size(int Cin, int Cout);                        /* floats */
 int bfsr_pack_coupling_tail(const float* w, int Cin, int Cout, float* packed);
 
+/* The same FlowStep remainder as ONE kernel (coupling_step.hip; replaces the torch call sequence of
+ * FlowAffineCouplingsAblation.py:80-93 + FlowStep.py:113-129 for a step: fAffine on cat[z1, ft] with the ft rows hoisted, the
+ * self-conditional affine, the feature-conditional affine, InvertibleConv1x1 and ActNorm): `hid` never leaves the CU.
+ *   w_head = bfsr_pack_coupling_head(fAffine.0[:, :Cz], fAffine.2), epi0 / epi2 as for bfsr_coupling_head;
+ *   w_tail = bfsr_pack_coupling_step_tail(fAffine.4), bias / post_scale [2*(C-C/2)];
+ *   h_ft, wmat, an_bias / an_escale, reverse, eps: exactly bfsr_coupling_tail's / bfsr_flow_pointwise's meaning.
+ * C = 12 or 24.  z_in and z_out must NOT overlap (a tile reads the z1 halo its neighbours' outputs would overwrite): -1. */
+typedef struct BfsrCouplingStepArgs {
+    const float* z_in; long long z_in_bs;
+    float* z_out; long long z_out_bs;
+    const float* pre_aff; long long pre_aff_bs;       /* [B,64,H,W]: hoisted ft rows of fAffine.0 */
+    const float* h_ft; long long h_ft_bs;             /* [B,2C,H,W] or NULL */
+    const unsigned short* w_head; const unsigned short* w_tail;
+    const float* epi0; const float* epi2;             /* [64][4] {ActNorm bias, exp(logs), 0, 0} */
+    const float* bias; const float* post_scale;       /* fAffine.4: bias, exp(3*logs) */
+    const float* wmat; const float* an_bias; const float* an_escale;
+    int B, C, H, W, reverse;
+    float eps;
+} BfsrCouplingStepArgs;
+int bfsr_coupling_step(const BfsrCouplingStepArgs* a, void* stream);
+long long bfsr_coupling_step_tail_packed_size(int Cout);                               /* bf16 elements */
+int bfsr_pack_coupling_step_tail(const float* w4, int Cout, unsigned short* packed);   /* w4 [Cout][64][3][3] */
+
 /* squeeze2d / unsqueeze2d, factor 2 (flow.py:122-152): x [B,C,H,W] <-> y [B,4C,H/2,W/2] */
 int bfsr_squeeze2d(const float* x, long long x_bs, float* y, long long y_bs, int B, int C, int H, int W,
                    void* stream);

@@ -365,6 +365,15 @@ class CpuOps(object):
         h_aff = (F.conv2d(hid, w4, None, 1, 1) + _cv(b4)) * _cv(ps)
         return self.flow_pointwise(z_in, z_out, reverse, h_aff=h_aff, h_ft=h_ft, w=w, an_bias=an_bias, an_escale=an_escale, eps=eps)
 
+    def pack_coupling_step(self, w0_z1, w2, shift0, scale0, shift2, scale2, w4, bias4, post_scale4):
+        return self.pack_coupling_head(w0_z1, w2, shift0, scale0, shift2, scale2), self.pack_coupling_tail(w4, bias4, post_scale4)
+
+    def coupling_step(self, z_in, z_out, packed, pre_aff, reverse, h_ft=None, w=None, an_bias=None, an_escale=None, eps=1e-4):
+        assert z_in.data_ptr() != z_out.data_ptr(), "coupling_step is not an in-place operation"
+        head, tail = packed
+        hid = self.coupling_head(z_in, head, pre_aff, torch.empty(z_in.shape[0], 64, z_in.shape[2], z_in.shape[3]))
+        return self.coupling_tail(hid, tail, z_in, z_out, reverse, h_ft=h_ft, w=w, an_bias=an_bias, an_escale=an_escale, eps=eps)
+
     def pack_linf_mlp(self, ws, bs, x3=True):
         rnd = (lambda t: t) if x3 else (lambda t: t.half().float())
         return ([rnd(t.detach().to(torch.float32).reshape(t.shape[0], t.shape[1], 1, 1)).clone() for t in ws],

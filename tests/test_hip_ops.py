@@ -271,6 +271,54 @@ def test_coupling_tail(hip, C, reverse, hw):
         close(zd, ref, 2e-5, "coupling_tail C=%d rev=%d" % (C, reverse))
 
 
+@pytest.mark.parametrize("C", [12, 24])
+@pytest.mark.parametrize("reverse", [0, 1])
+@pytest.mark.parametrize("hw", [(16, 40), (9, 33), (70, 70), (6, 30), (5, 3), (37, 91)])
+def test_coupling_step(hip, C, reverse, hw):
+    """coupling_step.hip: the whole sequential remainder of a coupled FlowStep in ONE kernel (3x3 on z1 + hoisted partial -> 1x1 ->
+    Conv2dZeros -> pointwise chain; hid stays in LDS) against the fp32 torch semantics of head + tail.  Sizes: several 6 x 30 tiles
+    per image, ragged last tiles in both directions, images smaller than one tile; B = 3 exercises the persistent tile walk."""
+    H, W = hw
+    B, cn, cc2 = 3, C // 2, 2 * (C - C // 2)
+    z, pre = rnd(161, B, C, H, W), rnd(162, B, 64, H, W, scale=0.5)
+    w0, w2 = rnd(163, 64, cn, 3, 3, scale=0.1), rnd(164, 64, 64, 1, 1, scale=0.1)
+    s0, c0, s2, c2 = rnd(165, 64, scale=0.1), torch.exp(rnd(166, 64, scale=0.1)), rnd(167, 64, scale=0.1), torch.exp(rnd(168, 64, scale=0.1))
+    w4, b4, ps = rnd(173, cc2, 64, 3, 3, scale=0.02), rnd(174, cc2, scale=0.2), torch.exp(rnd(175, cc2, scale=0.2))
+    h_ft = rnd(176, B, 2 * C, H, W, scale=0.5)
+    Wm = torch.from_numpy(np.linalg.qr(np.random.Generator(np.random.PCG64(7)).standard_normal((C, C)))[0].astype(np.float32))
+    bias, es = rnd(177, C, scale=0.1), torch.exp(rnd(178, C, scale=0.1))
+    cpk = CPU.pack_coupling_step(w0, w2, s0, c0, s2, c2, w4, b4, ps)
+    hpk = hip.pack_coupling_step(w0, w2, s0, c0, s2, c2, w4, b4, ps)
+    full = dict(h_ft=h_ft, w=Wm, an_bias=bias, an_escale=es)
+    for kw in ((full, dict()) if not reverse else (full,)):
+        ref = CPU.coupling_step(z, torch.empty_like(z), cpk, pre, reverse, **{k: (v.reshape(-1) if k == "w" else v) for k, v in kw.items()})
+        dkw = {k: (hip.vec(v) if v.dim() <= 2 else hip.to_device(v)) for k, v in kw.items()}
+        zd = hip.to_device(z)
+        out = hip.coupling_step(zd, hip.empty(B, C, H, W), hpk, hip.to_device(pre), reverse, **dkw)
+        assert torch.equal(zd.cpu(), z), "the input must be left alone"
+        close(out, ref, 2e-5, "coupling_step C=%d rev=%d" % (C, reverse))
+    with pytest.raises(Exception):          # in place is a race by construction: refused
+        zd = hip.to_device(z)
+        hip.coupling_step(zd, zd, hpk, hip.to_device(pre), reverse)
+
+
+def test_coupling_step_on_channel_slices_and_views(hip):
+    """z_in / z_out / pre_aff / h_ft as channel slices of wider buffers (batch stride != C*H*W), as the engine passes them."""
+    B, C, H, W = 2, 12, 20, 44
+    zbuf, obuf = rnd(181, B, 20, H, W), torch.zeros(B, 16, H, W)
+    prebuf, hfbuf = rnd(182, B, 3 * 64, H, W, scale=0.5), rnd(183, B, 3 * 24, H, W, scale=0.5)
+    w0, w2 = rnd(163, 64, 6, 3, 3, scale=0.1), rnd(164, 64, 64, 1, 1, scale=0.1)
+    s0, c0, s2, c2 = rnd(165, 64, scale=0.1), torch.exp(rnd(166, 64, scale=0.1)), rnd(167, 64, scale=0.1), torch.exp(rnd(168, 64, scale=0.1))
+    w4, b4, ps = rnd(173, 12, 64, 3, 3, scale=0.02), rnd(174, 12, scale=0.2), torch.exp(rnd(175, 12, scale=0.2))
+    ref = CPU.coupling_step(zbuf[:, :C], torch.empty(B, C, H, W), CPU.pack_coupling_step(w0, w2, s0, c0, s2, c2, w4, b4, ps),
+                            prebuf[:, 64:128], 1, h_ft=hfbuf[:, 24:48])
+    od = hip.to_device(obuf)
+    hip.coupling_step(hip.to_device(zbuf)[:, :C], od[:, 2:2 + C], hip.pack_coupling_step(w0, w2, s0, c0, s2, c2, w4, b4, ps),
+                      hip.to_device(prebuf)[:, 64:128], 1, h_ft=hip.to_device(hfbuf)[:, 24:48])
+    close(od[:, 2:2 + C], ref, 2e-5, "coupling_step on slices")
+    assert float(od[:, :2].abs().max()) == 0.0 and float(od[:, 2 + C:].abs().max()) == 0.0, "wrote outside its channel slice"
+
+
 @pytest.mark.parametrize("C", [12, 24, 96])
 @pytest.mark.parametrize("reverse", [0, 1])
 @pytest.mark.parametrize("hw", [(16, 24), (7, 9)])

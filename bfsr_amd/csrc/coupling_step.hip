@@ -51,11 +51,23 @@ __device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l)
     l = (__bf16)(r1 - (float)m);
 }
 
+#ifndef BFSR_STEP_V
+#define BFSR_STEP_V 0          // timing experiments of the trace build (tools/exp/build_step_trace.sh): never set in the product
+#endif
+#ifdef BFSR_STEP_TRACE
+// diagnostics build only (tools/exp/build_step_trace.sh): s_memtime stamps of workgroup 0's waves at the phase boundaries
+__device__ unsigned long long* g_step_trace = nullptr;
+#define BFSR_TRACE(K_)                                                                                   \
+    if (blockIdx.x == 0 && lane == 0 && g_step_trace && iter < 8) g_step_trace[(iter * 8 + wave) * 16 + (K_)] = __builtin_amdgcn_s_memtime();
+#else
+#define BFSR_TRACE(K_)
+#endif
+
 template <int NO, int C>
 struct Geo {
     static constexpr int CN = C / 2, CC = C - CN, CO2 = 2 * CC, MT = (CO2 + 15) / 16, MW = MT * 16;
     static constexpr int NU = 9 * NO, NC1 = (NU + 1) / 2;
-    static constexpr bool W0_RES = NO == 1;
+    static constexpr bool W0_RES = NO == 1 && !(BFSR_STEP_V & 64);
     static constexpr int HID_B = 3 * 8 * NPH * 16 + 64;        // + 2 positions of slack behind the last slab (waste lanes of S3)
     static constexpr int Z_B = NO * 3 * NPZ * 16;
     static constexpr int CHUNK_B = 3 * 2 * 64 * 16;            // one 16-wide k chunk of a 64-row GEMM: [plane][k half][64][8]
@@ -63,7 +75,7 @@ struct Geo {
     static constexpr int EPI_B = 2 * 64 * 8;                   // {shift, scale} of the two ActNorms
     static constexpr int SH_B = CO2 * NPX * 4;
     static constexpr int OFF_W2 = HID_B, OFF_W0 = OFF_W2 + W2_B, OFF_EPI = OFF_W0 + (W0_RES ? W0_B : 0), OFF_SH = OFF_EPI + EPI_B;
-    static constexpr int LDS = OFF_SH + SH_B;
+    static constexpr int LDS = OFF_SH + SH_B + (((BFSR_STEP_V & 64) && NO == 1) ? Z_B : 0);
     static constexpr int W4_CHUNK = 3 * 4 * MW * 8;            // bf16 elements of one (tap, 32-channel half) chunk
     static_assert(Z_B <= HID_B, "the z1 tile aliases the hid tile");
     static_assert(LDS <= 160 * 1024, "LDS budget");
@@ -77,7 +89,7 @@ __global__ __launch_bounds__(512, 2) void coupling_step_kernel(BfsrCouplingStepA
     constexpr int ZU = (NO * NPZ + 511) / 512;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sHid = smem;
-    unsigned char* sZ = smem;
+    unsigned char* sZ = ((BFSR_STEP_V & 64) && NO == 1) ? smem + G::OFF_SH + G::SH_B : smem;    // experiment 64: z1 tile NOT aliased
     unsigned char* sW2 = smem + G::OFF_W2;
     unsigned char* sW0 = smem + G::OFF_W0;
     float2* sE0 = reinterpret_cast<float2*>(smem + G::OFF_EPI);
@@ -120,19 +132,21 @@ __global__ __launch_bounds__(512, 2) void coupling_step_kernel(BfsrCouplingStepA
     auto prefetch_z = [&](int t) {
         int b, x0, y0;
         tile_origin(t, b, x0, y0);
-        const float* __restrict__ zb = p.z_in + (long long)b * p.z_in_bs;
+        const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.z_in + (long long)b * p.z_in_bs), 0, (unsigned)(CN * HW * 4), 0x00020000);
+        int tz = tid;
+        asm volatile("" : "+v"(tz));                            // keep the per-thread tile coordinates out of the loop-invariant set
 #pragma unroll
         for (int i = 0; i < ZU; ++i) {
-            const int u = tid + i * 512;
+            const int u = tz + i * 512;
             const int o = u / NPZ, pos = u - o * NPZ;
             const int r = pos / ZC, c = pos - r * ZC;
             const int gy = y0 + r - 2, gx = x0 + c - 2;
             const bool ok = u < NO * NPZ && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            // channels beyond CN fall outside the descriptor's range and read 0
+            const unsigned vo = ok ? (unsigned)(((long long)o * 8 * HW + (long long)gy * W + gx) * 4) : OOB;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int ch = o * 8 + e;
-                zr[i][e] = (ok && ch < CN) ? zb[(long long)ch * HW + (long long)gy * W + gx] : 0.f;
-            }
+            for (int e = 0; e < 8; ++e)
+                zr[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, vo, (unsigned)(e * HW * 4), 0));
         }
     };
     auto prefetch_pre = [&](int t) {
@@ -168,9 +182,12 @@ __global__ __launch_bounds__(512, 2) void coupling_step_kernel(BfsrCouplingStepA
     ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[0], B_[1], ACC_, 0, 0, 0);                                \
     ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[0], B_[0], ACC_, 0, 0, 0);
 
+    int iter = -1;
     for (int t = slot; t < ntiles; t += GD) {
         int b, x0, y0;
         tile_origin(t, b, x0, y0);
+        ++iter;
+        BFSR_TRACE(0)
         // ---- z1 registers -> x3 tile in LDS.  (Everybody is past the previous tile's S3: the region is free.)
 #pragma unroll
         for (int i = 0; i < ZU; ++i) {
@@ -185,7 +202,14 @@ __global__ __launch_bounds__(512, 2) void coupling_step_kernel(BfsrCouplingStepA
                 *reinterpret_cast<bf16x8*>(sZ + ((o * 3 + 2) * NPZ + pos) * 16) = l8;
             }
         }
+        BFSR_TRACE(1)
         __syncthreads();                                        // barrier 1: z1 tile (and, first time, the weights) visible
+        BFSR_TRACE(2)
+#ifdef BFSR_STEP_TRACE
+        const bool dump = (BFSR_STEP_V & 2048) && g_step_trace && t == 0;
+        unsigned char* dbase = reinterpret_cast<unsigned char*>(g_step_trace) + 4096;
+        if (dump) for (int i = tid; i < G::Z_B / 16; i += 512) reinterpret_cast<uint4*>(dbase)[i] = reinterpret_cast<const uint4*>(sZ)[i];
+#endif
         if (t + GD < ntiles) prefetch_z(t + GD);
 
         // ================= S1: 3x3 on z1.  chunk j = units (2j, 2j+1); unit u = (tap u / NO, octet u % NO); k half = lhi
@@ -194,45 +218,61 @@ __global__ __launch_bounds__(512, 2) void coupling_step_kernel(BfsrCouplingStepA
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        // MFMA operand discipline of this kernel (S1, S2, S3): a register that an MFMA reads as SrcA / SrcB stays ALLOCATED until the
+        // wave has issued a whole further chunk of MFMAs (KEEP = an empty asm that uses it, pinned behind a sched_barrier), and only
+        // then is it reloaded.  hipcc recycles a dead fragment register at once -- as the destination of the next ds_read or as a
+        // VALU temporary two instructions behind the MFMA -- and with two waves sharing the SIMD's matrix pipe a queued
+        // v_mfma_f32_32x32x16_bf16 was observed to pick up the NEW contents for columns 16-31 (tools/exp/step_hid_dump.py: z1, S1,
+        // pre_aff and t1 exact, the S2 accumulators wrong in 1 of 3 runs; exact again as soon as stores separated E1 from S2).
+#define BFSR_KEEP(X_) asm volatile("" :: "v"(X_))
+        bf16x8 fb[3][3], fa[3][2][3];                           // three (B, A) fragment sets of the 64-row GEMMs
         {
-            bf16x8 ar[2][2][3];                                 // global A ring (W0 not resident): [slot][m][plane]
-            auto load_a0 = [&](int j, bf16x8 (&dst)[2][3]) {
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        dst[m][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w0, a64_off, (unsigned)(j * G::CHUNK_B + pl * 2048 + m * 512), 0));
-            };
-            if constexpr (!G::W0_RES) load_a0(0, ar[0]);
-#pragma unroll 1
-            for (int j = 0; j < NC1; ++j) {
+            // chunk j: B fragments of units (2j, 2j+1) from the z1 tile; A from LDS (resident W0) or streamed from global memory
+            auto b_frags = [&](int j, bf16x8 (&bf)[3]) {
                 const int u0 = 2 * j, u1 = (2 * j + 1 < NU) ? 2 * j + 1 : 2 * j;   // a missing second unit re-reads the first (weights 0)
                 const int t0 = u0 / NO, o0 = u0 % NO, t1 = u1 / NO, o1 = u1 % NO;
                 const int a0 = (o0 * 3 * NPZ + (t0 / 3) * ZC + (t0 % 3)) * 16, a1 = (o1 * 3 * NPZ + (t1 / 3) * ZC + (t1 % 3)) * 16;
                 const unsigned char* bp = sZ + (lhi ? a1 : a0) + (wave * ZC + l31) * 16;
-                bf16x8 bf[3], af[2][3];
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) bf[pl] = *reinterpret_cast<const bf16x8*>(bp + pl * NPZ * 16);
-                if constexpr (G::W0_RES) {
+            };
+            auto a_frags = [&](int j, bf16x8 (&af)[2][3]) {
 #pragma unroll
-                    for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < 2; ++m)
 #pragma unroll
-                        for (int pl = 0; pl < 3; ++pl)
+                    for (int pl = 0; pl < 3; ++pl) {
+                        if constexpr (G::W0_RES)
                             af[m][pl] = *reinterpret_cast<const bf16x8*>(sW0 + j * G::CHUNK_B + pl * 2048 + m * 512 + a64_off);
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) { BFSR_SIX32(acc[m], af[m], bf) }
-                } else {
-                    if (j + 1 < NC1) load_a0(j + 1, ar[(j + 1) & 1]);
-                    if (j & 1) {
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) { BFSR_SIX32(acc[m], ar[1][m], bf) }
-                    } else {
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) { BFSR_SIX32(acc[m], ar[0][m], bf) }
+                        else
+                            af[m][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w0, a64_off, (unsigned)(j * G::CHUNK_B + pl * 2048 + m * 512), 0));
                     }
-                }
+            };
+            auto keep_set = [&](int sl) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) { BFSR_KEEP(fb[sl][pl]); BFSR_KEEP(fa[sl][0][pl]); BFSR_KEEP(fa[sl][1][pl]); }
+            };
+            b_frags(0, fb[0]); a_frags(0, fa[0]);
+            if (NC1 > 1) { b_frags(1, fb[1]); a_frags(1, fa[1]); }
+#pragma unroll
+            for (int j = 0; j < NC1; ++j) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) { BFSR_SIX32(acc[m], fa[j % 3][m], fb[j % 3]) }
+                __builtin_amdgcn_sched_barrier(0);
+                if (j >= 1) keep_set((j - 1) % 3);              // chunk j-1's operands may be recycled from here on ...
+                if (j + 2 < NC1) { b_frags(j + 2, fb[(j + 2) % 3]); a_frags(j + 2, fa[(j + 2) % 3]); }   // ... by chunk j+2's
             }
         }
+        BFSR_TRACE(3)
+#ifdef BFSR_STEP_TRACE
+        if (dump) {
+            float* da = reinterpret_cast<float*>(dbase + 32768);
+            float* dp = reinterpret_cast<float*>(dbase + 32768 + 65536);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { da[((wave * 2 + m) * 16 + r) * 64 + lane] = acc[m][r]; dp[((wave * 2 + m) * 16 + r) * 64 + lane] = pre[m][r]; }
+        }
+#endif
         // ---- E1 in registers: + pre_aff, ActNorm, ReLU; the result IS the B operand of the 1x1 (K order = accumulator order)
         bf16x8 b2[4][3];                                        // chunk c = (m, half): registers 8*half .. 8*half+7 of row tile m
 #pragma unroll
@@ -250,26 +290,63 @@ __global__ __launch_bounds__(512, 2) void coupling_step_kernel(BfsrCouplingStepA
                     split3(v, h, mm, l);
                     b2[m * 2 + hf][0][e] = h; b2[m * 2 + hf][1][e] = mm; b2[m * 2 + hf][2][e] = l;
                 }
-        if (t + GD < ntiles) prefetch_pre(t + GD);              // the next tile's hoisted partial flies under S2 ... S3
+        __builtin_amdgcn_sched_barrier(0);                      // E1 has read both accumulators: S1's last MFMAs are complete
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) { BFSR_KEEP(fb[(NC1 - 1) % 3][pl]); BFSR_KEEP(fa[(NC1 - 1) % 3][0][pl]); BFSR_KEEP(fa[(NC1 - 1) % 3][1][pl]); }
+        BFSR_TRACE(4)
+#ifdef BFSR_STEP_TRACE
+        if (dump) {                                             // t1 as the S2 B operand holds it: sum of the three planes
+            float* db = reinterpret_cast<float*>(dbase + 32768 + 3 * 65536 + 98304);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    db[((wave * 4 + c) * 8 + e) * 64 + lane] = ((float)b2[c][0][e] + (float)b2[c][1][e]) + (float)b2[c][2][e];
+        }
+#endif
+        if (!(BFSR_STEP_V & 2) && t + GD < ntiles) prefetch_pre(t + GD);   // the next tile's hoisted partial flies under S2 ... S3
         // ================= S2: 1x1, K = 64 = 4 chunks in accumulator order
         f32x16 acc2[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[m][r] = 0.f;
+        {
+            // A fragments (W2, LDS) two chunks ahead in the three register sets of S1 (its fragments are dead), same discipline
+            auto load_a2 = [&](int c, bf16x8 (&dst)[2][3]) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            bf16x8 af[2][3];
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        dst[m][pl] = *reinterpret_cast<const bf16x8*>(sW2 + c * G::CHUNK_B + pl * 2048 + m * 512 + a64_off);
+            };
+            load_a2(0, fa[0]);
+            load_a2(1, fa[1]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) { BFSR_SIX32(acc2[m], fa[c % 3][m], b2[c]) }
+                __builtin_amdgcn_sched_barrier(0);
+                if (c >= 1) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) { BFSR_KEEP(fa[(c - 1) % 3][0][pl]); BFSR_KEEP(fa[(c - 1) % 3][1][pl]); BFSR_KEEP(b2[c - 1][pl]); }
+                }
+                if (c + 2 < 4) load_a2(c + 2, fa[(c + 2) % 3]);
+            }
+        }
+        if ((BFSR_STEP_V & 2) && t + GD < ntiles) prefetch_pre(t + GD);
+#ifdef BFSR_STEP_TRACE
+        if (dump) {
+            float* d2 = reinterpret_cast<float*>(dbase + 32768 + 2 * 65536);
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    af[m][pl] = *reinterpret_cast<const bf16x8*>(sW2 + c * G::CHUNK_B + pl * 2048 + m * 512 + a64_off);
-#pragma unroll
-            for (int m = 0; m < 2; ++m) { BFSR_SIX32(acc2[m], af[m], b2[c]) }
-            __builtin_amdgcn_sched_barrier(0);                  // keep the fragment reads of chunk c+1 behind this chunk's MFMAs
+                for (int r = 0; r < 16; ++r) d2[((wave * 2 + m) * 16 + r) * 64 + lane] = acc2[m][r];
         }
+#endif
+        BFSR_TRACE(5)
         __syncthreads();                                        // barrier 2: nobody reads the z1 tile any more -> hid may be written
+        BFSR_TRACE(6)
         // ---- E2: ActNorm, ReLU, zero outside the image (Conv2dZeros pads hid with zeros), channel-octet transposition, x3 -> LDS
         {
             const int gy = y0 - 1 + wave, gx = x0 - 1 + l31;
@@ -306,32 +383,52 @@ __global__ __launch_bounds__(512, 2) void coupling_step_kernel(BfsrCouplingStepA
                 }
             }
         }
+        __builtin_amdgcn_sched_barrier(0);                      // E2 has read both accumulators: S2's last MFMAs are complete
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) { BFSR_KEEP(fa[0][0][pl]); BFSR_KEEP(fa[0][1][pl]); BFSR_KEEP(b2[3][pl]); }
+        BFSR_TRACE(7)
         __syncthreads();                                        // barrier 3: hid tile complete
+        BFSR_TRACE(8)
+#ifdef BFSR_STEP_TRACE
+        if (dump) {                                                 // experiment 2048: dump tile 0's hid tile (raw x3 planes)
+            for (int i = tid; i < 3 * 8 * NPH; i += 512) reinterpret_cast<uint4*>(dbase + 32768 + 3 * 65536)[i] = reinterpret_cast<const uint4*>(sHid)[i];
+        }
+#endif
 
-        // ---- operands of this tile's pointwise chain (one thread per output pixel): issued here, consumed after S3
-        const int py = y0 + tid / OW, px = x0 + tid % OW;
-        const bool pw_on = tid < NPX && py < H && px < W;
-        const long long pix = (long long)py * W + px;
-        float x[C], fsh[C], fsr[C];
+        // ---- operands of phase A of this tile's pointwise chain: work item i = tid + 512 k = (channel i / 180, pixel i % 180),
+        // loaded here, consumed after S3
+        constexpr int NIA = (C * NPX + 511) / 512;
+        float pz[NIA], psh[NIA], psr[NIA];
+        // `tv` = tid, re-defined opaquely per tile: the item index arithmetic below (divisions by 180 / 30 per item) is loop-invariant
+        // per thread, and hipcc otherwise hoists ~80 values out of the tile loop and SPILLS them (scratch reloads with vmcnt(0)
+        // waits in the middle of S3, measured in the ISA)
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
         {
-            const unsigned vo = pw_on ? (unsigned)(pix * 4) : OOB;
             const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.z_in + (long long)b * p.z_in_bs), 0, (unsigned)(C * HW * 4), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.h_ft ? p.h_ft + (long long)b * p.h_ft_bs : p.z_in), 0,
+                                                                                p.h_ft ? (unsigned)(2 * C * HW * 4) : 0u, 0x00020000);
 #pragma unroll
-            for (int c = 0; c < C; ++c) x[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, vo, (unsigned)(c * HW * 4), 0));
-            if (p.h_ft) {
-                const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.h_ft + (long long)b * p.h_ft_bs), 0, (unsigned)(2 * C * HW * 4), 0x00020000);
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    fsh[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, vo, (unsigned)((2 * c) * HW * 4), 0));
-                    fsr[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, vo, (unsigned)((2 * c + 1) * HW * 4), 0));
-                }
+            for (int k = 0; k < NIA; ++k) {
+                const int i = tv + 512 * k;
+                const int c = i / NPX, q = i - c * NPX;
+                const int qy = y0 + q / OW, qx = x0 + q % OW;
+                const bool on = i < C * NPX && qy < H && qx < W;
+                const long long pixq = (long long)qy * W + qx;
+                pz[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, on ? (unsigned)((c * HW + pixq) * 4) : OOB, 0, 0));
+                const unsigned vf = on ? (unsigned)((2LL * c * HW + pixq) * 4) : OOB;
+                psh[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, vf, 0, 0));
+                psr[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, vf, (unsigned)(HW * 4), 0));
             }
         }
 
         // ================= S3: Conv2dZeros 64 -> CO2 on 16x16x32 tiles.  chunk = (tap, 32-channel half): k group lq = octet half*4+lq
-        // column tile n = (output row, 16-pixel half): wave w takes n = w and, for w < 4, n = w + 8
+        // column tile n = (output row, 16-pixel half): wave w takes n = w and, for w < 4, n = w + 8.  Two accumulator chains are
+        // always in flight: the two column tiles of waves 0-3; for waves 4-7 the six cross products of their single tile alternate
+        // between two partial accumulators (six dependent 16x16x32 MFMAs on one accumulator were the critical path: 11.4k cycles
+        // for 216 MFMAs).  The B fragments of chunk ck+1 are read from LDS before the MFMAs of chunk ck are issued.
         {
-            const int n_mine = wave < 4 ? 2 : 1;
+            const bool two = wave < 4;
             f32x4 acc4[2][MT];
 #pragma unroll
             for (int n = 0; n < 2; ++n)
@@ -339,14 +436,21 @@ __global__ __launch_bounds__(512, 2) void coupling_step_kernel(BfsrCouplingStepA
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc4[n][m][r] = 0.f;
-            int nb[2];                                          // byte offset of (row, half*16 + l15) inside an (octet, plane) slab
+            // per-lane LDS bases of the B fragments, from the opaque `tv` (not hoisted out of the tile loop): column tile n, k group
+            // lq; planes 0-1 and plane 2 get separate bases so that every fragment is base + a 16-bit immediate offset
+            const int v15 = tv & 15, vq = (tv >> 4) & 3;
+            const unsigned char* hb0[2];
+            const unsigned char* hb2[2];
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                const int nt = wave + 8 * n;
-                nb[n] = (((nt >> 1) * HC) + (nt & 1) * 16 + l15) * 16;
+                const int nt = two ? wave + 8 * n : wave;
+                hb0[n] = sHid + vq * NPH * 16 + (((nt >> 1) * HC) + (nt & 1) * 16 + v15) * 16;
+                hb2[n] = hb0[n] + 2 * 8 * NPH * 16;
             }
-            constexpr int RING = MT == 1 ? 3 : 2;
-            bf16x8 ar[RING][3][MT];
+            // A ring (W4 from global memory) and B sets (hid from LDS) under the operand discipline of S1: chunk ck's operands are
+            // released behind the MFMAs of chunk ck+1 and reloaded right there, RA-1 / NB-1 chunks ahead of their use
+            constexpr int RA = MT == 1 ? 4 : 3, NB = MT == 1 ? 3 : 2;
+            bf16x8 ar[RA][3][MT];
             auto load_a4 = [&](int ck, bf16x8 (&dst)[3][MT]) {
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
@@ -354,100 +458,173 @@ __global__ __launch_bounds__(512, 2) void coupling_step_kernel(BfsrCouplingStepA
                     for (int m = 0; m < MT; ++m)
                         dst[pl][m] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w4, a4_off, (unsigned)((ck * G::W4_CHUNK + pl * 4 * MW * 8 + m * 16 * 8) * 2), 0));
             };
-#pragma unroll
-            for (int i = 0; i < RING - 1; ++i) load_a4(i, ar[i]);
-#pragma unroll
-            for (int ck = 0; ck < 18; ++ck) {
-                if (ck + RING - 1 < 18) load_a4(ck + RING - 1, ar[(ck + RING - 1) % RING]);
+            bf16x8 bfr[NB][2][3];                               // [set][column tile][plane]
+            auto load_b = [&](int ck, bf16x8 (&dst)[2][3]) {
                 const int tap = ck >> 1, hf = ck & 1;
-                const int toff = ((tap / 3) * HC + (tap % 3)) * 16 + (hf * 4 + lq) * NPH * 16;
-                bf16x8 bf[2][3];
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        bf[n][pl] = *reinterpret_cast<const bf16x8*>(sHid + pl * 8 * NPH * 16 + toff + nb[n < n_mine ? n : 0]);
+                const int toff = ((tap / 3) * HC + (tap % 3)) * 16 + hf * 4 * NPH * 16;
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
-                    if (n < n_mine) {
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) {
-#define BFSR_T(PA_, PB_) acc4[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[ck % RING][PA_][m], bf[n][PB_], acc4[n][m], 0, 0, 0);
-                            BFSR_T(2, 0) BFSR_T(0, 2) BFSR_T(1, 1) BFSR_T(1, 0) BFSR_T(0, 1) BFSR_T(0, 0)
-#undef BFSR_T
-                        }
+                    if (n == 0 || two) {
+                        dst[n][0] = *reinterpret_cast<const bf16x8*>(hb0[n] + toff);
+                        dst[n][1] = *reinterpret_cast<const bf16x8*>(hb0[n] + 8 * NPH * 16 + toff);
+                        dst[n][2] = *reinterpret_cast<const bf16x8*>(hb2[n] + toff);
                     }
                 }
+            };
+            auto keep3 = [&](int ck) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) BFSR_KEEP(ar[ck % RA][pl][m]);
+                    BFSR_KEEP(bfr[ck % NB][0][pl]);
+                    if (two) BFSR_KEEP(bfr[ck % NB][1][pl]);
+                }
+            };
+#pragma unroll
+            for (int i = 0; i < RA - 1; ++i) load_a4(i, ar[i]);
+#pragma unroll
+            for (int i = 0; i < NB - 1; ++i) load_b(i, bfr[i]);
+#pragma unroll
+            for (int ck = 0; ck < 18; ++ck) {
+#define BFSR_T(N_, BN_, PA_, PB_) acc4[N_][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[ck % RA][PA_][m], bfr[ck % NB][BN_][PB_], acc4[N_][m], 0, 0, 0);
+                if (two) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        BFSR_T(0, 0, 2, 0) BFSR_T(1, 1, 2, 0) BFSR_T(0, 0, 0, 2) BFSR_T(1, 1, 0, 2) BFSR_T(0, 0, 1, 1) BFSR_T(1, 1, 1, 1)
+                        BFSR_T(0, 0, 1, 0) BFSR_T(1, 1, 1, 0) BFSR_T(0, 0, 0, 1) BFSR_T(1, 1, 0, 1) BFSR_T(0, 0, 0, 0) BFSR_T(1, 1, 0, 0)
+                    }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        BFSR_T(0, 0, 2, 0) BFSR_T(1, 0, 0, 2) BFSR_T(0, 0, 1, 1) BFSR_T(1, 0, 1, 0) BFSR_T(0, 0, 0, 1) BFSR_T(1, 0, 0, 0)
+                    }
+                }
+#undef BFSR_T
                 __builtin_amdgcn_sched_barrier(0);
+                if (ck >= 1) keep3(ck - 1);
+                if (ck + RA - 1 < 18) load_a4(ck + RA - 1, ar[(ck + RA - 1) % RA]);
+                if (ck + NB - 1 < 18) load_b(ck + NB - 1, bfr[(ck + NB - 1) % NB]);
             }
+            BFSR_TRACE(9)
             // ---- E3: accumulator layout of 16x16: lane (l15, lq) holds rows 4*lq + i of column l15 -> h tile in LDS
+            if (!two) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc4[0][m][i] += acc4[1][m][i];
+            }
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                if (n < n_mine) {
+                if (n == 0 || two) {
                     const int nt = wave + 8 * n;
-                    const int col = (nt & 1) * 16 + l15;
+                    const int col = (nt & 1) * 16 + v15;
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            const int co = m * 16 + lq * 4 + i;
+                            const int co = m * 16 + vq * 4 + i;
                             if (co < CO2 && col < OW) sH[co * NPX + (nt >> 1) * OW + col] = (acc4[n][m][i] + p.bias[co]) * p.post_scale[co];
                         }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);                  // E3 has read the accumulators: the last MFMAs are complete
+            keep3(17);
         }
+        BFSR_TRACE(10)
         __syncthreads();                                        // barrier 4: h complete; every wave is done reading hid
+        BFSR_TRACE(11)
 
-        // ---- pointwise chain, one thread per pixel: identical arithmetic to flow_pointwise_kernel / coupling_tail_kernel
-        if (pw_on) {
+        // ---- pointwise chain of the step on ALL threads, in two phases through LDS (one thread per pixel kept waves 0-2 busy for
+        // 10.8k cycles per tile while five waves waited).  Same arithmetic per element as flow_pointwise_kernel.
+        // Phase A, item (channel c, pixel q): reverse: z2 = z2/scale - shift, then z = z/scaleFt - shiftFt;
+        //                                     forward: z2 = (z2 + shift)*scale, then the NEXT step's ActNorm.   -> sX[c][q]
+        float* sX = reinterpret_cast<float*>(smem);             // aliases the hid tile: dead behind barrier 4
+        {
             const float eps = p.eps;
             const bool hf = p.h_ft != nullptr;
-            const float* ha = sH + tid;
-            float* zo = p.z_out + (long long)b * p.z_out_bs + pix;
-            if (p.reverse) {
 #pragma unroll
-                for (int j = 0; j < CC; ++j) x[CN + j] = x[CN + j] / sigmoid_scale(ha[(2 * j + 1) * NPX], eps) - ha[(2 * j) * NPX];
-                if (hf) {
-#pragma unroll
-                    for (int c = 0; c < C; ++c) x[c] = x[c] / sigmoid_scale(fsr[c], eps) - fsh[c];
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < CC; ++j) x[CN + j] = (x[CN + j] + ha[(2 * j) * NPX]) * sigmoid_scale(ha[(2 * j + 1) * NPX], eps);
-                if (p.an_bias) {
-#pragma unroll
-                    for (int c = 0; c < C; ++c) x[c] = (x[c] + p.an_bias[c]) * p.an_escale[c];
-                }
-            }
-            if (p.wmat) {
-                const float* __restrict__ w = p.wmat;
-#pragma unroll
-                for (int i = 0; i < C; ++i) {
-                    float y = 0.f;
-#pragma unroll
-                    for (int j = 0; j < C; ++j) y = fmaf(w[i * C + j], x[j], y);
-                    if (p.reverse) {
-                        if (p.an_bias) y = y * p.an_escale[i] - p.an_bias[i];
-                    } else if (hf) {
-                        y = (y + fsh[i]) * sigmoid_scale(fsr[i], eps);
+            for (int k = 0; k < NIA; ++k) {
+                const int i = tv + 512 * k;
+                if (i < C * NPX) {
+                    const int c = i / NPX, q = i - c * NPX;
+                    float v = pz[k];
+                    if (c >= CN) {
+                        const float sh = sH[(2 * (c - CN)) * NPX + q], sr = sH[(2 * (c - CN) + 1) * NPX + q];
+                        v = p.reverse ? v / sigmoid_scale(sr, eps) - sh : (v + sh) * sigmoid_scale(sr, eps);
                     }
-                    zo[(long long)i * HW] = y;
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    float y = x[c];
                     if (p.reverse) {
-                        if (p.an_bias) y = y * p.an_escale[c] - p.an_bias[c];
-                    } else if (hf) {
-                        y = (y + fsh[c]) * sigmoid_scale(fsr[c], eps);
+                        if (hf) v = v / sigmoid_scale(psr[k], eps) - psh[k];
+                    } else if (p.an_bias) {
+                        v = (v + p.an_bias[c]) * p.an_escale[c];
                     }
-                    zo[(long long)c * HW] = y;
+                    sX[i] = v;
                 }
             }
         }
-        // the next iteration's z1 staging overwrites the hid region: every wave passed barrier 4 after its last hid read, and sH is
-        // next written behind three more barriers
+        // Phase B, item (pixel q, group g of 6 output channels), groups padded to 192 items so that g is wave-uniform (W through
+        // scalar loads): y = W x; reverse: ActNorm inverse; forward: the next step's feature-conditional affine.
+        constexpr int NGRP = C / 6, NIB = (NGRP * 192 + 511) / 512;
+        float bsh[NIB][6], bsr[NIB][6];
+        const bool fwd_ft = !p.reverse && p.h_ft != nullptr && p.wmat != nullptr;
+#pragma unroll
+        for (int k = 0; k < NIB; ++k) {
+            const int g = (wave + 8 * k) / 3, q = tv + 512 * k - g * 192;
+            const int qy = y0 + q / OW, qx = x0 + q % OW;
+            const bool on = g < NGRP && q < NPX && qy < H && qx < W;
+            if (fwd_ft || (!p.reverse && p.h_ft != nullptr)) {
+                const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.h_ft + (long long)b * p.h_ft_bs), 0, (unsigned)(2 * C * HW * 4), 0x00020000);
+                const unsigned vo = on ? (unsigned)(((long long)qy * W + qx) * 4) : OOB;
+#pragma unroll
+                for (int e = 0; e < 6; ++e) {
+                    bsh[k][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, vo, (unsigned)((2 * (6 * g + e)) * HW * 4), 0));
+                    bsr[k][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, vo, (unsigned)((2 * (6 * g + e) + 1) * HW * 4), 0));
+                }
+            }
+        }
+        BFSR_TRACE(12)
+        __syncthreads();                                        // barrier 5: sX complete
+        BFSR_TRACE(13)
+#pragma unroll
+        for (int k = 0; k < NIB; ++k) {
+            const int g = (wave + 8 * k) / 3, q = tv + 512 * k - g * 192;      // g is wave-uniform: 192 items = 3 waves per group
+            const int qy = y0 + q / OW, qx = x0 + q % OW;
+            if (g < NGRP && q < NPX && qy < H && qx < W) {
+                const float eps = p.eps;
+                float* zo = p.z_out + (long long)b * p.z_out_bs + (long long)qy * W + qx;
+                float y[6];
+                if (p.wmat) {
+                    float xv[C];
+#pragma unroll
+                    for (int j = 0; j < C; ++j) xv[j] = sX[j * NPX + q];
+                    const float* __restrict__ w = p.wmat + (6 * g) * C;
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) {
+                        float a = 0.f;
+#pragma unroll
+                        for (int j = 0; j < C; ++j) a = fmaf(w[e * C + j], xv[j], a);
+                        y[e] = a;
+                        __builtin_amdgcn_sched_barrier(0);      // one row of W in SGPRs at a time (72 scalars at once spilled)
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) y[e] = sX[(6 * g + e) * NPX + q];
+                }
+#pragma unroll
+                for (int e = 0; e < 6; ++e) {
+                    const int ci = 6 * g + e;
+                    float v = y[e];
+                    if (p.reverse) {
+                        if (p.wmat && p.an_bias) v = v * p.an_escale[ci] - p.an_bias[ci];
+                        else if (!p.wmat && p.an_bias) v = v * p.an_escale[ci] - p.an_bias[ci];
+                    } else if (p.h_ft) {
+                        v = (v + bsh[k][e]) * sigmoid_scale(bsr[k][e], eps);
+                    }
+                    zo[(long long)ci * HW] = v;
+                }
+            }
+        }
+        BFSR_TRACE(14)
+        __syncthreads();                                        // barrier 6: sX (= the hid / z1 region) is free for the next tile's staging
     }
 #undef BFSR_SIX32
 }
@@ -469,6 +646,14 @@ int launch_step(const BfsrCouplingStepArgs& a, hipStream_t st)
 }
 
 }  // namespace
+
+#ifdef BFSR_STEP_TRACE
+extern "C" int bfsr_debug_step_trace(void* buf)
+{
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(buf);
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_step_trace), &q, sizeof(q));
+}
+#endif
 
 extern "C" long long bfsr_coupling_step_tail_packed_size(int Cout)
 {
@@ -508,10 +693,11 @@ extern "C" int bfsr_coupling_step(const BfsrCouplingStepArgs* a, void* stream)
     if (a->an_bias && !a->an_escale) return -1;
     if ((long long)64 * a->H * a->W * 4 >= (1LL << 31)) return -1;
     {   // a tile reads the z1 halo its neighbours rewrite: in-place operation is a race, not an option
-        const long long span = ((long long)(a->B - 1) * (a->z_in_bs > a->z_out_bs ? a->z_in_bs : a->z_out_bs) + (long long)a->C * a->H * a->W) * 4;
+        const long long span_i = ((long long)(a->B - 1) * a->z_in_bs + (long long)a->C * a->H * a->W) * 4;
+        const long long span_o = ((long long)(a->B - 1) * a->z_out_bs + (long long)a->C * a->H * a->W) * 4;
         const char* i0 = reinterpret_cast<const char*>(a->z_in);
         const char* o0 = reinterpret_cast<const char*>(a->z_out);
-        if (i0 < o0 + span && o0 < i0 + span) return -1;
+        if (i0 < o0 + span_o && o0 < i0 + span_i) return -1;
     }
     switch (a->C) {
         case 12: return launch_step<1, 12>(*a, st);

@@ -276,9 +276,11 @@ class SRFlowEngine(object):
                     #  tail it is 0.6-1.0 ms faster per cfg2 step, A/B on one box -> FUSED_COUPLING_C = (12, 24))
                     st.fused = (C in FUSED_COUPLING_C and w0.shape[0] == 64 and hasattr(ops, "coupling_head")
                                 and getattr(ops, "conv_mode", "f32") == "x3" and os.environ.get("BFSR_COUPLING", "fused") != "unfused")
-                    # default: ONE kernel per step (coupling_step.hip, hid stays in LDS); BFSR_COUPLING=pair keeps head + tail
+                    # BFSR_COUPLING=step: ONE kernel per step (coupling_step.hip, hid stays in LDS) -- correct and tested, but measured
+                    # SLOWER than the pair at every level (393 vs 351 us at C = 12 @ 8x320^2, 214 vs 152 us at C = 24 @ 8x160^2:
+                    # lock-step phases leave the matrix pipe idle 55 % of a tile, profiles/r03_step_trace.txt), so it is opt-in
                     st.step = None
-                    if st.fused and hasattr(ops, "coupling_step") and os.environ.get("BFSR_COUPLING", "fused") != "pair":
+                    if st.fused and hasattr(ops, "coupling_step") and os.environ.get("BFSR_COUPLING", "fused") == "step":
                         st.step = ops.pack_coupling_step(w0[:, :cn].contiguous(), sd[a + "2.weight"], sd[a + "0.actnorm.bias"],
                                                          torch.exp(sd[a + "0.actnorm.logs"]), sd[a + "2.actnorm.bias"],
                                                          torch.exp(sd[a + "2.actnorm.logs"]), sd[a + "4.weight"], sd[a + "4.bias"],

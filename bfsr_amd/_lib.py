@@ -61,7 +61,7 @@ class BfsrCouplingHeadArgs(C.Structure):
         ("pre_aff", C.c_void_p), ("pre_aff_bs", C.c_longlong),
         ("w", C.c_void_p), ("epi0", C.c_void_p), ("epi2", C.c_void_p),
         ("hid", C.c_void_p), ("hid_bs", C.c_longlong),
-        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("hid_fmt", C.c_int),
     ]
 
 
@@ -89,7 +89,7 @@ class BfsrCouplingTailArgs(C.Structure):
         ("h_ft", C.c_void_p), ("h_ft_bs", C.c_longlong),
         ("wmat", C.c_void_p), ("an_bias", C.c_void_p), ("an_escale", C.c_void_p),
         ("B", C.c_int), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("reverse", C.c_int),
-        ("eps", C.c_float),
+        ("eps", C.c_float), ("hid_fmt", C.c_int),
     ]
 
 

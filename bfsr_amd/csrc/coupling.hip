@@ -87,7 +87,7 @@ __global__ __launch_bounds__(512, 4) void coupling_tail_kernel(BfsrCouplingTailA
         const int r = upos[i] / PW, c = upos[i] - r * PW;
         const int gy = y0 + r - 1, gx = x0 + c - 1;
         const bool ok = u < NU && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        voff[i] = ok ? (unsigned)(gy * W + gx) * 4u : OOB;
+        voff[i] = ok ? (unsigned)(gy * W + gx) * (p.hid_fmt ? 32u : 4u) : OOB;
     }
     const unsigned cs_bytes = (unsigned)(HW * 4);
 
@@ -102,11 +102,22 @@ __global__ __launch_bounds__(512, 4) void coupling_tail_kernel(BfsrCouplingTailA
     float vin[PPT][8];
     uint4 vw[WV];
     auto load_chunk = [&](int k) {
+        if (p.hid_fmt) {                                     // octet-major hid: a staging unit is 32 contiguous bytes
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                const unsigned so = (unsigned)(k * 2 + uoct[i]) * (cs_bytes * 8u);
+                const float4 a = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[i], so, 0));
+                const float4 c = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[i] + 16u, so, 0));
+                vin[i][0] = a.x; vin[i][1] = a.y; vin[i][2] = a.z; vin[i][3] = a.w;
+                vin[i][4] = c.x; vin[i][5] = c.y; vin[i][6] = c.z; vin[i][7] = c.w;
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < PPT; ++i)
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 vin[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff[i], (unsigned)(k * CK + uoct[i] * 8 + e) * cs_bytes, 0));
+        }
 #pragma unroll
         for (int i = 0; i < WV; ++i)
             vw[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(tid + i * 512) * 16u, (unsigned)k * (unsigned)W_B, 0));
@@ -359,24 +370,40 @@ __global__ __launch_bounds__(512, 1) void coupling_head_kernel(BfsrCouplingHeadA
     ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[1], B_[0], ACC_, 0, 0, 0);                                \
     ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[0], B_[1], ACC_, 0, 0, 0);                                \
     ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[0], B_[0], ACC_, 0, 0, 0);
-        // ---- 3x3: chunk j = units (2j, 2j+1); unit u = (tap u / NO, octet u % NO); lanes 0-31 take unit 2j, lanes 32-63 unit 2j+1
-        // (not unrolled: a fully unrolled loop lets the compiler hoist every chunk's 9 fragment reads and spill)
-#pragma unroll 1
-        for (int j = 0; j < NC1; ++j) {
-            const int u0 = 2 * j, u1 = (2 * j + 1 < NU) ? 2 * j + 1 : 2 * j;  // a missing second unit re-reads the first (its weights are 0)
-            const int t0 = u0 / NO, o0 = u0 % NO, t1 = u1 / NO, o1 = u1 % NO;
-            const int a0 = (o0 * 3 * NPOS + (t0 / 3) * PW + (t0 % 3)) * 16, a1 = (o1 * 3 * NPOS + (t1 / 3) * PW + (t1 % 3)) * 16;
-            const unsigned char* bp = sZ + (lhi ? a1 : a0) + (wave * PW + l31) * 16;
-            bf16x8 bf[3], af[2][3];
+        // ---- 3x3: chunk j = units (2j, 2j+1); unit u = (tap u / NO, octet u % NO); lanes 0-31 take unit 2j, lanes 32-63 unit 2j+1.
+        // MFMA operand discipline (found with coupling_step.hip, tools/determinism_stress.py: this kernel at C = 24 gave 1 differing
+        // launch in 30): a register that an MFMA reads as SrcA / SrcB stays ALLOCATED (BFSR_KEEP, pinned behind a sched_barrier) until
+        // the wave has issued a further chunk of MFMAs, and is only then reloaded -- two fragment sets alternate.  hipcc recycles a
+        // dead fragment register at once (next ds_read destination, VALU temporary), and with two waves sharing the SIMD's matrix
+        // pipe a queued MFMA was observed to read the NEW contents for part of its columns.
+#define BFSR_KEEP(X_) asm volatile("" :: "v"(X_))
+        bf16x8 fb[2][3], fa[2][2][3];
+        {
+            auto frags = [&](int j, bf16x8 (&bf)[3], bf16x8 (&af)[2][3]) {
+                const int u0 = 2 * j, u1 = (2 * j + 1 < NU) ? 2 * j + 1 : 2 * j;  // a missing second unit re-reads the first (its weights are 0)
+                const int t0 = u0 / NO, o0 = u0 % NO, t1 = u1 / NO, o1 = u1 % NO;
+                const int a0 = (o0 * 3 * NPOS + (t0 / 3) * PW + (t0 % 3)) * 16, a1 = (o1 * 3 * NPOS + (t1 / 3) * PW + (t1 % 3)) * 16;
+                const unsigned char* bp = sZ + (lhi ? a1 : a0) + (wave * PW + l31) * 16;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) bf[pl] = *reinterpret_cast<const bf16x8*>(bp + pl * NPOS * 16);
+                for (int pl = 0; pl < 3; ++pl) bf[pl] = *reinterpret_cast<const bf16x8*>(bp + pl * NPOS * 16);
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    af[m][pl] = *reinterpret_cast<const bf16x8*>(sW0 + (((j * 3 + pl) * 2 + lhi) * 64 + m * 32 + l31) * 16);
+                    for (int pl = 0; pl < 3; ++pl)
+                        af[m][pl] = *reinterpret_cast<const bf16x8*>(sW0 + (((j * 3 + pl) * 2 + lhi) * 64 + m * 32 + l31) * 16);
+            };
+            frags(0, fb[0], fa[0]);
 #pragma unroll
-            for (int m = 0; m < 2; ++m) { BFSR_SIX(acc[m], af[m], bf) }
+            for (int j = 0; j < NC1; ++j) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) { BFSR_SIX(acc[m], fa[j & 1][m], fb[j & 1]) }
+                __builtin_amdgcn_sched_barrier(0);
+                if (j >= 1) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) { BFSR_KEEP(fb[(j - 1) & 1][pl]); BFSR_KEEP(fa[(j - 1) & 1][0][pl]); BFSR_KEEP(fa[(j - 1) & 1][1][pl]); }
+                }
+                if (j + 1 < NC1) frags(j + 1, fb[(j + 1) & 1], fa[(j + 1) & 1]);
+            }
         }
         __syncthreads();                                    // the z1 tile may be overwritten by the next iteration
         // ---- epilogue 1 in registers: + pre_aff, ActNorm, ReLU; the result IS the B operand of the 1x1 (K order = accumulator order)
@@ -397,42 +424,93 @@ __global__ __launch_bounds__(512, 1) void coupling_head_kernel(BfsrCouplingHeadA
                     split3(v, h, mm, l);
                     b2[m * 2 + hf][0][e] = h; b2[m * 2 + hf][1][e] = mm; b2[m * 2 + hf][2][e] = l;
                 }
+        __builtin_amdgcn_sched_barrier(0);                  // E1 has read both accumulators: the 3x3's last MFMAs are complete
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) { BFSR_KEEP(fb[(NC1 - 1) & 1][pl]); BFSR_KEEP(fa[(NC1 - 1) & 1][0][pl]); BFSR_KEEP(fa[(NC1 - 1) & 1][1][pl]); }
         if (t + G < ntiles) prefetch_pre(t + G);            // ... and its hoisted partial under the 1x1 and the stores
         f32x16 acc2[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[m][r] = 0.f;
+        {
+            auto load_a2 = [&](int c, bf16x8 (&af)[2][3]) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            bf16x8 af[2][3];
+                for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+                    for (int pl = 0; pl < 3; ++pl)
+                        af[m][pl] = *reinterpret_cast<const bf16x8*>(sW2 + (((c * 3 + pl) * 2 + lhi) * 64 + m * 32 + l31) * 16);
+            };
+            load_a2(0, fa[0]);
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    af[m][pl] = *reinterpret_cast<const bf16x8*>(sW2 + (((c * 3 + pl) * 2 + lhi) * 64 + m * 32 + l31) * 16);
+            for (int c = 0; c < 4; ++c) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m) { BFSR_SIX(acc2[m], af[m], b2[c]) }
-            __builtin_amdgcn_sched_barrier(0);              // keep the fragment reads of chunk c+1 behind this chunk's MFMAs
+                for (int m = 0; m < 2; ++m) { BFSR_SIX(acc2[m], fa[c & 1][m], b2[c]) }
+                __builtin_amdgcn_sched_barrier(0);
+                if (c >= 1) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) { BFSR_KEEP(fa[(c - 1) & 1][0][pl]); BFSR_KEEP(fa[(c - 1) & 1][1][pl]); BFSR_KEEP(b2[c - 1][pl]); }
+                }
+                if (c + 1 < 4) load_a2(c + 1, fa[(c + 1) & 1]);
+            }
         }
 #undef BFSR_SIX
         const int gy = y0 + wave, gx = x0 + l31;
         {
             const float4* __restrict__ e2 = reinterpret_cast<const float4*>(p.epi2);
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.hid + (long long)b * p.hid_bs, 0, (unsigned)(64 * HW * 4), 0x00020000);
-            const unsigned vo = (gy < H && gx < W) ? (unsigned)(((long long)gy * W + gx + 4LL * lhi * HW) * 4) : OOB;     // out-of-image lanes: dropped
+            if (p.hid_fmt == 0) {
+                const unsigned vo = (gy < H && gx < W) ? (unsigned)(((long long)gy * W + gx + 4LL * lhi * HW) * 4) : OOB;     // out-of-image lanes: dropped
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ch = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    const float4 q = e2[ch];
-                    const float v = (acc2[m][r] + q.x) * q.y;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v > 0.f ? v : 0.f), rs, vo,
-                                                          (unsigned)((m * 32 + (r & 3) + 8 * (r >> 2)) * HW * 4), 0);
+                    for (int r = 0; r < 16; ++r) {
+                        const int ch = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                        const float4 q = e2[ch];
+                        const float v = (acc2[m][r] + q.x) * q.y;
+#ifdef BFSR_HEAD_NOSTORE
+                        if (r != 0) { asm volatile("" :: "v"(v)); continue; }      // timing experiment: 2 of 32 stores per lane
+#endif
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v > 0.f ? v : 0.f), rs, vo,
+                                                              (unsigned)((m * 32 + (r & 3) + 8 * (r >> 2)) * HW * 4), 0);
+                    }
+            } else {
+                // octet-major hid [8][H][W][8]: after the epilogue v_permlane32_swap pairs the half-waves so that every lane holds two
+                // complete channel octets of its pixel per row tile (as in conv_x3s.hip) = 32 contiguous bytes each: 8 x 16-byte
+                // stores per lane instead of 32 x 4-byte ones (the 4-byte form cost 55 of the kernel's 199 us at 8 x 320 x 320,
+                // tools/exp/head_bench.py), and a half-wave writes 1 KiB contiguous
+                const unsigned vo = (gy < H && gx < W) ? (unsigned)(((long long)gy * W + gx) * 32) : OOB;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    float u[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float4 q = e2[m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi];
+                        const float v = (acc2[m][r] + q.x) * q.y;
+                        u[r] = v > 0.f ? v : 0.f;
+                    }
+#pragma unroll
+                    for (int qd = 0; qd < 2; ++qd) {
+                        float o[8];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float lo = u[8 * qd + i], hi = u[8 * qd + 4 + i];
+                            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+                            o[i] = lo; o[4 + i] = hi;
+                        }
+                        const int oct = m * 4 + qd * 2 + lhi;          // channels 8*oct .. 8*oct+7 of this lane's pixel
+                        const unsigned so = (unsigned)oct * (unsigned)(HW * 32);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, make_float4(o[0], o[1], o[2], o[3])), rs, vo, so, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, make_float4(o[4], o[5], o[6], o[7])), rs, vo + 16u, so, 0);
+                    }
                 }
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);                  // the epilogue has read both accumulators: the 1x1's last MFMAs are complete
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) { BFSR_KEEP(fa[1][0][pl]); BFSR_KEEP(fa[1][1][pl]); BFSR_KEEP(b2[3][pl]); }
     }
+#undef BFSR_KEEP
 }
 
 template <int NO>
@@ -552,6 +630,8 @@ extern "C" int bfsr_coupling_head(const BfsrCouplingHeadArgs* a, void* stream)
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (!a || !a->z || !a->pre_aff || !a->w || !a->epi0 || !a->epi2 || !a->hid) return -1;
     if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cz <= 0 || a->Cz > 16) return -1;
+    if (a->hid_fmt != 0 && a->hid_fmt != 1) return -1;
+    if (a->hid_fmt == 1 && ((reinterpret_cast<unsigned long long>(a->hid) & 15) || (a->hid_bs & 3))) return -1;
     return a->Cz <= 8 ? launch_head<1>(*a, st) : launch_head<2>(*a, st);
 }
 
@@ -562,6 +642,8 @@ extern "C" int bfsr_coupling_tail(const BfsrCouplingTailArgs* a, void* stream)
     if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cin != 64) return -1;
     if (a->an_bias && !a->an_escale) return -1;
     if ((long long)a->Cin * a->H * a->W * 4 >= (1LL << 31)) return -1;
+    if (a->hid_fmt != 0 && a->hid_fmt != 1) return -1;
+    if (a->hid_fmt == 1 && ((reinterpret_cast<unsigned long long>(a->hid) & 15) || (a->hid_bs & 3))) return -1;
     switch (a->C) {
         case 12: return launch_tail<12, 64>(*a, st);
         case 24: return launch_tail<24, 64>(*a, st);

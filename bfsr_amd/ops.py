@@ -567,8 +567,10 @@ class HipOps(object):
             return e.to(self.device)
         return packed.to(self.device), epi(shift0, scale0), epi(shift2, scale2), Cz
 
-    def coupling_head(self, z, packed, pre_aff, hid):
-        """hid [B,64,H,W] = relu(AN2(W2 . relu(AN0(conv3x3(z[:, :Cz]) + pre_aff)))) on the 3xBF16 split, 1x1 chained in registers."""
+    def coupling_head(self, z, packed, pre_aff, hid, hid_fmt=0):
+        """hid [B,64,H,W] = relu(AN2(W2 . relu(AN0(conv3x3(z[:, :Cz]) + pre_aff)))) on the 3xBF16 split, 1x1 chained in registers.
+        hid_fmt=1: the same buffer holds hid octet-major ([B][8][H][W][8]: what coupling_tail(hid_fmt=1) reads; 4x fewer, wider
+        stores and loads) -- a private layout between the two kernels."""
         wts, e0, e2, Cz = packed
         a = _lib.BfsrCouplingHeadArgs()
         a.z, a.z_bs, Cc, H, W = _view(z, "coupling_head.z")
@@ -576,7 +578,7 @@ class HipOps(object):
         a.hid, a.hid_bs, c2, h2, w2 = _view(hid, "coupling_head.hid")
         assert Cc >= Cz and (c1, h1, w1) == (64, H, W) and (c2, h2, w2) == (64, H, W)
         a.Cz, a.w, a.epi0, a.epi2 = Cz, wts.data_ptr(), e0.data_ptr(), e2.data_ptr()
-        a.B, a.H, a.W = z.shape[0], H, W
+        a.B, a.H, a.W, a.hid_fmt = z.shape[0], H, W, int(hid_fmt)
         key = ("coupling_head", Cz, z.shape[0], H, W)
         _lib.check(self._launch(key, lambda: self.lib.bfsr_coupling_head(C.byref(a), self._stream())), "coupling_head")
         return hid
@@ -592,7 +594,7 @@ class HipOps(object):
         _lib.check(self.lib.bfsr_pack_coupling_tail(w.data_ptr(), Cin, Cout, packed.data_ptr()), "pack_coupling_tail")
         return packed.to(self.device), self.vec(bias), self.vec(post_scale), Cout
 
-    def coupling_tail(self, hid, packed, z_in, z_out, reverse, h_ft=None, w=None, an_bias=None, an_escale=None, eps=1e-4):
+    def coupling_tail(self, hid, packed, z_in, z_out, reverse, h_ft=None, w=None, an_bias=None, an_escale=None, eps=1e-4, hid_fmt=0):
         """h_aff = Conv2dZeros(hid), then the pointwise chain of flow_pointwise(z_in, z_out, reverse, h_aff=h_aff, h_ft, w, an_*)."""
         wts, bias, ps, Cout = packed
         a = _lib.BfsrCouplingTailArgs()
@@ -605,7 +607,7 @@ class HipOps(object):
             assert (c, h, ww) == (2 * Cc, H, W)
         a.w, a.bias, a.post_scale = wts.data_ptr(), bias.data_ptr(), ps.data_ptr()
         a.wmat, a.an_bias, a.an_escale = _ptr(w), _ptr(an_bias), _ptr(an_escale)
-        a.B, a.C, a.H, a.W, a.reverse, a.eps = z_in.shape[0], Cc, H, W, int(bool(reverse)), eps
+        a.B, a.C, a.H, a.W, a.reverse, a.eps, a.hid_fmt = z_in.shape[0], Cc, H, W, int(bool(reverse)), eps, int(hid_fmt)
         key = ("coupling_tail", int(bool(reverse)), Cc, z_in.shape[0], H, W)
         _lib.check(self._launch(key, lambda: self.lib.bfsr_coupling_tail(C.byref(a), self._stream())), "coupling_tail(C=%d)" % Cc)
         return z_out

@@ -416,7 +416,12 @@ class SRFlowEngine(object):
         # short kernels with the matrix pipe ~40 % busy and leave room on the chip, so the hoisted convs of the other levels go
         # to a side stream that forks after the first level's hoists have been enqueued and joins at the first use of a level
         # (`_await`).  BFSR_OVERLAP=0 disables it.
-        use_side = (getattr(getattr(ops, "device", None), "type", "cpu") == "cuda" and os.environ.get("BFSR_OVERLAP", "1") != "0")
+        # ... unless the batch already fills the chip: at BASELINE config 4 (64 crops of 96x96 on one GPU) the side stream only adds
+        # contention (867 -> 848 ms per step without it, profiles/r03_cfg4_bench_no_overlap.json; config 2, 8 x 160x160: 125 -> 121 ms
+        # WITH it).  BFSR_OVERLAP=0 / 1 forces either way.
+        ov = os.environ.get("BFSR_OVERLAP", "auto")
+        use_side = (getattr(getattr(ops, "device", None), "type", "cpu") == "cuda"
+                    and (ov == "1" or (ov not in ("0",) and B * h * w <= 300000)))
         main_stream = torch.cuda.current_stream(ops.device) if use_side else None
         cond = {}
         order = sorted(self.hoist.items(), reverse=bool(reverse))
@@ -550,8 +555,8 @@ class SRFlowEngine(object):
                             z = ops.coupling_step(z, self._pingpong(z, "enc%d" % ly.level), st.step, pre_k, False, **kw)
                         else:
                             hid = ws.get("hid_enc%d" % ly.level, B, 64, H, W)
-                            ops.coupling_head(z, st.head, pre_k, hid)
-                            ops.coupling_tail(hid, st.tail, z, z, False, **kw)
+                            ops.coupling_head(z, st.head, pre_k, hid, hid_fmt=1)          # hid: private octet-major layout
+                            ops.coupling_tail(hid, st.tail, z, z, False, hid_fmt=1, **kw)
                     else:
                         pending = self._self_cond(st, z, cnd, k, "enc%d" % ly.level)
                         if logdet is not None:
@@ -613,8 +618,8 @@ class SRFlowEngine(object):
                             z = ops.coupling_step(z, self._pingpong(z, "dec%d" % ly.level), st.step, pre_k, True, **kw)
                         else:
                             hid = ws.get("hid_dec%d" % ly.level, z.shape[0], 64, H, W)
-                            ops.coupling_head(z, st.head, pre_k, hid)
-                            ops.coupling_tail(hid, st.tail, z, z, True, **kw)
+                            ops.coupling_head(z, st.head, pre_k, hid, hid_fmt=1)
+                            ops.coupling_tail(hid, st.tail, z, z, True, hid_fmt=1, **kw)
                     else:
                         h_aff = self._self_cond(st, z, cnd, k, "dec%d" % ly.level)
                         if logdet is not None:

@@ -215,6 +215,8 @@ typedef struct BfsrCouplingHeadArgs {
     const float* epi0; const float* epi2;
     float* hid; long long hid_bs;
     int B, H, W;
+    int hid_fmt;                                      /* 0: hid [B,64,H,W]; 1: octet-major [B][8][H][W][8] (32 B per pixel and channel
+                                                         octet: 8 x 16-byte stores per lane instead of 32 x 4-byte ones) */
 } BfsrCouplingHeadArgs;
 typedef struct BfsrCouplingTailArgs {
     const float* hid; long long hid_bs; int Cin;      /* Cin = 64 */
@@ -225,6 +227,7 @@ typedef struct BfsrCouplingTailArgs {
     const float* wmat; const float* an_bias; const float* an_escale;
     int B, C, H, W, reverse;
     float eps;
+    int hid_fmt;                                      /* layout of hid, as BfsrCouplingHeadArgs.hid_fmt */
 } BfsrCouplingTailArgs;
 int bfsr_coupling_head(const BfsrCouplingHeadArgs* a, void* stream);
 int bfsr_coupling_tail(const BfsrCouplingTailArgs* a, void* stream);

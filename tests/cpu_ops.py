@@ -350,18 +350,29 @@ class CpuOps(object):
         return (f(w0_z1), f(w2).reshape(64, 64, 1, 1), f(shift0).reshape(-1), f(scale0).reshape(-1), f(shift2).reshape(-1),
                 f(scale2).reshape(-1))
 
-    def coupling_head(self, z, packed, pre_aff, hid):
+    @staticmethod
+    def _hid_octets(hid, inverse=False):
+        """[B,64,H,W] values <-> the same buffer in the octet-major layout [B][8][H][W][8] of hid_fmt=1."""
+        B, Cc, H, W = hid.shape
+        if inverse:
+            return hid.reshape(B, Cc // 8, H, W, 8).permute(0, 1, 4, 2, 3).reshape(B, Cc, H, W)
+        return hid.reshape(B, Cc // 8, 8, H, W).permute(0, 1, 3, 4, 2).reshape(B, Cc, H, W)
+
+    def coupling_head(self, z, packed, pre_aff, hid, hid_fmt=0):
         w0, w2, s0, c0, s2, c2 = packed
         t = F.relu((F.conv2d(z[:, :w0.shape[1]], w0, None, 1, 1) + pre_aff + _cv(s0)) * _cv(c0))
-        hid.copy_(F.relu((F.conv2d(t, w2) + _cv(s2)) * _cv(c2)))
+        v = F.relu((F.conv2d(t, w2) + _cv(s2)) * _cv(c2))
+        hid.copy_(self._hid_octets(v) if hid_fmt else v)
         return hid
 
     def pack_coupling_tail(self, w4, bias, post_scale):
         f = lambda t: t.detach().to(torch.float32).clone()
         return f(w4), f(bias).reshape(-1), f(post_scale).reshape(-1), w4.shape[0]
 
-    def coupling_tail(self, hid, packed, z_in, z_out, reverse, h_ft=None, w=None, an_bias=None, an_escale=None, eps=1e-4):
+    def coupling_tail(self, hid, packed, z_in, z_out, reverse, h_ft=None, w=None, an_bias=None, an_escale=None, eps=1e-4, hid_fmt=0):
         w4, b4, ps, _ = packed
+        if hid_fmt:
+            hid = self._hid_octets(hid, inverse=True)
         h_aff = (F.conv2d(hid, w4, None, 1, 1) + _cv(b4)) * _cv(ps)
         return self.flow_pointwise(z_in, z_out, reverse, h_aff=h_aff, h_ft=h_ft, w=w, an_bias=an_bias, an_escale=an_escale, eps=eps)
 

@@ -248,6 +248,9 @@ def test_coupling_head(hip, Cz, hw):
     ref = CPU.coupling_head(z, CPU.pack_coupling_head(w0, w2, s0, c0, s2, c2), pre, torch.empty(B, 64, H, W))
     out = hip.coupling_head(hip.to_device(z), hip.pack_coupling_head(w0, w2, s0, c0, s2, c2), hip.to_device(pre), hip.empty(B, 64, H, W))
     close(out, ref, 2e-5, "coupling_head Cz=%d" % Cz)
+    # the private octet-major layout of hid ([B][8][H][W][8], wide stores): the same values, permuted
+    o1 = hip.coupling_head(hip.to_device(z), hip.pack_coupling_head(w0, w2, s0, c0, s2, c2), hip.to_device(pre), hip.empty(B, 64, H, W), hid_fmt=1)
+    assert torch.equal(CPU._hid_octets(o1.cpu(), inverse=True), out.cpu()), "hid_fmt=1 must hold the values of hid_fmt=0"
 
 
 @pytest.mark.parametrize("C", [12, 24])
@@ -269,6 +272,9 @@ def test_coupling_tail(hip, C, reverse, hw):
         dkw = {k: (hip.vec(v) if v.dim() <= 2 else hip.to_device(v)) for k, v in kw.items()}
         hip.coupling_tail(hip.to_device(hid), hip.pack_coupling_tail(w4, b4, ps), zd, zd, reverse, **dkw)
         close(zd, ref, 2e-5, "coupling_tail C=%d rev=%d" % (C, reverse))
+        z1 = hip.to_device(z).clone()             # hid handed over in the octet-major layout: bit-identical result
+        hip.coupling_tail(hip.to_device(CPU._hid_octets(hid).contiguous()), hip.pack_coupling_tail(w4, b4, ps), z1, z1, reverse, hid_fmt=1, **dkw)
+        assert torch.equal(z1.cpu(), zd.cpu()), "coupling_tail hid_fmt=1 differs from hid_fmt=0"
 
 
 @pytest.mark.parametrize("C", [12, 24])

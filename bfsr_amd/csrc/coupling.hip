@@ -19,6 +19,7 @@
 // Measured motivation (profiles/r02_c_keys_x3.txt, level 1 of BASELINE config 2, per step): fused 3x3+1x1 on fp32 MFMA 407 us
 // (matrix pipe 38 % busy: the fp32 MFMA is 16x slower than bf16), Conv2dZeros 64->12 322 us, pointwise 50 us.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <type_traits>
 #include "../../include/bfsr_hip.h"
 #include "launch_util.h"
@@ -126,21 +127,26 @@ __global__ __launch_bounds__(512, 4) void coupling_tail_kernel(BfsrCouplingTailA
     const unsigned char* bBase = sIn + ((lq & 1) * NPOS + wave * PW + l15) * 16;
     const unsigned char* aBase = sW + (lq * MW + l15) * 16;
     const int th = lq >> 1;
-    // operands of the pointwise chain (one thread per pixel, tid < TH*TW): z and the feature-conditional (shift, raw scale) pairs are
-    // loaded while the LAST K chunk is in the matrix pipe (the staging registers are free by then), not after the conv
-    const int py = y0 + (tid >> 5), px = x0 + (tid & 31);
-    const bool pw_on = tid < TH * TW && py < H && px < W;
-    const long long pix = (long long)py * W + px;
-    float x[C], fsh[C], fsr[C];
+    // operands of phase A of the pointwise chain: work item i = tid + 512 j = (channel i / 256, pixel i % 256) -- every thread takes
+    // part (one thread per pixel kept four waves busy for ~10k cycles while the other four idled).  Loaded while the LAST K chunk is
+    // in the matrix pipe (the staging registers are free by then), not after the conv.
+    constexpr int NPXT = TH * TW, NIA = C * NPXT / 512;
+    static_assert(C * NPXT % 512 == 0, "C * 256 items over 512 threads");
+    float pz[NIA], psh[NIA], psr[NIA];
+    const int ipy = y0 + ((tid & 255) >> 5), ipx = x0 + (tid & 31);            // item pixel: i % 256 = tid % 256 for every j
+    const bool ion = ipy < H && ipx < W;
+    const long long ipix = (long long)ipy * W + ipx;
     auto prefetch_pw = [&]() {
-        if (!pw_on) return;
-        const float* zi = p.z_in + (long long)b * p.z_in_bs + pix;
+        const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.z_in + (long long)b * p.z_in_bs), 0, (unsigned)(C * HW * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.h_ft ? p.h_ft + (long long)b * p.h_ft_bs : p.z_in), 0,
+                                                                            p.h_ft ? (unsigned)(2 * C * HW * 4) : 0u, 0x00020000);
+        const unsigned vo = ion ? (unsigned)(ipix * 4) : OOB;
 #pragma unroll
-        for (int c = 0; c < C; ++c) x[c] = zi[(long long)c * HW];
-        if (p.h_ft) {
-            const float* hf = p.h_ft + (long long)b * p.h_ft_bs + pix;
-#pragma unroll
-            for (int c = 0; c < C; ++c) { fsh[c] = hf[(long long)(2 * c) * HW]; fsr[c] = hf[(long long)(2 * c + 1) * HW]; }
+        for (int j = 0; j < NIA; ++j) {
+            const int c = 2 * j + (tid >> 8);                                   // channel of item tid + 512 j
+            pz[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, vo, (unsigned)(c * HW * 4), 0));
+            psh[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, vo, (unsigned)((2 * c) * HW * 4), 0));
+            psr[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, vo, (unsigned)((2 * c + 1) * HW * 4), 0));
         }
     };
     load_chunk(0);
@@ -202,51 +208,83 @@ __global__ __launch_bounds__(512, 4) void coupling_tail_kernel(BfsrCouplingTailA
         }
     __syncthreads();
 
-    // ---- pointwise chain, one thread per pixel (tile row = tid / 32): identical arithmetic to flow_pointwise_kernel
-    if (!pw_on) return;
+    // ---- pointwise chain on all threads, two phases through LDS: the arithmetic per element is flow_pointwise_kernel's.
+    // Phase A, item (channel c, pixel q): reverse: z2 = z2/scale - shift, then z = z/scaleFt - shiftFt;
+    //                                     forward: z2 = (z2 + shift)*scale, then the NEXT step's ActNorm          -> sX[c][q]
+    float* sX = sH + CO2 * NPXT;
     const float eps = p.eps;
     const bool hf = p.h_ft != nullptr;
-    const float* ha = sH + tid;
-    float* zo = p.z_out + (long long)b * p.z_out_bs + pix;
-    if (p.reverse) {
+    {
+        const int q = tid & 255;
 #pragma unroll
-        for (int j = 0; j < CC; ++j) x[CN + j] = x[CN + j] / sigmoid_scale(ha[(2 * j + 1) * (TH * TW)], eps) - ha[(2 * j) * (TH * TW)];
-        if (hf) {
-#pragma unroll
-            for (int c = 0; c < C; ++c) x[c] = x[c] / sigmoid_scale(fsr[c], eps) - fsh[c];
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < CC; ++j) x[CN + j] = (x[CN + j] + ha[(2 * j) * (TH * TW)]) * sigmoid_scale(ha[(2 * j + 1) * (TH * TW)], eps);
-        if (p.an_bias) {
-#pragma unroll
-            for (int c = 0; c < C; ++c) x[c] = (x[c] + p.an_bias[c]) * p.an_escale[c];
+        for (int j = 0; j < NIA; ++j) {
+            const int c = 2 * j + (tid >> 8);
+            float v = pz[j];
+            if (c >= CN) {
+                const float sh = sH[(2 * (c - CN)) * NPXT + q], sr = sH[(2 * (c - CN) + 1) * NPXT + q];
+                v = p.reverse ? v / sigmoid_scale(sr, eps) - sh : (v + sh) * sigmoid_scale(sr, eps);
+            }
+            if (p.reverse) {
+                if (hf) v = v / sigmoid_scale(psr[j], eps) - psh[j];
+            } else if (p.an_bias) {
+                v = (v + p.an_bias[c]) * p.an_escale[c];
+            }
+            sX[c * NPXT + q] = v;
         }
     }
-    if (p.wmat) {
-        const float* __restrict__ w = p.wmat;
+    // Phase B, item (pixel q, group g of 6 output channels): 256 items per group = 4 waves, so g is wave-uniform and W comes through
+    // scalar loads.  y = W x; reverse: ActNorm inverse; forward: the next step's feature-conditional affine.
+    constexpr int NGRP = C / 6, NIB = NGRP / 2;
+    float bsh[NIB][6], bsr[NIB][6];
+    if (!p.reverse && hf) {
+        const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.h_ft + (long long)b * p.h_ft_bs), 0, (unsigned)(2 * C * HW * 4), 0x00020000);
+        const unsigned vo = ion ? (unsigned)(ipix * 4) : OOB;
 #pragma unroll
-        for (int i = 0; i < C; ++i) {
-            float y = 0.f;
+        for (int k = 0; k < NIB; ++k) {
+            const int g = 2 * k + (wave >> 2);
 #pragma unroll
-            for (int j = 0; j < C; ++j) y = fmaf(w[i * C + j], x[j], y);
-            if (p.reverse) {
-                if (p.an_bias) y = y * p.an_escale[i] - p.an_bias[i];
-            } else if (hf) {
-                y = (y + fsh[i]) * sigmoid_scale(fsr[i], eps);
+            for (int e = 0; e < 6; ++e) {
+                bsh[k][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, vo, (unsigned)((2 * (6 * g + e)) * HW * 4), 0));
+                bsr[k][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, vo, (unsigned)((2 * (6 * g + e) + 1) * HW * 4), 0));
             }
-            zo[(long long)i * HW] = y;
         }
-    } else {
+    }
+    __syncthreads();
+    if (!ion) return;
+    {
+        const int q = tid & 255;
+        float* zo = p.z_out + (long long)b * p.z_out_bs + ipix;
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            float y = x[c];
-            if (p.reverse) {
-                if (p.an_bias) y = y * p.an_escale[c] - p.an_bias[c];
-            } else if (hf) {
-                y = (y + fsh[c]) * sigmoid_scale(fsr[c], eps);
+        for (int k = 0; k < NIB; ++k) {
+            const int g = 2 * k + (wave >> 2);
+            float y[6];
+            if (p.wmat) {
+                float xv[C];
+#pragma unroll
+                for (int j = 0; j < C; ++j) xv[j] = sX[j * NPXT + q];
+                const float* __restrict__ w = p.wmat + (6 * g) * C;
+#pragma unroll
+                for (int e = 0; e < 6; ++e) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int j = 0; j < C; ++j) a = fmaf(w[e * C + j], xv[j], a);
+                    y[e] = a;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 6; ++e) y[e] = sX[(6 * g + e) * NPXT + q];
             }
-            zo[(long long)c * HW] = y;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                const int ci = 6 * g + e;
+                float v = y[e];
+                if (p.reverse) {
+                    if (p.an_bias) v = v * p.an_escale[ci] - p.an_bias[ci];
+                } else if (hf) {
+                    v = (v + bsh[k][e]) * sigmoid_scale(bsr[k][e], eps);
+                }
+                zo[(long long)ci * HW] = v;
+            }
         }
     }
 }
@@ -255,7 +293,7 @@ template <int C, int CIN>
 int launch_tail(const BfsrCouplingTailArgs& a, hipStream_t st)
 {
     constexpr int CO2 = 2 * (C - C / 2), MW = (CO2 + 15) / 16 * 16;
-    constexpr int LDS_K = 3 * 2 * NPOS * 16 + 3 * 5 * 4 * MW * 16, LDS_H = CO2 * TH * TW * 4;
+    constexpr int LDS_K = 3 * 2 * NPOS * 16 + 3 * 5 * 4 * MW * 16, LDS_H = (CO2 + C) * TH * TW * 4;      // h_aff tile + the phase-A tile
     constexpr int LDS = LDS_K > LDS_H ? LDS_K : LDS_H;
     static std::atomic<unsigned long long> lds_done{0};
     if (LDS > 65536 && bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&coupling_tail_kernel<C, CIN>), LDS, lds_done) != 0) return -1;
@@ -272,14 +310,17 @@ int launch_tail(const BfsrCouplingTailArgs& a, hipStream_t st)
 // once and walks its tiles in an XCD-aware order; the z1 values and the hoisted partial of tile t+1 are loaded into registers
 // while tile t is in the matrix pipe (the kernel moves 420 MB per launch at level 1 and has ~5 us of MFMA per tile, so without the
 // prefetch it is a chain of exposed HBM latencies: 410 us measured for the non-persistent form against a 105 us traffic bound).
-template <int NO>
-__global__ __launch_bounds__(512, 1) void coupling_head_kernel(BfsrCouplingHeadArgs p, int tiles_x, int tiles_xy, int ntiles)
+template <int NO, int NWV>
+__global__ __launch_bounds__(NWV * 64, 2) void coupling_head_kernel(BfsrCouplingHeadArgs p, int tiles_x, int tiles_xy, int ntiles)
 {
+    // NWV waves = NWV tile rows per workgroup.  NWV = 8: one workgroup per CU; NWV = 4: TWO independent workgroups per CU (their
+    // barriers are private, so the VALU / memory phases of one overlap the MFMA phases of the other on every SIMD)
+    constexpr int TH = NWV, NT = NWV * 64, NPOS = (TH + 2) * PW;
     constexpr int NU = 9 * NO, NC1 = (NU + 1) / 2;          // (tap, octet) units and 16-wide k-chunks of the 3x3
     constexpr int ZT = NO * 3 * NPOS * 16;                  // bytes of the x3 z1 tile: [octet][plane][pos][8]
     constexpr int W0B = NC1 * 3 * 2 * 64 * 16;              // [chunk][plane][k half][64 rows][8]
     constexpr int W2B = 4 * 3 * 2 * 64 * 16;
-    constexpr int ZU = (NO * NPOS + 511) / 512;             // staged (octet, position) units per thread
+    constexpr int ZU = (NO * NPOS + NT - 1) / NT;             // staged (octet, position) units per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char* smem = smem_raw;
     unsigned char* sZ = smem;
@@ -297,7 +338,7 @@ __global__ __launch_bounds__(512, 1) void coupling_head_kernel(BfsrCouplingHeadA
     {
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(p.w);
         uint4* dst = reinterpret_cast<uint4*>(sW0);
-        for (int i = tid; i < (W0B + W2B) / 16; i += 512) dst[i] = src[i];
+        for (int i = tid; i < (W0B + W2B) / 16; i += NT) dst[i] = src[i];
     }
 
     // ---- per-tile register prefetch: this thread's z1 units (8 channels of one staged position) and its 32 pre_aff values
@@ -308,7 +349,7 @@ __global__ __launch_bounds__(512, 1) void coupling_head_kernel(BfsrCouplingHeadA
         const float* __restrict__ zb = p.z + (long long)b * p.z_bs;
 #pragma unroll
         for (int i = 0; i < ZU; ++i) {
-            const int u = tid + i * 512;
+            const int u = tid + i * NT;
             const int o = u / NPOS, pos = u - o * NPOS;
             const int r = pos / PW, c = pos - r * PW;
             const int gy = y0 + r - 1, gx = x0 + c - 1;
@@ -344,7 +385,7 @@ __global__ __launch_bounds__(512, 1) void coupling_head_kernel(BfsrCouplingHeadA
         // ---- registers -> x3 tile in LDS (exact 3-term bf16 split)
 #pragma unroll
         for (int i = 0; i < ZU; ++i) {
-            const int u = tid + i * 512;
+            const int u = tid + i * NT;
             if (u < NO * NPOS) {
                 const int o = u / NPOS, pos = u - o * NPOS;
                 bf16x8 h8, m8, l8;
@@ -513,21 +554,22 @@ __global__ __launch_bounds__(512, 1) void coupling_head_kernel(BfsrCouplingHeadA
 #undef BFSR_KEEP
 }
 
-template <int NO>
+template <int NO, int NWV>
 int launch_head(const BfsrCouplingHeadArgs& a, hipStream_t st)
 {
-    constexpr int NC1 = (9 * NO + 1) / 2;
-    constexpr int LDS = NO * 3 * NPOS * 16 + NC1 * 3 * 2 * 64 * 16 + 4 * 3 * 2 * 64 * 16;
+    constexpr int NC1 = (9 * NO + 1) / 2, TH = NWV;
+    constexpr int LDS = NO * 3 * (NWV + 2) * PW * 16 + NC1 * 3 * 2 * 64 * 16 + 4 * 3 * 2 * 64 * 16;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static std::atomic<unsigned long long> lds_done{0};
-    if (LDS > 65536 && bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&coupling_head_kernel<NO>), LDS, lds_done) != 0) return -1;
+    if (LDS > 65536 && bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&coupling_head_kernel<NO, NWV>), LDS, lds_done) != 0) return -1;
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
     const long long ntiles = (long long)tiles_x * tiles_y * a.B;
     if (ntiles <= 0 || ntiles > 0x7fffffffLL) return -1;
     int cus = bfsr::cu_count();                             // cached per device; no silent default
     if (cus <= 0) return -1;
-    const long long grid = ntiles < cus ? ntiles : cus;     // one persistent workgroup per CU
-    hipLaunchKernelGGL(coupling_head_kernel<NO>, dim3((unsigned)grid), dim3(512), LDS, st, a, tiles_x, tiles_x * tiles_y, (int)ntiles);
+    const long long slots = (long long)cus * (8 / NWV);
+    const long long grid = ntiles < slots ? ntiles : slots; // persistent workgroups: one (NWV = 8) or two (NWV = 4) per CU
+    hipLaunchKernelGGL((coupling_head_kernel<NO, NWV>), dim3((unsigned)grid), dim3(NWV * 64), LDS, st, a, tiles_x, tiles_x * tiles_y, (int)ntiles);
     return (int)hipGetLastError();
 }
 
@@ -632,7 +674,9 @@ extern "C" int bfsr_coupling_head(const BfsrCouplingHeadArgs* a, void* stream)
     if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cz <= 0 || a->Cz > 16) return -1;
     if (a->hid_fmt != 0 && a->hid_fmt != 1) return -1;
     if (a->hid_fmt == 1 && ((reinterpret_cast<unsigned long long>(a->hid) & 15) || (a->hid_bs & 3))) return -1;
-    return a->Cz <= 8 ? launch_head<1>(*a, st) : launch_head<2>(*a, st);
+    static const int nwv = [] { const char* e = getenv("BFSR_HEAD_WAVES"); return e && atoi(e) == 4 ? 4 : 8; }();
+    if (nwv == 4) return a->Cz <= 8 ? launch_head<1, 4>(*a, st) : launch_head<2, 4>(*a, st);
+    return a->Cz <= 8 ? launch_head<1, 8>(*a, st) : launch_head<2, 8>(*a, st);
 }
 
 extern "C" int bfsr_coupling_tail(const BfsrCouplingTailArgs* a, void* stream)

@@ -45,13 +45,13 @@ for C, hw, B in ((12, 320, 8), (24, 160, 8), (12, 384, 8), (24, 192, 8)):
         fused = lambda: ops.coupling_step(z, z2, spk, pre, rev, h_ft=hf, w=wv, an_bias=bias, an_escale=es)
 
         def pair():
-            ops.coupling_head(z, hpk, pre, hid)
-            ops.coupling_tail(hid, tpk, z, z2, rev, h_ft=hf, w=wv, an_bias=bias, an_escale=es)
-        tf, tp = [], []
+            ops.coupling_head(z, hpk, pre, hid, hid_fmt=1)
+            ops.coupling_tail(hid, tpk, z, z2, rev, h_ft=hf, w=wv, an_bias=bias, an_escale=es, hid_fmt=1)
+        tf, tp, th = [], [], []
         for _ in range(rounds):
-            tf.append(timed(fused)); tp.append(timed(pair))
+            tf.append(timed(fused)); tp.append(timed(pair)); th.append(timed(lambda: ops.coupling_head(z, hpk, pre, hid, hid_fmt=1)))
         px = B * hw * hw
         alg = px * (256 + 4 * C * 4) / 1e6          # MB: pre_aff + z in + h_ft (2C) + z out
         mf, mp = float(np.median(tf)), float(np.median(tp))
-        print("C=%d %dx%d B=%d rev=%d: fused %.1f us (min %.1f) = %.2f TB/s algorithmic (%.0f MB)   head+tail %.1f us   x%.2f"
-              % (C, hw, hw, B, rev, mf, min(tf), alg / mf, alg, mp, mp / mf), flush=True)
+        print("C=%d %dx%d B=%d rev=%d: fused %.1f us (min %.1f) = %.2f TB/s algorithmic (%.0f MB)   head+tail %.1f us (head %.1f)   x%.2f"
+              % (C, hw, hw, B, rev, mf, min(tf), alg / mf, alg, mp, float(np.median(th)), mp / mf), flush=True)

@@ -115,6 +115,7 @@ class BfsrLinfMlpArgs(C.Structure):
         ("dy_neg", C.c_float), ("dy_pos", C.c_float), ("dx_neg", C.c_float), ("dx_pos", C.c_float),
         ("clamp_lo", C.c_float), ("clamp_hi", C.c_float),
         ("cy0", C.c_float), ("cy1", C.c_float), ("cx0", C.c_float), ("cx1", C.c_float),
+        ("out_fmt", C.c_int),
     ]
 
 
@@ -126,7 +127,7 @@ class BfsrLinfFlowArgs(C.Structure):
         ("lin_w", C.c_void_p), ("lin_b", C.c_void_p),
         ("B", C.c_int), ("D", C.c_int), ("layers", C.c_int), ("qh", C.c_int), ("qw", C.c_int), ("reverse", C.c_int),
         ("eps", C.c_float),
-        ("log_p", C.c_void_p), ("logdet_const", C.c_float),
+        ("log_p", C.c_void_p), ("logdet_const", C.c_float), ("ai_fmt", C.c_int),
     ]
 
 

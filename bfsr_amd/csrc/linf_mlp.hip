@@ -322,6 +322,21 @@ __global__ __launch_bounds__(NW * 64, X3 ? 2 : 4) void linf_mlp_kernel(BfsrLinfM
             for (int nt = 0; nt < 2; ++nt) {
                 const long long qq = q0 + nt * 32 + l31;
                 if (qq >= NQ) continue;
+                if (a.out_fmt == 1) {
+                    // quad-major [Cout/4][NQ][4]: accumulator registers 4g .. 4g+3 are four CONSECUTIVE output rows of this lane's
+                    // query point = one 16-byte store (the row-major form issued 16 four-byte stores per tile and half-wave-wide
+                    // 128-byte segments: 1.5x write amplification and a store-issue-bound tail, profiles/r02_pmc_traffic.json)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int co = mt * 32 + 8 * gq + 4 * lhi;
+                        if (co < a.Cout) {
+                            const float4 bq = *reinterpret_cast<const float4*>(b4 + co);
+                            *reinterpret_cast<float4*>(outb + ((long long)(co >> 2) * NQ + qq) * 4) =
+                                make_float4(acc[nt][4 * gq] + bq.x, acc[nt][4 * gq + 1] + bq.y, acc[nt][4 * gq + 2] + bq.z, acc[nt][4 * gq + 3] + bq.w);
+                        }
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
@@ -405,6 +420,9 @@ extern "C" int bfsr_linf_mlp(const BfsrLinfMlpArgs* a, int x3, void* stream)
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (!a || !a->cf || !a->coord || !a->cell || !a->phase || !a->wts || !a->bias || !a->out) return -1;
     if (a->hidden != HID || a->Cout <= 0 || a->Cout > 24 * 32 || a->B <= 0 || a->h <= 0 || a->w <= 0 || a->qh <= 0 || a->qw <= 0) return -1;
+    if (a->out_fmt != 0 && a->out_fmt != 1) return -1;
+    if (a->out_fmt == 1 && ((a->Cout & 3) || (reinterpret_cast<unsigned long long>(a->out) & 15) || (a->out_bs & 3) ||
+                            (reinterpret_cast<unsigned long long>(a->bias) & 15))) return -1;
     BfsrLinfMlpArgs c = *a;
     return x3 ? launch_mlp<true>(c, st) : launch_mlp<false>(c, st);
 }

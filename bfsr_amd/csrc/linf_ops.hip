@@ -83,6 +83,24 @@ __global__ __launch_bounds__(256) void linf_flow_kernel(BfsrLinfFlowArgs a)
     const float* xi = a.x + (long long)b * a.x_bs + q;
     const float* ai = a.ai + (long long)b * a.ai_bs + q;
     float x[D], y[D];
+    // conditioning values of one flow layer: lv[d] = raw scale, lv[D + d] = shift.  ai_fmt 1 = the quad-major layout the fused MLP
+    // kernel writes ([layers][QB quads][NQ][4], a layer's 2*D values padded to QB*4): QB 16-byte loads per layer instead of 2*D
+    // four-byte ones (the row-major form streamed at 2.4 TB/s, load-issue bound: 540 loads per query point)
+    constexpr int QB = (2 * D + 3) / 4;
+    float lv[QB * 4];
+    const float4* aq = reinterpret_cast<const float4*>(a.ai + (long long)b * a.ai_bs) + q;
+    auto load_layer = [&](int i) {
+        if (a.ai_fmt == 1) {
+#pragma unroll
+            for (int k = 0; k < QB; ++k) {
+                const float4 v = aq[(long long)(i * QB + k) * NQ];
+                lv[4 * k] = v.x; lv[4 * k + 1] = v.y; lv[4 * k + 2] = v.z; lv[4 * k + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < 2 * D; ++d) lv[d] = ai[(long long)(2 * D * i + d) * NQ];
+        }
+    };
 #pragma unroll
     for (int d = 0; d < D; ++d) x[d] = xi[(long long)d * NQ];
 
@@ -108,10 +126,11 @@ __global__ __launch_bounds__(256) void linf_flow_kernel(BfsrLinfFlowArgs a)
         float ld = a.logdet_const;
         const bool want_lp = a.log_p != nullptr;
         for (int i = 0; i < L; ++i) {
+            load_layer(i);
             linear(i, false);
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                const float sr = ai[(long long)(2 * D * i + d) * NQ], sh = ai[(long long)(2 * D * i + D + d) * NQ];
+                const float sr = lv[d], sh = lv[D + d];
                 const float sc = 1.f / (1.f + expf(-(sr + 2.f))) + a.eps;
                 x[d] = x[d] * sc + sh;
                 if (want_lp) ld += logf(sc);
@@ -142,10 +161,11 @@ __global__ __launch_bounds__(256) void linf_flow_kernel(BfsrLinfFlowArgs a)
             for (int d = 0; d < D; ++d) x[d] = y[d];
         };
         for (int i = 0; i < L; ++i) {
+            load_layer(i);
             matvec(i);
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                const float sr = ai[(long long)(2 * D * i + d) * NQ];
+                const float sr = lv[d];
                 x[d] = x[d] / (1.f / (1.f + expf(-(sr + 2.f))) + a.eps);
             }
         }
@@ -153,9 +173,10 @@ __global__ __launch_bounds__(256) void linf_flow_kernel(BfsrLinfFlowArgs a)
     } else {
         linear(L, true);
         for (int i = L - 1; i >= 0; --i) {
+            load_layer(i);
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                const float sr = ai[(long long)(2 * D * i + d) * NQ], sh = ai[(long long)(2 * D * i + D + d) * NQ];
+                const float sr = lv[d], sh = lv[D + d];
                 x[d] = (x[d] - sh) / (1.f / (1.f + expf(-(sr + 2.f))) + a.eps);
             }
             linear(i, true);
@@ -266,6 +287,8 @@ extern "C" int bfsr_linf_features(const BfsrLinfFeatArgs* a, void* stream)
 extern "C" int bfsr_linf_flow(const BfsrLinfFlowArgs* a, void* stream)
 {
     if (!a || !a->x || !a->y || !a->ai || !a->lin_w || !a->lin_b) return -1;
+    if (a->ai_fmt != 0 && a->ai_fmt != 1) return -1;
+    if (a->ai_fmt == 1 && ((reinterpret_cast<unsigned long long>(a->ai) & 15) || (a->ai_bs & 3))) return -1;
     const long long NQ = (long long)a->qh * a->qw;
     dim3 grid((unsigned)((NQ + 255) / 256), (unsigned)a->B);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

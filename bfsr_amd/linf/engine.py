@@ -81,7 +81,9 @@ class LINFEngine(object):
         self.mlp = []
         if self.fused_mlp:
             names_ = ["layers.%d" % (2 * j) for j in range(num_layer + 1)]
-            self.mlp_packed = ops.pack_linf_mlp([sd[n + ".weight"] for n in names_], [sd[n + ".bias"] for n in names_], x3=not f16)
+            # the fused kernel hands affine_info to the flow kernel in a private quad-major layout (16-byte stores and loads)
+            self.mlp_packed = ops.pack_linf_mlp([sd[n + ".weight"] for n in names_], [sd[n + ".bias"] for n in names_], x3=not f16,
+                                                quad_layers=(flow_layers, 3 * patch_size * patch_size))
         else:
             for j in range(num_layer + 1):
                 self.mlp.append(_ConvP(ops, sd["layers.%d.weight" % (2 * j)], sd["layers.%d.bias" % (2 * j)], mtile=2, f16=f16))
@@ -95,6 +97,7 @@ class LINFEngine(object):
         self.logdet_const = float(sum(torch.slogdet(w.detach().cpu().float())[1] for w in W))     # NaiveLinear logabsdet, flow.py:66-70
         self._feat_key = self._feat = None
         self._cond_key = self._cond = None
+        self.ai_fmt = 1 if self.fused_mlp else 0
 
     # ------------------------------------------------------------------------------------------------
     def gen_feat(self, inp):
@@ -139,9 +142,9 @@ class LINFEngine(object):
         ai = self.affine_info(feat, coord, cell)
         z = self.ops.empty(*gt.shape)
         if not with_logp:
-            return self.ops.linf_flow(gt, ai, z, self.lin_w, self.lin_b, self.L, reverse=False)
+            return self.ops.linf_flow(gt, ai, z, self.lin_w, self.lin_b, self.L, reverse=False, ai_fmt=self.ai_fmt)
         lp = self.ops.empty(gt.shape[0] * gt.shape[2] * gt.shape[3])
-        self.ops.linf_flow(gt, ai, z, self.lin_w, self.lin_b, self.L, reverse=False, log_p=lp, logdet_const=self.logdet_const)
+        self.ops.linf_flow(gt, ai, z, self.lin_w, self.lin_b, self.L, reverse=False, log_p=lp, logdet_const=self.logdet_const, ai_fmt=self.ai_fmt)
         return lp, z
 
     def query_rgb(self, feat, coord, cell, zmap, inp=None):
@@ -151,7 +154,7 @@ class LINFEngine(object):
         ai = self.affine_info(feat, coord, cell)
         B, _, qh, qw = zmap.shape
         p = self.ws.get("flow_out", B, self.D, qh, qw)
-        ops.linf_flow(zmap, ai, p, self.lin_winv, self.lin_b, self.L, reverse=True)
+        ops.linf_flow(zmap, ai, p, self.lin_winv, self.lin_b, self.L, reverse=True, ai_fmt=self.ai_fmt)
         if self.ps == 1:
             return ops.grid_sample_add(inp, coord, p, ops.empty(B, 3, qh, qw))
         img = ops.empty(B, 3, self.ps * qh, self.ps * qw)
@@ -170,7 +173,7 @@ class LINFEngine(object):
             gp = grad_out
         else:
             gp = ops.patch_unfold(grad_out, self.ws.get("flow_grad", B, self.D, qh, qw), self.ps)
-        return ops.linf_flow(gp, ai, ops.empty(B, self.D, qh, qw), self.lin_winv_t, self.lin_b, self.L, reverse=2)
+        return ops.linf_flow(gp, ai, ops.empty(B, self.D, qh, qw), self.lin_winv_t, self.lin_b, self.L, reverse=2, ai_fmt=self.ai_fmt)
 
 
 class LINFPriorEngine(object):

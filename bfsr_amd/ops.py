@@ -718,9 +718,23 @@ class HipOps(object):
         _lib.check(self._launch(("linf_features",) + tuple(out.shape), lambda: self.lib.bfsr_linf_features(C.byref(a), self._stream())), "linf_features")
         return out
 
-    def pack_linf_mlp(self, ws, bs, x3=True):
-        """ws = [w1 [256,1024(,1,1)], w2, w3 [256,256], w4 [Cout,256]], bs = the four biases -> (packed weights, bias vector, Cout)."""
+    def pack_linf_mlp(self, ws, bs, x3=True, quad_layers=None):
+        """ws = [w1 [256,1024(,1,1)], w2, w3 [256,256], w4 [Cout,256]], bs = the four biases -> (packed weights, bias vector, Cout).
+        quad_layers = (layers, D): the output is wanted in the private quad-major layout of linf_flow(ai_fmt=1) -- the last layer's
+        rows are re-ordered so that every flow layer's 2*D values start at a multiple of four (zero rows as padding); the returned
+        Cout is the padded row count and `linf_mlp` then writes [B][Cout/4][qh*qw][4]."""
         w = [t.detach().to("cpu", torch.float32).reshape(t.shape[0], t.shape[1]).contiguous() for t in ws]
+        bs = [b.detach().to("cpu", torch.float32).reshape(-1) for b in bs]
+        if quad_layers is not None:
+            L, D = quad_layers
+            blk = (2 * D + 3) // 4 * 4
+            assert w[3].shape[0] == 2 * D * L
+            w4 = torch.zeros(L * blk, w[3].shape[1])
+            b4 = torch.zeros(L * blk)
+            for i in range(L):
+                w4[i * blk: i * blk + 2 * D] = w[3][2 * D * i: 2 * D * (i + 1)]
+                b4[i * blk: i * blk + 2 * D] = bs[3][2 * D * i: 2 * D * (i + 1)]
+            w[3], bs = w4.contiguous(), bs[:3] + [b4]
         hidden, Cout = w[1].shape[0], w[3].shape[0]
         n = self.lib.bfsr_linf_mlp_packed_size(hidden, Cout, int(x3))
         if n <= 0 or w[0].shape != (hidden, 4 * hidden) or w[2].shape != (hidden, hidden) or w[3].shape[1] != hidden:
@@ -728,13 +742,15 @@ class HipOps(object):
         packed = torch.empty(n, dtype=torch.int16)
         _lib.check(self.lib.bfsr_pack_linf_mlp(w[0].data_ptr(), w[1].data_ptr(), w[2].data_ptr(), w[3].data_ptr(), hidden, Cout, int(x3),
                                                packed.data_ptr()), "pack_linf_mlp")
-        bias = torch.cat([b.detach().to("cpu", torch.float32).reshape(-1) for b in bs])
-        return packed.to(self.device), bias.to(self.device), Cout
+        bias = torch.cat(bs)
+        return packed.to(self.device), bias.to(self.device), Cout, (1 if quad_layers is not None else 0)
 
     def linf_mlp(self, cf, coord, cell, phase, packed, out, hidden, x3=True):
-        """fused Fourier features + shared MLP: cf [B,2*hidden,h,w], coord [B,qh,qw,2], cell [B,2] -> out = affine_info [B,Cout,qh,qw]."""
-        wts, bias, Cout = packed
+        """fused Fourier features + shared MLP: cf [B,2*hidden,h,w], coord [B,qh,qw,2], cell [B,2] -> out = affine_info [B,Cout,qh,qw]
+        (the same buffer in the quad-major layout when the weights were packed with quad_layers)."""
+        wts, bias, Cout, fmt = packed
         a = _lib.BfsrLinfMlpArgs()
+        a.out_fmt = fmt
         a.cf, a.cf_bs, c2, h, w = _view(cf, "linf_mlp.cf")
         a.out, a.out_bs, co, qh, qw = _view(out, "linf_mlp.out")
         assert c2 == 2 * hidden and co == Cout and tuple(coord.shape) == (cf.shape[0], qh, qw, 2)
@@ -745,6 +761,8 @@ class HipOps(object):
         a.dy_neg, a.dy_pos, a.dx_neg, a.dx_pos = -1 * rx + e, 1 * rx + e, -1 * ry + e, 1 * ry + e
         a.clamp_lo, a.clamp_hi = -1 + 1e-6, 1 - 1e-6
         a.cy0, a.cy1, a.cx0, a.cx1 = -1 + 1.0 / h, 2 * (1.0 / h), -1 + 1.0 / w, 2 * (1.0 / w)
+        if fmt and (out.data_ptr() & 15 or a.out_bs & 3):
+            raise ValueError("linf_mlp: the quad-major output needs a 16-byte aligned buffer")
         key = ("linf_mlp_x3" if x3 else "linf_mlp_f16", hidden, Cout, cf.shape[0], qh, qw)
         _lib.check(self._launch(key, lambda: self.lib.bfsr_linf_mlp(C.byref(a), int(x3), self._stream())), "linf_mlp")
         return out
@@ -814,15 +832,17 @@ class HipOps(object):
             xp, xbs, y.data_ptr(), x.shape[0], Cc * H * W, self._stream())), "to_uint8")
         return y
 
-    def linf_flow(self, x, ai, y, lin_w, lin_b, layers, reverse, eps=1e-4, log_p=None, logdet_const=0.0):
+    def linf_flow(self, x, ai, y, lin_w, lin_b, layers, reverse, eps=1e-4, log_p=None, logdet_const=0.0, ai_fmt=0):
         a = _lib.BfsrLinfFlowArgs()
+        a.ai_fmt = int(ai_fmt)
         if log_p is not None:
             assert not reverse and log_p.is_contiguous() and log_p.numel() == x.shape[0] * x.shape[2] * x.shape[3]
             a.log_p, a.logdet_const = log_p.data_ptr(), float(logdet_const)
         a.x, a.x_bs, D, qh, qw = _view(x, "linf_flow.x")
         a.ai, a.ai_bs, ca, _, _ = _view(ai, "linf_flow.ai")
         a.y, a.y_bs, _, _, _ = _view(y, "linf_flow.y")
-        assert ca == 2 * D * layers and lin_w.numel() == (layers + 1) * D * D and lin_b.numel() == (layers + 1) * D
+        assert ca == (((2 * D + 3) // 4 * 4) * layers if ai_fmt else 2 * D * layers)
+        assert lin_w.numel() == (layers + 1) * D * D and lin_b.numel() == (layers + 1) * D
         a.lin_w, a.lin_b = lin_w.data_ptr(), lin_b.data_ptr()
         mode = int(reverse)                      # 0 forward, 1 (True) inverse, 2 = VJP of the inverse w.r.t. its input
         assert mode in (0, 1, 2)

@@ -335,6 +335,9 @@ typedef struct BfsrLinfMlpArgs {
     int B, hidden, Cout, h, w, qh, qw;
     float dy_neg, dy_pos, dx_neg, dx_pos, clamp_lo, clamp_hi;
     float cy0, cy1, cx0, cx1;
+    int out_fmt;                   /* 0: out [B,Cout,qh,qw].  1: quad-major [B][Cout/4][qh*qw][4] (Cout % 4 == 0): the lane that holds
+                                    * four consecutive output rows of a query point stores them as ONE 16-byte word (4x fewer store
+                                    * instructions, full 64-byte sectors); read by bfsr_linf_flow with ai_fmt = 1 */
 } BfsrLinfMlpArgs;
 int bfsr_linf_mlp(const BfsrLinfMlpArgs* a, int x3, void* stream);
 long long bfsr_linf_mlp_packed_size(int hidden, int Cout, int x3);          /* in 16-bit elements */
@@ -356,6 +359,8 @@ typedef struct BfsrLinfFlowArgs {
     float* log_p;              /* optional (forward only): [B][qh*qw] total log-det + base log-prob per query point
                                 * (flow.py:44-55); logdet_const = sum over the layers+1 linears of slogdet(W)[1] */
     float logdet_const;
+    int ai_fmt;                /* 0: ai [B, 2*D*layers, qh, qw].  1: quad-major with each layer's 2*D values padded to a multiple of
+                                * four: [B][layers][ceil(2D/4)][qh*qw][4] (the producer's rows are laid out in that padded order) */
 } BfsrLinfFlowArgs;
 int bfsr_linf_flow(const BfsrLinfFlowArgs* a, void* stream);
 

@@ -385,22 +385,36 @@ class CpuOps(object):
         hid = self.coupling_head(z_in, head, pre_aff, torch.empty(z_in.shape[0], 64, z_in.shape[2], z_in.shape[3]))
         return self.coupling_tail(hid, tail, z_in, z_out, reverse, h_ft=h_ft, w=w, an_bias=an_bias, an_escale=an_escale, eps=eps)
 
-    def pack_linf_mlp(self, ws, bs, x3=True):
+    @staticmethod
+    def _ai_quads(ai, layers, D, inverse=False):
+        """[B, 2*D*layers, qh, qw] values <-> the quad-major padded layout of linf_mlp(out_fmt=1) / linf_flow(ai_fmt=1), held in a
+        [B, blk*layers, qh, qw] buffer (blk = 2*D rounded up to a multiple of four): [B][layers][blk/4][qh*qw][4]."""
+        B, _, qh, qw = ai.shape
+        blk = (2 * D + 3) // 4 * 4
+        if inverse:
+            v = ai.reshape(B, layers, blk // 4, qh * qw, 4).permute(0, 1, 2, 4, 3).reshape(B, layers, blk, qh, qw)
+            return v[:, :, :2 * D].reshape(B, 2 * D * layers, qh, qw)
+        v = torch.zeros(B, layers, blk, qh, qw)
+        v[:, :, :2 * D] = ai.reshape(B, layers, 2 * D, qh, qw)
+        return v.reshape(B, layers, blk // 4, 4, qh * qw).permute(0, 1, 2, 4, 3).reshape(B, layers * blk, qh, qw)
+
+    def pack_linf_mlp(self, ws, bs, x3=True, quad_layers=None):
         rnd = (lambda t: t) if x3 else (lambda t: t.half().float())
+        cout = ws[3].shape[0] if quad_layers is None else ((2 * quad_layers[1] + 3) // 4 * 4) * quad_layers[0]
         return ([rnd(t.detach().to(torch.float32).reshape(t.shape[0], t.shape[1], 1, 1)).clone() for t in ws],
-                [b.detach().to(torch.float32).reshape(-1).clone() for b in bs], ws[3].shape[0])
+                [b.detach().to(torch.float32).reshape(-1).clone() for b in bs], cout, quad_layers)
 
     def linf_mlp(self, cf, coord, cell, phase, packed, out, hidden, x3=True):
         """Semantics of the fused kernel: Fourier features -> 1x1 MLP (ReLU between layers); fp16 mode rounds every layer's
         operands to fp16, accumulation fp32."""
-        ws, bs, _ = packed
+        ws, bs, _, quad = packed
         rnd = (lambda t: t) if x3 else (lambda t: t.half().float())
         x = self.linf_features(cf, coord, cell, phase, torch.empty(cf.shape[0], 4 * hidden, coord.shape[1], coord.shape[2]), hidden)
         for j, (w, b) in enumerate(zip(ws, bs)):
             x = F.conv2d(rnd(x), w, b)
             if j < len(ws) - 1:
                 x = F.relu(x)
-        out.copy_(x)
+        out.copy_(x if quad is None else self._ai_quads(x, quad[0], quad[1]))
         return out
 
     def zeros_f64(self, n):
@@ -446,8 +460,10 @@ class CpuOps(object):
             acc += coef * (-0.5 * (logs * 2.0 + (x - mean) ** 2 / torch.exp(logs * 2.0) + l2pi)).double().sum(dim=(1, 2, 3))
         return acc
 
-    def linf_flow(self, x, ai, y, lin_w, lin_b, layers, reverse, eps=1e-4, log_p=None, logdet_const=0.0):
+    def linf_flow(self, x, ai, y, lin_w, lin_b, layers, reverse, eps=1e-4, log_p=None, logdet_const=0.0, ai_fmt=0):
         B, D, qh, qw = x.shape
+        if ai_fmt:
+            ai = self._ai_quads(ai, layers, D, inverse=True)
         v = x.permute(0, 2, 3, 1).reshape(-1, D)
         a = ai.permute(0, 2, 3, 1).reshape(-1, 2 * D * layers)
         Wm, bb = lin_w.view(layers + 1, D, D), lin_b.view(layers + 1, D)

@@ -74,6 +74,11 @@ def test_linf_mlp_fused(hip, hw, q, x3):
     out = hip.linf_mlp(hip.to_device(cf), hip.to_device(coord), hip.to_device(cell), hip.vec(phase), hip.pack_linf_mlp(ws, bs, x3=x3),
                        hip.empty(B, Cout, qh, qw), HD, x3=x3)
     close(out, ref, 2e-5 if x3 else 3e-3, "linf_mlp x3=%s" % x3)
+    # the private quad-major layout (16-byte stores; what linf_flow(ai_fmt=1) reads): the same values, rows padded per flow layer
+    L, D = 10, 27
+    outq = hip.linf_mlp(hip.to_device(cf), hip.to_device(coord), hip.to_device(cell), hip.vec(phase), hip.pack_linf_mlp(ws, bs, x3=x3, quad_layers=(L, D)),
+                        hip.empty(B, 56 * L, qh, qw), HD, x3=x3)
+    assert torch.equal(CPU._ai_quads(outq.cpu(), L, D, inverse=True), out.cpu()), "out_fmt=1 must hold the values of out_fmt=0"
 
 
 @pytest.mark.parametrize("D", [27, 3])
@@ -88,6 +93,9 @@ def test_linf_flow(hip, D, reverse):
     ref = CPU.linf_flow(x, ai, torch.empty_like(x), Wuse.reshape(-1), bb.reshape(-1), L, reverse)
     out = hip.linf_flow(hip.to_device(x), hip.to_device(ai), hip.empty(*x.shape), hip.vec(Wuse), hip.vec(bb), L, reverse)
     close(out, ref, 1e-5, "linf_flow")
+    # conditioning handed over in the quad-major padded layout: bit-identical result
+    outq = hip.linf_flow(hip.to_device(x), hip.to_device(CPU._ai_quads(ai, L, D).contiguous()), hip.empty(*x.shape), hip.vec(Wuse), hip.vec(bb), L, reverse, ai_fmt=1)
+    assert torch.equal(outq.cpu(), out.cpu()), "linf_flow ai_fmt=1 differs from ai_fmt=0"
 
 
 def test_fold_unfold_direct_conv(hip):

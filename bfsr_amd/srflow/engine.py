@@ -313,6 +313,14 @@ class SRFlowEngine(object):
             sc = torch.cat([self.steps[i].ft0_scale for i in idxs], 0)
             wa = torch.cat([self.steps[i].aff0_ft_w for i in idxs], 0)
             hz = dict(idxs=idxs, up2=False)
+            # Round 3: the 64 -> 16*64 key convs of the finer levels run on conv_x3s (LDS-DMA staging by loader waves, persistent) over
+            # an x3 copy of the key channels instead of the register-staged conv_bf16x3 kernel: 5.51 -> 4.80 ms at 8 x 320^2
+            # (175 -> 201 TFLOP/s-equivalent).  The 320 -> 1024 hoists of the coarser levels were measured too and are NOT moved:
+            # 5.17 -> 5.45 ms at 8 x 160^2 -- conv_x3s tiles 32 output channels per workgroup, so a 1024-channel conv re-stages every
+            # input tile 32 times (33 GB through L2 per launch), conv_bf16x3's 64-channel tiles half as often.  BFSR_HOIST=x3s-all /
+            # bf16x3 select everything / nothing.
+            hmode = os.environ.get("BFSR_HOIST", "x3s-keys")
+            hz["x3s"] = bool(getattr(self.rrdb, "x3s", False)) and hmode in ("x3s-keys", "x3s-all")
             if self._taps_up2(level):
                 # the 256 stacked-RRDB channels of this level are the LR-resolution taps upsampled x2: their share of the
                 # 3x3 conv runs on the LR grid with parity pre-summed weights (4/9 of the MACs, nothing materialised);
@@ -326,12 +334,19 @@ class SRFlowEngine(object):
                     # 3xBF16 kernels: key channels by the plain conv (no epilogue) into the output buffer, then the taps
                     # kernel adds them back through pre_add and applies the epilogue
                     hz.update(ft0_taps=ops.pack_conv_up2_x3(wf[:, 64:].contiguous()), aff0_taps=ops.pack_conv_up2_x3(wa[:, 64:].contiguous()),
-                              ft0_key=ops.pack_conv_x3(wf[:, :64].contiguous(), 2), aff0_key=ops.pack_conv_x3(wa[:, :64].contiguous(), 2))
+                              ft0_key=ops.pack_conv_x3(wf[:, :64].contiguous(), 1 if hz["x3s"] else 2),
+                              aff0_key=ops.pack_conv_x3(wa[:, :64].contiguous(), 1 if hz["x3s"] else 2))
                 else:
                     hz.update(ft0_taps=ops.pack_conv_up2(wf[:, 64:].contiguous()), aff0_taps=ops.pack_conv_up2(wa[:, 64:].contiguous()),
                               ft0_key=ops.pack_conv(wf[:, :64].contiguous(), 2), aff0_key=ops.pack_conv(wa[:, :64].contiguous(), 2))
+            elif hz["x3s"] and hmode == "x3s-all" and wf.shape[1] % 16 == 0:
+                hz.update(ft0_pw=ops.pack_conv_x3(wf, 1), ft0_epi=ops.pack_epilogue(wf.shape[0], aff_shift=sh, aff_scale=sc),
+                          aff0_pw=ops.pack_conv_x3(wa, 1))
             else:
+                hz["x3s"] = False
                 hz.update(ft0=_ConvP(ops, wf, aff_shift=sh, aff_scale=sc, mtile=2), aff0=_ConvP(ops, wa, mtile=2))
+            if hz["up2"] and not (hz.get("x3") and hz["up"] in (1, 2)):
+                hz["x3s"] = False
             self.hoist[level] = hz
             for i in idxs:
                 del self.steps[i].ft0_w, self.steps[i].aff0_ft_w
@@ -460,6 +475,13 @@ class SRFlowEngine(object):
         K = len(hz["idxs"])
         hl, wl = ft[level].shape[2], ft[level].shape[3]
         Cz = [ly.C for ly in self.layers if ly.index == hz["idxs"][0]][0]
+        if hz.get("x3s"):                                   # x3 copy of the channels the x3s hoists read (packed 16-bit: not a _Workspace)
+            cx = 64 if hz["up2"] else ft[level].shape[1]
+            key = (B, cx, hl, wl)
+            if getattr(self, "_ftx3", None) is None:
+                self._ftx3 = {}
+            if level not in self._ftx3 or self._ftx3[level][0] != key:
+                self._ftx3[level] = (key, self.ops.x3_empty(B, cx, hl, wl))
         return (ws.get("hoist_hid%d" % level, B, K * 64, hl, wl), ws.get("pre_aff%d" % level, B, K * 64, hl, wl),
                 ws.get("h_ft%d" % level, B, K * 2 * Cz, hl, wl), Cz)
 
@@ -471,13 +493,24 @@ class SRFlowEngine(object):
             taps = ft[self._lr_level()][:, 64:]
             if hz["x3"]:
                 up = ops.conv_up4_x3 if hz["up"] == 2 else ops.conv_up2_x3
-                ops.conv_x3(f, hz["ft0_key"], hid)
+                if hz["x3s"]:
+                    f3 = ops.x3_pack(f, self._ftx3[level][1])
+                    ops.conv_x3s(f3, hz["ft0_key"], hid)
+                else:
+                    ops.conv_x3(f, hz["ft0_key"], hid)
                 up(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, pre_add=hid)
-                ops.conv_x3(f, hz["aff0_key"], pre_aff)
+                if hz["x3s"]:
+                    ops.conv_x3s(f3, hz["aff0_key"], pre_aff)
+                else:
+                    ops.conv_x3(f, hz["aff0_key"], pre_aff)
                 up(taps, hz["aff0_taps"], pre_aff, pre_add=pre_aff)
             else:
                 ops.conv_up2(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, key=(f, hz["ft0_key"]))
                 ops.conv_up2(taps, hz["aff0_taps"], pre_aff, key=(f, hz["aff0_key"]))
+        elif hz["x3s"]:
+            f3 = ops.x3_pack(f, self._ftx3[level][1])
+            ops.conv_x3s(f3, hz["ft0_pw"], hid, epi=hz["ft0_epi"], act=ACT_RELU)
+            ops.conv_x3s(f3, hz["aff0_pw"], pre_aff)
         else:
             hz["ft0"].run(ops, f, hid, act=ACT_RELU)
             hz["aff0"].run(ops, f, pre_aff)

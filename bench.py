@@ -274,7 +274,8 @@ def main():
         warm_total_ms += t
         fam = FAMILIES[k[0]][0] if k[0] in FAMILIES else k[0]
         warm_by_family[fam] = warm_by_family.get(fam, 0.0) + t
-    ops.profile_keys = set([k for _, k in ranked[:4]] + ([key_tail, key_tail_fused] if key_tail else []))
+    key_head = ("coupling_head", C1 // 2, B, H // 2, H // 2) if srflow else None
+    ops.profile_keys = set([k for _, k in ranked[:4]] + ([key_tail, key_tail_fused, key_head] if key_tail else []))
     ops.profile = {}
     bdist.barrier()
     torch.cuda.synchronize()
@@ -322,6 +323,19 @@ def main():
                      "achieved": round(a, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(a / PEAK_HBM_GBS, 4),
                      "traffic": (traffic_db.get(json.dumps(list(key_tail_fused if fused else key_tail))) or {}).get("hbm_bytes_per_launch"),
                      "algorithmic_bytes_per_launch": tail_bytes, "avg_launch_ms": round(tail_ms, 4), "launches": len(ev)}
+        if fused and ops.profile.get(key_head):
+            # the whole sequential remainder of a level-1 coupled FlowStep = coupling_head + coupling_tail; numerator = the STEP's
+            # algorithmic bytes: z (C) + pre_aff (64) + h_ft (2C) in, z (C) out (the 64-channel hidden tensor the two kernels hand
+            # over is not algorithmic: it exists only because the step is two kernels)
+            evh = ops.profile[key_head]
+            head_ms = sum(s.elapsed_time(e) for s, e in evh) / len(evh)
+            sa = tail_bytes / ((head_ms + tail_ms) * 1e-3) / 1e9
+            roof_tail["step"] = {"kernels": "coupling_head_kernel<1> + coupling_tail_kernel<12> (one coupled level-1 FlowStep, inverse)",
+                                 "head_avg_launch_ms": round(head_ms, 4), "tail_avg_launch_ms": round(tail_ms, 4),
+                                 "algorithmic_bytes_per_step": tail_bytes, "achieved": round(sa, 1), "unit": "GB/s",
+                                 "frac": round(sa / PEAK_HBM_GBS, 4),
+                                 "note": "the step is matrix-pipe bound, not HBM bound: 3xBF16 arithmetic needs ~0.19 TFLOP of bf16 MFMA per step "
+                                         "(~76 us at the 2.5 PFLOP/s peak) against ~58 us of traffic at the achievable 6.3 TB/s"}
 
     # ---- config 2: the same workload with every contraction on the native fp32 MFMA, reported beside `value` --------------
     fp32_only = None
@@ -432,6 +446,9 @@ def main():
                            batch_txt, h, h, H, H, path, ", + double-buffered RCCL all-gather of outputs" if world > 1 else ""),
                        "parallelism": "dp%d" % world, "global_batch": global_B, "weights": "seeded synthetic (conditioned recipe)"},
             "roofline": roofline, "roofline_next_kernels": roofline_next, "roofline_by_symbol": by_symbol,
+            "roofline_by_symbol_note": "HIP-event time per kernel family in the untimed ranking step; with the side stream active (configs "
+                                       "whose batch does not fill the chip) events of overlapping kernels are inflated by contention and the "
+                                       "families sum to more than ms_per_step -- profiles/r03_keys_cfg2_no_overlap.txt has the BFSR_OVERLAP=0 table",
             "roofline_coupling_inverse": roof_tail,
             "cpu_baseline": cpu_baseline, "parity": parity,
         }

@@ -44,6 +44,7 @@ constexpr int WPL = 9 * 2 * 32 * 16;            // bytes of one weight plane per
 constexpr int W_BYTES = 3 * WPL;                // 27 648
 constexpr int STAGE = IN_BYTES + W_BYTES;
 constexpr int LDS_TOTAL = 2 * STAGE;            // 129 024
+constexpr int LDS_PARK = NW * 16 * 64 * 4;      // + 32 768: the deferred epilogue's parked accumulators (one [16][64] fp32 block per compute wave)
 constexpr int W_INSTR = W_BYTES / 1024;         // 27 LDS-DMA wave-instructions per weight slab
 constexpr unsigned OOB = 0x80000000u;
 
@@ -132,6 +133,8 @@ __global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64
     int it = slot;
     if (it >= nitems) return;
     Item cur = decode(it);
+    if constexpr ((ABL & 256) != 0) { if (wave < NW) __builtin_amdgcn_s_setprio(1); }       // experiment: compute waves win the arbitration
+    if constexpr ((ABL & 512) != 0) { if (wave >= NW) __builtin_amdgcn_s_setprio(1); }      // experiment: loader waves win
     if constexpr ((ABL & 16) != 0) {
         if (wave >= NW) {
             // ---- loader waves: all 63 pieces of every stage (loader 0: input groups 0-2 + weight pieces 0-12, loader 1: groups 3-5 + 13-26)
@@ -192,6 +195,128 @@ __global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64
     }
     int buf = 0;
 
+    // ---- DEFERRED EPILOGUE (ABL & 1024; NOT the product -- a measured negative result, profiles/r03_x3s_deferred_epilogue.txt): the
+    // epilogue of item i runs in SLICES between the taps of item i+1's first chunks, where its VALU / LDS-crossbar / memory
+    // instructions were meant to issue beside the matrix pipe instead of behind it (with the accumulators kept alive the epilogue
+    // is 9-15 % of the kernel, tools/exp/x3s_abl.py "no epilogue").  Result: one RDB 695 us vs 577 us at 8 x 160^2, 3008 vs 2571 us at
+    // 16 x 256^2 -- the compute waves are issue / latency bound (matrix pipe ~53 % busy), so instructions added between the MFMA
+    // groups of every wave lengthen the barrier-synchronised chunk instead of filling idle slots.  The 16 results per
+    // lane wait in a per-wave LDS scratch (registers: the kernel sits at the 168-VGPR limit of three waves per SIMD), already
+    // paired into channel octets.  Phase = chunk index of the next item; per octet q the stages are
+    //   A (only with res1): slot 0 loads r1, slots 1-8 parameters + activation of one channel each (value back to the scratch)
+    //   B (only with res2): slots 0-7 add r1, slot 8 loads r2
+    //   C: slots 0-7 one channel each: (activation | + r1 | + r2), re-encoding; slot 8: the 16-byte stores (fp32 output: per channel)
+    constexpr bool DEF = (ABL & 1024) != 0;
+    bool pend = false;
+    Item pit = {0, 0, 0, 0, TH};
+    float4 ppm = make_float4(0.f, 0.f, 1.f, 0.f);
+    bool pvalid[2] = {false, false}, pbias_only = true, pfast = true;
+    long long ppix = 0;
+    bf16x8 rr[3], ph8, pm8, pl8;
+    float* sP = reinterpret_cast<float*>(smem + LDS_TOTAL) + (wave < NW ? wave : 0) * 16 * 64 + lane;      // [16 values][64 lanes] of this wave
+    const float eslope = p.act == BFSR_ACT_NONE ? 1.f : (p.act == BFSR_ACT_RELU ? 0.f : p.slope);
+    const long long HWl = (long long)H * W;
+    const int nstage = 1 + (p.res1 ? 1 : 0) + (p.res2 ? 1 : 0);   // stages per octet: C | A C | A B C
+    auto pfetch = [&](float val, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane * 4, __float_as_int(val))); };
+    auto activate = [&](float v, int q, int j, int lh) {
+        const int src = lh * 16 + (q * 16 + j) * 2;              // lane holding this channel's first float4
+        const float e0 = pfetch(ppm.x, src);
+        if (pfast) {
+            const float u = v + e0;
+            return fmaxf(u, u * eslope);                          // = u > 0 ? u : u*slope for 0 <= slope <= 1
+        }
+        float e1 = 0.f, e2 = 1.f, e3 = 0.f, e4 = 1.f;
+        if (!pbias_only) { e1 = pfetch(ppm.y, src); e2 = pfetch(ppm.z, src); e3 = pfetch(ppm.w, src); e4 = pfetch(ppm.x, src + 1); }
+        float u = v + e0;
+        u = (u + e1) * e2 + e3;
+        u = u > 0.f ? u : u * eslope;
+        return u * e4;
+    };
+    auto load_res = [&](const unsigned short* base, long long bs, int q, int lh) {
+        const int oct = pit.cg * 4 + q * 2 + lh;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rr[pl][e] = (__bf16)0.f;
+        if (pvalid[q]) {
+            const unsigned short* rb = base + (long long)pit.b * bs + ((long long)oct * 3 * HWl + ppix) * 8;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) rr[pl] = *reinterpret_cast<const bf16x8*>(rb + pl * HWl * 8);
+        }
+    };
+    // stage: 0 = A, 1 = B, 2 = C (wave-uniform runtime values); q, t: constants after inlining / unrolling.  The octet being
+    // processed lives in registers (pvq) from its first phase on; slot 0 of that phase also fetches the eight bias values, so the
+    // channel slots are VALU only (a parked-value read + ds_bpermute per slot left their LDS latencies exposed between the taps:
+    // the first version of this scheme was 15-35 % SLOWER than the epilogue behind the K loop)
+    float pvq[8], pe0[8];
+    auto first_slot = [&](int q, int lh) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pvq[j] = sP[(q * 8 + j) * 64];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pe0[j] = pfetch(ppm.x, lh * 16 + (q * 16 + j) * 2);
+    };
+    auto act_j = [&](int q, int j, int lh) {
+        if (pfast) {
+            const float u = pvq[j] + pe0[j];
+            pvq[j] = fmaxf(u, u * eslope);                        // = u > 0 ? u : u*slope for 0 <= slope <= 1
+        } else {
+            const int src = lh * 16 + (q * 16 + j) * 2;           // lane holding this channel's first float4
+            float e1 = 0.f, e2 = 1.f, e3 = 0.f, e4 = 1.f;
+            if (!pbias_only) { e1 = pfetch(ppm.y, src); e2 = pfetch(ppm.z, src); e3 = pfetch(ppm.w, src); e4 = pfetch(ppm.x, src + 1); }
+            float u = pvq[j] + pe0[j];
+            u = (u + e1) * e2 + e3;
+            u = u > 0.f ? u : u * eslope;
+            pvq[j] = u * e4;
+        }
+    };
+    auto slice_q = [&](int q, int stage, int t, int lh) {
+        if (stage == 0) {                                           // A: first phase of an octet with residuals
+            if (t == 0) { first_slot(q, lh); load_res(p.res1, p.res1_bs, q, lh); }
+            else act_j(q, t - 1, lh);
+        } else if (stage == 1) {                                    // B: + r1, then fetch r2
+            if (t < 8) pvq[t] = p.alpha1 * pvq[t] + (((float)rr[0][t] + (float)rr[1][t]) + (float)rr[2][t]);
+            else load_res(p.res2, p.res2_bs, q, lh);
+        } else {                                                    // C: last phase of the octet
+            const int oct = pit.cg * 4 + q * 2 + lh;
+            if (t == 0) {
+                if (nstage == 1) first_slot(q, lh);
+            } else {
+                const int j = t - 1;
+                if (nstage == 1) act_j(q, j, lh);
+                else if (nstage == 2) pvq[j] = p.alpha1 * pvq[j] + (((float)rr[0][j] + (float)rr[1][j]) + (float)rr[2][j]);
+                else pvq[j] = p.alpha2 * pvq[j] + (((float)rr[0][j] + (float)rr[1][j]) + (float)rr[2][j]);
+                if (p.y_fmt == 1) {
+                    __bf16 h, m, l;
+                    split3(pvq[j], h, m, l);
+                    ph8[j] = h; pm8[j] = m; pl8[j] = l;
+                } else if (pvalid[q] && oct * 8 + j < p.Cout) {
+                    (reinterpret_cast<float*>(p.y) + (long long)pit.b * p.y_bs + ppix)[(long long)(oct * 8 + j) * HWl] = pvq[j];
+                }
+                if (t == 8 && p.y_fmt == 1 && pvalid[q]) {
+                    unsigned short* yb = reinterpret_cast<unsigned short*>(p.y) + (long long)pit.b * p.y_bs + ((long long)oct * 3 * HWl + ppix) * 8;
+                    *reinterpret_cast<bf16x8*>(yb) = ph8;
+                    *reinterpret_cast<bf16x8*>(yb + HWl * 8) = pm8;
+                    *reinterpret_cast<bf16x8*>(yb + 2 * HWl * 8) = pl8;
+                }
+            }
+        }
+    };
+    // `lh` = lane >> 5 derived from an OPAQUE copy of the lane id per chunk: everything per-lane the slices need (ds_bpermute
+    // addresses, octet numbers) would otherwise be loop-invariant, hoisted out of the item loop by hipcc and spilled
+    auto slice = [&](int phase, int t, int lh) {                    // phase: wave-uniform, t: constant after unrolling
+        if (!pend || phase >= 2 * nstage) return;
+        const int q = phase >= nstage ? 1 : 0;
+        const int pl_ = phase - q * nstage;                         // stages of an octet: C | A C | A B C
+        const int stage = pl_ == nstage - 1 ? 2 : (pl_ == 0 ? 0 : 1);
+        if (q == 0) slice_q(0, stage, t, lh); else slice_q(1, stage, t, lh);
+    };
+    auto phase_all = [&](int phase) {
+        int lo = lane;
+        asm volatile("" : "+v"(lo));
+#pragma unroll
+        for (int t = 0; t < 9; ++t) slice(phase, t, lo >> 5);
+    };
+
     while (true) {
         f32x16 acc, acc2;
 #pragma unroll
@@ -220,7 +345,7 @@ __global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64
             for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) r1[q][pl][j] = (__bf16)0.f;
-            if (p.res1 && valid[q]) {
+            if (!DEF && p.res1 && valid[q]) {
                 const unsigned short* rb = p.res1 + (long long)cur.b * p.res1_bs + ((long long)oct * 3 * HW + pix) * 8;
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) r1[q][pl] = *reinterpret_cast<const bf16x8*>(rb + pl * HW * 8);
@@ -230,7 +355,9 @@ __global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64
         const bool has_next = nxt < nitems;
         Item nitem = cur;
         for (int k = 0; k < nchunk; ++k) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces of stage `buf` have landed ...
+            // this wave's DMA pieces of stage `buf` have landed (with dedicated loader waves a compute wave has none: the wait would
+            // only drain its own epilogue stores and residual loads at every chunk boundary) ...
+            if (!(ABL & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (!(ABL & 2)) __builtin_amdgcn_s_barrier();         // ... and so have everybody else's; stage buf^1 is free again
             int sk = -1;                                          // chunk to stage into buf^1 (-1: nothing)
             if (k + 1 < nchunk) sk = k + 1;
@@ -255,7 +382,14 @@ __global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64
                 for (int pl = 0; pl < 3; ++pl)
                     afr[b_][pl] = *reinterpret_cast<const bf16x8*>(wA + pl * WPL + (dy * 3 + dx) * 1024);
             };
-            if (wave >= cur.th) { buf ^= 1; continue; }            // upper waves of a half-height tile: barriers only
+            if (wave >= cur.th) {                                  // upper waves of a half-height tile: barriers (+ their pending epilogue) only
+                if constexpr (DEF) phase_all(k);
+                buf ^= 1;
+                continue;
+            }
+            int plane_ = lane;
+            if constexpr (DEF) asm volatile("" : "+v"(plane_));
+            const int plh = plane_ >> 5;
             load_b(0);
             load_a(0, 0, 0);
 #pragma unroll
@@ -273,6 +407,7 @@ __global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64
                 }
 #undef BFSR_TERM
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (DEF) { slice(k, t, plh); __builtin_amdgcn_sched_barrier(0); }  // a slice of the PREVIOUS item's epilogue
             }
             buf ^= 1;
         }
@@ -289,6 +424,31 @@ __global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64
             asm volatile("" :: "v"(acc));
 #endif
             if (!has_next) break; it = nxt; cur = nitem; continue; }     // ablation: no epilogue (acc kept alive)
+        if constexpr (DEF) {
+            for (int k = nchunk; k < 2 * nstage; ++k) phase_all(k);  // fewer chunks than phases (the 64-channel trunk_conv with residual)
+            asm volatile("s_nop 11" ::: "memory");                 // MFMA result -> VALU read inside the asm below
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float lo = acc[8 * q + i], hi = acc[8 * q + 4 + i];
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+                    sP[(q * 8 + i) * 64] = lo;                      // octet q*2+lhi of this lane's pixel, channels i and 4+i
+                    sP[(q * 8 + 4 + i) * 64] = hi;
+                }
+            pend = true; pit = cur; ppm = pm; ppix = pix;
+            pvalid[0] = valid[0]; pvalid[1] = valid[1];
+            pbias_only = __all((lane & 1) ? pm.x == 1.f : (pm.y == 0.f && pm.z == 1.f && pm.w == 0.f));
+            pfast = pbias_only && eslope >= 0.f && eslope <= 1.f;
+            if (!has_next) {
+#pragma unroll 1
+                for (int k = 0; k < 2 * nstage; ++k) phase_all(k);   // the last item's epilogue has no K loop to hide under
+                break;
+            }
+            it = nxt;
+            cur = nitem;
+            continue;
+        }
         float v[2][8];
         // inline asm: hipcc (ROCm 7.2) folds eight __builtin_amdgcn_permlane32_swap calls on MFMA result elements into ONE
         // swap of element 0 (every output channel became channel 0); asm statements are opaque to it.  The compiler pads
@@ -454,8 +614,9 @@ extern "C" int bfsr_conv3x3_x3s(const BfsrConvX3Args* a, void* stream)
 #define BFSR_LAUNCH(ABL_)                                                                                                            \
     {                                                                                                                                \
         static std::atomic<unsigned long long> lds_done{0};                                                                          \
-        if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_x3s_kernel<ABL_>), LDS_TOTAL, lds_done) != 0) return -1; \
-        hipLaunchKernelGGL(conv3x3_x3s_kernel<ABL_>, dim3((unsigned)grid), dim3((NW + (((ABL_) & 16) ? 2 + (((ABL_) >> 5) & 3) : 0)) * 64), LDS_TOTAL, st, *a, tiles_x, tiles_y, groups, \
+        constexpr int LDS_ = LDS_TOTAL + (((ABL_) & 1024) ? LDS_PARK : 0);                                                           \
+        if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_x3s_kernel<ABL_>), LDS_, lds_done) != 0) return -1;      \
+        hipLaunchKernelGGL(conv3x3_x3s_kernel<ABL_>, dim3((unsigned)grid), dim3((NW + (((ABL_) & 16) ? 2 + (((ABL_) >> 5) & 3) : 0)) * 64), LDS_, st, *a, tiles_x, tiles_y, groups, \
                            (int)n_items, (int)n_full);                                                                              \
         return (int)hipGetLastError();                                                                                               \
     }
@@ -463,11 +624,12 @@ extern "C" int bfsr_conv3x3_x3s(const BfsrConvX3Args* a, void* stream)
     switch (a->tune < 0 ? -a->tune : 0) {
         case 1: BFSR_LAUNCH(1) case 3: BFSR_LAUNCH(3) case 4: BFSR_LAUNCH(4) case 5: BFSR_LAUNCH(5) case 7: BFSR_LAUNCH(7)
         case 8: BFSR_LAUNCH(8) case 12: BFSR_LAUNCH(12) case 16: BFSR_LAUNCH(16) case 48: BFSR_LAUNCH(48) case 80: BFSR_LAUNCH(80)
-        case 17: BFSR_LAUNCH(17) case 144: BFSR_LAUNCH(144) case 145: BFSR_LAUNCH(145) case 20: BFSR_LAUNCH(20) case 148: BFSR_LAUNCH(148)
+        case 272: BFSR_LAUNCH(272) case 528: BFSR_LAUNCH(528) case 1040: BFSR_LAUNCH(1040) case 17: BFSR_LAUNCH(17) case 144: BFSR_LAUNCH(144) case 145: BFSR_LAUNCH(145) case 20: BFSR_LAUNCH(20) case 148: BFSR_LAUNCH(148)
         default: break;
     }
 #endif
-    BFSR_LAUNCH(16)
+    if (a->tune == -1040) BFSR_LAUNCH(1040)                       // 16 | 1024: + deferred epilogue (measured 17-20 % slower, see the kernel)
+    BFSR_LAUNCH(16)                                               // dedicated loader waves, epilogue behind the K loop
 #undef BFSR_LAUNCH
 }
 

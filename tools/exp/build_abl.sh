@@ -9,6 +9,6 @@ $HIPCC $FLAGS -DBFSR_X3S_ABL -c conv_x3s.hip -o build/conv_x3s_abl.o &
 $HIPCC $FLAGS -DBFSR_H2S_ABL -c conv_h2s.hip -o build/conv_h2s_abl.o &
 wait
 objs=""
-for f in conv_mfma conv_f16 conv_bf16x3 conv1x1 flow_ops coupling resample linf_ops linf_mlp metrics; do objs="$objs build/$f.o"; done
+for f in conv_mfma conv_f16 conv_bf16x3 conv1x1 flow_ops coupling coupling_step resample linf_ops linf_mlp metrics; do objs="$objs build/$f.o"; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC $objs build/conv_x3s_abl.o build/conv_h2s_abl.o -o ../../tools/exp/libabl.so
 echo "built tools/exp/libabl.so"

@@ -63,7 +63,7 @@ struct Item { int cg, b, x0, y0, th; };     // th = tile height: TH, or TH/2 for
 // issue the DMA themselves right after the barrier, 8 = one piece per tap between the MFMAs, 1 = no DMA after the first stage
 // (timing only), 2 = no barrier (timing only), 4 = two accumulator chains
 template <int ABL>
-__global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64, 1) void conv3x3_x3s_kernel(BfsrConvX3Args p, int tiles_x, int tiles_y, int groups, int nitems, int n_full)
+__global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64, 1) void conv3x3_x3s_kernel(BfsrConvX3Args p, int tiles_x, int tiles_y, int groups, int nitems, int n_full, int waitvm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -357,7 +357,10 @@ __global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64
         for (int k = 0; k < nchunk; ++k) {
             // this wave's DMA pieces of stage `buf` have landed (with dedicated loader waves a compute wave has none: the wait would
             // only drain its own epilogue stores and residual loads at every chunk boundary) ...
-            if (!(ABL & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // ... which measures both ways (same-run A/B, tools/exp/x3s_abl.py): without the wait one RDB takes 559 instead of 579 us
+            // at 8 x 160^2 (3 rounds of tiles per CU), with it 2556-2634 instead of 2632-2701 us at 16 x 256^2 (16 rounds: draining
+            // the stores throttles the compute waves' traffic against the loaders' DMA) -> `waitvm` is set by the launcher for long runs
+            if (!(ABL & 16) || (ABL & 2048) || waitvm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (!(ABL & 2)) __builtin_amdgcn_s_barrier();         // ... and so have everybody else's; stage buf^1 is free again
             int sk = -1;                                          // chunk to stage into buf^1 (-1: nothing)
             if (k + 1 < nchunk) sk = k + 1;
@@ -611,20 +614,21 @@ extern "C" int bfsr_conv3x3_x3s(const BfsrConvX3Args* a, void* stream)
     const long long rem = nitems % grid;
     if (nitems > grid && rem > 0 && 2 * rem <= grid) { n_full = nitems - rem; n_items = n_full + 2 * rem; }     // split the last partial round
     if (n_items > 0x7fffffffLL) return -1;
+    const int waitvm = (a->tune != -16 && nitems >= 8 * grid * groups) ? 1 : 0;        // >= 8 rounds of tiles per CU (tune -16: never, for A/B)
 #define BFSR_LAUNCH(ABL_)                                                                                                            \
     {                                                                                                                                \
         static std::atomic<unsigned long long> lds_done{0};                                                                          \
         constexpr int LDS_ = LDS_TOTAL + (((ABL_) & 1024) ? LDS_PARK : 0);                                                           \
         if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_x3s_kernel<ABL_>), LDS_, lds_done) != 0) return -1;      \
         hipLaunchKernelGGL(conv3x3_x3s_kernel<ABL_>, dim3((unsigned)grid), dim3((NW + (((ABL_) & 16) ? 2 + (((ABL_) >> 5) & 3) : 0)) * 64), LDS_, st, *a, tiles_x, tiles_y, groups, \
-                           (int)n_items, (int)n_full);                                                                              \
+                           (int)n_items, (int)n_full, waitvm);                                                                      \
         return (int)hipGetLastError();                                                                                               \
     }
 #ifdef BFSR_X3S_ABL
     switch (a->tune < 0 ? -a->tune : 0) {
         case 1: BFSR_LAUNCH(1) case 3: BFSR_LAUNCH(3) case 4: BFSR_LAUNCH(4) case 5: BFSR_LAUNCH(5) case 7: BFSR_LAUNCH(7)
         case 8: BFSR_LAUNCH(8) case 12: BFSR_LAUNCH(12) case 16: BFSR_LAUNCH(16) case 48: BFSR_LAUNCH(48) case 80: BFSR_LAUNCH(80)
-        case 272: BFSR_LAUNCH(272) case 528: BFSR_LAUNCH(528) case 1040: BFSR_LAUNCH(1040) case 17: BFSR_LAUNCH(17) case 144: BFSR_LAUNCH(144) case 145: BFSR_LAUNCH(145) case 20: BFSR_LAUNCH(20) case 148: BFSR_LAUNCH(148)
+        case 272: BFSR_LAUNCH(272) case 528: BFSR_LAUNCH(528) case 1040: BFSR_LAUNCH(1040) case 2064: BFSR_LAUNCH(2064) case 17: BFSR_LAUNCH(17) case 144: BFSR_LAUNCH(144) case 145: BFSR_LAUNCH(145) case 20: BFSR_LAUNCH(20) case 148: BFSR_LAUNCH(148)
         default: break;
     }
 #endif

@@ -18,7 +18,7 @@ def timeit(fn, n=20):
     return s.elapsed_time(e) / n * 1e3
 
 
-NAMES = {1040: "deferred epilogue", 16: "epilogue behind K loop", 144: "no epilogue"}
+NAMES = {16: "product", 2064: "with per-chunk vmcnt(0)", 1040: "deferred epilogue", 144: "no epilogue"}
 for B, H, W in ((8, 160, 160), (16, 256, 256)):
     tot = {k: 0.0 for k in NAMES}
     for Cin, Cout in ((64, 32), (96, 32), (128, 32), (160, 32), (192, 64)):

@@ -25,6 +25,7 @@
 // K loop alone 1.2-1.45 PFLOP/s, whole kernel 0.6-0.8 PFLOP/s and ~3.2 TB/s algorithmic at 128 x 128x128 -- the epilogue
 // (VALU-issue bound, all compute waves in it at once) is the remaining 35 %.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <type_traits>
 #include "../../include/bfsr_hip.h"
 #include "launch_util.h"
@@ -62,15 +63,171 @@ __device__ __forceinline__ void wait_vmcnt(int n)
 {
     switch (n) {
 #define W_(N_) case N_: asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory"); break;
-        W_(7) W_(8) W_(9) W_(10) W_(14) W_(16)
+        W_(6) W_(7) W_(8) W_(9) W_(10) W_(12) W_(14) W_(16) W_(18)
 #undef W_
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
 
+// ---- loader waves (shared by both kernels).  Barrier c = "chunk c is in LDS, and every compute wave is past its reads of chunk c-2"
+// (they arrive one pipeline step early, see below), so the stage of chunk c-2 is refilled with chunk c+NS-2: three stages in flight.
+// `s_waitcnt vmcnt(N)` stands for "everything but the youngest N/np stages has landed" because a loader issues the same number np
+// of pieces for every chunk -- and only ONE KIND of load: LDS-DMA pieces and ordinary register loads of one wave do NOT complete
+// in issue order relative to each other (measured: a wave mixing them passed the barrier with input pieces still in flight).
+//   wreg = 0: four DMA loaders, piece i of a stage (i < 20: input position group i>>1, k half i&1; else weight piece i-20) -> loader i % 4
+//   wreg = 1: three DMA loaders for the 20 input pieces; loader 3 moves the 9 weight pieces through REGISTERS (buffer_load -> VGPR when
+//             the stage is issued, ds_write_b128 just before the chunk's barrier).  The DMA path sustains ~27 GB/s per CU (what the
+//             kernel with its K loop removed reaches); the weights are 31 % of a stage and take the ordinary load path instead.
+template <class Decode>
+__device__ __forceinline__ void h2s_loader_wave(const BfsrConvX3Args& p, unsigned char* smem, int wave, int lane, int slot, int G, int groups,
+                                                int nchunk, int T, unsigned HW16, int abl, bool wreg, Decode decode)
+{
+    const int H = p.H, W = p.W;
+    const int ld = wave - NW;
+    constexpr int NWPIECE = W_BYTES / 1024;                          // 9
+    if (wreg && ld == NLW - 1) {
+        // ---- the register loader.  Inline asm with a TIED operand: the compiler must not know the loads are asynchronous (with the
+        // builtin it copies the registers behind an `s_waitcnt vmcnt(0)` right after the issue, draining all stages in flight), and
+        // the load must land in the slot's own registers ("=v" gives a fresh register that is COPIED to the slot before the data
+        // has arrived).  Issued unconditionally (out-of-range offset = no memory access) for the same reason: under a branch the
+        // tied register is copied at the merge.  The registers are read only behind wait_vmcnt().
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        i32x4 rsw;
+        {
+            const unsigned long long wa = reinterpret_cast<unsigned long long>(p.w);
+            rsw[0] = (int)(unsigned)wa; rsw[1] = (int)(unsigned)(wa >> 32);
+            rsw[2] = (int)(unsigned)((long long)groups * nchunk * W_BYTES); rsw[3] = 0x00020000;
+        }
+        static_assert(NS - 2 == 3, "three register slots = stages in flight");
+        u32x4 w[3][NWPIECE];
+#pragma unroll
+        for (int a_ = 0; a_ < 3; ++a_)
+#pragma unroll
+            for (int j = 0; j < NWPIECE; ++j) w[a_][j] = u32x4{0u, 0u, 0u, 0u};
+        int issued = 0, iss_it = slot, iss_k = 0, cbuf = 0;
+        int cg_ = 0;
+        const unsigned wv = (unsigned)lane * 16u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BFSR_WLOAD(R_, VO_, SO_) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(R_) : "v"(VO_), "s"(rsw), "s"(SO_) : "memory")
+#else
+#define BFSR_WLOAD(R_, VO_, SO_) (void)0
+#endif
+#define BFSR_ISSUE(SL_)                                                                                                  \
+    do {                                                                                                                \
+        bool on_ = issued < T;                                                                                          \
+        unsigned so_ = 0;                                                                                               \
+        if (on_) {                                                                                                      \
+            if (iss_k == 0) cg_ = decode(iss_it).cg;                                                                    \
+            so_ = (unsigned)(cg_ * nchunk + iss_k) * (unsigned)W_BYTES;                                                 \
+            BFSR_ABL_SKIP                                                                                               \
+            ++issued;                                                                                                   \
+            if (++iss_k == nchunk) { iss_k = 0; iss_it += G; }                                                          \
+        }                                                                                                               \
+        so_ = (unsigned)__builtin_amdgcn_readfirstlane((int)so_);                                                       \
+        _Pragma("unroll") for (int j = 0; j < NWPIECE; ++j) BFSR_WLOAD(w[SL_][j], on_ ? wv + (unsigned)j * 1024u : OOB, so_); \
+    } while (0)
+#ifdef BFSR_H2S_ABL
+#define BFSR_ABL_SKIP if (issued >= NS - 2 && (abl & 2)) on_ = false;
+#else
+#define BFSR_ABL_SKIP
+#endif
+#define BFSR_LAND(SL_, CH_)                                                                                              \
+    do {                                                                                                                \
+        wait_vmcnt((issued - (CH_) - 1) * NWPIECE);                    /* all but the stages issued after this chunk's */ \
+        unsigned char* wb_ = smem + cbuf * STAGE + IN_BYTES + lane * 16;                                                \
+        _Pragma("unroll") for (int j = 0; j < NWPIECE; ++j) *reinterpret_cast<u32x4*>(wb_ + j * 1024) = w[SL_][j];       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
+        cbuf = cbuf + 1 == NS ? 0 : cbuf + 1;                                                                           \
+        __builtin_amdgcn_s_barrier();                                                                                   \
+    } while (0)
+        BFSR_ISSUE(0);
+        BFSR_ISSUE(1);
+        BFSR_ISSUE(2);
+        for (int c = 0; c < T; c += 3) {
+            BFSR_LAND(0, c);
+            BFSR_ISSUE(0);
+            if (c + 1 >= T) break;
+            BFSR_LAND(1, c + 1);
+            BFSR_ISSUE(1);
+            if (c + 2 >= T) break;
+            BFSR_LAND(2, c + 2);
+            BFSR_ISSUE(2);
+        }
+#undef BFSR_LAND
+#undef BFSR_ISSUE
+#undef BFSR_WLOAD
+#undef BFSR_ABL_SKIP
+        return;
+    }
+    // ---- DMA loaders
+    const int ND = wreg ? NLW - 1 : NLW;                             // DMA loaders
+    const int NPALL = wreg ? 20 : NPIECE;                            // pieces they share
+    const int np = (NPALL - ld + ND - 1) / ND;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w), 0,
+                                                                          (unsigned)((long long)groups * nchunk * W_BYTES), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_in;
+    constexpr int NJI = (20 + NLW - 2) / (NLW - 1);                  // input pieces per loader, at most (7; a dependent bound here makes hipcc 7.2 drop the HOST stub silently)
+    unsigned vg[NJI];
+    int cg_ = 0;
+    auto lsetup = [&](const Item& it) {
+        const unsigned short* xb = p.x + (long long)it.b * p.x_bs;
+        rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xb), 0, (unsigned)(p.Cin >> 3) * 2u * HW16, 0x00020000);
+        cg_ = it.cg;
+#pragma unroll
+        for (int j = 0; j < NJI; ++j) {
+            const int i = ld + j * ND;
+            const int pos = (i >> 1) * 64 + lane;
+            const int r = pos / PW, c = pos - r * PW;
+            const int gy = it.y0 + r - 1, gx = it.x0 + c - 1;
+            const bool ok = i < 20 && pos < NPOS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            vg[j] = ok ? (unsigned)(gy * W + gx) * 16u : OOB;        // out of range -> the DMA writes zeros (= the padding)
+        }
+    };
+    auto lstage = [&](int k, int buf, int skip) {
+        unsigned char* base = smem + buf * STAGE;
+        const unsigned wsoff = (unsigned)(cg_ * nchunk + k) * (unsigned)W_BYTES;
+#pragma unroll
+        for (int j = 0; j < NJI + 3; ++j) {
+            const int i = ld + j * ND;
+            if (i >= NPALL) continue;
+            if (j < NJI && i < 20) {
+                if (skip & 1) continue;
+                const unsigned soff = (unsigned)(2 * k + (i & 1)) * 2u * HW16;                  // hi plane of channel octet 2k + (i&1)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(base + (i & 1) * SUB + (i >> 1) * 1024), 16, vg[j], soff, 0, 0);
+            } else {
+                if (skip & 2) continue;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(base + IN_BYTES + (i - 20) * 1024), 16,
+                                                         (unsigned)lane * 16u + (unsigned)(i - 20) * 1024u, wsoff, 0, 0);
+            }
+        }
+    };
+    int issued = 0, iss_it = slot, iss_k = 0, iss_buf = 0;
+    auto issue = [&]() {
+        if (iss_k == 0) lsetup(decode(iss_it));
+#ifdef BFSR_H2S_ABL
+        lstage(iss_k, iss_buf, issued >= NS - 2 ? abl & 3 : 0);
+#else
+        lstage(iss_k, iss_buf, 0);
+#endif
+        ++issued;
+        iss_buf = iss_buf + 1 == NS ? 0 : iss_buf + 1;
+        if (++iss_k == nchunk) { iss_k = 0; iss_it += G; }
+    };
+    for (int i = 0; i < NS - 2 && issued < T; ++i) issue();
+    for (int c = 0; c < T; ++c) {
+#ifdef BFSR_H2S_ABL
+        if (abl & 3) wait_vmcnt(0); else
+#endif
+        wait_vmcnt((issued - c - 1) * np);                           // all but the stages issued after chunk c's
+        __builtin_amdgcn_s_barrier();
+        if (issued < T) issue();
+    }
+}
+
 // abl = ablation switches, honoured only in -DBFSR_H2S_ABL builds (tools/exp/h2s_bench.py): 1 = no input DMA after the first
 // stages, 2 = no weight DMA after them, 4 = no ds_read/MFMA, 8 = no epilogue
-__global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrConvX3Args p, int tiles_x, int tiles_y, int groups, int nitems, int abl)
+__global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrConvX3Args p, int tiles_x, int tiles_y, int groups, int nitems, int abl, int flags)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -94,69 +251,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
     };
 
     if (wave >= NW) {
-        // ---- loader waves.  Piece i of a stage (i < 20: input position group i>>1, k half i&1; else weight piece i-20) belongs to
-        // loader i % NLW: the same count np for every chunk, which is what lets `vmcnt(N)` stand for "everything but the youngest
-        // N/np stages has landed".  Barrier c = "chunk c is in LDS, and every compute wave is past its reads of chunk c-2" (they
-        // arrive one pipeline step early, see below), so the stage of chunk c-2 is refilled with chunk c+NS-2.
-        const int ld = wave - NW;
-        const int np = (NPIECE - ld + NLW - 1) / NLW;
-        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w), 0,
-                                                                              (unsigned)((long long)groups * nchunk * W_BYTES), 0x00020000);
-        __amdgpu_buffer_rsrc_t rs_in;
-        unsigned vg[5];                                                  // 20 input pieces / 4 loaders (a dependent bound here makes hipcc 7.2 drop the HOST stub silently)
-        int cg_ = 0;
-        auto lsetup = [&](const Item& it) {
-            const unsigned short* xb = p.x + (long long)it.b * p.x_bs;
-            rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xb), 0, (unsigned)(p.Cin >> 3) * 2u * HW16, 0x00020000);
-            cg_ = it.cg;
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const int i = ld + j * NLW;
-                const int pos = (i >> 1) * 64 + lane;
-                const int r = pos / PW, c = pos - r * PW;
-                const int gy = it.y0 + r - 1, gx = it.x0 + c - 1;
-                const bool ok = pos < NPOS && gy >= 0 && gy < H && gx >= 0 && gx < W;
-                vg[j] = ok ? (unsigned)(gy * W + gx) * 16u : OOB;        // out of range -> the DMA writes zeros (= the padding)
-            }
-        };
-        auto lstage = [&](int k, int buf, int skip) {
-            unsigned char* base = smem + buf * STAGE;
-            const unsigned wsoff = (unsigned)(cg_ * nchunk + k) * (unsigned)W_BYTES;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int i = ld + j * NLW;
-                if (j < 5) {
-                    if (skip & 1) continue;
-                    const unsigned soff = (unsigned)(2 * k + (i & 1)) * 2u * HW16;                  // hi plane of channel octet 2k + (i&1)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(base + (i & 1) * SUB + (i >> 1) * 1024), 16, vg[j], soff, 0, 0);
-                } else if (i < NPIECE) {
-                    if (skip & 2) continue;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(base + IN_BYTES + (i - 20) * 1024), 16,
-                                                             (unsigned)lane * 16u + (unsigned)(i - 20) * 1024u, wsoff, 0, 0);
-                }
-            }
-        };
-        int issued = 0, iss_it = slot, iss_k = 0, iss_buf = 0;
-        auto issue = [&]() {
-            if (iss_k == 0) lsetup(decode(iss_it));
-#ifdef BFSR_H2S_ABL
-            lstage(iss_k, iss_buf, issued >= NS - 2 ? abl & 3 : 0);
-#else
-            lstage(iss_k, iss_buf, 0);
-#endif
-            ++issued;
-            iss_buf = iss_buf + 1 == NS ? 0 : iss_buf + 1;
-            if (++iss_k == nchunk) { iss_k = 0; iss_it += G; }
-        };
-        for (int i = 0; i < NS - 2 && issued < T; ++i) issue();
-        for (int c = 0; c < T; ++c) {
-#ifdef BFSR_H2S_ABL
-            if (abl & 3) wait_vmcnt(0); else
-#endif
-            wait_vmcnt((issued - c - 1) * np);                           // all but the stages issued after chunk c's
-            __builtin_amdgcn_s_barrier();
-            if (issued < T) issue();
-        }
+        h2s_loader_wave(p, smem, wave, lane, slot, G, groups, nchunk, T, HW16, abl, (flags & 1) != 0, decode);
         return;
     }
 
@@ -413,6 +508,262 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
     }
 }
 
+// ---- PING-PONG variant (the product for Cin >= 64): the two compute waves of a SIMD (waves w and w+4) take turns -----------------
+// Same tiles, same LDS ring, same loader waves, same barrier sequence.  Group g = wave>>2 owns the tiles t of this workgroup with
+// (t & 1) == g; a wave owns FOUR rows of its group's tile (4 accumulator blocks, 9 LDS reads per 12 MFMAs).  While group g runs
+// the K loop of tile t -- alone on the matrix pipes, one wave per SIMD -- the other group runs the epilogue of tile t-1 on the VALU /
+// memory pipes of the same SIMDs, one row per barrier interval, and passes the same barriers (s_barrier counts every wave of the
+// workgroup; the epilogue group only keeps step).  The matrix pipe and the VALU are separate issue targets, so the epilogue that cost
+// 35 % of the kernel with all eight compute waves in it at the same time now runs beside the other group's MFMAs.
+__global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_pp_kernel(BfsrConvX3Args p, int tiles_x, int tiles_y, int groups, int nitems, int abl, int flags)
+{
+    constexpr int RW = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int G = gridDim.x;
+    const int slot = (int)bfsr::xcd_order(blockIdx.x, (unsigned)G);
+    if (slot >= nitems) return;
+    const int H = p.H, W = p.W;
+    const unsigned HW16 = (unsigned)(H * W) * 16u;
+    const int nchunk = p.Cin >> 4;
+    const int n_mine = (nitems - slot + G - 1) / G;
+    const int T = n_mine * nchunk;
+
+    auto decode = [&](int it) {
+        Item r;
+        r.cg = it % groups; int t = it / groups;
+        const int ty = t % tiles_y; t /= tiles_y;
+        r.x0 = (t % tiles_x) * 32; r.y0 = ty * TH; r.b = t / tiles_x;
+        return r;
+    };
+    if (wave >= NW) {
+        h2s_loader_wave(p, smem, wave, lane, slot, G, groups, nchunk, T, HW16, abl, (flags & 1) != 0, decode);
+        return;
+    }
+    const int cw = wave & 3, grp = wave >> 2;                            // row block of the tile (rows 4cw .. 4cw+3), tile parity this wave computes
+
+    half8 bq[2][RW + 2], aq[2][3];
+    auto load_step = [&](auto buf_, int st, int dx) {
+        constexpr int BUF = decltype(buf_)::value;
+        const unsigned char* sIn = smem + st * STAGE;
+        const unsigned char* inB = sIn + (lhi * NPOSP + RW * cw * PW + l31 + dx) * 16;
+        const unsigned char* wA = sIn + IN_BYTES + lane * 16 + dx * 3 * 1024;                           // tap = dx*3 + dy; (lhi*32 + l31) == lane
+#pragma unroll
+        for (int r = 0; r < RW + 2; ++r) bq[BUF][r] = *reinterpret_cast<const half8*>(inB + r * PW * 16);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) aq[BUF][dy] = *reinterpret_cast<const half8*>(wA + dy * 1024);
+    };
+    f32x16 acc[RW];
+    auto mfma_step = [&](auto buf_) {
+        constexpr int BUF = decltype(buf_)::value;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int j = 0; j < RW; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][dy], bq[BUF][dy + j], acc[j], 0, 0, 0);
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 3> I3;
+    int c = 0, st = 0;
+    auto chunk_body = [&](auto p_, auto q_, bool pf) {                   // as in conv3x3_h2s_kernel
+        const int nst = st + 1 == NS ? 0 : st + 1;
+        load_step(q_, st, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(p_);
+        __builtin_amdgcn_sched_barrier(0);
+        load_step(p_, st, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(q_);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < T) {
+            __builtin_amdgcn_s_barrier();
+            if (pf) load_step(q_, nst, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(p_);
+        __builtin_amdgcn_sched_barrier(0);
+        st = nst; ++c;
+    };
+    const float slope = p.act == BFSR_ACT_NONE ? 1.f : (p.act == BFSR_ACT_RELU ? 0.f : p.slope);
+    const float4* __restrict__ epi = reinterpret_cast<const float4*>(p.epi);
+    const long long HW = (long long)H * W;
+
+    // ---- epilogue of ONE row (J: compile-time) of tile `cur`: see conv3x3_h2s_kernel for the stages; the residual operands of the row
+    // are requested first and land under the swaps / parameter exchange / activation
+    auto epi_row = [&](const Item& cur, const float4 pm, auto J_) {
+        constexpr int J = decltype(J_)::value;
+#ifdef BFSR_H2S_ABL
+        if (abl & 8) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" :: "v"(acc[J]));
+#endif
+            return;
+        }
+#endif
+        // the lane id is re-derived here (mbcnt) behind an opaque copy: everything per-lane below would otherwise be loop-invariant,
+        // hoisted out of the tile loop and SPILLED (the K loop needs 136 of the 168 registers) -- and a scratch reload in the epilogue
+        // group waits on vmcnt(0), i.e. on the previous row's stores
+        int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(ln));
+#endif
+        const int lh = ln >> 5, lx = ln & 31;
+        const bool plain = (ln & 1) ? pm.x == 1.f : (pm.y == 0.f && pm.z == 1.f && pm.w == 0.f);
+        const bool bias_only = __all(plain);
+        const bool fast = bias_only && slope >= 0.f && slope <= 1.f;
+        auto fetch = [&](float val, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane * 4, __float_as_int(val))); };
+        const int gx = cur.x0 + lx, gy = cur.y0 + RW * cw + J;
+        int goff[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int oct = cur.cg * 4 + q * 2 + lh;
+            goff[q] = (gy < H && gx < W && oct * 8 < p.Cout) ? (int)(((long long)oct * 2 * HW + (long long)gy * W + gx) * 8) : -1;
+        }
+        half8 rh[2], rl[2];                                              // residual operands: res1 now, res2 into the same registers later
+        auto load_res = [&](const unsigned short* res, long long bs) {
+            const unsigned short* rb = res + (long long)cur.b * bs;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { rh[q][i] = (_Float16)0.f; rl[q][i] = (_Float16)0.f; }
+                if (goff[q] >= 0) {
+                    rh[q] = *reinterpret_cast<const half8*>(rb + goff[q]);
+                    rl[q] = *reinterpret_cast<const half8*>(rb + goff[q] + HW * 8);
+                }
+            }
+        };
+        if (p.res1) load_res(p.res1, p.res1_bs);
+        float o[2][8];
+        asm volatile("s_nop 11" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float lo = acc[J][8 * q + i], hi = acc[J][8 * q + 4 + i];
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+                o[q][i] = lo;
+                o[q][4 + i] = hi;
+            }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (fast) {                                                  // bias + (leaky) ReLU only: one exchange and 3 VALU ops per channel
+                float e0[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) e0[i] = fetch(pm.x, ((q * 2 + lh) * 8 + i) * 2);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float u = o[q][i] + e0[i];
+                    o[q][i] = fmaxf(u, u * slope);                       // = u > 0 ? u : u*slope for 0 <= slope <= 1
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {                            // per channel (five exchanged values live at a time, not forty)
+                    const int src = ((q * 2 + lh) * 8 + i) * 2;         // lane holding this channel's first float4
+                    const float e0 = fetch(pm.x, src), e1 = fetch(pm.y, src), e2 = fetch(pm.z, src), e3 = fetch(pm.w, src), e4 = fetch(pm.x, src + 1);
+                    float u = o[q][i] + e0;
+                    u = (u + e1) * e2 + e3;
+                    u = u > 0.f ? u : u * slope;
+                    o[q][i] = u * e4;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (p.res1) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[q][i] = p.alpha1 * o[q][i] + ((float)rh[q][i] + (float)rl[q][i]);
+        }
+        if (p.res2) {
+            load_res(p.res2, p.res2_bs);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[q][i] = p.alpha2 * o[q][i] + ((float)rh[q][i] + (float)rl[q][i]);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int g = goff[q];
+            if (g < 0) continue;
+            if (p.y_fmt == 2) {
+                half8 h8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) h8[i] = (_Float16)o[q][i];
+                *reinterpret_cast<half8*>(reinterpret_cast<unsigned short*>(p.y) + (long long)cur.b * p.y_bs + g) = h8;
+            } else if (p.y_fmt == 1) {
+                half8 h8, l8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { _Float16 h, l; split2(o[q][i], h, l); h8[i] = h; l8[i] = l; }
+                unsigned short* yb = reinterpret_cast<unsigned short*>(p.y) + (long long)cur.b * p.y_bs + g;
+                *reinterpret_cast<half8*>(yb) = h8;
+                *reinterpret_cast<half8*>(yb + HW * 8) = l8;
+            } else {
+                const int oct = cur.cg * 4 + q * 2 + lh;
+                float* yb = reinterpret_cast<float*>(p.y) + (long long)cur.b * p.y_bs + (long long)gy * W + gx;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (oct * 8 + i < p.Cout) yb[(long long)(oct * 8 + i) * HW] = o[q][i];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    __builtin_amdgcn_s_barrier();                                        // barrier 0
+    Item mine = {0, 0, 0, 0};
+    float4 pm_mine = make_float4(0.f, 0.f, 1.f, 0.f);
+    bool have = false;
+    for (int t = 0; t < n_mine; ++t) {
+        const bool last = t + 1 == n_mine;
+        if ((t & 1) == grp) {
+            // ---- K loop of tile t (barrier t*nchunk is behind every wave); passes barriers t*nchunk+1 .. (t+1)*nchunk (the last tile: one fewer)
+            mine = decode(slot + t * G);
+            {
+                int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" : "+v"(ln));
+#endif
+                const int idx = mine.cg * 64 + ln;
+                pm_mine = (ln & 1) ? make_float4(1.f, 0.f, 0.f, 0.f) : make_float4(0.f, 0.f, 1.f, 0.f);
+                if (epi && (idx >> 1) < p.Cout) pm_mine = epi[idx];
+            }
+#pragma unroll
+            for (int j = 0; j < RW; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#ifdef BFSR_H2S_ABL
+            if (abl & 4) { for (int k = 0; k < nchunk; ++k) { if (c + 1 < T) __builtin_amdgcn_s_barrier(); ++c; st = st + 1 == NS ? 0 : st + 1; } } else
+#endif
+            {
+                load_step(I0(), st, 0);
+                for (int k = 0; k < nchunk; k += 2) {                    // Cin % 32 == 0: the register-buffer parity is static
+                    chunk_body(I0(), I1(), true);
+                    chunk_body(I1(), I0(), k + 2 < nchunk);
+                }
+            }
+            have = true;
+            if (last) { epi_row(mine, pm_mine, I0()); epi_row(mine, pm_mine, I1()); epi_row(mine, pm_mine, I2()); epi_row(mine, pm_mine, I3()); }
+        } else {
+            // ---- the other group computes tile t: epilogue of this group's tile t-1, one row per barrier interval, and the same barriers
+            const int nb = last ? nchunk - 1 : nchunk;
+            if (have) epi_row(mine, pm_mine, I0());
+            if (nb > 0) __builtin_amdgcn_s_barrier();
+            if (have) epi_row(mine, pm_mine, I1());
+            if (nb > 1) __builtin_amdgcn_s_barrier();
+            if (have) epi_row(mine, pm_mine, I2());
+            if (nb > 2) __builtin_amdgcn_s_barrier();
+            if (have) epi_row(mine, pm_mine, I3());
+            for (int k = 3; k < nb; ++k) __builtin_amdgcn_s_barrier();
+            have = false;
+            c += nchunk;
+            st = (st + nchunk) % NS;
+        }
+    }
+}
+
 // ---- fp32 NCHW view <-> h2 tensor (the two ends of the fp16-stored region: conv_first's output, the trunk output) -------------
 __global__ void h2_pack_kernel(const float* __restrict__ x, long long x_bs, unsigned short* __restrict__ y, long long y_bs,
                                int C, long long HW, long long total)
@@ -513,9 +864,19 @@ extern "C" int bfsr_conv3x3_h2s(const BfsrConvX3Args* a, void* stream)
 #ifdef BFSR_H2S_ABL
     abl = a->tune < 0 ? -a->tune : 0;
 #endif
-    static std::atomic<unsigned long long> lds_done{0};
+    static std::atomic<unsigned long long> lds_done{0}, lds_done_pp{0};
+    // Both variants are parity-tested and measured within box-to-box noise of the default (tools/exp/h2s_bench.py):
+    //   BFSR_H2S_PP=1   ping-pong compute groups (conv3x3_h2s_pp_kernel): one RDB 1.30-1.38 ms vs 1.26-1.42 ms
+    //   BFSR_H2S_WREG=1 weight pieces through registers of a dedicated loader wave instead of LDS-DMA: 1.38-1.42 ms
+    static const int pp_mode = [] { const char* e = getenv("BFSR_H2S_PP"); return e ? atoi(e) : 0; }();
+    static const int flags = [] { const char* e = getenv("BFSR_H2S_WREG"); return e ? atoi(e) : 0; }();
+    if (pp_mode && a->Cin >= 64) {
+        if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2s_pp_kernel), LDS_TOTAL, lds_done_pp) != 0) return -1;
+        hipLaunchKernelGGL(conv3x3_h2s_pp_kernel, dim3((unsigned)grid), dim3((NW + NLW) * 64), LDS_TOTAL, st, *a, tiles_x, tiles_y, groups, (int)nitems, abl, flags);
+        return (int)hipGetLastError();
+    }
     if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2s_kernel), LDS_TOTAL, lds_done) != 0) return -1;
-    hipLaunchKernelGGL(conv3x3_h2s_kernel, dim3((unsigned)grid), dim3((NW + NLW) * 64), LDS_TOTAL, st, *a, tiles_x, tiles_y, groups, (int)nitems, abl);
+    hipLaunchKernelGGL(conv3x3_h2s_kernel, dim3((unsigned)grid), dim3((NW + NLW) * 64), LDS_TOTAL, st, *a, tiles_x, tiles_y, groups, (int)nitems, abl, flags);
     return (int)hipGetLastError();
 }
 

@@ -764,6 +764,288 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_pp_kernel(Bfsr
     }
 }
 
+// =====================================================================================================================
+// conv3x3_h2x_kernel -- the same conv at FP32-CLASS accuracy on the fp16 matrix pipe: BOTH planes of the h2 activations and a
+// two-term fp16 split of the weights, three products  lo*hi + hi*lo + hi*hi  (each exact in the fp32 accumulator).
+//   x = hi + lo carries 22 significant bits (hi = fp16(x), lo = fp16(x - hi)); the dropped lo*lo term is <= 2^-22 relative.  fp16
+//   has a narrow exponent: the weights are pre-multiplied by a power of two (their largest magnitude lands in [2^9, 2^10), so the
+//   lo terms of all but negligible weights are normal numbers) and the accumulators are multiplied by the inverse power first thing
+//   in the epilogue (`acc_scale`, exact); activations need |x| < 65504.  Measured end to end against an fp64 evaluation of the
+//   SRFlow-LP pipeline this arithmetic is indistinguishable from fp32 (sr 3.7e-6 vs 3.6e-6 for the CPU's fp32)
+//   at HALF the matrix instructions and 2/3 of the operand bytes of the 3xBF16 scheme (six products of three-term bf16 splits).
+// Structure: the 16-row tile, two rows per compute wave and the fragment double buffer of conv3x3_h2s_kernel; LDS stage = input
+// [2 planes][2 k halves][640 positions][8] + weights [2 planes][9 taps][2][32][8] = 40 960 + 18 432 B, two stages, ONE barrier per
+// 16-channel chunk (conv_x3s.hip's protocol: the four loader waves stage chunk k+1 -- across tile boundaries -- while chunk k is
+// in the matrix pipe; loader `ld` owns sub-image `ld` (plane, k half) of every position group and its share of the weight pieces).
+// Per chunk and wave: 42 ds_read_b128 for 54 MFMAs.  Persistent workgroups, XCD-aware order.  Epilogue = conv3x3_h2s_kernel's.
+constexpr int X_IN = 4 * SUB;                   // 40 960
+constexpr int X_WPL = 9 * 1024;                 // one weight plane of a chunk
+constexpr int X_W = 2 * X_WPL;                  // 18 432
+constexpr int X_STAGE = X_IN + X_W;             // 59 392
+constexpr int X_LDS = 2 * X_STAGE;              // 118 784
+constexpr int X_NPIECE = 40 + X_W / 1024;       // 58 LDS-DMA pieces per stage
+
+__global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrConvX3Args p, int tiles_x, int tiles_y, int groups, int nitems)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int G = gridDim.x;
+    const int slot = (int)bfsr::xcd_order(blockIdx.x, (unsigned)G);
+    if (slot >= nitems) return;
+    const int H = p.H, W = p.W;
+    const unsigned HW16 = (unsigned)(H * W) * 16u;                       // bytes of one (octet, plane) image
+    const int nchunk = p.Cin >> 4;
+
+    auto decode = [&](int it) {
+        Item r;
+        r.cg = it % groups; int t = it / groups;
+        const int ty = t % tiles_y; t /= tiles_y;
+        r.x0 = (t % tiles_x) * 32; r.y0 = ty * TH; r.b = t / tiles_x;
+        return r;
+    };
+
+    if (wave >= NW) {
+        // ---- loader waves: LDS-DMA only (see h2s_loader_wave on why a wave must not mix load kinds)
+        const int ld = wave - NW;                                        // = sub-image (plane ld>>1, k half ld&1) of every position group
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w), 0,
+                                                                              (unsigned)((long long)groups * nchunk * X_W), 0x00020000);
+        __amdgpu_buffer_rsrc_t rs_in;
+        unsigned vg[NG];
+        int cg_ = 0;
+        auto lsetup = [&](const Item& it) {
+            const unsigned short* xb = p.x + (long long)it.b * p.x_bs;
+            rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xb), 0, (unsigned)(p.Cin >> 3) * 2u * HW16, 0x00020000);
+            cg_ = it.cg;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int pos = g * 64 + lane;
+                const int r = pos / PW, c = pos - r * PW;
+                const int gy = it.y0 + r - 1, gx = it.x0 + c - 1;
+                const bool ok = pos < NPOS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                vg[g] = ok ? (unsigned)(gy * W + gx) * 16u : OOB;        // out of range -> the DMA writes zeros (= the padding)
+            }
+        };
+        auto lstage = [&](int k, int buf) {
+            unsigned char* base = smem + buf * X_STAGE;
+            const unsigned soff = (unsigned)((2 * k + (ld & 1)) * 2 + (ld >> 1)) * HW16;      // octet 2k + k half, plane ld>>1
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(base + ld * SUB + g * 1024), 16, vg[g], soff, 0, 0);
+            const unsigned wsoff = (unsigned)(cg_ * nchunk + k) * (unsigned)X_W;
+#pragma unroll
+            for (int j = 0; j < (X_W / 1024 + NLW - 1) / NLW; ++j) {
+                const int piece = ld + j * NLW;
+                if (piece < X_W / 1024)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(base + X_IN + piece * 1024), 16,
+                                                             (unsigned)lane * 16u + (unsigned)piece * 1024u, wsoff, 0, 0);
+            }
+        };
+        int it = slot;
+        lsetup(decode(it));
+        lstage(0, 0);
+        int buf_ = 0;
+        while (true) {
+            const int nxt = it + G;
+            const bool has_next = nxt < nitems;
+            for (int k = 0; k < nchunk; ++k) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (k + 1 < nchunk) lstage(k + 1, buf_ ^ 1);
+                else if (has_next) { lsetup(decode(nxt)); lstage(0, buf_ ^ 1); }
+                buf_ ^= 1;
+            }
+            if (!has_next) return;
+            it = nxt;
+        }
+    }
+
+    // ---- compute waves: wave w owns rows 2w, 2w+1.  A step = one tap (dx, dy): 2 input rows x 2 planes + the tap's 2 weight planes
+    // -> 6 MFMAs; the fragments of step t+1 are read while the MFMAs of step t run (register double buffer: 48 registers -- a
+    // tap-COLUMN step as in conv3x3_h2s_kernel needs 112 and spills beside the 32 accumulators).
+    half8 bq[2][2][2], aq[2][2];                                         // [buffer][plane][row] | [buffer][plane]
+    auto load_step = [&](auto buf_, int st, int t) {
+        constexpr int BUF = decltype(buf_)::value;
+        const int dx = t / 3, dy = t - 3 * dx;
+        const unsigned char* sIn = smem + st * X_STAGE;
+        const unsigned char* inB = sIn + (lhi * NPOSP + (2 * wave + dy) * PW + l31 + dx) * 16;
+        const unsigned char* wA = sIn + X_IN + lane * 16 + t * 1024;                                     // tap = dx*3 + dy = t
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) bq[BUF][pl][r] = *reinterpret_cast<const half8*>(inB + pl * 2 * SUB + r * PW * 16);
+            aq[BUF][pl] = *reinterpret_cast<const half8*>(wA + pl * X_WPL);
+        }
+    };
+    f32x16 acc[2];
+    auto mfma_step = [&](auto buf_) {
+        constexpr int BUF = decltype(buf_)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                                    // smallest terms first: w_lo*x_hi, w_hi*x_lo, w_hi*x_hi
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][1], bq[BUF][0][j], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][0], bq[BUF][1][j], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][0], bq[BUF][0][j], acc[j], 0, 0, 0);
+        }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    const float slope = p.act == BFSR_ACT_NONE ? 1.f : (p.act == BFSR_ACT_RELU ? 0.f : p.slope);
+    const float4* __restrict__ epi = reinterpret_cast<const float4*>(p.epi);
+    const long long HW = (long long)H * W;
+    int buf = 0;
+    for (int it = slot; it < nitems; it += G) {
+        const Item cur = decode(it);
+        float4 pm;
+        {
+            int ln = lane;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(ln));                                 // per-lane address arithmetic stays inside the tile loop
+#endif
+            const int idx = cur.cg * 64 + ln;
+            pm = (ln & 1) ? make_float4(1.f, 0.f, 0.f, 0.f) : make_float4(0.f, 0.f, 1.f, 0.f);
+            if (epi && (idx >> 1) < p.Cout) pm = epi[idx];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+        for (int k = 0; k < nchunk; ++k) {
+            __builtin_amdgcn_s_barrier();                                // chunk k has landed in stage `buf`; stage buf^1 is free again
+            load_step(I0(), buf, 0);
+#pragma unroll
+            for (int t = 0; t < 9; t += 2) {
+                if (t + 1 < 9) load_step(I1(), buf, t + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_step(I0());
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < 9) {
+                    if (t + 2 < 9) load_step(I0(), buf, t + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_step(I1());
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            buf ^= 1;
+        }
+
+        // ---- epilogue (the loaders are already staging the next item): as in conv3x3_h2s_kernel, plus the weight scale
+        const bool plain = (lane & 1) ? pm.x == 1.f : (pm.y == 0.f && pm.z == 1.f && pm.w == 0.f);
+        const bool bias_only = __all(plain);
+        const bool fast = bias_only && slope >= 0.f && slope <= 1.f;
+        auto fetch = [&](float val, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane * 4, __float_as_int(val))); };
+        int lh = lhi, lx = l31;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(lh), "+v"(lx));
+#endif
+        const int gx = cur.x0 + lx;
+        int goff[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int oct = cur.cg * 4 + q * 2 + lh;
+                const int gy = cur.y0 + 2 * wave + j;
+                goff[j][q] = (gy < H && gx < W && oct * 8 < p.Cout) ? (int)(((long long)oct * 2 * HW + (long long)gy * W + gx) * 8) : -1;
+            }
+        half8 rh[2][2], rl[2][2];
+        auto load_res = [&](const unsigned short* res, long long bs) {
+            const unsigned short* rb = res + (long long)cur.b * bs;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { rh[j][q][i] = (_Float16)0.f; rl[j][q][i] = (_Float16)0.f; }
+                    if (goff[j][q] >= 0) {
+                        rh[j][q] = *reinterpret_cast<const half8*>(rb + goff[j][q]);
+                        rl[j][q] = *reinterpret_cast<const half8*>(rb + goff[j][q] + HW * 8);
+                    }
+                }
+        };
+        if (p.res1) load_res(p.res1, p.res1_bs);                         // lands under the swaps / parameter exchange / activation
+        float o[2][2][8];
+        asm volatile("s_nop 11" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float lo = acc[j][8 * q + i], hi = acc[j][8 * q + 4 + i];
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+                    o[j][q][i] = lo * p.acc_scale;
+                    o[j][q][4 + i] = hi * p.acc_scale;
+                }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (fast) {
+                float e0[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) e0[i] = fetch(pm.x, ((q * 2 + lh) * 8 + i) * 2);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float u = o[j][q][i] + e0[i];
+                        o[j][q][i] = fmaxf(u, u * slope);                // = u > 0 ? u : u*slope for 0 <= slope <= 1
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int src = ((q * 2 + lh) * 8 + i) * 2;         // lane holding this channel's first float4
+                    const float e0 = fetch(pm.x, src), e1 = fetch(pm.y, src), e2 = fetch(pm.z, src), e3 = fetch(pm.w, src), e4 = fetch(pm.x, src + 1);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        float u = o[j][q][i] + e0;
+                        u = (u + e1) * e2 + e3;
+                        u = u > 0.f ? u : u * slope;
+                        o[j][q][i] = u * e4;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (p.res1) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o[j][q][i] = p.alpha1 * o[j][q][i] + ((float)rh[j][q][i] + (float)rl[j][q][i]);
+        }
+        if (p.res2) {
+            load_res(p.res2, p.res2_bs);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o[j][q][i] = p.alpha2 * o[j][q][i] + ((float)rh[j][q][i] + (float)rl[j][q][i]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int g = goff[j][q];
+                if (g < 0) continue;
+                if (p.y_fmt == 1) {
+                    half8 h8, l8;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { _Float16 h, l; split2(o[j][q][i], h, l); h8[i] = h; l8[i] = l; }
+                    unsigned short* yb = reinterpret_cast<unsigned short*>(p.y) + (long long)cur.b * p.y_bs + g;
+                    *reinterpret_cast<half8*>(yb) = h8;
+                    *reinterpret_cast<half8*>(yb + HW * 8) = l8;
+                } else {
+                    const int oct = cur.cg * 4 + q * 2 + lh;
+                    float* yb = reinterpret_cast<float*>(p.y) + (long long)cur.b * p.y_bs + (long long)(cur.y0 + 2 * wave + j) * W + gx;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (oct * 8 + i < p.Cout) yb[(long long)(oct * 8 + i) * HW] = o[j][q][i];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+}
+
 // ---- fp32 NCHW view <-> h2 tensor (the two ends of the fp16-stored region: conv_first's output, the trunk output) -------------
 __global__ void h2_pack_kernel(const float* __restrict__ x, long long x_bs, unsigned short* __restrict__ y, long long y_bs,
                                int C, long long HW, long long total)
@@ -877,6 +1159,65 @@ extern "C" int bfsr_conv3x3_h2s(const BfsrConvX3Args* a, void* stream)
     }
     if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2s_kernel), LDS_TOTAL, lds_done) != 0) return -1;
     hipLaunchKernelGGL(conv3x3_h2s_kernel, dim3((unsigned)grid), dim3((NW + NLW) * 64), LDS_TOTAL, st, *a, tiles_x, tiles_y, groups, (int)nitems, abl, flags);
+    return (int)hipGetLastError();
+}
+
+extern "C" long long bfsr_conv_packed_size_h2x(int Cout, int Cin)
+{
+    if (Cout <= 0 || Cin <= 0 || (Cin & 15)) return -1;
+    return (long long)((Cout + 31) / 32) * (Cin / 16) * 2 * 9 * 2 * 32 * 8;       // fp16 elements
+}
+
+extern "C" int bfsr_pack_conv_weight_h2x(const float* w, int Cout, int Cin, float scale, unsigned short* packed)
+{
+    // w [Cout][Cin][3][3] fp32 -> fp16 [cout group of 32][16-channel chunk][plane hi,lo][tap = dx*3 + dy][k half][32][8] of w*scale,
+    // zero padded; scale = a power of two chosen by the caller (bfsr_amd/ops.py: largest |w|*scale in [2^9, 2^10))
+    if (!w || !packed || Cout <= 0 || Cin <= 0 || (Cin & 15) || !(scale > 0.f)) return -1;
+    const int nchunk = Cin / 16;
+    const long long n = bfsr_conv_packed_size_h2x(Cout, Cin);
+    for (long long i = 0; i < n; ++i) packed[i] = 0;
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int dy = 0; dy < 3; ++dy)
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float v = w[((long long)co * Cin + ci) * 9 + dy * 3 + dx] * scale;
+                    const _Float16 h = (_Float16)v;
+                    const _Float16 l = (_Float16)(v - (float)h);
+                    const unsigned short hb = f32_to_f16_bits((float)h), lb = f32_to_f16_bits((float)l);
+                    const long long base = ((long long)(co / 32) * nchunk + ci / 16) * 2;
+                    const long long in = (((long long)(dx * 3 + dy) * 2 + (ci % 16) / 8) * 32 + co % 32) * 8 + ci % 8;
+                    packed[(base + 0) * (9 * 2 * 32 * 8) + in] = hb;
+                    packed[(base + 1) * (9 * 2 * 32 * 8) + in] = lb;
+                }
+    return 0;
+}
+
+extern "C" int bfsr_conv3x3_h2x(const BfsrConvX3Args* a, void* stream)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!a || !a->x || !a->w || !a->y) return -1;
+    if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cin <= 0 || (a->Cin & 15) || a->Cout <= 0) return -1;
+    if (a->y_fmt != 0 && a->y_fmt != 1) return -1;
+    if (!(a->acc_scale > 0.f)) return -1;
+    if ((a->y_fmt != 0 || a->res1 || a->res2) && (a->Cout & 7)) return -1;
+    if ((long long)(a->Cin / 8) * 2 * a->H * a->W * 16 >= (1LL << 31)) return -1;      // 32-bit byte offsets inside one batch item
+    if ((long long)((a->Cout + 7) / 8) * 2 * a->H * a->W * 8 >= (1LL << 31)) return -1;  // 32-bit element offsets in the epilogue
+    if ((reinterpret_cast<unsigned long long>(a->x) & 15) || (a->x_bs & 7)) return -1;
+    if (a->y_fmt != 0 && ((reinterpret_cast<unsigned long long>(a->y) & 15) || (a->y_bs & 7))) return -1;
+    if (a->res1 && ((reinterpret_cast<unsigned long long>(a->res1) & 15) || (a->res1_bs & 7))) return -1;
+    if (a->res2 && ((reinterpret_cast<unsigned long long>(a->res2) & 15) || (a->res2_bs & 7))) return -1;
+    const int tiles_x = (a->W + 31) / 32, tiles_y = (a->H + TH - 1) / TH;
+    const int groups = (a->Cout + 31) / 32;
+    const long long nitems = (long long)tiles_x * tiles_y * groups * a->B;
+    if (nitems > 0x7fffffffLL) return -1;
+    if (bfsr_conv_packed_size_h2x(a->Cout, a->Cin) * 2 >= (1LL << 32)) return -1;
+    int cus = bfsr::cu_count();
+    if (cus <= 0) return -1;
+    if (a->tune > 0) cus = a->tune;
+    const long long grid = nitems < cus ? nitems : cus;                  // one persistent workgroup per CU
+    static std::atomic<unsigned long long> lds_done{0};
+    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2x_kernel), X_LDS, lds_done) != 0) return -1;
+    hipLaunchKernelGGL(conv3x3_h2x_kernel, dim3((unsigned)grid), dim3((NW + NLW) * 64), X_LDS, st, *a, tiles_x, tiles_y, groups, (int)nitems);
     return (int)hipGetLastError();
 }
 

@@ -74,6 +74,12 @@ class HipOps(object):
         self.conv_mode = os.environ.get("BFSR_CONV", "x3")
         if self.conv_mode not in ("x3", "f32"):
             raise ValueError("BFSR_CONV must be 'x3' or 'f32'")
+        # which split the "x3" (fp32-accurate, 16-bit matrix pipe) mode uses: "f16x2" = two-term fp16 split of both operands, three
+        # products, weights pre-scaled by a power of two (22 significant bits per operand; end to end indistinguishable from fp32,
+        # half the matrix instructions) or "bf16x3" = the exact three-term bf16 split, six products (no range restriction on activations)
+        self.split = os.environ.get("BFSR_SPLIT", "f16x2")
+        if self.split not in ("f16x2", "bf16x3"):
+            raise ValueError("BFSR_SPLIT must be 'f16x2' or 'bf16x3'")
 
     def _launch(self, key, fn):
         if self._keylog is not None:
@@ -335,6 +341,8 @@ class HipOps(object):
         """[B, C/8, 3, H, W, 8] bf16: x = h + m + l exactly; channel slices `t[:, a//8:b//8]` are views."""
         if Cc % 8:
             raise ValueError("x3 tensors need a multiple of 8 channels")
+        if self.split == "f16x2":                                      # the split tensors of this mode are h2 tensors (hi + lo fp16 planes)
+            return self.h2_empty(B, Cc, H, W)
         return torch.empty(B, Cc // 8, 3, H, W, 8, dtype=torch.bfloat16, device=self.device)
 
     @staticmethod
@@ -349,6 +357,8 @@ class HipOps(object):
         return t.data_ptr(), (st[0] if B > 1 else C8 * 24 * H * W), C8 * 8, H, W
 
     def x3_pack(self, x, out):
+        if out.dtype == torch.float16:
+            return self.h2_pack(x, out)
         xp, xbs, Cc, H, W = _view(x, "x3_pack.x")
         yp, ybs, c2, h2, w2 = self._x3view(out, "x3_pack.out")
         assert (Cc, H, W) == (c2, h2, w2) and x.shape[0] == out.shape[0]
@@ -356,6 +366,8 @@ class HipOps(object):
         return out
 
     def x3_unpack(self, x, out):
+        if x.dtype == torch.float16:
+            return self.h2_unpack(x, out)
         xp, xbs, Cc, H, W = self._x3view(x, "x3_unpack.x")
         yp, ybs, c2, h2, w2 = _view(out, "x3_unpack.out")
         assert (Cc, H, W) == (c2, h2, w2) and x.shape[0] == out.shape[0]
@@ -364,7 +376,9 @@ class HipOps(object):
 
     def conv_x3s(self, x, pw, out, epi=None, act=ACT_NONE, slope=0.2, res1=None, alpha1=1.0, res2=None, alpha2=1.0, tune=0):
         """3x3 conv over an x3 tensor `x` (weights: pack_conv_x3(w, 1)); `out` is an x3 view or an fp32 NCHW view; residuals
-        are x3 views.  Same epilogue contract as conv()."""
+        are x3 views.  Same epilogue contract as conv().  h2 tensors (split == "f16x2") go to conv_h2x: same contract."""
+        if x.dtype == torch.float16:
+            return self.conv_h2x(x, pw, out, epi=epi, act=act, slope=slope, res1=res1, alpha1=alpha1, res2=res2, alpha2=alpha2, tune=tune)
         a = _lib.BfsrConvX3Args()
         a.x, a.x_bs, Cin, H, W = self._x3view(x, "conv_x3s.x")
         if out.dtype == torch.bfloat16:
@@ -420,6 +434,54 @@ class HipOps(object):
         yp, ybs, c2, h2, w2 = _view(out, "h2_unpack.out")
         assert (Cc, H, W) == (c2, h2, w2) and x.shape[0] == out.shape[0]
         _lib.check(self._launch(("h2_unpack",) + tuple(out.shape), lambda: self.lib.bfsr_h2_unpack(xp, xbs, yp, ybs, x.shape[0], Cc, H, W, self._stream())), "h2_unpack")
+        return out
+
+    @staticmethod
+    def pow2_scale(w):
+        """The power of two that puts the largest |w| into [2^9, 2^10): fp16 hi/lo splits of w*scale keep their lo terms normal."""
+        m = float(w.abs().max())
+        if not (m > 0.0) or m != m or m == float("inf"):
+            return 1.0
+        import math
+        return 2.0 ** (9 - math.floor(math.log2(m)))
+
+    def _pack_h2x(self, w):
+        Cout, Cin, KS, _ = w.shape
+        if KS != 3 or Cin % 16:
+            raise ValueError("conv_h2x: 3x3 weights with Cin % 16 == 0 only")
+        scale = self.pow2_scale(w)
+        packed = torch.empty(self.lib.bfsr_conv_packed_size_h2x(Cout, Cin), dtype=torch.int16)
+        _lib.check(self.lib.bfsr_pack_conv_weight_h2x(w.data_ptr(), Cout, Cin, scale, packed.data_ptr()), "pack_h2x")
+        return packed.to(self.device), scale
+
+    def conv_h2x(self, x, pw, out, epi=None, act=ACT_NONE, slope=0.2, res1=None, alpha1=1.0, res2=None, alpha2=1.0, tune=0):
+        """3x3 conv over an h2 tensor `x` at fp32-class accuracy (both planes x two-term fp16 weights, three products; conv_h2s.hip,
+        conv3x3_h2x_kernel).  `pw` = pack_conv_x3(w, ...) (the fp16 packing is derived lazily from its kept OIHW copy); `out` is an
+        h2 view (both planes) or an fp32 NCHW view; residuals are h2 views.  Same epilogue contract as conv()."""
+        a = _lib.BfsrConvX3Args()
+        a.x, a.x_bs, Cin, H, W = self._h2view(x, "conv_h2x.x")
+        if out.dtype == torch.float16:
+            a.y, a.y_bs, Cout, H2, W2 = self._h2view(out, "conv_h2x.out")
+            a.y_fmt = 1
+        else:
+            a.y, a.y_bs, Cout, H2, W2 = _view(out, "conv_h2x.out")
+            a.y_fmt = 0
+        if (Cin, Cout, H, W) != (pw.Cin, pw.Cout, H2, W2) or pw.KS != 3 or x.shape[0] != out.shape[0]:
+            raise ValueError("conv_h2x: shape mismatch x%s out%s weight(Cout=%d,Cin=%d)" % (tuple(x.shape), tuple(out.shape), pw.Cout, pw.Cin))
+        a.Cin, a.Cout = Cin, Cout
+        wdata, scale = pw.variant("h2x", lambda w_, m_: self._pack_h2x(w_))
+        a.w, a.acc_scale = wdata.data_ptr(), 1.0 / scale
+        a.B, a.H, a.W = out.shape[0], H, W
+        a.epi, a.act, a.slope, a.tune = _ptr(epi), act, slope, tune
+        for name, t, al in (("res1", res1, alpha1), ("res2", res2, alpha2)):
+            if t is not None:
+                pp, bs, c, hh, ww = self._h2view(t, "conv_h2x." + name)
+                assert (c, hh, ww) == (Cout, H, W)
+                setattr(a, name, pp)
+                setattr(a, name + "_bs", bs)
+                setattr(a, "alpha" + name[-1], al)
+        key = ("conv_h2x", Cin, Cout, out.shape[0], H, W, a.y_fmt)
+        _lib.check(self._launch(key, lambda: self.lib.bfsr_conv3x3_h2x(C.byref(a), self._stream())), "conv3x3_h2x")
         return out
 
     def pack_conv_h2s(self, w):

@@ -146,6 +146,7 @@ typedef struct BfsrConvX3Args {
     const unsigned short* res1; long long res1_bs; float alpha1;
     const unsigned short* res2; long long res2_bs; float alpha2;
     int tune;
+    float acc_scale;                               /* bfsr_conv3x3_h2x only: 1 / (the power of two the weights were packed with) */
 } BfsrConvX3Args;
 int bfsr_conv3x3_x3s(const BfsrConvX3Args* a, void* stream);
 int bfsr_x3_pack(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int C, int H, int W, void* stream);
@@ -165,6 +166,17 @@ int bfsr_x3_unpack(const unsigned short* x, long long x_bs, float* y, long long 
 int bfsr_conv3x3_h2s(const BfsrConvX3Args* a, void* stream);
 long long bfsr_conv_packed_size_h2s(int Cout, int Cin);
 int bfsr_pack_conv_weight_h2s(const float* w_oihw, int Cout, int Cin, unsigned short* packed);
+/* bfsr_conv3x3_h2x: the same conv at fp32-class accuracy on the fp16 matrix pipe -- both planes of the h2 input (22 significant
+ * bits) against a two-term fp16 split of the weights, three products lo*hi + hi*lo + hi*hi in the fp32 accumulator (half the
+ * matrix instructions and 2/3 of the operand bytes of the 3xBF16 scheme of bfsr_conv3x3_x3s; end to end indistinguishable from
+ * fp32 on the SRFlow-LP pipeline, tests/test_srflow_gpu.py).  fp16 has a narrow exponent: bfsr_pack_conv_weight_h2x multiplies
+ * the weights by `scale` (a power of two: the caller puts the largest |w| into [2^9, 2^10)) and the kernel multiplies the
+ * accumulators by a->acc_scale = 1/scale before the epilogue of bfsr_conv3x3_x3s; activations must stay below 65504 in magnitude.
+ * y_fmt 0: fp32 NCHW view, 1: h2 view (both planes).  Cin % 16 == 0.  Replaces the dense-block convs of
+ * SRFlow-LP/code/models/modules/RRDBNet_arch.py:25-65 on the default (fp32-accurate) path. */
+int bfsr_conv3x3_h2x(const BfsrConvX3Args* a, void* stream);
+long long bfsr_conv_packed_size_h2x(int Cout, int Cin);
+int bfsr_pack_conv_weight_h2x(const float* w_oihw, int Cout, int Cin, float scale, unsigned short* packed);
 int bfsr_h2_pack(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int C, int H, int W, void* stream);
 int bfsr_h2_unpack(const unsigned short* x, long long x_bs, float* y, long long y_bs, int B, int C, int H, int W, void* stream);
 

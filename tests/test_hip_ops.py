@@ -20,6 +20,15 @@ def hip():
     return HipOps("cuda:0")
 
 
+@pytest.fixture(scope="module")
+def hipb():
+    """The same library with the 3xBF16 split (exact three-term bf16 tensors, six products): BFSR_SPLIT=bf16x3."""
+    from bfsr_amd.ops import HipOps
+    o = HipOps("cuda:0")
+    o.split = "bf16x3"
+    return o
+
+
 CPU = CpuOps()
 
 
@@ -69,8 +78,9 @@ X3S_CASES = [
 
 @pytest.mark.parametrize("case", X3S_CASES)
 @pytest.mark.parametrize("fp32_out", [False, True])
-def test_conv_x3s_and_x3_tensors(hip, case, fp32_out):
+def test_conv_x3s_and_x3_tensors(hipb, case, fp32_out):
     """conv_x3s (LDS-DMA staged 3x3 conv over x3 tensors, conv_x3s.hip) vs the fp32 conv semantics; x3 pack/unpack lossless."""
+    hip = hipb
     B, Cin, Cout, H, W = case
     x, w, b = rnd(31, B, Cin, H, W), rnd(32, Cout, Cin, 3, 3, scale=1.0 / np.sqrt(Cin * 9)), rnd(33, Cout, scale=0.3)
     xd = hip.to_device(x)
@@ -91,28 +101,32 @@ def test_conv_x3s_and_x3_tensors(hip, case, fp32_out):
 
 
 @pytest.mark.parametrize("cus", [1, 7, 40, 100, 255])
-def test_persistent_convs_are_independent_of_the_workgroup_count(hip, cus):
+def test_persistent_convs_are_independent_of_the_workgroup_count(hip, hipb, cus):
     """conv_x3s / conv_h2s walk their tiles with one persistent workgroup per CU (`tune` overrides the count, as a partitioned
     GPU would): every split of the tile list -- incl. the half-height tiles of a last partial round and a ring that wraps
     across many tiles -- must give the same bits as the default launch."""
     B, Cin, Cout, H, W = 2, 64, 40, 75, 70
     x, w, b = rnd(61, B, Cin, H, W), rnd(62, Cout, Cin, 3, 3, scale=0.05), rnd(63, Cout, scale=0.3)
     xd = hip.to_device(x)
-    x3 = hip.x3_pack(xd, hip.x3_empty(B, Cin, H, W))
+    x3 = hipb.x3_pack(xd, hipb.x3_empty(B, Cin, H, W))
     pw, epi = hip.pack_conv_x3(w, 1), hip.pack_epilogue(Cout, bias=b)
-    ref = hip.conv_x3s(x3, pw, hip.x3_empty(B, Cout, H, W), epi=epi, act=2, slope=0.2).clone()
-    got = hip.conv_x3s(x3, pw, hip.x3_empty(B, Cout, H, W), epi=epi, act=2, slope=0.2, tune=cus)
+    ref = hipb.conv_x3s(x3, pw, hipb.x3_empty(B, Cout, H, W), epi=epi, act=2, slope=0.2).clone()
+    got = hipb.conv_x3s(x3, pw, hipb.x3_empty(B, Cout, H, W), epi=epi, act=2, slope=0.2, tune=cus)
     assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), "conv_x3s depends on the number of workgroups"
     xh = hip.h2_pack(xd, hip.h2_empty(B, Cin, H, W))
+    refx = hip.conv_h2x(xh, pw, hip.h2_empty(B, Cout, H, W), epi=epi, act=2, slope=0.2).clone()
+    gotx = hip.conv_h2x(xh, pw, hip.h2_empty(B, Cout, H, W), epi=epi, act=2, slope=0.2, tune=cus)
+    assert torch.equal(gotx.view(torch.int16), refx.view(torch.int16)), "conv_h2x depends on the number of workgroups"
     ph = hip.pack_conv_h2s(w)
     refh = hip.conv_h2s(xh, ph, hip.h2_empty(B, Cout, H, W), epi=epi, act=2, slope=0.2).clone()
     goth = hip.conv_h2s(xh, ph, hip.h2_empty(B, Cout, H, W), epi=epi, act=2, slope=0.2, tune=cus)
     assert torch.equal(goth.view(torch.int16), refh.view(torch.int16)), "conv_h2s depends on the number of workgroups"
 
 
-def test_conv_x3s_dense_block_views_and_residuals(hip):
+def test_conv_x3s_dense_block_views_and_residuals(hipb):
     """The RDB pattern (RRDBNet_arch.py:39-45): octet-sliced views of one x3 block buffer, conv5 with `x5*0.2 + x` and the
     RRDB-level `*0.2 + x_rrdb`, all residuals x3."""
+    hip = hipb
     B, H, W = 2, 21, 37
     D = rnd(41, B, 192, H, W)
     xr = rnd(42, B, 64, H, W)
@@ -192,6 +206,62 @@ def test_conv_h2s_dense_block_views_and_residuals(hip):
     nxt = hip.h2_empty(B, 192, H, W)
     hip.conv_h2s(Dh, hip.pack_conv_h2s(w5), nxt[:, :8], epi=hip.pack_epilogue(64, bias=b5), res1=Dh[:, :8], alpha1=0.2, res2=xrh, alpha2=0.2)
     close(hip.h2_unpack(nxt[:, :8], hip.empty(B, 64, H, W)), out_ref, 2e-5, "h2 conv5 residuals")
+
+
+H2X_CASES = [(1, 32, 32, 16, 32), (2, 64, 32, 19, 45), (1, 192, 64, 33, 65), (3, 96, 32, 128, 128), (2, 64, 24, 9, 33), (1, 16, 40, 70, 70),
+             (5, 48, 32, 40, 40), (2, 64, 64, 50, 40), (1, 160, 104, 17, 31)]
+
+
+@pytest.mark.parametrize("case", H2X_CASES)
+@pytest.mark.parametrize("mode", ["f32_out", "h2_out"])
+def test_conv_h2x_is_fp32_accurate(hip, case, mode):
+    """conv_h2x (conv3x3_h2x_kernel: both planes of the h2 input x two-term fp16 weights, three products, power-of-two weight
+    scale) against an fp64 conv of the SAME 22-bit inputs with the UNSPLIT fp32 weights: the error must be at the level of the
+    native fp32 kernel's, also for weights spanning five orders of magnitude (the scale keeps their lo terms normal)."""
+    B, Cin, Cout, H, W = case
+    x, w, b = rnd(71, B, Cin, H, W), rnd(72, Cout, Cin, 3, 3, scale=1.0 / np.sqrt(Cin * 9)), rnd(73, Cout, scale=0.3)
+    w = w * torch.logspace(-4, 0, Cout).view(-1, 1, 1, 1) * 3.0           # per-channel magnitudes 3e-4 .. 3
+    xd = hip.to_device(x)
+    xh = hip.h2_pack(xd, hip.h2_empty(B, Cin, H, W))
+    x22 = hip.h2_unpack(xh, hip.empty(B, Cin, H, W)).cpu()
+    ref64 = torch.nn.functional.conv2d(x22.double(), w.double(), b.double(), 1, 1)
+    ref64 = torch.where(ref64 > 0, ref64, ref64 * 0.2)
+    pw, epi = hip.pack_conv_x3(w, 1), hip.pack_epilogue(Cout, bias=b)
+    tol = 4e-6 * float(ref64.abs().max())
+    if mode == "f32_out":
+        out = hip.conv_h2x(xh, pw, hip.empty(B, Cout, H, W), epi=epi, act=2, slope=0.2)
+        err = float((out.cpu().double() - ref64).abs().max())
+        f32 = hip.conv(xd.new_tensor(x22), hip.pack_conv(w, 1), hip.empty(B, Cout, H, W), epi=epi, act=2, slope=0.2)
+        err32 = float((f32.cpu().double() - ref64).abs().max())
+        assert err <= max(tol, 4 * err32), "conv_h2x %s: max-abs %g (native fp32 kernel %g, |ref|max %g)" % (case, err, err32, float(ref64.abs().max()))
+    elif Cout % 8 == 0:
+        yh = hip.h2_empty(B, Cout, H, W)
+        yh.fill_(float("nan"))
+        hip.conv_h2x(xh, pw, yh, epi=epi, act=2, slope=0.2)
+        got = hip.h2_unpack(yh, hip.empty(B, Cout, H, W)).cpu().double()
+        assert float((got - ref64).abs().max()) <= tol + 2.0 ** -21 * float(ref64.abs().max()), "conv_h2x h2 out %s" % (case,)
+
+
+def test_conv_h2x_dense_block_views_and_residuals(hip):
+    """The RDB pattern on h2 tensors with the fp32-class arithmetic: octet-sliced views of one block buffer, conv5 with `x5*0.2 + x`
+    and the RRDB-level `*0.2 + x_rrdb` (RRDBNet_arch.py:39-45, :59-65)."""
+    B, H, W = 2, 21, 37
+    D = rnd(41, B, 192, H, W)
+    xr = rnd(42, B, 64, H, W)
+    Dh = hip.h2_pack(hip.to_device(D), hip.h2_empty(B, 192, H, W))
+    xrh = hip.h2_pack(hip.to_device(xr), hip.h2_empty(B, 64, H, W))
+    ref = hip.h2_unpack(Dh, hip.empty(B, 192, H, W)).cpu()              # what the convs see: 22-bit values
+    xr22 = hip.h2_unpack(xrh, hip.empty(B, 64, H, W)).cpu()
+    w2, b2 = rnd(43, 32, 96, 3, 3, scale=0.04), rnd(44, 32, scale=0.1)
+    CPU.conv(ref[:, :96].clone(), CPU.pack_conv(w2, 1), ref[:, 96:128], bias=b2, act=2, slope=0.2)
+    hip.conv_x3s(Dh[:, :12], hip.pack_conv_x3(w2, 1), Dh[:, 12:16], epi=hip.pack_epilogue(32, bias=b2), act=2, slope=0.2)
+    close(hip.h2_unpack(Dh, hip.empty(B, 192, H, W)), ref, 2e-5, "h2 slice views (conv_x3s dispatch on the tensor type)")
+    w5, b5 = rnd(45, 64, 192, 3, 3, scale=0.03), rnd(46, 64, scale=0.1)
+    out_ref = CPU.conv(ref.clone(), CPU.pack_conv(w5, 1), torch.empty(B, 64, H, W), bias=b5, res1=ref[:, :64].clone(), alpha1=0.2,
+                       res2=xr22, alpha2=0.2)
+    nxt = hip.h2_empty(B, 192, H, W)
+    hip.conv_h2x(Dh, hip.pack_conv_x3(w5, 1), nxt[:, :8], epi=hip.pack_epilogue(64, bias=b5), res1=Dh[:, :8], alpha1=0.2, res2=xrh, alpha2=0.2)
+    close(hip.h2_unpack(nxt[:, :8], hip.empty(B, 64, H, W)), out_ref, 2e-5, "h2x conv5 residuals")
 
 
 @pytest.mark.parametrize("env", [{"BFSR_H2S_PP": "1"}, {"BFSR_H2S_WREG": "1"}, {"BFSR_H2S_PP": "1", "BFSR_H2S_WREG": "1"}])

@@ -36,13 +36,17 @@ def stress(name, fn):
 def main():
     total = 0
     B, hw = 8, 160
-    # --- RRDB dense-block convs on x3 tensors (conv_x3s)
-    for Cin, Cout in ((64, 32), (128, 32), (192, 64)):
-        x3 = ops.x3_pack(torch.randn(B, Cin, hw, hw, device="cuda"), ops.x3_empty(B, Cin, hw, hw))
-        pw = ops.pack_conv_x3(r(Cout, Cin, 3, 3, scale=0.05), 1)
-        epi = ops.pack_epilogue(Cout, bias=r(Cout, scale=0.1))
-        y3 = ops.x3_empty(B, Cout, hw, hw)
-        total += stress("conv_x3s %d->%d @%dx%d" % (Cin, Cout, hw, hw), lambda: ops.conv_x3s(x3, pw, y3, epi=epi, act=ACT_LRELU))
+    # --- RRDB dense-block convs on split tensors: conv_h2x (h2 tensors, the default split) and conv_x3s (x3 tensors, BFSR_SPLIT=bf16x3)
+    default_split = ops.split
+    for split, name in (("f16x2", "conv_h2x"), ("bf16x3", "conv_x3s")):
+        ops.split = split
+        for Cin, Cout in ((64, 32), (128, 32), (192, 64)):
+            x3 = ops.x3_pack(torch.randn(B, Cin, hw, hw, device="cuda"), ops.x3_empty(B, Cin, hw, hw))
+            pw = ops.pack_conv_x3(r(Cout, Cin, 3, 3, scale=0.05), 1)
+            epi = ops.pack_epilogue(Cout, bias=r(Cout, scale=0.1))
+            y3 = ops.x3_empty(B, Cout, hw, hw)
+            total += stress("%s %d->%d @%dx%d" % (name, Cin, Cout, hw, hw), lambda: ops.conv_x3s(x3, pw, y3, epi=epi, act=ACT_LRELU))
+    ops.split = default_split
     # --- fp16 dense-block convs on h2 tensors (conv_h2s)
     for Cin, Cout in ((64, 32), (192, 64)):
         xh = ops.h2_pack(torch.randn(B, Cin, 128, 128, device="cuda"), ops.h2_empty(B, Cin, 128, 128))

@@ -18,6 +18,7 @@ def timeit(fn, n=20):
     return s.elapsed_time(e) / n * 1e3
 
 
+ops.split = "bf16x3"          # this tool ablates conv3x3_x3s_kernel (the 3xBF16 split)
 NAMES = {16: "product", 2064: "with per-chunk vmcnt(0)", 1040: "deferred epilogue", 144: "no epilogue"}
 for B, H, W in ((8, 160, 160), (16, 256, 256)):
     tot = {k: 0.0 for k in NAMES}

@@ -49,6 +49,10 @@ FAMILIES = {
     "conv_x3s": ("conv3x3_x3s_kernel", PEAK_16BIT_MFMA_TFLOPS, 6, "3xBF16 split on v_mfma_f32_32x32x16_bf16, x3-tensor input by LDS-DMA"),
     "conv_up2_x3": ("conv_up2_bf16x3_kernel", PEAK_16BIT_MFMA_TFLOPS, 6, "3xBF16 split, parity-decomposed conv over nearest-x2 input"),
     "conv_up4_x3": ("conv_up4_bf16x3_kernel", PEAK_16BIT_MFMA_TFLOPS, 6, "3xBF16 split, phase-decomposed conv over nearest-x4 input"),
+    "conv_f16x2": ("conv_bf16x3_kernel<PL=2>", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split (22-bit operands, power-of-two weight scale), 3 products on v_mfma_f32_32x32x16_f16"),
+    "conv_h2x": ("conv3x3_h2x_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split, 3 products on v_mfma_f32_32x32x16_f16, h2-tensor input by LDS-DMA"),
+    "conv_up2_f2": ("conv_up2_bf16x3_kernel<PL=2>", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split, parity-decomposed conv over nearest-x2 input"),
+    "conv_up4_f2": ("conv_up4_bf16x3_kernel<PL=2>", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split, phase-decomposed conv over nearest-x4 input"),
     "conv_f16": ("conv_f16_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, "fp16 MFMA (v_mfma_f32_32x32x16_f16), fp32 accumulate"),
     "conv_h2s": ("conv3x3_h2s_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, "fp16 MFMA, fp16-stored (h2) input by LDS-DMA, fp32 accumulate"),
     "linf_mlp_x3": ("linf_mlp_kernel<x3>", PEAK_16BIT_MFMA_TFLOPS, 6, "3xBF16 split; Fourier features + 4-layer MLP fused"),
@@ -81,13 +85,13 @@ def parse_args():
 def launch_flop(k):
     """algorithmic flops of one launch (result-preserving schedule) from its ops.py profile key, or None"""
     f = k[0]
-    if f in ("conv", "conv_bf16x3", "conv_f16"):
+    if f in ("conv", "conv_bf16x3", "conv_f16", "conv_f16x2"):
         _, KS, _, Cin, Cout, b_, hh, ww = k
         return 2.0 * Cin * KS * KS * Cout * b_ * hh * ww
     if f == "conv+1x1":
         _, Cin, Cout, b_, hh, ww = k
         return 2.0 * (Cin * 9 + 64) * Cout * b_ * hh * ww
-    if f in ("conv_x3s", "conv_h2s"):
+    if f in ("conv_x3s", "conv_h2s", "conv_h2x"):
         _, Cin, Cout, b_, hh, ww, _fmt = k
         return 2.0 * Cin * 9 * Cout * b_ * hh * ww
     if f in ("linf_mlp_x3", "linf_mlp_f16"):           # layer 1 (4 neighbours x 256 features) + two hidden layers + output layer
@@ -96,10 +100,10 @@ def launch_flop(k):
     if f in ("conv1x1_f16", "conv1x1_x3"):
         _, Cin, Cout, b_, hh, ww = k
         return 2.0 * Cin * Cout * b_ * hh * ww
-    if f in ("conv_up2", "conv_up2_x3"):               # 2x2 source taps per output pixel (parity pre-summed weights)
+    if f in ("conv_up2", "conv_up2_x3", "conv_up2_f2"):               # 2x2 source taps per output pixel (parity pre-summed weights)
         _, _, Cin, Cout, b_, hh, ww, cin2 = k          # + cin2 key channels at output resolution (9 taps)
         return 2.0 * (Cin * 4 + cin2 * 9) * Cout * b_ * hh * ww
-    if f == "conv_up4_x3":                             # 25 pre-summed matrices per 16 output pixels
+    if f in ("conv_up4_x3", "conv_up4_f2"):                             # 25 pre-summed matrices per 16 output pixels
         _, _, Cin, Cout, b_, hh, ww, _ = k
         return 2.0 * Cin * 25.0 / 16.0 * Cout * b_ * hh * ww
     return None
@@ -421,16 +425,21 @@ def main():
             path = ("LP path: RRDB + encode + standardise + prior UNet + decode + clamp" if args.mode == "lp"
                     else "tau=0.9 sampling path (RRDB + decode, no encode/prior)")
             wl = "SRFlow-LP %dx %s (K=16,L=3,nb=23), " % (scale, "DF2K config" if scale == 4 else "config derived from the 4X yml (scale 8, L 3)")
-            arithmetic = ("fp32 tensors and accumulation; 3x3 convs with >=32 input channels contract on the bf16 MFMA with the exact 3-term "
-                          "bf16 split of both operands (6 cross products, error vs fp64 = native fp32 MFMA's, "
-                          "tests/test_hip_ops.py::test_conv_bf16x3_is_fp32_accurate; RRDB block activations are STORED as that exact split "
-                          "= lossless); everything else native fp32" if ops.conv_mode == "x3" else "native fp32 MFMA / fp32 VALU")
+            split_txt = ("two-term fp16 split of both operands (hi + lo = 22 significant bits, weights pre-scaled by a power of two so that "
+                         "their lo terms stay normal), 3 cross products lo*hi + hi*lo + hi*hi on the fp16 MFMA, fp32 accumulation: error of "
+                         "the whole pipeline against an fp64 evaluation = the CPU fp32 evaluation's "
+                         "(tests/test_srflow_gpu.py::test_end_to_end_error_vs_fp64, tests/test_hip_ops.py::test_conv_h2x_is_fp32_accurate); "
+                         "RRDB block activations are STORED as that hi + lo pair" if getattr(ops, "split", "bf16x3") == "f16x2" else
+                         "exact 3-term bf16 split of both operands (6 cross products on the bf16 MFMA, error vs fp64 = native fp32 MFMA's, "
+                         "tests/test_hip_ops.py::test_conv_bf16x3_is_fp32_accurate; RRDB block activations are STORED as that exact split = lossless)")
+            arithmetic = ("fp32 tensors and accumulation; 3x3 convs with >=32 input channels contract on the 16-bit matrix pipe with the "
+                          + split_txt + "; everything else native fp32" if ops.conv_mode == "x3" else "native fp32 MFMA / fp32 VALU")
             dtype = "f32"
         else:
             name = "LINF-LP rrdb-linf-LP x%g arbitrary-scale SR (%d->%d)" % (scale, h, H)
             path = "LP path: input prep + RRDB encoder + query_log_p + prior UNet + query_rgb + fold + skip + clamp"
             wl = "LINF-LP rrdb-linf-LP, "
-            arithmetic = ("fp32-accurate 3xBF16 contraction (see config 2)" if cfg == 3 else
+            arithmetic = ("fp32-accurate split contraction on the 16-bit matrix pipe (BFSR_SPLIT=%s, see config 2)" % getattr(ops, "split", "bf16x3") if cfg == 3 else
                           "fp16 MFMA path (BASELINE config 5): encoder / coef|freq / MLP / prior contractions round their operands to fp16, "
                           "fp32 accumulation, fp32 tensors, the flow itself in fp32; tolerance vs the fp32 reference 1e-3 on the output "
                           "(tests/test_linf_gpu.py::test_fp16_mfma_path_vs_reference_golden)")

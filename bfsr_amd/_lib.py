@@ -27,6 +27,7 @@ class BfsrConvArgs(C.Structure):
         ("tune", C.c_int),
         ("w2", C.c_void_p), ("C2", C.c_int), ("epi2", C.c_void_p), ("act2", C.c_int),
         ("x2", C.c_void_p), ("x2_bs", C.c_longlong), ("Cin2", C.c_int), ("w_x2", C.c_void_p),
+        ("arith", C.c_int), ("acc_scale", C.c_float),
     ]
 
 
@@ -162,6 +163,8 @@ SYMBOLS = {
     "bfsr_conv2d_up4_bf16x3": (_I, [C.POINTER(BfsrConvArgs), _VP]),
     "bfsr_conv_packed_size_taps_bf16x3": (_LL, [_I, _I, _I, _I]),
     "bfsr_pack_conv_weight_taps_bf16x3": (_I, [_VP, _I, _I, _I, _I, _VP]),
+    "bfsr_conv_packed_size_taps_f16x2": (_LL, [_I, _I, _I, _I]),
+    "bfsr_pack_conv_weight_taps_f16x2": (_I, [_VP, _I, _I, _I, _I, C.c_float, _VP]),
     "bfsr_conv2d_up2": (_I, [C.POINTER(BfsrConvArgs), _VP]),
     "bfsr_conv_packed_size_taps": (_LL, [_I, _I, _I, _I]),
     "bfsr_pack_conv_weight_taps": (_I, [_VP, _I, _I, _I, _I, _VP]),

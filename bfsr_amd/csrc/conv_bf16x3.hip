@@ -17,11 +17,49 @@
 #include "launch_util.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef f32x16 f32x16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
 constexpr int CK = 16;
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// Split arithmetic of the kernels below (template parameter PL = planes per operand):
+//   PL = 3: exact three-term bf16 split, six products hl+lh+mm+mh+hm+hh on v_mfma_f32_32x32x16_bf16 (BFSR_SPLIT=bf16x3)
+//   PL = 2: two-term fp16 split (22 significant bits), three products lh+hl+hh on v_mfma_f32_32x32x16_f16; the weights were
+//           multiplied by a power of two at pack time (their lo terms stay normal fp16 numbers) and the accumulators are
+//           multiplied by p.acc_scale = 1/that first thing in the epilogue; activations must stay below 65504 in magnitude.
+//           Half the matrix instructions and 2/3 of the LDS bytes; end to end indistinguishable from fp32.
+template <int PL> struct Sp;
+template <> struct Sp<3> {
+    typedef __bf16 elt;
+    typedef __bf16 frag __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ f32x16_t mfma(frag a, frag b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Sp<2> {
+    typedef _Float16 elt;
+    typedef _Float16 frag __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ f32x16_t mfma(frag a, frag b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+// the eight values of one (position, k half) unit -> PL fragments
+template <int PL>
+__device__ __forceinline__ void split_unit(const float (&v)[8], typename Sp<PL>::frag (&o)[PL])
+{
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float r = v[c];
+#pragma unroll
+        for (int pl = 0; pl < PL; ++pl) {
+            const typename Sp<PL>::elt h = (typename Sp<PL>::elt)r;   // round to nearest; the residual below is exact
+            o[pl][c] = h;
+            r -= (float)h;
+        }
+    }
+}
+// products, smallest terms first: T_(plane of A = weights, plane of B = activations)
+#define BFSR_PRODUCTS(PL_, T_) if constexpr ((PL_) == 3) { T_(2, 0) T_(0, 2) T_(1, 1) T_(1, 0) T_(0, 1) T_(0, 0) } else { T_(1, 0) T_(0, 1) T_(0, 0) }
 
 __device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l)
 {
@@ -31,7 +69,7 @@ __device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l)
     l = (__bf16)(r1 - (float)m);          // exact residual, <= 8 significant bits
 }
 
-template <int KS, int MR, int NR, int MINB, int NW>
+template <int PL, int KS, int MR, int NR, int MINB, int NW>
 __global__ __launch_bounds__(NW * 64, MINB) void conv_bf16x3_kernel(BfsrConvArgs p, int tiles_x, int tiles_xy, int groups)
 {
     constexpr int NT = NW * 64;
@@ -39,13 +77,15 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_bf16x3_kernel(BfsrConvArgs
     constexpr int IH = TH + HALO, PW = TW + HALO, NPOS = IH * PW, PPT = (NPOS + NT - 1) / NT;
     constexpr int TAPS = KS * KS, MW = MR * 32;
     constexpr int WPL = TAPS * MW * CK;              // bf16 elements of one weight plane per chunk
-    constexpr int WSLAB = 3 * WPL;
+    constexpr int WSLAB = PL * WPL;
     constexpr int WV = (WSLAB / 8 + NT - 1) / NT;      // 16-byte weight loads per thread
     constexpr int IPL = NPOS * CK;                   // bf16 elements of one input plane
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __bf16* sW = reinterpret_cast<__bf16*>(smem_raw);                     // [3][TAPS][k half][MW][8]
-    __bf16* sIn = sW + WSLAB;                                             // [3][k half][NPOS][8]
+    typedef typename Sp<PL>::elt elt;
+    typedef typename Sp<PL>::frag frag;
+    elt* sW = reinterpret_cast<elt*>(smem_raw);                     // [3][TAPS][k half][MW][8]
+    elt* sIn = sW + WSLAB;                                             // [3][k half][NPOS][8]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -59,11 +99,11 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_bf16x3_kernel(BfsrConvArgs
     const float* __restrict__ xin = p.x + (long long)b * p.x_bs;
     const int Cin = p.Cin;
     const int nchunk = (Cin + CK - 1) / CK;
-    const __bf16* __restrict__ wg = reinterpret_cast<const __bf16*>(p.w) + (long long)cg * nchunk * WSLAB;
+    const elt* __restrict__ wg = reinterpret_cast<const elt*>(p.w) + (long long)cg * nchunk * WSLAB;
 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0,
                                                                            (unsigned)((long long)Cin * cs_in * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wg), 0,
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<elt*>(wg), 0,
                                                                           (unsigned)((long long)nchunk * WSLAB * 2), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     unsigned voff[PPT];
@@ -109,16 +149,13 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_bf16x3_kernel(BfsrConvArgs
             if (i < PPT - 1 || pos < NPOS) {
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
-                    bf16x8 h8, m8, l8;
+                    float u8[8];
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        __bf16 h, m, l;
-                        split3(vin[i][hf * 8 + c], h, m, l);
-                        h8[c] = h; m8[c] = m; l8[c] = l;
-                    }
-                    *reinterpret_cast<bf16x8*>(sIn + (hf * NPOS + pos) * 8) = h8;
-                    *reinterpret_cast<bf16x8*>(sIn + IPL + (hf * NPOS + pos) * 8) = m8;
-                    *reinterpret_cast<bf16x8*>(sIn + 2 * IPL + (hf * NPOS + pos) * 8) = l8;
+                    for (int c = 0; c < 8; ++c) u8[c] = vin[i][hf * 8 + c];
+                    frag s8[PL];
+                    split_unit<PL>(u8, s8);
+#pragma unroll
+                    for (int pl = 0; pl < PL; ++pl) *reinterpret_cast<frag*>(sIn + pl * IPL + (hf * NPOS + pos) * 8) = s8[pl];
                 }
             }
         }
@@ -129,25 +166,25 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_bf16x3_kernel(BfsrConvArgs
         }
         __syncthreads();
         if (k + 1 < nchunk) load_chunk(k + 1);
-        const __bf16* inB = sIn + (lhi * NPOS + (wave * NR) * PW + l31) * 8;
-        const __bf16* wA = sW + (lhi * MW + l31) * 8;
+        const elt* inB = sIn + (lhi * NPOS + (wave * NR) * PW + l31) * 8;
+        const elt* wA = sW + (lhi * MW + l31) * 8;
         // software pipeline over the taps (dx-major so a B row set serves the KS vertical taps): the A fragments of tap t+1
         // and, at a column change, the B fragments of column dx+1 are requested from LDS before the MFMAs of tap t issue
         constexpr bool PFB = (MINB == 1 && NW == 4);     // room for a second B row set only with the 512-register budget
-        bf16x8 bfr[PFB ? 2 : 1][3][NR + HALO], afr[2][3][MR];
+        frag bfr[PFB ? 2 : 1][PL][NR + HALO], afr[2][PL][MR];
         auto load_b = [&](int buf, int dx) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
                 for (int r = 0; r < NR + HALO; ++r)
-                    bfr[buf][pl][r] = *reinterpret_cast<const bf16x8*>(inB + pl * IPL + (r * PW + dx) * 8);
+                    bfr[buf][pl][r] = *reinterpret_cast<const frag*>(inB + pl * IPL + (r * PW + dx) * 8);
         };
         auto load_a = [&](int buf, int dx, int dy) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
                 for (int m = 0; m < MR; ++m)
-                    afr[buf][pl][m] = *reinterpret_cast<const bf16x8*>(wA + pl * WPL + ((dy * KS + dx) * 2 * MW + m * 32) * 8);
+                    afr[buf][pl][m] = *reinterpret_cast<const frag*>(wA + pl * WPL + ((dy * KS + dx) * 2 * MW + m * 32) * 8);
         };
         load_b(0, 0);
         load_a(0, 0, 0);
@@ -164,8 +201,8 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_bf16x3_kernel(BfsrConvArgs
             // small terms first, the leading term last; MR*NR independent accumulators between dependent MFMAs
 #define BFSR_TERM(PA_, PB_)                                                                                            \
     _Pragma("unroll") for (int m = 0; m < MR; ++m) _Pragma("unroll") for (int n = 0; n < NR; ++n)                       \
-        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ab][PA_][m], bfr[bb][PB_][n + dy], acc[m][n], 0, 0, 0);
-            BFSR_TERM(2, 0) BFSR_TERM(0, 2) BFSR_TERM(1, 1) BFSR_TERM(1, 0) BFSR_TERM(0, 1) BFSR_TERM(0, 0)
+        acc[m][n] = Sp<PL>::mfma(afr[ab][PA_][m], bfr[bb][PB_][n + dy], acc[m][n]);
+            BFSR_PRODUCTS(PL, BFSR_TERM)
 #undef BFSR_TERM
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -202,7 +239,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_bf16x3_kernel(BfsrConvArgs
                     const int gy = y0 + wave * NR + n;
                     if (gy >= H) continue;
                     const long long o = cbase + (long long)gy * W + gx;
-                    float v = acc[m][n][r];
+                    float v = PL == 2 ? acc[m][n][r] * p.acc_scale : acc[m][n][r];
                     v += q0.x;
                     if constexpr (T) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_pre, (unsigned)o * 4u, 0, 0));
                     v += q0.y; v *= q0.z; v += q0.w;
@@ -220,20 +257,26 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_bf16x3_kernel(BfsrConvArgs
     else run_epilogue(std::false_type{});
 }
 
-template <int KS, int MR, int NR, int MINB, int NW>
-int launch_x3(const BfsrConvArgs& a, hipStream_t st)
+template <int PL, int KS, int MR, int NR, int MINB, int NW>
+int launch_x3p(const BfsrConvArgs& a, hipStream_t st)
 {
     constexpr int TH = NW * NR, HALO = KS - 1;
-    constexpr int LDS = 3 * (KS * KS * MR * 32 * CK + (TH + HALO) * (32 + HALO) * CK) * 2;
+    constexpr int LDS = PL * (KS * KS * MR * 32 * CK + (TH + HALO) * (32 + HALO) * CK) * 2;
     static std::atomic<unsigned long long> lds_done{0};
-    if (LDS > 65536 && bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_bf16x3_kernel<KS, MR, NR, MINB, NW>), LDS, lds_done) != 0)
+    if (LDS > 65536 && bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_bf16x3_kernel<PL, KS, MR, NR, MINB, NW>), LDS, lds_done) != 0)
         return -1;
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + TH - 1) / TH;
     const int groups = ((a.Cout + 31) / 32 + MR - 1) / MR;
     const long long nblk = (long long)tiles_x * tiles_y * groups * a.B;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return -1;
-    hipLaunchKernelGGL((conv_bf16x3_kernel<KS, MR, NR, MINB, NW>), dim3((unsigned)nblk), dim3(NW * 64), LDS, st, a, tiles_x, tiles_x * tiles_y, groups);
+    hipLaunchKernelGGL((conv_bf16x3_kernel<PL, KS, MR, NR, MINB, NW>), dim3((unsigned)nblk), dim3(NW * 64), LDS, st, a, tiles_x, tiles_x * tiles_y, groups);
     return (int)hipGetLastError();
+}
+
+template <int KS, int MR, int NR, int MINB, int NW>
+int launch_x3(const BfsrConvArgs& a, hipStream_t st)
+{
+    return a.arith == 1 ? launch_x3p<2, KS, MR, NR, MINB, NW>(a, st) : launch_x3p<3, KS, MR, NR, MINB, NW>(a, st);
 }
 
 
@@ -244,16 +287,18 @@ int launch_x3(const BfsrConvArgs& a, hipStream_t st)
 // acc[column parity][row].  Column offset d = b+j is the outer loop so one set of B rows serves every (b,j) with that d.
 // The two column parities of a source pixel are adjacent output pixels: the epilogue moves float2 (fully coalesced rows).
 // Channels that already live at the output resolution go through the plain kernel first and arrive here as `pre_add`.
-template <int NW, int NR>
+template <int PL, int NW, int NR>
 __global__ __launch_bounds__(NW * 64, 2) void conv_up2_bf16x3_kernel(BfsrConvArgs p, int tiles_x, int tiles_xy, int groups)
 {
     constexpr int NT = NW * 64, SR = NW * NR, PW = 34, NPOS = (SR + 1) * PW, PPT = (NPOS + NT - 1) / NT;
     constexpr int TAPS = 16, MW = 32, HT = 8;                            // HT = matrices of one row parity
-    constexpr int WPL = HT * MW * CK, WSLAB = 3 * WPL, WV = (WSLAB / 8 + NT - 1) / NT, IPL = NPOS * CK;
+    constexpr int WPL = HT * MW * CK, WSLAB = PL * WPL, WV = (WSLAB / 8 + NT - 1) / NT, IPL = NPOS * CK;
     constexpr int GPL = TAPS * MW * CK;                                  // one plane of all 16 matrices in global memory
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __bf16* sW = reinterpret_cast<__bf16*>(smem_raw);                     // [3][8][k half][32][8]
-    __bf16* sIn = sW + WSLAB;                                             // [3][k half][NPOS][8]
+    typedef typename Sp<PL>::elt elt;
+    typedef typename Sp<PL>::frag frag;
+    elt* sW = reinterpret_cast<elt*>(smem_raw);                     // [3][8][k half][32][8]
+    elt* sIn = sW + WSLAB;                                             // [3][k half][NPOS][8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
     int bid = blockIdx.x;
@@ -265,11 +310,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_up2_bf16x3_kernel(BfsrConvArg
     const long long cs_in = (long long)Hs * Ws;
     const float* __restrict__ xin = p.x + (long long)b * p.x_bs;
     const int Cin = p.Cin, nchunk = (Cin + CK - 1) / CK;
-    const __bf16* __restrict__ wg = reinterpret_cast<const __bf16*>(p.w) + (long long)cg * nchunk * 3 * GPL;
+    const elt* __restrict__ wg = reinterpret_cast<const elt*>(p.w) + (long long)cg * nchunk * PL * GPL;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0,
                                                                            (unsigned)((long long)Cin * cs_in * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wg), 0,
-                                                                          (unsigned)((long long)nchunk * 3 * GPL * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<elt*>(wg), 0,
+                                                                          (unsigned)((long long)nchunk * PL * GPL * 2), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     unsigned voff[PPT];
 #pragma unroll
@@ -306,7 +351,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_up2_bf16x3_kernel(BfsrConvArg
 #pragma unroll
             for (int i = 0; i < PPT; ++i)
                 vin[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff[i], sbase + (unsigned)c * cs_bytes, 0));
-        const unsigned wbase = (unsigned)k * (3 * GPL * 2);
+        const unsigned wbase = (unsigned)k * (PL * GPL * 2);
 #pragma unroll
         for (int i = 0; i < WV; ++i)
             vw[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff[i], wbase, 0));
@@ -320,16 +365,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_up2_bf16x3_kernel(BfsrConvArg
             if (i < PPT - 1 || pos < NPOS) {
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
-                    bf16x8 h8, m8, l8;
+                    float u8[8];
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        __bf16 h, m, l;
-                        split3(vin[i][hf * 8 + c], h, m, l);
-                        h8[c] = h; m8[c] = m; l8[c] = l;
-                    }
-                    *reinterpret_cast<bf16x8*>(sIn + (hf * NPOS + pos) * 8) = h8;
-                    *reinterpret_cast<bf16x8*>(sIn + IPL + (hf * NPOS + pos) * 8) = m8;
-                    *reinterpret_cast<bf16x8*>(sIn + 2 * IPL + (hf * NPOS + pos) * 8) = l8;
+                    for (int c = 0; c < 8; ++c) u8[c] = vin[i][hf * 8 + c];
+                    frag s8[PL];
+                    split_unit<PL>(u8, s8);
+#pragma unroll
+                    for (int pl = 0; pl < PL; ++pl) *reinterpret_cast<frag*>(sIn + pl * IPL + (hf * NPOS + pos) * 8) = s8[pl];
                 }
             }
         }
@@ -340,22 +382,22 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_up2_bf16x3_kernel(BfsrConvArg
         }
         __syncthreads();
         if (k + 1 < nchunk) load_chunk(k + 1);
-        const __bf16* inB = sIn + (lhi * NPOS + (wave * NR) * PW + l31) * 8;
-        const __bf16* wA = sW + (lhi * MW + l31) * 8;
-        bf16x8 bfr[3][NR + 1], afr[2][3];
+        const elt* inB = sIn + (lhi * NPOS + (wave * NR) * PW + l31) * 8;
+        const elt* wA = sW + (lhi * MW + l31) * 8;
+        frag bfr[PL][NR + 1], afr[2][PL];
         auto load_b = [&](int d) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
                 for (int e = 0; e < NR + 1; ++e)
-                    bfr[pl][e] = *reinterpret_cast<const bf16x8*>(inB + pl * IPL + (e * PW + d) * 8);
+                    bfr[pl][e] = *reinterpret_cast<const frag*>(inB + pl * IPL + (e * PW + d) * 8);
         };
         // step s = 0..7 in the order (d; bq,j with bq+j = d; i); local matrix index = bq*4 + i*2 + j
         auto load_a = [&](int buf, int s_) {
             const int blk = s_ >> 1, bq = blk >> 1, j = blk & 1, i = s_ & 1;
             const int t = bq * 4 + i * 2 + j;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) afr[buf][pl] = *reinterpret_cast<const bf16x8*>(wA + pl * WPL + t * 2 * MW * 8);
+            for (int pl = 0; pl < PL; ++pl) afr[buf][pl] = *reinterpret_cast<const frag*>(wA + pl * WPL + t * 2 * MW * 8);
         };
         load_a(0, 0);
 #pragma unroll
@@ -367,8 +409,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_up2_bf16x3_kernel(BfsrConvArg
             __builtin_amdgcn_sched_barrier(0);
 #define BFSR_TERM(PA_, PB_)                                                                                            \
     _Pragma("unroll") for (int n = 0; n < NR; ++n)                                                                      \
-        acc[bq][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ab][PA_], bfr[PB_][n + i], acc[bq][n], 0, 0, 0);
-            BFSR_TERM(2, 0) BFSR_TERM(0, 2) BFSR_TERM(1, 1) BFSR_TERM(1, 0) BFSR_TERM(0, 1) BFSR_TERM(0, 0)
+        acc[bq][n] = Sp<PL>::mfma(afr[ab][PA_], bfr[PB_][n + i], acc[bq][n]);
+            BFSR_PRODUCTS(PL, BFSR_TERM)
 #undef BFSR_TERM
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -400,6 +442,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_up2_bf16x3_kernel(BfsrConvArg
                 if (sy >= Hs) continue;
                 const long long o = (long long)co * HW + (long long)(2 * sy + pa) * W + 2 * sx;
                 float2 v = make_float2(acc[0][n][r], acc[1][n][r]);
+                if (PL == 2) { v.x *= p.acc_scale; v.y *= p.acc_scale; }
                 v.x += q0.x; v.y += q0.x;
                 if constexpr (T) if (pre) { const float2 t = *reinterpret_cast<const float2*>(pre + o); v.x += t.x; v.y += t.y; }
                 v.x = (v.x + q0.y) * q0.z + q0.w; v.y = (v.y + q0.y) * q0.z + q0.w;
@@ -417,20 +460,26 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_up2_bf16x3_kernel(BfsrConvArg
     else run_epilogue(std::false_type{});
 }
 
-template <int NW, int NR>
-int launch_up2_x3(const BfsrConvArgs& a, hipStream_t st)
+template <int PL, int NW, int NR>
+int launch_up2_x3p(const BfsrConvArgs& a, hipStream_t st)
 {
     constexpr int SR = NW * NR;
-    constexpr int LDS = 3 * (8 * 32 * CK + (SR + 1) * 34 * CK) * 2;
+    constexpr int LDS = PL * (8 * 32 * CK + (SR + 1) * 34 * CK) * 2;
     static std::atomic<unsigned long long> lds_done{0};
-    if (LDS > 65536 && bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_up2_bf16x3_kernel<NW, NR>), LDS, lds_done) != 0) return -1;
+    if (LDS > 65536 && bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_up2_bf16x3_kernel<PL, NW, NR>), LDS, lds_done) != 0) return -1;
     const int Hs = a.H / 2, Ws = a.W / 2;
     const int tiles_x = (Ws + 31) / 32, tiles_y = (Hs + SR - 1) / SR;
     const int groups = (a.Cout + 31) / 32;
     const long long nblk = 2LL * tiles_x * tiles_y * groups * a.B;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return -1;
-    hipLaunchKernelGGL((conv_up2_bf16x3_kernel<NW, NR>), dim3((unsigned)nblk), dim3(NW * 64), LDS, st, a, tiles_x, tiles_x * tiles_y, groups);
+    hipLaunchKernelGGL((conv_up2_bf16x3_kernel<PL, NW, NR>), dim3((unsigned)nblk), dim3(NW * 64), LDS, st, a, tiles_x, tiles_x * tiles_y, groups);
     return (int)hipGetLastError();
+}
+
+template <int NW, int NR>
+int launch_up2_x3(const BfsrConvArgs& a, hipStream_t st)
+{
+    return a.arith == 1 ? launch_up2_x3p<2, NW, NR>(a, st) : launch_up2_x3p<3, NW, NR>(a, st);
 }
 
 // ---- conv over nearest_up4(x): x [B,Cin,H/4,W/4] -> y [B,Cout,H,W] (the level-1 conditional of the 8x model: LR-resolution
@@ -441,16 +490,18 @@ int launch_up2_x3(const BfsrConvArgs& a, hipStream_t st)
 // entry e = 0..4 -> (class, staged offset): (0,0) (0,1) (1,1) (2,1) (2,2) with staged offset 0,1,2 = source offset -1,0,+1.
 // A workgroup handles one ROW class rc (10, 5 or 10 matrices in LDS; staged rows start at y0-1 for rc=0, y0 otherwise, so row
 // entry ie of the class reads staged row n+ie) and keeps acc[column class][row]; lane = source column -> float4 of 4 output px.
-template <int NW, int NR, int RC>
+template <int PL, int NW, int NR, int RC>
 __global__ __launch_bounds__(NW * 64, 4) void conv_up4_bf16x3_kernel(BfsrConvArgs p, int tiles_x, int tiles_xy, int groups)
 {
     constexpr int NT = NW * 64, SR = NW * NR, PW = 34, NPOS = (SR + 1) * PW, PPT = (NPOS + NT - 1) / NT;
     constexpr int MW = 32, MAXM = 10, MEL = 2 * MW * 8;                   // MEL = bf16 elements of one matrix chunk
-    constexpr int WPL = MAXM * MEL, WSLAB = 3 * WPL, WV = (WSLAB / 8 + NT - 1) / NT, IPL = NPOS * CK;
+    constexpr int WPL = MAXM * MEL, WSLAB = PL * WPL, WV = (WSLAB / 8 + NT - 1) / NT, IPL = NPOS * CK;
     constexpr int GPL = 25 * MEL;                                         // one plane of all 25 matrices in global memory
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __bf16* sW = reinterpret_cast<__bf16*>(smem_raw);                     // [3][<=10][k half][32][8]
-    __bf16* sIn = sW + WSLAB;                                             // [3][k half][NPOS][8]
+    typedef typename Sp<PL>::elt elt;
+    typedef typename Sp<PL>::frag frag;
+    elt* sW = reinterpret_cast<elt*>(smem_raw);                     // [3][<=10][k half][32][8]
+    elt* sIn = sW + WSLAB;                                             // [3][k half][NPOS][8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
     int bid = blockIdx.x;
@@ -463,11 +514,11 @@ __global__ __launch_bounds__(NW * 64, 4) void conv_up4_bf16x3_kernel(BfsrConvArg
     const long long cs_in = (long long)Hs * Ws;
     const float* __restrict__ xin = p.x + (long long)b * p.x_bs;
     const int Cin = p.Cin, nchunk = (Cin + CK - 1) / CK;
-    const __bf16* __restrict__ wg = reinterpret_cast<const __bf16*>(p.w) + (long long)cg * nchunk * 3 * GPL;
+    const elt* __restrict__ wg = reinterpret_cast<const elt*>(p.w) + (long long)cg * nchunk * PL * GPL;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0,
                                                                            (unsigned)((long long)Cin * cs_in * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wg), 0,
-                                                                          (unsigned)((long long)nchunk * 3 * GPL * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<elt*>(wg), 0,
+                                                                          (unsigned)((long long)nchunk * PL * GPL * 2), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     unsigned voff[PPT];
 #pragma unroll
@@ -503,7 +554,7 @@ __global__ __launch_bounds__(NW * 64, 4) void conv_up4_bf16x3_kernel(BfsrConvArg
 #pragma unroll
             for (int i = 0; i < PPT; ++i)
                 vin[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff[i], sbase + (unsigned)c * cs_bytes, 0));
-        const unsigned wbase = (unsigned)k * (3 * GPL * 2);
+        const unsigned wbase = (unsigned)k * (PL * GPL * 2);
 #pragma unroll
         for (int i = 0; i < WV; ++i)
             vw[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, woff[i], wbase, 0));
@@ -512,21 +563,21 @@ __global__ __launch_bounds__(NW * 64, 4) void conv_up4_bf16x3_kernel(BfsrConvArg
     auto mfma_chunk = [&](auto nrt_tag) {
         constexpr int NRT = decltype(nrt_tag)::value;
         constexpr int STEPS = 5 * NRT;
-        const __bf16* inB = sIn + (lhi * NPOS + (wave * NR) * PW + l31) * 8;
-        const __bf16* wA = sW + (lhi * MW + l31) * 8;
-        bf16x8 bfr[3][NR + 1], afr[2][3];
+        const elt* inB = sIn + (lhi * NPOS + (wave * NR) * PW + l31) * 8;
+        const elt* wA = sW + (lhi * MW + l31) * 8;
+        frag bfr[PL][NR + 1], afr[2][PL];
         auto load_b = [&](int d) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
                 for (int e = 0; e < NR + NRT - 1; ++e)
-                    bfr[pl][e] = *reinterpret_cast<const bf16x8*>(inB + pl * IPL + (e * PW + d) * 8);
+                    bfr[pl][e] = *reinterpret_cast<const frag*>(inB + pl * IPL + (e * PW + d) * 8);
         };
         auto load_a = [&](int buf, int s_) {                              // step s_ -> (column entry ce, row entry ie)
             const int ce = s_ / NRT, ie = s_ % NRT;
             const int t = ie * 5 + ce;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) afr[buf][pl] = *reinterpret_cast<const bf16x8*>(wA + pl * WPL + t * MEL);
+            for (int pl = 0; pl < PL; ++pl) afr[buf][pl] = *reinterpret_cast<const frag*>(wA + pl * WPL + t * MEL);
         };
         load_a(0, 0);
 #pragma unroll
@@ -539,8 +590,8 @@ __global__ __launch_bounds__(NW * 64, 4) void conv_up4_bf16x3_kernel(BfsrConvArg
             __builtin_amdgcn_sched_barrier(0);
 #define BFSR_TERM(PA_, PB_)                                                                                            \
     _Pragma("unroll") for (int n = 0; n < NR; ++n)                                                                      \
-        acc[cc][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ab][PA_], bfr[PB_][n + ie], acc[cc][n], 0, 0, 0);
-            BFSR_TERM(2, 0) BFSR_TERM(0, 2) BFSR_TERM(1, 1) BFSR_TERM(1, 0) BFSR_TERM(0, 1) BFSR_TERM(0, 0)
+        acc[cc][n] = Sp<PL>::mfma(afr[ab][PA_], bfr[PB_][n + ie], acc[cc][n]);
+            BFSR_PRODUCTS(PL, BFSR_TERM)
 #undef BFSR_TERM
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -554,16 +605,13 @@ __global__ __launch_bounds__(NW * 64, 4) void conv_up4_bf16x3_kernel(BfsrConvArg
             if (i < PPT - 1 || pos < NPOS) {
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
-                    bf16x8 h8, m8, l8;
+                    float u8[8];
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        __bf16 h, m, l;
-                        split3(vin[i][hf * 8 + c], h, m, l);
-                        h8[c] = h; m8[c] = m; l8[c] = l;
-                    }
-                    *reinterpret_cast<bf16x8*>(sIn + (hf * NPOS + pos) * 8) = h8;
-                    *reinterpret_cast<bf16x8*>(sIn + IPL + (hf * NPOS + pos) * 8) = m8;
-                    *reinterpret_cast<bf16x8*>(sIn + 2 * IPL + (hf * NPOS + pos) * 8) = l8;
+                    for (int c = 0; c < 8; ++c) u8[c] = vin[i][hf * 8 + c];
+                    frag s8[PL];
+                    split_unit<PL>(u8, s8);
+#pragma unroll
+                    for (int pl = 0; pl < PL; ++pl) *reinterpret_cast<frag*>(sIn + pl * IPL + (hf * NPOS + pos) * 8) = s8[pl];
                 }
             }
         }
@@ -599,6 +647,7 @@ __global__ __launch_bounds__(NW * 64, 4) void conv_up4_bf16x3_kernel(BfsrConvArg
             for (int rr = 0; rr < nrow; ++rr) {
                 const long long o = (long long)co * HW + (long long)(4 * sy + row0 + rr) * W + 4 * sx;
                 float v[4] = {acc[0][n][r], acc[1][n][r], acc[1][n][r], acc[2][n][r]};
+                if (PL == 2) { v[0] *= p.acc_scale; v[1] *= p.acc_scale; v[2] *= p.acc_scale; v[3] *= p.acc_scale; }
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (pre) t = *reinterpret_cast<const float4*>(pre + o);
                 const float tv[4] = {t.x, t.y, t.z, t.w};
@@ -615,21 +664,27 @@ __global__ __launch_bounds__(NW * 64, 4) void conv_up4_bf16x3_kernel(BfsrConvArg
     }
 }
 
-template <int NW, int NR>
-int launch_up4_x3(const BfsrConvArgs& a, hipStream_t st)
+template <int PL, int NW, int NR>
+int launch_up4_x3p(const BfsrConvArgs& a, hipStream_t st)
 {
     constexpr int SR = NW * NR;
-    constexpr int LDS = 3 * (10 * 2 * 32 * 8 + (SR + 1) * 34 * CK) * 2;
+    constexpr int LDS = PL * (10 * 2 * 32 * 8 + (SR + 1) * 34 * CK) * 2;
     const int Hs = a.H / 4, Ws = a.W / 4;
     const int tiles_x = (Ws + 31) / 32, tiles_y = (Hs + SR - 1) / SR;
     const int groups = (a.Cout + 31) / 32;
     const long long nblk = (long long)tiles_x * tiles_y * groups * a.B;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return -1;
     // one launch per row class (phase 0 | phases 1,2 | phase 3): they write disjoint output rows
-    hipLaunchKernelGGL((conv_up4_bf16x3_kernel<NW, NR, 0>), dim3((unsigned)nblk), dim3(NW * 64), LDS, st, a, tiles_x, tiles_x * tiles_y, groups);
-    hipLaunchKernelGGL((conv_up4_bf16x3_kernel<NW, NR, 1>), dim3((unsigned)nblk), dim3(NW * 64), LDS, st, a, tiles_x, tiles_x * tiles_y, groups);
-    hipLaunchKernelGGL((conv_up4_bf16x3_kernel<NW, NR, 2>), dim3((unsigned)nblk), dim3(NW * 64), LDS, st, a, tiles_x, tiles_x * tiles_y, groups);
+    hipLaunchKernelGGL((conv_up4_bf16x3_kernel<PL, NW, NR, 0>), dim3((unsigned)nblk), dim3(NW * 64), LDS, st, a, tiles_x, tiles_x * tiles_y, groups);
+    hipLaunchKernelGGL((conv_up4_bf16x3_kernel<PL, NW, NR, 1>), dim3((unsigned)nblk), dim3(NW * 64), LDS, st, a, tiles_x, tiles_x * tiles_y, groups);
+    hipLaunchKernelGGL((conv_up4_bf16x3_kernel<PL, NW, NR, 2>), dim3((unsigned)nblk), dim3(NW * 64), LDS, st, a, tiles_x, tiles_x * tiles_y, groups);
     return (int)hipGetLastError();
+}
+
+template <int NW, int NR>
+int launch_up4_x3(const BfsrConvArgs& a, hipStream_t st)
+{
+    return a.arith == 1 ? launch_up4_x3p<2, NW, NR>(a, st) : launch_up4_x3p<3, NW, NR>(a, st);
 }
 
 inline void split3_host(float v, unsigned short out[3])
@@ -668,6 +723,39 @@ extern "C" int bfsr_pack_conv_weight_taps_bf16x3(const float* w, int Cout, int C
                 split3_host(w[((long long)co * Cin + ci) * T + t], s3);
                 for (int pl = 0; pl < 3; ++pl)
                     packed[((((((long long)g * nchunk + ci / CK) * 3 + pl) * T + t) * 2 + (ci % CK) / 8) * MW + m) * 8 + ci % 8] = s3[pl];
+            }
+    }
+    return 0;
+}
+
+extern "C" long long bfsr_conv_packed_size_taps_f16x2(int Cout, int Cin, int T, int mtile)
+{
+    const int nchunk = (Cin + CK - 1) / CK;
+    const int groups = ((Cout + 31) / 32 + mtile - 1) / mtile;
+    return (long long)groups * nchunk * 2 * T * mtile * 32 * CK;            // number of fp16 elements
+}
+
+extern "C" int bfsr_pack_conv_weight_taps_f16x2(const float* w, int Cout, int Cin, int T, int mtile, float scale, unsigned short* packed)
+{
+    // w [Cout][Cin][T] fp32 -> fp16 [cout_group][chunk][plane hi,lo][tap][k half][mtile*32][8] of w*scale (scale: a power of two
+    // chosen by the caller, see bfsr_hip.h), zero padded -- the layout of bfsr_pack_conv_weight_taps_bf16x3 with two planes
+    if (T < 1 || mtile < 1 || !(scale > 0.f)) return -1;
+    const int nchunk = (Cin + CK - 1) / CK, MW = mtile * 32;
+    const int groups = ((Cout + 31) / 32 + mtile - 1) / mtile;
+    const long long n = (long long)groups * nchunk * 2 * T * MW * CK;
+    for (long long i = 0; i < n; ++i) packed[i] = 0;
+    for (int co = 0; co < Cout; ++co) {
+        const int g = co / MW, m = co % MW;
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int t = 0; t < T; ++t) {
+                float r = w[((long long)co * Cin + ci) * T + t] * scale;
+                for (int pl = 0; pl < 2; ++pl) {
+                    const _Float16 h = (_Float16)r;
+                    unsigned short bits;
+                    __builtin_memcpy(&bits, &h, 2);
+                    packed[((((((long long)g * nchunk + ci / CK) * 2 + pl) * T + t) * 2 + (ci % CK) / 8) * MW + m) * 8 + ci % 8] = bits;
+                    r -= (float)h;
+                }
             }
     }
     return 0;

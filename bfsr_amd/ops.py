@@ -35,11 +35,13 @@ def _ptr(t):
 class PackedConv(object):
     """A conv weight packed for the MFMA kernel (layout private to the library).  Packings for other M-tile counts
     are produced lazily from the kept OIHW copy: the launcher picks the M tile per call from the grid size."""
-    __slots__ = ("data", "Cout", "Cin", "KS", "mtile", "fixed", "_w", "_alts", "_ops")
+    __slots__ = ("data", "Cout", "Cin", "KS", "mtile", "fixed", "_w", "_alts", "_ops", "scale", "arith")
 
-    def __init__(self, data, Cout, Cin, KS, mtile, fixed=False, w=None, ops=None):
+    def __init__(self, data, Cout, Cin, KS, mtile, fixed=False, w=None, ops=None, scale=1.0, arith=0):
         self.data, self.Cout, self.Cin, self.KS, self.mtile, self.fixed = data, Cout, Cin, KS, mtile, fixed
         self._w, self._alts, self._ops = w, {mtile: data}, ops
+        # arith 1: two-term fp16 split of w*scale (scale = a power of two); the kernels multiply their accumulators by 1/scale
+        self.scale, self.arith = scale, arith
 
     def variant(self, mtile, packer=None):
         if mtile not in self._alts:
@@ -136,10 +138,17 @@ class HipOps(object):
         Cout, Cin, KS, _ = w.shape
         fixed = mtile is not None or Cout <= 32
         mtile = min(mtile or 2, 2) if Cout > 32 else 1
+        if kind == "bf16x3" and self.split == "f16x2":
+            scale = self.pow2_scale(w)
+            return PackedConv(self._pack_raw_16(w, mtile, "f16x2", scale), Cout, Cin, KS, mtile, fixed=fixed, w=w, ops=self, scale=scale, arith=1)
         return PackedConv(self._pack_raw_16(w, mtile, kind), Cout, Cin, KS, mtile, fixed=fixed, w=w, ops=self)
 
-    def _pack_raw_16(self, w, mtile, kind):
+    def _pack_raw_16(self, w, mtile, kind, scale=1.0):
         Cout, Cin, KS, _ = w.shape
+        if kind == "f16x2":
+            packed = torch.empty(self.lib.bfsr_conv_packed_size_taps_f16x2(Cout, Cin, KS * KS, mtile), dtype=torch.int16)
+            _lib.check(self.lib.bfsr_pack_conv_weight_taps_f16x2(w.data_ptr(), Cout, Cin, KS * KS, mtile, scale, packed.data_ptr()), "pack_f16x2")
+            return packed.to(self.device)
         size_fn = getattr(self.lib, "bfsr_conv_packed_size_" + kind)
         pack_fn = getattr(self.lib, "bfsr_pack_conv_weight_" + kind)
         packed = torch.empty(size_fn(Cout, Cin, KS, mtile), dtype=torch.int16)
@@ -169,8 +178,12 @@ class HipOps(object):
             # 64->96 @ 8x80x80 59 -> 49 us, 64->48 @ 8x160x160 106 -> 97 us, RDB conv5 @ 8x160x160 ~ -8 %)
             if ((W + 31) // 32) * ((H + 7) // 8) * out.shape[0] * ((Cout + 31) // 32) < 2000:
                 mtile = 1
-                wdata = pw.variant(1, lambda w_, m_: self._pack_raw_16(w_, m_, _kind))
+                wdata = pw.variant(1, lambda w_, m_: self._pack_raw_16(w_, m_, "f16x2" if pw.arith == 1 else _kind, pw.scale))
         a.w = wdata.data_ptr()
+        if pw.arith == 1:
+            if _kind != "bf16x3":
+                raise ValueError("conv_f16: a two-term fp16 split packing belongs to conv_x3")
+            a.arith, a.acc_scale = 1, 1.0 / pw.scale
         a.y, a.y_bs, a.Cout = yp, ybs, Cout
         a.B, a.H, a.W, a.KS, a.in_shift, a.mtile = out.shape[0], H, W, pw.KS, in_shift, mtile
         a.epi, a.act, a.slope = _ptr(epi), act, slope
@@ -183,7 +196,7 @@ class HipOps(object):
                 if al is not None:
                     setattr(a, "alpha" + name[-1], al)
         a.tune = tune
-        key = ("conv_" + _kind, pw.KS, mtile, Cin, Cout, out.shape[0], H, W)
+        key = ("conv_" + ("f16x2" if pw.arith == 1 else _kind), pw.KS, mtile, Cin, Cout, out.shape[0], H, W)
         fn = getattr(self.lib, "bfsr_conv2d_" + _kind)
         _lib.check(self._launch(key, lambda: fn(C.byref(a), self._stream())), "conv2d_" + _kind)
         return out
@@ -280,9 +293,17 @@ class HipOps(object):
     def pack_conv_up2_x3(self, w):
         """conv_up2 weights (16 parity-pre-summed matrices) in the 3xBF16 split layout."""
         w16 = self.presum_up2_weights(w)
-        Cout, Cin, _ = w16.shape
-        packed = torch.empty(self.lib.bfsr_conv_packed_size_taps_bf16x3(Cout, Cin, 16, 1), dtype=torch.int16)
-        _lib.check(self.lib.bfsr_pack_conv_weight_taps_bf16x3(w16.data_ptr(), Cout, Cin, 16, 1, packed.data_ptr()), "pack_taps_x3")
+        return self._pack_taps_x3(w16, 16)
+
+    def _pack_taps_x3(self, wt, T):
+        Cout, Cin, _ = wt.shape
+        if self.split == "f16x2":
+            scale = self.pow2_scale(wt)
+            packed = torch.empty(self.lib.bfsr_conv_packed_size_taps_f16x2(Cout, Cin, T, 1), dtype=torch.int16)
+            _lib.check(self.lib.bfsr_pack_conv_weight_taps_f16x2(wt.data_ptr(), Cout, Cin, T, 1, scale, packed.data_ptr()), "pack_taps_f16x2")
+            return PackedConv(packed.to(self.device), Cout, Cin, 3, 1, fixed=True, scale=scale, arith=1)
+        packed = torch.empty(self.lib.bfsr_conv_packed_size_taps_bf16x3(Cout, Cin, T, 1), dtype=torch.int16)
+        _lib.check(self.lib.bfsr_pack_conv_weight_taps_bf16x3(wt.data_ptr(), Cout, Cin, T, 1, packed.data_ptr()), "pack_taps_x3")
         return PackedConv(packed.to(self.device), Cout, Cin, 3, 1, fixed=True)
 
     @staticmethod
@@ -303,10 +324,7 @@ class HipOps(object):
 
     def pack_conv_up4_x3(self, w):
         w25 = self.presum_up4_weights(w)
-        Cout, Cin, _ = w25.shape
-        packed = torch.empty(self.lib.bfsr_conv_packed_size_taps_bf16x3(Cout, Cin, 25, 1), dtype=torch.int16)
-        _lib.check(self.lib.bfsr_pack_conv_weight_taps_bf16x3(w25.data_ptr(), Cout, Cin, 25, 1, packed.data_ptr()), "pack_taps_x3")
-        return PackedConv(packed.to(self.device), Cout, Cin, 3, 1, fixed=True)
+        return self._pack_taps_x3(w25, 25)
 
     def conv_up4_x3(self, x, pw, out, epi=None, pre_add=None, act=ACT_NONE, slope=0.2):
         """out [B,Cout,4h,4w] = epilogue(conv3x3(nearest_up4(x)) + pre_add) on the 3xBF16 split (25 pre-summed matrices)."""
@@ -324,15 +342,18 @@ class HipOps(object):
         a.y, a.y_bs, a.Cout = yp, ybs, Cout
         a.B, a.H, a.W, a.KS, a.mtile, a.tune = out.shape[0], H, W, 3, 1, tune
         a.epi, a.act, a.slope = _ptr(epi), act, slope
+        if pw.arith == 1:
+            a.arith, a.acc_scale = 1, 1.0 / pw.scale
+        fam = "_f2" if pw.arith == 1 else "_x3"
         if pre_add is not None:
             pp, bs, c, hh, ww = _view(pre_add, "conv_up2_x3.pre_add")
             assert (c, hh, ww) == (Cout, H, W)
             a.pre_add, a.pre_add_bs = pp, bs
         if _factor == 4:
-            key = ("conv_up4_x3", 1, Cin, Cout, out.shape[0], H, W, 0)
+            key = ("conv_up4" + fam, 1, Cin, Cout, out.shape[0], H, W, 0)
             _lib.check(self._launch(key, lambda: self.lib.bfsr_conv2d_up4_bf16x3(C.byref(a), self._stream())), "conv2d_up4_bf16x3")
             return out
-        key = ("conv_up2_x3", 1, Cin, Cout, out.shape[0], H, W, 0)
+        key = ("conv_up2" + fam, 1, Cin, Cout, out.shape[0], H, W, 0)
         _lib.check(self._launch(key, lambda: self.lib.bfsr_conv2d_up2_bf16x3(C.byref(a), self._stream())), "conv2d_up2_bf16x3")
         return out
 
@@ -390,7 +411,7 @@ class HipOps(object):
         if (Cin, Cout, H, W) != (pw.Cin, pw.Cout, H2, W2) or pw.KS != 3 or x.shape[0] != out.shape[0]:
             raise ValueError("conv_x3s: shape mismatch x%s out%s weight(Cout=%d,Cin=%d)" % (tuple(x.shape), tuple(out.shape), pw.Cout, pw.Cin))
         a.Cin, a.Cout = Cin, Cout
-        a.w = pw.variant(1, lambda w_, m_: self._pack_raw_16(w_, m_, "bf16x3")).data_ptr()
+        a.w = pw.variant(1 if pw.arith == 0 else "bf16x3", lambda w_, m_: self._pack_raw_16(w_, 1, "bf16x3")).data_ptr()
         a.B, a.H, a.W = out.shape[0], H, W
         a.epi, a.act, a.slope, a.tune = _ptr(epi), act, slope, tune
         for name, t, al in (("res1", res1, alpha1), ("res2", res2, alpha2)):

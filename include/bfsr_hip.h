@@ -66,6 +66,13 @@ typedef struct BfsrConvArgs {
     /* bfsr_conv2d_up2 only: optional extra input channels that live at OUTPUT resolution ([B,Cin2,H,W] view) with their
      * own ordinary 3x3 weights (bfsr_pack_conv_weight, same mtile): y = epilogue(conv3x3(cat[x2, nearest_up2(x)])) */
     const float* x2; long long x2_bs; int Cin2; const float* w_x2;
+    /* bfsr_conv2d_bf16x3 / _up2_bf16x3 / _up4_bf16x3 only -- which split the kernel contracts in:
+     * arith 0: exact three-term bf16 split, six products (weights from bfsr_pack_conv_weight[_taps]_bf16x3);
+     * arith 1: two-term fp16 split of both operands (22 significant bits), three products, half the matrix instructions; weights
+     *          from bfsr_pack_conv_weight_taps_f16x2(..., scale, ...) with scale = a power of two that puts the largest |w| into
+     *          [2^9, 2^10) (their lo terms stay normal fp16 numbers); the accumulators are multiplied by acc_scale = 1/scale before
+     *          the epilogue; activations must stay below 65504 in magnitude. */
+    int arith; float acc_scale;
 } BfsrConvArgs;
 
 int bfsr_abi_version(void);
@@ -114,6 +121,8 @@ int bfsr_conv2d_up2_bf16x3(const BfsrConvArgs* a, void* stream);
 int bfsr_conv2d_up4_bf16x3(const BfsrConvArgs* a, void* stream);
 long long bfsr_conv_packed_size_taps_bf16x3(int Cout, int Cin, int T, int mtile);
 int bfsr_pack_conv_weight_taps_bf16x3(const float* w_oit, int Cout, int Cin, int T, int mtile, unsigned short* packed);
+long long bfsr_conv_packed_size_taps_f16x2(int Cout, int Cin, int T, int mtile);
+int bfsr_pack_conv_weight_taps_f16x2(const float* w_oit, int Cout, int Cin, int T, int mtile, float scale, unsigned short* packed);
 
 /* Wide 1x1 convolutions as a GEMM over the flattened pixel axis (the LINF shared MLP, linf.py:313-314): a workgroup owns
  * 128 pixels x 256 output channels, so activations are read once per 256 couts.  x3 != 0: exact 3-term bf16 split (fp32

@@ -29,6 +29,15 @@ def hipb():
     return o
 
 
+@pytest.fixture(scope="module", params=["f16x2", "bf16x3"])
+def hips(request):
+    """The library under each split of its fp32-accurate 16-bit contraction mode (BFSR_SPLIT)."""
+    from bfsr_amd.ops import HipOps
+    o = HipOps("cuda:0")
+    o.split = request.param
+    return o
+
+
 CPU = CpuOps()
 
 
@@ -616,9 +625,12 @@ X3_CASES = [(2, 64, 32, 40, 72, 3, 1), (1, 192, 64, 20, 36, 3, 2), (1, 70, 50, 1
 
 
 @pytest.mark.parametrize("case", X3_CASES)
-def test_conv_bf16x3_is_fp32_accurate(hip, case):
-    """The 3xBF16 split conv: error against an fp64 conv is at the level of the native fp32 MFMA kernel (and of the CPU
-    fp32 conv the oracle uses) -- i.e. it is an fp32 conv, not a reduced-precision one."""
+def test_conv_bf16x3_is_fp32_accurate(hips, case):
+    """The split convs (three-term bf16 / two-term fp16): error against an fp64 conv is at the level of the native fp32 MFMA kernel
+    (and of the CPU fp32 conv the oracle uses) -- i.e. they are fp32 convs, not reduced-precision ones.  The fp16 pair carries 22
+    instead of 24 significant bits per operand: its bound is 4x instead of 2x the fp32 kernels' error."""
+    hip = hips
+    slack = 2.0 if hip.split == "bf16x3" else 4.0
     B, Cin, Cout, H, W, KS, mt = case
     x = rnd(170, B, Cin, H, W) * 3.0
     x[:, :, ::3] *= 1e-3                                        # wide dynamic range
@@ -635,16 +647,17 @@ def test_conv_bf16x3_is_fp32_accurate(hip, case):
         ex3 = (ox3.cpu().double() - truth).abs().max().item()
         cpu = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x, w, b, padding=KS // 2), 0.2) * 0.2 + r1
         ecpu = (cpu.double() - truth).abs().max().item()
-        print("case %s tune %d: max-abs err vs fp64: bf16x3 %.2e, fp32 MFMA %.2e, torch CPU fp32 %.2e" % (case, tune, ex3, e32, ecpu))
-        assert ex3 <= 2.0 * max(e32, ecpu) + 1e-7, (ex3, e32, ecpu)
+        print("case %s tune %d: max-abs err vs fp64: %s %.2e, fp32 MFMA %.2e, torch CPU fp32 %.2e" % (case, tune, hip.split, ex3, e32, ecpu))
+        assert ex3 <= slack * max(e32, ecpu) + 1e-7, (ex3, e32, ecpu)
         close(ox3, o32.cpu(), 1e-5, "bf16x3 vs fp32 %s" % (case,))
 
 
 @pytest.mark.parametrize("case", [(2, 70, 64, 64, 9, 21), (1, 256, 64, 128, 12, 40), (1, 24, 10, 40, 7, 35), (1, 48, 16, 96, 33, 50)])
 @pytest.mark.parametrize("tune", [402, 401, 801])
-def test_conv_up2_bf16x3_with_key_channels(hip, case, tune):
+def test_conv_up2_bf16x3_with_key_channels(hips, case, tune):
     """The 3xBF16 pair (plain conv over the key channels -> taps kernel with pre_add aliasing the output) == the conv over
     cat[key, nearest_up2(taps)], at fp32 accuracy."""
+    hip = hips
     B, Ct, Ck, Cout, h, w_ = case
     taps, key = rnd(180, B, Ct, h, w_), rnd(181, B, Ck, 2 * h, 2 * w_)
     w = rnd(182, Cout, Ck + Ct, 3, 3, scale=1.0 / np.sqrt((Ck + Ct) * 9))
@@ -661,7 +674,7 @@ def test_conv_up2_bf16x3_with_key_channels(hip, case, tune):
                        epi=hip.pack_epilogue(Cout, aff_shift=sh, aff_scale=sc), act=1, key=(hip.to_device(key), hip.pack_conv(wk, 2)))
     ex3 = (out.cpu().double() - truth).abs().max().item()
     e32 = (o32.cpu().double() - truth).abs().max().item()
-    assert ex3 <= 2.0 * e32 + 1e-7, (ex3, e32)
+    assert ex3 <= (2.0 if hip.split == "bf16x3" else 4.0) * e32 + 1e-7, (ex3, e32)
     close(out, o32.cpu(), 1e-5, "conv_up2_x3 %s" % (case,))
 
 
@@ -687,8 +700,9 @@ def test_likelihood_reductions(hip):
 
 
 @pytest.mark.parametrize("case", [(2, 70, 64, 64, 9, 21), (1, 256, 64, 96, 12, 40), (1, 24, 10, 40, 7, 35)])
-def test_conv_up4_bf16x3_with_key_channels(hip, case):
+def test_conv_up4_bf16x3_with_key_channels(hips, case):
     """x4 parity kernel (25 pre-summed matrices, 3 row-class launches) + key conv == conv over cat[key, nearest_up4(taps)]."""
+    hip = hips
     B, Ct, Ck, Cout, h, w_ = case
     taps, key = rnd(200, B, Ct, h, w_), rnd(201, B, Ck, 4 * h, 4 * w_)
     w = rnd(202, Cout, Ck + Ct, 3, 3, scale=1.0 / np.sqrt((Ck + Ct) * 9))
@@ -706,7 +720,7 @@ def test_conv_up4_bf16x3_with_key_channels(hip, case):
                    epi=hip.pack_epilogue(Cout, aff_shift=sh, aff_scale=sc), act=1)        # native fp32 MFMA on the materialised input
     ex3 = (out.cpu().double() - truth).abs().max().item()
     e32 = max((ref32.double() - truth).abs().max().item(), (o32.cpu().double() - truth).abs().max().item())
-    assert ex3 <= 2.0 * e32 + 1e-7, (ex3, e32)
+    assert ex3 <= (2.0 if hip.split == "bf16x3" else 4.0) * e32 + 1e-7, (ex3, e32)
     close(out, ref32, 1e-5, "conv_up4_x3 %s" % (case,))
 
 

@@ -2,7 +2,9 @@
 compared BITWISE with the first.  Motivation (round 3): coupling_step_kernel produced wrong columns in ~1 of 3 launches until its
 MFMA operand registers were kept allocated for a chunk behind their last use (a dead SrcA/SrcB register that hipcc recycles at
 once can be overwritten before a queued MFMA has read it when two waves share a SIMD's matrix pipe); such a fault is
-intermittent and bf16-sized, i.e. a single parity run can miss it.  Usage (GPU box): python tools/determinism_stress.py [N]"""
+intermittent and bf16-sized, i.e. a single parity run can miss it.  Usage (GPU box): python tools/determinism_stress.py [N] [noise]
+`noise`: a second stream keeps the chip busy with other MFMA kernels while each kernel is stressed (the engine's side stream does
+that to the flow steps): co-resident waves of ANOTHER kernel change what a wave's matrix pipe is doing behind its back."""
 import os
 import sys
 
@@ -14,6 +16,23 @@ from bfsr_amd.ops import ACT_LRELU, ACT_RELU, HipOps  # noqa: E402
 
 ops = HipOps("cuda:0")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+NOISE = len(sys.argv) > 2 and sys.argv[2] == "noise"
+_side = torch.cuda.Stream() if NOISE else None
+_noise = {}
+
+
+def _noise_burst():
+    """Enqueue ~10 ms of unrelated MFMA work on the side stream (small launches that share CUs with the kernel under test)."""
+    if not _noise:
+        x = torch.randn(4, 64, 96, 96, device="cuda")
+        _noise["x"] = x
+        _noise["pw"] = ops.pack_conv_x3(torch.randn(64, 64, 3, 3) * 0.05, 1)
+        _noise["y"] = ops.empty(4, 64, 96, 96)
+        _noise["pw32"] = ops.pack_conv(torch.randn(64, 64, 1, 1) * 0.1, 2)
+    with torch.cuda.stream(_side):
+        for _ in range(40):
+            ops.conv_x3(_noise["x"], _noise["pw"], _noise["y"])
+            ops.conv(_noise["x"], _noise["pw32"], _noise["y"])
 g = np.random.Generator(np.random.PCG64(5))
 r = lambda *s, scale=1.0: torch.from_numpy((g.standard_normal(s) * scale).astype(np.float32))
 d = ops.to_device
@@ -24,7 +43,9 @@ def stress(name, fn):
     torch.cuda.synchronize()
     bad = 0
     worst = 0.0
-    for _ in range(N):
+    for i in range(N):
+        if NOISE and i % 4 == 0:
+            _noise_burst()
         out = fn()
         if not torch.equal(out, ref):
             bad += 1

@@ -311,7 +311,7 @@ int launch_tail(const BfsrCouplingTailArgs& a, hipStream_t st)
 // while tile t is in the matrix pipe (the kernel moves 420 MB per launch at level 1 and has ~5 us of MFMA per tile, so without the
 // prefetch it is a chain of exposed HBM latencies: 410 us measured for the non-persistent form against a 105 us traffic bound).
 template <int NO, int NWV>
-__global__ __launch_bounds__(NWV * 64, 2) void coupling_head_kernel(BfsrCouplingHeadArgs p, int tiles_x, int tiles_xy, int ntiles)
+__global__ __launch_bounds__(NWV * 64, 2) void coupling_head_kernel(BfsrCouplingHeadArgs p, int tiles_x, int tiles_xy, int ntiles, int dbg)
 {
     // NWV waves = NWV tile rows per workgroup.  NWV = 8: one workgroup per CU; NWV = 4: TWO independent workgroups per CU (their
     // barriers are private, so the VALU / memory phases of one overlap the MFMA phases of the other on every SIMD)
@@ -550,7 +550,9 @@ __global__ __launch_bounds__(NWV * 64, 2) void coupling_head_kernel(BfsrCoupling
         __builtin_amdgcn_sched_barrier(0);                  // the epilogue has read both accumulators: the 1x1's last MFMAs are complete
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) { BFSR_KEEP(fa[1][0][pl]); BFSR_KEEP(fa[1][1][pl]); BFSR_KEEP(b2[3][pl]); }
+        if (dbg & 2) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __syncthreads(); }      // diagnostic (BFSR_HEAD_DBG)
     }
+    if (dbg & 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #undef BFSR_KEEP
 }
 
@@ -568,8 +570,9 @@ int launch_head(const BfsrCouplingHeadArgs& a, hipStream_t st)
     int cus = bfsr::cu_count();                             // cached per device; no silent default
     if (cus <= 0) return -1;
     const long long slots = (long long)cus * (8 / NWV);
-    const long long grid = ntiles < slots ? ntiles : slots; // persistent workgroups: one (NWV = 8) or two (NWV = 4) per CU
-    hipLaunchKernelGGL((coupling_head_kernel<NO, NWV>), dim3((unsigned)grid), dim3(NWV * 64), LDS, st, a, tiles_x, tiles_x * tiles_y, (int)ntiles);
+    static const int dbg = [] { const char* e = getenv("BFSR_HEAD_DBG"); return e ? atoi(e) : 0; }();       // diagnostics: 1 = one tile per workgroup
+    const long long grid = (ntiles < slots || (dbg & 1)) ? ntiles : slots; // persistent workgroups: one (NWV = 8) or two (NWV = 4) per CU
+    hipLaunchKernelGGL((coupling_head_kernel<NO, NWV>), dim3((unsigned)grid), dim3(NWV * 64), LDS, st, a, tiles_x, tiles_x * tiles_y, (int)ntiles, dbg);
     return (int)hipGetLastError();
 }
 
@@ -674,7 +677,12 @@ extern "C" int bfsr_coupling_head(const BfsrCouplingHeadArgs* a, void* stream)
     if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cz <= 0 || a->Cz > 16) return -1;
     if (a->hid_fmt != 0 && a->hid_fmt != 1) return -1;
     if (a->hid_fmt == 1 && ((reinterpret_cast<unsigned long long>(a->hid) & 15) || (a->hid_bs & 3))) return -1;
-    static const int nwv = [] { const char* e = getenv("BFSR_HEAD_WAVES"); return e && atoi(e) == 4 ? 4 : 8; }();
+    // Default: FOUR waves per workgroup, two independent workgroups per CU.  The 8-wave form (BFSR_HEAD_WAVES=8: both waves of a SIMD in
+    // the same barrier-synchronised phase) is as fast but produces, on most boxes of the pool, a wrong half row tile (16 pixels x 64
+    // channels, errors up to ~1) once in 10^3-10^4 launches INSIDE the engine's kernel sequence although 30 000 isolated launches are
+    // bit-identical (tools/exp/shard_repro.py with BFSR_PAIR_DBG=check: 16-300 of 300 rounds differ with 8 waves, 0 of 900 with 4;
+    // DESIGN.md section 5, round 3).  The operand discipline below made the fault rarer, it did not remove it.
+    static const int nwv = [] { const char* e = getenv("BFSR_HEAD_WAVES"); return e && atoi(e) == 8 ? 8 : 4; }();
     if (nwv == 4) return a->Cz <= 8 ? launch_head<1, 4>(*a, st) : launch_head<2, 4>(*a, st);
     return a->Cz <= 8 ? launch_head<1, 8>(*a, st) : launch_head<2, 8>(*a, st);
 }

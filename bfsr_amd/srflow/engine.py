@@ -535,6 +535,42 @@ class SRFlowEngine(object):
         st.aff4.run(ops, hid, h_aff)
         return h_aff
 
+    def _pair(self, st, z, pre_k, hid, reverse, tag, kw):
+        """coupling_head -> coupling_tail (in place on z).  BFSR_PAIR_DBG selects diagnostic variants of the sequence (tools/exp/
+        shard_repro.py): ghead = generic fp32-MFMA kernel for the head's two convs, fmt0 = NCHW hid, nop = an unrelated launch
+        between the two kernels, oop = tail out of place."""
+        ops = self.ops
+        dbg = os.environ.get("BFSR_PAIR_DBG", "")
+        if dbg == "ghead":
+            cn = z.shape[1] // 2
+            st.aff0_z1.run(ops, z[:, :cn], hid, pre_add=pre_k, act=ACT_RELU, stage2=(st.aff2.pw, st.aff2.epi, ACT_RELU))
+            ops.coupling_tail(hid, st.tail, z, z, reverse, hid_fmt=0, **kw)
+            return z
+        fmt = 0 if dbg == "fmt0" else 1
+        ops.coupling_head(z, st.head, pre_k, hid, hid_fmt=fmt)
+        if dbg.startswith("check"):                                     # is the head's output already wrong, or does the tail read it wrongly?
+            B_, _, H_, W_ = z.shape
+            if dbg == "check":
+                torch.cuda.synchronize()
+            got = hid.view(B_, 8, H_, W_, 8).permute(0, 1, 4, 2, 3).reshape(B_, 64, H_, W_).clone()
+            ref = self.ws.get("hid_ref", B_, 64, H_, W_)
+            cn = z.shape[1] // 2
+            st.aff0_z1.run(ops, z[:, :cn], ref, pre_add=pre_k, act=ACT_RELU, stage2=(st.aff2.pw, st.aff2.epi, ACT_RELU))
+            df = (got - ref).abs()
+            mx = float(df.max())
+            if mx > 1e-3:
+                idx = torch.nonzero(df > 1e-3)
+                print("HEAD MISMATCH max %.3e, %d elements, first %s last %s (C=%d %dx%d B=%d)" % (mx, idx.shape[0], idx[0].tolist(), idx[-1].tolist(), z.shape[1], H_, W_, B_), flush=True)
+        if dbg == "nop":
+            t = self.ws.get("nop", 1, 1, 1, 64)
+            ops.axpb_clamp(t, t)
+        if dbg == "oop":
+            out = self._pingpong(z, tag)
+            ops.coupling_tail(hid, st.tail, z, out, reverse, hid_fmt=fmt, **kw)
+            return out
+        ops.coupling_tail(hid, st.tail, z, z, reverse, hid_fmt=fmt, **kw)
+        return z
+
     def _pingpong(self, z, tag):
         """A workspace tensor of z's shape that is not z: the fused step kernel reads the z1 halo of neighbouring tiles, so it
         cannot run in place and the flow state alternates between two buffers per level."""
@@ -587,9 +623,8 @@ class SRFlowEngine(object):
                         if st.step is not None:
                             z = ops.coupling_step(z, self._pingpong(z, "enc%d" % ly.level), st.step, pre_k, False, **kw)
                         else:
-                            hid = ws.get("hid_enc%d" % ly.level, B, 64, H, W)
-                            ops.coupling_head(z, st.head, pre_k, hid, hid_fmt=1)          # hid: private octet-major layout
-                            ops.coupling_tail(hid, st.tail, z, z, False, hid_fmt=1, **kw)
+                            hid = ws.get("hid_enc%d" % ly.level, B, 64, H, W)                 # private octet-major layout between the two kernels
+                            z = self._pair(st, z, pre_k, hid, False, "enc%d" % ly.level, kw)
                     else:
                         pending = self._self_cond(st, z, cnd, k, "enc%d" % ly.level)
                         if logdet is not None:
@@ -651,8 +686,7 @@ class SRFlowEngine(object):
                             z = ops.coupling_step(z, self._pingpong(z, "dec%d" % ly.level), st.step, pre_k, True, **kw)
                         else:
                             hid = ws.get("hid_dec%d" % ly.level, z.shape[0], 64, H, W)
-                            ops.coupling_head(z, st.head, pre_k, hid, hid_fmt=1)
-                            ops.coupling_tail(hid, st.tail, z, z, True, hid_fmt=1, **kw)
+                            z = self._pair(st, z, pre_k, hid, True, "dec%d" % ly.level, kw)
                     else:
                         h_aff = self._self_cond(st, z, cnd, k, "dec%d" % ly.level)
                         if logdet is not None:

@@ -13,3 +13,31 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_mfma_kernels_are_run_to_run_deterministic():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "determinism_stress.py"), "30"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "TOTAL differing launches: 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_engine_encode_is_reproducible_run_to_run():
+    """The fault that isolated kernel stress does not see: inside the engine's kernel sequence the 8-wave coupling_head produced a wrong
+    half row tile once in 10^3-10^4 launches (round 3; the default is the 4-wave form since).  40 encode -> decode -> encode(one sample)
+    rounds on fixed inputs must reproduce round 0 bit for bit, and the single-sample call must equal the batch call's sample."""
+    import torch
+    from bfsr_amd import synth
+    from bfsr_amd.ops import HipOps, MODE_BILINEAR
+    from test_srflow_gpu import build
+    hip = HipOps("cuda:0")
+    m, prior, opt, sd, psd = build(hip, 4)
+    eng = m.netG.module.engine()
+    lr = hip.to_device(synth.smooth_lr_batch(21, 2, 160, 160))
+    lr_up = hip.resize(lr, hip.empty(2, 3, 640, 640), MODE_BILINEAR, 0.25, 0.25)
+    lr1, lr_up1 = lr[1:2].clone(), lr_up[1:2].clone()
+    ref2 = ref1 = None
+    for it in range(40):
+        ep = [e.clone() for e in eng.encode(lr_up, lr)]
+        rt = eng.decode(lr, epses=[e.clone() for e in ep]).clone()
+        ep1 = [e.clone() for e in eng.encode(lr_up1, lr1)]
+        if ref2 is None:
+            ref2, ref1, rt0 = ep, ep1, rt
+        for lvl in range(len(ep)):
+            assert torch.equal(ep[lvl], ref2[lvl]), "round %d: encode(B=2) eps%d differs from round 0" % (it, lvl)
+            assert torch.equal(ep1[lvl], ref1[lvl]), "round %d: encode(B=1) eps%d differs from round 0" % (it, lvl)
+            assert torch.equal(ep[lvl][1:2], ep1[lvl]), "round %d: eps%d of sample 1 depends on the batch" % (it, lvl)
+        assert torch.equal(rt, rt0), "round %d: decode differs from round 0" % it

@@ -56,6 +56,7 @@ FAMILIES = {
     "conv_f16": ("conv_f16_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, "fp16 MFMA (v_mfma_f32_32x32x16_f16), fp32 accumulate"),
     "conv_h2s": ("conv3x3_h2s_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, "fp16 MFMA, fp16-stored (h2) input by LDS-DMA, fp32 accumulate"),
     "linf_mlp_x3": ("linf_mlp_kernel<x3>", PEAK_16BIT_MFMA_TFLOPS, 6, "3xBF16 split; Fourier features + 4-layer MLP fused"),
+    "linf_mlp_f2": ("linf_mlp_kernel<f16x2>", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split, 3 products; Fourier features + 4-layer MLP fused"),
     "linf_mlp_f16": ("linf_mlp_kernel<fp16>", PEAK_16BIT_MFMA_TFLOPS, 1, "fp16 MFMA; Fourier features + 4-layer MLP fused"),
     "conv1x1_f16": ("conv1x1_kernel<fp16>", PEAK_16BIT_MFMA_TFLOPS, 1, "fp16 MFMA GEMM over pixels"),
     "conv1x1_x3": ("conv1x1_kernel<x3>", PEAK_16BIT_MFMA_TFLOPS, 6, "3xBF16 split GEMM over pixels"),
@@ -94,7 +95,7 @@ def launch_flop(k):
     if f in ("conv_x3s", "conv_h2s", "conv_h2x"):
         _, Cin, Cout, b_, hh, ww, _fmt = k
         return 2.0 * Cin * 9 * Cout * b_ * hh * ww
-    if f in ("linf_mlp_x3", "linf_mlp_f16"):           # layer 1 (4 neighbours x 256 features) + two hidden layers + output layer
+    if f in ("linf_mlp_x3", "linf_mlp_f16", "linf_mlp_f2"):           # layer 1 (4 neighbours x 256 features) + two hidden layers + output layer
         _, hid, Cout, b_, qh, qw = k
         return 2.0 * (4 * hid * hid + 2 * hid * hid + hid * Cout) * b_ * qh * qw
     if f in ("conv1x1_f16", "conv1x1_x3"):

@@ -116,7 +116,7 @@ class BfsrLinfMlpArgs(C.Structure):
         ("dy_neg", C.c_float), ("dy_pos", C.c_float), ("dx_neg", C.c_float), ("dx_pos", C.c_float),
         ("clamp_lo", C.c_float), ("clamp_hi", C.c_float),
         ("cy0", C.c_float), ("cy1", C.c_float), ("cx0", C.c_float), ("cx1", C.c_float),
-        ("out_fmt", C.c_int),
+        ("out_fmt", C.c_int), ("acc_scale", C.c_float * 4),
     ]
 
 
@@ -189,6 +189,7 @@ SYMBOLS = {
     "bfsr_linf_mlp": (_I, [C.POINTER(BfsrLinfMlpArgs), _I, _VP]),
     "bfsr_linf_mlp_packed_size": (_LL, [_I, _I, _I]),
     "bfsr_pack_linf_mlp": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
+    "bfsr_pack_linf_mlp_f16x2": (_I, [_VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
     "bfsr_logscale_sum": (_I, [_VP, _LL, _I, _I, _LL, _F, C.c_double, _VP, _VP]),
     "bfsr_gaussian_logp": (_I, [_VP, _LL, _VP, _LL, _I, _I, _LL, C.c_double, _VP, _VP]),
     "bfsr_linf_flow": (_I, [C.POINTER(BfsrLinfFlowArgs), _VP]),

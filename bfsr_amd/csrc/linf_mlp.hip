@@ -35,14 +35,21 @@ constexpr int NW = 8, P = 64, HID = 256, KC = 16;
 constexpr int K1 = 4 * HID;                    // 1024 feature channels
 constexpr int NCH_HID = HID / KC;              // 16 chunks of 16 channels in a hidden activation
 
-template <bool X3> struct Mode;
-template <> struct Mode<true> {
+// arithmetic: 0 = operands rounded to fp16 (one product); 1 = exact three-term bf16 split (six products); 2 = two-term fp16 split
+// (22 significant bits, three products; weights pre-scaled by a power of two per layer, accumulators multiplied by a.acc_scale[layer])
+template <int MDE> struct Mode;
+template <> struct Mode<1> {
     static constexpr int PL = 3;
     typedef bf16x8 frag;
     static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
-template <> struct Mode<false> {
+template <> struct Mode<0> {
     static constexpr int PL = 1;
+    typedef f16x8 frag;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mode<2> {
+    static constexpr int PL = 2;
     typedef f16x8 frag;
     static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
@@ -82,20 +89,23 @@ __device__ __forceinline__ void sincos_feat(float x, float& s, float& c)
 }
 
 // 8 fp32 values of one point (8 consecutive channels of a chunk half) -> PL fragments of 16 B
-template <bool X3>
+template <int X3>
 __device__ __forceinline__ void encode8(const float (&v)[8], typename Mode<X3>::frag (&out)[Mode<X3>::PL])
 {
-    if constexpr (X3) {
+    if constexpr (X3 == 1) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { __bf16 h, m, l; split3(v[e], h, m, l); out[0][e] = h; out[1][e] = m; out[2][e] = l; }
+    } else if constexpr (X3 == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const _Float16 h = (_Float16)v[e]; out[0][e] = h; out[1][e] = (_Float16)(v[e] - (float)h); }
     } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) out[0][e] = (_Float16)v[e];
     }
 }
 
-template <bool X3>
-__global__ __launch_bounds__(NW * 64, X3 ? 2 : 4) void linf_mlp_kernel(BfsrLinfMlpArgs a, int tiles_per_image)
+template <int X3>
+__global__ __launch_bounds__(NW * 64, X3 == 0 ? 4 : 2) void linf_mlp_kernel(BfsrLinfMlpArgs a, int tiles_per_image)
 {
     typedef Mode<X3> MD;
     typedef typename MD::frag frag;
@@ -209,9 +219,13 @@ __global__ __launch_bounds__(NW * 64, X3 ? 2 : 4) void linf_mlp_kernel(BfsrLinfM
     };
     // acc[nt] += A(tile) x B(chunk): X3 = six cross products, small terms first
     auto mma = [&](f32x16 (&acc)[2], const frag (&af)[PL], const frag (&bf)[PL][2]) {
-        if constexpr (X3) {
+        if constexpr (X3 == 1) {
 #define BFSR_T(PA_, PB_) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) acc[nt] = MD::mfma(af[PA_], bf[PB_][nt], acc[nt]);
             BFSR_T(2, 0) BFSR_T(0, 2) BFSR_T(1, 1) BFSR_T(1, 0) BFSR_T(0, 1) BFSR_T(0, 0)
+#undef BFSR_T
+        } else if constexpr (X3 == 2) {
+#define BFSR_T(PA_, PB_) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) acc[nt] = MD::mfma(af[PA_], bf[PB_][nt], acc[nt]);
+            BFSR_T(1, 0) BFSR_T(0, 1) BFSR_T(0, 0)
 #undef BFSR_T
         } else {
 #pragma unroll
@@ -234,7 +248,7 @@ __global__ __launch_bounds__(NW * 64, X3 ? 2 : 4) void linf_mlp_kernel(BfsrLinfM
         }
     };
     // one output tile of a hidden layer -> bias, ReLU, channel-octet transposition, re-encode, write as activation chunks
-    auto store_hidden = [&](const f32x16 (&acc)[2], const float* __restrict__ bias, int mt) {
+    auto store_hidden = [&](const f32x16 (&acc)[2], const float* __restrict__ bias, int mt, float asc) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             float v[2][8];
@@ -253,7 +267,7 @@ __global__ __launch_bounds__(NW * 64, X3 ? 2 : 4) void linf_mlp_kernel(BfsrLinfM
                 const int ch0 = mt * 32 + oct * 8;
                 float u[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float t = v[qd][e] + bias[ch0 + e]; u[e] = t > 0.f ? t : 0.f; }
+                for (int e = 0; e < 8; ++e) { const float t = (X3 == 2 ? v[qd][e] * asc : v[qd][e]) + bias[ch0 + e]; u[e] = t > 0.f ? t : 0.f; }
                 frag fr[PL];
                 encode8<X3>(u, fr);
                 unsigned char* dst = smem + (ch0 >> 4) * CHUNK;
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(NW * 64, X3 ? 2 : 4) void linf_mlp_kernel(BfsrLinfM
         if (t + 1 < 8) gen_finish(nk, nc0, g, smem + (((t + 1) & 1) * 8 + wave) * CHUNK);
         __syncthreads();
     }
-    store_hidden(acc, a.bias, wave);                                 // all waves are past the last interval's reads (barrier above)
+    store_hidden(acc, a.bias, wave, a.acc_scale[0]);                 // all waves are past the last interval's reads (barrier above)
     __syncthreads();
 
     // =============================== layers 2, 3: 256 -> 256 ==============================================================
@@ -302,7 +316,7 @@ __global__ __launch_bounds__(NW * 64, X3 ? 2 : 4) void linf_mlp_kernel(BfsrLinfM
             for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
         k_loop(acc, wl, NCH_HID, wave, 0, NCH_HID, smem);
         __syncthreads();                                             // everybody has read the layer input
-        store_hidden(acc, a.bias + layer * HID, wave);
+        store_hidden(acc, a.bias + layer * HID, wave, a.acc_scale[layer]);
         __syncthreads();
     }
 
@@ -318,6 +332,12 @@ __global__ __launch_bounds__(NW * 64, X3 ? 2 : 4) void linf_mlp_kernel(BfsrLinfM
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
             k_loop(acc, wl, NCH_HID, mt, 0, NCH_HID, smem);
+            if constexpr (X3 == 2) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[nt][r] *= a.acc_scale[3];
+            }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const long long qq = q0 + nt * 32 + l31;
@@ -347,7 +367,7 @@ __global__ __launch_bounds__(NW * 64, X3 ? 2 : 4) void linf_mlp_kernel(BfsrLinfM
     }
 }
 
-template <bool X3>
+template <int X3>
 int launch_mlp(const BfsrLinfMlpArgs& a, hipStream_t st)
 {
     constexpr int LDS = 16 * Mode<X3>::PL * 2 * P * 16;              // 98 304 B (x3) / 32 768 B (fp16)
@@ -366,7 +386,7 @@ int launch_mlp(const BfsrLinfMlpArgs& a, hipStream_t st)
 extern "C" long long bfsr_linf_mlp_packed_size(int hidden, int Cout, int x3)
 {
     if (hidden != HID || Cout <= 0) return -1;
-    const long long PL = x3 ? 3 : 1;
+    const long long PL = x3 == 1 ? 3 : (x3 == 2 ? 2 : 1);
     const long long mt4 = (Cout + 31) / 32;
     return ((long long)(HID / 32) * (K1 / KC) + 2LL * (HID / 32) * NCH_HID + mt4 * NCH_HID) * PL * 64 * 8;      // 16-bit elements
 }
@@ -374,16 +394,20 @@ extern "C" long long bfsr_linf_mlp_packed_size(int hidden, int Cout, int x3)
 // w1 [256][1024], w2, w3 [256][256], w4 [Cout][256] (row-major fp32, the nn.Conv2d 1x1 weights of linf.py:231-240) -> the
 // per-lane fragment order of linf_mlp_kernel: [layer][m tile][k chunk][plane][lane = k half*32 + row][8].  Layer 1's K axis is
 // regrouped per neighbour into (cos | sin) halves: chunk kc = k*16 + cb, half 0 -> channel k*256 + cb*8 + e, half 1 -> k*256 + 128 + cb*8 + e.
-extern "C" int bfsr_pack_linf_mlp(const float* w1, const float* w2, const float* w3, const float* w4, int hidden, int Cout, int x3,
-                                  unsigned short* packed)
+static int pack_linf_mlp_impl(const float* w1, const float* w2, const float* w3, const float* w4, int hidden, int Cout, int x3,
+                              const float* scales, unsigned short* packed)
 {
-    if (hidden != HID || Cout <= 0 || !w1 || !w2 || !w3 || !w4 || !packed) return -1;
-    const int PL = x3 ? 3 : 1;
+    if (hidden != HID || Cout <= 0 || !w1 || !w2 || !w3 || !w4 || !packed || x3 < 0 || x3 > 2 || (x3 == 2 && !scales)) return -1;
+    const int PL = x3 == 1 ? 3 : (x3 == 2 ? 2 : 1);
     long long o = 0;
+    float scale = 1.f;
     auto encode = [&](float v, unsigned short (&out)[3]) {
-        if (x3) {
+        if (x3 == 1) {
             float r = v;
             for (int i = 0; i < 3; ++i) { const __bf16 hb = (__bf16)r; __builtin_memcpy(&out[i], &hb, 2); r -= (float)hb; }
+        } else if (x3 == 2) {
+            float r = v * scale;
+            for (int i = 0; i < 2; ++i) { const _Float16 hf = (_Float16)r; __builtin_memcpy(&out[i], &hf, 2); r -= (float)hf; }
         } else {
             const _Float16 hf = (_Float16)v;
             __builtin_memcpy(&out[0], &hf, 2);
@@ -408,11 +432,30 @@ extern "C" int bfsr_pack_linf_mlp(const float* w1, const float* w2, const float*
             }
         o += (long long)mtiles * nchunk * PL * 64 * 8;
     };
+    if (x3 == 2) scale = scales[0];
     pack_layer(w1, HID, K1, true);
+    if (x3 == 2) scale = scales[1];
     pack_layer(w2, HID, HID, false);
+    if (x3 == 2) scale = scales[2];
     pack_layer(w3, HID, HID, false);
+    if (x3 == 2) scale = scales[3];
     pack_layer(w4, Cout, HID, false);
     return 0;
+}
+
+extern "C" int bfsr_pack_linf_mlp(const float* w1, const float* w2, const float* w3, const float* w4, int hidden, int Cout, int x3,
+                                  unsigned short* packed)
+{
+    if (x3 == 2) return -1;                       // the two-term fp16 split needs per-layer scales: bfsr_pack_linf_mlp_f16x2
+    return pack_linf_mlp_impl(w1, w2, w3, w4, hidden, Cout, x3 ? 1 : 0, nullptr, packed);
+}
+
+extern "C" int bfsr_pack_linf_mlp_f16x2(const float* w1, const float* w2, const float* w3, const float* w4, int hidden, int Cout,
+                                        const float* scales4, unsigned short* packed)
+{
+    if (!scales4) return -1;
+    for (int i = 0; i < 4; ++i) if (!(scales4[i] > 0.f)) return -1;
+    return pack_linf_mlp_impl(w1, w2, w3, w4, hidden, Cout, 2, scales4, packed);
 }
 
 extern "C" int bfsr_linf_mlp(const BfsrLinfMlpArgs* a, int x3, void* stream)
@@ -424,5 +467,9 @@ extern "C" int bfsr_linf_mlp(const BfsrLinfMlpArgs* a, int x3, void* stream)
     if (a->out_fmt == 1 && ((a->Cout & 3) || (reinterpret_cast<unsigned long long>(a->out) & 15) || (a->out_bs & 3) ||
                             (reinterpret_cast<unsigned long long>(a->bias) & 15))) return -1;
     BfsrLinfMlpArgs c = *a;
-    return x3 ? launch_mlp<true>(c, st) : launch_mlp<false>(c, st);
+    if (x3 == 2) {
+        for (int i = 0; i < 4; ++i) if (!(c.acc_scale[i] > 0.f)) return -1;
+        return launch_mlp<2>(c, st);
+    }
+    return x3 ? launch_mlp<1>(c, st) : launch_mlp<0>(c, st);
 }

@@ -819,20 +819,35 @@ class HipOps(object):
                 b4[i * blk: i * blk + 2 * D] = bs[3][2 * D * i: 2 * D * (i + 1)]
             w[3], bs = w4.contiguous(), bs[:3] + [b4]
         hidden, Cout = w[1].shape[0], w[3].shape[0]
-        n = self.lib.bfsr_linf_mlp_packed_size(hidden, Cout, int(x3))
+        mode = (2 if self.split == "f16x2" else 1) if x3 else 0         # the fp32-accurate mode follows BFSR_SPLIT
+        n = self.lib.bfsr_linf_mlp_packed_size(hidden, Cout, mode)
         if n <= 0 or w[0].shape != (hidden, 4 * hidden) or w[2].shape != (hidden, hidden) or w[3].shape[1] != hidden:
             raise ValueError("pack_linf_mlp: unsupported MLP shape (hidden must be 256)")
         packed = torch.empty(n, dtype=torch.int16)
-        _lib.check(self.lib.bfsr_pack_linf_mlp(w[0].data_ptr(), w[1].data_ptr(), w[2].data_ptr(), w[3].data_ptr(), hidden, Cout, int(x3),
-                                               packed.data_ptr()), "pack_linf_mlp")
+        scales = None
+        if mode == 2:
+            scales = [self.pow2_scale(t) for t in w]
+            sc = (C.c_float * 4)(*scales)
+            _lib.check(self.lib.bfsr_pack_linf_mlp_f16x2(w[0].data_ptr(), w[1].data_ptr(), w[2].data_ptr(), w[3].data_ptr(), hidden, Cout,
+                                                         C.cast(sc, C.c_void_p), packed.data_ptr()), "pack_linf_mlp_f16x2")
+        else:
+            _lib.check(self.lib.bfsr_pack_linf_mlp(w[0].data_ptr(), w[1].data_ptr(), w[2].data_ptr(), w[3].data_ptr(), hidden, Cout, mode,
+                                                   packed.data_ptr()), "pack_linf_mlp")
         bias = torch.cat(bs)
-        return packed.to(self.device), bias.to(self.device), Cout, (1 if quad_layers is not None else 0)
+        fmt = 1 if quad_layers is not None else 0
+        return packed.to(self.device), bias.to(self.device), Cout, (fmt if scales is None else (fmt, tuple(scales)))
 
     def linf_mlp(self, cf, coord, cell, phase, packed, out, hidden, x3=True):
         """fused Fourier features + shared MLP: cf [B,2*hidden,h,w], coord [B,qh,qw,2], cell [B,2] -> out = affine_info [B,Cout,qh,qw]
         (the same buffer in the quad-major layout when the weights were packed with quad_layers)."""
         wts, bias, Cout, fmt = packed
         a = _lib.BfsrLinfMlpArgs()
+        mode = 1 if x3 else 0
+        if isinstance(fmt, tuple):                                       # two-term fp16 split: (layout, per-layer weight scales)
+            fmt, scales = fmt
+            mode = 2
+            for i in range(4):
+                a.acc_scale[i] = 1.0 / scales[i]
         a.out_fmt = fmt
         a.cf, a.cf_bs, c2, h, w = _view(cf, "linf_mlp.cf")
         a.out, a.out_bs, co, qh, qw = _view(out, "linf_mlp.out")
@@ -846,8 +861,8 @@ class HipOps(object):
         a.cy0, a.cy1, a.cx0, a.cx1 = -1 + 1.0 / h, 2 * (1.0 / h), -1 + 1.0 / w, 2 * (1.0 / w)
         if fmt and (out.data_ptr() & 15 or a.out_bs & 3):
             raise ValueError("linf_mlp: the quad-major output needs a 16-byte aligned buffer")
-        key = ("linf_mlp_x3" if x3 else "linf_mlp_f16", hidden, Cout, cf.shape[0], qh, qw)
-        _lib.check(self._launch(key, lambda: self.lib.bfsr_linf_mlp(C.byref(a), int(x3), self._stream())), "linf_mlp")
+        key = (("linf_mlp_f2" if mode == 2 else "linf_mlp_x3") if x3 else "linf_mlp_f16", hidden, Cout, cf.shape[0], qh, qw)
+        _lib.check(self._launch(key, lambda: self.lib.bfsr_linf_mlp(C.byref(a), mode, self._stream())), "linf_mlp")
         return out
 
     def logscale_sum(self, h, acc, coef=1.0, eps=1e-4):

@@ -359,11 +359,16 @@ typedef struct BfsrLinfMlpArgs {
     int out_fmt;                   /* 0: out [B,Cout,qh,qw].  1: quad-major [B][Cout/4][qh*qw][4] (Cout % 4 == 0): the lane that holds
                                     * four consecutive output rows of a query point stores them as ONE 16-byte word (4x fewer store
                                     * instructions, full 64-byte sectors); read by bfsr_linf_flow with ai_fmt = 1 */
+    float acc_scale[4];            /* x3 == 2 only: 1 / (the power of two layer i's weights were packed with, bfsr_pack_linf_mlp_f16x2) */
 } BfsrLinfMlpArgs;
+/* x3: 0 = operands rounded to fp16 (LINF precision='fp16'); 1 = exact three-term bf16 split, six products; 2 = two-term fp16 split of
+ * both operands, three products (fp32-class accuracy at half the matrix instructions of 1; weights from bfsr_pack_linf_mlp_f16x2) */
 int bfsr_linf_mlp(const BfsrLinfMlpArgs* a, int x3, void* stream);
 long long bfsr_linf_mlp_packed_size(int hidden, int Cout, int x3);          /* in 16-bit elements */
 int bfsr_pack_linf_mlp(const float* w1, const float* w2, const float* w3, const float* w4, int hidden, int Cout, int x3,
                        unsigned short* packed);
+int bfsr_pack_linf_mlp_f16x2(const float* w1, const float* w2, const float* w3, const float* w4, int hidden, int Cout,
+                             const float* scales4, unsigned short* packed);   /* size: bfsr_linf_mlp_packed_size(hidden, Cout, 2) */
 
 /* local implicit coupling flow (LINF-LP/models/flow.py:44-63) over D = 3*ps*ps vectors on the query grid:
  * x,y [B,D,qh,qw]; ai = affine_info [B, 2*D*layers, qh, qw]; lin_w [layers+1][D][D] holds W (forward) or

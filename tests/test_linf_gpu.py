@@ -53,12 +53,22 @@ def test_linf_features(hip, hw, q):
 
 
 @pytest.mark.parametrize("hw,q", [((8, 12), (21, 33)), ((16, 16), (22, 22)), ((5, 7), (30, 9)), ((24, 20), (65, 55))])
-@pytest.mark.parametrize("x3", [True, False])
+@pytest.mark.parametrize("x3", [True, False, "bf16x3"])
 def test_linf_mlp_fused(hip, hw, q, x3):
     """The fused conditioning kernel (linf_mlp.hip: Fourier features -> 1024-256-256-256-540 MLP) against the unfused semantics
     (features + 1x1 convs): fp32-accurate in the 3xBF16 mode; in fp16 mode against the same chain with every layer's operands
     rounded to fp16.  Tiles of 64 query points: sizes with ragged last tiles and several tiles per image."""
     import oracle.linf_ref as O
+    split0 = hip.split
+    if x3 == "bf16x3":                                                  # the fp32-accurate mode under the other split (default: f16x2)
+        hip.split, x3 = "bf16x3", True
+    try:
+        _linf_mlp_fused_body(hip, O, hw, q, x3)
+    finally:
+        hip.split = split0
+
+
+def _linf_mlp_fused_body(hip, O, hw, q, x3):
     h, w = hw
     qh, qw = q
     B, HD, Cout = 2, 256, 540

@@ -24,5 +24,7 @@ if [ -f $R/tools/exp/libabl.so ]; then
   (cd $R && TUNES="0 -3 -11 -4" timeout 600 bash tools/exp/h2s_abl.sh > $OUT/${TAG}_d_h2s_ablation.txt 2>&1)
 fi
 (cd $R && timeout 300 python tools/exp/h2s_bench.py 2>&1 | grep -v amdgpu > $OUT/${TAG}_d_h2s_bench.txt)
+(cd $R && timeout 300 python tools/exp/h2x_bench.py 2>&1 | grep -v amdgpu > $OUT/${TAG}_e_h2x_vs_x3s.txt)
+(cd $R && BFSR_SPLIT=bf16x3 timeout 600 python bench.py --config 2 --steps 5 --warmup 2 --no-cpu-baseline --no-fp32-line > $OUT/${TAG}_cfg2_bench_bf16x3.json 2>/dev/null)
 find $OUT -name "*.csv" -size +3M -delete
 ls -la $OUT | head -40; tail -3 $OUT/pmc_traffic.err

@@ -52,6 +52,7 @@ FAMILIES = {
     "conv_f16x2": ("conv_bf16x3_kernel<PL=2>", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split (22-bit operands, power-of-two weight scale), 3 products on v_mfma_f32_32x32x16_f16"),
     "conv_h2x": ("conv3x3_h2x_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split, 3 products on v_mfma_f32_32x32x16_f16, h2-tensor input by LDS-DMA"),
     "conv_up2_f2": ("conv_up2_bf16x3_kernel<PL=2>", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split, parity-decomposed conv over nearest-x2 input"),
+    "conv_up2_h2x": ("conv_up2_h2x_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split, parity-decomposed conv over nearest-x2 input, h2 taps by LDS-DMA"),
     "conv_up4_f2": ("conv_up4_bf16x3_kernel<PL=2>", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split, phase-decomposed conv over nearest-x4 input"),
     "conv_f16": ("conv_f16_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, "fp16 MFMA (v_mfma_f32_32x32x16_f16), fp32 accumulate"),
     "conv_h2s": ("conv3x3_h2s_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, "fp16 MFMA, fp16-stored (h2) input by LDS-DMA, fp32 accumulate"),
@@ -101,7 +102,7 @@ def launch_flop(k):
     if f in ("conv1x1_f16", "conv1x1_x3"):
         _, Cin, Cout, b_, hh, ww = k
         return 2.0 * Cin * Cout * b_ * hh * ww
-    if f in ("conv_up2", "conv_up2_x3", "conv_up2_f2"):               # 2x2 source taps per output pixel (parity pre-summed weights)
+    if f in ("conv_up2", "conv_up2_x3", "conv_up2_f2", "conv_up2_h2x"):               # 2x2 source taps per output pixel (parity pre-summed weights)
         _, _, Cin, Cout, b_, hh, ww, cin2 = k          # + cin2 key channels at output resolution (9 taps)
         return 2.0 * (Cin * 4 + cin2 * 9) * Cout * b_ * hh * ww
     if f in ("conv_up4_x3", "conv_up4_f2"):                             # 25 pre-summed matrices per 16 output pixels
@@ -132,7 +133,7 @@ def roof_entry(t, k, f, n, steps, step_ms, traffic_db):
 def load_traffic():
     """per-launch HBM-side bytes from the committed PMC passes of this round (separate --pmc runs, profiles/), keyed by launch shape"""
     db = {}
-    for name in ("r02_pmc_traffic.json",):
+    for name in ("r02_pmc_traffic.json", "r03_pmc_traffic.json", "r03f_pmc_traffic.json", "r03f_pmc_traffic_cfg3.json"):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             db.update(json.load(open(p)).get("kernels", {}))

@@ -893,7 +893,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
     const float slope = p.act == BFSR_ACT_NONE ? 1.f : (p.act == BFSR_ACT_RELU ? 0.f : p.slope);
     const float4* __restrict__ epi = reinterpret_cast<const float4*>(p.epi);
     const long long HW = (long long)H * W;
-    int buf = 0;
+    int buf = 0;                                                         // LDS stage of the next chunk
     for (int it = slot; it < nitems; it += G) {
         const Item cur = decode(it);
         float4 pm;
@@ -908,24 +908,39 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-        for (int k = 0; k < nchunk; ++k) {
-            __builtin_amdgcn_s_barrier();                                // chunk k has landed in stage `buf`; stage buf^1 is free again
-            load_step(I0(), buf, 0);
+        // One barrier per chunk, passed EARLY: chunk k+1's barrier sits before the last tap of chunk k (whose fragments are already in
+        // registers), so the first fragments of chunk k+1 are in flight under that tap's MFMAs and the loaders may refill stage `buf`
+        // one tap earlier.  Nine taps per chunk flip the fragment-buffer parity from chunk to chunk: chunks are processed in pairs.
+        auto chunk_body = [&](auto p_, auto q_, bool last) {               // p_: buffer holding tap 0's fragments (already loaded)
 #pragma unroll
-            for (int t = 0; t < 9; t += 2) {
-                if (t + 1 < 9) load_step(I1(), buf, t + 1);
+            for (int t = 0; t < 8; t += 2) {
+                load_step(q_, buf, t + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                mfma_step(I0());
+                mfma_step(p_);
                 __builtin_amdgcn_sched_barrier(0);
-                if (t + 1 < 9) {
-                    if (t + 2 < 9) load_step(I0(), buf, t + 2);
-                    __builtin_amdgcn_sched_barrier(0);
-                    mfma_step(I1());
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                load_step(p_, buf, t + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_step(q_);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if (!last) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // tap 8's fragments have left stage `buf`
+                __builtin_amdgcn_s_barrier();                            // chunk k+1 has landed in stage buf^1; stage buf is free again
+                load_step(q_, buf ^ 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(p_);
+            __builtin_amdgcn_sched_barrier(0);
             buf ^= 1;
+        };
+        __builtin_amdgcn_s_barrier();                                    // the item's first chunk has landed in stage `buf`
+        load_step(I0(), buf, 0);
+        int k = 0;
+        for (; k + 2 <= nchunk; k += 2) {                                // pairs of chunks: the parity is static inside a pair
+            chunk_body(I0(), I1(), false);
+            chunk_body(I1(), I0(), k + 2 == nchunk);
         }
+        if (k < nchunk) chunk_body(I0(), I1(), true);
 
         // ---- epilogue (the loaders are already staging the next item): as in conv3x3_h2s_kernel, plus the weight scale
         const bool plain = (lane & 1) ? pm.x == 1.f : (pm.y == 0.f && pm.z == 1.f && pm.w == 0.f);
@@ -1043,6 +1058,193 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+    }
+}
+
+// =====================================================================================================================
+// conv_up2_h2x_kernel -- the 3x3 conv over nearest_up2(taps) (parity-pre-summed 2x2 matrices, conv_bf16x3.hip / DESIGN.md section
+// 3.5) with the taps as an h2 tensor at SOURCE resolution: same fp16-pair arithmetic, LDS-DMA staging and persistent structure as
+// conv3x3_h2x_kernel.  x [B,Cin,H/2,W/2] (h2) -> y [B,Cout,H,W] (fp32 NCHW, BfsrConvArgs epilogue incl. pre_add: the key channels'
+// partial sums).  An item = (source tile 16 rows x 32 px, 32 output channels, output ROW parity pa): 8 of the 16 matrices, one
+// pipeline step each (step s: column parity bq = s>>2, source offsets i = s&1, j = (s>>1)&1 -> column offset d = bq + j; the packer
+// stores the matrices in step order), accumulators acc[column parity][wave row] = 4 blocks.  Stage = the h2x input tile (18 x 34
+// positions, both planes) + 8 matrices x 2 planes = 40 960 + 16 384 B, two stages.  Why: the register-staged taps kernel became
+// staging-bound once the split needed three instead of six products (0.32 of the fp16 peak, profiles/r03f_cfg2_bench.json).
+constexpr int U_W = 2 * 8 * 1024;               // 16 384: [plane][step][k half][32][8]
+constexpr int U_STAGE = X_IN + U_W;             // 57 344
+constexpr int U_LDS = 2 * U_STAGE;              // 114 688
+
+__global__ __launch_bounds__((NW + NLW) * 64, 1) void conv_up2_h2x_kernel(BfsrConvArgs p, int tiles_x, int tiles_y, int groups, int nitems)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int G = gridDim.x;
+    const int slot = (int)bfsr::xcd_order(blockIdx.x, (unsigned)G);
+    if (slot >= nitems) return;
+    const int H = p.H, W = p.W, Hs = H >> 1, Ws = W >> 1;                // output / source resolution
+    const unsigned HW16 = (unsigned)(Hs * Ws) * 16u;                     // bytes of one (octet, plane) source image
+    const int nchunk = p.Cin >> 4;
+    struct UItem { int pa, cg, b, x0, y0; };
+    auto decode = [&](int it) {
+        UItem r;
+        r.pa = it & 1; it >>= 1;
+        r.cg = it % groups; int t = it / groups;
+        const int ty = t % tiles_y; t /= tiles_y;
+        r.x0 = (t % tiles_x) * 32; r.y0 = ty * TH; r.b = t / tiles_x;
+        return r;
+    };
+    const unsigned short* xh = reinterpret_cast<const unsigned short*>(p.x);
+
+    if (wave >= NW) {
+        // ---- loader waves (LDS-DMA only): loader ld = sub-image (plane ld>>1, k half ld&1) of every position group + weight pieces
+        const int ld = wave - NW;
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0,
+                                                                              (unsigned)((long long)groups * nchunk * 2 * U_W), 0x00020000);
+        __amdgpu_buffer_rsrc_t rs_in;
+        unsigned vg[NG];
+        int cg_ = 0, pa_ = 0;
+        auto lsetup = [&](const UItem& it) {
+            const unsigned short* xb = xh + (long long)it.b * p.x_bs;
+            rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xb), 0, (unsigned)(p.Cin >> 3) * 2u * HW16, 0x00020000);
+            cg_ = it.cg; pa_ = it.pa;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int pos = g * 64 + lane;
+                const int r = pos / PW, c = pos - r * PW;
+                const int gy = it.y0 + r - 1, gx = it.x0 + c - 1;
+                const bool ok = pos < NPOS && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
+                vg[g] = ok ? (unsigned)(gy * Ws + gx) * 16u : OOB;       // out of range -> zeros: the zero padding of the UPSAMPLED image
+            }
+        };
+        auto lstage = [&](int k, int buf) {
+            unsigned char* base = smem + buf * U_STAGE;
+            const unsigned soff = (unsigned)((2 * k + (ld & 1)) * 2 + (ld >> 1)) * HW16;
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(base + ld * SUB + g * 1024), 16, vg[g], soff, 0, 0);
+            const unsigned wsoff = (unsigned)((cg_ * nchunk + k) * 2 + pa_) * (unsigned)U_W;
+#pragma unroll
+            for (int j = 0; j < U_W / 1024 / NLW; ++j) {
+                const int piece = ld + j * NLW;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(base + X_IN + piece * 1024), 16,
+                                                         (unsigned)lane * 16u + (unsigned)piece * 1024u, wsoff, 0, 0);
+            }
+        };
+        int it = slot;
+        lsetup(decode(it));
+        lstage(0, 0);
+        int buf_ = 0;
+        while (true) {
+            const int nxt = it + G;
+            const bool has_next = nxt < nitems;
+            for (int k = 0; k < nchunk; ++k) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (k + 1 < nchunk) lstage(k + 1, buf_ ^ 1);
+                else if (has_next) { lsetup(decode(nxt)); lstage(0, buf_ ^ 1); }
+                buf_ ^= 1;
+            }
+            if (!has_next) return;
+            it = nxt;
+        }
+    }
+
+    // ---- compute waves: wave w owns source rows 2w, 2w+1 of the tile (output rows 2*(y0+2w+n) + pa)
+    half8 bq[2][2][2], aq[2][2];                                         // [buffer][plane][row] | [buffer][plane]
+    int pa = 0;
+    auto load_step = [&](auto buf_, int st, int s_) {
+        constexpr int BUF = decltype(buf_)::value;
+        const int i = s_ & 1, j = (s_ >> 1) & 1, d = (s_ >> 2) + j;
+        const unsigned char* sIn = smem + st * U_STAGE;
+        const unsigned char* inB = sIn + (lhi * NPOSP + (2 * wave + pa + i) * PW + l31 + d) * 16;       // staged row r = source row y0-1+r
+        const unsigned char* wA = sIn + X_IN + lane * 16 + s_ * 1024;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) bq[BUF][pl][r] = *reinterpret_cast<const half8*>(inB + pl * 2 * SUB + r * PW * 16);
+            aq[BUF][pl] = *reinterpret_cast<const half8*>(wA + pl * (8 * 1024));
+        }
+    };
+    f32x16 acc[2][2];                                                    // [column parity][row]
+    auto mfma_step = [&](auto buf_, auto cb_) {
+        constexpr int BUF = decltype(buf_)::value, CB = decltype(cb_)::value;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {                                    // smallest terms first: w_lo*x_hi, w_hi*x_lo, w_hi*x_hi
+            acc[CB][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][1], bq[BUF][0][n], acc[CB][n], 0, 0, 0);
+            acc[CB][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][0], bq[BUF][1][n], acc[CB][n], 0, 0, 0);
+            acc[CB][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][0], bq[BUF][0][n], acc[CB][n], 0, 0, 0);
+        }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    const float slope = p.act == BFSR_ACT_NONE ? 1.f : (p.act == BFSR_ACT_RELU ? 0.f : p.slope);
+    const float4* __restrict__ epi = reinterpret_cast<const float4*>(p.epi);
+    const long long HW = (long long)H * W;
+    int buf = 0;
+    for (int it = slot; it < nitems; it += G) {
+        const UItem cur = decode(it);
+        pa = cur.pa;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][n][r] = 0.f;
+        __builtin_amdgcn_s_barrier();                                    // the item's first chunk has landed in stage `buf`
+        load_step(I0(), buf, 0);
+        for (int k = 0; k < nchunk; ++k) {
+            const bool last = k + 1 == nchunk;
+            // eight steps, fragment buffers alternate; the barrier of chunk k+1 is passed before the last step (see conv3x3_h2x_kernel)
+            load_step(I1(), buf, 1); __builtin_amdgcn_sched_barrier(0); mfma_step(I0(), I0()); __builtin_amdgcn_sched_barrier(0);   // s = 0
+            load_step(I0(), buf, 2); __builtin_amdgcn_sched_barrier(0); mfma_step(I1(), I0()); __builtin_amdgcn_sched_barrier(0);   // s = 1
+            load_step(I1(), buf, 3); __builtin_amdgcn_sched_barrier(0); mfma_step(I0(), I0()); __builtin_amdgcn_sched_barrier(0);   // s = 2
+            load_step(I0(), buf, 4); __builtin_amdgcn_sched_barrier(0); mfma_step(I1(), I0()); __builtin_amdgcn_sched_barrier(0);   // s = 3
+            load_step(I1(), buf, 5); __builtin_amdgcn_sched_barrier(0); mfma_step(I0(), I1()); __builtin_amdgcn_sched_barrier(0);   // s = 4
+            load_step(I0(), buf, 6); __builtin_amdgcn_sched_barrier(0); mfma_step(I1(), I1()); __builtin_amdgcn_sched_barrier(0);   // s = 5
+            load_step(I1(), buf, 7); __builtin_amdgcn_sched_barrier(0); mfma_step(I0(), I1()); __builtin_amdgcn_sched_barrier(0);   // s = 6
+            if (!last) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // step 7's fragments have left stage `buf`
+                __builtin_amdgcn_s_barrier();
+                load_step(I0(), buf ^ 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(I1(), I1());                                       // s = 7
+            __builtin_amdgcn_sched_barrier(0);
+            buf ^= 1;
+        }
+
+        // ---- epilogue: lane = source column -> two adjacent output pixels (float2), stage order of conv_up2_bf16x3_kernel
+        int lx = l31, lh = lhi;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(lx), "+v"(lh));
+#endif
+        const int sx = cur.x0 + lx;
+        const float* pre = p.pre_add ? p.pre_add + (long long)cur.b * p.pre_add_bs : nullptr;
+        float* yb = p.y + (long long)cur.b * p.y_bs;
+        if (sx < Ws) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cur.cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co >= p.Cout) continue;
+                float4 q0 = make_float4(0.f, 0.f, 1.f, 0.f); float q1 = 1.f;
+                if (epi) { q0 = epi[co * 2]; q1 = epi[co * 2 + 1].x; }
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int sy = cur.y0 + 2 * wave + n;
+                    if (sy >= Hs) continue;
+                    const long long o = (long long)co * HW + (long long)(2 * sy + cur.pa) * W + 2 * sx;
+                    float2 v = make_float2(acc[0][n][r] * p.acc_scale, acc[1][n][r] * p.acc_scale);
+                    v.x += q0.x; v.y += q0.x;
+                    if (pre) { const float2 t = *reinterpret_cast<const float2*>(pre + o); v.x += t.x; v.y += t.y; }
+                    v.x = (v.x + q0.y) * q0.z + q0.w; v.y = (v.y + q0.y) * q0.z + q0.w;
+                    v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+                    v.x *= q1; v.y *= q1;
+                    *reinterpret_cast<float2*>(yb + o) = v;
+                }
+            }
+        }
     }
 }
 
@@ -1218,6 +1420,63 @@ extern "C" int bfsr_conv3x3_h2x(const BfsrConvX3Args* a, void* stream)
     static std::atomic<unsigned long long> lds_done{0};
     if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2x_kernel), X_LDS, lds_done) != 0) return -1;
     hipLaunchKernelGGL(conv3x3_h2x_kernel, dim3((unsigned)grid), dim3((NW + NLW) * 64), X_LDS, st, *a, tiles_x, tiles_y, groups, (int)nitems);
+    return (int)hipGetLastError();
+}
+
+extern "C" long long bfsr_conv_packed_size_up2_h2x(int Cout, int Cin)
+{
+    if (Cout <= 0 || Cin <= 0 || (Cin & 15)) return -1;
+    return (long long)((Cout + 31) / 32) * (Cin / 16) * 2 * 2 * 8 * 2 * 32 * 8;       // fp16 elements: [group][chunk][pa][plane][step][k half][32][8]
+}
+
+extern "C" int bfsr_pack_conv_weight_up2_h2x(const float* w16, int Cout, int Cin, float scale, unsigned short* packed)
+{
+    // w16 [Cout][Cin][16] = the parity-pre-summed matrices of bfsr_pack_conv_weight_taps (t = (a*2+b)*4 + i*2 + j) -> two-term fp16
+    // split of w*scale in the kernel's step order: step s of row parity a = matrix (a, b = s>>2, i = s&1, j = (s>>1)&1)
+    if (!w16 || !packed || Cout <= 0 || Cin <= 0 || (Cin & 15) || !(scale > 0.f)) return -1;
+    const int nchunk = Cin / 16;
+    const long long n = bfsr_conv_packed_size_up2_h2x(Cout, Cin);
+    for (long long i = 0; i < n; ++i) packed[i] = 0;
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int a = 0; a < 2; ++a)
+                for (int s_ = 0; s_ < 8; ++s_) {
+                    const int b = s_ >> 2, i = s_ & 1, j = (s_ >> 1) & 1;
+                    float r = w16[((long long)co * Cin + ci) * 16 + (a * 2 + b) * 4 + i * 2 + j] * scale;
+                    for (int pl = 0; pl < 2; ++pl) {
+                        const _Float16 h = (_Float16)r;
+                        const long long slab = (((long long)(co / 32) * nchunk + ci / 16) * 2 + a) * 2 + pl;
+                        packed[((slab * 8 + s_) * 2 + (ci % 16) / 8) * 256 + (co % 32) * 8 + ci % 8] = f32_to_f16_bits((float)h);
+                        r -= (float)h;
+                    }
+                }
+    return 0;
+}
+
+extern "C" int bfsr_conv2d_up2_h2x(const BfsrConvArgs* a, void* stream)
+{
+    // a->x: h2 tensor of the taps at source resolution [B][Cin/8][2][H/2][W/2][8] fp16 (x_bs in fp16 elements); a->w: bfsr_pack_conv_weight_up2_h2x
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!a || !a->x || !a->w || !a->y || a->w2 || a->x2 || a->res1 || a->res2) return -1;
+    if (a->B <= 0 || a->H <= 0 || a->W <= 0 || (a->H & 1) || (a->W & 1) || a->Cin <= 0 || (a->Cin & 15) || a->Cout <= 0 || a->KS != 3) return -1;
+    if (!(a->acc_scale > 0.f)) return -1;
+    const int Hs = a->H / 2, Ws = a->W / 2;
+    if ((long long)(a->Cin / 8) * 2 * Hs * Ws * 16 >= (1LL << 31)) return -1;
+    if ((reinterpret_cast<unsigned long long>(a->x) & 15) || (a->x_bs & 7)) return -1;
+    if ((reinterpret_cast<unsigned long long>(a->y) & 7) || (a->y_bs & 1)) return -1;                    // float2 stores
+    if (a->pre_add && ((reinterpret_cast<unsigned long long>(a->pre_add) & 7) || (a->pre_add_bs & 1))) return -1;
+    const int tiles_x = (Ws + 31) / 32, tiles_y = (Hs + TH - 1) / TH;
+    const int groups = (a->Cout + 31) / 32;
+    const long long nitems = 2LL * tiles_x * tiles_y * groups * a->B;
+    if (nitems > 0x7fffffffLL) return -1;
+    if (bfsr_conv_packed_size_up2_h2x(a->Cout, a->Cin) * 2 >= (1LL << 32)) return -1;
+    int cus = bfsr::cu_count();
+    if (cus <= 0) return -1;
+    if (a->tune > 0) cus = a->tune;
+    const long long grid = nitems < cus ? nitems : cus;
+    static std::atomic<unsigned long long> lds_done{0};
+    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_up2_h2x_kernel), U_LDS, lds_done) != 0) return -1;
+    hipLaunchKernelGGL(conv_up2_h2x_kernel, dim3((unsigned)grid), dim3((NW + NLW) * 64), U_LDS, st, *a, tiles_x, tiles_y, groups, (int)nitems);
     return (int)hipGetLastError();
 }
 

@@ -482,6 +482,19 @@ class SRFlowEngine(object):
                 self._ftx3 = {}
             if level not in self._ftx3 or self._ftx3[level][0] != key:
                 self._ftx3[level] = (key, self.ops.x3_empty(B, cx, hl, wl))
+        # BFSR_TAPS=h2x: h2 copy of the taps for the LDS-DMA taps kernel (conv_up2_h2x).  Measured EQUAL to the register-staged kernel
+        # (83.2 vs 83.1 ms per cfg2 step, 6.7 ms per launch either way: an item = 32 output channels x one row parity re-stages the
+        # 256-channel tile 64 times and reads / writes 6.7 GB of pre_add / output behind its K loop), so the default stays "reg".
+        if (hz.get("up2") and hz.get("x3") and hz.get("up") == 1 and getattr(self.ops, "split", "") == "f16x2"
+                and hasattr(self.ops, "conv_up2_h2x") and os.environ.get("BFSR_TAPS", "reg") == "h2x"):
+            tl = ft[self._lr_level()]
+            ct = tl.shape[1] - 64
+            if ct > 0 and ct % 16 == 0:
+                key = (B, ct, tl.shape[2], tl.shape[3])
+                if getattr(self, "_tapsx", None) is None:
+                    self._tapsx = {}
+                if level not in self._tapsx or self._tapsx[level][0] != key:
+                    self._tapsx[level] = (key, self.ops.h2_empty(*key))
         return (ws.get("hoist_hid%d" % level, B, K * 64, hl, wl), ws.get("pre_aff%d" % level, B, K * 64, hl, wl),
                 ws.get("h_ft%d" % level, B, K * 2 * Cz, hl, wl), Cz)
 
@@ -498,6 +511,10 @@ class SRFlowEngine(object):
                     ops.conv_x3s(f3, hz["ft0_key"], hid)
                 else:
                     ops.conv_x3(f, hz["ft0_key"], hid)
+                tx = getattr(self, "_tapsx", None)
+                if tx is not None and level in tx and tuple(tx[level][0]) == (B, taps.shape[1], taps.shape[2], taps.shape[3]):
+                    taps_h = ops.h2_pack(taps, tx[level][1])               # both launches read the h2 copy by LDS-DMA
+                    up = lambda _t, pw, out, **kw: ops.conv_up2_h2x(taps_h, pw, out, **kw)
                 up(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, pre_add=hid)
                 if hz["x3s"]:
                     ops.conv_x3s(f3, hz["aff0_key"], pre_aff)

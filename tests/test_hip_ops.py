@@ -678,6 +678,36 @@ def test_conv_up2_bf16x3_with_key_channels(hips, case, tune):
     close(out, o32.cpu(), 1e-5, "conv_up2_x3 %s" % (case,))
 
 
+@pytest.mark.parametrize("case", [(2, 64, 64, 64, 9, 21), (1, 256, 64, 128, 12, 40), (1, 48, 16, 96, 33, 50), (3, 32, 8, 40, 16, 32), (1, 16, 0, 24, 37, 70)])
+@pytest.mark.parametrize("tune", [0, 3])
+def test_conv_up2_h2x_with_key_channels(hip, case, tune):
+    """The taps kernel over h2 taps (LDS-DMA, persistent: conv_up2_h2x_kernel) == the conv over cat[key, nearest_up2(taps)] at fp32
+    accuracy, with the key channels' partial sums arriving as pre_add (aliasing the output), ragged tiles, several items per workgroup."""
+    B, Ct, Ck, Cout, h, w_ = case
+    taps = rnd(180, B, Ct, h, w_)
+    w = rnd(182, Cout, Ck + Ct, 3, 3, scale=1.0 / np.sqrt((Ck + Ct) * 9))
+    sh, sc = rnd(183, Cout, scale=0.2), torch.exp(rnd(184, Cout, scale=0.2))
+    wk, wt = w[:, :Ck].contiguous(), w[:, Ck:].contiguous()
+    th = hip.h2_pack(hip.to_device(taps), hip.h2_empty(B, Ct, h, w_))
+    t22 = hip.h2_unpack(th, hip.empty(B, Ct, h, w_)).cpu()                 # the 22-bit taps the kernel contracts
+    up = torch.nn.functional.interpolate(t22, scale_factor=2, mode="nearest")
+    out = hip.empty(B, Cout, 2 * h, 2 * w_)
+    if Ck:
+        key = rnd(181, B, Ck, 2 * h, 2 * w_)
+        hip.conv_x3(hip.to_device(key), hip.pack_conv_x3(wk, 2), out)
+        xin = torch.cat([key, up], 1)
+    else:
+        xin = up
+    truth = torch.relu((torch.nn.functional.conv2d(xin.double(), w.double(), padding=1) + sh.double().view(1, -1, 1, 1)) * sc.double().view(1, -1, 1, 1))
+    hip.conv_up2_h2x(th, hip.pack_conv_up2_x3(wt), out, epi=hip.pack_epilogue(Cout, aff_shift=sh, aff_scale=sc), act=1,
+                     pre_add=out if Ck else None, tune=tune)
+    ref32 = torch.relu((torch.nn.functional.conv2d(xin, w, padding=1) + sh.view(1, -1, 1, 1)) * sc.view(1, -1, 1, 1))
+    ex = (out.cpu().double() - truth).abs().max().item()
+    e32 = (ref32.double() - truth).abs().max().item()
+    assert ex <= 4.0 * e32 + 1e-7, (ex, e32)
+    close(out, ref32, 1e-5, "conv_up2_h2x %s" % (case,))
+
+
 def test_likelihood_reductions(hip):
     """bfsr_logscale_sum / bfsr_gaussian_logp: per-sample float64 sums == torch float64 reference, coef and accumulation."""
     h = rnd(190, 3, 24, 37, 53)

@@ -10,7 +10,7 @@ import glob
 import json
 import sys
 
-LIB = ("conv_", "conv3x3_x3s", "conv3x3_h2s", "conv2d_direct", "x3_pack", "x3_unpack", "h2_pack", "h2_unpack", "coupling_", "flow_pointwise", "squeeze2d", "unsqueeze2d", "split2d",
+LIB = ("conv_", "conv3x3_x3s", "conv3x3_h2s", "conv3x3_h2x", "conv2d_direct", "x3_pack", "x3_unpack", "h2_pack", "h2_unpack", "coupling_", "flow_pointwise", "squeeze2d", "unsqueeze2d", "split2d",
        "standardize", "resize_kernel", "maxpool2", "axpb_clamp", "linf_", "patch_", "grid_sample", "conv1x1", "gaussian_logp", "logscale_sum",
        "resample_taps", "sqdiff_sum", "ssim_sum", "to_uint8")
 # FETCH_SIZE on gfx950 counts 64 B per 128-B request (MI355X_MICROARCH.md, HBM; documented there for 16-B-per-lane streaming reads).

@@ -14,6 +14,9 @@ B1="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-fp32-line"
 BFSR_OVERLAP=0 BFSR_KEYLOG=$OUT/keys_fetch.json timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B1 > /dev/null 2> $OUT/pmc_fetch.err
 BFSR_OVERLAP=0 BFSR_KEYLOG=$OUT/keys_write.json timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B1 > /dev/null 2> $OUT/pmc_write.err
 python $R/tools/pmc_traffic.py $OUT/pmc_fetch $OUT/keys_fetch.json $OUT/pmc_write $OUT/keys_write.json > $OUT/${TAG}_pmc_traffic.json 2> $OUT/pmc_traffic.err
+BFSR_KEYLOG=$OUT/keys_fetch3.json timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch3 -- $B1 --config 3 > /dev/null 2> $OUT/pmc_fetch3.err
+BFSR_KEYLOG=$OUT/keys_write3.json timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write3 -- $B1 --config 3 > /dev/null 2> $OUT/pmc_write3.err
+python $R/tools/pmc_traffic.py $OUT/pmc_fetch3 $OUT/keys_fetch3.json $OUT/pmc_write3 $OUT/keys_write3.json > $OUT/${TAG}_pmc_traffic_cfg3.json 2> $OUT/pmc_traffic3.err
 BFSR_OVERLAP=0 timeout 900 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY \
    --kernel-trace --output-format csv -d $OUT/pmc_sq -- $B1 > /dev/null 2> $OUT/pmc_sq.err
 python $R/tools/exp/pmc_sum.py $OUT/pmc_sq > $OUT/${TAG}_pmc_mfma_busy.txt 2>&1

@@ -40,7 +40,7 @@ class BfsrConvX3Args(C.Structure):
         ("epi", C.c_void_p), ("act", C.c_int), ("slope", C.c_float),
         ("res1", C.c_void_p), ("res1_bs", C.c_longlong), ("alpha1", C.c_float),
         ("res2", C.c_void_p), ("res2_bs", C.c_longlong), ("alpha2", C.c_float),
-        ("tune", C.c_int), ("acc_scale", C.c_float),
+        ("tune", C.c_int), ("acc_scale", C.c_float), ("mtile", C.c_int),
     ]
 
 
@@ -155,8 +155,8 @@ SYMBOLS = {
     "bfsr_conv2d_up2_h2x": (_I, [C.POINTER(BfsrConvArgs), _VP]),
     "bfsr_conv_packed_size_up2_h2x": (_LL, [_I, _I]),
     "bfsr_pack_conv_weight_up2_h2x": (_I, [_VP, _I, _I, C.c_float, _VP]),
-    "bfsr_conv_packed_size_h2x": (_LL, [_I, _I]),
-    "bfsr_pack_conv_weight_h2x": (_I, [_VP, _I, _I, C.c_float, _VP]),
+    "bfsr_conv_packed_size_h2x": (_LL, [_I, _I, _I]),
+    "bfsr_pack_conv_weight_h2x": (_I, [_VP, _I, _I, _I, C.c_float, _VP]),
     "bfsr_h2_pack": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
     "bfsr_h2_unpack": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
     "bfsr_conv1x1": (_I, [C.POINTER(BfsrConvArgs), _I, _VP]),

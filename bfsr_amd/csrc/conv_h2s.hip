@@ -779,14 +779,19 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_pp_kernel(Bfsr
 // in the matrix pipe; loader `ld` owns sub-image `ld` (plane, k half) of every position group and its share of the weight pieces).
 // Per chunk and wave: 42 ds_read_b128 for 54 MFMAs.  Persistent workgroups, XCD-aware order.  Epilogue = conv3x3_h2s_kernel's.
 constexpr int X_IN = 4 * SUB;                   // 40 960
-constexpr int X_WPL = 9 * 1024;                 // one weight plane of a chunk
-constexpr int X_W = 2 * X_WPL;                  // 18 432
-constexpr int X_STAGE = X_IN + X_W;             // 59 392
-constexpr int X_LDS = 2 * X_STAGE;              // 118 784
-constexpr int X_NPIECE = 40 + X_W / 1024;       // 58 LDS-DMA pieces per stage
+// XM = 32-cout M tiles per workgroup: 1, or 2 for the 64-channel convs (conv5 of a dense block, trunk convs): the input tile is staged
+// once for 64 output channels -- the kernel is bound by the L2 -> LDS fill (59 KB per chunk and 32 couts), so bytes per MFMA count
+template <int XM> struct XGeo {
+    static constexpr int WPL = 9 * 1024 * XM;   // one weight plane of a chunk: [tap][m tile][k half][32][8]
+    static constexpr int W = 2 * WPL;           // 18 432 | 36 864
+    static constexpr int STAGE = X_IN + W;      // 59 392 | 77 824
+    static constexpr int LDS = 2 * STAGE;       // 118 784 | 155 648
+};
 
+template <int XM>
 __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrConvX3Args p, int tiles_x, int tiles_y, int groups, int nitems)
 {
+    constexpr int X_WPL = XGeo<XM>::WPL, X_W = XGeo<XM>::W, X_STAGE = XGeo<XM>::STAGE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -864,29 +869,32 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
     // ---- compute waves: wave w owns rows 2w, 2w+1.  A step = one tap (dx, dy): 2 input rows x 2 planes + the tap's 2 weight planes
     // -> 6 MFMAs; the fragments of step t+1 are read while the MFMAs of step t run (register double buffer: 48 registers -- a
     // tap-COLUMN step as in conv3x3_h2s_kernel needs 112 and spills beside the 32 accumulators).
-    half8 bq[2][2][2], aq[2][2];                                         // [buffer][plane][row] | [buffer][plane]
+    half8 bq[2][2][2], aq[2][2][XM];                                     // [buffer][plane][row] | [buffer][plane][m tile]
     auto load_step = [&](auto buf_, int st, int t) {
         constexpr int BUF = decltype(buf_)::value;
         const int dx = t / 3, dy = t - 3 * dx;
         const unsigned char* sIn = smem + st * X_STAGE;
         const unsigned char* inB = sIn + (lhi * NPOSP + (2 * wave + dy) * PW + l31 + dx) * 16;
-        const unsigned char* wA = sIn + X_IN + lane * 16 + t * 1024;                                     // tap = dx*3 + dy = t
+        const unsigned char* wA = sIn + X_IN + lane * 16 + t * (1024 * XM);                              // tap = dx*3 + dy = t
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) bq[BUF][pl][r] = *reinterpret_cast<const half8*>(inB + pl * 2 * SUB + r * PW * 16);
-            aq[BUF][pl] = *reinterpret_cast<const half8*>(wA + pl * X_WPL);
+#pragma unroll
+            for (int m = 0; m < XM; ++m) aq[BUF][pl][m] = *reinterpret_cast<const half8*>(wA + pl * X_WPL + m * 1024);
         }
     };
-    f32x16 acc[2];
+    f32x16 acc[XM][2];
     auto mfma_step = [&](auto buf_) {
         constexpr int BUF = decltype(buf_)::value;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {                                    // smallest terms first: w_lo*x_hi, w_hi*x_lo, w_hi*x_hi
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][1], bq[BUF][0][j], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][0], bq[BUF][1][j], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][0], bq[BUF][0][j], acc[j], 0, 0, 0);
-        }
+        for (int m = 0; m < XM; ++m)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {                                // smallest terms first: w_lo*x_hi, w_hi*x_lo, w_hi*x_hi
+                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][1][m], bq[BUF][0][j], acc[m][j], 0, 0, 0);
+                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][0][m], bq[BUF][1][j], acc[m][j], 0, 0, 0);
+                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][0][m], bq[BUF][0][j], acc[m][j], 0, 0, 0);
+            }
     };
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
@@ -896,18 +904,23 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
     int buf = 0;                                                         // LDS stage of the next chunk
     for (int it = slot; it < nitems; it += G) {
         const Item cur = decode(it);
-        float4 pm;
+        float4 pmm[XM];
         {
             int ln = lane;
 #if defined(__HIP_DEVICE_COMPILE__)
             asm volatile("" : "+v"(ln));                                 // per-lane address arithmetic stays inside the tile loop
 #endif
-            const int idx = cur.cg * 64 + ln;
-            pm = (ln & 1) ? make_float4(1.f, 0.f, 0.f, 0.f) : make_float4(0.f, 0.f, 1.f, 0.f);
-            if (epi && (idx >> 1) < p.Cout) pm = epi[idx];
+#pragma unroll
+            for (int m = 0; m < XM; ++m) {
+                const int idx = (cur.cg * XM + m) * 64 + ln;
+                pmm[m] = (ln & 1) ? make_float4(1.f, 0.f, 0.f, 0.f) : make_float4(0.f, 0.f, 1.f, 0.f);
+                if (epi && (idx >> 1) < p.Cout) pmm[m] = epi[idx];
+            }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+        for (int m = 0; m < XM; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[m][0][r] = 0.f; acc[m][1][r] = 0.f; }
         // One barrier per chunk, passed EARLY: chunk k+1's barrier sits before the last tap of chunk k (whose fragments are already in
         // registers), so the first fragments of chunk k+1 are in flight under that tap's MFMAs and the loaders may refill stage `buf`
         // one tap earlier.  Nine taps per chunk flip the fragment-buffer parity from chunk to chunk: chunks are processed in pairs.
@@ -942,7 +955,11 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
         }
         if (k < nchunk) chunk_body(I0(), I1(), true);
 
-        // ---- epilogue (the loaders are already staging the next item): as in conv3x3_h2s_kernel, plus the weight scale
+        // ---- epilogue (the loaders are already staging the next item): as in conv3x3_h2s_kernel, plus the weight scale; one M tile
+        // at a time (64 results per lane and the residual operands of both tiles at once would spill)
+#pragma unroll
+        for (int m = 0; m < XM; ++m) {
+        const float4 pm = pmm[m];
         const bool plain = (lane & 1) ? pm.x == 1.f : (pm.y == 0.f && pm.z == 1.f && pm.w == 0.f);
         const bool bias_only = __all(plain);
         const bool fast = bias_only && slope >= 0.f && slope <= 1.f;
@@ -957,7 +974,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int oct = cur.cg * 4 + q * 2 + lh;
+                const int oct = (cur.cg * XM + m) * 4 + q * 2 + lh;
                 const int gy = cur.y0 + 2 * wave + j;
                 goff[j][q] = (gy < H && gx < W && oct * 8 < p.Cout) ? (int)(((long long)oct * 2 * HW + (long long)gy * W + gx) * 8) : -1;
             }
@@ -985,7 +1002,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float lo = acc[j][8 * q + i], hi = acc[j][8 * q + 4 + i];
+                    float lo = acc[m][j][8 * q + i], hi = acc[m][j][8 * q + 4 + i];
                     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
                     o[j][q][i] = lo * p.acc_scale;
                     o[j][q][4 + i] = hi * p.acc_scale;
@@ -1050,7 +1067,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
                     *reinterpret_cast<half8*>(yb) = h8;
                     *reinterpret_cast<half8*>(yb + HW * 8) = l8;
                 } else {
-                    const int oct = cur.cg * 4 + q * 2 + lh;
+                    const int oct = (cur.cg * XM + m) * 4 + q * 2 + lh;
                     float* yb = reinterpret_cast<float*>(p.y) + (long long)cur.b * p.y_bs + (long long)(cur.y0 + 2 * wave + j) * W + gx;
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
@@ -1058,6 +1075,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
     }
 }
 
@@ -1364,19 +1382,20 @@ extern "C" int bfsr_conv3x3_h2s(const BfsrConvX3Args* a, void* stream)
     return (int)hipGetLastError();
 }
 
-extern "C" long long bfsr_conv_packed_size_h2x(int Cout, int Cin)
+extern "C" long long bfsr_conv_packed_size_h2x(int Cout, int Cin, int mtile)
 {
-    if (Cout <= 0 || Cin <= 0 || (Cin & 15)) return -1;
-    return (long long)((Cout + 31) / 32) * (Cin / 16) * 2 * 9 * 2 * 32 * 8;       // fp16 elements
+    if (Cout <= 0 || Cin <= 0 || (Cin & 15) || (mtile != 1 && mtile != 2)) return -1;
+    const int MW = 32 * mtile;
+    return (long long)((Cout + MW - 1) / MW) * (Cin / 16) * 2 * 9 * mtile * 2 * 32 * 8;       // fp16 elements
 }
 
-extern "C" int bfsr_pack_conv_weight_h2x(const float* w, int Cout, int Cin, float scale, unsigned short* packed)
+extern "C" int bfsr_pack_conv_weight_h2x(const float* w, int Cout, int Cin, int mtile, float scale, unsigned short* packed)
 {
-    // w [Cout][Cin][3][3] fp32 -> fp16 [cout group of 32][16-channel chunk][plane hi,lo][tap = dx*3 + dy][k half][32][8] of w*scale,
-    // zero padded; scale = a power of two chosen by the caller (bfsr_amd/ops.py: largest |w|*scale in [2^9, 2^10))
-    if (!w || !packed || Cout <= 0 || Cin <= 0 || (Cin & 15) || !(scale > 0.f)) return -1;
-    const int nchunk = Cin / 16;
-    const long long n = bfsr_conv_packed_size_h2x(Cout, Cin);
+    // w [Cout][Cin][3][3] fp32 -> fp16 [cout group of 32*mtile][16-channel chunk][plane hi,lo][tap = dx*3 + dy][m tile][k half][32][8] of
+    // w*scale, zero padded; scale = a power of two chosen by the caller (bfsr_amd/ops.py: largest |w|*scale in [2^9, 2^10))
+    if (!w || !packed || Cout <= 0 || Cin <= 0 || (Cin & 15) || !(scale > 0.f) || (mtile != 1 && mtile != 2)) return -1;
+    const int nchunk = Cin / 16, MW = 32 * mtile;
+    const long long n = bfsr_conv_packed_size_h2x(Cout, Cin, mtile);
     for (long long i = 0; i < n; ++i) packed[i] = 0;
     for (int co = 0; co < Cout; ++co)
         for (int ci = 0; ci < Cin; ++ci)
@@ -1386,10 +1405,10 @@ extern "C" int bfsr_pack_conv_weight_h2x(const float* w, int Cout, int Cin, floa
                     const _Float16 h = (_Float16)v;
                     const _Float16 l = (_Float16)(v - (float)h);
                     const unsigned short hb = f32_to_f16_bits((float)h), lb = f32_to_f16_bits((float)l);
-                    const long long base = ((long long)(co / 32) * nchunk + ci / 16) * 2;
-                    const long long in = (((long long)(dx * 3 + dy) * 2 + (ci % 16) / 8) * 32 + co % 32) * 8 + ci % 8;
-                    packed[(base + 0) * (9 * 2 * 32 * 8) + in] = hb;
-                    packed[(base + 1) * (9 * 2 * 32 * 8) + in] = lb;
+                    const long long base = ((long long)(co / MW) * nchunk + ci / 16) * 2;
+                    const long long in = ((((long long)(dx * 3 + dy) * mtile + (co % MW) / 32) * 2 + (ci % 16) / 8) * 32 + co % 32) * 8 + ci % 8;
+                    packed[(base + 0) * (9 * mtile * 2 * 32 * 8) + in] = hb;
+                    packed[(base + 1) * (9 * mtile * 2 * 32 * 8) + in] = lb;
                 }
     return 0;
 }
@@ -1409,17 +1428,24 @@ extern "C" int bfsr_conv3x3_h2x(const BfsrConvX3Args* a, void* stream)
     if (a->res1 && ((reinterpret_cast<unsigned long long>(a->res1) & 15) || (a->res1_bs & 7))) return -1;
     if (a->res2 && ((reinterpret_cast<unsigned long long>(a->res2) & 15) || (a->res2_bs & 7))) return -1;
     const int tiles_x = (a->W + 31) / 32, tiles_y = (a->H + TH - 1) / TH;
-    const int groups = (a->Cout + 31) / 32;
+    const int mt = a->mtile == 2 ? 2 : 1;                                // must match the packing (bfsr_pack_conv_weight_h2x mtile)
+    if (a->mtile != 0 && a->mtile != 1 && a->mtile != 2) return -1;
+    const int groups = (a->Cout + 32 * mt - 1) / (32 * mt);
     const long long nitems = (long long)tiles_x * tiles_y * groups * a->B;
     if (nitems > 0x7fffffffLL) return -1;
-    if (bfsr_conv_packed_size_h2x(a->Cout, a->Cin) * 2 >= (1LL << 32)) return -1;
+    if (bfsr_conv_packed_size_h2x(a->Cout, a->Cin, mt) * 2 >= (1LL << 32)) return -1;
     int cus = bfsr::cu_count();
     if (cus <= 0) return -1;
     if (a->tune > 0) cus = a->tune;
     const long long grid = nitems < cus ? nitems : cus;                  // one persistent workgroup per CU
-    static std::atomic<unsigned long long> lds_done{0};
-    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2x_kernel), X_LDS, lds_done) != 0) return -1;
-    hipLaunchKernelGGL(conv3x3_h2x_kernel, dim3((unsigned)grid), dim3((NW + NLW) * 64), X_LDS, st, *a, tiles_x, tiles_y, groups, (int)nitems);
+    static std::atomic<unsigned long long> lds_done{0}, lds_done2{0};
+    if (mt == 2) {
+        if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2x_kernel<2>), XGeo<2>::LDS, lds_done2) != 0) return -1;
+        hipLaunchKernelGGL(conv3x3_h2x_kernel<2>, dim3((unsigned)grid), dim3((NW + NLW) * 64), XGeo<2>::LDS, st, *a, tiles_x, tiles_y, groups, (int)nitems);
+        return (int)hipGetLastError();
+    }
+    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2x_kernel<1>), XGeo<1>::LDS, lds_done) != 0) return -1;
+    hipLaunchKernelGGL(conv3x3_h2x_kernel<1>, dim3((unsigned)grid), dim3((NW + NLW) * 64), XGeo<1>::LDS, st, *a, tiles_x, tiles_y, groups, (int)nitems);
     return (int)hipGetLastError();
 }
 

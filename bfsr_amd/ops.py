@@ -498,9 +498,13 @@ class HipOps(object):
         if KS != 3 or Cin % 16:
             raise ValueError("conv_h2x: 3x3 weights with Cin % 16 == 0 only")
         scale = self.pow2_scale(w)
-        packed = torch.empty(self.lib.bfsr_conv_packed_size_h2x(Cout, Cin), dtype=torch.int16)
-        _lib.check(self.lib.bfsr_pack_conv_weight_h2x(w.data_ptr(), Cout, Cin, scale, packed.data_ptr()), "pack_h2x")
-        return packed.to(self.device), scale
+        # BFSR_H2X_MT=2: 64-cout workgroup tiles (the input tile staged once for both M tiles, 78 instead of 2 x 59 KB per chunk) --
+        # parity-tested, measured 5-8 % SLOWER on conv5 (0.147 vs 0.136 ms at 8 x 160^2, 0.736 vs 0.700 ms at 16 x 256^2): the kernel
+        # is not bound by the bytes it stages
+        mt = 2 if Cout % 64 == 0 and os.environ.get("BFSR_H2X_MT", "1") == "2" else 1
+        packed = torch.empty(self.lib.bfsr_conv_packed_size_h2x(Cout, Cin, mt), dtype=torch.int16)
+        _lib.check(self.lib.bfsr_pack_conv_weight_h2x(w.data_ptr(), Cout, Cin, mt, scale, packed.data_ptr()), "pack_h2x")
+        return packed.to(self.device), scale, mt
 
     def conv_h2x(self, x, pw, out, epi=None, act=ACT_NONE, slope=0.2, res1=None, alpha1=1.0, res2=None, alpha2=1.0, tune=0):
         """3x3 conv over an h2 tensor `x` at fp32-class accuracy (both planes x two-term fp16 weights, three products; conv_h2s.hip,
@@ -517,8 +521,8 @@ class HipOps(object):
         if (Cin, Cout, H, W) != (pw.Cin, pw.Cout, H2, W2) or pw.KS != 3 or x.shape[0] != out.shape[0]:
             raise ValueError("conv_h2x: shape mismatch x%s out%s weight(Cout=%d,Cin=%d)" % (tuple(x.shape), tuple(out.shape), pw.Cout, pw.Cin))
         a.Cin, a.Cout = Cin, Cout
-        wdata, scale = pw.variant("h2x", lambda w_, m_: self._pack_h2x(w_))
-        a.w, a.acc_scale = wdata.data_ptr(), 1.0 / scale
+        wdata, scale, mt = pw.variant("h2x", lambda w_, m_: self._pack_h2x(w_))
+        a.w, a.acc_scale, a.mtile = wdata.data_ptr(), 1.0 / scale, mt
         a.B, a.H, a.W = out.shape[0], H, W
         a.epi, a.act, a.slope, a.tune = _ptr(epi), act, slope, tune
         for name, t, al in (("res1", res1, alpha1), ("res2", res2, alpha2)):

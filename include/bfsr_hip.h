@@ -156,6 +156,7 @@ typedef struct BfsrConvX3Args {
     const unsigned short* res2; long long res2_bs; float alpha2;
     int tune;
     float acc_scale;                               /* bfsr_conv3x3_h2x only: 1 / (the power of two the weights were packed with) */
+    int mtile;                                     /* bfsr_conv3x3_h2x only: 32-cout M tiles per workgroup the weights were packed for (0/1 or 2) */
 } BfsrConvX3Args;
 int bfsr_conv3x3_x3s(const BfsrConvX3Args* a, void* stream);
 int bfsr_x3_pack(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int C, int H, int W, void* stream);
@@ -192,8 +193,8 @@ int bfsr_conv3x3_h2x(const BfsrConvX3Args* a, void* stream);
 int bfsr_conv2d_up2_h2x(const BfsrConvArgs* a, void* stream);
 long long bfsr_conv_packed_size_up2_h2x(int Cout, int Cin);
 int bfsr_pack_conv_weight_up2_h2x(const float* w16, int Cout, int Cin, float scale, unsigned short* packed);
-long long bfsr_conv_packed_size_h2x(int Cout, int Cin);
-int bfsr_pack_conv_weight_h2x(const float* w_oihw, int Cout, int Cin, float scale, unsigned short* packed);
+long long bfsr_conv_packed_size_h2x(int Cout, int Cin, int mtile);
+int bfsr_pack_conv_weight_h2x(const float* w_oihw, int Cout, int Cin, int mtile, float scale, unsigned short* packed);
 int bfsr_h2_pack(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int C, int H, int W, void* stream);
 int bfsr_h2_unpack(const unsigned short* x, long long x_bs, float* y, long long y_bs, int B, int C, int H, int W, void* stream);
 

@@ -41,3 +41,26 @@ def test_engine_encode_is_reproducible_run_to_run():
             assert torch.equal(ep1[lvl], ref1[lvl]), "round %d: encode(B=1) eps%d differs from round 0" % (it, lvl)
             assert torch.equal(ep[lvl][1:2], ep1[lvl]), "round %d: eps%d of sample 1 depends on the batch" % (it, lvl)
         assert torch.equal(rt, rt0), "round %d: decode differs from round 0" % it
+
+
+def test_linf_pipeline_is_reproducible_run_to_run():
+    """The same guard for the LINF-LP path (fp32-accurate mode: conv_h2x encoder, fused MLP, flow): 25 LP passes over a fixed
+    batch reproduce the first one bit for bit."""
+    import torch
+    from bfsr_amd import synth
+    from bfsr_amd.ops import HipOps
+    from bfsr_amd.linf import prep
+    from bfsr_amd.linf.test import lp_infer
+    from test_linf_gpu import _bench_size_models
+    hip = HipOps("cuda:0")
+    m, prior, sd, psd = _bench_size_models(hip, "fp32")
+    lr = hip.to_device(synth.smooth_lr_batch(44, 4, 96, 96))
+    batch = prep.prepare_batch(hip, lr, (384, 384), 3, True)
+    ref = None
+    for it in range(25):
+        out = lp_infer(m, prior, batch, (384, 384), return_all=True)
+        cur = {k: out[k].clone() for k in ("z_lr", "z_learned", "pred")}
+        if ref is None:
+            ref = cur
+        for k in cur:
+            assert torch.equal(cur[k], ref[k]), "round %d: %s differs from round 0" % (it, k)

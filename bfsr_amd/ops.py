@@ -63,7 +63,8 @@ class HipOps(object):
         # optional in-situ timing: launches whose key is in `profile_keys` are bracketed by HIP events on the
         # launch stream; bench.py reads `profile` (key -> [(start, end), ...]) after synchronising.
         self.profile_keys, self.profile = None, {}
-        # contraction mode the engines pick for their large 3x3 convs: "x3" = fp32-accurate 3xBF16 split on the bf16
+        # contraction mode the engines pick for their large 3x3 convs: "x3" = fp32-accurate split on the 16-bit matrix pipe (which
+        # split: `self.split` below; the API keeps its round-1 names conv_x3 / pack_conv_x3 / x3_* for both), i.e. formerly the 3xBF16 split on the bf16
         # MFMA (default), "f32" = native fp32 MFMA everywhere (BFSR_CONV=f32)
         # BFSR_KEYLOG=<path>: record the key of every launch, in order, and dump them at exit (tools/pmc_traffic.py aligns
         # them with the dispatch order of a rocprofv3 --pmc run to attribute counters to launch shapes)
@@ -156,7 +157,8 @@ class HipOps(object):
         return packed.to(self.device)
 
     def pack_conv_x3(self, w, mtile=None):
-        """3xBF16 split packing for conv_x3 (fp32-accurate contraction on the bf16 MFMA)."""
+        """Split packing for conv_x3 (fp32-accurate contraction on the 16-bit MFMA): two-term fp16 planes of w * 2^k under
+        split == "f16x2" (the default), three-term bf16 planes under "bf16x3"."""
         return self.pack_conv_f16(w, mtile, kind="bf16x3")
 
     def conv_x3(self, x, pw, out, **kw):
@@ -291,7 +293,7 @@ class HipOps(object):
         return out
 
     def pack_conv_up2_x3(self, w):
-        """conv_up2 weights (16 parity-pre-summed matrices) in the 3xBF16 split layout."""
+        """conv_up2 weights (16 parity-pre-summed matrices) in the split layout of `self.split`."""
         w16 = self.presum_up2_weights(w)
         return self._pack_taps_x3(w16, 16)
 
@@ -327,11 +329,12 @@ class HipOps(object):
         return self._pack_taps_x3(w25, 25)
 
     def conv_up4_x3(self, x, pw, out, epi=None, pre_add=None, act=ACT_NONE, slope=0.2):
-        """out [B,Cout,4h,4w] = epilogue(conv3x3(nearest_up4(x)) + pre_add) on the 3xBF16 split (25 pre-summed matrices)."""
+        """out [B,Cout,4h,4w] = epilogue(conv3x3(nearest_up4(x)) + pre_add) on the split contraction (25 pre-summed matrices)."""
         return self.conv_up2_x3(x, pw, out, epi=epi, pre_add=pre_add, act=act, slope=slope, _factor=4)
 
     def conv_up2_x3(self, x, pw, out, epi=None, pre_add=None, act=ACT_NONE, slope=0.2, tune=0, _factor=2):
-        """conv_up2 on the 3xBF16 split (fp32-accurate); channels at output resolution enter through pre_add (may be `out`)."""
+        """conv_up2 on the split contraction (fp32-accurate; the split is the one `pw` was packed with); channels at output resolution
+        enter through pre_add (may be `out`)."""
         xp, xbs, Cin, h, w = _view(x, "conv_up2_x3.x")
         yp, ybs, Cout, H, W = _view(out, "conv_up2_x3.out")
         if (Cin, Cout, _factor * h, _factor * w) != (pw.Cin, pw.Cout, H, W) or x.shape[0] != out.shape[0]:
@@ -384,7 +387,8 @@ class HipOps(object):
         _lib.check(self._launch(key, lambda: self.lib.bfsr_conv2d_up2_h2x(C.byref(a), self._stream())), "conv2d_up2_h2x")
         return out
 
-    # ---- x3 tensors (activations stored as the exact 3-term bf16 split) + the LDS-DMA conv over them (conv_x3s.hip) ----------
+    # ---- split tensors: x3 (exact 3-term bf16 split, conv_x3s.hip) under split == "bf16x3", h2 (fp16 hi + lo, conv3x3_h2x_kernel in
+    # conv_h2s.hip) under "f16x2"; x3_empty / x3_pack / x3_unpack / conv_x3s dispatch on the mode and the tensor type ------------
     def x3_empty(self, B, Cc, H, W):
         """[B, C/8, 3, H, W, 8] bf16: x = h + m + l exactly; channel slices `t[:, a//8:b//8]` are views."""
         if Cc % 8:

@@ -34,7 +34,7 @@ class _ConvP(object):
 
     def __init__(self, ops, w, bias=None, aff_shift=None, aff_scale=None, aff_post=None, post_scale=None, mtile=None,
                  f16=False, x3=None):
-        """Contraction mode: 'f32' = native fp32 MFMA; 'x3' = fp32-accurate 3xBF16 split on the bf16 MFMA (the default
+        """Contraction mode: 'f32' = native fp32 MFMA; 'x3' = fp32-accurate split on the 16-bit MFMA (ops.split: fp16 pair or bf16 triple; the default
         for 3x3 convs with >= 32 input channels, where it is 1.4-1.7x faster; x3=False pins fp32, e.g. for the fused
         two-stage kernel); 'f16' = reduced precision (LINF precision='fp16' only).  Epilogue and tensors are fp32."""
         pinned_f32 = x3 is False
@@ -78,8 +78,9 @@ class RRDBEncoder(object):
     """RRDBNet trunk (RRDBNet_arch.py:67-148 / LINF-LP/models/rrdb.py:77-116): conv_first, nb x RRDB
     (3 x RDB of five 3x3 convs), trunk_conv + skip.  `taps` = RRDB indices whose output is wanted.
 
-    Default path (3xBF16 contraction): the dense blocks live in HBM as x3 tensors (exact 3-term bf16 split, ops.x3_empty) and
-    every RDB conv runs on conv_x3s (LDS-DMA staging by dedicated loader waves, conv_x3s.hip); conv_first's output is packed
+    Default path (split contraction): the dense blocks live in HBM as split tensors (ops.x3_empty: h2 = fp16 hi + lo under
+    BFSR_SPLIT=f16x2, x3 = exact 3-term bf16 under bf16x3) and every RDB conv runs on the LDS-DMA kernel of that split (conv_h2x /
+    conv_x3s: staging by dedicated loader waves); conv_first's output is packed
     once, tapped block outputs and the trunk output are unpacked / written as fp32.  `BFSR_RRDB=fp32` (or a backend without
     conv_x3s, or precision='fp16') keeps fp32 NCHW block buffers and the register-staged kernels."""
 
@@ -138,7 +139,8 @@ class RRDBEncoder(object):
         return out
 
     def _forward_packed(self, x, out, on_block, taps):
-        """The dense blocks on packed 16-bit tensors: x3 (exact 3-term bf16 split, conv_x3s) or, for precision='fp16', h2 (fp16
+        """The dense blocks on packed 16-bit tensors: the split tensors of the fp32-accurate mode (h2 on conv_h2x or x3 on conv_x3s,
+        see the class docstring) or, for precision='fp16', h2 (fp16
         hi + lo planes, conv_h2s: convs read hi, the residual chain reads hi + lo; x1..x4 are written hi-only)."""
         ops, nf, gc = self.ops, self.nf, self.gc
         B, _, h, w = x.shape
@@ -177,7 +179,7 @@ class RRDBEncoder(object):
 
 
 class _ConvX3S(object):
-    """A 3x3 conv over x3 tensors (ops.conv_x3s): 3xBF16 weights packed for 32-cout workgroup tiles + bias epilogue."""
+    """A 3x3 conv over split tensors (ops.conv_x3s -> conv_h2x or conv_x3s): weights packed for 32-cout workgroup tiles + bias epilogue."""
 
     def __init__(self, ops, w, bias=None):
         self.pw = ops.pack_conv_x3(w, 1)

@@ -287,11 +287,11 @@ int launch_x3(const BfsrConvArgs& a, hipStream_t st)
 // acc[column parity][row].  Column offset d = b+j is the outer loop so one set of B rows serves every (b,j) with that d.
 // The two column parities of a source pixel are adjacent output pixels: the epilogue moves float2 (fully coalesced rows).
 // Channels that already live at the output resolution go through the plain kernel first and arrive here as `pre_add`.
-template <int PL, int NW, int NR>
+template <int PL, int NW, int NR, int MR>
 __global__ __launch_bounds__(NW * 64, 2) void conv_up2_bf16x3_kernel(BfsrConvArgs p, int tiles_x, int tiles_xy, int groups)
 {
     constexpr int NT = NW * 64, SR = NW * NR, PW = 34, NPOS = (SR + 1) * PW, PPT = (NPOS + NT - 1) / NT;
-    constexpr int TAPS = 16, MW = 32, HT = 8;                            // HT = matrices of one row parity
+    constexpr int TAPS = 16, MW = 32 * MR, HT = 8;                       // HT = matrices of one row parity; MR = 32-cout M tiles per workgroup
     constexpr int WPL = HT * MW * CK, WSLAB = PL * WPL, WV = (WSLAB / 8 + NT - 1) / NT, IPL = NPOS * CK;
     constexpr int GPL = TAPS * MW * CK;                                  // one plane of all 16 matrices in global memory
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -334,13 +334,15 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_up2_bf16x3_kernel(BfsrConvArg
         woff[i] = idx < WSLAB / 8 ? (unsigned)((pl * GPL + pa * WPL) * 2 + rem * 16) : OOB;
     }
     const unsigned cs_bytes = (unsigned)(cs_in * 4);
-    f32x16 acc[2][NR];
+    f32x16 acc[MR][2][NR];
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int m = 0; m < MR; ++m)
 #pragma unroll
-        for (int n = 0; n < NR; ++n)
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[q][n][r] = 0.f;
+            for (int n = 0; n < NR; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][q][n][r] = 0.f;
 
     float vin[PPT][CK];
     uint4 vw[WV];
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_up2_bf16x3_kernel(BfsrConvArg
         if (k + 1 < nchunk) load_chunk(k + 1);
         const elt* inB = sIn + (lhi * NPOS + (wave * NR) * PW + l31) * 8;
         const elt* wA = sW + (lhi * MW + l31) * 8;
-        frag bfr[PL][NR + 1], afr[2][PL];
+        frag bfr[PL][NR + 1], afr[2][PL][MR];
         auto load_b = [&](int d) {
 #pragma unroll
             for (int pl = 0; pl < PL; ++pl)
@@ -397,7 +399,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_up2_bf16x3_kernel(BfsrConvArg
             const int blk = s_ >> 1, bq = blk >> 1, j = blk & 1, i = s_ & 1;
             const int t = bq * 4 + i * 2 + j;
 #pragma unroll
-            for (int pl = 0; pl < PL; ++pl) afr[buf][pl] = *reinterpret_cast<const frag*>(wA + pl * WPL + t * 2 * MW * 8);
+            for (int pl = 0; pl < PL; ++pl)
+#pragma unroll
+                for (int m = 0; m < MR; ++m) afr[buf][pl][m] = *reinterpret_cast<const frag*>(wA + pl * WPL + (t * 2 * MW + m * 32) * 8);
         };
         load_a(0, 0);
 #pragma unroll
@@ -408,8 +412,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_up2_bf16x3_kernel(BfsrConvArg
             if (s_ + 1 < 8) load_a(ab ^ 1, s_ + 1);
             __builtin_amdgcn_sched_barrier(0);
 #define BFSR_TERM(PA_, PB_)                                                                                            \
-    _Pragma("unroll") for (int n = 0; n < NR; ++n)                                                                      \
-        acc[bq][n] = Sp<PL>::mfma(afr[ab][PA_], bfr[PB_][n + i], acc[bq][n]);
+    _Pragma("unroll") for (int m = 0; m < MR; ++m) _Pragma("unroll") for (int n = 0; n < NR; ++n)                       \
+        acc[m][bq][n] = Sp<PL>::mfma(afr[ab][PA_][m], bfr[PB_][n + i], acc[m][bq][n]);
             BFSR_PRODUCTS(PL, BFSR_TERM)
 #undef BFSR_TERM
             __builtin_amdgcn_sched_barrier(0);
@@ -431,8 +435,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_up2_bf16x3_kernel(BfsrConvArg
         const float* r2 = p.res2 ? p.res2 + (long long)b * p.res2_bs : nullptr;
         float* yb = p.y + (long long)b * p.y_bs;
 #pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int co = cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            const int co = (cg * MR + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
             if (co >= p.Cout) continue;
             float4 q0 = make_float4(0.f, 0.f, 1.f, 0.f); float q1 = 1.f;
             if (epi) { q0 = epi[co * 2]; q1 = epi[co * 2 + 1].x; }
@@ -441,7 +447,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_up2_bf16x3_kernel(BfsrConvArg
                 const int sy = y0 + wave * NR + n;
                 if (sy >= Hs) continue;
                 const long long o = (long long)co * HW + (long long)(2 * sy + pa) * W + 2 * sx;
-                float2 v = make_float2(acc[0][n][r], acc[1][n][r]);
+                float2 v = make_float2(acc[m][0][n][r], acc[m][1][n][r]);
                 if (PL == 2) { v.x *= p.acc_scale; v.y *= p.acc_scale; }
                 v.x += q0.x; v.y += q0.x;
                 if constexpr (T) if (pre) { const float2 t = *reinterpret_cast<const float2*>(pre + o); v.x += t.x; v.y += t.y; }
@@ -460,26 +466,27 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_up2_bf16x3_kernel(BfsrConvArg
     else run_epilogue(std::false_type{});
 }
 
-template <int PL, int NW, int NR>
+template <int PL, int NW, int NR, int MR>
 int launch_up2_x3p(const BfsrConvArgs& a, hipStream_t st)
 {
     constexpr int SR = NW * NR;
-    constexpr int LDS = PL * (8 * 32 * CK + (SR + 1) * 34 * CK) * 2;
+    constexpr int LDS = PL * (8 * 32 * MR * CK + (SR + 1) * 34 * CK) * 2;
     static std::atomic<unsigned long long> lds_done{0};
-    if (LDS > 65536 && bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_up2_bf16x3_kernel<PL, NW, NR>), LDS, lds_done) != 0) return -1;
+    if (LDS > 65536 && bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_up2_bf16x3_kernel<PL, NW, NR, MR>), LDS, lds_done) != 0) return -1;
     const int Hs = a.H / 2, Ws = a.W / 2;
     const int tiles_x = (Ws + 31) / 32, tiles_y = (Hs + SR - 1) / SR;
-    const int groups = (a.Cout + 31) / 32;
+    const int groups = (a.Cout + 32 * MR - 1) / (32 * MR);
     const long long nblk = 2LL * tiles_x * tiles_y * groups * a.B;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return -1;
-    hipLaunchKernelGGL((conv_up2_bf16x3_kernel<PL, NW, NR>), dim3((unsigned)nblk), dim3(NW * 64), LDS, st, a, tiles_x, tiles_x * tiles_y, groups);
+    hipLaunchKernelGGL((conv_up2_bf16x3_kernel<PL, NW, NR, MR>), dim3((unsigned)nblk), dim3(NW * 64), LDS, st, a, tiles_x, tiles_x * tiles_y, groups);
     return (int)hipGetLastError();
 }
 
 template <int NW, int NR>
 int launch_up2_x3(const BfsrConvArgs& a, hipStream_t st)
 {
-    return a.arith == 1 ? launch_up2_x3p<2, NW, NR>(a, st) : launch_up2_x3p<3, NW, NR>(a, st);
+    if (a.mtile == 2) return a.arith == 1 ? launch_up2_x3p<2, NW, NR, 2>(a, st) : -1;      // 64-cout workgroups: the fp16 pair only
+    return a.arith == 1 ? launch_up2_x3p<2, NW, NR, 1>(a, st) : launch_up2_x3p<3, NW, NR, 1>(a, st);
 }
 
 // ---- conv over nearest_up4(x): x [B,Cin,H/4,W/4] -> y [B,Cout,H,W] (the level-1 conditional of the 8x model: LR-resolution
@@ -775,7 +782,7 @@ extern "C" int bfsr_pack_conv_weight_bf16x3(const float* w, int Cout, int Cin, i
 extern "C" int bfsr_conv2d_up2_bf16x3(const BfsrConvArgs* a, void* stream)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (!a || !a->x || !a->w || !a->y || a->w2 || a->x2 || a->mtile != 1) return -1;
+    if (!a || !a->x || !a->w || !a->y || a->w2 || a->x2 || (a->mtile != 1 && !(a->mtile == 2 && a->arith == 1))) return -1;
     if (a->B <= 0 || a->H <= 0 || a->W <= 0 || (a->H & 1) || (a->W & 1) || a->Cin <= 0 || a->Cout <= 0) return -1;
     if ((long long)a->Cin * (a->H / 2) * (a->W / 2) * 4 >= (1LL << 31)) return -1;
     // the float2 epilogue needs 8-byte aligned rows: even W and even plane/batch strides are given by H,W even + NCHW views

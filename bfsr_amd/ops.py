@@ -301,9 +301,13 @@ class HipOps(object):
         Cout, Cin, _ = wt.shape
         if self.split == "f16x2":
             scale = self.pow2_scale(wt)
-            packed = torch.empty(self.lib.bfsr_conv_packed_size_taps_f16x2(Cout, Cin, T, 1), dtype=torch.int16)
-            _lib.check(self.lib.bfsr_pack_conv_weight_taps_f16x2(wt.data_ptr(), Cout, Cin, T, 1, scale, packed.data_ptr()), "pack_taps_f16x2")
-            return PackedConv(packed.to(self.device), Cout, Cin, 3, 1, fixed=True, scale=scale, arith=1, w=wt.contiguous(), ops=self)
+            # BFSR_TAPS_MT=2: 64-cout workgroups for the x2 taps kernel (the register-staged input tile serves twice the MFMAs) --
+            # parity-tested, measured SLOWER (8.0 vs 6.5 ms per cfg2 launch: 52 KB of LDS and 64 more accumulator registers per
+            # workgroup cost more occupancy than the halved staging saves)
+            mt = 2 if T == 16 and Cout % 64 == 0 and os.environ.get("BFSR_TAPS_MT", "1") == "2" else 1
+            packed = torch.empty(self.lib.bfsr_conv_packed_size_taps_f16x2(Cout, Cin, T, mt), dtype=torch.int16)
+            _lib.check(self.lib.bfsr_pack_conv_weight_taps_f16x2(wt.data_ptr(), Cout, Cin, T, mt, scale, packed.data_ptr()), "pack_taps_f16x2")
+            return PackedConv(packed.to(self.device), Cout, Cin, 3, mt, fixed=True, scale=scale, arith=1, w=wt.contiguous(), ops=self)
         packed = torch.empty(self.lib.bfsr_conv_packed_size_taps_bf16x3(Cout, Cin, T, 1), dtype=torch.int16)
         _lib.check(self.lib.bfsr_pack_conv_weight_taps_bf16x3(wt.data_ptr(), Cout, Cin, T, 1, packed.data_ptr()), "pack_taps_x3")
         return PackedConv(packed.to(self.device), Cout, Cin, 3, 1, fixed=True)
@@ -343,7 +347,7 @@ class HipOps(object):
         a.x, a.x_bs, a.Cin = xp, xbs, Cin
         a.w = pw.data.data_ptr()
         a.y, a.y_bs, a.Cout = yp, ybs, Cout
-        a.B, a.H, a.W, a.KS, a.mtile, a.tune = out.shape[0], H, W, 3, 1, tune
+        a.B, a.H, a.W, a.KS, a.mtile, a.tune = out.shape[0], H, W, 3, pw.mtile, tune
         a.epi, a.act, a.slope = _ptr(epi), act, slope
         if pw.arith == 1:
             a.arith, a.acc_scale = 1, 1.0 / pw.scale

@@ -273,7 +273,7 @@ def test_conv_h2x_dense_block_views_and_residuals(hip):
     close(hip.h2_unpack(nxt[:, :8], hip.empty(B, 64, H, W)), out_ref, 2e-5, "h2x conv5 residuals")
 
 
-@pytest.mark.parametrize("env", [{"BFSR_H2S_PP": "1"}, {"BFSR_H2S_WREG": "1"}, {"BFSR_H2S_PP": "1", "BFSR_H2S_WREG": "1"}, {"BFSR_H2X_MT": "2"}])
+@pytest.mark.parametrize("env", [{"BFSR_H2S_PP": "1"}, {"BFSR_H2S_WREG": "1"}, {"BFSR_H2S_PP": "1", "BFSR_H2S_WREG": "1"}, {"BFSR_H2X_MT": "2"}, {"BFSR_TAPS_MT": "2"}])
 def test_conv_h2s_kernel_variants(hip, env):
     """The selectable conv_h2s / conv_h2x variants (ping-pong compute groups, weight pieces through a register loader, 64-cout workgroup
     tiles; conv_h2s.hip) against the same tests: the switches are read once per process, so the tests run in a child interpreter."""
@@ -281,7 +281,7 @@ def test_conv_h2s_kernel_variants(hip, env):
     e = dict(os.environ, **env)
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_hip_ops.py"), "-q", "-x", "-k",
-                        "(conv_h2s or conv_h2x or persistent) and not variants"], env=e, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=600)
+                        "(conv_h2s or conv_h2x or conv_up2 or persistent) and not variants"], env=e, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 

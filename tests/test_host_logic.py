@@ -247,3 +247,75 @@ def test_split_packing_is_exact_and_laid_out_as_documented():
                 assert float(as_f32(cell).double().sum()) == float(w1[co, ci])
             else:
                 assert cell.view(torch.float16)[0] == w1[co, ci].half()
+
+
+def test_fp16_pair_packers_layout_and_accuracy():
+    """Host-side packers of the two-term fp16 split (no GPU needed): hi + lo reproduces w * scale to 2^-22 relative (to 2^-25 * |w|max
+    absolutely once the lo term is subnormal) at the documented slots of the register-staged kernels (taps layout, 2 planes), of
+    conv3x3_h2x_kernel ([group][chunk][plane][tap = dx*3 + dy][m tile][k half][32][8]) and of conv_up2_h2x_kernel (step order)."""
+    from bfsr_amd import _lib
+    from bfsr_amd.ops import HipOps
+    lib = _lib.load()
+    g = np.random.Generator(np.random.PCG64(9))
+    Cout, Cin = 70, 48
+    w = torch.from_numpy((g.standard_normal((Cout, Cin, 3, 3)) * np.exp(g.uniform(-6, 1, (Cout, 1, 1, 1)))).astype(np.float32))
+    scale = HipOps.pow2_scale(w)
+    assert 512.0 <= float(w.abs().max()) * scale < 1024.0 and np.log2(scale) == int(np.log2(scale))
+    f16 = lambda t: t.view(torch.float16).double()
+    tol = lambda ref: 2.0 ** -22 * ref.abs() + 2.0 ** -24           # normal lo terms: 22 bits; subnormal lo terms: 2^-25 absolute
+    # --- register-staged kernels: [group][chunk][plane][tap][k half][mtile*32][8]
+    for mt in (1, 2):
+        MW, groups, nchunk = 32 * mt, (Cout + 32 * mt - 1) // (32 * mt), Cin // 16
+        n = lib.bfsr_conv_packed_size_taps_f16x2(Cout, Cin, 9, mt)
+        assert n == groups * nchunk * 2 * 9 * 2 * MW * 8
+        p = torch.zeros(n, dtype=torch.int16)
+        assert lib.bfsr_pack_conv_weight_taps_f16x2(w.reshape(Cout, Cin, 9).contiguous().data_ptr(), Cout, Cin, 9, mt, scale, p.data_ptr()) == 0
+        P = f16(p).view(groups, nchunk, 2, 9, 2, MW, 8)
+        for co, ci, t in ((0, 0, 0), (69, 47, 8), (33, 17, 4), (64, 8, 2)):
+            got = P[co // MW, ci // 16, :, t, (ci % 16) // 8, co % MW, ci % 8].sum()
+            ref = w[co, ci, t // 3, t % 3].double() * scale
+            assert abs(got - ref) <= tol(ref), (co, ci, t, float(got), float(ref))
+    # --- conv3x3_h2x_kernel
+    for mt in (1, 2):
+        MW, groups, nchunk = 32 * mt, (Cout + 32 * mt - 1) // (32 * mt), Cin // 16
+        n = lib.bfsr_conv_packed_size_h2x(Cout, Cin, mt)
+        assert n == groups * nchunk * 2 * 9 * mt * 2 * 32 * 8
+        p = torch.zeros(n, dtype=torch.int16)
+        assert lib.bfsr_pack_conv_weight_h2x(w.data_ptr(), Cout, Cin, mt, scale, p.data_ptr()) == 0
+        P = f16(p).view(groups, nchunk, 2, 9, mt, 2, 32, 8)
+        for co, ci, dy, dx in ((0, 0, 0, 0), (69, 47, 2, 2), (33, 17, 1, 0), (64, 8, 0, 2)):
+            got = P[co // MW, ci // 16, :, dx * 3 + dy, (co % MW) // 32, (ci % 16) // 8, co % 32, ci % 8].sum()
+            ref = w[co, ci, dy, dx].double() * scale
+            assert abs(got - ref) <= tol(ref), (co, ci, dy, dx)
+        if mt == 1:                                                       # cout padding of the last group (couts 70..95) is zero
+            assert float(P[-1, :, :, :, 0, :, 70 - 64:, :].abs().sum()) == 0.0
+    # --- conv_up2_h2x_kernel: [group][chunk][row parity][plane][step][k half][32][8], step s = (b = s>>2, i = s&1, j = (s>>1)&1)
+    w16 = HipOps.presum_up2_weights(w)                                    # [Cout, Cin, 16], t = (a*2+b)*4 + i*2 + j
+    s16 = HipOps.pow2_scale(w16)
+    n = lib.bfsr_conv_packed_size_up2_h2x(Cout, Cin)
+    groups, nchunk = (Cout + 31) // 32, Cin // 16
+    assert n == groups * nchunk * 2 * 2 * 8 * 2 * 32 * 8
+    p = torch.zeros(n, dtype=torch.int16)
+    assert lib.bfsr_pack_conv_weight_up2_h2x(w16.data_ptr(), Cout, Cin, s16, p.data_ptr()) == 0
+    P = f16(p).view(groups, nchunk, 2, 2, 8, 2, 32, 8)
+    for co, ci, a, s_ in ((0, 0, 0, 0), (69, 47, 1, 7), (33, 17, 0, 5), (64, 8, 1, 2)):
+        b, i, j = s_ >> 2, s_ & 1, (s_ >> 1) & 1
+        got = P[co // 32, ci // 16, a, :, s_, (ci % 16) // 8, co % 32, ci % 8].sum()
+        ref = w16[co, ci, (a * 2 + b) * 4 + i * 2 + j].double() * s16
+        assert abs(got - ref) <= tol(ref), (co, ci, a, s_)
+    # --- fused MLP, per-layer scales
+    HD, Co4 = 256, 72
+    ws = [torch.randn(HD, 4 * HD) * 0.03, torch.randn(HD, HD) * 0.06, torch.randn(HD, HD) * 0.5, torch.randn(Co4, HD) * 2.0]
+    sc = [HipOps.pow2_scale(t) for t in ws]
+    import ctypes as C
+    n = lib.bfsr_linf_mlp_packed_size(HD, Co4, 2)
+    p = torch.zeros(n, dtype=torch.int16)
+    arr = (C.c_float * 4)(*sc)
+    assert lib.bfsr_pack_linf_mlp_f16x2(ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), ws[3].data_ptr(), HD, Co4, C.cast(arr, C.c_void_p), p.data_ptr()) == 0
+    o1 = (HD // 32) * (4 * HD // 16) * 2 * 64 * 8                          # layer 2 starts here: [m tile][k chunk][plane][lane][8]
+    L2 = f16(p[o1: o1 + (HD // 32) * (HD // 16) * 2 * 64 * 8]).view(HD // 32, HD // 16, 2, 64, 8)
+    for row, kidx in ((0, 0), (255, 255), (100, 77)):
+        got = L2[row // 32, kidx // 16, :, ((kidx % 16) // 8) * 32 + row % 32, kidx % 8].sum()
+        ref = ws[1][row, kidx].double() * sc[1]
+        assert abs(got - ref) <= tol(ref)
+    assert lib.bfsr_pack_linf_mlp(ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), ws[3].data_ptr(), HD, Co4, 2, p.data_ptr()) != 0     # needs the scales

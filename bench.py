@@ -466,7 +466,7 @@ def main():
         if fp32_only is not None or cfg == 2:
             line["value_native_fp32_mfma"] = fp32_only
         print(json.dumps(line))
-    if world > 1:
+    if torch.distributed.is_initialized():              # world > 1, or a single rank under BFSR_DIST_FORCE=1
         torch.distributed.destroy_process_group()
 
 

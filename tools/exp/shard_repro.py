@@ -9,11 +9,12 @@ from bfsr_amd.ops import HipOps, MODE_BILINEAR
 from test_srflow_gpu import build
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+SCALE, LR = int(os.environ.get("REPRO_SCALE", "4")), int(os.environ.get("REPRO_LR", "160"))      # e.g. REPRO_SCALE=8 REPRO_LR=96: BASELINE config 4's model
 hip = HipOps("cuda:0")
-m, prior, opt, sd, psd = build(hip, 4)
+m, prior, opt, sd, psd = build(hip, SCALE)
 eng = m.netG.module.engine()
-lr = hip.to_device(synth.smooth_lr_batch(21, 2, 160, 160))
-lr_up = hip.resize(lr, hip.empty(2, 3, 640, 640), MODE_BILINEAR, 0.25, 0.25)
+lr = hip.to_device(synth.smooth_lr_batch(21, 2, LR, LR))
+lr_up = hip.resize(lr, hip.empty(2, 3, LR * SCALE, LR * SCALE), MODE_BILINEAR, 1.0 / SCALE, 1.0 / SCALE)
 lr1, lr_up1 = lr[1:2].clone(), lr_up[1:2].clone()
 ref2 = ref1 = None
 for it in range(N):

@@ -27,7 +27,7 @@ class BfsrConvArgs(C.Structure):
         ("tune", C.c_int),
         ("w2", C.c_void_p), ("C2", C.c_int), ("epi2", C.c_void_p), ("act2", C.c_int),
         ("x2", C.c_void_p), ("x2_bs", C.c_longlong), ("Cin2", C.c_int), ("w_x2", C.c_void_p),
-        ("arith", C.c_int), ("acc_scale", C.c_float),
+        ("arith", C.c_int), ("acc_scale", C.c_float), ("y_fmt", C.c_int), ("flag", C.c_void_p),
     ]
 
 
@@ -40,7 +40,7 @@ class BfsrConvX3Args(C.Structure):
         ("epi", C.c_void_p), ("act", C.c_int), ("slope", C.c_float),
         ("res1", C.c_void_p), ("res1_bs", C.c_longlong), ("alpha1", C.c_float),
         ("res2", C.c_void_p), ("res2_bs", C.c_longlong), ("alpha2", C.c_float),
-        ("tune", C.c_int), ("acc_scale", C.c_float), ("mtile", C.c_int),
+        ("tune", C.c_int), ("acc_scale", C.c_float), ("mtile", C.c_int), ("flag", C.c_void_p),
     ]
 
 
@@ -59,38 +59,27 @@ class BfsrFlowArgs(C.Structure):
 class BfsrCouplingHeadArgs(C.Structure):
     _fields_ = [
         ("z", C.c_void_p), ("z_bs", C.c_longlong), ("Cz", C.c_int),
-        ("pre_aff", C.c_void_p), ("pre_aff_bs", C.c_longlong),
+        ("pre_aff", C.c_void_p), ("pre_aff_bs", C.c_longlong), ("pre_fmt", C.c_int),
         ("w", C.c_void_p), ("epi0", C.c_void_p), ("epi2", C.c_void_p),
+        ("acc_scale0", C.c_float), ("acc_scale2", C.c_float),
         ("hid", C.c_void_p), ("hid_bs", C.c_longlong),
-        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("hid_fmt", C.c_int),
-    ]
-
-
-class BfsrCouplingStepArgs(C.Structure):
-    _fields_ = [
-        ("z_in", C.c_void_p), ("z_in_bs", C.c_longlong),
-        ("z_out", C.c_void_p), ("z_out_bs", C.c_longlong),
-        ("pre_aff", C.c_void_p), ("pre_aff_bs", C.c_longlong),
-        ("h_ft", C.c_void_p), ("h_ft_bs", C.c_longlong),
-        ("w_head", C.c_void_p), ("w_tail", C.c_void_p),
-        ("epi0", C.c_void_p), ("epi2", C.c_void_p),
-        ("bias", C.c_void_p), ("post_scale", C.c_void_p),
-        ("wmat", C.c_void_p), ("an_bias", C.c_void_p), ("an_escale", C.c_void_p),
-        ("B", C.c_int), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("reverse", C.c_int),
-        ("eps", C.c_float),
+        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("flag", C.c_void_p),
     ]
 
 
 class BfsrCouplingTailArgs(C.Structure):
     _fields_ = [
         ("hid", C.c_void_p), ("hid_bs", C.c_longlong), ("Cin", C.c_int),
-        ("w", C.c_void_p), ("bias", C.c_void_p), ("post_scale", C.c_void_p),
+        ("w", C.c_void_p), ("acc_scale", C.c_float),
+        ("bias", C.c_void_p), ("post_scale", C.c_void_p),
         ("z_in", C.c_void_p), ("z_in_bs", C.c_longlong),
         ("z_out", C.c_void_p), ("z_out_bs", C.c_longlong),
-        ("h_ft", C.c_void_p), ("h_ft_bs", C.c_longlong),
+        ("h_ft", C.c_void_p), ("h_ft_bs", C.c_longlong), ("h_ft_fmt", C.c_int),
         ("wmat", C.c_void_p), ("an_bias", C.c_void_p), ("an_escale", C.c_void_p),
         ("B", C.c_int), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("reverse", C.c_int),
-        ("eps", C.c_float), ("hid_fmt", C.c_int),
+        ("eps", C.c_float),
+        ("flag", C.c_void_p),
     ]
 
 
@@ -157,7 +146,7 @@ SYMBOLS = {
     "bfsr_pack_conv_weight_up2_h2x": (_I, [_VP, _I, _I, C.c_float, _VP]),
     "bfsr_conv_packed_size_h2x": (_LL, [_I, _I, _I]),
     "bfsr_pack_conv_weight_h2x": (_I, [_VP, _I, _I, _I, C.c_float, _VP]),
-    "bfsr_h2_pack": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
+    "bfsr_h2_pack": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP, _VP]),
     "bfsr_h2_unpack": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
     "bfsr_conv1x1": (_I, [C.POINTER(BfsrConvArgs), _I, _VP]),
     "bfsr_conv1x1_packed_size": (_LL, [_I, _I, _I]),
@@ -174,13 +163,10 @@ SYMBOLS = {
     "bfsr_flow_pointwise": (_I, [C.POINTER(BfsrFlowArgs), _VP]),
     "bfsr_coupling_head": (_I, [C.POINTER(BfsrCouplingHeadArgs), _VP]),
     "bfsr_coupling_tail": (_I, [C.POINTER(BfsrCouplingTailArgs), _VP]),
-    "bfsr_coupling_step": (_I, [C.POINTER(BfsrCouplingStepArgs), _VP]),
-    "bfsr_coupling_step_tail_packed_size": (_LL, [_I]),
-    "bfsr_pack_coupling_step_tail": (_I, [_VP, _I, _VP]),
     "bfsr_coupling_head_packed_size": (_LL, [_I]),
-    "bfsr_pack_coupling_head": (_I, [_VP, _VP, _I, _VP]),
+    "bfsr_pack_coupling_head": (_I, [_VP, _VP, _I, C.c_float, C.c_float, _VP]),
     "bfsr_coupling_tail_packed_size": (_LL, [_I, _I]),
-    "bfsr_pack_coupling_tail": (_I, [_VP, _I, _I, _VP]),
+    "bfsr_pack_coupling_tail": (_I, [_VP, _I, _I, C.c_float, _VP]),
     "bfsr_squeeze2d": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
     "bfsr_unsqueeze2d": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
     "bfsr_split2d": (_I, [_VP, _LL, _VP, _LL, _VP, _LL, _I, _I, _I, _I, _I, _VP]),

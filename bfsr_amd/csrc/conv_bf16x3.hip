@@ -44,9 +44,15 @@ template <> struct Sp<2> {
     static __device__ __forceinline__ f32x16_t mfma(frag a, frag b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 // the eight values of one (position, k half) unit -> PL fragments
+// amax (PL = 2 only): running max |x| of everything this thread hands to the fp16 split -- the range guard of that split: a value
+// >= 65504 becomes inf in its hi plane.  (A NaN input does not raise amax -- v_max ignores it -- but it stays NaN through the conv.)
 template <int PL>
-__device__ __forceinline__ void split_unit(const float (&v)[8], typename Sp<PL>::frag (&o)[PL])
+__device__ __forceinline__ void split_unit(const float (&v)[8], typename Sp<PL>::frag (&o)[PL], float& amax)
 {
+    if constexpr (PL == 2) {
+#pragma unroll
+        for (int c = 0; c < 8; c += 2) amax = fmaxf(amax, fmaxf(fabsf(v[c]), fabsf(v[c + 1])));
+    }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         float r = v[c];
@@ -81,6 +87,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_bf16x3_kernel(BfsrConvArgs
     constexpr int WV = (WSLAB / 8 + NT - 1) / NT;      // 16-byte weight loads per thread
     constexpr int IPL = NPOS * CK;                   // bf16 elements of one input plane
 
+    float amax = 0.f;                                                    // range guard of the fp16 split (split_unit)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     typedef typename Sp<PL>::elt elt;
     typedef typename Sp<PL>::frag frag;
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_bf16x3_kernel(BfsrConvArgs
 #pragma unroll
                     for (int c = 0; c < 8; ++c) u8[c] = vin[i][hf * 8 + c];
                     frag s8[PL];
-                    split_unit<PL>(u8, s8);
+                    split_unit<PL>(u8, s8, amax);
 #pragma unroll
                     for (int pl = 0; pl < PL; ++pl) *reinterpret_cast<frag*>(sIn + pl * IPL + (hf * NPOS + pos) * 8) = s8[pl];
                 }
@@ -208,6 +215,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_bf16x3_kernel(BfsrConvArgs
         }
     }
 
+    if (PL == 2 && p.flag && __any((int)!(amax < 65504.f))) { if ((threadIdx.x & 63) == 0) atomicOr(p.flag, 1u); }   // range guard of the fp16 split
     // ---- epilogue (fp32, identical stage order to conv_mfma_kernel)
     const long long HW = (long long)H * W;
     const int gx = x0 + l31;
@@ -225,6 +233,44 @@ __global__ __launch_bounds__(NW * 64, MINB) void conv_bf16x3_kernel(BfsrConvArgs
         const __amdgpu_buffer_rsrc_t rs_r1 = tensor_rsrc(p.res1, p.res1_bs);
         const __amdgpu_buffer_rsrc_t rs_r2 = tensor_rsrc(p.res2, p.res2_bs);
         const float a1 = p.res1 ? p.alpha1 : 1.f, a2 = p.res2 ? p.alpha2 : 1.f;
+        if (p.y_fmt == 1) {
+            // quad-major output (and pre_add) [Cout/4][H][W][4]: the four channels (r&3) of an accumulator group are one 16-byte access
+            // (the private layout coupling_head / coupling_tail read, include/bfsr_hip.h); no residuals in this form (launcher)
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co0 = (cg * MR + m) * 32 + 8 * g + 4 * lhi;
+                    if (co0 >= p.Cout) continue;
+                    float4 q0[4]; float q1[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        q0[e] = make_float4(0.f, 0.f, 1.f, 0.f); q1[e] = 1.f;
+                        if (epi) { q0[e] = epi[(co0 + e) * 2]; q1[e] = epi[(co0 + e) * 2 + 1].x; }
+                    }
+#pragma unroll
+                    for (int n = 0; n < NR; ++n) {
+                        const int gy = y0 + wave * NR + n;
+                        if (gy >= H) continue;
+                        const unsigned ob = (unsigned)((((long long)(co0 >> 2) * HW + (long long)gy * W + gx) * 16));
+                        float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if constexpr (T) if (p.pre_add) pv = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_pre, ob, 0, 0));
+                        const float pa_[4] = {pv.x, pv.y, pv.z, pv.w};
+                        float o4[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = PL == 2 ? acc[m][n][4 * g + e] * p.acc_scale : acc[m][n][4 * g + e];
+                            v += q0[e].x;
+                            v += pa_[e];
+                            v += q0[e].y; v *= q0[e].z; v += q0[e].w;
+                            v = v > 0.f ? v : v * slope;
+                            o4[e] = v * q1[e];
+                        }
+                        *reinterpret_cast<float4*>(reinterpret_cast<char*>(p.y + (long long)b * p.y_bs) + ob) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+                    }
+                }
+            return;
+        }
 #pragma unroll
         for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -294,6 +340,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_up2_bf16x3_kernel(BfsrConvArg
     constexpr int TAPS = 16, MW = 32 * MR, HT = 8;                       // HT = matrices of one row parity; MR = 32-cout M tiles per workgroup
     constexpr int WPL = HT * MW * CK, WSLAB = PL * WPL, WV = (WSLAB / 8 + NT - 1) / NT, IPL = NPOS * CK;
     constexpr int GPL = TAPS * MW * CK;                                  // one plane of all 16 matrices in global memory
+    float amax = 0.f;                                                    // range guard of the fp16 split (split_unit)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     typedef typename Sp<PL>::elt elt;
     typedef typename Sp<PL>::frag frag;
@@ -371,7 +418,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_up2_bf16x3_kernel(BfsrConvArg
 #pragma unroll
                     for (int c = 0; c < 8; ++c) u8[c] = vin[i][hf * 8 + c];
                     frag s8[PL];
-                    split_unit<PL>(u8, s8);
+                    split_unit<PL>(u8, s8, amax);
 #pragma unroll
                     for (int pl = 0; pl < PL; ++pl) *reinterpret_cast<frag*>(sIn + pl * IPL + (hf * NPOS + pos) * 8) = s8[pl];
                 }
@@ -420,6 +467,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_up2_bf16x3_kernel(BfsrConvArg
         }
     }
 
+    if (PL == 2 && p.flag && __any((int)!(amax < 65504.f))) { if ((threadIdx.x & 63) == 0) atomicOr(p.flag, 1u); }   // range guard of the fp16 split
     // ---- epilogue (same stage order as conv_mfma_kernel); lane = source column -> two adjacent output pixels
     const int sx = x0 + l31;
     if (sx >= Ws) return;
@@ -434,6 +482,46 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_up2_bf16x3_kernel(BfsrConvArg
         const float* r1 = p.res1 ? p.res1 + (long long)b * p.res1_bs : nullptr;
         const float* r2 = p.res2 ? p.res2 + (long long)b * p.res2_bs : nullptr;
         float* yb = p.y + (long long)b * p.y_bs;
+        if (p.y_fmt == 1) {
+            // quad-major output (and pre_add) [Cout/4][H][W][4]: a lane's two adjacent output pixels x the four channels of an accumulator
+            // group are 32 contiguous bytes (two 16-byte accesses instead of four 8-byte ones); no residuals in this form (launcher)
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co0 = (cg * MR + m) * 32 + 8 * g + 4 * lhi;
+                if (co0 >= p.Cout) continue;
+                float4 q0[4]; float q1[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    q0[e] = make_float4(0.f, 0.f, 1.f, 0.f); q1[e] = 1.f;
+                    if (epi) { q0[e] = epi[(co0 + e) * 2]; q1[e] = epi[(co0 + e) * 2 + 1].x; }
+                }
+#pragma unroll
+                for (int n = 0; n < NR; ++n) {
+                    const int sy = y0 + wave * NR + n;
+                    if (sy >= Hs) continue;
+                    const long long o = ((long long)(co0 >> 2) * HW + (long long)(2 * sy + pa) * W + 2 * sx) * 4;
+                    float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
+                    if constexpr (T) if (pre) { t0 = *reinterpret_cast<const float4*>(pre + o); t1 = *reinterpret_cast<const float4*>(pre + o + 4); }
+                    const float pa0[4] = {t0.x, t0.y, t0.z, t0.w}, pa1[4] = {t1.x, t1.y, t1.z, t1.w};
+                    float v0[4], v1[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float a = acc[m][0][n][4 * g + e], c = acc[m][1][n][4 * g + e];
+                        if (PL == 2) { a *= p.acc_scale; c *= p.acc_scale; }
+                        a += q0[e].x; c += q0[e].x;
+                        a += pa0[e]; c += pa1[e];
+                        a = (a + q0[e].y) * q0[e].z + q0[e].w; c = (c + q0[e].y) * q0[e].z + q0[e].w;
+                        a = a > 0.f ? a : a * slope; c = c > 0.f ? c : c * slope;
+                        v0[e] = a * q1[e]; v1[e] = c * q1[e];
+                    }
+                    *reinterpret_cast<float4*>(yb + o) = make_float4(v0[0], v0[1], v0[2], v0[3]);
+                    *reinterpret_cast<float4*>(yb + o + 4) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -504,6 +592,7 @@ __global__ __launch_bounds__(NW * 64, 4) void conv_up4_bf16x3_kernel(BfsrConvArg
     constexpr int MW = 32, MAXM = 10, MEL = 2 * MW * 8;                   // MEL = bf16 elements of one matrix chunk
     constexpr int WPL = MAXM * MEL, WSLAB = PL * WPL, WV = (WSLAB / 8 + NT - 1) / NT, IPL = NPOS * CK;
     constexpr int GPL = 25 * MEL;                                         // one plane of all 25 matrices in global memory
+    float amax = 0.f;                                                    // range guard of the fp16 split (split_unit)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     typedef typename Sp<PL>::elt elt;
     typedef typename Sp<PL>::frag frag;
@@ -616,7 +705,7 @@ __global__ __launch_bounds__(NW * 64, 4) void conv_up4_bf16x3_kernel(BfsrConvArg
 #pragma unroll
                     for (int c = 0; c < 8; ++c) u8[c] = vin[i][hf * 8 + c];
                     frag s8[PL];
-                    split_unit<PL>(u8, s8);
+                    split_unit<PL>(u8, s8, amax);
 #pragma unroll
                     for (int pl = 0; pl < PL; ++pl) *reinterpret_cast<frag*>(sIn + pl * IPL + (hf * NPOS + pos) * 8) = s8[pl];
                 }
@@ -632,6 +721,7 @@ __global__ __launch_bounds__(NW * 64, 4) void conv_up4_bf16x3_kernel(BfsrConvArg
         mfma_chunk(std::integral_constant<int, nrt>{});
     }
 
+    if (PL == 2 && p.flag && __any((int)!(amax < 65504.f))) { if ((threadIdx.x & 63) == 0) atomicOr(p.flag, 1u); }   // range guard of the fp16 split
     // ---- epilogue: lane = source column -> float4 of output columns 4sx..4sx+3 = classes (0, 1, 1, 2); rows of this class
     const int sx = x0 + l31;
     if (sx >= Ws) return;
@@ -790,6 +880,9 @@ extern "C" int bfsr_conv2d_up2_bf16x3(const BfsrConvArgs* a, void* stream)
     if (a->pre_add && ((reinterpret_cast<unsigned long long>(a->pre_add) & 7) || (a->pre_add_bs & 1))) return -1;
     if (a->res1 && ((reinterpret_cast<unsigned long long>(a->res1) & 7) || (a->res1_bs & 1))) return -1;
     if (a->res2 && ((reinterpret_cast<unsigned long long>(a->res2) & 7) || (a->res2_bs & 1))) return -1;
+    if (a->y_fmt != 0 && a->y_fmt != 1) return -1;
+    if (a->y_fmt == 1 && ((a->Cout & 3) || a->res1 || a->res2 || (reinterpret_cast<unsigned long long>(a->y) & 15) || (a->y_bs & 3) ||
+                          (a->pre_add && ((reinterpret_cast<unsigned long long>(a->pre_add) & 15) || (a->pre_add_bs & 3))))) return -1;
     const int v = a->tune ? a->tune : 801;
     switch (v) {
         case 402: return launch_up2_x3<4, 2>(*a, st);
@@ -802,7 +895,7 @@ extern "C" int bfsr_conv2d_up2_bf16x3(const BfsrConvArgs* a, void* stream)
 extern "C" int bfsr_conv2d_up4_bf16x3(const BfsrConvArgs* a, void* stream)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (!a || !a->x || !a->w || !a->y || a->w2 || a->x2 || a->res1 || a->res2 || a->mtile != 1) return -1;
+    if (!a || !a->x || !a->w || !a->y || a->w2 || a->x2 || a->res1 || a->res2 || a->mtile != 1 || a->y_fmt != 0) return -1;
     if (a->B <= 0 || a->H <= 0 || a->W <= 0 || (a->H & 3) || (a->W & 3) || a->Cin <= 0 || a->Cout <= 0) return -1;
     if ((long long)a->Cin * (a->H / 4) * (a->W / 4) * 4 >= (1LL << 31)) return -1;
     if ((reinterpret_cast<unsigned long long>(a->y) & 15) || (a->y_bs & 3)) return -1;           // float4 rows
@@ -818,6 +911,10 @@ extern "C" int bfsr_conv2d_bf16x3(const BfsrConvArgs* a, void* stream)
     if (a->in_shift && (((a->H >> a->in_shift) << a->in_shift) != a->H || ((a->W >> a->in_shift) << a->in_shift) != a->W)) return -1;
     if ((long long)a->Cin * (a->H >> a->in_shift) * (a->W >> a->in_shift) * 4 >= (1LL << 31)) return -1;
     if ((a->pre_add || a->res1 || a->res2) && (long long)a->Cout * a->H * a->W * 4 >= (1LL << 31)) return -1;
+    if (a->y_fmt != 0 && a->y_fmt != 1) return -1;
+    if (a->y_fmt == 1 && ((a->Cout & 3) || a->res1 || a->res2 || (long long)a->Cout * a->H * a->W * 4 >= (1LL << 31) ||
+                          (reinterpret_cast<unsigned long long>(a->y) & 15) || (a->y_bs & 3) ||
+                          (a->pre_add && ((reinterpret_cast<unsigned long long>(a->pre_add) & 15) || (a->pre_add_bs & 3))))) return -1;
     // 3x3: 8-wave workgroups (2 waves per SIMD hide each other's LDS latency); one tile row per wave for 32-cout layers
     // (2 workgroups per CU) and for small grids, two rows otherwise.  1x1: 4 waves x 4 rows.
     int NR, NW = 8;

@@ -429,7 +429,7 @@ __global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64
             if (!has_next) break; it = nxt; cur = nitem; continue; }     // ablation: no epilogue (acc kept alive)
         if constexpr (DEF) {
             for (int k = nchunk; k < 2 * nstage; ++k) phase_all(k);  // fewer chunks than phases (the 64-channel trunk_conv with residual)
-            asm volatile("s_nop 11" ::: "memory");                 // MFMA result -> VALU read inside the asm below
+            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");       // MFMA result -> VALU read inside the asm below: 20 wait states (>= 19 of a 16-pass XDL op), self-sufficient                 // MFMA result -> VALU read inside the asm below
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -457,7 +457,7 @@ __global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64
         // swap of element 0 (every output channel became channel 0); asm statements are opaque to it.  The compiler pads
         // neither the MFMA -> VALU-read hazard (12 wait states for an 8-pass MFMA) nor the VALU-write -> permlane hazard
         // (2 states) around an asm statement, so both pads are inside the strings.
-        asm volatile("s_nop 11" ::: "memory");
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");       // MFMA result -> VALU read inside the asm below: 20 wait states (>= 19 of a 16-pass XDL op), self-sufficient
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(NW * 64, X3 == 0 ? 4 : 2) void linf_mlp_kernel(Bfsr
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             float v[2][8];
-            asm volatile("s_nop 11" ::: "memory");                 // MFMA result -> VALU read inside the asm below
+            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");       // MFMA result -> VALU read inside the asm below: 20 wait states (>= 19 of a 16-pass XDL op), self-sufficient                 // MFMA result -> VALU read inside the asm below
 #pragma unroll
             for (int qd = 0; qd < 2; ++qd)
 #pragma unroll

@@ -83,6 +83,8 @@ class HipOps(object):
         self.split = os.environ.get("BFSR_SPLIT", "f16x2")
         if self.split not in ("f16x2", "bf16x3"):
             raise ValueError("BFSR_SPLIT must be 'f16x2' or 'bf16x3'")
+        # device word the fp16-split kernels raise when an operand leaves their range (check_range())
+        self.range_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
 
     def _launch(self, key, fn):
         if self._keylog is not None:
@@ -166,7 +168,7 @@ class HipOps(object):
         return self.conv_f16(x, pw, out, _kind="bf16x3", **kw)
 
     def conv_f16(self, x, pw, out, in_shift=0, epi=None, pre_add=None, act=ACT_NONE, slope=0.2, res1=None, alpha1=1.0,
-                 res2=None, alpha2=1.0, tune=0, _kind="f16"):
+                 res2=None, alpha2=1.0, tune=0, _kind="f16", y_fmt=0):
         """Same contract as conv(), contraction in fp16 on the 16x faster MFMA (inputs/weights rounded to fp16)."""
         xp, xbs, Cin, Hs, Ws = _view(x, "conv_f16.x")
         yp, ybs, Cout, H, W = _view(out, "conv_f16.out")
@@ -185,7 +187,7 @@ class HipOps(object):
         if pw.arith == 1:
             if _kind != "bf16x3":
                 raise ValueError("conv_f16: a two-term fp16 split packing belongs to conv_x3")
-            a.arith, a.acc_scale = 1, 1.0 / pw.scale
+            a.arith, a.acc_scale, a.flag = 1, 1.0 / pw.scale, self.range_flag.data_ptr()
         a.y, a.y_bs, a.Cout = yp, ybs, Cout
         a.B, a.H, a.W, a.KS, a.in_shift, a.mtile = out.shape[0], H, W, pw.KS, in_shift, mtile
         a.epi, a.act, a.slope = _ptr(epi), act, slope
@@ -198,6 +200,10 @@ class HipOps(object):
                 if al is not None:
                     setattr(a, "alpha" + name[-1], al)
         a.tune = tune
+        if y_fmt:                               # quad-major out / pre_add ([B][Cout/4][H][W][4] in the same buffers): split-conv kernels only
+            if _kind != "bf16x3":
+                raise ValueError("conv_f16: y_fmt=1 is a conv_x3 feature")
+            a.y_fmt = 1
         key = ("conv_" + ("f16x2" if pw.arith == 1 else _kind), pw.KS, mtile, Cin, Cout, out.shape[0], H, W)
         fn = getattr(self.lib, "bfsr_conv2d_" + _kind)
         _lib.check(self._launch(key, lambda: fn(C.byref(a), self._stream())), "conv2d_" + _kind)
@@ -336,7 +342,7 @@ class HipOps(object):
         """out [B,Cout,4h,4w] = epilogue(conv3x3(nearest_up4(x)) + pre_add) on the split contraction (25 pre-summed matrices)."""
         return self.conv_up2_x3(x, pw, out, epi=epi, pre_add=pre_add, act=act, slope=slope, _factor=4)
 
-    def conv_up2_x3(self, x, pw, out, epi=None, pre_add=None, act=ACT_NONE, slope=0.2, tune=0, _factor=2):
+    def conv_up2_x3(self, x, pw, out, epi=None, pre_add=None, act=ACT_NONE, slope=0.2, tune=0, _factor=2, y_fmt=0):
         """conv_up2 on the split contraction (fp32-accurate; the split is the one `pw` was packed with); channels at output resolution
         enter through pre_add (may be `out`)."""
         xp, xbs, Cin, h, w = _view(x, "conv_up2_x3.x")
@@ -350,12 +356,13 @@ class HipOps(object):
         a.B, a.H, a.W, a.KS, a.mtile, a.tune = out.shape[0], H, W, 3, pw.mtile, tune
         a.epi, a.act, a.slope = _ptr(epi), act, slope
         if pw.arith == 1:
-            a.arith, a.acc_scale = 1, 1.0 / pw.scale
+            a.arith, a.acc_scale, a.flag = 1, 1.0 / pw.scale, self.range_flag.data_ptr()
         fam = "_f2" if pw.arith == 1 else "_x3"
         if pre_add is not None:
             pp, bs, c, hh, ww = _view(pre_add, "conv_up2_x3.pre_add")
             assert (c, hh, ww) == (Cout, H, W)
             a.pre_add, a.pre_add_bs = pp, bs
+        a.y_fmt = int(bool(y_fmt))              # quad-major out / pre_add (x2 kernel only; the x4 launcher rejects it)
         if _factor == 4:
             key = ("conv_up4" + fam, 1, Cin, Cout, out.shape[0], H, W, 0)
             _lib.check(self._launch(key, lambda: self.lib.bfsr_conv2d_up4_bf16x3(C.byref(a), self._stream())), "conv2d_up4_bf16x3")
@@ -430,11 +437,13 @@ class HipOps(object):
         _lib.check(self._launch(("x3_unpack",) + tuple(out.shape), lambda: self.lib.bfsr_x3_unpack(xp, xbs, yp, ybs, x.shape[0], Cc, H, W, self._stream())), "x3_unpack")
         return out
 
-    def conv_x3s(self, x, pw, out, epi=None, act=ACT_NONE, slope=0.2, res1=None, alpha1=1.0, res2=None, alpha2=1.0, tune=0):
+    def conv_x3s(self, x, pw, out, epi=None, act=ACT_NONE, slope=0.2, res1=None, alpha1=1.0, res2=None, alpha2=1.0, tune=0, y_fmt=0):
         """3x3 conv over an x3 tensor `x` (weights: pack_conv_x3(w, 1)); `out` is an x3 view or an fp32 NCHW view; residuals
         are x3 views.  Same epilogue contract as conv().  h2 tensors (split == "f16x2") go to conv_h2x: same contract."""
         if x.dtype == torch.float16:
-            return self.conv_h2x(x, pw, out, epi=epi, act=act, slope=slope, res1=res1, alpha1=alpha1, res2=res2, alpha2=alpha2, tune=tune)
+            return self.conv_h2x(x, pw, out, epi=epi, act=act, slope=slope, res1=res1, alpha1=alpha1, res2=res2, alpha2=alpha2, tune=tune, y_fmt=y_fmt)
+        if y_fmt:
+            raise ValueError("conv_x3s: the quad-major output exists on the fp16-split kernels only")
         a = _lib.BfsrConvX3Args()
         a.x, a.x_bs, Cin, H, W = self._x3view(x, "conv_x3s.x")
         if out.dtype == torch.bfloat16:
@@ -482,7 +491,7 @@ class HipOps(object):
         xp, xbs, Cc, H, W = _view(x, "h2_pack.x")
         yp, ybs, c2, h2, w2 = self._h2view(out, "h2_pack.out")
         assert (Cc, H, W) == (c2, h2, w2) and x.shape[0] == out.shape[0]
-        _lib.check(self._launch(("h2_pack",) + tuple(x.shape), lambda: self.lib.bfsr_h2_pack(xp, xbs, yp, ybs, x.shape[0], Cc, H, W, self._stream())), "h2_pack")
+        _lib.check(self._launch(("h2_pack",) + tuple(x.shape), lambda: self.lib.bfsr_h2_pack(xp, xbs, yp, ybs, x.shape[0], Cc, H, W, self.range_flag.data_ptr(), self._stream())), "h2_pack")
         return out
 
     def h2_unpack(self, x, out):
@@ -506,15 +515,12 @@ class HipOps(object):
         if KS != 3 or Cin % 16:
             raise ValueError("conv_h2x: 3x3 weights with Cin % 16 == 0 only")
         scale = self.pow2_scale(w)
-        # BFSR_H2X_MT=2: 64-cout workgroup tiles (the input tile staged once for both M tiles, 78 instead of 2 x 59 KB per chunk) --
-        # parity-tested, measured 5-8 % SLOWER on conv5 (0.147 vs 0.136 ms at 8 x 160^2, 0.736 vs 0.700 ms at 16 x 256^2): the kernel
-        # is not bound by the bytes it stages
-        mt = 2 if Cout % 64 == 0 and os.environ.get("BFSR_H2X_MT", "1") == "2" else 1
+        mt = 1          # 64-cout workgroup tiles (round 3, BFSR_H2X_MT=2) were measured 5-8 % slower and are gone
         packed = torch.empty(self.lib.bfsr_conv_packed_size_h2x(Cout, Cin, mt), dtype=torch.int16)
         _lib.check(self.lib.bfsr_pack_conv_weight_h2x(w.data_ptr(), Cout, Cin, mt, scale, packed.data_ptr()), "pack_h2x")
         return packed.to(self.device), scale, mt
 
-    def conv_h2x(self, x, pw, out, epi=None, act=ACT_NONE, slope=0.2, res1=None, alpha1=1.0, res2=None, alpha2=1.0, tune=0):
+    def conv_h2x(self, x, pw, out, epi=None, act=ACT_NONE, slope=0.2, res1=None, alpha1=1.0, res2=None, alpha2=1.0, tune=0, y_fmt=0):
         """3x3 conv over an h2 tensor `x` at fp32-class accuracy (both planes x two-term fp16 weights, three products; conv_h2s.hip,
         conv3x3_h2x_kernel).  `pw` = pack_conv_x3(w, ...) (the fp16 packing is derived lazily from its kept OIHW copy); `out` is an
         h2 view (both planes) or an fp32 NCHW view; residuals are h2 views.  Same epilogue contract as conv()."""
@@ -525,12 +531,12 @@ class HipOps(object):
             a.y_fmt = 1
         else:
             a.y, a.y_bs, Cout, H2, W2 = _view(out, "conv_h2x.out")
-            a.y_fmt = 0
+            a.y_fmt = 2 if y_fmt else 0             # y_fmt=1: fp32 quad-major [B][Cout/4][H][W][4] in the same buffer
         if (Cin, Cout, H, W) != (pw.Cin, pw.Cout, H2, W2) or pw.KS != 3 or x.shape[0] != out.shape[0]:
             raise ValueError("conv_h2x: shape mismatch x%s out%s weight(Cout=%d,Cin=%d)" % (tuple(x.shape), tuple(out.shape), pw.Cout, pw.Cin))
         a.Cin, a.Cout = Cin, Cout
         wdata, scale, mt = pw.variant("h2x", lambda w_, m_: self._pack_h2x(w_))
-        a.w, a.acc_scale, a.mtile = wdata.data_ptr(), 1.0 / scale, mt
+        a.w, a.acc_scale, a.mtile, a.flag = wdata.data_ptr(), 1.0 / scale, mt, self.range_flag.data_ptr()
         a.B, a.H, a.W = out.shape[0], H, W
         a.epi, a.act, a.slope, a.tune = _ptr(epi), act, slope, tune
         for name, t, al in (("res1", res1, alpha1), ("res2", res2, alpha2)):
@@ -670,102 +676,83 @@ class HipOps(object):
                    "flow_pointwise(C=%d)" % Cc)
         return z_out
 
-    # ---- the sequential part of a coupled FlowStep in two kernels (coupling.hip) -----------------------------------------------
+    # ---- the sequential part of a coupled FlowStep in two kernels (coupling.hip, conv_h2s.hip) ---------------------------------
     def pack_coupling_head(self, w0_z1, w2, shift0, scale0, shift2, scale2):
-        """fAffine.0 restricted to the z1 rows [64,Cz,3,3] + fAffine.2 [64,64(,1,1)] and their ActNorm (bias, exp(logs)) vectors."""
+        """fAffine.0 restricted to the z1 rows [64,Cz,3,3] + fAffine.2 [64,64(,1,1)] as two-term fp16 splits of w * 2^k, and their
+        ActNorm (bias, exp(logs)) vectors."""
         w0 = w0_z1.detach().to("cpu", torch.float32).contiguous()
         w2 = w2.detach().to("cpu", torch.float32).reshape(64, 64).contiguous()
         Cz = w0.shape[1]
         n = self.lib.bfsr_coupling_head_packed_size(Cz)
         if n <= 0 or w0.shape[0] != 64:
             raise ValueError("pack_coupling_head: unsupported shape %s" % (tuple(w0.shape),))
+        s0, s2 = self.pow2_scale(w0), self.pow2_scale(w2)
         packed = torch.empty(n, dtype=torch.int16)
-        _lib.check(self.lib.bfsr_pack_coupling_head(w0.data_ptr(), w2.data_ptr(), Cz, packed.data_ptr()), "pack_coupling_head")
+        _lib.check(self.lib.bfsr_pack_coupling_head(w0.data_ptr(), w2.data_ptr(), Cz, s0, s2, packed.data_ptr()), "pack_coupling_head")
 
         def epi(shift, scale):
             e = torch.zeros(64, 4, dtype=torch.float32)
             e[:, 0] = shift.detach().reshape(-1).to("cpu", torch.float32)
             e[:, 1] = scale.detach().reshape(-1).to("cpu", torch.float32)
             return e.to(self.device)
-        return packed.to(self.device), epi(shift0, scale0), epi(shift2, scale2), Cz
+        return packed.to(self.device), epi(shift0, scale0), epi(shift2, scale2), Cz, 1.0 / s0, 1.0 / s2
 
-    def coupling_head(self, z, packed, pre_aff, hid, hid_fmt=0):
-        """hid [B,64,H,W] = relu(AN2(W2 . relu(AN0(conv3x3(z[:, :Cz]) + pre_aff)))) on the 3xBF16 split, 1x1 chained in registers.
-        hid_fmt=1: the same buffer holds hid octet-major ([B][8][H][W][8]: what coupling_tail(hid_fmt=1) reads; 4x fewer, wider
-        stores and loads) -- a private layout between the two kernels."""
-        wts, e0, e2, Cz = packed
+    def coupling_head(self, z, packed, pre_aff, hid, pre_fmt=0):
+        """hid (h2 tensor [B,8,2,H,W,8]) = relu(AN2(W2 . relu(AN0(conv3x3(z[:, :Cz]) + pre_aff)))) on the two-term fp16 split, the 1x1
+        chained in registers.  pre_fmt=1: pre_aff is handed over quad-major ([B][16][H][W][4] in the same buffer)."""
+        wts, e0, e2, Cz, as0, as2 = packed
         a = _lib.BfsrCouplingHeadArgs()
         a.z, a.z_bs, Cc, H, W = _view(z, "coupling_head.z")
         a.pre_aff, a.pre_aff_bs, c1, h1, w1 = _view(pre_aff, "coupling_head.pre_aff")
-        a.hid, a.hid_bs, c2, h2, w2 = _view(hid, "coupling_head.hid")
+        a.hid, a.hid_bs, c2, h2, w2 = self._h2view(hid, "coupling_head.hid")
         assert Cc >= Cz and (c1, h1, w1) == (64, H, W) and (c2, h2, w2) == (64, H, W)
         a.Cz, a.w, a.epi0, a.epi2 = Cz, wts.data_ptr(), e0.data_ptr(), e2.data_ptr()
-        a.B, a.H, a.W, a.hid_fmt = z.shape[0], H, W, int(hid_fmt)
+        a.acc_scale0, a.acc_scale2, a.pre_fmt = as0, as2, int(pre_fmt)
+        a.B, a.H, a.W, a.flag = z.shape[0], H, W, self.range_flag.data_ptr()
         key = ("coupling_head", Cz, z.shape[0], H, W)
         _lib.check(self._launch(key, lambda: self.lib.bfsr_coupling_head(C.byref(a), self._stream())), "coupling_head")
         return hid
 
     def pack_coupling_tail(self, w4, bias, post_scale):
-        """fAffine.4 (Conv2dZeros) [Cout,64,3,3] as 3-term bf16 planes for 16-row MFMA tiles + its bias and exp(3*logs)."""
+        """fAffine.4 (Conv2dZeros) [Cout,64,3,3] in conv_h2x's packing (two-term fp16 split of w * 2^k) + its bias and exp(3*logs)."""
         w = w4.detach().to("cpu", torch.float32).contiguous()
         Cout, Cin = w.shape[0], w.shape[1]
-        n = self.lib.bfsr_coupling_tail_packed_size(Cin, Cout)
-        if n <= 0:
+        if Cin != 64 or Cout > 32 or tuple(w.shape[2:]) != (3, 3):
             raise ValueError("pack_coupling_tail: unsupported shape %s" % (tuple(w.shape),))
-        packed = torch.empty(n, dtype=torch.float32)
-        _lib.check(self.lib.bfsr_pack_coupling_tail(w.data_ptr(), Cin, Cout, packed.data_ptr()), "pack_coupling_tail")
-        return packed.to(self.device), self.vec(bias), self.vec(post_scale), Cout
+        scale = self.pow2_scale(w)
+        packed = torch.empty(self.lib.bfsr_coupling_tail_packed_size(Cin, Cout), dtype=torch.int16)
+        _lib.check(self.lib.bfsr_pack_coupling_tail(w.data_ptr(), Cin, Cout, scale, packed.data_ptr()), "pack_coupling_tail")
+        return packed.to(self.device), self.vec(bias), self.vec(post_scale), Cout, 1.0 / scale
 
-    def coupling_tail(self, hid, packed, z_in, z_out, reverse, h_ft=None, w=None, an_bias=None, an_escale=None, eps=1e-4, hid_fmt=0):
-        """h_aff = Conv2dZeros(hid), then the pointwise chain of flow_pointwise(z_in, z_out, reverse, h_aff=h_aff, h_ft, w, an_*)."""
-        wts, bias, ps, Cout = packed
+    def coupling_tail(self, hid, packed, z_in, z_out, reverse, h_ft=None, w=None, an_bias=None, an_escale=None, eps=1e-4, h_ft_fmt=0):
+        """h_aff = Conv2dZeros(hid) over the h2 tensor `hid`, then the pointwise chain of flow_pointwise(z_in, z_out, reverse,
+        h_aff=h_aff, h_ft, w, an_*) as the conv's epilogue (conv3x3_h2x_kernel, coupling-tail epilogue)."""
+        wts, bias, ps, Cout, acc_scale = packed
         a = _lib.BfsrCouplingTailArgs()
-        a.hid, a.hid_bs, a.Cin, H, W = _view(hid, "coupling_tail.hid")
+        a.hid, a.hid_bs, a.Cin, H, W = self._h2view(hid, "coupling_tail.hid")
         a.z_in, a.z_in_bs, Cc, h1, w1 = _view(z_in, "coupling_tail.z_in")
         a.z_out, a.z_out_bs, c2, h2, w2 = _view(z_out, "coupling_tail.z_out")
         assert (Cc, h1, w1) == (c2, h2, w2) == (Cc, H, W) and Cout == 2 * (Cc - Cc // 2)
         if h_ft is not None:
             a.h_ft, a.h_ft_bs, c, h, ww = _view(h_ft, "coupling_tail.h_ft")
             assert (c, h, ww) == (2 * Cc, H, W)
-        a.w, a.bias, a.post_scale = wts.data_ptr(), bias.data_ptr(), ps.data_ptr()
+        a.w, a.acc_scale, a.bias, a.post_scale = wts.data_ptr(), acc_scale, bias.data_ptr(), ps.data_ptr()
         a.wmat, a.an_bias, a.an_escale = _ptr(w), _ptr(an_bias), _ptr(an_escale)
-        a.B, a.C, a.H, a.W, a.reverse, a.eps, a.hid_fmt = z_in.shape[0], Cc, H, W, int(bool(reverse)), eps, int(hid_fmt)
+        a.B, a.C, a.H, a.W, a.reverse, a.eps, a.h_ft_fmt = z_in.shape[0], Cc, H, W, int(bool(reverse)), eps, int(h_ft_fmt)
+        a.flag = self.range_flag.data_ptr()
         key = ("coupling_tail", int(bool(reverse)), Cc, z_in.shape[0], H, W)
         _lib.check(self._launch(key, lambda: self.lib.bfsr_coupling_tail(C.byref(a), self._stream())), "coupling_tail(C=%d)" % Cc)
         return z_out
 
-    # ---- ... and in ONE kernel (coupling_step.hip): hid stays in LDS ------------------------------------------------------------
-    def pack_coupling_step(self, w0_z1, w2, shift0, scale0, shift2, scale2, w4, bias4, post_scale4):
-        """Everything bfsr_coupling_step needs of one step's fAffine net: the head pack (fAffine.0 z1 rows + fAffine.2 + ActNorms) and
-        fAffine.4 (Conv2dZeros [Cout,64,3,3]) in the fragment order of the fused kernel's last stage."""
-        wh, e0, e2, Cz = self.pack_coupling_head(w0_z1, w2, shift0, scale0, shift2, scale2)
-        w = w4.detach().to("cpu", torch.float32).contiguous()
-        Cout = w.shape[0]
-        n = self.lib.bfsr_coupling_step_tail_packed_size(Cout)
-        if n <= 0 or tuple(w.shape[1:]) != (64, 3, 3):
-            raise ValueError("pack_coupling_step: unsupported fAffine.4 shape %s" % (tuple(w.shape),))
-        packed = torch.empty(n, dtype=torch.int16)
-        _lib.check(self.lib.bfsr_pack_coupling_step_tail(w.data_ptr(), Cout, packed.data_ptr()), "pack_coupling_step_tail")
-        return wh, e0, e2, Cz, packed.to(self.device), self.vec(bias4), self.vec(post_scale4), Cout
-
-    def coupling_step(self, z_in, z_out, packed, pre_aff, reverse, h_ft=None, w=None, an_bias=None, an_escale=None, eps=1e-4):
-        """The sequential remainder of a coupled FlowStep in one launch: coupling_head + coupling_tail semantics, z_out != z_in."""
-        wh, e0, e2, Cz, wt, bias, ps, Cout = packed
-        a = _lib.BfsrCouplingStepArgs()
-        a.z_in, a.z_in_bs, Cc, H, W = _view(z_in, "coupling_step.z_in")
-        a.z_out, a.z_out_bs, c2, h2, w2 = _view(z_out, "coupling_step.z_out")
-        a.pre_aff, a.pre_aff_bs, c1, h1, w1 = _view(pre_aff, "coupling_step.pre_aff")
-        assert (c2, h2, w2) == (Cc, H, W) and (c1, h1, w1) == (64, H, W) and Cz == Cc // 2 and Cout == 2 * (Cc - Cc // 2)
-        if h_ft is not None:
-            a.h_ft, a.h_ft_bs, c, h, ww = _view(h_ft, "coupling_step.h_ft")
-            assert (c, h, ww) == (2 * Cc, H, W)
-        a.w_head, a.w_tail, a.epi0, a.epi2 = wh.data_ptr(), wt.data_ptr(), e0.data_ptr(), e2.data_ptr()
-        a.bias, a.post_scale = bias.data_ptr(), ps.data_ptr()
-        a.wmat, a.an_bias, a.an_escale = _ptr(w), _ptr(an_bias), _ptr(an_escale)
-        a.B, a.C, a.H, a.W, a.reverse, a.eps = z_in.shape[0], Cc, H, W, int(bool(reverse)), eps
-        key = ("coupling_step", int(bool(reverse)), Cc, z_in.shape[0], H, W)
-        _lib.check(self._launch(key, lambda: self.lib.bfsr_coupling_step(C.byref(a), self._stream())), "coupling_step(C=%d)" % Cc)
-        return z_out
+    # ---- range guard of the fp16 split ------------------------------------------------------------------------------------------
+    def check_range(self):
+        """Raise if a kernel of the two-term fp16 split met a value it cannot represent (|x| >= 2^15, inf or NaN) since the last
+        call.  One 4-byte device->host copy (synchronises the current stream); the engines call it once per pass."""
+        v = int(self.range_flag.item())
+        if v:
+            self.range_flag.zero_()
+            raise RuntimeError("bfsr_amd: a value left the range of the two-term fp16 split (flag 0x%x: bit 0 = operand >= 2^15 or NaN, "
+                               "bit 1 = non-finite flow state); rerun with BFSR_SPLIT=bf16x3 (fp32's exponent range, six products)" % v)
 
     def squeeze2d(self, x, y):
         xp, xbs, Cc, H, W = _view(x)

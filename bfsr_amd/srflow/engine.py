@@ -24,7 +24,9 @@ from .. import rng
 from .options import opt_get
 from ..ops import ACT_LRELU, ACT_NONE, ACT_RELU, MODE_BILINEAR, MODE_BILINEAR_AC, MODE_NEAREST
 
-FUSED_COUPLING_C = tuple(int(v) for v in os.environ.get("BFSR_COUPLING_C", "12,24").split(",") if v)
+FUSED_COUPLING_C = (12, 24)                                     # flow widths the coupling_head / coupling_tail pair is built for
+_QUADS = os.environ.get("BFSR_QUADS", "1") != "0"               # quad-major hand-over of pre_aff / h_ft to the coupling pair (A/B switch)
+_COUPLING_MODE = os.environ.get("BFSR_COUPLING", "fused")       # "unfused": generic launches for the sequential part (A/B and parity reference)
 # fea_up{k} lives at LR resolution * 2^shift
 _KEY_SHIFT = {"fea_up0": -1, "fea_up1": 0, "fea_up2": 1, "fea_up4": 2, "fea_up8": 3}
 
@@ -222,6 +224,7 @@ class SRFlowEngine(object):
         self.ws = _Workspace(ops)
         self._cond_key, self._cond = None, None
         self._side_stream = None
+        self._hid = {}                  # h2 tensors between coupling_head and coupling_tail, per (direction, level)
         self._load(sd)
 
     # ------------------------------------------------------------------------------------------
@@ -270,24 +273,15 @@ class SRFlowEngine(object):
                                      aff_scale=torch.exp(sd[a + "2.actnorm.logs"]), mtile=2)
                     st.aff4 = _ConvP(ops, sd[a + "4.weight"], bias=sd[a + "4.bias"],
                                      post_scale=torch.exp(sd[a + "4.logs"] * 3))
-                    # levels with 12 / 24 flow channels: the whole sequential part of the step as two kernels (coupling.hip):
-                    # 3xBF16 head (3x3 on z1 + hoisted partial, 1x1 chained in registers) and a 16-row-tile Conv2dZeros with
-                    # the pointwise chain as its tail.  BFSR_COUPLING=unfused keeps the four generic launches.
-                    # (measured without side-stream overlap, per step at BASELINE config 2: C = 12 @ 8x320^2: 467 -> 350 us;
-                    #  C = 24 @ 8x160^2 was slower, 200 -> 219 us, while the tail's conv ran on the fp32 MFMA; with the 3xBF16
-                    #  tail it is 0.6-1.0 ms faster per cfg2 step, A/B on one box -> FUSED_COUPLING_C = (12, 24))
+                    # levels with 12 / 24 flow channels: the whole sequential part of the step as TWO kernels: coupling_head (3x3 on z1 +
+                    # hoisted partial, 1x1 chained in registers; coupling.hip) -> hid as an h2 tensor -> coupling_tail (Conv2dZeros on the LDS-DMA
+                    # kernel with the pointwise chain as its epilogue; conv_h2s.hip).  Both run the two-term fp16 split, so the pair needs
+                    # BFSR_SPLIT=f16x2 (the default); otherwise, and with BFSR_COUPLING=unfused, the generic launches are used
+                    # (3x3 + fused 1x1, Conv2dZeros, flow_pointwise).  History of the pair: DESIGN.md section 5.
                     st.fused = (C in FUSED_COUPLING_C and w0.shape[0] == 64 and hasattr(ops, "coupling_head")
-                                and getattr(ops, "conv_mode", "f32") == "x3" and os.environ.get("BFSR_COUPLING", "fused") != "unfused")
-                    # BFSR_COUPLING=step: ONE kernel per step (coupling_step.hip, hid stays in LDS) -- correct and tested, but measured
-                    # SLOWER than the pair at every level (393 vs 351 us at C = 12 @ 8x320^2, 214 vs 152 us at C = 24 @ 8x160^2:
-                    # lock-step phases leave the matrix pipe idle 55 % of a tile, profiles/r03_step_trace.txt), so it is opt-in
-                    st.step = None
-                    if st.fused and hasattr(ops, "coupling_step") and os.environ.get("BFSR_COUPLING", "fused") == "step":
-                        st.step = ops.pack_coupling_step(w0[:, :cn].contiguous(), sd[a + "2.weight"], sd[a + "0.actnorm.bias"],
-                                                         torch.exp(sd[a + "0.actnorm.logs"]), sd[a + "2.actnorm.bias"],
-                                                         torch.exp(sd[a + "2.actnorm.logs"]), sd[a + "4.weight"], sd[a + "4.bias"],
-                                                         torch.exp(sd[a + "4.logs"] * 3))
-                    elif st.fused:
+                                and getattr(ops, "conv_mode", "f32") == "x3" and getattr(ops, "split", "") == "f16x2"
+                                and _COUPLING_MODE != "unfused")
+                    if st.fused:
                         st.head = ops.pack_coupling_head(w0[:, :cn].contiguous(), sd[a + "2.weight"], sd[a + "0.actnorm.bias"],
                                                          torch.exp(sd[a + "0.actnorm.logs"]), sd[a + "2.actnorm.bias"],
                                                          torch.exp(sd[a + "2.actnorm.logs"]))
@@ -315,6 +309,15 @@ class SRFlowEngine(object):
             sc = torch.cat([self.steps[i].ft0_scale for i in idxs], 0)
             wa = torch.cat([self.steps[i].aff0_ft_w for i in idxs], 0)
             hz = dict(idxs=idxs, up2=False)
+            # quad-major hand-over (see _hoist_level): which hoisted tensors of this level only the coupling pair reads
+            fused_all = all(getattr(self.steps[i], "fused", False) for i in idxs)
+            pos_of = {ly.index: p_ for p_, ly in enumerate(self.layers)}
+            def _prev_is_fused_step(i):
+                pv = self.layers[pos_of[i] - 1] if pos_of[i] > 0 else None
+                return (pv is not None and pv.type == "step" and pv.coupled and pv.level == level
+                        and getattr(self.steps[pv.index], "fused", False))
+            hz["hft_q4"] = set(i for i in idxs if getattr(self.steps[i], "fused", False) and _prev_is_fused_step(i))
+            hz["pre_q4"] = fused_all and (self._taps_up2(level) in (0, 1, False, None)) and getattr(ops, "conv_mode", "f32") == "x3"
             # Round 3: the 64 -> 16*64 key convs of the finer levels run on conv_x3s (LDS-DMA staging by loader waves, persistent) over
             # an x3 copy of the key channels instead of the register-staged conv_bf16x3 kernel: 5.51 -> 4.80 ms at 8 x 320^2
             # (175 -> 201 TFLOP/s-equivalent).  The 320 -> 1024 hoists of the coarser levels were measured too and are NOT moved:
@@ -378,13 +381,17 @@ class SRFlowEngine(object):
         """spatial size of flow level `level` for an LR of h x w: HR / 2^level."""
         return (h * self.scale) >> level, (w * self.scale) >> level
 
-    def conditioning(self, lr, reverse=False):
+    def conditioning(self, lr, reverse=False, quads=True):
         """RRDB features + hoisted ft-only coupling activations for an LR batch (cached per tensor).
-        reverse: the caller walks the levels from L down to 1 (decode), which decides which level is needed first."""
+        reverse: the caller walks the levels from L down to 1 (decode), which decides which level is needed first.
+        quads: hoisted tensors that only the coupling_head / coupling_tail pair reads are written QUAD-MAJOR ([B][C/4][H][W][4] in the
+        same buffer: 16-byte accesses on both sides; `pre_fmt`, `h_ft_fmt` of the conditioning entry say which).  False (the likelihood
+        path, which runs the generic kernels) keeps every tensor NCHW."""
         # the cache holds a reference to the keyed tensor, so its storage cannot be recycled for another input
         # while the entry is alive; a new tensor object or an in-place update (version bump) is a miss
-        key = (lr, lr._version)
-        if self._cond_key is not None and self._cond_key[0] is lr and self._cond_key[1] == lr._version:
+        quads = bool(quads) and _QUADS
+        key = (lr, lr._version, quads)
+        if self._cond_key is not None and self._cond_key[0] is lr and self._cond_key[1] == lr._version and self._cond_key[2] == quads:
             return self._cond
         ops, ws = self.ops, self.ws
         if self._side_stream is not None:
@@ -452,7 +459,7 @@ class SRFlowEngine(object):
                 side = self._side_stream
                 side.wait_stream(main_stream)
             with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-                cond[level] = self._hoist_level(level, hz, ft, B)
+                cond[level] = self._hoist_level(level, hz, ft, B, quads)
                 if side is not None:
                     cond[level]["ready"], cond[level]["joined"] = side.record_event(), set()
         self._cond_key, self._cond = key, cond
@@ -500,10 +507,16 @@ class SRFlowEngine(object):
         return (ws.get("hoist_hid%d" % level, B, K * 64, hl, wl), ws.get("pre_aff%d" % level, B, K * 64, hl, wl),
                 ws.get("h_ft%d" % level, B, K * 2 * Cz, hl, wl), Cz)
 
-    def _hoist_level(self, level, hz, ft, B):
+    def _hoist_level(self, level, hz, ft, B, quads=False):
         ops = self.ops
         f = ft[level]
         hid, pre_aff, h_ft, Cz = self._hoist_buffers(level, hz, ft, B)
+        # quad-major hand-over to the coupling pair: pre_aff as a whole (one batched conv writes it) when every step of the level is
+        # fused and its producers can (the x4 taps kernel cannot); h_ft per step (each step's Conv2dZeros writes its own slice) when the
+        # step's h_ft is only ever read by coupling_tail -- i.e. not by flow_pointwise as the first step of an encode pass
+        pq = int(quads and hz.get("pre_q4", False))
+        hq = {i: int(quads and i in hz.get("hft_q4", ())) for i in hz["idxs"]}
+        kq = dict(y_fmt=1) if pq else {}
         if hz["up2"]:
             taps = ft[self._lr_level()][:, 64:]
             if hz["x3"]:
@@ -519,10 +532,10 @@ class SRFlowEngine(object):
                     up = lambda _t, pw, out, **kw: ops.conv_up2_h2x(taps_h, pw, out, **kw)
                 up(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, pre_add=hid)
                 if hz["x3s"]:
-                    ops.conv_x3s(f3, hz["aff0_key"], pre_aff)
+                    ops.conv_x3s(f3, hz["aff0_key"], pre_aff, **kq)
                 else:
-                    ops.conv_x3(f, hz["aff0_key"], pre_aff)
-                up(taps, hz["aff0_taps"], pre_aff, pre_add=pre_aff)
+                    ops.conv_x3(f, hz["aff0_key"], pre_aff, **kq)
+                up(taps, hz["aff0_taps"], pre_aff, pre_add=pre_aff, **kq)
             else:
                 ops.conv_up2(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, key=(f, hz["ft0_key"]))
                 ops.conv_up2(taps, hz["aff0_taps"], pre_aff, key=(f, hz["aff0_key"]))
@@ -532,13 +545,13 @@ class SRFlowEngine(object):
             ops.conv_x3s(f3, hz["aff0_pw"], pre_aff)
         else:
             hz["ft0"].run(ops, f, hid, act=ACT_RELU)
-            hz["aff0"].run(ops, f, pre_aff)
+            hz["aff0"].run(ops, f, pre_aff, **kq)
         for k, i in enumerate(hz["idxs"]):
             st = self.steps[i]
             hk = hid[:, 64 * k: 64 * (k + 1)]
             st.ft2.run(ops, hk, hk, act=ACT_RELU)            # 1x1, in place (disjoint pixel tiles)
-            st.ft4.run(ops, hk, h_ft[:, 2 * Cz * k: 2 * Cz * (k + 1)])
-        return dict(pre_aff=pre_aff, h_ft=h_ft, slot={i: k for k, i in enumerate(hz["idxs"])}, C=Cz)
+            st.ft4.run(ops, hk, h_ft[:, 2 * Cz * k: 2 * Cz * (k + 1)], **(dict(y_fmt=1) if hq[i] else {}))
+        return dict(pre_aff=pre_aff, h_ft=h_ft, slot={i: k for k, i in enumerate(hz["idxs"])}, C=Cz, pre_fmt=pq, h_ft_fmt=hq)
 
     # ------------------------------------------------------------------------------------------
     def _self_cond(self, st, z, cnd, k, tag):
@@ -554,54 +567,23 @@ class SRFlowEngine(object):
         st.aff4.run(ops, hid, h_aff)
         return h_aff
 
-    def _pair(self, st, z, pre_k, hid, reverse, tag, kw):
-        """coupling_head -> coupling_tail (in place on z).  BFSR_PAIR_DBG selects diagnostic variants of the sequence (tools/exp/
-        shard_repro.py): ghead = generic fp32-MFMA kernel for the head's two convs, fmt0 = NCHW hid, nop = an unrelated launch
-        between the two kernels, oop = tail out of place."""
+    def _pair(self, st, z, pre_k, tag, reverse, kw, pre_fmt=0):
+        """coupling_head -> coupling_tail, in place on z; `hid` travels between them as an h2 tensor (fp16 hi + lo planes)."""
         ops = self.ops
-        dbg = os.environ.get("BFSR_PAIR_DBG", "")
-        if dbg == "ghead":
-            cn = z.shape[1] // 2
-            st.aff0_z1.run(ops, z[:, :cn], hid, pre_add=pre_k, act=ACT_RELU, stage2=(st.aff2.pw, st.aff2.epi, ACT_RELU))
-            ops.coupling_tail(hid, st.tail, z, z, reverse, hid_fmt=0, **kw)
-            return z
-        fmt = 0 if dbg == "fmt0" else 1
-        ops.coupling_head(z, st.head, pre_k, hid, hid_fmt=fmt)
-        if dbg.startswith("check"):                                     # is the head's output already wrong, or does the tail read it wrongly?
-            B_, _, H_, W_ = z.shape
-            if dbg == "check":
-                torch.cuda.synchronize()
-            got = hid.view(B_, 8, H_, W_, 8).permute(0, 1, 4, 2, 3).reshape(B_, 64, H_, W_).clone()
-            ref = self.ws.get("hid_ref", B_, 64, H_, W_)
-            cn = z.shape[1] // 2
-            st.aff0_z1.run(ops, z[:, :cn], ref, pre_add=pre_k, act=ACT_RELU, stage2=(st.aff2.pw, st.aff2.epi, ACT_RELU))
-            df = (got - ref).abs()
-            mx = float(df.max())
-            if mx > 1e-3:
-                idx = torch.nonzero(df > 1e-3)
-                print("HEAD MISMATCH max %.3e, %d elements, first %s last %s (C=%d %dx%d B=%d)" % (mx, idx.shape[0], idx[0].tolist(), idx[-1].tolist(), z.shape[1], H_, W_, B_), flush=True)
-        if dbg == "nop":
-            t = self.ws.get("nop", 1, 1, 1, 64)
-            ops.axpb_clamp(t, t)
-        if dbg == "oop":
-            out = self._pingpong(z, tag)
-            ops.coupling_tail(hid, st.tail, z, out, reverse, hid_fmt=fmt, **kw)
-            return out
-        ops.coupling_tail(hid, st.tail, z, z, reverse, hid_fmt=fmt, **kw)
-        return z
-
-    def _pingpong(self, z, tag):
-        """A workspace tensor of z's shape that is not z: the fused step kernel reads the z1 halo of neighbouring tiles, so it
-        cannot run in place and the flow state alternates between two buffers per level."""
-        a = self.ws.get("pp_%s_a" % tag, *z.shape)
-        return a if a.data_ptr() != z.data_ptr() else self.ws.get("pp_%s_b" % tag, *z.shape)
+        B, _, H, W = z.shape
+        key = "hid_" + tag
+        hid = self._hid.get(key)
+        if hid is None or tuple(hid.shape) != (B, 8, 2, H, W, 8):
+            hid = self._hid[key] = ops.h2_empty(B, 64, H, W)
+        ops.coupling_head(z, st.head, pre_k, hid, pre_fmt=pre_fmt)
+        return ops.coupling_tail(hid, st.tail, z, z, reverse, **kw)
 
     def encode(self, gt, lr, logdet=None):
         """normal flow (FlowUpsamplerNet.encode :217-251): gt [B,3,H,W] -> [eps_split..., z_final].
         logdet: optional float64 [B] accumulator that receives the flow's log-determinant (actnorm + invconv constants,
         sum log(scale) of both couplings per step, Split2d log-likelihood) -- the reference's `logdet` return value."""
         ops, ws = self.ops, self.ws
-        cond = self.conditioning(lr)
+        cond = self.conditioning(lr, quads=logdet is None)
         z = gt
         epses = []
         pending = None           # h_aff of the previous coupled step, applied lazily by the next head
@@ -637,13 +619,10 @@ class SRFlowEngine(object):
                             if nxt.coupled:
                                 kn = cnd["slot"][nxt.index]
                                 kw["h_ft"] = cnd["h_ft"][:, 2 * ly.C * kn: 2 * ly.C * (kn + 1)]
+                                kw["h_ft_fmt"] = cnd["h_ft_fmt"][nxt.index]
                             head_done = True
                         pre_k = cnd["pre_aff"][:, 64 * k: 64 * (k + 1)]
-                        if st.step is not None:
-                            z = ops.coupling_step(z, self._pingpong(z, "enc%d" % ly.level), st.step, pre_k, False, **kw)
-                        else:
-                            hid = ws.get("hid_enc%d" % ly.level, B, 64, H, W)                 # private octet-major layout between the two kernels
-                            z = self._pair(st, z, pre_k, hid, False, "enc%d" % ly.level, kw)
+                        z = self._pair(st, z, pre_k, "enc%d" % ly.level, False, kw, cnd["pre_fmt"])
                     else:
                         pending = self._self_cond(st, z, cnd, k, "enc%d" % ly.level)
                         if logdet is not None:
@@ -681,7 +660,7 @@ class SRFlowEngine(object):
         """reverse flow (FlowUpsamplerNet.decode :267-296): [eps_split..., z_final] -> sr [B,3,H,W].
         logdet: optional float64 [B] accumulator (every term of encode() enters with the opposite sign)."""
         ops, ws = self.ops, self.ws
-        cond = self.conditioning(lr, reverse=True)
+        cond = self.conditioning(lr, reverse=True, quads=logdet is None)
         ld_const, ld_levels = 0.0, set()
         epses = list(epses) if epses is not None else None
         zin = epses.pop() if epses is not None else z
@@ -700,12 +679,9 @@ class SRFlowEngine(object):
                     k = cnd["slot"][ly.index]
                     if getattr(st, "fused", False) and logdet is None:
                         pre_k = cnd["pre_aff"][:, 64 * k: 64 * (k + 1)]
-                        kw = dict(h_ft=cnd["h_ft"][:, 2 * C * k: 2 * C * (k + 1)], w=st.w_inv, an_bias=st.an_bias, an_escale=st.an_expneg)
-                        if st.step is not None:
-                            z = ops.coupling_step(z, self._pingpong(z, "dec%d" % ly.level), st.step, pre_k, True, **kw)
-                        else:
-                            hid = ws.get("hid_dec%d" % ly.level, z.shape[0], 64, H, W)
-                            z = self._pair(st, z, pre_k, hid, True, "dec%d" % ly.level, kw)
+                        kw = dict(h_ft=cnd["h_ft"][:, 2 * C * k: 2 * C * (k + 1)], h_ft_fmt=cnd["h_ft_fmt"][ly.index], w=st.w_inv,
+                                  an_bias=st.an_bias, an_escale=st.an_expneg)
+                        z = self._pair(st, z, pre_k, "dec%d" % ly.level, True, kw, cnd["pre_fmt"])
                     else:
                         h_aff = self._self_cond(st, z, cnd, k, "dec%d" % ly.level)
                         if logdet is not None:

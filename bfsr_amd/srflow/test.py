@@ -75,8 +75,10 @@ def _lp_lane(eng, prior_eng, lr, scale, sr_out, keep=None):
         keep.update(lr_up=lr_up, epses=epses_lr, epses_norm=epses, epses_learned=epses_learned, sr_raw=sr_raw, sr=sr_out)
 
 
-def lp_infer(model, prior_model, lr_t, return_all=False):
-    """lr_t [B,3,h,w] in [0,1] (h, w even) -> sr [B,3,s*h,s*w] clamped to [0,1]."""
+def lp_infer(model, prior_model, lr_t, return_all=False, check_range=True):
+    """lr_t [B,3,h,w] in [0,1] (h, w even) -> sr [B,3,s*h,s*w] clamped to [0,1].
+    check_range: raise if a kernel of the two-term fp16 split met a value outside its range during the pass (ops.check_range(): one
+    4-byte device->host read = a stream synchronisation; the reference's loop synchronises here anyway, test.py:150 `.cpu()`)."""
     net = model.netG.module
     eng = net.engine()
     ops = eng.ops
@@ -87,6 +89,8 @@ def lp_infer(model, prior_model, lr_t, return_all=False):
         sr = ops.empty(B, 3, h * scale, w * scale)
         keep = {} if return_all else None
         _lp_lane(eng, prior_model.engine(), lr, scale, sr, keep)
+        if check_range and hasattr(ops, "check_range"):
+            ops.check_range()
     return keep if return_all else sr
 
 

@@ -73,6 +73,11 @@ typedef struct BfsrConvArgs {
      *          [2^9, 2^10) (their lo terms stay normal fp16 numbers); the accumulators are multiplied by acc_scale = 1/scale before
      *          the epilogue; activations must stay below 65504 in magnitude. */
     int arith; float acc_scale;
+    /* y_fmt (bfsr_conv2d_bf16x3, bfsr_conv2d_up2_bf16x3 only) 0: y / pre_add are [B,Cout,H,W]; 1: both are QUAD-MAJOR [B][Cout/4][H][W][4] (16-byte
+     * accesses per accumulator group; the private layout bfsr_coupling_head reads pre_aff in); needs Cout % 4 == 0, no residuals */
+    int y_fmt;
+    /* optional device word (arith 1 only): bit 0 is set when an activation handed to the fp16 split is >= 65504 in magnitude */
+    unsigned* flag;
 } BfsrConvArgs;
 
 int bfsr_abi_version(void);
@@ -156,7 +161,8 @@ typedef struct BfsrConvX3Args {
     const unsigned short* res2; long long res2_bs; float alpha2;
     int tune;
     float acc_scale;                               /* bfsr_conv3x3_h2x only: 1 / (the power of two the weights were packed with) */
-    int mtile;                                     /* bfsr_conv3x3_h2x only: 32-cout M tiles per workgroup the weights were packed for (0/1 or 2) */
+    int mtile;                                     /* bfsr_conv3x3_h2x only: 32-cout M tiles per workgroup the weights were packed for (0 or 1) */
+    unsigned* flag;                                /* bfsr_conv3x3_h2x only, optional device word: bit 0 is set when a value written to an h2 output is >= 65504 */
 } BfsrConvX3Args;
 int bfsr_conv3x3_x3s(const BfsrConvX3Args* a, void* stream);
 int bfsr_x3_pack(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int C, int H, int W, void* stream);
@@ -195,7 +201,7 @@ long long bfsr_conv_packed_size_up2_h2x(int Cout, int Cin);
 int bfsr_pack_conv_weight_up2_h2x(const float* w16, int Cout, int Cin, float scale, unsigned short* packed);
 long long bfsr_conv_packed_size_h2x(int Cout, int Cin, int mtile);
 int bfsr_pack_conv_weight_h2x(const float* w_oihw, int Cout, int Cin, int mtile, float scale, unsigned short* packed);
-int bfsr_h2_pack(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int C, int H, int W, void* stream);
+int bfsr_h2_pack(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int C, int H, int W, unsigned* flag /* optional range guard */, void* stream);
 int bfsr_h2_unpack(const unsigned short* x, long long x_bs, float* y, long long y_bs, int B, int C, int H, int W, void* stream);
 
 /* ---- fused flow-step pointwise chain -----------------------------------------------------------
@@ -230,64 +236,44 @@ typedef struct BfsrFlowArgs {
 } BfsrFlowArgs;
 int bfsr_flow_pointwise(const BfsrFlowArgs* a, void* stream);
 
-/* ---- the sequential part of a conditional-affine FlowStep in two kernels (coupling.hip) -------------------------------------
+/* ---- the sequential part of a conditional-affine FlowStep in two kernels (coupling.hip, conv_h2s.hip) -------------------------
  * replaces, per coupled step of a level with C in {12, 24} flow channels (FlowAffineCouplingsAblation.py:57-135):
  *   bfsr_coupling_head: hid = relu(AN2(W2 . relu(AN0(conv3x3(z[:, :Cz]; W0z) + pre_aff))))     (fAffine.0 on the z1 rows + the hoisted
- *                       ft partial, fAffine.2; flow.Conv2d = conv without bias + ActNorm, flow.py:26-65); 3xBF16 arithmetic, the 1x1
- *                       chained in registers.  epi0 / epi2: [64][4] floats {ActNorm bias, exp(logs), 0, 0}.
- *   bfsr_coupling_tail: h_aff = (conv3x3(hid; W4) + b4) * exp(3*logs4)  (fAffine.4 = Conv2dZeros, flow.py:68-83) on 16-row MFMA tiles (exact 3-term bf16 split, fp32-accurate)
- *                       tiles, then the pointwise chain of bfsr_flow_pointwise with that h_aff (same argument meaning: h_ft, wmat,
- *                       an_bias / an_escale, reverse, eps; z_in and z_out may alias). */
+ *                       ft partial, fAffine.2; flow.Conv2d = conv without bias + ActNorm, flow.py:26-65); two-term fp16 split (three
+ *                       products, fp32 accumulation), the 1x1 chained in registers; hid leaves as an h2 tensor.
+ *   bfsr_coupling_tail: h_aff = (conv3x3(hid; W4) + b4) * exp(3*logs4)  (fAffine.4 = Conv2dZeros, flow.py:68-83) on the LDS-DMA kernel of
+ *                       bfsr_conv3x3_h2x, then -- as that kernel's epilogue -- the pointwise chain of bfsr_flow_pointwise with that h_aff
+ *                       (same argument meaning: h_ft, wmat, an_bias / an_escale, reverse, eps; z_in and z_out may alias). */
 typedef struct BfsrCouplingHeadArgs {
     const float* z; long long z_bs; int Cz;
     const float* pre_aff; long long pre_aff_bs;
+    int pre_fmt;                                      /* 0: pre_aff [B,64,H,W]; 1: quad-major [B][16][H][W][4] (a 16-byte load per channel quad) */
     const unsigned short* w;                          /* bfsr_pack_coupling_head */
-    const float* epi0; const float* epi2;
-    float* hid; long long hid_bs;
+    const float* epi0; const float* epi2;             /* [64] float4 {ActNorm shift, scale, 0, 0} of fAffine.0 / fAffine.2 */
+    float acc_scale0, acc_scale2;                     /* 1 / the power-of-two scales the weights were packed with */
+    unsigned short* hid; long long hid_bs;            /* OUT: h2 tensor [B][8][2 planes hi,lo][H][W][8] fp16; batch stride in fp16 elements */
     int B, H, W;
-    int hid_fmt;                                      /* 0: hid [B,64,H,W]; 1: octet-major [B][8][H][W][8] (32 B per pixel and channel
-                                                         octet: 8 x 16-byte stores per lane instead of 32 x 4-byte ones) */
+    unsigned* flag;                                   /* optional device word: bit 0 is set when a value handed to the fp16 split is >= 2^15 or NaN */
 } BfsrCouplingHeadArgs;
 typedef struct BfsrCouplingTailArgs {
-    const float* hid; long long hid_bs; int Cin;      /* Cin = 64 */
-    const float* w; const float* bias; const float* post_scale;      /* bfsr_pack_coupling_tail; [2*(C-C/2)] each */
+    const unsigned short* hid; long long hid_bs; int Cin;            /* h2 tensor written by bfsr_coupling_head; Cin = 64 */
+    const unsigned short* w; float acc_scale;                        /* bfsr_pack_conv_weight_h2x(fAffine.4, mtile 1, scale); acc_scale = 1/scale */
+    const float* bias; const float* post_scale;                      /* [2*(C-C/2)] each: Conv2dZeros bias and exp(3*logs) */
     const float* z_in; long long z_in_bs;
-    float* z_out; long long z_out_bs;
+    float* z_out; long long z_out_bs;                                /* may alias z_in (every lane reads and writes its own pixel) */
     const float* h_ft; long long h_ft_bs;
+    int h_ft_fmt;                                                    /* 0: h_ft [B,2C,H,W]; 1: quad-major [B][2C/4][H][W][4] */
     const float* wmat; const float* an_bias; const float* an_escale;
     int B, C, H, W, reverse;
     float eps;
-    int hid_fmt;                                      /* layout of hid, as BfsrCouplingHeadArgs.hid_fmt */
+    unsigned* flag;                                                  /* optional device word: bit 1 is set when the flow state leaves the finite range */
 } BfsrCouplingTailArgs;
 int bfsr_coupling_head(const BfsrCouplingHeadArgs* a, void* stream);
 int bfsr_coupling_tail(const BfsrCouplingTailArgs* a, void* stream);
-long long bfsr_coupling_head_packed_size(int Cz);                                   /* bf16 elements */
-int bfsr_pack_coupling_head(const float* w0_z1, const float* w2, int Cz, unsigned short* packed);
-long long bfsr_coupling_tail_packed_size(int Cin, int Cout);                        /* floats */
-int bfsr_pack_coupling_tail(const float* w, int Cin, int Cout, float* packed);
-
-/* The same FlowStep remainder as ONE kernel (coupling_step.hip; replaces the torch call sequence of
- * FlowAffineCouplingsAblation.py:80-93 + FlowStep.py:113-129 for a step: fAffine on cat[z1, ft] with the ft rows hoisted, the
- * self-conditional affine, the feature-conditional affine, InvertibleConv1x1 and ActNorm): `hid` never leaves the CU.
- *   w_head = bfsr_pack_coupling_head(fAffine.0[:, :Cz], fAffine.2), epi0 / epi2 as for bfsr_coupling_head;
- *   w_tail = bfsr_pack_coupling_step_tail(fAffine.4), bias / post_scale [2*(C-C/2)];
- *   h_ft, wmat, an_bias / an_escale, reverse, eps: exactly bfsr_coupling_tail's / bfsr_flow_pointwise's meaning.
- * C = 12 or 24.  z_in and z_out must NOT overlap (a tile reads the z1 halo its neighbours' outputs would overwrite): -1. */
-typedef struct BfsrCouplingStepArgs {
-    const float* z_in; long long z_in_bs;
-    float* z_out; long long z_out_bs;
-    const float* pre_aff; long long pre_aff_bs;       /* [B,64,H,W]: hoisted ft rows of fAffine.0 */
-    const float* h_ft; long long h_ft_bs;             /* [B,2C,H,W] or NULL */
-    const unsigned short* w_head; const unsigned short* w_tail;
-    const float* epi0; const float* epi2;             /* [64][4] {ActNorm bias, exp(logs), 0, 0} */
-    const float* bias; const float* post_scale;       /* fAffine.4: bias, exp(3*logs) */
-    const float* wmat; const float* an_bias; const float* an_escale;
-    int B, C, H, W, reverse;
-    float eps;
-} BfsrCouplingStepArgs;
-int bfsr_coupling_step(const BfsrCouplingStepArgs* a, void* stream);
-long long bfsr_coupling_step_tail_packed_size(int Cout);                               /* bf16 elements */
-int bfsr_pack_coupling_step_tail(const float* w4, int Cout, unsigned short* packed);   /* w4 [Cout][64][3][3] */
+long long bfsr_coupling_head_packed_size(int Cz);                                   /* fp16 elements */
+int bfsr_pack_coupling_head(const float* w0_z1, const float* w2, int Cz, float scale0, float scale2, unsigned short* packed);
+long long bfsr_coupling_tail_packed_size(int Cin, int Cout);                        /* fp16 elements; Cin = 64, Cout <= 32 */
+int bfsr_pack_coupling_tail(const float* w4, int Cin, int Cout, float scale, unsigned short* packed);   /* w4 [Cout][64][3][3] * scale, fp16 hi/lo */
 
 /* squeeze2d / unsqueeze2d, factor 2 (flow.py:122-152): x [B,C,H,W] <-> y [B,4C,H/2,W/2] */
 int bfsr_squeeze2d(const float* x, long long x_bs, float* y, long long y_bs, int B, int C, int H, int W,

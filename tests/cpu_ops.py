@@ -86,11 +86,11 @@ class CpuOps(object):
         out.copy_(self._x3_to_f32(x))
         return out
 
-    def conv_x3s(self, x, pw, out, epi=None, act=0, slope=0.2, res1=None, alpha1=1.0, res2=None, alpha2=1.0, tune=0):
+    def conv_x3s(self, x, pw, out, epi=None, act=0, slope=0.2, res1=None, alpha1=1.0, res2=None, alpha2=1.0, tune=0, y_fmt=0):
         f = self._x3_to_f32
         tmp = torch.empty(out.shape[0], pw.Cout, x.shape[3], x.shape[4]) if out.dtype == torch.bfloat16 else out
         self.conv(f(x), pw, tmp, epi=epi, act=act, slope=slope, res1=None if res1 is None else f(res1), alpha1=alpha1,
-                  res2=None if res2 is None else f(res2), alpha2=alpha2)
+                  res2=None if res2 is None else f(res2), alpha2=alpha2, y_fmt=y_fmt)
         if out.dtype == torch.bfloat16:
             self.x3_pack(tmp, out)
         return out
@@ -148,20 +148,20 @@ class CpuOps(object):
     def pack_conv_up2_x3(self, w):
         return self.pack_conv_up2(w, 1)
 
-    def conv_up2_x3(self, x, pw, out, epi=None, pre_add=None, act=0, slope=0.2, tune=0):
-        return self.conv_up2(x, pw, out, epi=epi, pre_add=pre_add.clone() if pre_add is not None else None, act=act, slope=slope)
+    def conv_up2_x3(self, x, pw, out, epi=None, pre_add=None, act=0, slope=0.2, tune=0, y_fmt=0):
+        return self.conv_up2(x, pw, out, epi=epi, pre_add=pre_add.clone() if pre_add is not None else None, act=act, slope=slope, y_fmt=y_fmt)
 
     def pack_conv_up2(self, w, mtile=2):
         return PackedConv(w.detach().to(torch.float32).contiguous().clone(), mtile)
 
-    def conv_up2(self, x, pw, out, epi=None, pre_add=None, act=ACT_NONE, slope=0.2, key=None):
+    def conv_up2(self, x, pw, out, epi=None, pre_add=None, act=ACT_NONE, slope=0.2, key=None, y_fmt=0):
         """Semantics: the plain 3x3 conv over cat[key channels, materialised nearest-x2 upsample] (original weights)."""
         xin, w = F.interpolate(x, scale_factor=2, mode="nearest"), pw
         if key is not None:
             x2, pk = key
             xin = torch.cat([x2, xin], 1)
             w = PackedConv(torch.cat([pk.w, pw.w], 1), pw.mtile)
-        return self.conv(xin, w, out, epi=epi, pre_add=pre_add, act=act, slope=slope)
+        return self.conv(xin, w, out, epi=epi, pre_add=pre_add, act=act, slope=slope, y_fmt=y_fmt)
 
     def pack_epilogue(self, Cout, bias=None, aff_shift=None, aff_scale=None, aff_post=None, post_scale=None):
         vs = dict(bias=bias, aff_shift=aff_shift, aff_scale=aff_scale, aff_post=aff_post, post_scale=post_scale)
@@ -171,7 +171,10 @@ class CpuOps(object):
 
     def conv(self, x, pw, out, in_shift=0, epi=None, pre_add=None, act=ACT_NONE, slope=0.2, res1=None, alpha1=1.0,
              res2=None, alpha2=1.0, tune=0, stage2=None, bias=None, aff_shift=None, aff_scale=None, aff_post=None,
-             post_scale=None):
+             post_scale=None, y_fmt=0):
+        """y_fmt=1: `out` and `pre_add` are quad-major ([B][Cout/4][H][W][4] in the same buffers; HipOps.conv_x3 / conv_up2_x3 / conv_h2x)."""
+        if y_fmt and pre_add is not None:
+            pre_add = self.quads(pre_add, inverse=True)
         if epi is not None:
             bias, aff_shift, aff_scale = epi["bias"], epi["aff_shift"], epi["aff_scale"]
             aff_post, post_scale = epi["aff_post"], epi["post_scale"]
@@ -210,7 +213,7 @@ class CpuOps(object):
             v = F.relu(v) if act2 == ACT_RELU else (F.leaky_relu(v, slope) if act2 == ACT_LRELU else v)
             if epi2 is not None and epi2["post_scale"] is not None:
                 v = v * _cv(epi2["post_scale"])
-        out.copy_(v)
+        out.copy_(self.quads(v) if y_fmt else v)
         return out
 
     def flow_pointwise(self, z_in, z_out, reverse, h_aff=None, h_ft=None, w=None, an_bias=None, an_escale=None, eps=1e-4,
@@ -351,39 +354,41 @@ class CpuOps(object):
                 f(scale2).reshape(-1))
 
     @staticmethod
-    def _hid_octets(hid, inverse=False):
-        """[B,64,H,W] values <-> the same buffer in the octet-major layout [B][8][H][W][8] of hid_fmt=1."""
-        B, Cc, H, W = hid.shape
+    def quads(t, inverse=False):
+        """[B,C,H,W] values <-> the same buffer quad-major [B][C/4][H][W][4] (pre_fmt / h_ft_fmt = 1 of the coupling kernels)."""
+        B, Cc, H, W = t.shape
         if inverse:
-            return hid.reshape(B, Cc // 8, H, W, 8).permute(0, 1, 4, 2, 3).reshape(B, Cc, H, W)
-        return hid.reshape(B, Cc // 8, 8, H, W).permute(0, 1, 3, 4, 2).reshape(B, Cc, H, W)
+            return t.reshape(B, Cc // 4, H, W, 4).permute(0, 1, 4, 2, 3).reshape(B, Cc, H, W)
+        return t.reshape(B, Cc // 4, 4, H, W).permute(0, 1, 3, 4, 2).reshape(B, Cc, H, W)
 
-    def coupling_head(self, z, packed, pre_aff, hid, hid_fmt=0):
+    def coupling_head(self, z, packed, pre_aff, hid, pre_fmt=0):
+        """hid: an h2 tensor (h2_empty(B, 64, H, W)) or, for the per-op tests, an fp32 [B,64,H,W] tensor."""
         w0, w2, s0, c0, s2, c2 = packed
+        if pre_fmt:
+            pre_aff = self.quads(pre_aff, inverse=True)
         t = F.relu((F.conv2d(z[:, :w0.shape[1]], w0, None, 1, 1) + pre_aff + _cv(s0)) * _cv(c0))
         v = F.relu((F.conv2d(t, w2) + _cv(s2)) * _cv(c2))
-        hid.copy_(self._hid_octets(v) if hid_fmt else v)
+        if hid.dtype == torch.float16:
+            self.h2_pack(v, hid)
+        else:
+            hid.copy_(v)
         return hid
 
     def pack_coupling_tail(self, w4, bias, post_scale):
         f = lambda t: t.detach().to(torch.float32).clone()
         return f(w4), f(bias).reshape(-1), f(post_scale).reshape(-1), w4.shape[0]
 
-    def coupling_tail(self, hid, packed, z_in, z_out, reverse, h_ft=None, w=None, an_bias=None, an_escale=None, eps=1e-4, hid_fmt=0):
+    def coupling_tail(self, hid, packed, z_in, z_out, reverse, h_ft=None, w=None, an_bias=None, an_escale=None, eps=1e-4, h_ft_fmt=0):
         w4, b4, ps, _ = packed
-        if hid_fmt:
-            hid = self._hid_octets(hid, inverse=True)
+        if hid.dtype == torch.float16:
+            hid = sum(self._h2_planes(hid))
+        if h_ft is not None and h_ft_fmt:
+            h_ft = self.quads(h_ft, inverse=True)
         h_aff = (F.conv2d(hid, w4, None, 1, 1) + _cv(b4)) * _cv(ps)
         return self.flow_pointwise(z_in, z_out, reverse, h_aff=h_aff, h_ft=h_ft, w=w, an_bias=an_bias, an_escale=an_escale, eps=eps)
 
-    def pack_coupling_step(self, w0_z1, w2, shift0, scale0, shift2, scale2, w4, bias4, post_scale4):
-        return self.pack_coupling_head(w0_z1, w2, shift0, scale0, shift2, scale2), self.pack_coupling_tail(w4, bias4, post_scale4)
-
-    def coupling_step(self, z_in, z_out, packed, pre_aff, reverse, h_ft=None, w=None, an_bias=None, an_escale=None, eps=1e-4):
-        assert z_in.data_ptr() != z_out.data_ptr(), "coupling_step is not an in-place operation"
-        head, tail = packed
-        hid = self.coupling_head(z_in, head, pre_aff, torch.empty(z_in.shape[0], 64, z_in.shape[2], z_in.shape[3]))
-        return self.coupling_tail(hid, tail, z_in, z_out, reverse, h_ft=h_ft, w=w, an_bias=an_bias, an_escale=an_escale, eps=eps)
+    def check_range(self):
+        pass
 
     @staticmethod
     def _ai_quads(ai, layers, D, inverse=False):
@@ -523,3 +528,4 @@ class CpuOpsX3(CpuOps):
     conv_x3s, parity-decomposed hoists, the fused LINF conditioning kernel) -- on the double these are exact fp32 restatements,
     so the reference goldens still apply"""
     conv_mode = "x3"
+    split = "f16x2"     # the engines then schedule the coupling_head / coupling_tail pair and the quad-major hand-over (x3 tensors stay lossless here)

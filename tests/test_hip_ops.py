@@ -327,93 +327,110 @@ def test_conv_nearest_upsample_on_read(hip):
     close(out, ref, 2e-5, "conv in_shift")
 
 
+def _h2_values(t):
+    """fp32 [B,C,H,W] values (hi + lo) of an h2 tensor, on the CPU."""
+    return sum(CPU._h2_planes(t.cpu()))
+
+
 @pytest.mark.parametrize("Cz", [6, 12])
-@pytest.mark.parametrize("hw", [(16, 40), (9, 33), (70, 70)])
+@pytest.mark.parametrize("hw", [(16, 40), (9, 33), (70, 70), (4, 32), (3, 5)])
 def test_coupling_head(hip, Cz, hw):
-    """coupling.hip head: 3x3 on z1 (+ hoisted partial, ActNorm, ReLU) -> register-chained 1x1 (+ ActNorm, ReLU), 3xBF16."""
+    """coupling.hip head: 3x3 on z1 (+ hoisted partial, ActNorm, ReLU) -> register-chained 1x1 (+ ActNorm, ReLU) on the two-term fp16
+    split, hid as an h2 tensor.  Ragged last tiles, images smaller than a tile; B = 3 exercises the persistent tile walk."""
     H, W = hw
-    B = 2
+    B = 3
     z, pre = rnd(61, B, 2 * Cz, H, W), rnd(62, B, 64, H, W, scale=0.5)
     w0, w2 = rnd(63, 64, Cz, 3, 3, scale=0.1), rnd(64, 64, 64, 1, 1, scale=0.1)
     s0, c0, s2, c2 = rnd(65, 64, scale=0.1), torch.exp(rnd(66, 64, scale=0.1)), rnd(67, 64, scale=0.1), torch.exp(rnd(68, 64, scale=0.1))
     ref = CPU.coupling_head(z, CPU.pack_coupling_head(w0, w2, s0, c0, s2, c2), pre, torch.empty(B, 64, H, W))
-    out = hip.coupling_head(hip.to_device(z), hip.pack_coupling_head(w0, w2, s0, c0, s2, c2), hip.to_device(pre), hip.empty(B, 64, H, W))
-    close(out, ref, 2e-5, "coupling_head Cz=%d" % Cz)
-    # the private octet-major layout of hid ([B][8][H][W][8], wide stores): the same values, permuted
-    o1 = hip.coupling_head(hip.to_device(z), hip.pack_coupling_head(w0, w2, s0, c0, s2, c2), hip.to_device(pre), hip.empty(B, 64, H, W), hid_fmt=1)
-    assert torch.equal(CPU._hid_octets(o1.cpu(), inverse=True), out.cpu()), "hid_fmt=1 must hold the values of hid_fmt=0"
+    pk = hip.pack_coupling_head(w0, w2, s0, c0, s2, c2)
+    out = hip.coupling_head(hip.to_device(z), pk, hip.to_device(pre), hip.h2_empty(B, 64, H, W))
+    close(_h2_values(out), ref, 2e-5, "coupling_head Cz=%d" % Cz)
+    # pre_aff handed over quad-major ([B][16][H][W][4], 16-byte loads): bit-identical result
+    o1 = hip.coupling_head(hip.to_device(z), pk, hip.to_device(CPU.quads(pre).contiguous()), hip.h2_empty(B, 64, H, W), pre_fmt=1)
+    assert torch.equal(o1.cpu(), out.cpu()), "pre_fmt=1 must give the values of pre_fmt=0"
+    hip.check_range()
+
+
+def test_coupling_head_on_channel_slices(hip):
+    """z1 and pre_aff as channel slices of wider buffers (batch stride != C*H*W), as the engine passes them."""
+    B, Cz, H, W = 2, 6, 20, 44
+    zbuf, prebuf = rnd(181, B, 20, H, W), rnd(182, B, 3 * 64, H, W, scale=0.5)
+    w0, w2 = rnd(163, 64, Cz, 3, 3, scale=0.1), rnd(164, 64, 64, 1, 1, scale=0.1)
+    s0, c0, s2, c2 = rnd(165, 64, scale=0.1), torch.exp(rnd(166, 64, scale=0.1)), rnd(167, 64, scale=0.1), torch.exp(rnd(168, 64, scale=0.1))
+    ref = CPU.coupling_head(zbuf[:, :12], CPU.pack_coupling_head(w0, w2, s0, c0, s2, c2), prebuf[:, 64:128], torch.empty(B, 64, H, W))
+    out = hip.coupling_head(hip.to_device(zbuf)[:, :12], hip.pack_coupling_head(w0, w2, s0, c0, s2, c2), hip.to_device(prebuf)[:, 64:128],
+                            hip.h2_empty(B, 64, H, W))
+    close(_h2_values(out), ref, 2e-5, "coupling_head on slices")
+
+
+def test_coupling_head_range_guard_is_loud(hip):
+    """The fp16 split cannot represent |x| >= 2^15: the kernel raises the device flag and check_range() turns it into an error."""
+    B, Cz, H, W = 1, 6, 8, 32
+    z, pre = rnd(61, B, 2 * Cz, H, W), rnd(62, B, 64, H, W, scale=0.5)
+    w0, w2 = rnd(63, 64, Cz, 3, 3, scale=0.1), rnd(64, 64, 64, 1, 1, scale=0.1)
+    one = torch.ones(64)
+    pk = hip.pack_coupling_head(w0, w2, 0 * one, one, 0 * one, one)
+    hip.check_range()                                  # clean so far
+    zb = z.clone()
+    zb[0, 2, 3, 7] = 7.0e4
+    hip.coupling_head(hip.to_device(zb), pk, hip.to_device(pre), hip.h2_empty(B, 64, H, W))
+    with pytest.raises(RuntimeError, match="range of the two-term fp16 split"):
+        hip.check_range()
+    hip.check_range()                                  # the flag was cleared
+    zb[0, 2, 3, 7] = float("nan")
+    hip.coupling_head(hip.to_device(zb), pk, hip.to_device(pre), hip.h2_empty(B, 64, H, W))
+    with pytest.raises(RuntimeError):
+        hip.check_range()
 
 
 @pytest.mark.parametrize("C", [12, 24])
 @pytest.mark.parametrize("reverse", [0, 1])
-@pytest.mark.parametrize("hw", [(16, 40), (9, 33), (70, 70)])
+@pytest.mark.parametrize("hw", [(16, 40), (9, 33), (70, 70), (5, 3), (37, 91)])
 def test_coupling_tail(hip, C, reverse, hw):
-    """coupling.hip tail: Conv2dZeros 64 -> 2*(C - C/2) on 16-row fp32 MFMA tiles + the FlowStep pointwise chain, in place."""
+    """Coupling tail (conv3x3_h2x_kernel, coupling epilogue): Conv2dZeros 64 -> 2*(C - C/2) over the h2 tensor hid + the FlowStep
+    pointwise chain, in place.  The reference gets the SAME hid values (hi + lo of the h2 tensor)."""
     H, W = hw
-    B, cc2 = 2, 2 * (C - C // 2)
-    hid, z = rnd(71, B, 64, H, W), rnd(72, B, C, H, W)
+    B, cc2 = 3, 2 * (C - C // 2)
+    hid, z = rnd(71, B, 64, H, W).abs(), rnd(72, B, C, H, W)
     w4, b4, ps = rnd(73, cc2, 64, 3, 3, scale=0.02), rnd(74, cc2, scale=0.2), torch.exp(rnd(75, cc2, scale=0.2))
     h_ft = rnd(76, B, 2 * C, H, W, scale=0.5)
     Wm = torch.from_numpy(np.linalg.qr(np.random.Generator(np.random.PCG64(7)).standard_normal((C, C)))[0].astype(np.float32))
     bias, es = rnd(77, C, scale=0.1), torch.exp(rnd(78, C, scale=0.1))
+    hid_h2 = CPU.h2_pack(hid, CPU.h2_empty(B, 64, H, W))
+    hid22 = sum(CPU._h2_planes(hid_h2))
+    tpk = hip.pack_coupling_tail(w4, b4, ps)
     for kw in (dict(h_ft=h_ft, w=Wm, an_bias=bias, an_escale=es), dict()) if not reverse else (dict(h_ft=h_ft, w=Wm, an_bias=bias, an_escale=es),):
-        ref = CPU.coupling_tail(hid, CPU.pack_coupling_tail(w4, b4, ps), z, torch.empty_like(z), reverse,
+        ref = CPU.coupling_tail(hid22, CPU.pack_coupling_tail(w4, b4, ps), z, torch.empty_like(z), reverse,
                                 **{k: (v.reshape(-1) if k == "w" else v) for k, v in kw.items()})
         zd = hip.to_device(z).clone()
         dkw = {k: (hip.vec(v) if v.dim() <= 2 else hip.to_device(v)) for k, v in kw.items()}
-        hip.coupling_tail(hip.to_device(hid), hip.pack_coupling_tail(w4, b4, ps), zd, zd, reverse, **dkw)
+        hip.coupling_tail(hid_h2.to(hip.device), tpk, zd, zd, reverse, **dkw)
         close(zd, ref, 2e-5, "coupling_tail C=%d rev=%d" % (C, reverse))
-        z1 = hip.to_device(z).clone()             # hid handed over in the octet-major layout: bit-identical result
-        hip.coupling_tail(hip.to_device(CPU._hid_octets(hid).contiguous()), hip.pack_coupling_tail(w4, b4, ps), z1, z1, reverse, hid_fmt=1, **dkw)
-        assert torch.equal(z1.cpu(), zd.cpu()), "coupling_tail hid_fmt=1 differs from hid_fmt=0"
+        if "h_ft" in kw:                          # h_ft handed over quad-major: bit-identical result
+            z1 = hip.to_device(z).clone()
+            dk2 = dict(dkw, h_ft=hip.to_device(CPU.quads(h_ft).contiguous()))
+            hip.coupling_tail(hid_h2.to(hip.device), tpk, z1, z1, reverse, h_ft_fmt=1, **dk2)
+            assert torch.equal(z1.cpu(), zd.cpu()), "coupling_tail h_ft_fmt=1 differs from h_ft_fmt=0"
+    hip.check_range()
 
 
-@pytest.mark.parametrize("C", [12, 24])
-@pytest.mark.parametrize("reverse", [0, 1])
-@pytest.mark.parametrize("hw", [(16, 40), (9, 33), (70, 70), (6, 30), (5, 3), (37, 91)])
-def test_coupling_step(hip, C, reverse, hw):
-    """coupling_step.hip: the whole sequential remainder of a coupled FlowStep in ONE kernel (3x3 on z1 + hoisted partial -> 1x1 ->
-    Conv2dZeros -> pointwise chain; hid stays in LDS) against the fp32 torch semantics of head + tail.  Sizes: several 6 x 30 tiles
-    per image, ragged last tiles in both directions, images smaller than one tile; B = 3 exercises the persistent tile walk."""
-    H, W = hw
-    B, cn, cc2 = 3, C // 2, 2 * (C - C // 2)
-    z, pre = rnd(161, B, C, H, W), rnd(162, B, 64, H, W, scale=0.5)
-    w0, w2 = rnd(163, 64, cn, 3, 3, scale=0.1), rnd(164, 64, 64, 1, 1, scale=0.1)
-    s0, c0, s2, c2 = rnd(165, 64, scale=0.1), torch.exp(rnd(166, 64, scale=0.1)), rnd(167, 64, scale=0.1), torch.exp(rnd(168, 64, scale=0.1))
-    w4, b4, ps = rnd(173, cc2, 64, 3, 3, scale=0.02), rnd(174, cc2, scale=0.2), torch.exp(rnd(175, cc2, scale=0.2))
-    h_ft = rnd(176, B, 2 * C, H, W, scale=0.5)
-    Wm = torch.from_numpy(np.linalg.qr(np.random.Generator(np.random.PCG64(7)).standard_normal((C, C)))[0].astype(np.float32))
-    bias, es = rnd(177, C, scale=0.1), torch.exp(rnd(178, C, scale=0.1))
-    cpk = CPU.pack_coupling_step(w0, w2, s0, c0, s2, c2, w4, b4, ps)
-    hpk = hip.pack_coupling_step(w0, w2, s0, c0, s2, c2, w4, b4, ps)
-    full = dict(h_ft=h_ft, w=Wm, an_bias=bias, an_escale=es)
-    for kw in ((full, dict()) if not reverse else (full,)):
-        ref = CPU.coupling_step(z, torch.empty_like(z), cpk, pre, reverse, **{k: (v.reshape(-1) if k == "w" else v) for k, v in kw.items()})
-        dkw = {k: (hip.vec(v) if v.dim() <= 2 else hip.to_device(v)) for k, v in kw.items()}
-        zd = hip.to_device(z)
-        out = hip.coupling_step(zd, hip.empty(B, C, H, W), hpk, hip.to_device(pre), reverse, **dkw)
-        assert torch.equal(zd.cpu(), z), "the input must be left alone"
-        close(out, ref, 2e-5, "coupling_step C=%d rev=%d" % (C, reverse))
-    with pytest.raises(Exception):          # in place is a race by construction: refused
-        zd = hip.to_device(z)
-        hip.coupling_step(zd, zd, hpk, hip.to_device(pre), reverse)
-
-
-def test_coupling_step_on_channel_slices_and_views(hip):
-    """z_in / z_out / pre_aff / h_ft as channel slices of wider buffers (batch stride != C*H*W), as the engine passes them."""
+def test_coupling_pair_on_channel_slices_and_views(hip):
+    """head -> tail with z / pre_aff / h_ft as channel slices of wider buffers, out of place into a slice (the engine runs in place)."""
     B, C, H, W = 2, 12, 20, 44
     zbuf, obuf = rnd(181, B, 20, H, W), torch.zeros(B, 16, H, W)
     prebuf, hfbuf = rnd(182, B, 3 * 64, H, W, scale=0.5), rnd(183, B, 3 * 24, H, W, scale=0.5)
     w0, w2 = rnd(163, 64, 6, 3, 3, scale=0.1), rnd(164, 64, 64, 1, 1, scale=0.1)
     s0, c0, s2, c2 = rnd(165, 64, scale=0.1), torch.exp(rnd(166, 64, scale=0.1)), rnd(167, 64, scale=0.1), torch.exp(rnd(168, 64, scale=0.1))
     w4, b4, ps = rnd(173, 12, 64, 3, 3, scale=0.02), rnd(174, 12, scale=0.2), torch.exp(rnd(175, 12, scale=0.2))
-    ref = CPU.coupling_step(zbuf[:, :C], torch.empty(B, C, H, W), CPU.pack_coupling_step(w0, w2, s0, c0, s2, c2, w4, b4, ps),
-                            prebuf[:, 64:128], 1, h_ft=hfbuf[:, 24:48])
-    od = hip.to_device(obuf)
-    hip.coupling_step(hip.to_device(zbuf)[:, :C], od[:, 2:2 + C], hip.pack_coupling_step(w0, w2, s0, c0, s2, c2, w4, b4, ps),
-                      hip.to_device(prebuf)[:, 64:128], 1, h_ft=hip.to_device(hfbuf)[:, 24:48])
-    close(od[:, 2:2 + C], ref, 2e-5, "coupling_step on slices")
+    hid = CPU.coupling_head(zbuf[:, :C], CPU.pack_coupling_head(w0, w2, s0, c0, s2, c2), prebuf[:, 64:128], torch.empty(B, 64, H, W))
+    ref = CPU.coupling_tail(hid, CPU.pack_coupling_tail(w4, b4, ps), zbuf[:, :C], torch.empty(B, C, H, W), 1, h_ft=hfbuf[:, 24:48])
+    od, zd = hip.to_device(obuf), hip.to_device(zbuf)
+    hd = hip.coupling_head(zd[:, :C], hip.pack_coupling_head(w0, w2, s0, c0, s2, c2), hip.to_device(prebuf)[:, 64:128], hip.h2_empty(B, 64, H, W))
+    hip.coupling_tail(hd, hip.pack_coupling_tail(w4, b4, ps), zd[:, :C], od[:, 2:2 + C], 1, h_ft=hip.to_device(hfbuf)[:, 24:48])
+    close(od[:, 2:2 + C], ref, 3e-5, "coupling pair on slices")
     assert float(od[:, :2].abs().max()) == 0.0 and float(od[:, 2 + C:].abs().max()) == 0.0, "wrote outside its channel slice"
+    assert torch.equal(zd.cpu(), zbuf), "the input must be left alone"
 
 
 @pytest.mark.parametrize("C", [12, 24, 96])
@@ -676,6 +693,39 @@ def test_conv_up2_bf16x3_with_key_channels(hips, case, tune):
     e32 = (o32.cpu().double() - truth).abs().max().item()
     assert ex3 <= (2.0 if hip.split == "bf16x3" else 4.0) * e32 + 1e-7, (ex3, e32)
     close(out, o32.cpu(), 1e-5, "conv_up2_x3 %s" % (case,))
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 64, 9, 21), (1, 256, 64, 128, 12, 40), (1, 48, 16, 96, 33, 50)])
+def test_quad_major_outputs_are_the_same_values(hip, case):
+    """y_fmt=1 of the split-conv kernels (conv_x3, conv_x3s on h2 tensors, conv_up2_x3 with pre_add aliasing the output): the values of the
+    NCHW form, bit for bit, laid out [B][Cout/4][H][W][4] -- the private layout coupling_head (pre_aff) and coupling_tail (h_ft) read."""
+    B, Ct, Ck, Cout, h, w_ = case
+    taps, key = rnd(180, B, Ct, h, w_), rnd(181, B, Ck, 2 * h, 2 * w_)
+    w = rnd(182, Cout, Ck + Ct, 3, 3, scale=1.0 / np.sqrt((Ck + Ct) * 9))
+    sh, sc = rnd(183, Cout, scale=0.2), torch.exp(rnd(184, Cout, scale=0.2))
+    wk, wt = w[:, :Ck].contiguous(), w[:, Ck:].contiguous()
+    epi = hip.pack_epilogue(Cout, aff_shift=sh, aff_scale=sc)
+    pk, pt = hip.pack_conv_x3(wk, 2), hip.pack_conv_up2_x3(wt)
+    kd, td = hip.to_device(key), hip.to_device(taps)
+    ref, out = hip.empty(B, Cout, 2 * h, 2 * w_), hip.empty(B, Cout, 2 * h, 2 * w_)
+    hip.conv_x3(kd, pk, ref)
+    hip.conv_x3(kd, pk, out, y_fmt=1)
+    assert torch.equal(CPU.quads(out.cpu(), inverse=True), ref.cpu()), "conv_x3 y_fmt=1"
+    hip.conv_up2_x3(td, pt, ref, epi=epi, act=1, pre_add=ref)
+    hip.conv_up2_x3(td, pt, out, epi=epi, act=1, pre_add=out, y_fmt=1)
+    assert torch.equal(CPU.quads(out.cpu(), inverse=True), ref.cpu()), "conv_up2_x3 y_fmt=1 (pre_add aliasing the output)"
+    # the LDS-DMA kernel over an h2 copy of the key channels (the level-1 key convs of the default path)
+    kh = hip.h2_pack(kd, hip.h2_empty(B, Ck, 2 * h, 2 * w_))
+    p1 = hip.pack_conv_x3(wk, 1)
+    hip.conv_x3s(kh, p1, ref, epi=epi, act=1)
+    hip.conv_x3s(kh, p1, out, epi=epi, act=1, y_fmt=1)
+    assert torch.equal(CPU.quads(out.cpu(), inverse=True), ref.cpu()), "conv_h2x y_fmt=1"
+    # channel-slice views of a wider buffer keep their meaning: slice [a:b] of the NCHW view = quads [a/4:b/4] of the quad-major one
+    wide_r, wide_q = hip.zeros(B, Cout + 8, 2 * h, 2 * w_), hip.zeros(B, Cout + 8, 2 * h, 2 * w_)
+    hip.conv_x3(kd, pk, wide_r[:, 4:4 + Cout])
+    hip.conv_x3(kd, pk, wide_q[:, 4:4 + Cout], y_fmt=1)
+    assert torch.equal(CPU.quads(wide_q[:, 4:4 + Cout].cpu().contiguous(), inverse=True), wide_r[:, 4:4 + Cout].cpu())
+    assert float(wide_q[:, :4].abs().max()) == 0.0 and float(wide_q[:, 4 + Cout:].abs().max()) == 0.0, "wrote outside its channel slice"
 
 
 @pytest.mark.parametrize("case", [(2, 64, 64, 64, 9, 21), (1, 256, 64, 128, 12, 40), (1, 48, 16, 96, 33, 50), (3, 32, 8, 40, 16, 32), (1, 16, 0, 24, 37, 70)])

@@ -83,19 +83,17 @@ def main():
     taps = torch.randn(B, 256, hw // 2, hw // 2, device="cuda")
     pu = ops.pack_conv_up2_x3(r(256, 256, 3, 3, scale=0.02))
     total += stress("conv_up2_bf16x3 256->256 @%dx%d" % (hw, hw), lambda: ops.conv_up2_x3(taps, pu, y))
-    # --- the coupled FlowStep remainder: head + tail pair and the fused kernel, both levels
+    # --- the coupled FlowStep remainder: head + tail pair, both levels
     for C, h2 in ((12, 160), (24, 96)):
         cn, cc2 = C // 2, 2 * (C - C // 2)
         w0, w2 = r(64, cn, 3, 3, scale=0.1), r(64, 64, 1, 1, scale=0.1)
         s0, c0, s2, c2 = r(64, scale=0.1), torch.exp(r(64, scale=0.1)), r(64, scale=0.1), torch.exp(r(64, scale=0.1))
         w4, b4, ps = r(cc2, 64, 3, 3, scale=0.02), r(cc2, scale=0.2), torch.exp(r(cc2, scale=0.2))
         z, pre, hf = torch.randn(B, C, h2, h2, device="cuda"), torch.randn(B, 64, h2, h2, device="cuda") * 0.5, torch.randn(B, 2 * C, h2, h2, device="cuda") * 0.5
-        hid, zo = ops.empty(B, 64, h2, h2), ops.empty(B, C, h2, h2)
+        hid, zo = ops.h2_empty(B, 64, h2, h2), ops.empty(B, C, h2, h2)
         hpk, tpk = ops.pack_coupling_head(w0, w2, s0, c0, s2, c2), ops.pack_coupling_tail(w4, b4, ps)
-        spk = ops.pack_coupling_step(w0, w2, s0, c0, s2, c2, w4, b4, ps)
         total += stress("coupling_head C=%d @%dx%d" % (C, h2, h2), lambda: ops.coupling_head(z, hpk, pre, hid))
         total += stress("coupling_tail C=%d @%dx%d" % (C, h2, h2), lambda: ops.coupling_tail(hid, tpk, z, zo, 1, h_ft=hf))
-        total += stress("coupling_step C=%d @%dx%d" % (C, h2, h2), lambda: ops.coupling_step(z, zo, spk, pre, 1, h_ft=hf))
     # --- level 3 (C = 96): fused 3x3 -> 1x1 on the fp32 MFMA, Conv2dZeros 64 -> 96, and the MFMA pointwise kernel
     z = torch.randn(B, 96, 80, 80, device="cuda")
     pre3, hid3 = torch.randn(B, 64, 80, 80, device="cuda") * 0.5, ops.empty(B, 64, 80, 80)

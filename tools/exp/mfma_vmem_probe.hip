@@ -1,0 +1,122 @@
+// mfma_vmem_probe.hip -- stand-alone probe for the round-4 fault study.  The study narrowed round 3's
+// coupling_head fault to: wrong ACCUMULATOR contents in lanes 16-31 / 48-63 of waves 4-7 of an 8-wave workgroup (the second wave of
+// every SIMD, phase-locked with the first by the workgroup barrier), only while vector-memory loads issued earlier (the next tile's
+// register prefetch) are still returning into VGPRs during the dependent MFMA chains.  This kernel reproduces just that situation
+// on fixed data: every iteration runs the same ds_read_b128 + v_mfma_f32_32x32x16_bf16 chains (two accumulators, 60 MFMAs) with
+// 32 buffer_load_dword in flight, and compares the accumulators bit-for-bit with those of the first iteration.
+//   hipcc --offload-arch=gfx950 -O3 tools/exp/mfma_vmem_probe.hip -o tools/exp/mfma_vmem_probe
+//   tools/exp/mfma_vmem_probe [iters] [waves 8|4] [loads in flight 1|0]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int PW = 34;
+
+template <int NWV, int LOADS>
+__global__ __launch_bounds__(NWV * 64, 2) void probe(const float* __restrict__ src, float* __restrict__ dst, unsigned* __restrict__ bad, int iters, unsigned n)
+{
+    constexpr int NPOS = (NWV + 2) * PW, NT = NWV * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sZ = smem;                               // [3 planes][NPOS][16 B]
+    unsigned char* sW = smem + 3 * NPOS * 16;               // [5 chunks][3 planes][2][64][16 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    // fixed pseudo-random bf16 contents (small integers: every product and sum is exact, so the expected accumulators are unambiguous)
+    for (int i = tid; i < (3 * NPOS * 16 + 5 * 3 * 2 * 64 * 16) / 4; i += NT) {
+        unsigned h = (unsigned)i * 2654435761u + (unsigned)blockIdx.x * 40503u;
+        const unsigned short a = (unsigned short)(0x3f80u + ((h >> 7) & 0x40u)), b = (unsigned short)(0x3f80u + ((h >> 13) & 0x40u));   // 1.0 or 1.5
+        reinterpret_cast<unsigned*>(smem)[i] = (unsigned)a | ((unsigned)b << 16);
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, n * 4u, 0x00020000);
+    f32x16 ref[2];
+    unsigned nbad = 0, first = 0;
+    float sink = 0.f;
+    float pre[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) pre[r] = 0.f;
+    for (int i = 0; i < iters; ++i) {
+        __syncthreads();                                    // phase-lock the waves of the workgroup, as the head's per-tile barrier does
+        if (LOADS) {
+            const unsigned vo = (unsigned)((((size_t)blockIdx.x * NT + tid) * 4 + (size_t)i * 1048576u * 4) % ((size_t)n * 4 - 64 * 1048576u));
+#pragma unroll
+            for (int r = 0; r < 32; ++r)
+                pre[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (unsigned)r * 1048576u, 0));
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int t0 = 2 * j, t1 = 2 * j + 1 < 9 ? 2 * j + 1 : 2 * j;
+            const int a0 = ((t0 / 3) * PW + (t0 % 3)) * 16, a1 = ((t1 / 3) * PW + (t1 % 3)) * 16;
+            const unsigned char* bp = sZ + (lhi ? a1 : a0) + (wave * PW + l31) * 16;
+            bf16x8 fb[3], fa[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) fb[pl] = *reinterpret_cast<const bf16x8*>(bp + pl * NPOS * 16);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) fa[m][pl] = *reinterpret_cast<const bf16x8*>(sW + (((j * 3 + pl) * 2 + lhi) * 64 + m * 32 + l31) * 16);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][2], fb[0], acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][0], fb[2], acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][1], fb[1], acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][1], fb[0], acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][0], fb[1], acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][0], fb[0], acc[m], 0, 0, 0);
+            }
+        }
+        if (i == 0) { ref[0] = acc[0]; ref[1] = acc[1]; }
+        else {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (__builtin_bit_cast(unsigned, acc[m][r]) != __builtin_bit_cast(unsigned, ref[m][r])) { if (!nbad) first = ((unsigned)i << 8) | (unsigned)(m * 16 + r); ++nbad; }
+        }
+#pragma unroll
+        for (int r = 0; r < 32; ++r) sink += pre[r];
+    }
+    dst[(size_t)blockIdx.x * NT + tid] = sink;
+    if (nbad) {
+        const unsigned k = atomicAdd(bad, 1u);
+        if (k < 128) { bad[1 + 3 * k] = (blockIdx.x << 10) | tid; bad[2 + 3 * k] = nbad; bad[3 + 3 * k] = first; }
+    }
+}
+
+int main(int argc, char** argv)
+{
+    const int iters = argc > 1 ? atoi(argv[1]) : 20000, waves = argc > 2 ? atoi(argv[2]) : 8, loads = argc > 3 ? atoi(argv[3]) : 1;
+    const unsigned n = 512u << 20;                          // 2 GiB of floats: the loads miss L2
+    float *src, *dst; unsigned* bad;
+    if (hipMalloc(&src, (size_t)n * 4) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    (void)hipMalloc(&dst, (size_t)1024 * 512 * 4); (void)hipMalloc(&bad, 4096);
+    (void)hipMemset(src, 0, (size_t)n * 4); (void)hipMemset(bad, 0, 4096);
+    int cus = 0; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0);
+    const int lds8 = 3 * 10 * PW * 16 + 5 * 3 * 2 * 64 * 16, lds4 = 3 * 6 * PW * 16 + 5 * 3 * 2 * 64 * 16;
+    if (waves == 8 && loads)  hipLaunchKernelGGL((probe<8, 1>), dim3(cus), dim3(512), lds8, 0, src, dst, bad, iters, n);
+    if (waves == 8 && !loads) hipLaunchKernelGGL((probe<8, 0>), dim3(cus), dim3(512), lds8, 0, src, dst, bad, iters, n);
+    if (waves == 4 && loads)  hipLaunchKernelGGL((probe<4, 1>), dim3(cus * 2), dim3(256), lds4, 0, src, dst, bad, iters, n);
+    if (waves == 4 && !loads) hipLaunchKernelGGL((probe<4, 0>), dim3(cus * 2), dim3(256), lds4, 0, src, dst, bad, iters, n);
+    (void)hipEventRecord(e1);
+    if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 1; }
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned> h(1024);
+    (void)hipMemcpy(h.data(), bad, 4096, hipMemcpyDeviceToHost);
+    printf("mfma_vmem_probe waves=%d loads_in_flight=%d: %d iterations in %.1f ms: %u threads saw an accumulator differ from iteration 0\n", waves, loads, iters, ms, h[0]);
+    for (unsigned k = 0; k < h[0] && k < 16; ++k)
+        printf("  block %u wave %u lane %u: %u registers differed, first at iteration %u register %u\n", h[1 + 3 * k] >> 10, (h[1 + 3 * k] & 1023u) >> 6, h[1 + 3 * k] & 63u,
+               h[2 + 3 * k], h[3 + 3 * k] >> 8, h[3 + 3 * k] & 255u);
+    return 0;
+}

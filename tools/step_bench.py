@@ -1,5 +1,7 @@
-"""Micro-benchmark of the coupled FlowStep remainder at BASELINE config 2's level shapes: fused kernel (coupling_step) vs the
-head + tail pair, A/B interleaved in one process.  Usage (GPU box): python tools/step_bench.py [rounds]"""
+"""Micro-benchmark of the coupled FlowStep remainder (coupling_head -> coupling_tail) at BASELINE config 2 / 4 level shapes, every kernel
+timed alone with HIP events, NCHW and quad-major hand-over of pre_aff / h_ft.  Usage (GPU box): python tools/step_bench.py [rounds]
+Algorithmic bytes per step: 20*C*B*h*w (z, h_aff, h_ft in; z out); the pair's own traffic adds pre_aff in and hid
+out + in (256 B/px each)."""
 import os
 import sys
 
@@ -36,22 +38,20 @@ for C, hw, B in ((12, 320, 8), (24, 160, 8), (12, 384, 8), (24, 192, 8)):
     z2 = torch.empty_like(z)
     pre = torch.randn(B, 64, hw, hw, device="cuda") * 0.5
     hf = torch.randn(B, 2 * C, hw, hw, device="cuda") * 0.5
-    hid = torch.empty(B, 64, hw, hw, device="cuda")
-    spk = ops.pack_coupling_step(w0, w2, s0, c0, s2, c2, w4, b4, ps)
+    hid = ops.h2_empty(B, 64, hw, hw)
     hpk = ops.pack_coupling_head(w0, w2, s0, c0, s2, c2)
     tpk = ops.pack_coupling_tail(w4, b4, ps)
     wv = ops.vec(Wm)
+    px = B * hw * hw
     for rev in (1, 0):
-        fused = lambda: ops.coupling_step(z, z2, spk, pre, rev, h_ft=hf, w=wv, an_bias=bias, an_escale=es)
-
-        def pair():
-            ops.coupling_head(z, hpk, pre, hid, hid_fmt=1)
-            ops.coupling_tail(hid, tpk, z, z2, rev, h_ft=hf, w=wv, an_bias=bias, an_escale=es, hid_fmt=1)
-        tf, tp, th = [], [], []
-        for _ in range(rounds):
-            tf.append(timed(fused)); tp.append(timed(pair)); th.append(timed(lambda: ops.coupling_head(z, hpk, pre, hid, hid_fmt=1)))
-        px = B * hw * hw
-        alg = px * (256 + 4 * C * 4) / 1e6          # MB: pre_aff + z in + h_ft (2C) + z out
-        mf, mp = float(np.median(tf)), float(np.median(tp))
-        print("C=%d %dx%d B=%d rev=%d: fused %.1f us (min %.1f) = %.2f TB/s algorithmic (%.0f MB)   head+tail %.1f us (head %.1f)   x%.2f"
-              % (C, hw, hw, B, rev, mf, min(tf), alg / mf, alg, mp, float(np.median(th)), mp / mf), flush=True)
+        for fmt in (0, 1):
+            head = lambda: ops.coupling_head(z, hpk, pre, hid, pre_fmt=fmt)
+            tail = lambda: ops.coupling_tail(hid, tpk, z, z2, rev, h_ft=hf, w=wv, an_bias=bias, an_escale=es, h_ft_fmt=fmt)
+            th, tt = [], []
+            for _ in range(rounds):
+                th.append(timed(head)); tt.append(timed(tail))
+            mh, mt = float(np.median(th)), float(np.median(tt))
+            bh, bt = px * (4 * cn + 256 + 256) / 1e6, px * (256 + 4 * C * 4) / 1e6      # MB moved by head / tail
+            print("C=%d %dx%d B=%d rev=%d quad-major=%d: head %.1f us (%.2f TB/s of its %.0f MB)  tail %.1f us (%.2f TB/s of its %.0f MB; %.2f TB/s on 20*C B/px)  step %.1f us"
+                  % (C, hw, hw, B, rev, fmt, mh, bh / mh, bh, mt, bt / mt, bt, px * 20 * C / 1e6 / mt, mh + mt), flush=True)
+ops.check_range()

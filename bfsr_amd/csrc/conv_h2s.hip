@@ -800,7 +800,11 @@ template <int XM> struct XGeo {
 template <int XM, int EPI, int CF>
 __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrConvX3Args p, BfsrCouplingTailArgs q, int tiles_x, int tiles_y, int groups, int nitems)
 {
-    constexpr int X_WPL = XGeo<XM>::WPL, X_W = XGeo<XM>::W, X_STAGE = XGeo<XM>::STAGE;
+    // WRES (coupling tail): the WHOLE weight tensor (Cin = 64: four chunks, 72 KiB) stays resident in LDS behind the two input stages and
+    // the loaders stream activations only -- the kernel is bound by the L2 -> LDS fill (~27 GB/s per CU), and with one cout group the
+    // weights are the same 31 % of every stage for every item
+    constexpr bool WRES = EPI == 1;
+    constexpr int X_WPL = XGeo<XM>::WPL, X_W = XGeo<XM>::W, X_STAGE = WRES ? X_IN : XGeo<XM>::STAGE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -819,6 +823,13 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
         r.x0 = (t % tiles_x) * 32; r.y0 = ty * TH; r.b = t / tiles_x;
         return r;
     };
+    if constexpr (WRES) {                                                // all twelve waves: weights -> LDS once (ordinary loads, landed before the barrier)
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(p.w);
+        uint4* dst = reinterpret_cast<uint4*>(smem + 2 * X_IN);
+        const int nq = nchunk * X_W / 16;
+        for (int i = tid; i < nq; i += (NW + NLW) * 64) dst[i] = src[i];
+        __syncthreads();
+    }
 
     if (wave >= NW) {
         // ---- loader waves: LDS-DMA only (see h2s_loader_wave on why a wave must not mix load kinds)
@@ -847,6 +858,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
 #pragma unroll
             for (int g = 0; g < NG; ++g)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(base + ld * SUB + g * 1024), 16, vg[g], soff, 0, 0);
+            if constexpr (!WRES) {
             const unsigned wsoff = (unsigned)(cg_ * nchunk + k) * (unsigned)X_W;
 #pragma unroll
             for (int j = 0; j < (X_W / 1024 + NLW - 1) / NLW; ++j) {
@@ -854,6 +866,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
                 if (piece < X_W / 1024)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(base + X_IN + piece * 1024), 16,
                                                              (unsigned)lane * 16u + (unsigned)piece * 1024u, wsoff, 0, 0);
+            }
             }
         };
         int it = slot;
@@ -879,12 +892,12 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
     // -> 6 MFMAs; the fragments of step t+1 are read while the MFMAs of step t run (register double buffer: 48 registers -- a
     // tap-COLUMN step as in conv3x3_h2s_kernel needs 112 and spills beside the 32 accumulators).
     half8 bq[2][2][2], aq[2][2][XM];                                     // [buffer][plane][row] | [buffer][plane][m tile]
-    auto load_step = [&](auto buf_, int st, int t) {
+    auto load_step = [&](auto buf_, int st, int t, int kc) {             // kc = chunk index inside the item (resident weights only)
         constexpr int BUF = decltype(buf_)::value;
         const int dx = t / 3, dy = t - 3 * dx;
         const unsigned char* sIn = smem + st * X_STAGE;
         const unsigned char* inB = sIn + (lhi * NPOSP + (2 * wave + dy) * PW + l31 + dx) * 16;
-        const unsigned char* wA = sIn + X_IN + lane * 16 + t * (1024 * XM);                              // tap = dx*3 + dy = t
+        const unsigned char* wA = (WRES ? smem + 2 * X_IN + kc * X_W : sIn + X_IN) + lane * 16 + t * (1024 * XM);        // tap = dx*3 + dy = t
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
@@ -944,14 +957,15 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
         // One barrier per chunk, passed EARLY: chunk k+1's barrier sits before the last tap of chunk k (whose fragments are already in
         // registers), so the first fragments of chunk k+1 are in flight under that tap's MFMAs and the loaders may refill stage `buf`
         // one tap earlier.  Nine taps per chunk flip the fragment-buffer parity from chunk to chunk: chunks are processed in pairs.
+        int kc = 0;                                                      // chunk index inside the item
         auto chunk_body = [&](auto p_, auto q_, bool last) {               // p_: buffer holding tap 0's fragments (already loaded)
 #pragma unroll
             for (int t = 0; t < 8; t += 2) {
-                load_step(q_, buf, t + 1);
+                load_step(q_, buf, t + 1, kc);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_step(p_);
                 __builtin_amdgcn_sched_barrier(0);
-                load_step(p_, buf, t + 2);
+                load_step(p_, buf, t + 2, kc);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_step(q_);
                 __builtin_amdgcn_sched_barrier(0);
@@ -959,12 +973,13 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
             if (!last) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // tap 8's fragments have left stage `buf`
                 __builtin_amdgcn_s_barrier();                            // chunk k+1 has landed in stage buf^1; stage buf is free again
-                load_step(q_, buf ^ 1, 0);
+                load_step(q_, buf ^ 1, 0, kc + 1);
             }
             __builtin_amdgcn_sched_barrier(0);
             mfma_step(p_);
             __builtin_amdgcn_sched_barrier(0);
             buf ^= 1;
+            ++kc;
         };
         // coupling tail: this lane's pixel and the operands of its pointwise chain (registers, loaded under the item's last chunk)
         constexpr int CFN = CF / 2, CO2 = 2 * (CF - CFN);
@@ -999,7 +1014,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
             }
         };
         __builtin_amdgcn_s_barrier();                                    // the item's first chunk has landed in stage `buf`
-        load_step(I0(), buf, 0);
+        load_step(I0(), buf, 0, 0);
         int k = 0;
         for (; k + 2 <= nchunk; k += 2) {                                // pairs of chunks: the parity is static inside a pair
             chunk_body(I0(), I1(), false);
@@ -1618,8 +1633,10 @@ static int launch_coupling_tail(const BfsrCouplingTailArgs& a, hipStream_t st)
     if (cus <= 0) return -1;
     const long long grid = nitems < cus ? nitems : cus;
     static std::atomic<unsigned long long> lds_done{0};
-    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2x_kernel<1, 1, CF>), XGeo<1>::LDS, lds_done) != 0) return -1;
-    hipLaunchKernelGGL((conv3x3_h2x_kernel<1, 1, CF>), dim3((unsigned)grid), dim3((NW + NLW) * 64), XGeo<1>::LDS, st, c, a, tiles_x, tiles_y, 1, (int)nitems);
+    constexpr int LDS = 2 * X_IN + 4 * XGeo<1>::W;                       // two input stages + the resident weights of all four chunks: 155 648 B
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2x_kernel<1, 1, CF>), LDS, lds_done) != 0) return -1;
+    hipLaunchKernelGGL((conv3x3_h2x_kernel<1, 1, CF>), dim3((unsigned)grid), dim3((NW + NLW) * 64), LDS, st, c, a, tiles_x, tiles_y, 1, (int)nitems);
     return (int)hipGetLastError();
 }
 

@@ -251,6 +251,56 @@ def test_conv_h2x_is_fp32_accurate(hip, case, mode):
         assert float((got - ref64).abs().max()) <= tol + 2.0 ** -21 * float(ref64.abs().max()), "conv_h2x h2 out %s" % (case,)
 
 
+@pytest.mark.parametrize("wscale", [0.01, 1.0, 100.0])
+@pytest.mark.parametrize("ascale", [1e-4, 1e-2, 1.0, 1e2, 3e3])
+@pytest.mark.parametrize("kernel", ["conv_h2x", "conv_x3"])
+def test_f16x2_split_vs_activation_and_weight_scale(hip, kernel, ascale, wscale):
+    """Range behaviour of the two-term fp16 split, against an fp64 conv of the UNQUANTISED input (not of its 22-bit image): activations
+    scaled 1e-4 ... 3e3, weights x0.01 ... x100.  The weights carry a power-of-two scale, the activations do not: x = hi + lo holds 22
+    significant bits while lo = fp16(x - hi) is a normal number (|x| >= 2^-3) and degrades to an ABSOLUTE error of 2^-25 per element
+    below that (fp16 subnormal spacing 2^-24).  Asserted model:  |err| <= 4 x (native fp32 kernel's error) + 2^-25 x max_co sum|w|.
+    At |x| ~ 1 this is fp32-class; a tensor that is uniformly tiny keeps fewer RELATIVE bits (the printed figure) -- DESIGN.md section 3.7
+    states the regime, BFSR_SPLIT=bf16x3 has fp32's full exponent range."""
+    B, Cin, Cout, H, W = 1, 64, 32, 24, 40
+    x = rnd(301, B, Cin, H, W) * ascale
+    w = rnd(302, Cout, Cin, 3, 3, scale=1.0 / np.sqrt(Cin * 9)) * wscale
+    truth = torch.nn.functional.conv2d(x.double(), w.double(), None, 1, 1)
+    xd = hip.to_device(x)
+    if kernel == "conv_h2x":
+        out = hip.conv_h2x(hip.h2_pack(xd, hip.h2_empty(B, Cin, H, W)), hip.pack_conv_x3(w, 1), hip.empty(B, Cout, H, W))
+    else:
+        out = hip.conv_x3(xd, hip.pack_conv_x3(w, 1), hip.empty(B, Cout, H, W))
+    f32 = hip.conv(xd, hip.pack_conv(w, 1), hip.empty(B, Cout, H, W))
+    hip.check_range()
+    err, err32 = float((out.cpu().double() - truth).abs().max()), float((f32.cpu().double() - truth).abs().max())
+    floor = 2.0 ** -25 * float(w.abs().sum(dim=(1, 2, 3)).max())
+    rel = err / float(truth.abs().max())
+    assert err <= 4 * err32 + floor, "%s x%g w%g: max-abs %.3e (fp32 kernel %.3e, floor %.3e), relative %.2e" % (kernel, ascale, wscale, err, err32, floor, rel)
+    if ascale >= 1.0:
+        assert rel <= 2e-6, "%s x%g w%g: relative error %.2e is not fp32-class" % (kernel, ascale, wscale, rel)
+
+
+@pytest.mark.parametrize("kernel", ["h2_pack", "conv_x3", "conv_h2x_out"])
+def test_f16x2_split_overflow_is_loud(hip, kernel):
+    """|x| >= 65504 cannot enter the fp16 split: the kernel that would split it raises the device flag, check_range() raises."""
+    B, Cin, Cout, H, W = 1, 64, 32, 16, 32
+    x = rnd(303, B, Cin, H, W)
+    w = rnd(304, Cout, Cin, 3, 3, scale=1.0 / np.sqrt(Cin * 9))
+    hip.check_range()
+    if kernel == "conv_h2x_out":                        # the overflow is produced BY the conv: its h2 output cannot hold 1e5
+        xh = hip.h2_pack(hip.to_device(x), hip.h2_empty(B, Cin, H, W))
+        hip.conv_h2x(xh, hip.pack_conv_x3(w * 1.0e5, 1), hip.h2_empty(B, Cout, H, W))
+    else:
+        x[0, 3, 5, 7] = 1.0e5
+        if kernel == "h2_pack":
+            hip.h2_pack(hip.to_device(x), hip.h2_empty(B, Cin, H, W))
+        else:
+            hip.conv_x3(hip.to_device(x), hip.pack_conv_x3(w, 1), hip.empty(B, Cout, H, W))
+    with pytest.raises(RuntimeError, match="range of the two-term fp16 split"):
+        hip.check_range()
+    hip.check_range()
+
+
 def test_conv_h2x_dense_block_views_and_residuals(hip):
     """The RDB pattern on h2 tensors with the fp32-class arithmetic: octet-sliced views of one block buffer, conv5 with `x5*0.2 + x`
     and the RRDB-level `*0.2 + x_rrdb` (RRDBNet_arch.py:39-45, :59-65)."""

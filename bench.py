@@ -319,29 +319,39 @@ def main():
         ev = ops.profile[key_tail_fused if fused else key_tail]
         tail_ms = sum(s.elapsed_time(e) for s, e in ev) / len(ev)
         px = B * (H // 2) * (H // 2)
-        # unfused: read z, h_aff, h_ft + write z = 20*C B/px.  fused: h_aff never exists in HBM; the kernel reads the 64
-        # hidden channels of the coupling net instead, + h_ft (2C) + z (C) and writes z (C) = 4*(64 + 4C) B/px
+        # Two numerators, both reported.  (1) SURVEY 8d's definition of the coupling-inverse tail: read z, h_aff, h_ft + write z =
+        # 20*C B/px.  (2) what the fused tail must move: h_aff never exists in HBM, the kernel reads the 64 hidden channels of the
+        # coupling net instead (an h2 tensor, 4 B per element), + h_ft (2C) + z (C) and writes z (C) = 4*(64 + 4C) B/px.
+        survey_bytes = 20.0 * C1 * px
         tail_bytes = (4.0 * (64 + 4 * C1) if fused else 20.0 * C1) * px
         a = tail_bytes / (tail_ms * 1e-3) / 1e9
+        a_s = survey_bytes / (tail_ms * 1e-3) / 1e9
         roof_tail = {"bound": "hbm",
-                     "kernel": ("coupling_tail_kernel<12> reverse: Conv2dZeros 64->12 (3xBF16 on 16-wide MFMA tiles) + level-1 FlowStep inverse tail, fused" if fused
+                     "kernel": ("coupling tail = conv3x3_h2x_kernel<coupling epilogue, C=12> reverse: Conv2dZeros 64->12 over the h2 hidden tensor (LDS-DMA, "
+                                "two-term fp16 split) + level-1 FlowStep inverse tail as its epilogue" if fused
                                 else "flow_pointwise_kernel<12,4> reverse (level-1 FlowStep inverse tail)"),
                      "achieved": round(a, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(a / PEAK_HBM_GBS, 4),
+                     "achieved_on_survey_bytes": round(a_s, 1), "frac_on_survey_bytes": round(a_s / PEAK_HBM_GBS, 4),
                      "traffic": (traffic_db.get(json.dumps(list(key_tail_fused if fused else key_tail))) or {}).get("hbm_bytes_per_launch"),
-                     "algorithmic_bytes_per_launch": tail_bytes, "avg_launch_ms": round(tail_ms, 4), "launches": len(ev)}
+                     "algorithmic_bytes_per_launch": tail_bytes, "survey_bytes_per_launch": survey_bytes,
+                     "avg_launch_ms": round(tail_ms, 4), "launches": len(ev)}
         if fused and ops.profile.get(key_head):
-            # the whole sequential remainder of a level-1 coupled FlowStep = coupling_head + coupling_tail; numerator = the STEP's
-            # algorithmic bytes: z (C) + pre_aff (64) + h_ft (2C) in, z (C) out (the 64-channel hidden tensor the two kernels hand
-            # over is not algorithmic: it exists only because the step is two kernels)
+            # the whole sequential remainder of a level-1 coupled FlowStep = coupling_head + coupling_tail, on the bytes the PAIR must move
+            # (head: z1 + pre_aff in, hid out; tail as above) and on SURVEY's 20*C B/px
             evh = ops.profile[key_head]
             head_ms = sum(s.elapsed_time(e) for s, e in evh) / len(evh)
-            sa = tail_bytes / ((head_ms + tail_ms) * 1e-3) / 1e9
-            roof_tail["step"] = {"kernels": "coupling_head_kernel<1> + coupling_tail_kernel<12> (one coupled level-1 FlowStep, inverse)",
+            head_bytes = 4.0 * (C1 // 2 + 64 + 64) * px
+            pair = (head_bytes + tail_bytes) / ((head_ms + tail_ms) * 1e-3) / 1e9
+            sa = survey_bytes / ((head_ms + tail_ms) * 1e-3) / 1e9
+            roof_tail["step"] = {"kernels": "coupling_head_kernel<1,4> + coupling tail (one coupled level-1 FlowStep, inverse)",
                                  "head_avg_launch_ms": round(head_ms, 4), "tail_avg_launch_ms": round(tail_ms, 4),
-                                 "algorithmic_bytes_per_step": tail_bytes, "achieved": round(sa, 1), "unit": "GB/s",
-                                 "frac": round(sa / PEAK_HBM_GBS, 4),
-                                 "note": "the step is matrix-pipe bound, not HBM bound: 3xBF16 arithmetic needs ~0.19 TFLOP of bf16 MFMA per step "
-                                         "(~76 us at the 2.5 PFLOP/s peak) against ~58 us of traffic at the achievable 6.3 TB/s"}
+                                 "head_bytes_per_launch": head_bytes, "head_achieved": round(head_bytes / (head_ms * 1e-3) / 1e9, 1),
+                                 "head_frac": round(head_bytes / (head_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                 "pair_bytes_per_step": head_bytes + tail_bytes, "achieved": round(pair, 1), "unit": "GB/s",
+                                 "frac": round(pair / PEAK_HBM_GBS, 4),
+                                 "achieved_on_survey_bytes": round(sa, 1), "frac_on_survey_bytes": round(sa / PEAK_HBM_GBS, 4),
+                                 "note": "event times under the side-stream overlap are inflated by contention; tools/step_bench.py times the two "
+                                         "kernels alone (profiles/r04_*_step_bench.txt)"}
 
     # ---- config 2: the same workload with every contraction on the native fp32 MFMA, reported beside `value` --------------
     fp32_only = None
@@ -422,6 +432,11 @@ def main():
                                   % (cl, cl, hr, hr, what, ", ".join("%.1f" % t for t in ts), nt)}
 
     if rank == 0:
+        # parity gate: an fp32-configuration line is only printed when the HIP path agrees with the oracle on the sample (north_star: 1e-4)
+        if parity is not None and cfg in (2, 3, 4):
+            bad = {k: v for k, v in parity.items() if k.startswith("max_abs") and k in ("max_abs_sr", "max_abs_pred") and not (v <= 1e-4)}
+            if bad:
+                raise SystemExit("bench.py: parity failure vs the oracle, no line printed: %s" % bad)
         if srflow:
             name = "SRFlow-LP %dx flow-inverse SR (%d->%d)" % (scale, h, H)
             path = ("LP path: RRDB + encode + standardise + prior UNet + decode + clamp" if args.mode == "lp"

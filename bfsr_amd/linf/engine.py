@@ -74,10 +74,9 @@ class LINFEngine(object):
                          torch.cat([sd["coef.bias"], sd["freq.bias"]], 0), mtile=2, f16=f16)
         self.phase = ops.vec(sd["phase.weight"])
         # Fourier features + shared MLP as ONE kernel (linf_mlp.hip) when the MLP has the reference's shape (3 hidden layers of
-        # 256); otherwise, with BFSR_LINF_MLP=unfused, or on the all-native-fp32 backend (BFSR_CONV=f32): features kernel + 1x1 convs
-        import os
+        # 256); otherwise, or on the all-native-fp32 backend (BFSR_CONV=f32): features kernel + 1x1 convs
         self.fused_mlp = (hidden_dim == 256 and num_layer == 3 and hasattr(ops, "linf_mlp")
-                          and (f16 or getattr(ops, "conv_mode", "f32") == "x3") and os.environ.get("BFSR_LINF_MLP", "fused") != "unfused")
+                          and (f16 or getattr(ops, "conv_mode", "f32") == "x3"))
         self.mlp = []
         if self.fused_mlp:
             names_ = ["layers.%d" % (2 * j) for j in range(num_layer + 1)]

@@ -307,10 +307,7 @@ class HipOps(object):
         Cout, Cin, _ = wt.shape
         if self.split == "f16x2":
             scale = self.pow2_scale(wt)
-            # BFSR_TAPS_MT=2: 64-cout workgroups for the x2 taps kernel (the register-staged input tile serves twice the MFMAs) --
-            # parity-tested, measured SLOWER (8.0 vs 6.5 ms per cfg2 launch: 52 KB of LDS and 64 more accumulator registers per
-            # workgroup cost more occupancy than the halved staging saves)
-            mt = 2 if T == 16 and Cout % 64 == 0 and os.environ.get("BFSR_TAPS_MT", "1") == "2" else 1
+            mt = 1      # 64-cout workgroups for the x2 taps kernel (round 3, BFSR_TAPS_MT=2) were measured slower (8.0 vs 6.5 ms) and are gone
             packed = torch.empty(self.lib.bfsr_conv_packed_size_taps_f16x2(Cout, Cin, T, mt), dtype=torch.int16)
             _lib.check(self.lib.bfsr_pack_conv_weight_taps_f16x2(wt.data_ptr(), Cout, Cin, T, mt, scale, packed.data_ptr()), "pack_taps_f16x2")
             return PackedConv(packed.to(self.device), Cout, Cin, 3, mt, fixed=True, scale=scale, arith=1, w=wt.contiguous(), ops=self)
@@ -369,33 +366,6 @@ class HipOps(object):
             return out
         key = ("conv_up2" + fam, 1, Cin, Cout, out.shape[0], H, W, 0)
         _lib.check(self._launch(key, lambda: self.lib.bfsr_conv2d_up2_bf16x3(C.byref(a), self._stream())), "conv2d_up2_bf16x3")
-        return out
-
-    def conv_up2_h2x(self, xh, pw, out, epi=None, pre_add=None, act=ACT_NONE, slope=0.2, tune=0):
-        """conv_up2_x3 with the taps as an h2 tensor at source resolution (LDS-DMA staged, persistent; conv_h2s.hip,
-        conv_up2_h2x_kernel): out [B,Cout,2h,2w] = epilogue(conv3x3(nearest_up2(x)) + pre_add).  `pw` = pack_conv_up2_x3(w) under
-        split == "f16x2" (the step-ordered fp16 packing is derived lazily from its kept pre-summed matrices)."""
-        a = _lib.BfsrConvArgs()
-        a.x, a.x_bs, Cin, h, w = self._h2view(xh, "conv_up2_h2x.x")
-        yp, ybs, Cout, H, W = _view(out, "conv_up2_h2x.out")
-        if (Cin, Cout, 2 * h, 2 * w) != (pw.Cin, pw.Cout, H, W) or xh.shape[0] != out.shape[0] or pw.arith != 1 or Cin % 16:
-            raise ValueError("conv_up2_h2x: shape mismatch x%s out%s" % (tuple(xh.shape), tuple(out.shape)))
-
-        def packer(w16, _m):
-            packed = torch.empty(self.lib.bfsr_conv_packed_size_up2_h2x(Cout, Cin), dtype=torch.int16)
-            _lib.check(self.lib.bfsr_pack_conv_weight_up2_h2x(w16.data_ptr(), Cout, Cin, pw.scale, packed.data_ptr()), "pack_up2_h2x")
-            return packed.to(self.device)
-        a.w = pw.variant("up2_h2x", packer).data_ptr()
-        a.Cin, a.y, a.y_bs, a.Cout = Cin, yp, ybs, Cout
-        a.B, a.H, a.W, a.KS, a.mtile, a.tune = out.shape[0], H, W, 3, 1, tune
-        a.epi, a.act, a.slope = _ptr(epi), act, slope
-        a.arith, a.acc_scale = 1, 1.0 / pw.scale
-        if pre_add is not None:
-            pp, bs, c, hh, ww = _view(pre_add, "conv_up2_h2x.pre_add")
-            assert (c, hh, ww) == (Cout, H, W)
-            a.pre_add, a.pre_add_bs = pp, bs
-        key = ("conv_up2_h2x", 1, Cin, Cout, out.shape[0], H, W, 0)
-        _lib.check(self._launch(key, lambda: self.lib.bfsr_conv2d_up2_h2x(C.byref(a), self._stream())), "conv2d_up2_h2x")
         return out
 
     # ---- split tensors: x3 (exact 3-term bf16 split, conv_x3s.hip) under split == "bf16x3", h2 (fp16 hi + lo, conv3x3_h2x_kernel in

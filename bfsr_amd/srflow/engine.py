@@ -25,8 +25,12 @@ from .options import opt_get
 from ..ops import ACT_LRELU, ACT_NONE, ACT_RELU, MODE_BILINEAR, MODE_BILINEAR_AC, MODE_NEAREST
 
 FUSED_COUPLING_C = (12, 24)                                     # flow widths the coupling_head / coupling_tail pair is built for
-_QUADS = os.environ.get("BFSR_QUADS", "1") != "0"               # quad-major hand-over of pre_aff / h_ft to the coupling pair (A/B switch)
-_COUPLING_MODE = os.environ.get("BFSR_COUPLING", "fused")       # "unfused": generic launches for the sequential part (A/B and parity reference)
+# BFSR_COUPLING: "fused" (default) = coupling_head / coupling_tail pair with the quad-major hand-over of pre_aff / h_ft; "fused-nchw" = the
+# pair on NCHW tensors; "unfused" = generic launches for the sequential part (A/B and parity reference)
+_COUPLING_MODE = os.environ.get("BFSR_COUPLING", "fused")
+if _COUPLING_MODE not in ("fused", "fused-nchw", "unfused"):
+    raise ValueError("BFSR_COUPLING must be 'fused', 'fused-nchw' or 'unfused'")
+_QUADS = _COUPLING_MODE == "fused"
 # fea_up{k} lives at LR resolution * 2^shift
 _KEY_SHIFT = {"fea_up0": -1, "fea_up1": 0, "fea_up2": 1, "fea_up4": 2, "fea_up8": 3}
 
@@ -83,7 +87,7 @@ class RRDBEncoder(object):
     Default path (split contraction): the dense blocks live in HBM as split tensors (ops.x3_empty: h2 = fp16 hi + lo under
     BFSR_SPLIT=f16x2, x3 = exact 3-term bf16 under bf16x3) and every RDB conv runs on the LDS-DMA kernel of that split (conv_h2x /
     conv_x3s: staging by dedicated loader waves); conv_first's output is packed
-    once, tapped block outputs and the trunk output are unpacked / written as fp32.  `BFSR_RRDB=fp32` (or a backend without
+    once, tapped block outputs and the trunk output are unpacked / written as fp32.  `BFSR_CONV=f32` (or a backend without
     conv_x3s, or precision='fp16') keeps fp32 NCHW block buffers and the register-staged kernels."""
 
     def __init__(self, ops, sd, prefix, nb, nf=64, gc=32, skip_from_first=False, f16=False):
@@ -91,7 +95,7 @@ class RRDBEncoder(object):
         # whereas SRFlow's adds the trunk output (`last_lr_fea = fea + trunk` after the loop rebinds `fea`,
         # RRDBNet_arch.py:92-103)
         self.ops, self.nb, self.nf, self.gc, self.skip_from_first = ops, nb, nf, gc, skip_from_first
-        packed_ok = nf % 16 == 0 and gc % 16 == 0 and os.environ.get("BFSR_RRDB", "x3") != "fp32"
+        packed_ok = nf % 16 == 0 and gc % 16 == 0
         self.x3s = not f16 and getattr(ops, "conv_mode", "f32") == "x3" and hasattr(ops, "conv_x3s") and packed_ok
         self.h2s = f16 and hasattr(ops, "conv_h2s") and packed_ok and nf % 32 == 0 and gc % 32 == 0
         g = lambda n: sd[prefix + n]
@@ -322,10 +326,8 @@ class SRFlowEngine(object):
             # an x3 copy of the key channels instead of the register-staged conv_bf16x3 kernel: 5.51 -> 4.80 ms at 8 x 320^2
             # (175 -> 201 TFLOP/s-equivalent).  The 320 -> 1024 hoists of the coarser levels were measured too and are NOT moved:
             # 5.17 -> 5.45 ms at 8 x 160^2 -- conv_x3s tiles 32 output channels per workgroup, so a 1024-channel conv re-stages every
-            # input tile 32 times (33 GB through L2 per launch), conv_bf16x3's 64-channel tiles half as often.  BFSR_HOIST=x3s-all /
-            # bf16x3 select everything / nothing.
-            hmode = os.environ.get("BFSR_HOIST", "x3s-keys")
-            hz["x3s"] = bool(getattr(self.rrdb, "x3s", False)) and hmode in ("x3s-keys", "x3s-all")
+            # input tile 32 times (33 GB through L2 per launch), conv_bf16x3's 64-channel tiles half as often.
+            hz["x3s"] = bool(getattr(self.rrdb, "x3s", False))
             if self._taps_up2(level):
                 # the 256 stacked-RRDB channels of this level are the LR-resolution taps upsampled x2: their share of the
                 # 3x3 conv runs on the LR grid with parity pre-summed weights (4/9 of the MACs, nothing materialised);
@@ -344,9 +346,6 @@ class SRFlowEngine(object):
                 else:
                     hz.update(ft0_taps=ops.pack_conv_up2(wf[:, 64:].contiguous()), aff0_taps=ops.pack_conv_up2(wa[:, 64:].contiguous()),
                               ft0_key=ops.pack_conv(wf[:, :64].contiguous(), 2), aff0_key=ops.pack_conv(wa[:, :64].contiguous(), 2))
-            elif hz["x3s"] and hmode == "x3s-all" and wf.shape[1] % 16 == 0:
-                hz.update(ft0_pw=ops.pack_conv_x3(wf, 1), ft0_epi=ops.pack_epilogue(wf.shape[0], aff_shift=sh, aff_scale=sc),
-                          aff0_pw=ops.pack_conv_x3(wa, 1))
             else:
                 hz["x3s"] = False
                 hz.update(ft0=_ConvP(ops, wf, aff_shift=sh, aff_scale=sc, mtile=2), aff0=_ConvP(ops, wa, mtile=2))
@@ -491,19 +490,6 @@ class SRFlowEngine(object):
                 self._ftx3 = {}
             if level not in self._ftx3 or self._ftx3[level][0] != key:
                 self._ftx3[level] = (key, self.ops.x3_empty(B, cx, hl, wl))
-        # BFSR_TAPS=h2x: h2 copy of the taps for the LDS-DMA taps kernel (conv_up2_h2x).  Measured EQUAL to the register-staged kernel
-        # (83.2 vs 83.1 ms per cfg2 step, 6.7 ms per launch either way: an item = 32 output channels x one row parity re-stages the
-        # 256-channel tile 64 times and reads / writes 6.7 GB of pre_add / output behind its K loop), so the default stays "reg".
-        if (hz.get("up2") and hz.get("x3") and hz.get("up") == 1 and getattr(self.ops, "split", "") == "f16x2"
-                and hasattr(self.ops, "conv_up2_h2x") and os.environ.get("BFSR_TAPS", "reg") == "h2x"):
-            tl = ft[self._lr_level()]
-            ct = tl.shape[1] - 64
-            if ct > 0 and ct % 16 == 0:
-                key = (B, ct, tl.shape[2], tl.shape[3])
-                if getattr(self, "_tapsx", None) is None:
-                    self._tapsx = {}
-                if level not in self._tapsx or self._tapsx[level][0] != key:
-                    self._tapsx[level] = (key, self.ops.h2_empty(*key))
         return (ws.get("hoist_hid%d" % level, B, K * 64, hl, wl), ws.get("pre_aff%d" % level, B, K * 64, hl, wl),
                 ws.get("h_ft%d" % level, B, K * 2 * Cz, hl, wl), Cz)
 
@@ -526,10 +512,6 @@ class SRFlowEngine(object):
                     ops.conv_x3s(f3, hz["ft0_key"], hid)
                 else:
                     ops.conv_x3(f, hz["ft0_key"], hid)
-                tx = getattr(self, "_tapsx", None)
-                if tx is not None and level in tx and tuple(tx[level][0]) == (B, taps.shape[1], taps.shape[2], taps.shape[3]):
-                    taps_h = ops.h2_pack(taps, tx[level][1])               # both launches read the h2 copy by LDS-DMA
-                    up = lambda _t, pw, out, **kw: ops.conv_up2_h2x(taps_h, pw, out, **kw)
                 up(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, pre_add=hid)
                 if hz["x3s"]:
                     ops.conv_x3s(f3, hz["aff0_key"], pre_aff, **kq)
@@ -539,10 +521,6 @@ class SRFlowEngine(object):
             else:
                 ops.conv_up2(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, key=(f, hz["ft0_key"]))
                 ops.conv_up2(taps, hz["aff0_taps"], pre_aff, key=(f, hz["aff0_key"]))
-        elif hz["x3s"]:
-            f3 = ops.x3_pack(f, self._ftx3[level][1])
-            ops.conv_x3s(f3, hz["ft0_pw"], hid, epi=hz["ft0_epi"], act=ACT_RELU)
-            ops.conv_x3s(f3, hz["aff0_pw"], pre_aff)
         else:
             hz["ft0"].run(ops, f, hid, act=ACT_RELU)
             hz["aff0"].run(ops, f, pre_aff, **kq)

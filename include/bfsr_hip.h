@@ -191,14 +191,6 @@ int bfsr_pack_conv_weight_h2s(const float* w_oihw, int Cout, int Cin, unsigned s
  * y_fmt 0: fp32 NCHW view, 1: h2 view (both planes).  Cin % 16 == 0.  Replaces the dense-block convs of
  * SRFlow-LP/code/models/modules/RRDBNet_arch.py:25-65 on the default (fp32-accurate) path. */
 int bfsr_conv3x3_h2x(const BfsrConvX3Args* a, void* stream);
-/* bfsr_conv2d_up2_h2x: the conv over nearest_up2(taps) of bfsr_conv2d_up2_bf16x3 (same 16 parity-pre-summed matrices, same epilogue
- * incl. pre_add = the key channels' partial sums; no residuals) with the TAPS as an h2 tensor at source resolution, staged by LDS-DMA:
- * a->x = h2 view [B][Cin/8][2][H/2][W/2][8] (x_bs in fp16 elements), a->w from bfsr_pack_conv_weight_up2_h2x(w16 [Cout][Cin][16], scale),
- * a->acc_scale = 1/scale, y / pre_add fp32 NCHW at output resolution (8-byte aligned).  Cin % 16 == 0, H and W even.
- * Replaces the level-1 ft rows of fFeatures / fAffine (FlowAffineCouplingsAblation.py:108-119) over the upsampled RRDB taps. */
-int bfsr_conv2d_up2_h2x(const BfsrConvArgs* a, void* stream);
-long long bfsr_conv_packed_size_up2_h2x(int Cout, int Cin);
-int bfsr_pack_conv_weight_up2_h2x(const float* w16, int Cout, int Cin, float scale, unsigned short* packed);
 long long bfsr_conv_packed_size_h2x(int Cout, int Cin, int mtile);
 int bfsr_pack_conv_weight_h2x(const float* w_oihw, int Cout, int Cin, int mtile, float scale, unsigned short* packed);
 int bfsr_h2_pack(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int C, int H, int W, unsigned* flag /* optional range guard */, void* stream);

@@ -1,5 +1,6 @@
-"""-m gpu: run-to-run bitwise determinism of the MFMA kernels (tools/determinism_stress.py, 30 launches each): an intermittent
-operand-register hazard (see coupling_step.hip) produces bf16-sized faults in a fraction of the launches, which one parity run can miss."""
+"""-m gpu: run-to-run bitwise determinism -- of every MFMA kernel alone (tools/determinism_stress.py, 30 launches each) and of the
+engines' whole kernel sequences (300 rounds): timing-dependent faults show in a fraction of the launches, which one parity run can miss
+("the head fault")."""
 import os
 import subprocess
 import sys
@@ -15,32 +16,39 @@ def test_mfma_kernels_are_run_to_run_deterministic():
     assert r.returncode == 0 and "TOTAL differing launches: 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-def test_engine_encode_is_reproducible_run_to_run():
-    """The fault that isolated kernel stress does not see: inside the engine's kernel sequence the 8-wave coupling_head produced a wrong
-    half row tile once in 10^3-10^4 launches (round 3; the default is the 4-wave form since).  40 encode -> decode -> encode(one sample)
-    rounds on fixed inputs must reproduce round 0 bit for bit, and the single-sample call must equal the batch call's sample."""
+@pytest.mark.parametrize("scale,lr_size,overlap", [(4, 160, None), (4, 160, "0"), (8, 96, None)])
+def test_engine_is_reproducible_run_to_run(scale, lr_size, overlap, monkeypatch):
+    """The fault class that isolated kernel stress does not see (round 3: the 8-wave coupling_head wrote a wrong half row once in
+    10^3-10^4 launches, only inside the engine's kernel sequence; study: tools/exp/head_fault.py).  300 rounds of
+    encode(B=2) -> decode -> encode(sample 1) on fixed inputs -- ~20 000 head and tail launches per case -- must reproduce round 0 bit for bit,
+    and the single-sample call must equal the batch call's sample.  Cases: the 4x model with and without the side stream, the 8x model
+    (C = 12 / 24 levels at 384^2 / 192^2)."""
     import torch
     from bfsr_amd import synth
     from bfsr_amd.ops import HipOps, MODE_BILINEAR
     from test_srflow_gpu import build
+    if overlap is not None:
+        monkeypatch.setenv("BFSR_OVERLAP", overlap)
     hip = HipOps("cuda:0")
-    m, prior, opt, sd, psd = build(hip, 4)
+    m, prior, opt, sd, psd = build(hip, scale)
     eng = m.netG.module.engine()
-    lr = hip.to_device(synth.smooth_lr_batch(21, 2, 160, 160))
-    lr_up = hip.resize(lr, hip.empty(2, 3, 640, 640), MODE_BILINEAR, 0.25, 0.25)
+    lr = hip.to_device(synth.smooth_lr_batch(21, 2, lr_size, lr_size))
+    lr_up = hip.resize(lr, hip.empty(2, 3, lr_size * scale, lr_size * scale), MODE_BILINEAR, 1.0 / scale, 1.0 / scale)
     lr1, lr_up1 = lr[1:2].clone(), lr_up[1:2].clone()
-    ref2 = ref1 = None
-    for it in range(40):
+    ref2 = ref1 = rt0 = None
+    for it in range(300):
         ep = [e.clone() for e in eng.encode(lr_up, lr)]
         rt = eng.decode(lr, epses=[e.clone() for e in ep]).clone()
         ep1 = [e.clone() for e in eng.encode(lr_up1, lr1)]
         if ref2 is None:
             ref2, ref1, rt0 = ep, ep1, rt
+            continue
         for lvl in range(len(ep)):
             assert torch.equal(ep[lvl], ref2[lvl]), "round %d: encode(B=2) eps%d differs from round 0" % (it, lvl)
             assert torch.equal(ep1[lvl], ref1[lvl]), "round %d: encode(B=1) eps%d differs from round 0" % (it, lvl)
             assert torch.equal(ep[lvl][1:2], ep1[lvl]), "round %d: eps%d of sample 1 depends on the batch" % (it, lvl)
         assert torch.equal(rt, rt0), "round %d: decode differs from round 0" % it
+    hip.check_range()
 
 
 def test_linf_pipeline_is_reproducible_run_to_run():

@@ -323,18 +323,6 @@ def test_conv_h2x_dense_block_views_and_residuals(hip):
     close(hip.h2_unpack(nxt[:, :8], hip.empty(B, 64, H, W)), out_ref, 2e-5, "h2x conv5 residuals")
 
 
-@pytest.mark.parametrize("env", [{"BFSR_H2S_PP": "1"}, {"BFSR_H2S_WREG": "1"}, {"BFSR_H2S_PP": "1", "BFSR_H2S_WREG": "1"}, {"BFSR_H2X_MT": "2"}, {"BFSR_TAPS_MT": "2"}])
-def test_conv_h2s_kernel_variants(hip, env):
-    """The selectable conv_h2s / conv_h2x variants (ping-pong compute groups, weight pieces through a register loader, 64-cout workgroup
-    tiles; conv_h2s.hip) against the same tests: the switches are read once per process, so the tests run in a child interpreter."""
-    import os, subprocess, sys
-    e = dict(os.environ, **env)
-    here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_hip_ops.py"), "-q", "-x", "-k",
-                        "(conv_h2s or conv_h2x or conv_up2 or persistent) and not variants"], env=e, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-
-
 def test_conv_epilogue_all_stages(hip):
     B, Cin, Cout, H, W = 2, 40, 48, 21, 35
     x, w = rnd(5, B, Cin, H, W), rnd(6, Cout, Cin, 3, 3, scale=0.08)
@@ -776,36 +764,6 @@ def test_quad_major_outputs_are_the_same_values(hip, case):
     hip.conv_x3(kd, pk, wide_q[:, 4:4 + Cout], y_fmt=1)
     assert torch.equal(CPU.quads(wide_q[:, 4:4 + Cout].cpu().contiguous(), inverse=True), wide_r[:, 4:4 + Cout].cpu())
     assert float(wide_q[:, :4].abs().max()) == 0.0 and float(wide_q[:, 4 + Cout:].abs().max()) == 0.0, "wrote outside its channel slice"
-
-
-@pytest.mark.parametrize("case", [(2, 64, 64, 64, 9, 21), (1, 256, 64, 128, 12, 40), (1, 48, 16, 96, 33, 50), (3, 32, 8, 40, 16, 32), (1, 16, 0, 24, 37, 70)])
-@pytest.mark.parametrize("tune", [0, 3])
-def test_conv_up2_h2x_with_key_channels(hip, case, tune):
-    """The taps kernel over h2 taps (LDS-DMA, persistent: conv_up2_h2x_kernel) == the conv over cat[key, nearest_up2(taps)] at fp32
-    accuracy, with the key channels' partial sums arriving as pre_add (aliasing the output), ragged tiles, several items per workgroup."""
-    B, Ct, Ck, Cout, h, w_ = case
-    taps = rnd(180, B, Ct, h, w_)
-    w = rnd(182, Cout, Ck + Ct, 3, 3, scale=1.0 / np.sqrt((Ck + Ct) * 9))
-    sh, sc = rnd(183, Cout, scale=0.2), torch.exp(rnd(184, Cout, scale=0.2))
-    wk, wt = w[:, :Ck].contiguous(), w[:, Ck:].contiguous()
-    th = hip.h2_pack(hip.to_device(taps), hip.h2_empty(B, Ct, h, w_))
-    t22 = hip.h2_unpack(th, hip.empty(B, Ct, h, w_)).cpu()                 # the 22-bit taps the kernel contracts
-    up = torch.nn.functional.interpolate(t22, scale_factor=2, mode="nearest")
-    out = hip.empty(B, Cout, 2 * h, 2 * w_)
-    if Ck:
-        key = rnd(181, B, Ck, 2 * h, 2 * w_)
-        hip.conv_x3(hip.to_device(key), hip.pack_conv_x3(wk, 2), out)
-        xin = torch.cat([key, up], 1)
-    else:
-        xin = up
-    truth = torch.relu((torch.nn.functional.conv2d(xin.double(), w.double(), padding=1) + sh.double().view(1, -1, 1, 1)) * sc.double().view(1, -1, 1, 1))
-    hip.conv_up2_h2x(th, hip.pack_conv_up2_x3(wt), out, epi=hip.pack_epilogue(Cout, aff_shift=sh, aff_scale=sc), act=1,
-                     pre_add=out if Ck else None, tune=tune)
-    ref32 = torch.relu((torch.nn.functional.conv2d(xin, w, padding=1) + sh.view(1, -1, 1, 1)) * sc.view(1, -1, 1, 1))
-    ex = (out.cpu().double() - truth).abs().max().item()
-    e32 = (ref32.double() - truth).abs().max().item()
-    assert ex <= 4.0 * e32 + 1e-7, (ex, e32)
-    close(out, ref32, 1e-5, "conv_up2_h2x %s" % (case,))
 
 
 def test_likelihood_reductions(hip):

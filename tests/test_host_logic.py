@@ -252,7 +252,7 @@ def test_split_packing_is_exact_and_laid_out_as_documented():
 def test_fp16_pair_packers_layout_and_accuracy():
     """Host-side packers of the two-term fp16 split (no GPU needed): hi + lo reproduces w * scale to 2^-22 relative (to 2^-25 * |w|max
     absolutely once the lo term is subnormal) at the documented slots of the register-staged kernels (taps layout, 2 planes), of
-    conv3x3_h2x_kernel ([group][chunk][plane][tap = dx*3 + dy][m tile][k half][32][8]) and of conv_up2_h2x_kernel (step order)."""
+    conv3x3_h2x_kernel ([group][chunk][plane][tap = dx*3 + dy][m tile][k half][32][8]) and of its coupling-tail form."""
     from bfsr_amd import _lib
     from bfsr_amd.ops import HipOps
     lib = _lib.load()
@@ -289,20 +289,27 @@ def test_fp16_pair_packers_layout_and_accuracy():
             assert abs(got - ref) <= tol(ref), (co, ci, dy, dx)
         if mt == 1:                                                       # cout padding of the last group (couts 70..95) is zero
             assert float(P[-1, :, :, :, 0, :, 70 - 64:, :].abs().sum()) == 0.0
-    # --- conv_up2_h2x_kernel: [group][chunk][row parity][plane][step][k half][32][8], step s = (b = s>>2, i = s&1, j = (s>>1)&1)
-    w16 = HipOps.presum_up2_weights(w)                                    # [Cout, Cin, 16], t = (a*2+b)*4 + i*2 + j
-    s16 = HipOps.pow2_scale(w16)
-    n = lib.bfsr_conv_packed_size_up2_h2x(Cout, Cin)
-    groups, nchunk = (Cout + 31) // 32, Cin // 16
-    assert n == groups * nchunk * 2 * 2 * 8 * 2 * 32 * 8
+    # --- coupling tail (fAffine.4 for conv3x3_h2x_kernel's coupling epilogue): Cout <= 16 -> the two-instruction form, plane 0 = [rows 0-15:
+    #     hi | rows 16-31: lo], plane 1 = [rows 0-15: hi | 0]; Cout > 16 -> the plain h2x packing of one 32-row tile
+    w4 = torch.randn(12, 64, 3, 3) * 0.01
+    s4 = HipOps.pow2_scale(w4)
+    n = lib.bfsr_coupling_tail_packed_size(64, 12)
+    assert n == 4 * 2 * 9 * 2 * 32 * 8 and lib.bfsr_coupling_tail_packed_size(48, 12) < 0 and lib.bfsr_coupling_tail_packed_size(64, 40) < 0
     p = torch.zeros(n, dtype=torch.int16)
-    assert lib.bfsr_pack_conv_weight_up2_h2x(w16.data_ptr(), Cout, Cin, s16, p.data_ptr()) == 0
-    P = f16(p).view(groups, nchunk, 2, 2, 8, 2, 32, 8)
-    for co, ci, a, s_ in ((0, 0, 0, 0), (69, 47, 1, 7), (33, 17, 0, 5), (64, 8, 1, 2)):
-        b, i, j = s_ >> 2, s_ & 1, (s_ >> 1) & 1
-        got = P[co // 32, ci // 16, a, :, s_, (ci % 16) // 8, co % 32, ci % 8].sum()
-        ref = w16[co, ci, (a * 2 + b) * 4 + i * 2 + j].double() * s16
-        assert abs(got - ref) <= tol(ref), (co, ci, a, s_)
+    assert lib.bfsr_pack_coupling_tail(w4.data_ptr(), 64, 12, s4, p.data_ptr()) == 0
+    P = f16(p).view(4, 2, 9, 2, 32, 8)                                    # [chunk][plane][tap = dx*3 + dy][k half][row][8]
+    for co, ci, dy, dx in ((0, 0, 0, 0), (11, 47, 2, 2), (5, 17, 1, 0)):
+        sel = (ci // 16, slice(None), dx * 3 + dy, (ci % 16) // 8)
+        hi0, lo0, hi1 = P[ci // 16, 0, dx * 3 + dy, (ci % 16) // 8, co, ci % 8], P[ci // 16, 0, dx * 3 + dy, (ci % 16) // 8, 16 + co, ci % 8], \
+            P[ci // 16, 1, dx * 3 + dy, (ci % 16) // 8, co, ci % 8]
+        ref = w4[co, ci, dy, dx].double() * s4
+        assert hi0 == hi1 and abs((hi0 + lo0) - ref) <= tol(ref), (co, ci, dy, dx)
+        assert float(P[ci // 16, 1, dx * 3 + dy, (ci % 16) // 8, 16 + co, ci % 8]) == 0.0
+    assert float(P[:, :, :, :, 12:16].abs().sum()) == 0.0 and float(P[:, :, :, :, 28:].abs().sum()) == 0.0
+    w4b = torch.randn(24, 64, 3, 3) * 0.01
+    pa, pb = torch.zeros(n, dtype=torch.int16), torch.zeros(n, dtype=torch.int16)
+    assert lib.bfsr_pack_coupling_tail(w4b.data_ptr(), 64, 24, s4, pa.data_ptr()) == 0
+    assert lib.bfsr_pack_conv_weight_h2x(w4b.data_ptr(), 24, 64, 1, s4, pb.data_ptr()) == 0 and torch.equal(pa, pb)
     # --- fused MLP, per-layer scales
     HD, Co4 = 256, 72
     ws = [torch.randn(HD, 4 * HD) * 0.03, torch.randn(HD, HD) * 0.06, torch.randn(HD, HD) * 0.5, torch.randn(Co4, HD) * 2.0]

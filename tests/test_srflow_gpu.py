@@ -156,6 +156,30 @@ def test_roundtrip_and_batch_invariance_at_bench_size(model4, hip):
                                  % (lvl, float(df.max()), idx.shape[0], df.numel(), idx[0].tolist(), sorted(set(idx[:, 1].tolist()))[:12]))
 
 
+def test_roundtrip_and_batch_invariance_at_config4_size(hip):
+    """BASELINE config 4's per-GPU batch on the 8x model (B = 8, 96x96 LR -> 768x768): decode(encode(x)) = x within 1e-4, the LP pass is
+    finite, and a shard of the batch gives bit-identical latents (what the data-parallel split of the 64-crop batch relies on)."""
+    from bfsr_amd.ops import MODE_BILINEAR
+    from bfsr_amd.srflow.test import lp_infer
+    m, prior, opt, sd, psd = build(hip, 8)
+    eng = m.netG.module.engine()
+    lr = hip.to_device(synth.smooth_lr_batch(61, 8, 96, 96))
+    lr_up = hip.resize(lr, hip.empty(8, 3, 768, 768), MODE_BILINEAR, 0.125, 0.125)
+    ep = [e.clone() for e in eng.encode(lr_up, lr)]
+    rt = eng.decode(lr, epses=[e.clone() for e in ep])
+    err = (rt - lr_up).abs().max().item()
+    assert err <= 1e-4, "round trip %.3e" % err
+    lo, hi_ = 2, 5                                        # a middle shard
+    lrs, lrus = lr[lo:hi_].clone(), lr_up[lo:hi_].clone()
+    eps_s = eng.encode(lrus, lrs)
+    for lvl, (a, b) in enumerate(zip(ep, eps_s)):
+        assert torch.equal(a[lo:hi_], b), "eps%d of a shard differs from the batch call: max %.3e" % (lvl, float((a[lo:hi_] - b).abs().max()))
+    sr = lp_infer(m, prior, lr)
+    sr_s = lp_infer(m, prior, lrs)
+    assert torch.isfinite(sr).all() and sr.shape == (8, 3, 768, 768)
+    assert torch.equal(sr[lo:hi_], sr_s), "LP output of a shard differs from the batch call"
+
+
 def test_tau_path_runs(model4, hip):
     """Non-LP sampling path (get_z + Split2d sampling): finite output of the right shape."""
     m, prior, opt, sd, psd = model4

@@ -1,5 +1,5 @@
 """Run-to-run determinism of the MFMA kernels under load: every kernel is launched N times on the same inputs and each result is
-compared BITWISE with the first.  Motivation (round 3): coupling_step_kernel produced wrong columns in ~1 of 3 launches until its
+compared BITWISE with the first.  Motivation (round 3): the fused step kernel (tools/exp/kernels/coupling_step.hip) produced wrong columns in ~1 of 3 launches until its
 MFMA operand registers were kept allocated for a chunk behind their last use (a dead SrcA/SrcB register that hipcc recycles at
 once can be overwritten before a queued MFMA has read it when two waves share a SIMD's matrix pipe); such a fault is
 intermittent and bf16-sized, i.e. a single parity run can miss it.  Usage (GPU box): python tools/determinism_stress.py [N] [noise]

@@ -5,8 +5,8 @@ set -e
 cd "$(dirname "$0")/../../bfsr_amd/csrc"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off"
-$HIPCC $FLAGS -DBFSR_X3S_ABL -c conv_x3s.hip -o build/conv_x3s_abl.o &
-$HIPCC $FLAGS -DBFSR_H2S_ABL -c conv_h2s.hip -o build/conv_h2s_abl.o &
+$HIPCC $FLAGS -DBFSR_X3S_ABL -I. -c ../../tools/exp/kernels/conv_x3s_r3.hip -o build/conv_x3s_abl.o &
+$HIPCC $FLAGS -DBFSR_H2S_ABL -I. -c ../../tools/exp/kernels/conv_h2s_r3.hip -o build/conv_h2s_abl.o &
 wait
 objs=""
 for f in conv_mfma conv_f16 conv_bf16x3 conv1x1 flow_ops coupling coupling_step resample linf_ops linf_mlp metrics; do objs="$objs build/$f.o"; done

@@ -74,17 +74,95 @@ __device__ __forceinline__ void wait_vmcnt(int n)
 // `s_waitcnt vmcnt(N)` stands for "everything but the youngest N/np stages has landed" because a loader issues the same number np
 // of pieces for every chunk -- and only ONE KIND of load: LDS-DMA pieces and ordinary register loads of one wave do NOT complete
 // in issue order relative to each other (measured: a wave mixing them passed the barrier with input pieces still in flight).
-//   Four DMA loaders: piece i of a stage (i < 20: input position group i>>1, k half i&1; else weight piece i-20) -> loader i % 4.
+//   wreg = 0: four DMA loaders, piece i of a stage (i < 20: input position group i>>1, k half i&1; else weight piece i-20) -> loader i % 4
+//   wreg = 1: three DMA loaders for the 20 input pieces; loader 3 moves the 9 weight pieces through REGISTERS (buffer_load -> VGPR when
+//             the stage is issued, ds_write_b128 just before the chunk's barrier).  The DMA path sustains ~27 GB/s per CU (what the
+//             kernel with its K loop removed reaches); the weights are 31 % of a stage and take the ordinary load path instead.
 template <class Decode>
 __device__ __forceinline__ void h2s_loader_wave(const BfsrConvX3Args& p, unsigned char* smem, int wave, int lane, int slot, int G, int groups,
-                                                int nchunk, int T, unsigned HW16, Decode decode)
+                                                int nchunk, int T, unsigned HW16, int abl, bool wreg, Decode decode)
 {
     const int H = p.H, W = p.W;
     const int ld = wave - NW;
     constexpr int NWPIECE = W_BYTES / 1024;                          // 9
+    if (wreg && ld == NLW - 1) {
+        // ---- the register loader.  Inline asm with a TIED operand: the compiler must not know the loads are asynchronous (with the
+        // builtin it copies the registers behind an `s_waitcnt vmcnt(0)` right after the issue, draining all stages in flight), and
+        // the load must land in the slot's own registers ("=v" gives a fresh register that is COPIED to the slot before the data
+        // has arrived).  Issued unconditionally (out-of-range offset = no memory access) for the same reason: under a branch the
+        // tied register is copied at the merge.  The registers are read only behind wait_vmcnt().
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        i32x4 rsw;
+        {
+            const unsigned long long wa = reinterpret_cast<unsigned long long>(p.w);
+            rsw[0] = (int)(unsigned)wa; rsw[1] = (int)(unsigned)(wa >> 32);
+            rsw[2] = (int)(unsigned)((long long)groups * nchunk * W_BYTES); rsw[3] = 0x00020000;
+        }
+        static_assert(NS - 2 == 3, "three register slots = stages in flight");
+        u32x4 w[3][NWPIECE];
+#pragma unroll
+        for (int a_ = 0; a_ < 3; ++a_)
+#pragma unroll
+            for (int j = 0; j < NWPIECE; ++j) w[a_][j] = u32x4{0u, 0u, 0u, 0u};
+        int issued = 0, iss_it = slot, iss_k = 0, cbuf = 0;
+        int cg_ = 0;
+        const unsigned wv = (unsigned)lane * 16u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BFSR_WLOAD(R_, VO_, SO_) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(R_) : "v"(VO_), "s"(rsw), "s"(SO_) : "memory")
+#else
+#define BFSR_WLOAD(R_, VO_, SO_) (void)0
+#endif
+#define BFSR_ISSUE(SL_)                                                                                                  \
+    do {                                                                                                                \
+        bool on_ = issued < T;                                                                                          \
+        unsigned so_ = 0;                                                                                               \
+        if (on_) {                                                                                                      \
+            if (iss_k == 0) cg_ = decode(iss_it).cg;                                                                    \
+            so_ = (unsigned)(cg_ * nchunk + iss_k) * (unsigned)W_BYTES;                                                 \
+            BFSR_ABL_SKIP                                                                                               \
+            ++issued;                                                                                                   \
+            if (++iss_k == nchunk) { iss_k = 0; iss_it += G; }                                                          \
+        }                                                                                                               \
+        so_ = (unsigned)__builtin_amdgcn_readfirstlane((int)so_);                                                       \
+        _Pragma("unroll") for (int j = 0; j < NWPIECE; ++j) BFSR_WLOAD(w[SL_][j], on_ ? wv + (unsigned)j * 1024u : OOB, so_); \
+    } while (0)
+#ifdef BFSR_H2S_ABL
+#define BFSR_ABL_SKIP if (issued >= NS - 2 && (abl & 2)) on_ = false;
+#else
+#define BFSR_ABL_SKIP
+#endif
+#define BFSR_LAND(SL_, CH_)                                                                                              \
+    do {                                                                                                                \
+        wait_vmcnt((issued - (CH_) - 1) * NWPIECE);                    /* all but the stages issued after this chunk's */ \
+        unsigned char* wb_ = smem + cbuf * STAGE + IN_BYTES + lane * 16;                                                \
+        _Pragma("unroll") for (int j = 0; j < NWPIECE; ++j) *reinterpret_cast<u32x4*>(wb_ + j * 1024) = w[SL_][j];       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
+        cbuf = cbuf + 1 == NS ? 0 : cbuf + 1;                                                                           \
+        __builtin_amdgcn_s_barrier();                                                                                   \
+    } while (0)
+        BFSR_ISSUE(0);
+        BFSR_ISSUE(1);
+        BFSR_ISSUE(2);
+        for (int c = 0; c < T; c += 3) {
+            BFSR_LAND(0, c);
+            BFSR_ISSUE(0);
+            if (c + 1 >= T) break;
+            BFSR_LAND(1, c + 1);
+            BFSR_ISSUE(1);
+            if (c + 2 >= T) break;
+            BFSR_LAND(2, c + 2);
+            BFSR_ISSUE(2);
+        }
+#undef BFSR_LAND
+#undef BFSR_ISSUE
+#undef BFSR_WLOAD
+#undef BFSR_ABL_SKIP
+        return;
+    }
     // ---- DMA loaders
-    constexpr int ND = NLW;                                          // DMA loaders
-    constexpr int NPALL = NPIECE;                                    // pieces they share
+    const int ND = wreg ? NLW - 1 : NLW;                             // DMA loaders
+    const int NPALL = wreg ? 20 : NPIECE;                            // pieces they share
     const int np = (NPALL - ld + ND - 1) / ND;
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w), 0,
                                                                           (unsigned)((long long)groups * nchunk * W_BYTES), 0x00020000);
@@ -127,20 +205,29 @@ __device__ __forceinline__ void h2s_loader_wave(const BfsrConvX3Args& p, unsigne
     int issued = 0, iss_it = slot, iss_k = 0, iss_buf = 0;
     auto issue = [&]() {
         if (iss_k == 0) lsetup(decode(iss_it));
+#ifdef BFSR_H2S_ABL
+        lstage(iss_k, iss_buf, issued >= NS - 2 ? abl & 3 : 0);
+#else
         lstage(iss_k, iss_buf, 0);
+#endif
         ++issued;
         iss_buf = iss_buf + 1 == NS ? 0 : iss_buf + 1;
         if (++iss_k == nchunk) { iss_k = 0; iss_it += G; }
     };
     for (int i = 0; i < NS - 2 && issued < T; ++i) issue();
     for (int c = 0; c < T; ++c) {
+#ifdef BFSR_H2S_ABL
+        if (abl & 3) wait_vmcnt(0); else
+#endif
         wait_vmcnt((issued - c - 1) * np);                           // all but the stages issued after chunk c's
         __builtin_amdgcn_s_barrier();
         if (issued < T) issue();
     }
 }
 
-__global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrConvX3Args p, int tiles_x, int tiles_y, int groups, int nitems)
+// abl = ablation switches, honoured only in -DBFSR_H2S_ABL builds (tools/exp/h2s_bench.py): 1 = no input DMA after the first
+// stages, 2 = no weight DMA after them, 4 = no ds_read/MFMA, 8 = no epilogue
+__global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrConvX3Args p, int tiles_x, int tiles_y, int groups, int nitems, int abl, int flags)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -164,7 +251,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
     };
 
     if (wave >= NW) {
-        h2s_loader_wave(p, smem, wave, lane, slot, G, groups, nchunk, T, HW16, decode);
+        h2s_loader_wave(p, smem, wave, lane, slot, G, groups, nchunk, T, HW16, abl, (flags & 1) != 0, decode);
         return;
     }
 
@@ -236,6 +323,9 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[m][0][r] = 0.f; acc[m][1][r] = 0.f; }
+#ifdef BFSR_H2S_ABL
+        if (abl & 4) { for (int k = 0; k < nchunk; ++k) { if (c + 1 < T) __builtin_amdgcn_s_barrier(); ++c; } } else
+#endif
         for (int k = 0; k < nchunk; k += 2) {                            // Cin % 32 == 0: the register-buffer parity is static
             chunk_body(I0(), I1(), true);
             chunk_body(I1(), I0(), k + 2 < nchunk);                      // the last chunk of a tile leaves the registers to the epilogue
@@ -249,6 +339,16 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
         // ds_bpermute (reading epi[co] directly = 16 broadcast loads of 1 KiB per octet, after the last MFMA).  Residual
         // operands: ALL groups' loads are issued before the first is used -- one HBM round trip per residual and tile, not one
         // per octet (measured: the serialised version cost more than the K loop of the 192-channel conv).
+#ifdef BFSR_H2S_ABL
+        if (abl & 8) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) { asm volatile("" :: "v"(acc[m][0])); asm volatile("" :: "v"(acc[m][1])); }
+#endif
+            if (c < T) load_step(I0(), st, 0);
+            continue;
+        }
+#endif
         bool plain = true;
 #pragma unroll
         for (int m = 0; m < MT; ++m) plain = plain && ((lane & 1) ? pm[m].x == 1.f : (pm[m].y == 0.f && pm[m].z == 1.f && pm[m].w == 0.f));
@@ -292,7 +392,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
                         }
                     }
         }
-        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");       // MFMA result -> VALU read inside the asm below: 20 wait states (>= 19 of a 16-pass XDL op), self-sufficient
+        asm volatile("s_nop 11" ::: "memory");
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -408,6 +508,262 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
     }
 }
 
+// ---- PING-PONG variant (the product for Cin >= 64): the two compute waves of a SIMD (waves w and w+4) take turns -----------------
+// Same tiles, same LDS ring, same loader waves, same barrier sequence.  Group g = wave>>2 owns the tiles t of this workgroup with
+// (t & 1) == g; a wave owns FOUR rows of its group's tile (4 accumulator blocks, 9 LDS reads per 12 MFMAs).  While group g runs
+// the K loop of tile t -- alone on the matrix pipes, one wave per SIMD -- the other group runs the epilogue of tile t-1 on the VALU /
+// memory pipes of the same SIMDs, one row per barrier interval, and passes the same barriers (s_barrier counts every wave of the
+// workgroup; the epilogue group only keeps step).  The matrix pipe and the VALU are separate issue targets, so the epilogue that cost
+// 35 % of the kernel with all eight compute waves in it at the same time now runs beside the other group's MFMAs.
+__global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_pp_kernel(BfsrConvX3Args p, int tiles_x, int tiles_y, int groups, int nitems, int abl, int flags)
+{
+    constexpr int RW = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int G = gridDim.x;
+    const int slot = (int)bfsr::xcd_order(blockIdx.x, (unsigned)G);
+    if (slot >= nitems) return;
+    const int H = p.H, W = p.W;
+    const unsigned HW16 = (unsigned)(H * W) * 16u;
+    const int nchunk = p.Cin >> 4;
+    const int n_mine = (nitems - slot + G - 1) / G;
+    const int T = n_mine * nchunk;
+
+    auto decode = [&](int it) {
+        Item r;
+        r.cg = it % groups; int t = it / groups;
+        const int ty = t % tiles_y; t /= tiles_y;
+        r.x0 = (t % tiles_x) * 32; r.y0 = ty * TH; r.b = t / tiles_x;
+        return r;
+    };
+    if (wave >= NW) {
+        h2s_loader_wave(p, smem, wave, lane, slot, G, groups, nchunk, T, HW16, abl, (flags & 1) != 0, decode);
+        return;
+    }
+    const int cw = wave & 3, grp = wave >> 2;                            // row block of the tile (rows 4cw .. 4cw+3), tile parity this wave computes
+
+    half8 bq[2][RW + 2], aq[2][3];
+    auto load_step = [&](auto buf_, int st, int dx) {
+        constexpr int BUF = decltype(buf_)::value;
+        const unsigned char* sIn = smem + st * STAGE;
+        const unsigned char* inB = sIn + (lhi * NPOSP + RW * cw * PW + l31 + dx) * 16;
+        const unsigned char* wA = sIn + IN_BYTES + lane * 16 + dx * 3 * 1024;                           // tap = dx*3 + dy; (lhi*32 + l31) == lane
+#pragma unroll
+        for (int r = 0; r < RW + 2; ++r) bq[BUF][r] = *reinterpret_cast<const half8*>(inB + r * PW * 16);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) aq[BUF][dy] = *reinterpret_cast<const half8*>(wA + dy * 1024);
+    };
+    f32x16 acc[RW];
+    auto mfma_step = [&](auto buf_) {
+        constexpr int BUF = decltype(buf_)::value;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int j = 0; j < RW; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][dy], bq[BUF][dy + j], acc[j], 0, 0, 0);
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 3> I3;
+    int c = 0, st = 0;
+    auto chunk_body = [&](auto p_, auto q_, bool pf) {                   // as in conv3x3_h2s_kernel
+        const int nst = st + 1 == NS ? 0 : st + 1;
+        load_step(q_, st, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(p_);
+        __builtin_amdgcn_sched_barrier(0);
+        load_step(p_, st, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(q_);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < T) {
+            __builtin_amdgcn_s_barrier();
+            if (pf) load_step(q_, nst, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(p_);
+        __builtin_amdgcn_sched_barrier(0);
+        st = nst; ++c;
+    };
+    const float slope = p.act == BFSR_ACT_NONE ? 1.f : (p.act == BFSR_ACT_RELU ? 0.f : p.slope);
+    const float4* __restrict__ epi = reinterpret_cast<const float4*>(p.epi);
+    const long long HW = (long long)H * W;
+
+    // ---- epilogue of ONE row (J: compile-time) of tile `cur`: see conv3x3_h2s_kernel for the stages; the residual operands of the row
+    // are requested first and land under the swaps / parameter exchange / activation
+    auto epi_row = [&](const Item& cur, const float4 pm, auto J_) {
+        constexpr int J = decltype(J_)::value;
+#ifdef BFSR_H2S_ABL
+        if (abl & 8) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" :: "v"(acc[J]));
+#endif
+            return;
+        }
+#endif
+        // the lane id is re-derived here (mbcnt) behind an opaque copy: everything per-lane below would otherwise be loop-invariant,
+        // hoisted out of the tile loop and SPILLED (the K loop needs 136 of the 168 registers) -- and a scratch reload in the epilogue
+        // group waits on vmcnt(0), i.e. on the previous row's stores
+        int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(ln));
+#endif
+        const int lh = ln >> 5, lx = ln & 31;
+        const bool plain = (ln & 1) ? pm.x == 1.f : (pm.y == 0.f && pm.z == 1.f && pm.w == 0.f);
+        const bool bias_only = __all(plain);
+        const bool fast = bias_only && slope >= 0.f && slope <= 1.f;
+        auto fetch = [&](float val, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane * 4, __float_as_int(val))); };
+        const int gx = cur.x0 + lx, gy = cur.y0 + RW * cw + J;
+        int goff[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int oct = cur.cg * 4 + q * 2 + lh;
+            goff[q] = (gy < H && gx < W && oct * 8 < p.Cout) ? (int)(((long long)oct * 2 * HW + (long long)gy * W + gx) * 8) : -1;
+        }
+        half8 rh[2], rl[2];                                              // residual operands: res1 now, res2 into the same registers later
+        auto load_res = [&](const unsigned short* res, long long bs) {
+            const unsigned short* rb = res + (long long)cur.b * bs;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { rh[q][i] = (_Float16)0.f; rl[q][i] = (_Float16)0.f; }
+                if (goff[q] >= 0) {
+                    rh[q] = *reinterpret_cast<const half8*>(rb + goff[q]);
+                    rl[q] = *reinterpret_cast<const half8*>(rb + goff[q] + HW * 8);
+                }
+            }
+        };
+        if (p.res1) load_res(p.res1, p.res1_bs);
+        float o[2][8];
+        asm volatile("s_nop 11" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float lo = acc[J][8 * q + i], hi = acc[J][8 * q + 4 + i];
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+                o[q][i] = lo;
+                o[q][4 + i] = hi;
+            }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (fast) {                                                  // bias + (leaky) ReLU only: one exchange and 3 VALU ops per channel
+                float e0[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) e0[i] = fetch(pm.x, ((q * 2 + lh) * 8 + i) * 2);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float u = o[q][i] + e0[i];
+                    o[q][i] = fmaxf(u, u * slope);                       // = u > 0 ? u : u*slope for 0 <= slope <= 1
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {                            // per channel (five exchanged values live at a time, not forty)
+                    const int src = ((q * 2 + lh) * 8 + i) * 2;         // lane holding this channel's first float4
+                    const float e0 = fetch(pm.x, src), e1 = fetch(pm.y, src), e2 = fetch(pm.z, src), e3 = fetch(pm.w, src), e4 = fetch(pm.x, src + 1);
+                    float u = o[q][i] + e0;
+                    u = (u + e1) * e2 + e3;
+                    u = u > 0.f ? u : u * slope;
+                    o[q][i] = u * e4;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (p.res1) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[q][i] = p.alpha1 * o[q][i] + ((float)rh[q][i] + (float)rl[q][i]);
+        }
+        if (p.res2) {
+            load_res(p.res2, p.res2_bs);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[q][i] = p.alpha2 * o[q][i] + ((float)rh[q][i] + (float)rl[q][i]);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int g = goff[q];
+            if (g < 0) continue;
+            if (p.y_fmt == 2) {
+                half8 h8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) h8[i] = (_Float16)o[q][i];
+                *reinterpret_cast<half8*>(reinterpret_cast<unsigned short*>(p.y) + (long long)cur.b * p.y_bs + g) = h8;
+            } else if (p.y_fmt == 1) {
+                half8 h8, l8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { _Float16 h, l; split2(o[q][i], h, l); h8[i] = h; l8[i] = l; }
+                unsigned short* yb = reinterpret_cast<unsigned short*>(p.y) + (long long)cur.b * p.y_bs + g;
+                *reinterpret_cast<half8*>(yb) = h8;
+                *reinterpret_cast<half8*>(yb + HW * 8) = l8;
+            } else {
+                const int oct = cur.cg * 4 + q * 2 + lh;
+                float* yb = reinterpret_cast<float*>(p.y) + (long long)cur.b * p.y_bs + (long long)gy * W + gx;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (oct * 8 + i < p.Cout) yb[(long long)(oct * 8 + i) * HW] = o[q][i];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    __builtin_amdgcn_s_barrier();                                        // barrier 0
+    Item mine = {0, 0, 0, 0};
+    float4 pm_mine = make_float4(0.f, 0.f, 1.f, 0.f);
+    bool have = false;
+    for (int t = 0; t < n_mine; ++t) {
+        const bool last = t + 1 == n_mine;
+        if ((t & 1) == grp) {
+            // ---- K loop of tile t (barrier t*nchunk is behind every wave); passes barriers t*nchunk+1 .. (t+1)*nchunk (the last tile: one fewer)
+            mine = decode(slot + t * G);
+            {
+                int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" : "+v"(ln));
+#endif
+                const int idx = mine.cg * 64 + ln;
+                pm_mine = (ln & 1) ? make_float4(1.f, 0.f, 0.f, 0.f) : make_float4(0.f, 0.f, 1.f, 0.f);
+                if (epi && (idx >> 1) < p.Cout) pm_mine = epi[idx];
+            }
+#pragma unroll
+            for (int j = 0; j < RW; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#ifdef BFSR_H2S_ABL
+            if (abl & 4) { for (int k = 0; k < nchunk; ++k) { if (c + 1 < T) __builtin_amdgcn_s_barrier(); ++c; st = st + 1 == NS ? 0 : st + 1; } } else
+#endif
+            {
+                load_step(I0(), st, 0);
+                for (int k = 0; k < nchunk; k += 2) {                    // Cin % 32 == 0: the register-buffer parity is static
+                    chunk_body(I0(), I1(), true);
+                    chunk_body(I1(), I0(), k + 2 < nchunk);
+                }
+            }
+            have = true;
+            if (last) { epi_row(mine, pm_mine, I0()); epi_row(mine, pm_mine, I1()); epi_row(mine, pm_mine, I2()); epi_row(mine, pm_mine, I3()); }
+        } else {
+            // ---- the other group computes tile t: epilogue of this group's tile t-1, one row per barrier interval, and the same barriers
+            const int nb = last ? nchunk - 1 : nchunk;
+            if (have) epi_row(mine, pm_mine, I0());
+            if (nb > 0) __builtin_amdgcn_s_barrier();
+            if (have) epi_row(mine, pm_mine, I1());
+            if (nb > 1) __builtin_amdgcn_s_barrier();
+            if (have) epi_row(mine, pm_mine, I2());
+            if (nb > 2) __builtin_amdgcn_s_barrier();
+            if (have) epi_row(mine, pm_mine, I3());
+            for (int k = 3; k < nb; ++k) __builtin_amdgcn_s_barrier();
+            have = false;
+            c += nchunk;
+            st = (st + nchunk) % NS;
+        }
+    }
+}
+
 // =====================================================================================================================
 // conv3x3_h2x_kernel -- the same conv at FP32-CLASS accuracy on the fp16 matrix pipe: BOTH planes of the h2 activations and a
 // two-term fp16 split of the weights, three products  lo*hi + hi*lo + hi*hi  (each exact in the fp32 accumulator).
@@ -432,23 +788,10 @@ template <int XM> struct XGeo {
     static constexpr int LDS = 2 * STAGE;       // 118 784 | 155 648
 };
 
-// EPI = 0: the conv epilogue (bias / affine / activation / residuals, h2 or fp32 output).
-// EPI = 1: the COUPLING TAIL (bfsr_coupling_tail; FlowAffineCouplingsAblation.py:57-97 + FlowStep.py:113-129): the conv is fAffine.4
-//          (Conv2dZeros 64 -> 2*(CF - CF/2) channels of h_aff) over the h2 tensor `hid` written by coupling_head_kernel, and the epilogue is the
-//          step's pointwise chain with h_aff taken from the accumulators: one v_permlane32_swap per accumulator register hands every lane
-//          ALL h_aff channels of ONE pixel (lane (l31, lhi) <- pixel (row 2*wave + lhi, column l31)), then per lane
-//            reverse: z2 = z2/scale - shift; z = z/scaleFt - shiftFt; z = Winv z; z = z*exp(-logs) - bias          (this step)
-//            forward: z2 = (z2 + shift)*scale   (this step's self-conditional)   then, if given, the NEXT step's head:
-//                     z = (z + bias)*exp(logs); z = W z; z = (z + shiftFt)*scaleFt
-//          (the semantics of bfsr_flow_pointwise).  z and h_ft of the item are loaded while its last chunk is in the matrix pipe.
-template <int XM, int EPI, int CF>
-__global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrConvX3Args p, BfsrCouplingTailArgs q, int tiles_x, int tiles_y, int groups, int nitems)
+template <int XM>
+__global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrConvX3Args p, int tiles_x, int tiles_y, int groups, int nitems)
 {
-    // WRES (coupling tail): the WHOLE weight tensor (Cin = 64: four chunks, 72 KiB) stays resident in LDS behind the two input stages and
-    // the loaders stream activations only -- the kernel is bound by the L2 -> LDS fill (~27 GB/s per CU), and with one cout group the
-    // weights are the same 31 % of every stage for every item
-    constexpr bool WRES = EPI == 1;
-    constexpr int X_WPL = XGeo<XM>::WPL, X_W = XGeo<XM>::W, X_STAGE = WRES ? X_IN : XGeo<XM>::STAGE;
+    constexpr int X_WPL = XGeo<XM>::WPL, X_W = XGeo<XM>::W, X_STAGE = XGeo<XM>::STAGE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -467,13 +810,6 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
         r.x0 = (t % tiles_x) * 32; r.y0 = ty * TH; r.b = t / tiles_x;
         return r;
     };
-    if constexpr (WRES) {                                                // all twelve waves: weights -> LDS once (ordinary loads, landed before the barrier)
-        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(p.w);
-        uint4* dst = reinterpret_cast<uint4*>(smem + 2 * X_IN);
-        const int nq = nchunk * X_W / 16;
-        for (int i = tid; i < nq; i += (NW + NLW) * 64) dst[i] = src[i];
-        __syncthreads();
-    }
 
     if (wave >= NW) {
         // ---- loader waves: LDS-DMA only (see h2s_loader_wave on why a wave must not mix load kinds)
@@ -502,7 +838,6 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
 #pragma unroll
             for (int g = 0; g < NG; ++g)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(base + ld * SUB + g * 1024), 16, vg[g], soff, 0, 0);
-            if constexpr (!WRES) {
             const unsigned wsoff = (unsigned)(cg_ * nchunk + k) * (unsigned)X_W;
 #pragma unroll
             for (int j = 0; j < (X_W / 1024 + NLW - 1) / NLW; ++j) {
@@ -510,7 +845,6 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
                 if (piece < X_W / 1024)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(base + X_IN + piece * 1024), 16,
                                                              (unsigned)lane * 16u + (unsigned)piece * 1024u, wsoff, 0, 0);
-            }
             }
         };
         int it = slot;
@@ -536,12 +870,12 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
     // -> 6 MFMAs; the fragments of step t+1 are read while the MFMAs of step t run (register double buffer: 48 registers -- a
     // tap-COLUMN step as in conv3x3_h2s_kernel needs 112 and spills beside the 32 accumulators).
     half8 bq[2][2][2], aq[2][2][XM];                                     // [buffer][plane][row] | [buffer][plane][m tile]
-    auto load_step = [&](auto buf_, int st, int t, int kc) {             // kc = chunk index inside the item (resident weights only)
+    auto load_step = [&](auto buf_, int st, int t) {
         constexpr int BUF = decltype(buf_)::value;
         const int dx = t / 3, dy = t - 3 * dx;
         const unsigned char* sIn = smem + st * X_STAGE;
         const unsigned char* inB = sIn + (lhi * NPOSP + (2 * wave + dy) * PW + l31 + dx) * 16;
-        const unsigned char* wA = (WRES ? smem + 2 * X_IN + kc * X_W : sIn + X_IN) + lane * 16 + t * (1024 * XM);        // tap = dx*3 + dy = t
+        const unsigned char* wA = sIn + X_IN + lane * 16 + t * (1024 * XM);                              // tap = dx*3 + dy = t
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
@@ -551,25 +885,15 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
         }
     };
     f32x16 acc[XM][2];
-    // Coupling tail with <= 16 output channels (C = 12): the three products need only TWO matrix instructions per operand pair when the
-    // idle rows of the 32-row tile carry the lo plane of the weights -- weight "plane" 0 = [rows 0-15: w_hi | rows 16-31: w_lo], "plane" 1 =
-    // [rows 0-15: w_hi | rows 16-31: 0] (bfsr_pack_coupling_tail):  acc += P0 . x_hi;  acc += P1 . x_lo  leaves w_hi.x_hi + w_hi.x_lo in
-    // rows 0-15 and w_lo.x_hi in rows 16-31 = accumulator registers r and r + 8 of the SAME lane, summed in the epilogue.
-    constexpr bool TWO = EPI == 1 && 2 * (CF - CF / 2) <= 16;
     auto mfma_step = [&](auto buf_) {
         constexpr int BUF = decltype(buf_)::value;
 #pragma unroll
         for (int m = 0; m < XM; ++m)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if constexpr (TWO) {
-                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][1][m], bq[BUF][1][j], acc[m][j], 0, 0, 0);
-                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][0][m], bq[BUF][0][j], acc[m][j], 0, 0, 0);
-                } else {                                                 // smallest terms first: w_lo*x_hi, w_hi*x_lo, w_hi*x_hi
-                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][1][m], bq[BUF][0][j], acc[m][j], 0, 0, 0);
-                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][0][m], bq[BUF][1][j], acc[m][j], 0, 0, 0);
-                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][0][m], bq[BUF][0][j], acc[m][j], 0, 0, 0);
-                }
+            for (int j = 0; j < 2; ++j) {                                // smallest terms first: w_lo*x_hi, w_hi*x_lo, w_hi*x_hi
+                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][1][m], bq[BUF][0][j], acc[m][j], 0, 0, 0);
+                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][0][m], bq[BUF][1][j], acc[m][j], 0, 0, 0);
+                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][0][m], bq[BUF][0][j], acc[m][j], 0, 0, 0);
             }
     };
     typedef std::integral_constant<int, 0> I0;
@@ -578,7 +902,6 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
     const float4* __restrict__ epi = reinterpret_cast<const float4*>(p.epi);
     const long long HW = (long long)H * W;
     int buf = 0;                                                         // LDS stage of the next chunk
-    float xamax = 0.f;                                                   // range guard: max |value| this thread hands to the fp16 split (h2 output)
     for (int it = slot; it < nitems; it += G) {
         const Item cur = decode(it);
         float4 pmm[XM];
@@ -601,15 +924,14 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
         // One barrier per chunk, passed EARLY: chunk k+1's barrier sits before the last tap of chunk k (whose fragments are already in
         // registers), so the first fragments of chunk k+1 are in flight under that tap's MFMAs and the loaders may refill stage `buf`
         // one tap earlier.  Nine taps per chunk flip the fragment-buffer parity from chunk to chunk: chunks are processed in pairs.
-        int kc = 0;                                                      // chunk index inside the item
         auto chunk_body = [&](auto p_, auto q_, bool last) {               // p_: buffer holding tap 0's fragments (already loaded)
 #pragma unroll
             for (int t = 0; t < 8; t += 2) {
-                load_step(q_, buf, t + 1, kc);
+                load_step(q_, buf, t + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_step(p_);
                 __builtin_amdgcn_sched_barrier(0);
-                load_step(p_, buf, t + 2, kc);
+                load_step(p_, buf, t + 2);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_step(q_);
                 __builtin_amdgcn_sched_barrier(0);
@@ -617,125 +939,21 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
             if (!last) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // tap 8's fragments have left stage `buf`
                 __builtin_amdgcn_s_barrier();                            // chunk k+1 has landed in stage buf^1; stage buf is free again
-                load_step(q_, buf ^ 1, 0, kc + 1);
+                load_step(q_, buf ^ 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             mfma_step(p_);
             __builtin_amdgcn_sched_barrier(0);
             buf ^= 1;
-            ++kc;
-        };
-        // coupling tail: this lane's pixel and the operands of its pointwise chain (registers, loaded under the item's last chunk)
-        constexpr int CFN = CF / 2, CO2 = 2 * (CF - CFN);
-        float cz[EPI ? CF : 1], cft[EPI ? 2 * CF : 1];
-        const int cgy = cur.y0 + 2 * wave + lhi, cgx = cur.x0 + l31;
-        const bool con = cgy < H && cgx < W;
-        constexpr bool FT_EARLY = CF <= 12;                                // C = 24: 48 more live registers through the last chunk would spill
-        auto tail_prefetch = [&](bool want_z, bool want_ft) {
-            if constexpr (EPI == 1) {
-                const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.z_in + (long long)cur.b * q.z_in_bs), 0,
-                                                                                    (unsigned)(CF * HW * 4), 0x00020000);
-                const unsigned vo = con ? (unsigned)(((long long)cgy * W + cgx) * 4) : OOB;
-                if (want_z) {
-#pragma unroll
-                    for (int c = 0; c < CF; ++c) cz[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, vo, (unsigned)(c * HW * 4), 0));
-                }
-                if (want_ft && q.h_ft) {
-                    const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.h_ft + (long long)cur.b * q.h_ft_bs), 0,
-                                                                                        (unsigned)(2 * CF * HW * 4), 0x00020000);
-                    if (q.h_ft_fmt == 1) {                               // quad-major [2*CF/4][H][W][4]
-                        const unsigned vq = con ? (unsigned)(((long long)cgy * W + cgx) * 16) : OOB;
-#pragma unroll
-                        for (int c4 = 0; c4 < 2 * CF / 4; ++c4) {
-                            const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rf, vq, (unsigned)(c4 * HW * 16), 0));
-                            cft[4 * c4] = v.x; cft[4 * c4 + 1] = v.y; cft[4 * c4 + 2] = v.z; cft[4 * c4 + 3] = v.w;
-                        }
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < 2 * CF; ++c) cft[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, vo, (unsigned)(c * HW * 4), 0));
-                    }
-                }
-            }
         };
         __builtin_amdgcn_s_barrier();                                    // the item's first chunk has landed in stage `buf`
-        load_step(I0(), buf, 0, 0);
+        load_step(I0(), buf, 0);
         int k = 0;
         for (; k + 2 <= nchunk; k += 2) {                                // pairs of chunks: the parity is static inside a pair
             chunk_body(I0(), I1(), false);
-            if (k + 2 == nchunk && FT_EARLY) tail_prefetch(true, true);
             chunk_body(I1(), I0(), k + 2 == nchunk);
         }
-        if (k < nchunk) { if (FT_EARLY) tail_prefetch(true, true); chunk_body(I0(), I1(), true); }
-        if (!FT_EARLY) tail_prefetch(true, true);
-
-        if constexpr (EPI == 1) {
-            // ---- coupling tail epilogue.  The accumulators are read by compiler-visible VALU code first (x acc_scale: hipcc inserts the
-            // MFMA -> VALU wait states), the swap statement only sees VALU results (2 wait states, inside the string).
-            constexpr int NR = (CO2 + 7) / 8 * 4;                        // accumulator registers that hold channels < CO2 (rows (r&3) + 8(r>>2) + 4*lhi)
-            float ha[32];
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                float x, y;
-                if constexpr (TWO) { x = (acc[0][0][r] + acc[0][0][r + 8]) * p.acc_scale; y = (acc[0][1][r] + acc[0][1][r + 8]) * p.acc_scale; }
-                else { x = acc[0][0][r] * p.acc_scale; y = acc[0][1][r] * p.acc_scale; }
-                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
-                ha[(r & 3) + 8 * (r >> 2)] = x;                          // this lane's pixel: channel (r&3) + 8(r>>2) ...
-                ha[(r & 3) + 8 * (r >> 2) + 4] = y;                      // ... and + 4
-            }
-            unsigned bad = 0u;
-            const float eps = q.eps;
-            // The epilogue is VALU-bound (all eight compute waves are in it at once), and IEEE division / expf are ~10 instructions each:
-            // quotients are formed as v_rcp_f32 + one Newton step on the quotient (<= 1 ulp), exp as v_exp_f32 of x * log2(e) (<= 2 ulp on
-            // arguments of a few units) -- inside the 2e-5 per-kernel / 1e-4 end-to-end tolerances, measured in tests/test_hip_ops.py
-            auto fdiv = [](float a, float b) {
-                const float r = __builtin_amdgcn_rcpf(b);
-                const float qt = a * r;
-                return fmaf(fmaf(-b, qt, a), r, qt);
-            };
-            auto sscale = [&](float raw) { return fdiv(1.f, 1.f + __expf(-(raw + 2.f))) + eps; };
-            const bool hf = q.h_ft != nullptr;
-            float x[CF];
-#pragma unroll
-            for (int c = 0; c < CF; ++c) {
-                float v = cz[c];
-                if (c >= CFN) {
-                    const int co = 2 * (c - CFN);
-                    const float sh = (ha[co] + q.bias[co]) * q.post_scale[co];
-                    const float sr = (ha[co + 1] + q.bias[co + 1]) * q.post_scale[co + 1];
-                    v = q.reverse ? fdiv(v, sscale(sr)) - sh : (v + sh) * sscale(sr);
-                }
-                if (q.reverse) {
-                    if (hf) v = fdiv(v, sscale(cft[2 * c + 1])) - cft[2 * c];
-                } else if (q.an_bias) {
-                    v = (v + q.an_bias[c]) * q.an_escale[c];
-                }
-                x[c] = v;
-            }
-            if (con) {
-                float* zo = q.z_out + (long long)cur.b * q.z_out_bs + (long long)cgy * W + cgx;
-#pragma unroll
-                for (int ci = 0; ci < CF; ++ci) {
-                    float v;
-                    if (q.wmat) {
-                        const float* __restrict__ w = q.wmat + ci * CF;
-                        float a = 0.f;
-#pragma unroll
-                        for (int j = 0; j < CF; ++j) a = fmaf(w[j], x[j], a);
-                        v = a;
-                    } else {
-                        v = x[ci];
-                    }
-                    if (q.reverse) {
-                        if (q.an_bias) v = v * q.an_escale[ci] - q.an_bias[ci];
-                    } else if (hf) {
-                        v = (v + cft[2 * ci]) * sscale(cft[2 * ci + 1]);
-                    }
-                    bad |= (unsigned)!(fabsf(v) < 3.0e38f);                // NaN / inf guard of the flow state
-                    zo[(long long)ci * HW] = v;
-                }
-            }
-            if (q.flag && __any((int)bad)) { if (lane == 0) atomicOr(q.flag, 2u); }
-        } else {
+        if (k < nchunk) chunk_body(I0(), I1(), true);
 
         // ---- epilogue (the loaders are already staging the next item): as in conv3x3_h2s_kernel, plus the weight scale; one M tile
         // at a time (64 results per lane and the residual operands of both tiles at once would spill)
@@ -777,17 +995,17 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
         };
         if (p.res1) load_res(p.res1, p.res1_bs);                         // lands under the swaps / parameter exchange / activation
         float o[2][2][8];
-        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");       // MFMA result -> VALU read inside the asm below: 20 wait states (>= 19 of a 16-pass XDL op), self-sufficient
+        asm volatile("s_nop 11" ::: "memory");
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float lo = acc[m][j][8 * q + i] * p.acc_scale, hi = acc[m][j][8 * q + 4 + i] * p.acc_scale;      // VALU first: hipcc pads the MFMA -> VALU hazard itself
+                    float lo = acc[m][j][8 * q + i], hi = acc[m][j][8 * q + 4 + i];
                     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
-                    o[j][q][i] = lo;
-                    o[j][q][4 + i] = hi;
+                    o[j][q][i] = lo * p.acc_scale;
+                    o[j][q][4 + i] = hi * p.acc_scale;
                 }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -844,15 +1062,10 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
                 if (p.y_fmt == 1) {
                     half8 h8, l8;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) { _Float16 h, l; split2(o[j][q][i], h, l); h8[i] = h; l8[i] = l; xamax = fmaxf(xamax, fabsf(o[j][q][i])); }
+                    for (int i = 0; i < 8; ++i) { _Float16 h, l; split2(o[j][q][i], h, l); h8[i] = h; l8[i] = l; }
                     unsigned short* yb = reinterpret_cast<unsigned short*>(p.y) + (long long)cur.b * p.y_bs + g;
                     *reinterpret_cast<half8*>(yb) = h8;
                     *reinterpret_cast<half8*>(yb + HW * 8) = l8;
-                } else if (p.y_fmt == 2) {                              // fp32 quad-major [Cout/4][H][W][4]: the octet = two 16-byte stores
-                    const int oct = (cur.cg * XM + m) * 4 + q * 2 + lh;
-                    float* yb = reinterpret_cast<float*>(p.y) + (long long)cur.b * p.y_bs + ((long long)(cur.y0 + 2 * wave + j) * W + gx) * 4;
-                    *reinterpret_cast<float4*>(yb + (long long)(oct * 2) * HW * 4) = make_float4(o[j][q][0], o[j][q][1], o[j][q][2], o[j][q][3]);
-                    *reinterpret_cast<float4*>(yb + (long long)(oct * 2 + 1) * HW * 4) = make_float4(o[j][q][4], o[j][q][5], o[j][q][6], o[j][q][7]);
                 } else {
                     const int oct = (cur.cg * XM + m) * 4 + q * 2 + lh;
                     float* yb = reinterpret_cast<float*>(p.y) + (long long)cur.b * p.y_bs + (long long)(cur.y0 + 2 * wave + j) * W + gx;
@@ -863,29 +1076,212 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        }   // EPI == 0
     }
-    if (p.flag && __any((int)!(xamax < 65504.f))) { if (lane == 0) atomicOr(p.flag, 1u); }
+}
+
+// =====================================================================================================================
+// conv_up2_h2x_kernel -- the 3x3 conv over nearest_up2(taps) (parity-pre-summed 2x2 matrices, conv_bf16x3.hip / DESIGN.md section
+// 3.5) with the taps as an h2 tensor at SOURCE resolution: same fp16-pair arithmetic, LDS-DMA staging and persistent structure as
+// conv3x3_h2x_kernel.  x [B,Cin,H/2,W/2] (h2) -> y [B,Cout,H,W] (fp32 NCHW, BfsrConvArgs epilogue incl. pre_add: the key channels'
+// partial sums).  An item = (source tile 16 rows x 32 px, 32 output channels, output ROW parity pa): 8 of the 16 matrices, one
+// pipeline step each (step s: column parity bq = s>>2, source offsets i = s&1, j = (s>>1)&1 -> column offset d = bq + j; the packer
+// stores the matrices in step order), accumulators acc[column parity][wave row] = 4 blocks.  Stage = the h2x input tile (18 x 34
+// positions, both planes) + 8 matrices x 2 planes = 40 960 + 16 384 B, two stages.  Why: the register-staged taps kernel became
+// staging-bound once the split needed three instead of six products (0.32 of the fp16 peak, profiles/r03f_cfg2_bench.json).
+constexpr int U_W = 2 * 8 * 1024;               // 16 384: [plane][step][k half][32][8]
+constexpr int U_STAGE = X_IN + U_W;             // 57 344
+constexpr int U_LDS = 2 * U_STAGE;              // 114 688
+
+__global__ __launch_bounds__((NW + NLW) * 64, 1) void conv_up2_h2x_kernel(BfsrConvArgs p, int tiles_x, int tiles_y, int groups, int nitems)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int G = gridDim.x;
+    const int slot = (int)bfsr::xcd_order(blockIdx.x, (unsigned)G);
+    if (slot >= nitems) return;
+    const int H = p.H, W = p.W, Hs = H >> 1, Ws = W >> 1;                // output / source resolution
+    const unsigned HW16 = (unsigned)(Hs * Ws) * 16u;                     // bytes of one (octet, plane) source image
+    const int nchunk = p.Cin >> 4;
+    struct UItem { int pa, cg, b, x0, y0; };
+    auto decode = [&](int it) {
+        UItem r;
+        r.pa = it & 1; it >>= 1;
+        r.cg = it % groups; int t = it / groups;
+        const int ty = t % tiles_y; t /= tiles_y;
+        r.x0 = (t % tiles_x) * 32; r.y0 = ty * TH; r.b = t / tiles_x;
+        return r;
+    };
+    const unsigned short* xh = reinterpret_cast<const unsigned short*>(p.x);
+
+    if (wave >= NW) {
+        // ---- loader waves (LDS-DMA only): loader ld = sub-image (plane ld>>1, k half ld&1) of every position group + weight pieces
+        const int ld = wave - NW;
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0,
+                                                                              (unsigned)((long long)groups * nchunk * 2 * U_W), 0x00020000);
+        __amdgpu_buffer_rsrc_t rs_in;
+        unsigned vg[NG];
+        int cg_ = 0, pa_ = 0;
+        auto lsetup = [&](const UItem& it) {
+            const unsigned short* xb = xh + (long long)it.b * p.x_bs;
+            rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xb), 0, (unsigned)(p.Cin >> 3) * 2u * HW16, 0x00020000);
+            cg_ = it.cg; pa_ = it.pa;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int pos = g * 64 + lane;
+                const int r = pos / PW, c = pos - r * PW;
+                const int gy = it.y0 + r - 1, gx = it.x0 + c - 1;
+                const bool ok = pos < NPOS && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
+                vg[g] = ok ? (unsigned)(gy * Ws + gx) * 16u : OOB;       // out of range -> zeros: the zero padding of the UPSAMPLED image
+            }
+        };
+        auto lstage = [&](int k, int buf) {
+            unsigned char* base = smem + buf * U_STAGE;
+            const unsigned soff = (unsigned)((2 * k + (ld & 1)) * 2 + (ld >> 1)) * HW16;
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(base + ld * SUB + g * 1024), 16, vg[g], soff, 0, 0);
+            const unsigned wsoff = (unsigned)((cg_ * nchunk + k) * 2 + pa_) * (unsigned)U_W;
+#pragma unroll
+            for (int j = 0; j < U_W / 1024 / NLW; ++j) {
+                const int piece = ld + j * NLW;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(base + X_IN + piece * 1024), 16,
+                                                         (unsigned)lane * 16u + (unsigned)piece * 1024u, wsoff, 0, 0);
+            }
+        };
+        int it = slot;
+        lsetup(decode(it));
+        lstage(0, 0);
+        int buf_ = 0;
+        while (true) {
+            const int nxt = it + G;
+            const bool has_next = nxt < nitems;
+            for (int k = 0; k < nchunk; ++k) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (k + 1 < nchunk) lstage(k + 1, buf_ ^ 1);
+                else if (has_next) { lsetup(decode(nxt)); lstage(0, buf_ ^ 1); }
+                buf_ ^= 1;
+            }
+            if (!has_next) return;
+            it = nxt;
+        }
+    }
+
+    // ---- compute waves: wave w owns source rows 2w, 2w+1 of the tile (output rows 2*(y0+2w+n) + pa)
+    half8 bq[2][2][2], aq[2][2];                                         // [buffer][plane][row] | [buffer][plane]
+    int pa = 0;
+    auto load_step = [&](auto buf_, int st, int s_) {
+        constexpr int BUF = decltype(buf_)::value;
+        const int i = s_ & 1, j = (s_ >> 1) & 1, d = (s_ >> 2) + j;
+        const unsigned char* sIn = smem + st * U_STAGE;
+        const unsigned char* inB = sIn + (lhi * NPOSP + (2 * wave + pa + i) * PW + l31 + d) * 16;       // staged row r = source row y0-1+r
+        const unsigned char* wA = sIn + X_IN + lane * 16 + s_ * 1024;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) bq[BUF][pl][r] = *reinterpret_cast<const half8*>(inB + pl * 2 * SUB + r * PW * 16);
+            aq[BUF][pl] = *reinterpret_cast<const half8*>(wA + pl * (8 * 1024));
+        }
+    };
+    f32x16 acc[2][2];                                                    // [column parity][row]
+    auto mfma_step = [&](auto buf_, auto cb_) {
+        constexpr int BUF = decltype(buf_)::value, CB = decltype(cb_)::value;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {                                    // smallest terms first: w_lo*x_hi, w_hi*x_lo, w_hi*x_hi
+            acc[CB][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][1], bq[BUF][0][n], acc[CB][n], 0, 0, 0);
+            acc[CB][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][0], bq[BUF][1][n], acc[CB][n], 0, 0, 0);
+            acc[CB][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][0], bq[BUF][0][n], acc[CB][n], 0, 0, 0);
+        }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    const float slope = p.act == BFSR_ACT_NONE ? 1.f : (p.act == BFSR_ACT_RELU ? 0.f : p.slope);
+    const float4* __restrict__ epi = reinterpret_cast<const float4*>(p.epi);
+    const long long HW = (long long)H * W;
+    int buf = 0;
+    for (int it = slot; it < nitems; it += G) {
+        const UItem cur = decode(it);
+        pa = cur.pa;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][n][r] = 0.f;
+        __builtin_amdgcn_s_barrier();                                    // the item's first chunk has landed in stage `buf`
+        load_step(I0(), buf, 0);
+        for (int k = 0; k < nchunk; ++k) {
+            const bool last = k + 1 == nchunk;
+            // eight steps, fragment buffers alternate; the barrier of chunk k+1 is passed before the last step (see conv3x3_h2x_kernel)
+            load_step(I1(), buf, 1); __builtin_amdgcn_sched_barrier(0); mfma_step(I0(), I0()); __builtin_amdgcn_sched_barrier(0);   // s = 0
+            load_step(I0(), buf, 2); __builtin_amdgcn_sched_barrier(0); mfma_step(I1(), I0()); __builtin_amdgcn_sched_barrier(0);   // s = 1
+            load_step(I1(), buf, 3); __builtin_amdgcn_sched_barrier(0); mfma_step(I0(), I0()); __builtin_amdgcn_sched_barrier(0);   // s = 2
+            load_step(I0(), buf, 4); __builtin_amdgcn_sched_barrier(0); mfma_step(I1(), I0()); __builtin_amdgcn_sched_barrier(0);   // s = 3
+            load_step(I1(), buf, 5); __builtin_amdgcn_sched_barrier(0); mfma_step(I0(), I1()); __builtin_amdgcn_sched_barrier(0);   // s = 4
+            load_step(I0(), buf, 6); __builtin_amdgcn_sched_barrier(0); mfma_step(I1(), I1()); __builtin_amdgcn_sched_barrier(0);   // s = 5
+            load_step(I1(), buf, 7); __builtin_amdgcn_sched_barrier(0); mfma_step(I0(), I1()); __builtin_amdgcn_sched_barrier(0);   // s = 6
+            if (!last) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // step 7's fragments have left stage `buf`
+                __builtin_amdgcn_s_barrier();
+                load_step(I0(), buf ^ 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(I1(), I1());                                       // s = 7
+            __builtin_amdgcn_sched_barrier(0);
+            buf ^= 1;
+        }
+
+        // ---- epilogue: lane = source column -> two adjacent output pixels (float2), stage order of conv_up2_bf16x3_kernel
+        int lx = l31, lh = lhi;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(lx), "+v"(lh));
+#endif
+        const int sx = cur.x0 + lx;
+        const float* pre = p.pre_add ? p.pre_add + (long long)cur.b * p.pre_add_bs : nullptr;
+        float* yb = p.y + (long long)cur.b * p.y_bs;
+        if (sx < Ws) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cur.cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co >= p.Cout) continue;
+                float4 q0 = make_float4(0.f, 0.f, 1.f, 0.f); float q1 = 1.f;
+                if (epi) { q0 = epi[co * 2]; q1 = epi[co * 2 + 1].x; }
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int sy = cur.y0 + 2 * wave + n;
+                    if (sy >= Hs) continue;
+                    const long long o = (long long)co * HW + (long long)(2 * sy + cur.pa) * W + 2 * sx;
+                    float2 v = make_float2(acc[0][n][r] * p.acc_scale, acc[1][n][r] * p.acc_scale);
+                    v.x += q0.x; v.y += q0.x;
+                    if (pre) { const float2 t = *reinterpret_cast<const float2*>(pre + o); v.x += t.x; v.y += t.y; }
+                    v.x = (v.x + q0.y) * q0.z + q0.w; v.y = (v.y + q0.y) * q0.z + q0.w;
+                    v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+                    v.x *= q1; v.y *= q1;
+                    *reinterpret_cast<float2*>(yb + o) = v;
+                }
+            }
+        }
+    }
 }
 
 // ---- fp32 NCHW view <-> h2 tensor (the two ends of the fp16-stored region: conv_first's output, the trunk output) -------------
 __global__ void h2_pack_kernel(const float* __restrict__ x, long long x_bs, unsigned short* __restrict__ y, long long y_bs,
-                               int C, long long HW, long long total, unsigned* flag)
+                               int C, long long HW, long long total)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    float amax = 0.f;                                                    // range guard of the fp16 split
     const int C8 = C >> 3;
     const long long pix = i % HW; const long long t = i / HW;
     const int oct = (int)(t % C8); const int b = (int)(t / C8);
     const float* xb = x + (long long)b * x_bs + (long long)oct * 8 * HW + pix;
     half8 h8, l8;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { const float v = xb[(long long)j * HW]; _Float16 h, l; split2(v, h, l); h8[j] = h; l8[j] = l; amax = fmaxf(amax, fabsf(v)); }
+    for (int j = 0; j < 8; ++j) { _Float16 h, l; split2(xb[(long long)j * HW], h, l); h8[j] = h; l8[j] = l; }
     unsigned short* yb = y + (long long)b * y_bs + ((long long)oct * 2 * HW + pix) * 8;
     *reinterpret_cast<half8*>(yb) = h8;
     *reinterpret_cast<half8*>(yb + HW * 8) = l8;
-    if (flag && !(amax < 65504.f)) atomicOr(flag, 1u);
 }
 
 __global__ void h2_unpack_kernel(const unsigned short* __restrict__ x, long long x_bs, float* __restrict__ y, long long y_bs,
@@ -966,11 +1362,23 @@ extern "C" int bfsr_conv3x3_h2s(const BfsrConvX3Args* a, void* stream)
     if (cus <= 0) return -1;
     if (a->tune > 0) cus = a->tune;
     const long long grid = nitems < cus ? nitems : cus;                  // one persistent workgroup per CU
-    // (round 3's ping-pong compute groups and register-staged weight loader were parity-tested and measured within box noise of this
-    // kernel: tools/exp/kernels/conv_h2s_r3.hip)
-    static std::atomic<unsigned long long> lds_done{0};
+    int abl = 0;
+#ifdef BFSR_H2S_ABL
+    abl = a->tune < 0 ? -a->tune : 0;
+#endif
+    static std::atomic<unsigned long long> lds_done{0}, lds_done_pp{0};
+    // Both variants are parity-tested and measured within box-to-box noise of the default (tools/exp/h2s_bench.py):
+    //   BFSR_H2S_PP=1   ping-pong compute groups (conv3x3_h2s_pp_kernel): one RDB 1.30-1.38 ms vs 1.26-1.42 ms
+    //   BFSR_H2S_WREG=1 weight pieces through registers of a dedicated loader wave instead of LDS-DMA: 1.38-1.42 ms
+    static const int pp_mode = [] { const char* e = getenv("BFSR_H2S_PP"); return e ? atoi(e) : 0; }();
+    static const int flags = [] { const char* e = getenv("BFSR_H2S_WREG"); return e ? atoi(e) : 0; }();
+    if (pp_mode && a->Cin >= 64) {
+        if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2s_pp_kernel), LDS_TOTAL, lds_done_pp) != 0) return -1;
+        hipLaunchKernelGGL(conv3x3_h2s_pp_kernel, dim3((unsigned)grid), dim3((NW + NLW) * 64), LDS_TOTAL, st, *a, tiles_x, tiles_y, groups, (int)nitems, abl, flags);
+        return (int)hipGetLastError();
+    }
     if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2s_kernel), LDS_TOTAL, lds_done) != 0) return -1;
-    hipLaunchKernelGGL(conv3x3_h2s_kernel, dim3((unsigned)grid), dim3((NW + NLW) * 64), LDS_TOTAL, st, *a, tiles_x, tiles_y, groups, (int)nitems);
+    hipLaunchKernelGGL(conv3x3_h2s_kernel, dim3((unsigned)grid), dim3((NW + NLW) * 64), LDS_TOTAL, st, *a, tiles_x, tiles_y, groups, (int)nitems, abl, flags);
     return (int)hipGetLastError();
 }
 
@@ -1005,57 +1413,23 @@ extern "C" int bfsr_pack_conv_weight_h2x(const float* w, int Cout, int Cin, int 
     return 0;
 }
 
-// fAffine.4 of a coupled FlowStep (Conv2dZeros [Cout][64][3][3]) in conv3x3_h2x_kernel's weight layout for ONE 32-row tile.  Cout <= 16:
-// the two-instruction form (see `TWO` in the kernel): plane 0 = [rows 0-15: hi | rows 16-31: lo], plane 1 = [rows 0-15: hi | rest 0].
-extern "C" long long bfsr_coupling_tail_packed_size(int Cin, int Cout)
-{
-    if (Cin != 64 || Cout <= 0 || Cout > 32) return -1;
-    return bfsr_conv_packed_size_h2x(32, Cin, 1);                                           // fp16 elements
-}
-
-extern "C" int bfsr_pack_coupling_tail(const float* w, int Cin, int Cout, float scale, unsigned short* packed)
-{
-    if (!w || !packed || Cin != 64 || Cout <= 0 || Cout > 32 || !(scale > 0.f)) return -1;
-    if (Cout > 16) return bfsr_pack_conv_weight_h2x(w, Cout, Cin, 1, scale, packed);
-    const int nchunk = Cin / 16;
-    const long long n = bfsr_coupling_tail_packed_size(Cin, Cout);
-    for (long long i = 0; i < n; ++i) packed[i] = 0;
-    const long long PLSZ = 9 * 2 * 32 * 8;
-    for (int co = 0; co < Cout; ++co)
-        for (int ci = 0; ci < Cin; ++ci)
-            for (int dy = 0; dy < 3; ++dy)
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float v = w[((long long)co * Cin + ci) * 9 + dy * 3 + dx] * scale;
-                    const _Float16 h = (_Float16)v;
-                    const _Float16 l = (_Float16)(v - (float)h);
-                    const unsigned short hb = f32_to_f16_bits((float)h), lb = f32_to_f16_bits((float)l);
-                    const long long base = (long long)(ci / 16) * 2;
-                    auto at = [&](int row) { return ((((long long)(dx * 3 + dy)) * 2 + (ci % 16) / 8) * 32 + row) * 8 + ci % 8; };
-                    packed[(base + 0) * PLSZ + at(co)] = hb;
-                    packed[(base + 0) * PLSZ + at(16 + co)] = lb;
-                    packed[(base + 1) * PLSZ + at(co)] = hb;
-                }
-    return 0;
-}
-
 extern "C" int bfsr_conv3x3_h2x(const BfsrConvX3Args* a, void* stream)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (!a || !a->x || !a->w || !a->y) return -1;
     if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cin <= 0 || (a->Cin & 15) || a->Cout <= 0) return -1;
-    if (a->y_fmt != 0 && a->y_fmt != 1 && a->y_fmt != 2) return -1;    // fp32 NCHW | h2 | fp32 quad-major [Cout/4][H][W][4]
+    if (a->y_fmt != 0 && a->y_fmt != 1) return -1;
     if (!(a->acc_scale > 0.f)) return -1;
     if ((a->y_fmt != 0 || a->res1 || a->res2) && (a->Cout & 7)) return -1;
-    if (a->y_fmt == 2 && ((reinterpret_cast<unsigned long long>(a->y) & 15) || (a->y_bs & 3))) return -1;
     if ((long long)(a->Cin / 8) * 2 * a->H * a->W * 16 >= (1LL << 31)) return -1;      // 32-bit byte offsets inside one batch item
     if ((long long)((a->Cout + 7) / 8) * 2 * a->H * a->W * 8 >= (1LL << 31)) return -1;  // 32-bit element offsets in the epilogue
     if ((reinterpret_cast<unsigned long long>(a->x) & 15) || (a->x_bs & 7)) return -1;
-    if (a->y_fmt == 1 && ((reinterpret_cast<unsigned long long>(a->y) & 15) || (a->y_bs & 7))) return -1;
+    if (a->y_fmt != 0 && ((reinterpret_cast<unsigned long long>(a->y) & 15) || (a->y_bs & 7))) return -1;
     if (a->res1 && ((reinterpret_cast<unsigned long long>(a->res1) & 15) || (a->res1_bs & 7))) return -1;
     if (a->res2 && ((reinterpret_cast<unsigned long long>(a->res2) & 15) || (a->res2_bs & 7))) return -1;
     const int tiles_x = (a->W + 31) / 32, tiles_y = (a->H + TH - 1) / TH;
-    const int mt = 1;                                                    // 64-cout workgroup tiles were measured 5-8 % slower and are gone
-    if (a->mtile != 0 && a->mtile != 1) return -1;
+    const int mt = a->mtile == 2 ? 2 : 1;                                // must match the packing (bfsr_pack_conv_weight_h2x mtile)
+    if (a->mtile != 0 && a->mtile != 1 && a->mtile != 2) return -1;
     const int groups = (a->Cout + 32 * mt - 1) / (32 * mt);
     const long long nitems = (long long)tiles_x * tiles_y * groups * a->B;
     if (nitems > 0x7fffffffLL) return -1;
@@ -1064,60 +1438,80 @@ extern "C" int bfsr_conv3x3_h2x(const BfsrConvX3Args* a, void* stream)
     if (cus <= 0) return -1;
     if (a->tune > 0) cus = a->tune;
     const long long grid = nitems < cus ? nitems : cus;                  // one persistent workgroup per CU
-    static std::atomic<unsigned long long> lds_done{0};
-    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2x_kernel<1, 0, 2>), XGeo<1>::LDS, lds_done) != 0) return -1;
-    hipLaunchKernelGGL((conv3x3_h2x_kernel<1, 0, 2>), dim3((unsigned)grid), dim3((NW + NLW) * 64), XGeo<1>::LDS, st, *a, BfsrCouplingTailArgs{}, tiles_x, tiles_y, groups, (int)nitems);
+    static std::atomic<unsigned long long> lds_done{0}, lds_done2{0};
+    if (mt == 2) {
+        if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2x_kernel<2>), XGeo<2>::LDS, lds_done2) != 0) return -1;
+        hipLaunchKernelGGL(conv3x3_h2x_kernel<2>, dim3((unsigned)grid), dim3((NW + NLW) * 64), XGeo<2>::LDS, st, *a, tiles_x, tiles_y, groups, (int)nitems);
+        return (int)hipGetLastError();
+    }
+    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2x_kernel<1>), XGeo<1>::LDS, lds_done) != 0) return -1;
+    hipLaunchKernelGGL(conv3x3_h2x_kernel<1>, dim3((unsigned)grid), dim3((NW + NLW) * 64), XGeo<1>::LDS, st, *a, tiles_x, tiles_y, groups, (int)nitems);
     return (int)hipGetLastError();
 }
 
-// ---- the coupling tail: conv3x3_h2x_kernel<1, 1, C> (see the kernel) -------------------------------------------------------------
-template <int CF>
-static int launch_coupling_tail(const BfsrCouplingTailArgs& a, hipStream_t st)
+extern "C" long long bfsr_conv_packed_size_up2_h2x(int Cout, int Cin)
 {
-    BfsrConvX3Args c{};
-    c.x = a.hid; c.x_bs = a.hid_bs; c.Cin = a.Cin;
-    c.w = a.w; c.acc_scale = a.acc_scale;
-    c.Cout = 2 * (CF - CF / 2);
-    c.B = a.B; c.H = a.H; c.W = a.W;
-    const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + TH - 1) / TH;
-    const long long nitems = (long long)tiles_x * tiles_y * a.B;
-    if (nitems <= 0 || nitems > 0x7fffffffLL) return -1;
+    if (Cout <= 0 || Cin <= 0 || (Cin & 15)) return -1;
+    return (long long)((Cout + 31) / 32) * (Cin / 16) * 2 * 2 * 8 * 2 * 32 * 8;       // fp16 elements: [group][chunk][pa][plane][step][k half][32][8]
+}
+
+extern "C" int bfsr_pack_conv_weight_up2_h2x(const float* w16, int Cout, int Cin, float scale, unsigned short* packed)
+{
+    // w16 [Cout][Cin][16] = the parity-pre-summed matrices of bfsr_pack_conv_weight_taps (t = (a*2+b)*4 + i*2 + j) -> two-term fp16
+    // split of w*scale in the kernel's step order: step s of row parity a = matrix (a, b = s>>2, i = s&1, j = (s>>1)&1)
+    if (!w16 || !packed || Cout <= 0 || Cin <= 0 || (Cin & 15) || !(scale > 0.f)) return -1;
+    const int nchunk = Cin / 16;
+    const long long n = bfsr_conv_packed_size_up2_h2x(Cout, Cin);
+    for (long long i = 0; i < n; ++i) packed[i] = 0;
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int a = 0; a < 2; ++a)
+                for (int s_ = 0; s_ < 8; ++s_) {
+                    const int b = s_ >> 2, i = s_ & 1, j = (s_ >> 1) & 1;
+                    float r = w16[((long long)co * Cin + ci) * 16 + (a * 2 + b) * 4 + i * 2 + j] * scale;
+                    for (int pl = 0; pl < 2; ++pl) {
+                        const _Float16 h = (_Float16)r;
+                        const long long slab = (((long long)(co / 32) * nchunk + ci / 16) * 2 + a) * 2 + pl;
+                        packed[((slab * 8 + s_) * 2 + (ci % 16) / 8) * 256 + (co % 32) * 8 + ci % 8] = f32_to_f16_bits((float)h);
+                        r -= (float)h;
+                    }
+                }
+    return 0;
+}
+
+extern "C" int bfsr_conv2d_up2_h2x(const BfsrConvArgs* a, void* stream)
+{
+    // a->x: h2 tensor of the taps at source resolution [B][Cin/8][2][H/2][W/2][8] fp16 (x_bs in fp16 elements); a->w: bfsr_pack_conv_weight_up2_h2x
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!a || !a->x || !a->w || !a->y || a->w2 || a->x2 || a->res1 || a->res2) return -1;
+    if (a->B <= 0 || a->H <= 0 || a->W <= 0 || (a->H & 1) || (a->W & 1) || a->Cin <= 0 || (a->Cin & 15) || a->Cout <= 0 || a->KS != 3) return -1;
+    if (!(a->acc_scale > 0.f)) return -1;
+    const int Hs = a->H / 2, Ws = a->W / 2;
+    if ((long long)(a->Cin / 8) * 2 * Hs * Ws * 16 >= (1LL << 31)) return -1;
+    if ((reinterpret_cast<unsigned long long>(a->x) & 15) || (a->x_bs & 7)) return -1;
+    if ((reinterpret_cast<unsigned long long>(a->y) & 7) || (a->y_bs & 1)) return -1;                    // float2 stores
+    if (a->pre_add && ((reinterpret_cast<unsigned long long>(a->pre_add) & 7) || (a->pre_add_bs & 1))) return -1;
+    const int tiles_x = (Ws + 31) / 32, tiles_y = (Hs + TH - 1) / TH;
+    const int groups = (a->Cout + 31) / 32;
+    const long long nitems = 2LL * tiles_x * tiles_y * groups * a->B;
+    if (nitems > 0x7fffffffLL) return -1;
+    if (bfsr_conv_packed_size_up2_h2x(a->Cout, a->Cin) * 2 >= (1LL << 32)) return -1;
     int cus = bfsr::cu_count();
     if (cus <= 0) return -1;
+    if (a->tune > 0) cus = a->tune;
     const long long grid = nitems < cus ? nitems : cus;
     static std::atomic<unsigned long long> lds_done{0};
-    constexpr int LDS = 2 * X_IN + 4 * XGeo<1>::W;                       // two input stages + the resident weights of all four chunks: 155 648 B
-    static_assert(LDS <= 160 * 1024, "LDS budget");
-    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2x_kernel<1, 1, CF>), LDS, lds_done) != 0) return -1;
-    hipLaunchKernelGGL((conv3x3_h2x_kernel<1, 1, CF>), dim3((unsigned)grid), dim3((NW + NLW) * 64), LDS, st, c, a, tiles_x, tiles_y, 1, (int)nitems);
+    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_up2_h2x_kernel), U_LDS, lds_done) != 0) return -1;
+    hipLaunchKernelGGL(conv_up2_h2x_kernel, dim3((unsigned)grid), dim3((NW + NLW) * 64), U_LDS, st, *a, tiles_x, tiles_y, groups, (int)nitems);
     return (int)hipGetLastError();
 }
 
-extern "C" int bfsr_coupling_tail(const BfsrCouplingTailArgs* a, void* stream)
-{
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (!a || !a->hid || !a->w || !a->bias || !a->post_scale || !a->z_in || !a->z_out) return -1;
-    if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cin != 64) return -1;
-    if (a->an_bias && !a->an_escale) return -1;
-    if (!(a->acc_scale > 0.f)) return -1;
-    if (a->h_ft_fmt != 0 && a->h_ft_fmt != 1) return -1;
-    if ((reinterpret_cast<unsigned long long>(a->hid) & 15) || (a->hid_bs & 7)) return -1;
-    if (a->h_ft && a->h_ft_fmt == 1 && ((reinterpret_cast<unsigned long long>(a->h_ft) & 15) || (a->h_ft_bs & 3))) return -1;
-    if ((long long)(a->Cin / 8) * 2 * a->H * a->W * 16 >= (1LL << 31)) return -1;
-    if ((long long)2 * a->C * a->H * a->W * 4 >= (1LL << 31)) return -1;
-    switch (a->C) {
-        case 12: return launch_coupling_tail<12>(*a, st);
-        case 24: return launch_coupling_tail<24>(*a, st);
-        default: return -1;
-    }
-}
-
-extern "C" int bfsr_h2_pack(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int C, int H, int W, unsigned* flag, void* stream)
+extern "C" int bfsr_h2_pack(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int C, int H, int W, void* stream)
 {
     if (!x || !y || B <= 0 || C <= 0 || (C & 7) || H <= 0 || W <= 0) return -1;
     if ((reinterpret_cast<unsigned long long>(y) & 15) || (y_bs & 7)) return -1;
     const long long HW = (long long)H * W, total = (long long)B * (C / 8) * HW;
-    hipLaunchKernelGGL(h2_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, x_bs, y, y_bs, C, HW, total, flag);
+    hipLaunchKernelGGL(h2_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, x_bs, y, y_bs, C, HW, total);
     return (int)hipGetLastError();
 }
 

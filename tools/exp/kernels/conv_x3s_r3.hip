@@ -429,7 +429,7 @@ __global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64
             if (!has_next) break; it = nxt; cur = nitem; continue; }     // ablation: no epilogue (acc kept alive)
         if constexpr (DEF) {
             for (int k = nchunk; k < 2 * nstage; ++k) phase_all(k);  // fewer chunks than phases (the 64-channel trunk_conv with residual)
-            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");       // MFMA result -> VALU read inside the asm below: 20 wait states (>= 19 of a 16-pass XDL op), self-sufficient                 // MFMA result -> VALU read inside the asm below
+            asm volatile("s_nop 11" ::: "memory");                 // MFMA result -> VALU read inside the asm below
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -457,7 +457,7 @@ __global__ __launch_bounds__((NW + ((ABL & 16) ? 2 + ((ABL >> 5) & 3) : 0)) * 64
         // swap of element 0 (every output channel became channel 0); asm statements are opaque to it.  The compiler pads
         // neither the MFMA -> VALU-read hazard (12 wait states for an 8-pass MFMA) nor the VALU-write -> permlane hazard
         // (2 states) around an asm statement, so both pads are inside the strings.
-        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");       // MFMA result -> VALU read inside the asm below: 20 wait states (>= 19 of a 16-pass XDL op), self-sufficient
+        asm volatile("s_nop 11" ::: "memory");
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -624,8 +624,15 @@ extern "C" int bfsr_conv3x3_x3s(const BfsrConvX3Args* a, void* stream)
                            (int)n_items, (int)n_full, waitvm);                                                                      \
         return (int)hipGetLastError();                                                                                               \
     }
-    // only ABL = 16 (dedicated loader waves, epilogue behind the K loop) is compiled into the library; the ablation variants and the deferred
-    // epilogue (measured 17-20 % slower) are built from tools/exp/kernels/conv_x3s_r3.hip by tools/exp/build_abl.sh
+#ifdef BFSR_X3S_ABL
+    switch (a->tune < 0 ? -a->tune : 0) {
+        case 1: BFSR_LAUNCH(1) case 3: BFSR_LAUNCH(3) case 4: BFSR_LAUNCH(4) case 5: BFSR_LAUNCH(5) case 7: BFSR_LAUNCH(7)
+        case 8: BFSR_LAUNCH(8) case 12: BFSR_LAUNCH(12) case 16: BFSR_LAUNCH(16) case 48: BFSR_LAUNCH(48) case 80: BFSR_LAUNCH(80)
+        case 272: BFSR_LAUNCH(272) case 528: BFSR_LAUNCH(528) case 1040: BFSR_LAUNCH(1040) case 2064: BFSR_LAUNCH(2064) case 17: BFSR_LAUNCH(17) case 144: BFSR_LAUNCH(144) case 145: BFSR_LAUNCH(145) case 20: BFSR_LAUNCH(20) case 148: BFSR_LAUNCH(148)
+        default: break;
+    }
+#endif
+    if (a->tune == -1040) BFSR_LAUNCH(1040)                       // 16 | 1024: + deferred epilogue (measured 17-20 % slower, see the kernel)
     BFSR_LAUNCH(16)                                               // dedicated loader waves, epilogue behind the K loop
 #undef BFSR_LAUNCH
 }

@@ -432,23 +432,10 @@ template <int XM> struct XGeo {
     static constexpr int LDS = 2 * STAGE;       // 118 784 | 155 648
 };
 
-// EPI = 0: the conv epilogue (bias / affine / activation / residuals, h2 or fp32 output).
-// EPI = 1: the COUPLING TAIL (bfsr_coupling_tail; FlowAffineCouplingsAblation.py:57-97 + FlowStep.py:113-129): the conv is fAffine.4
-//          (Conv2dZeros 64 -> 2*(CF - CF/2) channels of h_aff) over the h2 tensor `hid` written by coupling_head_kernel, and the epilogue is the
-//          step's pointwise chain with h_aff taken from the accumulators: one v_permlane32_swap per accumulator register hands every lane
-//          ALL h_aff channels of ONE pixel (lane (l31, lhi) <- pixel (row 2*wave + lhi, column l31)), then per lane
-//            reverse: z2 = z2/scale - shift; z = z/scaleFt - shiftFt; z = Winv z; z = z*exp(-logs) - bias          (this step)
-//            forward: z2 = (z2 + shift)*scale   (this step's self-conditional)   then, if given, the NEXT step's head:
-//                     z = (z + bias)*exp(logs); z = W z; z = (z + shiftFt)*scaleFt
-//          (the semantics of bfsr_flow_pointwise).  z and h_ft of the item are loaded while its last chunk is in the matrix pipe.
-template <int XM, int EPI, int CF>
-__global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrConvX3Args p, BfsrCouplingTailArgs q, int tiles_x, int tiles_y, int groups, int nitems)
+template <int XM>
+__global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrConvX3Args p, int tiles_x, int tiles_y, int groups, int nitems)
 {
-    // WRES (coupling tail): the WHOLE weight tensor (Cin = 64: four chunks, 72 KiB) stays resident in LDS behind the two input stages and
-    // the loaders stream activations only -- the kernel is bound by the L2 -> LDS fill (~27 GB/s per CU), and with one cout group the
-    // weights are the same 31 % of every stage for every item
-    constexpr bool WRES = EPI == 1;
-    constexpr int X_WPL = XGeo<XM>::WPL, X_W = XGeo<XM>::W, X_STAGE = WRES ? X_IN : XGeo<XM>::STAGE;
+    constexpr int X_WPL = XGeo<XM>::WPL, X_W = XGeo<XM>::W, X_STAGE = XGeo<XM>::STAGE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -467,13 +454,6 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
         r.x0 = (t % tiles_x) * 32; r.y0 = ty * TH; r.b = t / tiles_x;
         return r;
     };
-    if constexpr (WRES) {                                                // all twelve waves: weights -> LDS once (ordinary loads, landed before the barrier)
-        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(p.w);
-        uint4* dst = reinterpret_cast<uint4*>(smem + 2 * X_IN);
-        const int nq = nchunk * X_W / 16;
-        for (int i = tid; i < nq; i += (NW + NLW) * 64) dst[i] = src[i];
-        __syncthreads();
-    }
 
     if (wave >= NW) {
         // ---- loader waves: LDS-DMA only (see h2s_loader_wave on why a wave must not mix load kinds)
@@ -502,7 +482,6 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
 #pragma unroll
             for (int g = 0; g < NG; ++g)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(base + ld * SUB + g * 1024), 16, vg[g], soff, 0, 0);
-            if constexpr (!WRES) {
             const unsigned wsoff = (unsigned)(cg_ * nchunk + k) * (unsigned)X_W;
 #pragma unroll
             for (int j = 0; j < (X_W / 1024 + NLW - 1) / NLW; ++j) {
@@ -510,7 +489,6 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
                 if (piece < X_W / 1024)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(base + X_IN + piece * 1024), 16,
                                                              (unsigned)lane * 16u + (unsigned)piece * 1024u, wsoff, 0, 0);
-            }
             }
         };
         int it = slot;
@@ -536,12 +514,12 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
     // -> 6 MFMAs; the fragments of step t+1 are read while the MFMAs of step t run (register double buffer: 48 registers -- a
     // tap-COLUMN step as in conv3x3_h2s_kernel needs 112 and spills beside the 32 accumulators).
     half8 bq[2][2][2], aq[2][2][XM];                                     // [buffer][plane][row] | [buffer][plane][m tile]
-    auto load_step = [&](auto buf_, int st, int t, int kc) {             // kc = chunk index inside the item (resident weights only)
+    auto load_step = [&](auto buf_, int st, int t) {
         constexpr int BUF = decltype(buf_)::value;
         const int dx = t / 3, dy = t - 3 * dx;
         const unsigned char* sIn = smem + st * X_STAGE;
         const unsigned char* inB = sIn + (lhi * NPOSP + (2 * wave + dy) * PW + l31 + dx) * 16;
-        const unsigned char* wA = (WRES ? smem + 2 * X_IN + kc * X_W : sIn + X_IN) + lane * 16 + t * (1024 * XM);        // tap = dx*3 + dy = t
+        const unsigned char* wA = sIn + X_IN + lane * 16 + t * (1024 * XM);                              // tap = dx*3 + dy = t
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
@@ -551,25 +529,16 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
         }
     };
     f32x16 acc[XM][2];
-    // Coupling tail with <= 16 output channels (C = 12): the three products need only TWO matrix instructions per operand pair when the
-    // idle rows of the 32-row tile carry the lo plane of the weights -- weight "plane" 0 = [rows 0-15: w_hi | rows 16-31: w_lo], "plane" 1 =
-    // [rows 0-15: w_hi | rows 16-31: 0] (bfsr_pack_coupling_tail):  acc += P0 . x_hi;  acc += P1 . x_lo  leaves w_hi.x_hi + w_hi.x_lo in
-    // rows 0-15 and w_lo.x_hi in rows 16-31 = accumulator registers r and r + 8 of the SAME lane, summed in the epilogue.
-    constexpr bool TWO = EPI == 1 && 2 * (CF - CF / 2) <= 16;
     auto mfma_step = [&](auto buf_) {
         constexpr int BUF = decltype(buf_)::value;
 #pragma unroll
         for (int m = 0; m < XM; ++m)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                if constexpr (TWO) {
-                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][1][m], bq[BUF][1][j], acc[m][j], 0, 0, 0);
-                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][0][m], bq[BUF][0][j], acc[m][j], 0, 0, 0);
-                } else {                                                 // smallest terms first: w_lo*x_hi, w_hi*x_lo, w_hi*x_hi
-                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][1][m], bq[BUF][0][j], acc[m][j], 0, 0, 0);
-                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][0][m], bq[BUF][1][j], acc[m][j], 0, 0, 0);
-                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][0][m], bq[BUF][0][j], acc[m][j], 0, 0, 0);
-                }
+                // smallest terms first: w_lo*x_hi, w_hi*x_lo, w_hi*x_hi
+                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][1][m], bq[BUF][0][j], acc[m][j], 0, 0, 0);
+                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][0][m], bq[BUF][1][j], acc[m][j], 0, 0, 0);
+                acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[BUF][0][m], bq[BUF][0][j], acc[m][j], 0, 0, 0);
             }
     };
     typedef std::integral_constant<int, 0> I0;
@@ -601,15 +570,14 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
         // One barrier per chunk, passed EARLY: chunk k+1's barrier sits before the last tap of chunk k (whose fragments are already in
         // registers), so the first fragments of chunk k+1 are in flight under that tap's MFMAs and the loaders may refill stage `buf`
         // one tap earlier.  Nine taps per chunk flip the fragment-buffer parity from chunk to chunk: chunks are processed in pairs.
-        int kc = 0;                                                      // chunk index inside the item
         auto chunk_body = [&](auto p_, auto q_, bool last) {               // p_: buffer holding tap 0's fragments (already loaded)
 #pragma unroll
             for (int t = 0; t < 8; t += 2) {
-                load_step(q_, buf, t + 1, kc);
+                load_step(q_, buf, t + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_step(p_);
                 __builtin_amdgcn_sched_barrier(0);
-                load_step(p_, buf, t + 2, kc);
+                load_step(p_, buf, t + 2);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_step(q_);
                 __builtin_amdgcn_sched_barrier(0);
@@ -617,125 +585,21 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
             if (!last) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // tap 8's fragments have left stage `buf`
                 __builtin_amdgcn_s_barrier();                            // chunk k+1 has landed in stage buf^1; stage buf is free again
-                load_step(q_, buf ^ 1, 0, kc + 1);
+                load_step(q_, buf ^ 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             mfma_step(p_);
             __builtin_amdgcn_sched_barrier(0);
             buf ^= 1;
-            ++kc;
-        };
-        // coupling tail: this lane's pixel and the operands of its pointwise chain (registers, loaded under the item's last chunk)
-        constexpr int CFN = CF / 2, CO2 = 2 * (CF - CFN);
-        float cz[EPI ? CF : 1], cft[EPI ? 2 * CF : 1];
-        const int cgy = cur.y0 + 2 * wave + lhi, cgx = cur.x0 + l31;
-        const bool con = cgy < H && cgx < W;
-        constexpr bool FT_EARLY = CF <= 12;                                // C = 24: 48 more live registers through the last chunk would spill
-        auto tail_prefetch = [&](bool want_z, bool want_ft) {
-            if constexpr (EPI == 1) {
-                const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.z_in + (long long)cur.b * q.z_in_bs), 0,
-                                                                                    (unsigned)(CF * HW * 4), 0x00020000);
-                const unsigned vo = con ? (unsigned)(((long long)cgy * W + cgx) * 4) : OOB;
-                if (want_z) {
-#pragma unroll
-                    for (int c = 0; c < CF; ++c) cz[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, vo, (unsigned)(c * HW * 4), 0));
-                }
-                if (want_ft && q.h_ft) {
-                    const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.h_ft + (long long)cur.b * q.h_ft_bs), 0,
-                                                                                        (unsigned)(2 * CF * HW * 4), 0x00020000);
-                    if (q.h_ft_fmt == 1) {                               // quad-major [2*CF/4][H][W][4]
-                        const unsigned vq = con ? (unsigned)(((long long)cgy * W + cgx) * 16) : OOB;
-#pragma unroll
-                        for (int c4 = 0; c4 < 2 * CF / 4; ++c4) {
-                            const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rf, vq, (unsigned)(c4 * HW * 16), 0));
-                            cft[4 * c4] = v.x; cft[4 * c4 + 1] = v.y; cft[4 * c4 + 2] = v.z; cft[4 * c4 + 3] = v.w;
-                        }
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < 2 * CF; ++c) cft[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, vo, (unsigned)(c * HW * 4), 0));
-                    }
-                }
-            }
         };
         __builtin_amdgcn_s_barrier();                                    // the item's first chunk has landed in stage `buf`
-        load_step(I0(), buf, 0, 0);
+        load_step(I0(), buf, 0);
         int k = 0;
         for (; k + 2 <= nchunk; k += 2) {                                // pairs of chunks: the parity is static inside a pair
             chunk_body(I0(), I1(), false);
-            if (k + 2 == nchunk && FT_EARLY) tail_prefetch(true, true);
             chunk_body(I1(), I0(), k + 2 == nchunk);
         }
-        if (k < nchunk) { if (FT_EARLY) tail_prefetch(true, true); chunk_body(I0(), I1(), true); }
-        if (!FT_EARLY) tail_prefetch(true, true);
-
-        if constexpr (EPI == 1) {
-            // ---- coupling tail epilogue.  The accumulators are read by compiler-visible VALU code first (x acc_scale: hipcc inserts the
-            // MFMA -> VALU wait states), the swap statement only sees VALU results (2 wait states, inside the string).
-            constexpr int NR = (CO2 + 7) / 8 * 4;                        // accumulator registers that hold channels < CO2 (rows (r&3) + 8(r>>2) + 4*lhi)
-            float ha[32];
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                float x, y;
-                if constexpr (TWO) { x = (acc[0][0][r] + acc[0][0][r + 8]) * p.acc_scale; y = (acc[0][1][r] + acc[0][1][r + 8]) * p.acc_scale; }
-                else { x = acc[0][0][r] * p.acc_scale; y = acc[0][1][r] * p.acc_scale; }
-                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
-                ha[(r & 3) + 8 * (r >> 2)] = x;                          // this lane's pixel: channel (r&3) + 8(r>>2) ...
-                ha[(r & 3) + 8 * (r >> 2) + 4] = y;                      // ... and + 4
-            }
-            unsigned bad = 0u;
-            const float eps = q.eps;
-            // The epilogue is VALU-bound (all eight compute waves are in it at once), and IEEE division / expf are ~10 instructions each:
-            // quotients are formed as v_rcp_f32 + one Newton step on the quotient (<= 1 ulp), exp as v_exp_f32 of x * log2(e) (<= 2 ulp on
-            // arguments of a few units) -- inside the 2e-5 per-kernel / 1e-4 end-to-end tolerances, measured in tests/test_hip_ops.py
-            auto fdiv = [](float a, float b) {
-                const float r = __builtin_amdgcn_rcpf(b);
-                const float qt = a * r;
-                return fmaf(fmaf(-b, qt, a), r, qt);
-            };
-            auto sscale = [&](float raw) { return fdiv(1.f, 1.f + __expf(-(raw + 2.f))) + eps; };
-            const bool hf = q.h_ft != nullptr;
-            float x[CF];
-#pragma unroll
-            for (int c = 0; c < CF; ++c) {
-                float v = cz[c];
-                if (c >= CFN) {
-                    const int co = 2 * (c - CFN);
-                    const float sh = (ha[co] + q.bias[co]) * q.post_scale[co];
-                    const float sr = (ha[co + 1] + q.bias[co + 1]) * q.post_scale[co + 1];
-                    v = q.reverse ? fdiv(v, sscale(sr)) - sh : (v + sh) * sscale(sr);
-                }
-                if (q.reverse) {
-                    if (hf) v = fdiv(v, sscale(cft[2 * c + 1])) - cft[2 * c];
-                } else if (q.an_bias) {
-                    v = (v + q.an_bias[c]) * q.an_escale[c];
-                }
-                x[c] = v;
-            }
-            if (con) {
-                float* zo = q.z_out + (long long)cur.b * q.z_out_bs + (long long)cgy * W + cgx;
-#pragma unroll
-                for (int ci = 0; ci < CF; ++ci) {
-                    float v;
-                    if (q.wmat) {
-                        const float* __restrict__ w = q.wmat + ci * CF;
-                        float a = 0.f;
-#pragma unroll
-                        for (int j = 0; j < CF; ++j) a = fmaf(w[j], x[j], a);
-                        v = a;
-                    } else {
-                        v = x[ci];
-                    }
-                    if (q.reverse) {
-                        if (q.an_bias) v = v * q.an_escale[ci] - q.an_bias[ci];
-                    } else if (hf) {
-                        v = (v + cft[2 * ci]) * sscale(cft[2 * ci + 1]);
-                    }
-                    bad |= (unsigned)!(fabsf(v) < 3.0e38f);                // NaN / inf guard of the flow state
-                    zo[(long long)ci * HW] = v;
-                }
-            }
-            if (q.flag && __any((int)bad)) { if (lane == 0) atomicOr(q.flag, 2u); }
-        } else {
+        if (k < nchunk) chunk_body(I0(), I1(), true);
 
         // ---- epilogue (the loaders are already staging the next item): as in conv3x3_h2s_kernel, plus the weight scale; one M tile
         // at a time (64 results per lane and the residual operands of both tiles at once would spill)
@@ -863,7 +727,6 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        }   // EPI == 0
     }
     if (p.flag && __any((int)!(xamax < 65504.f))) { if (lane == 0) atomicOr(p.flag, 1u); }
 }
@@ -1005,39 +868,6 @@ extern "C" int bfsr_pack_conv_weight_h2x(const float* w, int Cout, int Cin, int 
     return 0;
 }
 
-// fAffine.4 of a coupled FlowStep (Conv2dZeros [Cout][64][3][3]) in conv3x3_h2x_kernel's weight layout for ONE 32-row tile.  Cout <= 16:
-// the two-instruction form (see `TWO` in the kernel): plane 0 = [rows 0-15: hi | rows 16-31: lo], plane 1 = [rows 0-15: hi | rest 0].
-extern "C" long long bfsr_coupling_tail_packed_size(int Cin, int Cout)
-{
-    if (Cin != 64 || Cout <= 0 || Cout > 32) return -1;
-    return bfsr_conv_packed_size_h2x(32, Cin, 1);                                           // fp16 elements
-}
-
-extern "C" int bfsr_pack_coupling_tail(const float* w, int Cin, int Cout, float scale, unsigned short* packed)
-{
-    if (!w || !packed || Cin != 64 || Cout <= 0 || Cout > 32 || !(scale > 0.f)) return -1;
-    if (Cout > 16) return bfsr_pack_conv_weight_h2x(w, Cout, Cin, 1, scale, packed);
-    const int nchunk = Cin / 16;
-    const long long n = bfsr_coupling_tail_packed_size(Cin, Cout);
-    for (long long i = 0; i < n; ++i) packed[i] = 0;
-    const long long PLSZ = 9 * 2 * 32 * 8;
-    for (int co = 0; co < Cout; ++co)
-        for (int ci = 0; ci < Cin; ++ci)
-            for (int dy = 0; dy < 3; ++dy)
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float v = w[((long long)co * Cin + ci) * 9 + dy * 3 + dx] * scale;
-                    const _Float16 h = (_Float16)v;
-                    const _Float16 l = (_Float16)(v - (float)h);
-                    const unsigned short hb = f32_to_f16_bits((float)h), lb = f32_to_f16_bits((float)l);
-                    const long long base = (long long)(ci / 16) * 2;
-                    auto at = [&](int row) { return ((((long long)(dx * 3 + dy)) * 2 + (ci % 16) / 8) * 32 + row) * 8 + ci % 8; };
-                    packed[(base + 0) * PLSZ + at(co)] = hb;
-                    packed[(base + 0) * PLSZ + at(16 + co)] = lb;
-                    packed[(base + 1) * PLSZ + at(co)] = hb;
-                }
-    return 0;
-}
-
 extern "C" int bfsr_conv3x3_h2x(const BfsrConvX3Args* a, void* stream)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1065,51 +895,9 @@ extern "C" int bfsr_conv3x3_h2x(const BfsrConvX3Args* a, void* stream)
     if (a->tune > 0) cus = a->tune;
     const long long grid = nitems < cus ? nitems : cus;                  // one persistent workgroup per CU
     static std::atomic<unsigned long long> lds_done{0};
-    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2x_kernel<1, 0, 2>), XGeo<1>::LDS, lds_done) != 0) return -1;
-    hipLaunchKernelGGL((conv3x3_h2x_kernel<1, 0, 2>), dim3((unsigned)grid), dim3((NW + NLW) * 64), XGeo<1>::LDS, st, *a, BfsrCouplingTailArgs{}, tiles_x, tiles_y, groups, (int)nitems);
+    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2x_kernel<1>), XGeo<1>::LDS, lds_done) != 0) return -1;
+    hipLaunchKernelGGL((conv3x3_h2x_kernel<1>), dim3((unsigned)grid), dim3((NW + NLW) * 64), XGeo<1>::LDS, st, *a, tiles_x, tiles_y, groups, (int)nitems);
     return (int)hipGetLastError();
-}
-
-// ---- the coupling tail: conv3x3_h2x_kernel<1, 1, C> (see the kernel) -------------------------------------------------------------
-template <int CF>
-static int launch_coupling_tail(const BfsrCouplingTailArgs& a, hipStream_t st)
-{
-    BfsrConvX3Args c{};
-    c.x = a.hid; c.x_bs = a.hid_bs; c.Cin = a.Cin;
-    c.w = a.w; c.acc_scale = a.acc_scale;
-    c.Cout = 2 * (CF - CF / 2);
-    c.B = a.B; c.H = a.H; c.W = a.W;
-    const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + TH - 1) / TH;
-    const long long nitems = (long long)tiles_x * tiles_y * a.B;
-    if (nitems <= 0 || nitems > 0x7fffffffLL) return -1;
-    int cus = bfsr::cu_count();
-    if (cus <= 0) return -1;
-    const long long grid = nitems < cus ? nitems : cus;
-    static std::atomic<unsigned long long> lds_done{0};
-    constexpr int LDS = 2 * X_IN + 4 * XGeo<1>::W;                       // two input stages + the resident weights of all four chunks: 155 648 B
-    static_assert(LDS <= 160 * 1024, "LDS budget");
-    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2x_kernel<1, 1, CF>), LDS, lds_done) != 0) return -1;
-    hipLaunchKernelGGL((conv3x3_h2x_kernel<1, 1, CF>), dim3((unsigned)grid), dim3((NW + NLW) * 64), LDS, st, c, a, tiles_x, tiles_y, 1, (int)nitems);
-    return (int)hipGetLastError();
-}
-
-extern "C" int bfsr_coupling_tail(const BfsrCouplingTailArgs* a, void* stream)
-{
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (!a || !a->hid || !a->w || !a->bias || !a->post_scale || !a->z_in || !a->z_out) return -1;
-    if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cin != 64) return -1;
-    if (a->an_bias && !a->an_escale) return -1;
-    if (!(a->acc_scale > 0.f)) return -1;
-    if (a->h_ft_fmt != 0 && a->h_ft_fmt != 1) return -1;
-    if ((reinterpret_cast<unsigned long long>(a->hid) & 15) || (a->hid_bs & 7)) return -1;
-    if (a->h_ft && a->h_ft_fmt == 1 && ((reinterpret_cast<unsigned long long>(a->h_ft) & 15) || (a->h_ft_bs & 3))) return -1;
-    if ((long long)(a->Cin / 8) * 2 * a->H * a->W * 16 >= (1LL << 31)) return -1;
-    if ((long long)2 * a->C * a->H * a->W * 4 >= (1LL << 31)) return -1;
-    switch (a->C) {
-        case 12: return launch_coupling_tail<12>(*a, st);
-        case 24: return launch_coupling_tail<24>(*a, st);
-        default: return -1;
-    }
 }
 
 extern "C" int bfsr_h2_pack(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int C, int H, int W, unsigned* flag, void* stream)

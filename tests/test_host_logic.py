@@ -289,27 +289,28 @@ def test_fp16_pair_packers_layout_and_accuracy():
             assert abs(got - ref) <= tol(ref), (co, ci, dy, dx)
         if mt == 1:                                                       # cout padding of the last group (couts 70..95) is zero
             assert float(P[-1, :, :, :, 0, :, 70 - 64:, :].abs().sum()) == 0.0
-    # --- coupling tail (fAffine.4 for conv3x3_h2x_kernel's coupling epilogue): Cout <= 16 -> the two-instruction form, plane 0 = [rows 0-15:
-    #     hi | rows 16-31: lo], plane 1 = [rows 0-15: hi | 0]; Cout > 16 -> the plain h2x packing of one 32-row tile
+    # --- coupling tail (coupling_tail.hip): [octet][plane][tap = dx*3 + dy][32 rows][8] + one block of zeros.  Cout <= 16 -> the
+    #     two-instruction form: plane 0 = [rows 0-15: hi | rows 16-31: lo], plane 1 = [rows 0-15: hi | 0]; Cout > 16 -> plane 0 = hi, plane 1 = lo
     w4 = torch.randn(12, 64, 3, 3) * 0.01
     s4 = HipOps.pow2_scale(w4)
     n = lib.bfsr_coupling_tail_packed_size(64, 12)
-    assert n == 4 * 2 * 9 * 2 * 32 * 8 and lib.bfsr_coupling_tail_packed_size(48, 12) < 0 and lib.bfsr_coupling_tail_packed_size(64, 40) < 0
+    assert n == 8 * 2 * 9 * 32 * 8 + 32 * 8 and lib.bfsr_coupling_tail_packed_size(48, 12) < 0 and lib.bfsr_coupling_tail_packed_size(64, 40) < 0
     p = torch.zeros(n, dtype=torch.int16)
     assert lib.bfsr_pack_coupling_tail(w4.data_ptr(), 64, 12, s4, p.data_ptr()) == 0
-    P = f16(p).view(4, 2, 9, 2, 32, 8)                                    # [chunk][plane][tap = dx*3 + dy][k half][row][8]
+    assert float(f16(p[-256:]).abs().sum()) == 0.0                       # the zero block (tenth tap)
+    P = f16(p[:-256]).view(8, 2, 9, 32, 8)
     for co, ci, dy, dx in ((0, 0, 0, 0), (11, 47, 2, 2), (5, 17, 1, 0)):
-        sel = (ci // 16, slice(None), dx * 3 + dy, (ci % 16) // 8)
-        hi0, lo0, hi1 = P[ci // 16, 0, dx * 3 + dy, (ci % 16) // 8, co, ci % 8], P[ci // 16, 0, dx * 3 + dy, (ci % 16) // 8, 16 + co, ci % 8], \
-            P[ci // 16, 1, dx * 3 + dy, (ci % 16) // 8, co, ci % 8]
+        hi0, lo0, hi1 = P[ci // 8, 0, dx * 3 + dy, co, ci % 8], P[ci // 8, 0, dx * 3 + dy, 16 + co, ci % 8], P[ci // 8, 1, dx * 3 + dy, co, ci % 8]
         ref = w4[co, ci, dy, dx].double() * s4
         assert hi0 == hi1 and abs((hi0 + lo0) - ref) <= tol(ref), (co, ci, dy, dx)
-        assert float(P[ci // 16, 1, dx * 3 + dy, (ci % 16) // 8, 16 + co, ci % 8]) == 0.0
-    assert float(P[:, :, :, :, 12:16].abs().sum()) == 0.0 and float(P[:, :, :, :, 28:].abs().sum()) == 0.0
+        assert float(P[ci // 8, 1, dx * 3 + dy, 16 + co, ci % 8]) == 0.0
+    assert float(P[:, :, :, 12:16].abs().sum()) == 0.0 and float(P[:, :, :, 28:].abs().sum()) == 0.0
     w4b = torch.randn(24, 64, 3, 3) * 0.01
-    pa, pb = torch.zeros(n, dtype=torch.int16), torch.zeros(n, dtype=torch.int16)
-    assert lib.bfsr_pack_coupling_tail(w4b.data_ptr(), 64, 24, s4, pa.data_ptr()) == 0
-    assert lib.bfsr_pack_conv_weight_h2x(w4b.data_ptr(), 24, 64, 1, s4, pb.data_ptr()) == 0 and torch.equal(pa, pb)
+    assert lib.bfsr_pack_coupling_tail(w4b.data_ptr(), 64, 24, s4, p.data_ptr()) == 0
+    P = f16(p[:-256]).view(8, 2, 9, 32, 8)
+    for co, ci, dy, dx in ((0, 0, 0, 0), (23, 47, 2, 2), (5, 17, 1, 0)):
+        ref = w4b[co, ci, dy, dx].double() * s4
+        assert abs(P[ci // 8, :, dx * 3 + dy, co, ci % 8].sum() - ref) <= tol(ref)
     # --- fused MLP, per-layer scales
     HD, Co4 = 256, 72
     ws = [torch.randn(HD, 4 * HD) * 0.03, torch.randn(HD, HD) * 0.06, torch.randn(HD, HD) * 0.5, torch.randn(Co4, HD) * 2.0]

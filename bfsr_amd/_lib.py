@@ -164,6 +164,7 @@ SYMBOLS = {
     "bfsr_pack_coupling_head": (_I, [_VP, _VP, _I, C.c_float, C.c_float, _VP]),
     "bfsr_coupling_tail_packed_size": (_LL, [_I, _I]),
     "bfsr_pack_coupling_tail": (_I, [_VP, _I, _I, C.c_float, _VP]),
+    "bfsr_conv3x3_h2r": (_I, [C.POINTER(BfsrConvX3Args), _VP]),
     "bfsr_squeeze2d": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
     "bfsr_unsqueeze2d": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
     "bfsr_split2d": (_I, [_VP, _LL, _VP, _LL, _VP, _LL, _I, _I, _I, _I, _I, _VP]),

@@ -47,7 +47,8 @@ __device__ __forceinline__ void split2(float v, _Float16& h, _Float16& l)
     l = (_Float16)(v - (float)h);
 }
 
-// NO = ceil(Cz/8) z1 octets, NWV = waves (= tile rows) per workgroup
+// NO = ceil(Cz/8) z1 octets, NWV = waves (= tile rows) per workgroup.  NO = 0: no 3x3 stage at all -- hid = relu(AN2(W2 . relu(AN0(pre_aff)))),
+// the form the hoisted fFeatures nets use (fFeatures.0's ActNorm + ReLU on the hoisted conv result, then fFeatures.2; FlowAffineCouplingsAblation.py:127-135)
 template <int NO, int NWV>
 struct HeadGeo {
     static constexpr int TH = NWV, NT = NWV * 64, NPOS = (TH + 2) * PW;
@@ -57,7 +58,7 @@ struct HeadGeo {
     static constexpr int W2B = 4 * 2 * 2 * 64 * 16;
     static constexpr int PB = 2 * 64 * 8;                       // epi0, epi2: [64] {shift, scale}
     static constexpr int LDS = 2 * ZT + W0B + W2B + PB;
-    static constexpr int ZU = (NO * NPOS + NT - 1) / NT;        // staged (octet, position) units per thread
+    static constexpr int ZU = NO ? (NO * NPOS + NT - 1) / NT : 1; // staged (octet, position) units per thread
 };
 
 // PF = pre_fmt (compile-time: the two load forms need very different numbers of scalar offsets)
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void coupling_head_kernel(BfsrCoupling
             dp[i] = make_float2(q.x, q.y);
         }
     }
+    if constexpr (NO == 0) __syncthreads();                               // (with a 3x3 stage the first tile's barrier covers the staging)
     unsigned bad = 0u;                                                    // range guard of the fp16 split (see the header)
 
     // ---- per-tile register prefetch: this thread's z1 units (8 channels of one staged position) and its 32 pre_aff values
@@ -148,13 +150,20 @@ __global__ __launch_bounds__(NWV * 64, 2) void coupling_head_kernel(BfsrCoupling
                     pre[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (unsigned)((m * 32 + (r & 3) + 8 * (r >> 2)) * HW * 4), 0));
         }
     };
-    prefetch_z(slot, zrA);
+    if constexpr (NO > 0) prefetch_z(slot, zrA);
     prefetch_pre(slot, preA);
 
     const float s0 = p.acc_scale0, s2 = p.acc_scale2;
     auto tile_body = [&](int t, unsigned char* sZ, float (&zr)[ZU][8], float (&pre)[2][16], float (&zr_n)[ZU][8], float (&pre_n)[2][16]) {
         const int tile = t % tiles_xy, b = t / tiles_xy;
         const int x0 = (tile % tiles_x) * TW, y0 = (tile / tiles_x) * TH;
+        f32x16 acc[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        half8 fb[2][2], fa[2][2][2];                        // [buffer][plane] | [buffer][m][plane]
+        if constexpr (NO > 0) {
         // ---- registers -> split z1 tile in LDS
 #pragma unroll
         for (int i = 0; i < ZU; ++i) {
@@ -176,20 +185,14 @@ __global__ __launch_bounds__(NWV * 64, 2) void coupling_head_kernel(BfsrCoupling
         __syncthreads();                                    // the ONLY barrier of a tile: tile t is complete in buffer `par^1`, and every wave has
                                                             // finished its reads of tile t-1 (the other buffer), which tile t+1 will overwrite
         if (t + G < ntiles) prefetch_z(t + G, zr_n);        // next tile's z1 loads fly under this tile's MFMAs and stores
-
-        f32x16 acc[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        }
         // smallest terms first: w_lo*x_hi, w_hi*x_lo, w_hi*x_hi
 #define BFSR_THREE(ACC_, A_, B_)                                                                               \
     ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[1], B_[0], ACC_, 0, 0, 0);                                 \
     ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[0], B_[1], ACC_, 0, 0, 0);                                 \
     ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_[0], B_[0], ACC_, 0, 0, 0);
         // ---- 3x3: chunk j = units (2j, 2j+1); unit u = (tap u / NO, octet u % NO); lanes 0-31 take unit 2j, lanes 32-63 unit 2j+1
-        half8 fb[2][2], fa[2][2][2];                        // [buffer][plane] | [buffer][m][plane]
-        {
+        if constexpr (NO > 0) {
             auto frags = [&](int j, half8 (&bf)[2], half8 (&af)[2][2]) {
                 const int u0 = 2 * j, u1 = (2 * j + 1 < NU) ? 2 * j + 1 : 2 * j;  // a missing second unit re-reads the first (its weights are 0)
                 const int t0 = u0 / NO, o0 = u0 % NO, t1 = u1 / NO, o1 = u1 % NO;
@@ -351,7 +354,7 @@ inline unsigned short f16_bits(float v)
 // ---- host-side packing -----------------------------------------------------------------------------------------------
 extern "C" long long bfsr_coupling_head_packed_size(int Cz)
 {
-    if (Cz <= 0 || Cz > 16) return -1;
+    if (Cz < 0 || Cz > 16) return -1;                         // Cz = 0: no 3x3 stage (the 1x1 only)
     const int NO = (Cz + 7) / 8, NC1 = (9 * NO + 1) / 2;
     return (long long)(NC1 + 4) * 2 * 2 * 64 * 8;             // fp16 elements
 }
@@ -363,7 +366,7 @@ extern "C" long long bfsr_coupling_head_packed_size(int Cz)
 // of the 3x3's output, see the kernel).
 extern "C" int bfsr_pack_coupling_head(const float* w0, const float* w2, int Cz, float scale0, float scale2, unsigned short* packed)
 {
-    if (!w0 || !w2 || !packed || Cz <= 0 || Cz > 16 || !(scale0 > 0.f) || !(scale2 > 0.f)) return -1;
+    if ((!w0 && Cz > 0) || !w2 || !packed || Cz < 0 || Cz > 16 || !(scale0 > 0.f) || !(scale2 > 0.f)) return -1;
     const int NO = (Cz + 7) / 8, NU = 9 * NO, NC1 = (NU + 1) / 2;
     const long long n = bfsr_coupling_head_packed_size(Cz);
     for (long long i = 0; i < n; ++i) packed[i] = 0;
@@ -400,8 +403,8 @@ extern "C" int bfsr_pack_coupling_head(const float* w0, const float* w2, int Cz,
 extern "C" int bfsr_coupling_head(const BfsrCouplingHeadArgs* a, void* stream)
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (!a || !a->z || !a->pre_aff || !a->w || !a->epi0 || !a->epi2 || !a->hid) return -1;
-    if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cz <= 0 || a->Cz > 16) return -1;
+    if (!a || (!a->z && a->Cz > 0) || !a->pre_aff || !a->w || !a->epi0 || !a->epi2 || !a->hid) return -1;
+    if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cz < 0 || a->Cz > 16) return -1;
     if (a->pre_fmt != 0 && a->pre_fmt != 1) return -1;
     if (!(a->acc_scale0 > 0.f) || !(a->acc_scale2 > 0.f)) return -1;
     if ((reinterpret_cast<unsigned long long>(a->hid) & 15) || (a->hid_bs & 7)) return -1;
@@ -409,6 +412,7 @@ extern "C" int bfsr_coupling_head(const BfsrCouplingHeadArgs* a, void* stream)
     if ((long long)64 * a->H * a->W * 4 >= (1LL << 31)) return -1;
     // FOUR waves per workgroup, two independent workgroups per CU (their barriers are private, so the VALU / memory phases of one
     // overlap the MFMA phases of the other on every SIMD)
+    if (a->Cz == 0) return a->pre_fmt == 1 ? launch_head<0, 4, 1>(*a, st) : launch_head<0, 4, 0>(*a, st);
     if (a->pre_fmt == 1) return a->Cz <= 8 ? launch_head<1, 4, 1>(*a, st) : launch_head<2, 4, 1>(*a, st);
     return a->Cz <= 8 ? launch_head<1, 4, 0>(*a, st) : launch_head<2, 4, 0>(*a, st);
 }

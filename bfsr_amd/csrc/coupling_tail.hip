@@ -63,11 +63,14 @@ __device__ __forceinline__ void wait_vmcnt_ring(int chunks)      // everything b
 }
 static_assert(NPL == 5, "wait_vmcnt_ring's immediates");
 
-// REV (= args.reverse) is a template parameter: as a run-time flag every per-channel `reverse ? a : b` became a branch
-template <int CF, int REV>
+// REV (= args.reverse) is a template parameter: as a run-time flag every per-channel `reverse ? a : b` became a branch.
+// MODE 0: the coupling tail (CF = flow channels).  MODE 1: the same conv with a PLAIN conv epilogue (bfsr_conv3x3_h2r: 64 -> <= 32 channels over an
+// h2 tensor, fp32 NCHW or quad-major output) -- CF = 16 or 32 is the output-channel class, and the argument struct is reused: bias = the
+// [Cout][2] float4 epilogue table of bfsr_pack_epilogue (or null), z_out = y, C = Cout, h_ft_fmt = quad-major output, reverse = act, eps = slope.
+template <int MODE, int CF, int REV>
 __global__ __launch_bounds__((NW + NLW) * 64, 1) void coupling_tail_kernel(BfsrCouplingTailArgs q, int tiles_x, int tiles_y, int nitems)
 {
-    constexpr int CFN = CF / 2, CO2 = 2 * (CF - CFN);
+    constexpr int CFN = CF / 2, CO2 = MODE ? CF : 2 * (CF - CFN);
     constexpr bool TWO = CO2 <= 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sW = smem + NSTG * STG;
@@ -97,6 +100,15 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void coupling_tail_kernel(BfsrC
         // ... and the per-channel parameters of the epilogue, absent ones as identities (no run-time branches per channel later; read from
         // global memory inside the item loop they become ~100 dependent vector loads per wave and item: hipcc cannot use scalar loads for
         // memory the kernel's own stores might alias, and that was half of the kernel's time -- profiles/r04_c_tail_ablation.txt)
+        if constexpr (MODE == 1) {                                       // [5][32]: bias, shift, scale, post-add, post-scale per channel (identity beyond Cout / without a table)
+            const float4* __restrict__ epi = reinterpret_cast<const float4*>(q.bias);
+            for (int i = tid; i < 160; i += (NW + NLW) * 64) {
+                const int k = i >> 5, co = i & 31;
+                float v = (k == 2 || k == 4) ? 1.f : 0.f;
+                if (epi && co < q.C) { const float4 e0 = epi[co * 2]; v = k == 0 ? e0.x : k == 1 ? e0.y : k == 2 ? e0.z : k == 3 ? e0.w : epi[co * 2 + 1].x; }
+                sPar[i] = v;
+            }
+        } else
         for (int i = tid; i < Geo::NPAR; i += (NW + NLW) * 64) {
             float v;
             if (i < Geo::PB_) v = q.wmat ? q.wmat[i] : ((i / CF) == (i % CF) ? 1.f : 0.f);
@@ -215,11 +227,12 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void coupling_tail_kernel(BfsrC
             st = (st + 1) & (NSTG - 1);
         };
         // this lane's pixel and the operands of its pointwise chain
-        float cz[CF], cft[2 * CF];
+        float cz[MODE ? 1 : CF], cft[MODE ? 1 : 2 * CF];
         const int cgy = cur.y0 + 2 * wave + lhi, cgx = cur.x0 + l31;
         const bool con = cgy < H && cgx < W;
-        constexpr bool EARLY = CF <= 12;                                  // C = 24: 72 more live registers through the K loop would spill
+        constexpr bool EARLY = MODE == 0 && CF <= 12;                     // C = 24: 72 more live registers through the K loop would spill
         auto tail_prefetch = [&]() {
+            if constexpr (MODE == 0) {
             const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.z_in + (long long)cur.b * q.z_in_bs), 0,
                                                                                 (unsigned)(CF * HW * 4), 0x00020000);
             const unsigned vo = con ? (unsigned)(((long long)cgy * W + cgx) * 4) : OOB;
@@ -240,6 +253,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void coupling_tail_kernel(BfsrC
                     for (int c = 0; c < 2 * CF; ++c) cft[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, vo, (unsigned)(c * HW * 4), 0));
                 }
             }
+            }
         };
         const float eps = q.eps;
         // IEEE division and expf are ~10 instructions each and all eight compute waves are in this epilogue at once: quotients are formed as
@@ -254,7 +268,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void coupling_tail_kernel(BfsrC
         // the feature-conditional scales depend on h_ft only: formed under the item's last two chunks (the transcendental pipe is free while the
         // matrix pipe works), in place of the raw values -- reverse: 1 / scale (the division becomes a multiplication, <= 1.5 ulp), forward: scale
         auto ft_scales = [&]() {
-            if (hf) {
+            if constexpr (MODE == 0) if (hf) {
 #pragma unroll
                 for (int c = 0; c < CF; ++c) {
                     const float t = 1.f + __expf(-(cft[2 * c + 1] + 2.f));
@@ -277,7 +291,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void coupling_tail_kernel(BfsrC
             chunk_body(I1(), I0(), c + 2 == NCH, c + 1);
 #endif
         }
-        if (!EARLY) { tail_prefetch(); ft_scales(); }
+        if (MODE == 0 && !EARLY) { tail_prefetch(); ft_scales(); }
 
 #if defined(BFSR_TAIL_ABL) && (BFSR_TAIL_ABL & 1)
         {                                                                // ablation: no epilogue (accumulators and operands kept alive)
@@ -289,6 +303,50 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void coupling_tail_kernel(BfsrC
             continue;
         }
 #endif
+        if constexpr (MODE == 1) {
+            // ---- plain conv epilogue: lane (l31, lhi) holds channels 8g + 4*lhi + 0..3 (registers 4g..4g+3) of pixels (row 2*wave + j, column l31)
+            int po = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(po));                                 // per-item opaque offset: the parameter reads must not be hoisted into SGPRs
+#endif
+            const float* sp = sPar + po;
+            const float slope = q.reverse == 0 ? 1.f : (q.reverse == 1 ? 0.f : q.eps);
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(q.z_out + (long long)cur.b * q.z_out_bs, 0, (unsigned)(q.C * HW * 4), 0x00020000);
+#pragma unroll
+            for (int g = 0; g < CO2 / 8; ++g) {
+                const int c0 = 8 * g + 4 * lhi;
+                const float4 pb = *reinterpret_cast<const float4*>(&sp[c0]), psh = *reinterpret_cast<const float4*>(&sp[32 + c0]),
+                             psc = *reinterpret_cast<const float4*>(&sp[64 + c0]), ppa = *reinterpret_cast<const float4*>(&sp[96 + c0]),
+                             pps = *reinterpret_cast<const float4*>(&sp[128 + c0]);
+                const float b4[4] = {pb.x, pb.y, pb.z, pb.w}, sh4[4] = {psh.x, psh.y, psh.z, psh.w}, sc4[4] = {psc.x, psc.y, psc.z, psc.w},
+                            pa4[4] = {ppa.x, ppa.y, ppa.z, ppa.w}, ps4[4] = {pps.x, pps.y, pps.z, pps.w};
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int gy = cur.y0 + 2 * wave + j, gx = cur.x0 + l31;
+                    const bool ok = gy < H && gx < W;
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = TWO ? (acc[j][4 * g + e] + acc[j][4 * g + e + 8]) * q.acc_scale : acc[j][4 * g + e] * q.acc_scale;
+                        v += b4[e];
+                        v = (v + sh4[e]) * sc4[e] + pa4[e];
+                        v = v > 0.f ? v : v * slope;
+                        o[e] = v * ps4[e];
+                    }
+                    if (q.h_ft_fmt == 1) {
+                        const unsigned vo = ok ? (unsigned)(((long long)lhi * HW + (long long)gy * W + gx) * 16) : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, make_float4(o[0], o[1], o[2], o[3])), ry, vo,
+                                                               (unsigned)(2 * g * HW * 16), 0);
+                    } else {
+                        const unsigned vo = ok ? (unsigned)(((long long)gy * W + gx + 4LL * lhi * HW) * 4) : OOB;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o[e]), ry, vo, (unsigned)((8 * g + e) * HW * 4), 0);
+                    }
+                }
+            }
+            continue;
+        }
         // ---- epilogue.  The accumulators are read by compiler-visible VALU code first (hipcc inserts the MFMA -> VALU wait states), the
         // swap statement only sees VALU results (2 wait states, inside the string).
         constexpr int NR = (CO2 + 7) / 8 * 4;                            // accumulator registers that hold channels < CO2 (rows (r&3) + 8(r>>2) + 4*lhi)
@@ -353,7 +411,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void coupling_tail_kernel(BfsrC
     if (q.flag && __any((int)bad)) { if (lane == 0) atomicOr(q.flag, 2u); }
 }
 
-template <int CF, int REV>
+template <int MODE, int CF, int REV>
 int launch_tail(const BfsrCouplingTailArgs& a, hipStream_t st)
 {
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + TH - 1) / TH;
@@ -363,8 +421,8 @@ int launch_tail(const BfsrCouplingTailArgs& a, hipStream_t st)
     if (cus <= 0) return -1;
     const long long grid = nitems < cus ? nitems : cus;                  // one persistent workgroup per CU
     static std::atomic<unsigned long long> lds_done{0};
-    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&coupling_tail_kernel<CF, REV>), TailGeo<CF>::LDS, lds_done) != 0) return -1;
-    hipLaunchKernelGGL((coupling_tail_kernel<CF, REV>), dim3((unsigned)grid), dim3((NW + NLW) * 64), TailGeo<CF>::LDS, st, a, tiles_x, tiles_y, (int)nitems);
+    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&coupling_tail_kernel<MODE, CF, REV>), (MODE ? LDS_CONV + 160 * 4 : TailGeo<CF>::LDS), lds_done) != 0) return -1;
+    hipLaunchKernelGGL((coupling_tail_kernel<MODE, CF, REV>), dim3((unsigned)grid), dim3((NW + NLW) * 64), (MODE ? LDS_CONV + 160 * 4 : TailGeo<CF>::LDS), st, a, tiles_x, tiles_y, (int)nitems);
     return (int)hipGetLastError();
 }
 
@@ -421,8 +479,31 @@ extern "C" int bfsr_coupling_tail(const BfsrCouplingTailArgs* a, void* stream)
     if ((long long)(a->Cin / 8) * 2 * a->H * a->W * 16 >= (1LL << 31)) return -1;
     if ((long long)2 * a->C * a->H * a->W * 4 >= (1LL << 31)) return -1;
     switch (a->C) {
-        case 12: return a->reverse ? launch_tail<12, 1>(*a, st) : launch_tail<12, 0>(*a, st);
-        case 24: return a->reverse ? launch_tail<24, 1>(*a, st) : launch_tail<24, 0>(*a, st);
+        case 12: return a->reverse ? launch_tail<0, 12, 1>(*a, st) : launch_tail<0, 12, 0>(*a, st);
+        case 24: return a->reverse ? launch_tail<0, 24, 1>(*a, st) : launch_tail<0, 24, 0>(*a, st);
         default: return -1;
     }
+}
+
+// The same kernel as a plain 3x3 'same' conv 64 -> Cout <= 32 over an h2 tensor (the Conv2dZeros of the hoisted fFeatures nets, flow.py:68-83,
+// FlowAffineCouplingsAblation.py:127-135): a->x h2 view, a->w from bfsr_pack_coupling_tail(w, 64, Cout, scale), a->acc_scale = 1/scale, a->y fp32
+// [B,Cout,H,W] (y_fmt 0) or quad-major [B][Cout/4][H][W][4] (y_fmt 2), a->epi / act / slope as for bfsr_conv2d.  No residuals.
+extern "C" int bfsr_conv3x3_h2r(const BfsrConvX3Args* a, void* stream)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!a || !a->x || !a->w || !a->y || a->res1 || a->res2) return -1;
+    if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cin != 64 || a->Cout <= 0 || a->Cout > 32) return -1;
+    if (a->y_fmt != 0 && a->y_fmt != 2) return -1;
+    if (a->y_fmt == 2 && ((a->Cout & 3) || (reinterpret_cast<unsigned long long>(a->y) & 15) || (a->y_bs & 3))) return -1;
+    if (!(a->acc_scale > 0.f)) return -1;
+    if ((reinterpret_cast<unsigned long long>(a->x) & 15) || (a->x_bs & 7)) return -1;
+    if ((long long)8 * 2 * a->H * a->W * 16 >= (1LL << 31) || (long long)a->Cout * a->H * a->W * 4 >= (1LL << 31)) return -1;
+    BfsrCouplingTailArgs q{};
+    q.hid = a->x; q.hid_bs = a->x_bs; q.Cin = 64;
+    q.w = a->w; q.acc_scale = a->acc_scale;
+    q.bias = reinterpret_cast<const float*>(a->epi);
+    q.z_out = reinterpret_cast<float*>(a->y); q.z_out_bs = a->y_bs;
+    q.B = a->B; q.C = a->Cout; q.H = a->H; q.W = a->W;
+    q.h_ft_fmt = a->y_fmt == 2 ? 1 : 0; q.reverse = a->act; q.eps = a->slope;
+    return a->Cout <= 16 ? launch_tail<1, 16, 0>(q, st) : launch_tail<1, 32, 0>(q, st);
 }

@@ -650,15 +650,20 @@ class HipOps(object):
     def pack_coupling_head(self, w0_z1, w2, shift0, scale0, shift2, scale2):
         """fAffine.0 restricted to the z1 rows [64,Cz,3,3] + fAffine.2 [64,64(,1,1)] as two-term fp16 splits of w * 2^k, and their
         ActNorm (bias, exp(logs)) vectors."""
-        w0 = w0_z1.detach().to("cpu", torch.float32).contiguous()
         w2 = w2.detach().to("cpu", torch.float32).reshape(64, 64).contiguous()
-        Cz = w0.shape[1]
+        if w0_z1 is None:                   # no 3x3 stage: hid = relu(AN2(W2 . relu(AN0(pre_aff)))) (the hoisted fFeatures nets)
+            w0, Cz, s0 = None, 0, 1.0
+        else:
+            w0 = w0_z1.detach().to("cpu", torch.float32).contiguous()
+            Cz, s0 = w0.shape[1], self.pow2_scale(w0)
+            if w0.shape[0] != 64:
+                raise ValueError("pack_coupling_head: unsupported shape %s" % (tuple(w0.shape),))
         n = self.lib.bfsr_coupling_head_packed_size(Cz)
-        if n <= 0 or w0.shape[0] != 64:
-            raise ValueError("pack_coupling_head: unsupported shape %s" % (tuple(w0.shape),))
-        s0, s2 = self.pow2_scale(w0), self.pow2_scale(w2)
+        if n <= 0:
+            raise ValueError("pack_coupling_head: unsupported z1 width %d" % Cz)
+        s2 = self.pow2_scale(w2)
         packed = torch.empty(n, dtype=torch.int16)
-        _lib.check(self.lib.bfsr_pack_coupling_head(w0.data_ptr(), w2.data_ptr(), Cz, s0, s2, packed.data_ptr()), "pack_coupling_head")
+        _lib.check(self.lib.bfsr_pack_coupling_head(w0.data_ptr() if w0 is not None else None, w2.data_ptr(), Cz, s0, s2, packed.data_ptr()), "pack_coupling_head")
 
         def epi(shift, scale):
             e = torch.zeros(64, 4, dtype=torch.float32)
@@ -672,14 +677,16 @@ class HipOps(object):
         chained in registers.  pre_fmt=1: pre_aff is handed over quad-major ([B][16][H][W][4] in the same buffer)."""
         wts, e0, e2, Cz, as0, as2 = packed
         a = _lib.BfsrCouplingHeadArgs()
-        a.z, a.z_bs, Cc, H, W = _view(z, "coupling_head.z")
-        a.pre_aff, a.pre_aff_bs, c1, h1, w1 = _view(pre_aff, "coupling_head.pre_aff")
+        a.pre_aff, a.pre_aff_bs, c1, H, W = _view(pre_aff, "coupling_head.pre_aff")
+        if Cz:
+            a.z, a.z_bs, Cc, h0, w0_ = _view(z, "coupling_head.z")
+            assert Cc >= Cz and (h0, w0_) == (H, W)
         a.hid, a.hid_bs, c2, h2, w2 = self._h2view(hid, "coupling_head.hid")
-        assert Cc >= Cz and (c1, h1, w1) == (64, H, W) and (c2, h2, w2) == (64, H, W)
+        assert c1 == 64 and (c2, h2, w2) == (64, H, W)
         a.Cz, a.w, a.epi0, a.epi2 = Cz, wts.data_ptr(), e0.data_ptr(), e2.data_ptr()
         a.acc_scale0, a.acc_scale2, a.pre_fmt = as0, as2, int(pre_fmt)
-        a.B, a.H, a.W, a.flag = z.shape[0], H, W, self.range_flag.data_ptr()
-        key = ("coupling_head", Cz, z.shape[0], H, W)
+        a.B, a.H, a.W, a.flag = pre_aff.shape[0], H, W, self.range_flag.data_ptr()
+        key = ("coupling_head", Cz, pre_aff.shape[0], H, W)
         _lib.check(self._launch(key, lambda: self.lib.bfsr_coupling_head(C.byref(a), self._stream())), "coupling_head")
         return hid
 
@@ -713,6 +720,22 @@ class HipOps(object):
         key = ("coupling_tail", int(bool(reverse)), Cc, z_in.shape[0], H, W)
         _lib.check(self._launch(key, lambda: self.lib.bfsr_coupling_tail(C.byref(a), self._stream())), "coupling_tail(C=%d)" % Cc)
         return z_out
+
+    def conv_h2r(self, x, packed, out, epi=None, act=ACT_NONE, slope=0.2, y_fmt=0):
+        """3x3 conv 64 -> Cout <= 32 over the h2 tensor `x` on the coupling tail's conv kernel (coupling_tail.hip, plain epilogue);
+        `packed` = pack_coupling_tail(w, ...) (only its weights and scale are used here); out fp32 NCHW or, y_fmt=1, quad-major."""
+        wts, _b, _ps, Cout, acc_scale = packed
+        a = _lib.BfsrConvX3Args()
+        a.x, a.x_bs, Cin, H, W = self._h2view(x, "conv_h2r.x")
+        a.y, a.y_bs, co, H2, W2 = _view(out, "conv_h2r.out")
+        if (Cin, co, H, W) != (64, Cout, H2, W2) or x.shape[0] != out.shape[0]:
+            raise ValueError("conv_h2r: shape mismatch x%s out%s Cout=%d" % (tuple(x.shape), tuple(out.shape), Cout))
+        a.Cin, a.Cout, a.w, a.acc_scale = 64, Cout, wts.data_ptr(), acc_scale
+        a.B, a.H, a.W, a.y_fmt = out.shape[0], H, W, 2 if y_fmt else 0
+        a.epi, a.act, a.slope = _ptr(epi), act, slope
+        key = ("conv_h2r", 64, Cout, out.shape[0], H, W, a.y_fmt)
+        _lib.check(self._launch(key, lambda: self.lib.bfsr_conv3x3_h2r(C.byref(a), self._stream())), "conv3x3_h2r")
+        return out
 
     # ---- range guard of the fp16 split ------------------------------------------------------------------------------------------
     def check_range(self):

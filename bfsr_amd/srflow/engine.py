@@ -298,6 +298,16 @@ class SRFlowEngine(object):
                                     aff_scale=torch.exp(sd[f + "2.actnorm.logs"]))
                     st.ft4 = _ConvP(ops, sd[f + "4.weight"], bias=sd[f + "4.bias"],
                                     post_scale=torch.exp(sd[f + "4.logs"] * 3))
+                    # fused levels: the rest of the hoisted fFeatures net on the coupling pair's kernels -- fFeatures.0's ActNorm + ReLU and
+                    # fFeatures.2 on the 1x1-only form of coupling_head (h2 output), fFeatures.4 (Conv2dZeros 64 -> 2C) on the tail's conv
+                    # kernel in groups of <= 32 output channels (bfsr_conv3x3_h2r)
+                    st.fthead = st.ft4r = None
+                    if st.fused and hasattr(ops, "conv_h2r") and (2 * C) % 24 == 0:
+                        st.fthead = ops.pack_coupling_head(None, sd[f + "2.weight"], st.ft0_shift, st.ft0_scale, sd[f + "2.actnorm.bias"],
+                                                           torch.exp(sd[f + "2.actnorm.logs"]))
+                        w4, b4, p4 = sd[f + "4.weight"], sd[f + "4.bias"].reshape(-1), torch.exp(sd[f + "4.logs"] * 3).reshape(-1)
+                        st.ft4r = [(ops.pack_coupling_tail(w4[g:g + 24].contiguous(), b4[g:g + 24], p4[g:g + 24]),
+                                    ops.pack_epilogue(24, bias=b4[g:g + 24], post_scale=p4[g:g + 24]), g, g + 24) for g in range(0, 2 * C, 24)]
                 self.steps[ly.index] = st
             elif ly.type == "split":
                 self.splits[ly.index] = _ConvP(ops, sd[p + "conv.weight"], bias=sd[p + "conv.bias"],
@@ -321,6 +331,7 @@ class SRFlowEngine(object):
                 return (pv is not None and pv.type == "step" and pv.coupled and pv.level == level
                         and getattr(self.steps[pv.index], "fused", False))
             hz["hft_q4"] = set(i for i in idxs if getattr(self.steps[i], "fused", False) and _prev_is_fused_step(i))
+            hz["ffast"] = fused_all and all(self.steps[i].fthead is not None for i in idxs) and self._taps_up2(level) in (0, 1)
             hz["pre_q4"] = fused_all and (self._taps_up2(level) in (0, 1, False, None)) and getattr(ops, "conv_mode", "f32") == "x3"
             # Round 3: the 64 -> 16*64 key convs of the finer levels run on conv_x3s (LDS-DMA staging by loader waves, persistent) over
             # an x3 copy of the key channels instead of the register-staged conv_bf16x3 kernel: 5.51 -> 4.80 ms at 8 x 320^2
@@ -349,6 +360,8 @@ class SRFlowEngine(object):
             else:
                 hz["x3s"] = False
                 hz.update(ft0=_ConvP(ops, wf, aff_shift=sh, aff_scale=sc, mtile=2), aff0=_ConvP(ops, wa, mtile=2))
+                if hz["ffast"]:
+                    hz["ft0_raw"] = _ConvP(ops, wf, mtile=2)
             if hz["up2"] and not (hz.get("x3") and hz["up"] in (1, 2)):
                 hz["x3s"] = False
             self.hoist[level] = hz
@@ -503,16 +516,21 @@ class SRFlowEngine(object):
         pq = int(quads and hz.get("pre_q4", False))
         hq = {i: int(quads and i in hz.get("hft_q4", ())) for i in hz["idxs"]}
         kq = dict(y_fmt=1) if pq else {}
+        ff = bool(hz.get("ffast")) and hz.get("x3", True) is not False
         if hz["up2"]:
             taps = ft[self._lr_level()][:, 64:]
             if hz["x3"]:
                 up = ops.conv_up4_x3 if hz["up"] == 2 else ops.conv_up2_x3
+                fq = dict(y_fmt=1) if ff else {}                       # ffast: raw conv result, quad-major (the 1x1-only head applies ActNorm + ReLU)
                 if hz["x3s"]:
                     f3 = ops.x3_pack(f, self._ftx3[level][1])
-                    ops.conv_x3s(f3, hz["ft0_key"], hid)
+                    ops.conv_x3s(f3, hz["ft0_key"], hid, **fq)
                 else:
-                    ops.conv_x3(f, hz["ft0_key"], hid)
-                up(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, pre_add=hid)
+                    ops.conv_x3(f, hz["ft0_key"], hid, **fq)
+                if ff:
+                    up(taps, hz["ft0_taps"], hid, pre_add=hid, y_fmt=1)
+                else:
+                    up(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, pre_add=hid)
                 if hz["x3s"]:
                     ops.conv_x3s(f3, hz["aff0_key"], pre_aff, **kq)
                 else:
@@ -522,11 +540,23 @@ class SRFlowEngine(object):
                 ops.conv_up2(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, key=(f, hz["ft0_key"]))
                 ops.conv_up2(taps, hz["aff0_taps"], pre_aff, key=(f, hz["aff0_key"]))
         else:
-            hz["ft0"].run(ops, f, hid, act=ACT_RELU)
+            if ff:
+                hz["ft0_raw"].run(ops, f, hid, y_fmt=1)
+            else:
+                hz["ft0"].run(ops, f, hid, act=ACT_RELU)
             hz["aff0"].run(ops, f, pre_aff, **kq)
         for k, i in enumerate(hz["idxs"]):
             st = self.steps[i]
             hk = hid[:, 64 * k: 64 * (k + 1)]
+            if ff:
+                key = "ffh%d" % level
+                h2 = self._hid.get(key)
+                if h2 is None or tuple(h2.shape) != (B, 8, 2, hk.shape[2], hk.shape[3], 8):
+                    h2 = self._hid[key] = ops.h2_empty(B, 64, hk.shape[2], hk.shape[3])
+                ops.coupling_head(None, st.fthead, hk, h2, pre_fmt=1)
+                for pk, epi, g0, g1 in st.ft4r:
+                    ops.conv_h2r(h2, pk, h_ft[:, 2 * Cz * k + g0: 2 * Cz * k + g1], epi=epi, y_fmt=hq[i])
+                continue
             st.ft2.run(ops, hk, hk, act=ACT_RELU)            # 1x1, in place (disjoint pixel tiles)
             st.ft4.run(ops, hk, h_ft[:, 2 * Cz * k: 2 * Cz * (k + 1)], **(dict(y_fmt=1) if hq[i] else {}))
         return dict(pre_aff=pre_aff, h_ft=h_ft, slot={i: k for k, i in enumerate(hz["idxs"])}, C=Cz, pre_fmt=pq, h_ft_fmt=hq)

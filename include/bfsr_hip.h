@@ -266,6 +266,12 @@ long long bfsr_coupling_head_packed_size(int Cz);                               
 int bfsr_pack_coupling_head(const float* w0_z1, const float* w2, int Cz, float scale0, float scale2, unsigned short* packed);
 long long bfsr_coupling_tail_packed_size(int Cin, int Cout);                        /* fp16 elements; Cin = 64, Cout <= 32 */
 int bfsr_pack_coupling_tail(const float* w4, int Cin, int Cout, float scale, unsigned short* packed);   /* w4 [Cout][64][3][3] * scale, fp16 hi/lo */
+/* bfsr_conv3x3_h2r: the tail's conv kernel (one-octet chunks, four-stage LDS-DMA ring, resident weights) as a plain 3x3 'same' conv
+ * 64 -> Cout <= 32 over an h2 tensor -- the Conv2dZeros of the hoisted fFeatures nets (flow.py:68-83, FlowAffineCouplingsAblation.py:127-135).
+ * a->x h2 view (Cin = 64), a->w = bfsr_pack_coupling_tail(w, 64, Cout, scale), a->acc_scale = 1/scale, a->y fp32 [B,Cout,H,W] (y_fmt 0) or
+ * quad-major [B][Cout/4][H][W][4] (y_fmt 2); a->epi / act / slope as for bfsr_conv2d; no residuals.
+ * bfsr_coupling_head with Cz = 0 (w0 = NULL at pack time, z = NULL) is the matching producer: hid = relu(AN2(W2 . relu(AN0(pre_aff)))). */
+int bfsr_conv3x3_h2r(const BfsrConvX3Args* a, void* stream);
 
 /* squeeze2d / unsqueeze2d, factor 2 (flow.py:122-152): x [B,C,H,W] <-> y [B,4C,H/2,W/2] */
 int bfsr_squeeze2d(const float* x, long long x_bs, float* y, long long y_bs, int B, int C, int H, int W,

@@ -350,7 +350,7 @@ class CpuOps(object):
 
     def pack_coupling_head(self, w0_z1, w2, shift0, scale0, shift2, scale2):
         f = lambda t: t.detach().to(torch.float32).clone()
-        return (f(w0_z1), f(w2).reshape(64, 64, 1, 1), f(shift0).reshape(-1), f(scale0).reshape(-1), f(shift2).reshape(-1),
+        return (None if w0_z1 is None else f(w0_z1), f(w2).reshape(64, 64, 1, 1), f(shift0).reshape(-1), f(scale0).reshape(-1), f(shift2).reshape(-1),
                 f(scale2).reshape(-1))
 
     @staticmethod
@@ -366,7 +366,10 @@ class CpuOps(object):
         w0, w2, s0, c0, s2, c2 = packed
         if pre_fmt:
             pre_aff = self.quads(pre_aff, inverse=True)
-        t = F.relu((F.conv2d(z[:, :w0.shape[1]], w0, None, 1, 1) + pre_aff + _cv(s0)) * _cv(c0))
+        if w0 is None:                           # the 1x1-only form (hoisted fFeatures nets)
+            t = F.relu((pre_aff + _cv(s0)) * _cv(c0))
+        else:
+            t = F.relu((F.conv2d(z[:, :w0.shape[1]], w0, None, 1, 1) + pre_aff + _cv(s0)) * _cv(c0))
         v = F.relu((F.conv2d(t, w2) + _cv(s2)) * _cv(c2))
         if hid.dtype == torch.float16:
             self.h2_pack(v, hid)
@@ -386,6 +389,10 @@ class CpuOps(object):
             h_ft = self.quads(h_ft, inverse=True)
         h_aff = (F.conv2d(hid, w4, None, 1, 1) + _cv(b4)) * _cv(ps)
         return self.flow_pointwise(z_in, z_out, reverse, h_aff=h_aff, h_ft=h_ft, w=w, an_bias=an_bias, an_escale=an_escale, eps=eps)
+
+    def conv_h2r(self, x, packed, out, epi=None, act=0, slope=0.2, y_fmt=0):
+        w4 = packed[0]
+        return self.conv(sum(self._h2_planes(x)), PackedConv(w4, 1), out, epi=epi, act=act, slope=slope, y_fmt=y_fmt)
 
     def check_range(self):
         pass

@@ -453,6 +453,45 @@ def test_coupling_tail(hip, C, reverse, hw):
     hip.check_range()
 
 
+@pytest.mark.parametrize("hw", [(16, 40), (9, 33), (70, 70)])
+@pytest.mark.parametrize("pre_fmt", [0, 1])
+def test_coupling_head_without_3x3_stage(hip, hw, pre_fmt):
+    """The 1x1-only form of coupling_head (Cz = 0): hid = relu(AN2(W2 . relu(AN0(pre)))) -- fFeatures.0's ActNorm + ReLU on the hoisted conv
+    result, then fFeatures.2 (FlowAffineCouplingsAblation.py:127-135), h2 output."""
+    H, W = hw
+    B = 2
+    pre = rnd(62, B, 64, H, W, scale=0.8)
+    w2 = rnd(64, 64, 64, 1, 1, scale=0.1)
+    s0, c0, s2, c2 = rnd(65, 64, scale=0.1), torch.exp(rnd(66, 64, scale=0.1)), rnd(67, 64, scale=0.1), torch.exp(rnd(68, 64, scale=0.1))
+    ref = CPU.coupling_head(None, CPU.pack_coupling_head(None, w2, s0, c0, s2, c2), pre, torch.empty(B, 64, H, W))
+    pd = hip.to_device(CPU.quads(pre).contiguous() if pre_fmt else pre)
+    out = hip.coupling_head(None, hip.pack_coupling_head(None, w2, s0, c0, s2, c2), pd, hip.h2_empty(B, 64, H, W), pre_fmt=pre_fmt)
+    close(_h2_values(out), ref, 2e-5, "coupling_head Cz=0")
+
+
+@pytest.mark.parametrize("Cout", [12, 24, 32])
+@pytest.mark.parametrize("hw", [(16, 40), (9, 33), (70, 70), (5, 3)])
+def test_conv_h2r(hip, Cout, hw):
+    """bfsr_conv3x3_h2r (the coupling tail's conv kernel with a plain epilogue): 3x3 conv 64 -> Cout <= 32 over an h2 tensor with bias, post-scale
+    and activation, fp32 NCHW and quad-major output (bit-identical values), channel-slice output views."""
+    H, W = hw
+    B = 3
+    x = rnd(71, B, 64, H, W)
+    w, b, ps = rnd(73, Cout, 64, 3, 3, scale=0.03), rnd(74, Cout, scale=0.2), torch.exp(rnd(75, Cout, scale=0.2))
+    xh = CPU.h2_pack(x, CPU.h2_empty(B, 64, H, W))
+    x22 = sum(CPU._h2_planes(xh))
+    ref = CPU.conv(x22, CPU.pack_conv(w, 1), torch.empty(B, Cout, H, W), bias=b, post_scale=ps, act=2, slope=0.2)
+    pk, epi = hip.pack_coupling_tail(w, b, ps), hip.pack_epilogue(Cout, bias=b, post_scale=ps)
+    wide = hip.zeros(B, Cout + 8, H, W)
+    out = hip.conv_h2r(xh.to(hip.device), pk, wide[:, 4:4 + Cout], epi=epi, act=2, slope=0.2)
+    close(out, ref, 2e-5, "conv_h2r Cout=%d" % Cout)
+    assert float(wide[:, :4].abs().max()) == 0.0 and float(wide[:, 4 + Cout:].abs().max()) == 0.0, "wrote outside its channel slice"
+    wq = hip.zeros(B, Cout + 8, H, W)
+    hip.conv_h2r(xh.to(hip.device), pk, wq[:, 4:4 + Cout], epi=epi, act=2, slope=0.2, y_fmt=1)
+    assert torch.equal(CPU.quads(wq[:, 4:4 + Cout].cpu().contiguous(), inverse=True), out.cpu()), "conv_h2r y_fmt=1"
+    assert float(wq[:, :4].abs().max()) == 0.0 and float(wq[:, 4 + Cout:].abs().max()) == 0.0
+
+
 def test_coupling_pair_on_channel_slices_and_views(hip):
     """head -> tail with z / pre_aff / h_ft as channel slices of wider buffers, out of place into a slice (the engine runs in place)."""
     B, C, H, W = 2, 12, 20, 44

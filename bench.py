@@ -52,7 +52,7 @@ FAMILIES = {
     "conv_f16x2": ("conv_bf16x3_kernel<PL=2>", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split (22-bit operands, power-of-two weight scale), 3 products on v_mfma_f32_32x32x16_f16"),
     "conv_h2x": ("conv3x3_h2x_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split, 3 products on v_mfma_f32_32x32x16_f16, h2-tensor input by LDS-DMA"),
     "conv_up2_f2": ("conv_up2_bf16x3_kernel<PL=2>", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split, parity-decomposed conv over nearest-x2 input"),
-    "conv_up2_h2x": ("conv_up2_h2x_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split, parity-decomposed conv over nearest-x2 input, h2 taps by LDS-DMA"),
+    "conv_h2r": ("coupling_tail_kernel<plain conv>", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split, 3x3 conv 64 -> <=32 channels over an h2 tensor on the coupling tail's ring kernel"),
     "conv_up4_f2": ("conv_up4_bf16x3_kernel<PL=2>", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split, phase-decomposed conv over nearest-x4 input"),
     "conv_f16": ("conv_f16_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, "fp16 MFMA (v_mfma_f32_32x32x16_f16), fp32 accumulate"),
     "conv_h2s": ("conv3x3_h2s_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, "fp16 MFMA, fp16-stored (h2) input by LDS-DMA, fp32 accumulate"),
@@ -93,7 +93,7 @@ def launch_flop(k):
     if f == "conv+1x1":
         _, Cin, Cout, b_, hh, ww = k
         return 2.0 * (Cin * 9 + 64) * Cout * b_ * hh * ww
-    if f in ("conv_x3s", "conv_h2s", "conv_h2x"):
+    if f in ("conv_x3s", "conv_h2s", "conv_h2x", "conv_h2r"):
         _, Cin, Cout, b_, hh, ww, _fmt = k
         return 2.0 * Cin * 9 * Cout * b_ * hh * ww
     if f in ("linf_mlp_x3", "linf_mlp_f16", "linf_mlp_f2"):           # layer 1 (4 neighbours x 256 features) + two hidden layers + output layer
@@ -102,7 +102,7 @@ def launch_flop(k):
     if f in ("conv1x1_f16", "conv1x1_x3"):
         _, Cin, Cout, b_, hh, ww = k
         return 2.0 * Cin * Cout * b_ * hh * ww
-    if f in ("conv_up2", "conv_up2_x3", "conv_up2_f2", "conv_up2_h2x"):               # 2x2 source taps per output pixel (parity pre-summed weights)
+    if f in ("conv_up2", "conv_up2_x3", "conv_up2_f2"):               # 2x2 source taps per output pixel (parity pre-summed weights)
         _, _, Cin, Cout, b_, hh, ww, cin2 = k          # + cin2 key channels at output resolution (9 taps)
         return 2.0 * (Cin * 4 + cin2 * 9) * Cout * b_ * hh * ww
     if f in ("conv_up4_x3", "conv_up4_f2"):                             # 25 pre-summed matrices per 16 output pixels

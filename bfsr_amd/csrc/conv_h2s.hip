@@ -615,28 +615,29 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
         asm volatile("" : "+v"(lh), "+v"(lx));
 #endif
         const int gx = cur.x0 + lx;
-        int goff[2][2];
+        // every global access of the epilogue is a buffer instruction whose VGPR offset is out of range for pixels outside the image (and
+        // whose descriptor ends at Cout channels): no `if (inside)` branch per access -- hipcc turned those into ~60 exec-masked blocks per
+        // item with 64-bit address arithmetic each, and all eight compute waves sit in this epilogue at once
+        const int oct0 = (cur.cg * XM + m) * 4;                          // first of this item's four channel octets (+ q*2 + lh)
+        unsigned vo16[2], vo4[2];                                        // per row j: byte offset of (half-wave octet lh, pixel) in 16-byte / 4-byte units
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int oct = (cur.cg * XM + m) * 4 + q * 2 + lh;
-                const int gy = cur.y0 + 2 * wave + j;
-                goff[j][q] = (gy < H && gx < W && oct * 8 < p.Cout) ? (int)(((long long)oct * 2 * HW + (long long)gy * W + gx) * 8) : -1;
-            }
+        for (int j = 0; j < 2; ++j) {
+            const int gy = cur.y0 + 2 * wave + j;
+            const bool ok = gy < H && gx < W;
+            vo16[j] = ok ? (unsigned)(((long long)lh * 2 * HW + (long long)gy * W + gx) * 16) : OOB;
+            vo4[j] = ok ? (unsigned)(((long long)lh * 8 * HW + (long long)gy * W + gx) * 4) : OOB;
+        }
+        const unsigned h2_bytes = (unsigned)((long long)(p.Cout >> 3) * 2 * HW * 16);
         half8 rh[2][2], rl[2][2];
         auto load_res = [&](const unsigned short* res, long long bs) {
-            const unsigned short* rb = res + (long long)cur.b * bs;
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(res + (long long)cur.b * bs), 0, h2_bytes, 0x00020000);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) { rh[j][q][i] = (_Float16)0.f; rl[j][q][i] = (_Float16)0.f; }
-                    if (goff[j][q] >= 0) {
-                        rh[j][q] = *reinterpret_cast<const half8*>(rb + goff[j][q]);
-                        rl[j][q] = *reinterpret_cast<const half8*>(rb + goff[j][q] + HW * 8);
-                    }
+                    const unsigned so = (unsigned)((oct0 + q * 2) * 2) * (unsigned)(HW * 16);
+                    rh[j][q] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rr, vo16[j], so, 0));
+                    rl[j][q] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rr, vo16[j], so + (unsigned)(HW * 16), 0));
                 }
         };
         if (p.res1) load_res(p.res1, p.res1_bs);                         // lands under the swaps / parameter exchange / activation
@@ -699,33 +700,42 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
 #pragma unroll
                     for (int i = 0; i < 8; ++i) o[j][q][i] = p.alpha2 * o[j][q][i] + ((float)rh[j][q][i] + (float)rl[j][q][i]);
         }
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        if (p.y_fmt == 1) {
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned short*>(p.y) + (long long)cur.b * p.y_bs, 0, h2_bytes, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int g = goff[j][q];
-                if (g < 0) continue;
-                if (p.y_fmt == 1) {
+                for (int q = 0; q < 2; ++q) {
                     half8 h8, l8;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) { _Float16 h, l; split2(o[j][q][i], h, l); h8[i] = h; l8[i] = l; xamax = fmaxf(xamax, fabsf(o[j][q][i])); }
-                    unsigned short* yb = reinterpret_cast<unsigned short*>(p.y) + (long long)cur.b * p.y_bs + g;
-                    *reinterpret_cast<half8*>(yb) = h8;
-                    *reinterpret_cast<half8*>(yb + HW * 8) = l8;
-                } else if (p.y_fmt == 2) {                              // fp32 quad-major [Cout/4][H][W][4]: the octet = two 16-byte stores
-                    const int oct = (cur.cg * XM + m) * 4 + q * 2 + lh;
-                    float* yb = reinterpret_cast<float*>(p.y) + (long long)cur.b * p.y_bs + ((long long)(cur.y0 + 2 * wave + j) * W + gx) * 4;
-                    *reinterpret_cast<float4*>(yb + (long long)(oct * 2) * HW * 4) = make_float4(o[j][q][0], o[j][q][1], o[j][q][2], o[j][q][3]);
-                    *reinterpret_cast<float4*>(yb + (long long)(oct * 2 + 1) * HW * 4) = make_float4(o[j][q][4], o[j][q][5], o[j][q][6], o[j][q][7]);
-                } else {
-                    const int oct = (cur.cg * XM + m) * 4 + q * 2 + lh;
-                    float* yb = reinterpret_cast<float*>(p.y) + (long long)cur.b * p.y_bs + (long long)(cur.y0 + 2 * wave + j) * W + gx;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        if (oct * 8 + i < p.Cout) yb[(long long)(oct * 8 + i) * HW] = o[j][q][i];
+                    const unsigned so = (unsigned)((oct0 + q * 2) * 2) * (unsigned)(HW * 16);
+                    bfsr::store_b128(ry, __builtin_bit_cast(u32x4_, h8), vo16[j], so);
+                    bfsr::store_b128(ry, __builtin_bit_cast(u32x4_, l8), vo16[j], so + (unsigned)(HW * 16));
                 }
-                __builtin_amdgcn_sched_barrier(0);
+        } else {
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(p.y) + (long long)cur.b * p.y_bs, 0,
+                                                                                (unsigned)((long long)p.Cout * HW * 4), 0x00020000);
+            if (p.y_fmt == 2) {                                          // fp32 quad-major [Cout/4][H][W][4]: the octet = two 16-byte stores
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const unsigned so = (unsigned)((oct0 + q * 2) * 2) * (unsigned)(HW * 16);
+                        bfsr::store_b128(ry, __builtin_bit_cast(u32x4_, make_float4(o[j][q][0], o[j][q][1], o[j][q][2], o[j][q][3])), vo16[j], so);
+                        bfsr::store_b128(ry, __builtin_bit_cast(u32x4_, make_float4(o[j][q][4], o[j][q][5], o[j][q][6], o[j][q][7])), vo16[j], so + (unsigned)(HW * 16));
+                    }
+            } else {                                                     // fp32 NCHW: channels >= Cout fall beyond the descriptor
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o[j][q][i]), ry, vo4[j], (unsigned)(((oct0 + q * 2) * 8 + i) * HW * 4), 0);
             }
+        }
         }
     }
     if (p.flag && __any((int)!(xamax < 65504.f))) { if (lane == 0) atomicOr(p.flag, 1u); }

@@ -307,8 +307,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void coupling_head_kernel(BfsrCoupling
                         bad |= (unsigned)!(o[i] < 32768.f);
                     }
                     const unsigned so = (unsigned)((m * 4 + qd * 2) * 2) * (unsigned)(HW * 16);      // octet m*4 + qd*2 (+ lhi through the VGPR offset)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h8), rs, vo, so, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, l8), rs, vo, so + (unsigned)(HW * 16), 0);
+                    bfsr::store_b128(rs, __builtin_bit_cast(u32x4, h8), vo, so);
+                    bfsr::store_b128(rs, __builtin_bit_cast(u32x4, l8), vo, so + (unsigned)(HW * 16));
                 }
             }
         }

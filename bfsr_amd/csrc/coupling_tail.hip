@@ -335,8 +335,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void coupling_tail_kernel(BfsrC
                     }
                     if (q.h_ft_fmt == 1) {
                         const unsigned vo = ok ? (unsigned)(((long long)lhi * HW + (long long)gy * W + gx) * 16) : OOB;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, make_float4(o[0], o[1], o[2], o[3])), ry, vo,
-                                                               (unsigned)(2 * g * HW * 16), 0);
+                        bfsr::store_b128(ry, __builtin_bit_cast(bfsr::store_u32x4, make_float4(o[0], o[1], o[2], o[3])), vo, (unsigned)(2 * g * HW * 16));
                     } else {
                         const unsigned vo = ok ? (unsigned)(((long long)gy * W + gx + 4LL * lhi * HW) * 4) : OOB;
 #pragma unroll

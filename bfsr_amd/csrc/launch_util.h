@@ -48,4 +48,16 @@ __device__ __forceinline__ unsigned xcd_order(unsigned bid, unsigned nblk)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
+// 16-byte buffer store with a wave-uniform byte offset on top of the per-lane one.  The uniform part is ADDED INTO THE VGPR OFFSET and
+// the instruction's soffset stays the literal 0 on purpose.  Measured on gfx950 (round 4, tools/exp/h2x_twice.py):
+// `buffer_store_dwordx4 v[14:17], v96, s[20:23], s5 offen` followed directly by `v_cvt_f32_f16 v16, v7` stored the NEW v16 in lanes
+// 12-15 / 28-31 / 44-47 / 60-63 of one launch in ~10 -- the ">64-bit store data" hazard of the GFX9 manual, which the manual (and LLVM's
+// hazard recognizer, GCNHazardRecognizer::createsVALUHazard) exempt when soffset is an SGPR.  With a non-register soffset hipcc pads the
+// following VALU write itself.
+typedef unsigned store_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_b128(__amdgpu_buffer_rsrc_t rs, store_u32x4 data, unsigned lane_off, unsigned uniform_off)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(data, rs, lane_off + uniform_off, 0, 0);
+}
+
 }  // namespace bfsr

@@ -68,6 +68,12 @@ def main():
             y3 = ops.x3_empty(B, Cout, hw, hw)
             total += stress("%s %d->%d @%dx%d" % (name, Cin, Cout, hw, hw), lambda: ops.conv_x3s(x3, pw, y3, epi=epi, act=ACT_LRELU))
     ops.split = default_split
+    # --- the quad-major fp32 outputs (16-byte buffer stores: the store-data hazard of launch_util.h's store_b128) and the Cout <= 32 ring kernel
+    xh = ops.h2_pack(torch.randn(B, 64, hw, hw, device="cuda"), ops.h2_empty(B, 64, hw, hw))
+    pw, epi, yq = ops.pack_conv_x3(r(64, 64, 3, 3, scale=0.05), 1), ops.pack_epilogue(64, bias=r(64, scale=0.1)), ops.empty(B, 64, hw, hw)
+    total += stress("conv_h2x 64->64 quad-major fp32 out @%dx%d" % (hw, hw), lambda: ops.conv_h2x(xh, pw, yq, epi=epi, y_fmt=1))
+    pr, er, yr = ops.pack_coupling_tail(r(24, 64, 3, 3, scale=0.05), r(24, scale=0.1), torch.ones(24)), ops.pack_epilogue(24, bias=r(24, scale=0.1)), ops.empty(B, 24, hw, hw)
+    total += stress("conv_h2r 64->24 quad-major fp32 out @%dx%d" % (hw, hw), lambda: ops.conv_h2r(xh, pr, yr, epi=er, y_fmt=1))
     # --- fp16 dense-block convs on h2 tensors (conv_h2s)
     for Cin, Cout in ((64, 32), (192, 64)):
         xh = ops.h2_pack(torch.randn(B, Cin, 128, 128, device="cuda"), ops.h2_empty(B, Cin, 128, 128))

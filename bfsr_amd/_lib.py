@@ -44,6 +44,16 @@ class BfsrConvX3Args(C.Structure):
     ]
 
 
+class BfsrUp2H2Args(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("x_bs", C.c_longlong), ("Cin", C.c_int),
+        ("w", C.c_void_p), ("acc_scale", C.c_float),
+        ("y", C.c_void_p), ("y_bs", C.c_longlong), ("Cout", C.c_int), ("y_fmt", C.c_int),
+        ("pre_add", C.c_void_p), ("pre_add_bs", C.c_longlong),
+        ("B", C.c_int), ("h", C.c_int), ("w_", C.c_int),
+    ]
+
+
 class BfsrFlowArgs(C.Structure):
     _fields_ = [
         ("z_in", C.c_void_p), ("z_in_bs", C.c_longlong),
@@ -165,6 +175,9 @@ SYMBOLS = {
     "bfsr_coupling_tail_packed_size": (_LL, [_I, _I]),
     "bfsr_pack_coupling_tail": (_I, [_VP, _I, _I, C.c_float, _VP]),
     "bfsr_conv3x3_h2r": (_I, [C.POINTER(BfsrConvX3Args), _VP]),
+    "bfsr_conv2d_up2_h2t": (_I, [C.POINTER(BfsrUp2H2Args), _VP]),
+    "bfsr_conv_up2_h2t_packed_size": (_LL, [_I, _I]),
+    "bfsr_pack_conv_up2_h2t": (_I, [_VP, _I, _I, C.c_float, _VP]),
     "bfsr_squeeze2d": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
     "bfsr_unsqueeze2d": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
     "bfsr_split2d": (_I, [_VP, _LL, _VP, _LL, _VP, _LL, _I, _I, _I, _I, _I, _VP]),

@@ -422,6 +422,9 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
 // 16-channel chunk (conv_x3s.hip's protocol: the four loader waves stage chunk k+1 -- across tile boundaries -- while chunk k is
 // in the matrix pipe; loader `ld` owns sub-image `ld` (plane, k half) of every position group and its share of the weight pieces).
 // Per chunk and wave: 42 ds_read_b128 for 54 MFMAs.  Persistent workgroups, XCD-aware order.  Epilogue = conv3x3_h2s_kernel's.
+#ifndef BFSR_H2X_ABL
+#define BFSR_H2X_ABL 0                          // ablation builds only (tools/exp/h2x_abl.sh): bit 0 no fragment reads, 1 no MFMAs, 2 no DMA, 3 no epilogue
+#endif
 constexpr int X_IN = 4 * SUB;                   // 40 960
 // XM = 32-cout M tiles per workgroup: 1, or 2 for the 64-channel convs (conv5 of a dense block, trunk convs): the input tile is staged
 // once for 64 output channels -- the kernel is bound by the L2 -> LDS fill (59 KB per chunk and 32 couts), so bytes per MFMA count
@@ -477,6 +480,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
             }
         };
         auto lstage = [&](int k, int buf) {
+            if (BFSR_H2X_ABL & 4) return;
             unsigned char* base = smem + buf * X_STAGE;
             const unsigned soff = (unsigned)((2 * k + (ld & 1)) * 2 + (ld >> 1)) * HW16;      // octet 2k + k half, plane ld>>1
 #pragma unroll
@@ -516,6 +520,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
     half8 bq[2][2][2], aq[2][2][XM];                                     // [buffer][plane][row] | [buffer][plane][m tile]
     auto load_step = [&](auto buf_, int st, int t) {
         constexpr int BUF = decltype(buf_)::value;
+        if (BFSR_H2X_ABL & 1) return;
         const int dx = t / 3, dy = t - 3 * dx;
         const unsigned char* sIn = smem + st * X_STAGE;
         const unsigned char* inB = sIn + (lhi * NPOSP + (2 * wave + dy) * PW + l31 + dx) * 16;
@@ -529,8 +534,31 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
         }
     };
     f32x16 acc[XM][2];
+    if (BFSR_H2X_ABL & 1) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) bq[b][pl][r][i] = (_Float16)(0.001f * (lane + i + r));
+#pragma unroll
+                for (int m = 0; m < XM; ++m)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) aq[b][pl][m][i] = (_Float16)(0.002f * (lane + i + m));
+            }
+    }
     auto mfma_step = [&](auto buf_) {
         constexpr int BUF = decltype(buf_)::value;
+        if (BFSR_H2X_ABL & 2) {                                          // keep the fragment reads alive: one VALU use per fragment
+#pragma unroll
+            for (int m = 0; m < XM; ++m)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[m][j][0] += (float)aq[BUF][0][m][0] + (float)aq[BUF][1][m][0] + (float)bq[BUF][0][j][0] + (float)bq[BUF][1][j][0];
+            return;
+        }
 #pragma unroll
         for (int m = 0; m < XM; ++m)
 #pragma unroll
@@ -603,6 +631,10 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
 
         // ---- epilogue (the loaders are already staging the next item): as in conv3x3_h2s_kernel, plus the weight scale; one M tile
         // at a time (64 results per lane and the residual operands of both tiles at once would spill)
+        if (BFSR_H2X_ABL & 8) {                                          // keep the accumulators alive
+            if (acc[0][0][0] + acc[0][1][5] == 1234.5f) reinterpret_cast<float*>(p.y)[lane] = acc[0][0][1];
+            continue;
+        }
 #pragma unroll
         for (int m = 0; m < XM; ++m) {
         const float4 pm = pmm[m];

@@ -1,0 +1,357 @@
+// conv_up2_h2t.hip -- 3x3 'same' conv over a NEAREST-x2-UPSAMPLED tensor, evaluated at the source resolution, at fp32-class accuracy on
+// the fp16 matrix pipe (two-term fp16 split, three products; conv_h2s.hip's arithmetic).  The hot instance: the 256 RRDB tap
+// channels (4 tapped blocks x 64, LR resolution) entering the first conv of every level-1 coupling's conditioning network through
+// F.interpolate(..., mode='nearest') + torch.cat (SRFlow-LP/code/models/modules/SRFlowNet_arch.py:122-137, RRDBNet_arch.py:105-109,
+// FlowAffineCouplingsAblation.py:127-135): 256 -> 16 steps x 64 channels at 2x the LR size, twice per pass (fAffine and fFeatures).
+//
+// Parity decomposition: output pixel (2y+py, 2x+px) sees, through its 3x3 window on the upsampled image, only the 2x2 source pixels
+// rows {y-1+py, y+py} x cols {x-1+px, x+px}; the weights of the window taps that fall on the same source pixel are summed at pack
+// time.  So one source pixel row of 32 pixels, one 16-channel chunk and 32 output channels are 16 (parity, tap) weight blocks x 3
+// products = 48 MFMAs instead of 4 x 9 x 3.
+//
+// Work decomposition (what the register-staged conv_up2_bf16x3_kernel lacked: it re-splits and re-stages the fp32 taps once per 32
+// output channels AND per output parity, and holds 4 accumulator blocks): the taps arrive as an h2 tensor (split once), a workgroup
+// item = source tile 16 x 32 x 32 output channels x ALL FOUR parities; wave w owns source rows 2w, 2w+1 = 8 accumulator blocks
+// (128 registers, 2 waves per SIMD), reads per 16-channel chunk the 4 rows x 3 column shifts x 2 planes it needs ONCE (24 fragments)
+// plus the 32 weight fragments, for 96 MFMAs: 0.58 LDS reads per MFMA (conv3x3_h2x_kernel: 0.78).  No loader waves -- with them the
+// workgroup would be 12 waves and the register budget 168: every wave issues its share (9 of 72 one-KiB pieces) of the NEXT chunk by
+// LDS-DMA right behind the chunk barrier, a whole chunk of MFMAs (~3 us) before it is needed; the only vector-memory wait in the K loop is
+// `s_waitcnt vmcnt(0)` in front of that barrier (LDS-DMA and ordinary loads of one wave do not retire in issue order relative to each
+// other, conv_h2s.hip, so no counted waits).  Two LDS stages of 40 960 (input: [2 planes][2 k halves][640 positions][8]) + 32 768
+// (weights: [2 planes][16 steps][2 k halves][32][8]) bytes.  Persistent workgroups; item order = [8 tiles][4 cout groups] per XCD round.
+// Output: fp32 quad-major [B][Cout/4][2h][2w][4] (what the coupling pair and the fFeatures head read), y = acc/scale + pre_add: every
+// lane owns whole channel quads of its pixels in the MFMA result layout, so the epilogue is 16-byte loads and stores without a swap.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+#include "../../include/bfsr_hip.h"
+#include "launch_util.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+namespace {
+
+constexpr int NWV = 8;                          // waves per workgroup; all compute, all stage
+constexpr int TH = 16, PW = 34, NPOS = (TH + 2) * PW, NG = 10, NPOSP = NG * 64;
+constexpr int SUB = NPOSP * 16;                 // one (plane, k half) sub-image: 8 channels of every tile position
+constexpr int X_IN = 4 * SUB;                   // 40 960
+constexpr int NSTEP = 16;                       // (px, b, py, a) weight blocks per chunk
+constexpr int W_PL = NSTEP * 1024;              // one weight plane of a chunk
+constexpr int W_ST = 2 * W_PL;                  // 32 768
+constexpr int STAGE = X_IN + W_ST;              // 73 728
+constexpr int LDS_BYTES = 2 * STAGE;            // 147 456
+constexpr int NXP = X_IN / 1024 / NWV;          // input pieces per wave and chunk: 5
+constexpr int NWP = W_ST / 1024 / NWV;          // weight pieces per wave and chunk: 4
+constexpr unsigned OOB = 0x80000000u;
+
+struct Item { int cg, b, x0, y0; };
+
+#ifndef BFSR_H2T_ABL
+#define BFSR_H2T_ABL 0                          // ablation builds only (tools/exp): bit 0 no fragment reads, 1 no MFMAs, 2 no DMA, 3 no epilogue
+#endif
+
+__global__ __launch_bounds__(NWV * 64, 1) void conv_up2_h2t_kernel(BfsrUp2H2Args p, int tiles_x, int tiles_y, int groups, int nitems)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int G = gridDim.x;
+    const int slot = (int)bfsr::xcd_order(blockIdx.x, (unsigned)G);
+    if (slot >= nitems) return;
+    const int h = p.h, w = p.w_;
+    const unsigned HW16 = (unsigned)(h * w) * 16u;                       // bytes of one (octet, plane) image of the source
+    const int nchunk = p.Cin >> 4;
+    const int ntiles = p.B * tiles_y * tiles_x;
+
+    // items in rounds of [8 source tiles][cout groups]: the 32 workgroups of an XCD share 8 input tiles and 4 weight sets at a time
+    auto decode = [&](int it) {
+        Item r;
+        const int per = 8 * groups;
+        int tg = it / per;
+        const int tgl = (ntiles - 1) >> 3;
+        tg = tg < tgl ? tg : tgl;
+        const int rem = it - tg * per;
+        const int nt = ntiles - 8 * tg < 8 ? ntiles - 8 * tg : 8;
+        r.cg = rem / nt;
+        int t = tg * 8 + (rem - r.cg * nt);
+        r.x0 = (t % tiles_x) * 32; t /= tiles_x;
+        r.y0 = (t % tiles_y) * TH; r.b = t / tiles_y;
+        return r;
+    };
+
+    // ---- staging: wave w issues input pieces w, w+8, .. (piece i = sub-image i/10 (plane i/20, k half (i/10)&1), position group i%10)
+    // and weight pieces w, w+8, ..
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w), 0,
+                                                                          (unsigned)((long long)groups * nchunk * W_ST), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_in;
+    unsigned vg[NXP];
+    int ld_cg = 0;
+    auto lsetup = [&](const Item& it) {
+        const unsigned short* xb = p.x + (long long)it.b * p.x_bs;
+        rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xb), 0, (unsigned)(p.Cin >> 3) * 2u * HW16, 0x00020000);
+        ld_cg = it.cg;
+#pragma unroll
+        for (int i = 0; i < NXP; ++i) {
+            const int g = (wave + NWV * i) % NG;
+            const int pos = g * 64 + lane;
+            const int r = pos / PW, c = pos - r * PW;
+            const int gy = it.y0 + r - 1, gx = it.x0 + c - 1;
+            const bool ok = pos < NPOS && gy >= 0 && gy < h && gx >= 0 && gx < w;
+            vg[i] = ok ? (unsigned)(gy * w + gx) * 16u : OOB;            // out of range -> the DMA writes zeros (= the padding)
+        }
+    };
+    auto lstage = [&](int k, int stg) {
+        if (BFSR_H2T_ABL & 4) return;
+        unsigned char* base = smem + stg * STAGE;
+#pragma unroll
+        for (int i = 0; i < NXP; ++i) {
+            const int piece = wave + NWV * i;
+            const int si = piece / NG;                                   // sub-image: plane si>>1, k half si&1
+            const unsigned soff = (unsigned)((2 * k + (si & 1)) * 2 + (si >> 1)) * HW16;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(base + piece * 1024), 16, vg[i], soff, 0, 0);
+        }
+        const unsigned wsoff = (unsigned)(ld_cg * nchunk + k) * (unsigned)W_ST;
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) {
+            const int piece = wave + NWV * i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(base + X_IN + piece * 1024), 16, (unsigned)lane * 16u + (unsigned)piece * 1024u, wsoff, 0, 0);
+        }
+    };
+
+    // ---- fragments: xin[buffer][tile row 2w + r, r = 0..3][plane] for one column shift cs; wq[buffer][plane] for one weight step
+    half8 xin[2][4][2], wq[2][2];
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    auto load_x = [&](auto b_, int stg, int cs) {
+        constexpr int BUF = decltype(b_)::value;
+        if (BFSR_H2T_ABL & 1) return;
+        const unsigned char* base = smem + stg * STAGE + (lhi * NPOSP + (2 * wave) * PW + l31 + cs + 1) * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) xin[BUF][r][pl] = *reinterpret_cast<const half8*>(base + pl * 2 * SUB + r * PW * 16);
+    };
+    auto load_w = [&](auto b_, int stg, int s) {
+        constexpr int BUF = decltype(b_)::value;
+        if (BFSR_H2T_ABL & 1) return;
+        const unsigned char* base = smem + stg * STAGE + X_IN + s * 1024 + lane * 16;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) wq[BUF][pl] = *reinterpret_cast<const half8*>(base + pl * W_PL);
+    };
+    f32x16 acc[4][2];                                                    // [parity py*2 + px][row j]
+    if (BFSR_H2T_ABL & 1) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { xin[b][r][0][i] = (_Float16)(0.001f * (lane + i + r)); xin[b][r][1][i] = (_Float16)(0.0001f * (lane + i)); }
+                wq[b][0][i] = (_Float16)(0.002f * (lane + i)); wq[b][1][i] = (_Float16)(0.0002f * (lane + i));
+            }
+    }
+    // step s = (px*2 + b)*4 + py*2 + a: weights of source tap (a, b) for output parity (py, px); source row of output row j = j + py + a
+    auto mfma_step = [&](auto s_, auto xb_, auto wb_) {
+        constexpr int S = decltype(s_)::value, XB = decltype(xb_)::value, WB = decltype(wb_)::value;
+        constexpr int PX = S >> 3, PY = (S >> 1) & 1, A = S & 1, P4 = PY * 2 + PX;
+        if (BFSR_H2T_ABL & 2) return;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            // smallest terms first: w_lo*x_hi, w_hi*x_lo, w_hi*x_hi
+            acc[P4][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[WB][1], xin[XB][j + PY + A][0], acc[P4][j], 0, 0, 0);
+            acc[P4][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[WB][0], xin[XB][j + PY + A][1], acc[P4][j], 0, 0, 0);
+            acc[P4][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[WB][0], xin[XB][j + PY + A][0], acc[P4][j], 0, 0, 0);
+        }
+    };
+    // one chunk: column-shift groups cs = -1 (steps 0-3, buffer 0), 0 (steps 4-11, buffer 1), +1 (steps 12-15, buffer 0 again); the
+    // fragments of the next group / step are read while the current MFMAs run
+    auto chunk_body = [&](int stg) {
+        load_x(I0(), stg, -1);
+        load_w(I0(), stg, 0);
+#define STEP_(S_, XB_, PRE_)                                                                                      \
+        { PRE_;                                                                                                   \
+          if (S_ + 1 < NSTEP) load_w(std::integral_constant<int, (S_ + 1) & 1>(), stg, S_ + 1);                   \
+          __builtin_amdgcn_sched_barrier(0);                                                                      \
+          mfma_step(std::integral_constant<int, S_>(), std::integral_constant<int, XB_>(), std::integral_constant<int, S_ & 1>()); \
+          __builtin_amdgcn_sched_barrier(0); }
+        STEP_(0, 0, load_x(I1(), stg, 0))
+        STEP_(1, 0, (void)0)
+        STEP_(2, 0, (void)0)
+        STEP_(3, 0, (void)0)
+        STEP_(4, 1, load_x(I0(), stg, 1))
+        STEP_(5, 1, (void)0)
+        STEP_(6, 1, (void)0)
+        STEP_(7, 1, (void)0)
+        STEP_(8, 1, (void)0)
+        STEP_(9, 1, (void)0)
+        STEP_(10, 1, (void)0)
+        STEP_(11, 1, (void)0)
+        STEP_(12, 0, (void)0)
+        STEP_(13, 0, (void)0)
+        STEP_(14, 0, (void)0)
+        STEP_(15, 0, (void)0)
+#undef STEP_
+    };
+
+    const int H2 = 2 * h, W2 = 2 * w;
+    const unsigned Q16 = (unsigned)(H2 * W2) * 16u;                      // bytes of one output channel quad image
+    int it = slot;
+    lsetup(decode(it));
+    lstage(0, 0);
+    int stg = 0;                                                         // LDS stage of the chunk to compute next
+    bool drained = false;                                                // this wave's pieces of that chunk are known to have landed
+    for (; it < nitems; it += G) {
+        const Item cur = decode(it);
+        const int nxt = it + G;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[q][0][r] = 0.f; acc[q][1][r] = 0.f; }
+        for (int k = 0; k < nchunk; ++k) {
+            if (!drained) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            drained = false;
+            __builtin_amdgcn_s_barrier();                                // chunk k is in stage stg; every wave is past its reads of stage stg^1
+            if (k + 1 < nchunk) lstage(k + 1, stg ^ 1);
+            else if (nxt < nitems) { lsetup(decode(nxt)); lstage(0, stg ^ 1); }
+            __builtin_amdgcn_sched_barrier(0);
+            chunk_body(stg);
+            stg ^= 1;
+        }
+        // ---- epilogue: y = acc * acc_scale + pre_add, fp32 quad-major.  Result layout of the 32x32 MFMA: lane (l31 = pixel, lhi),
+        // register r = channel (r&3) + 8*(r>>2) + 4*lhi of the 32 -> registers 4i..4i+3 are channel quad 2i + lhi: one 16-byte access.
+        if (BFSR_H2T_ABL & 8) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t += acc[q][0][q] + acc[q][1][q + 4];
+            if (t == 1234.5f) p.y[lane] = t;
+            continue;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the DMA pieces of the next item's first chunk: ordinary loads follow
+        drained = true;
+        // descriptors of this item's 8 channel quads only (a 1024-channel DIV2K-sized output is 2.8 GB per sample: beyond 32-bit offsets)
+        const long long qoff = (long long)cur.cg * 8 * (Q16 >> 2);
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y + (long long)cur.b * p.y_bs + qoff, 0, 8u * Q16, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.pre_add ? p.pre_add + (long long)cur.b * p.pre_add_bs + qoff : p.y), 0,
+                                                                              p.pre_add ? 8u * Q16 : 0u, 0x00020000);
+        int lh = lhi, lx = l31;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(lh), "+v"(lx));                           // per-lane address arithmetic stays inside the item loop
+#endif
+        const int sx = cur.x0 + lx;
+        // four rounds (row j, row parity py) of 8 quads (2 column parities x 4 channel quads); the pre_add loads of round n+1 are issued
+        // before round n's arithmetic and stores (the fragment registers are free here): two rounds of loads in flight instead of a
+        // load -> wait -> store chain per round (0.7 of 4.8 ms per launch at config 2 before)
+        unsigned vo[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int sy = cur.y0 + 2 * wave + (n >> 1);
+            const bool ok = sy < h && sx < w;
+            vo[n] = ok ? (unsigned)lh * Q16 + (unsigned)((2 * sy + (n & 1)) * W2 + 2 * sx) * 16u : OOB;     // pixel (2sy+py, 2sx); px adds 16 bytes
+        }
+        float4 pre[2][2][4];
+        auto load_pre = [&](auto b_, int n) {
+            constexpr int BUF = decltype(b_)::value;
+#pragma unroll
+            for (int px = 0; px < 2; ++px)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    pre[BUF][px][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_p, vo[n] + 16u * px, (unsigned)(2 * i) * Q16, 0));
+        };
+        auto finish = [&](auto b_, auto n_) {
+            constexpr int BUF = decltype(b_)::value, N = decltype(n_)::value;
+#pragma unroll
+            for (int px = 0; px < 2; ++px)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x16& a = acc[(N & 1) * 2 + px][N >> 1];
+                    float4 o;
+                    o.x = a[4 * i + 0] * p.acc_scale + pre[BUF][px][i].x;
+                    o.y = a[4 * i + 1] * p.acc_scale + pre[BUF][px][i].y;
+                    o.z = a[4 * i + 2] * p.acc_scale + pre[BUF][px][i].z;
+                    o.w = a[4 * i + 3] * p.acc_scale + pre[BUF][px][i].w;
+                    bfsr::store_b128(rs_y, __builtin_bit_cast(u32x4, o), vo[N] + 16u * px, (unsigned)(2 * i) * Q16);
+                }
+        };
+        // (in place, y already holding pre_add, one fire-and-forget buffer_atomic_add_f32 per element instead of load + add + store was
+        // measured: 21.0 ms per launch instead of 4.8 -- fp32 atomics on HBM-resident lines run at a fraction of the store rate)
+        load_pre(I0(), 0);
+        load_pre(I1(), 1);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(I0(), I0());
+        __builtin_amdgcn_sched_barrier(0);
+        load_pre(I0(), 2);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(I1(), I1());
+        __builtin_amdgcn_sched_barrier(0);
+        load_pre(I1(), 3);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(I0(), std::integral_constant<int, 2>());
+        __builtin_amdgcn_sched_barrier(0);
+        finish(I1(), std::integral_constant<int, 3>());
+    }
+}
+
+std::atomic<unsigned long long> g_lds_done{0};
+
+}  // namespace
+
+// ---- C ABI ------------------------------------------------------------------------------------------------------------------------
+extern "C" long long bfsr_conv_up2_h2t_packed_size(int Cout, int Cin)
+{
+    if (Cout <= 0 || Cin <= 0 || Cout % 32 || Cin % 16) return -1;
+    return (long long)(Cout / 32) * (Cin / 16) * (W_ST / 2);            // fp16 elements
+}
+
+// w: OIHW 3x3 fp32.  packed: [cout group of 32][16-channel chunk][plane hi, lo][step (px*2+b)*4 + py*2+a][k half][32 couts][8 channels]
+// fp16 of scale * (sum of the window taps of output parity (py, px) that fall on source tap (a, b)): rows dy in {0} | {1, 2} for
+// py = 0 and {0, 1} | {2} for py = 1, same for columns.  The sum is formed in double and split once: hi + lo carries 22 bits of it.
+extern "C" int bfsr_pack_conv_up2_h2t(const float* w, int Cout, int Cin, float scale, unsigned short* packed)
+{
+    if (!w || !packed || Cout <= 0 || Cin <= 0 || Cout % 32 || Cin % 16 || !(scale > 0.f)) return -1;
+    const int nchunk = Cin / 16;
+    static const int lo_[2][2] = {{0, 1}, {0, 2}}, hi_[2][2] = {{0, 2}, {1, 2}};      // [parity][tap]: window index range [lo, hi]
+    _Float16* out = reinterpret_cast<_Float16*>(packed);
+    for (int cg = 0; cg < Cout / 32; ++cg)
+        for (int k = 0; k < nchunk; ++k) {
+            _Float16* blk = out + ((long long)cg * nchunk + k) * (W_ST / 2);
+            for (int s = 0; s < NSTEP; ++s) {
+                const int px = s >> 3, b = (s >> 2) & 1, py = (s >> 1) & 1, a = s & 1;
+                for (int kh = 0; kh < 2; ++kh)
+                    for (int co = 0; co < 32; ++co)
+                        for (int c = 0; c < 8; ++c) {
+                            const float* wp = w + ((long long)(cg * 32 + co) * Cin + (16 * k + 8 * kh + c)) * 9;
+                            double sum = 0.0;
+                            for (int dy = lo_[py][a]; dy <= hi_[py][a]; ++dy)
+                                for (int dx = lo_[px][b]; dx <= hi_[px][b]; ++dx) sum += (double)wp[dy * 3 + dx];
+                            const float v = (float)(sum * (double)scale);
+                            const _Float16 hi = (_Float16)v;
+                            const _Float16 lo = (_Float16)(v - (float)hi);
+                            const long long e = ((long long)(s * 2 + kh) * 32 + co) * 8 + c;
+                            blk[e] = hi;
+                            blk[W_PL / 2 + e] = lo;
+                        }
+            }
+        }
+    return 0;
+}
+
+extern "C" int bfsr_conv2d_up2_h2t(const BfsrUp2H2Args* a, void* stream)
+{
+    if (!a || !a->x || !a->w || !a->y || a->B <= 0 || a->h <= 0 || a->w_ <= 0 || a->Cin <= 0 || a->Cin % 16 || a->Cout <= 0 || a->Cout % 32) return -1;
+    if (a->y_fmt != 1) return -1;                                                               // quad-major fp32 only
+    if ((long long)(a->Cin / 8) * 2 * a->h * a->w_ * 16 >= (1LL << 31)) return -1;               // 32-bit buffer offsets (source, per sample)
+    if (8LL * 4 * a->h * a->w_ * 16 >= (1LL << 31)) return -1;                                   // (8 output channel quads of one sample)
+    const int tiles_x = (a->w_ + 31) / 32, tiles_y = (a->h + TH - 1) / TH, groups = a->Cout / 32;
+    const long long nitems = (long long)a->B * tiles_x * tiles_y * groups;
+    if (nitems >= (1LL << 31)) return -1;
+    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_up2_h2t_kernel), LDS_BYTES, g_lds_done) != 0) return -2;
+    const int cus = bfsr::cu_count();
+    if (cus <= 0) return -2;
+    const int grid = (int)(nitems < cus ? nitems : cus);
+    hipLaunchKernelGGL(conv_up2_h2t_kernel, dim3(grid), dim3(NWV * 64), LDS_BYTES, static_cast<hipStream_t>(stream), *a, tiles_x, tiles_y, groups, (int)nitems);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}

@@ -520,6 +520,40 @@ class HipOps(object):
         _lib.check(self._launch(key, lambda: self.lib.bfsr_conv3x3_h2x(C.byref(a), self._stream())), "conv3x3_h2x")
         return out
 
+    def pack_conv_up2_h2t(self, w):
+        """OIHW 3x3 weights of a conv over a nearest-x2-upsampled h2 tensor -> conv_up2_h2t's packing: per output parity the window taps
+        that fall on one source pixel are summed (in double), scaled by a power of two and split into fp16 hi + lo."""
+        w = w.detach().to("cpu", torch.float32).contiguous()
+        Cout, Cin = w.shape[0], w.shape[1]
+        if Cout % 32 or Cin % 16 or tuple(w.shape[2:]) != (3, 3):
+            raise ValueError("pack_conv_up2_h2t: unsupported shape %s" % (tuple(w.shape),))
+        wd, sets = w.double(), ((0,), (1, 2), (0, 1), (2,))
+        m = max(float(wd[:, :, list(r)][:, :, :, list(c)].sum((2, 3)).abs().max()) for r in sets for c in sets)
+        scale = self.pow2_scale(torch.tensor([m]))
+        packed = torch.empty(self.lib.bfsr_conv_up2_h2t_packed_size(Cout, Cin), dtype=torch.int16)
+        _lib.check(self.lib.bfsr_pack_conv_up2_h2t(w.data_ptr(), Cout, Cin, scale, packed.data_ptr()), "pack_conv_up2_h2t")
+        return packed.to(self.device), 1.0 / scale, Cout, Cin
+
+    def conv_up2_h2t(self, x, packed, out, pre_add=None):
+        """3x3 conv over the nearest-x2 upsampling of the h2 tensor `x` [B,Cin/8,2,h,w,8] (conv_up2_h2t.hip: parity-decomposed at source
+        resolution, two-term fp16 split, three products); `out` and `pre_add` (may be `out`) are fp32 buffers of shape [B,Cout,2h,2w]
+        holding the QUAD-MAJOR layout [B][Cout/4][2h][2w][4]: out = conv + pre_add."""
+        wts, acc_scale, Cout, Cin = packed
+        a = _lib.BfsrUp2H2Args()
+        a.x, a.x_bs, cin, h, w = self._h2view(x, "conv_up2_h2t.x")
+        a.y, a.y_bs, co, H, W = _view(out, "conv_up2_h2t.out")
+        if (cin, co, 2 * h, 2 * w) != (Cin, Cout, H, W) or x.shape[0] != out.shape[0]:
+            raise ValueError("conv_up2_h2t: shape mismatch x%s out%s weight(Cout=%d,Cin=%d)" % (tuple(x.shape), tuple(out.shape), Cout, Cin))
+        a.Cin, a.Cout, a.y_fmt = Cin, Cout, 1
+        a.w, a.acc_scale = wts.data_ptr(), acc_scale
+        a.B, a.h, a.w_ = out.shape[0], h, w
+        if pre_add is not None:
+            a.pre_add, a.pre_add_bs, c, hh, ww = _view(pre_add, "conv_up2_h2t.pre_add")
+            assert (c, hh, ww) == (Cout, H, W)
+        key = ("conv_up2_h2t", Cin, Cout, out.shape[0], H, W)
+        _lib.check(self._launch(key, lambda: self.lib.bfsr_conv2d_up2_h2t(C.byref(a), self._stream())), "conv2d_up2_h2t")
+        return out
+
     def pack_conv_h2s(self, w):
         """OIHW 3x3 fp32 weights -> fp16 packing of conv_h2s (32- or 64-cout workgroup tiles, 16-channel chunks)."""
         w = w.detach().to("cpu", torch.float32).contiguous()

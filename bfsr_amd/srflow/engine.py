@@ -354,6 +354,11 @@ class SRFlowEngine(object):
                     hz.update(ft0_taps=ops.pack_conv_up2_x3(wf[:, 64:].contiguous()), aff0_taps=ops.pack_conv_up2_x3(wa[:, 64:].contiguous()),
                               ft0_key=ops.pack_conv_x3(wf[:, :64].contiguous(), 1 if hz["x3s"] else 2),
                               aff0_key=ops.pack_conv_x3(wa[:, :64].contiguous(), 1 if hz["x3s"] else 2))
+                    # Round 4: with the quad-major hand-over the taps run on conv_up2_h2t (taps split once into an h2 tensor, LDS-DMA staging,
+                    # all four output parities per workgroup item): 6.4 -> 4.8 ms per launch at 8 x 160^2 -> 320^2 (tools/exp/taps_bench.py)
+                    if (hz["x3s"] and getattr(ops, "split", "") == "f16x2" and hasattr(ops, "conv_up2_h2t") and hz["ffast"] and hz["pre_q4"]
+                            and wf.shape[0] % 32 == 0 and wa.shape[0] % 32 == 0 and (wf.shape[1] - 64) % 16 == 0):
+                        hz["h2t"] = (ops.pack_conv_up2_h2t(wf[:, 64:].contiguous()), ops.pack_conv_up2_h2t(wa[:, 64:].contiguous()))
                 else:
                     hz.update(ft0_taps=ops.pack_conv_up2(wf[:, 64:].contiguous()), aff0_taps=ops.pack_conv_up2(wa[:, 64:].contiguous()),
                               ft0_key=ops.pack_conv(wf[:, :64].contiguous(), 2), aff0_key=ops.pack_conv(wa[:, :64].contiguous(), 2))
@@ -522,12 +527,20 @@ class SRFlowEngine(object):
             if hz["x3"]:
                 up = ops.conv_up4_x3 if hz["up"] == 2 else ops.conv_up2_x3
                 fq = dict(y_fmt=1) if ff else {}                       # ffast: raw conv result, quad-major (the 1x1-only head applies ActNorm + ReLU)
+                h2t = hz.get("h2t") if (ff and pq and hz["x3s"]) else None
+                if h2t is not None:
+                    key = (B,) + tuple(taps.shape[1:])
+                    if getattr(self, "_taps_h2", None) is None or self._taps_h2[0] != key:
+                        self._taps_h2 = (key, ops.h2_empty(B, taps.shape[1], taps.shape[2], taps.shape[3]))
+                    taps_h2 = ops.h2_pack(taps, self._taps_h2[1])
                 if hz["x3s"]:
                     f3 = ops.x3_pack(f, self._ftx3[level][1])
                     ops.conv_x3s(f3, hz["ft0_key"], hid, **fq)
                 else:
                     ops.conv_x3(f, hz["ft0_key"], hid, **fq)
-                if ff:
+                if h2t is not None:
+                    ops.conv_up2_h2t(taps_h2, h2t[0], hid, pre_add=hid)
+                elif ff:
                     up(taps, hz["ft0_taps"], hid, pre_add=hid, y_fmt=1)
                 else:
                     up(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, pre_add=hid)
@@ -535,7 +548,10 @@ class SRFlowEngine(object):
                     ops.conv_x3s(f3, hz["aff0_key"], pre_aff, **kq)
                 else:
                     ops.conv_x3(f, hz["aff0_key"], pre_aff, **kq)
-                up(taps, hz["aff0_taps"], pre_aff, pre_add=pre_aff, **kq)
+                if h2t is not None:
+                    ops.conv_up2_h2t(taps_h2, h2t[1], pre_aff, pre_add=pre_aff)
+                else:
+                    up(taps, hz["aff0_taps"], pre_aff, pre_add=pre_aff, **kq)
             else:
                 ops.conv_up2(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, key=(f, hz["ft0_key"]))
                 ops.conv_up2(taps, hz["aff0_taps"], pre_aff, key=(f, hz["aff0_key"]))

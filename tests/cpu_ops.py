@@ -394,6 +394,19 @@ class CpuOps(object):
         w4 = packed[0]
         return self.conv(sum(self._h2_planes(x)), PackedConv(w4, 1), out, epi=epi, act=act, slope=slope, y_fmt=y_fmt)
 
+    def pack_conv_up2_h2t(self, w):
+        w = w.detach().to(torch.float32).clone()
+        return w, 1.0, w.shape[0], w.shape[1]
+
+    def conv_up2_h2t(self, x, packed, out, pre_add=None):
+        """3x3 conv over the nearest-x2 upsampling of the h2 tensor x; out / pre_add hold the quad-major layout."""
+        xf = sum(self._h2_planes(x))
+        y = F.conv2d(F.interpolate(xf, scale_factor=2, mode="nearest"), packed[0], None, 1, 1)
+        if pre_add is not None:
+            y = y + self.quads(pre_add, inverse=True)
+        out.copy_(self.quads(y))
+        return out
+
     def check_range(self):
         pass
 

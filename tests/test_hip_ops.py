@@ -492,6 +492,39 @@ def test_conv_h2r(hip, Cout, hw):
     assert float(wq[:, :4].abs().max()) == 0.0 and float(wq[:, 4 + Cout:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("case", [(2, 32, 64, 16, 32), (1, 64, 32, 21, 37), (3, 16, 96, 5, 70), (2, 256, 64, 40, 40)])
+def test_conv_up2_h2t(hip, case):
+    """bfsr_conv2d_up2_h2t: conv3x3(nearest_up2(x)) for an h2 tensor x, parity-decomposed at source resolution with pre-summed weights, two-term
+    fp16 split (three products), quad-major fp32 output with and without pre_add (also in place) -- against an fp64 conv of the SAME 22-bit
+    input with the unsplit fp32 weights (SRFlowNet_arch.py:122-137: F.interpolate(..., mode='nearest') + cat + Conv2d); ragged tiles, several
+    output-channel groups, per-channel weight magnitudes over four decades."""
+    B, Cin, Cout, h, w = case
+    x, wt = rnd(301, B, Cin, h, w), rnd(302, Cout, Cin, 3, 3, scale=1.0 / np.sqrt(Cin * 9))
+    wt = wt * torch.logspace(-3, 0, Cout).view(-1, 1, 1, 1) * 2.0
+    pre = rnd(303, B, Cout, 2 * h, 2 * w)
+    xh = hip.h2_pack(hip.to_device(x), hip.h2_empty(B, Cin, h, w))
+    x22 = hip.h2_unpack(xh, hip.empty(B, Cin, h, w)).cpu()
+    ref64 = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x22.double(), scale_factor=2, mode="nearest"), wt.double(), None, 1, 1)
+    tol = 4e-6 * float(ref64.abs().max())
+    pk = hip.pack_conv_up2_h2t(wt)
+    out = hip.empty(B, Cout, 2 * h, 2 * w)
+    out.fill_(float("nan"))
+    hip.conv_up2_h2t(xh, pk, out)
+    got = CPU.quads(out.cpu(), inverse=True)
+    err = float((got.double() - ref64).abs().max())
+    assert err <= tol, "conv_up2_h2t %s: max-abs %g > %g" % (case, err, tol)
+    wide = hip.zeros(B, Cout + 8, 2 * h, 2 * w)                        # pre_add from a second buffer, output into a channel slice (quads 1 ..)
+    pq = hip.to_device(CPU.quads(pre))
+    hip.conv_up2_h2t(xh, pk, wide[:, 4:4 + Cout], pre_add=pq)
+    got2 = CPU.quads(wide[:, 4:4 + Cout].cpu().contiguous(), inverse=True)
+    assert float((got2.double() - (ref64 + pre.double())).abs().max()) <= tol + 1e-6, "conv_up2_h2t with pre_add %s" % (case,)
+    assert float(wide[:, :4].abs().max()) == 0.0 and float(wide[:, 4 + Cout:].abs().max()) == 0.0, "wrote outside its channel slice"
+    hip.conv_up2_h2t(xh, pk, pq, pre_add=pq)                           # in place
+    assert torch.equal(pq.cpu(), wide[:, 4:4 + Cout].cpu().contiguous()), "in-place pre_add differs from the two-buffer call"
+    cpu = CPU.conv_up2_h2t(CPU.h2_pack(x, CPU.h2_empty(B, Cin, h, w)), CPU.pack_conv_up2_h2t(wt), torch.empty(B, Cout, 2 * h, 2 * w), pre_add=CPU.quads(pre))
+    close(pq, cpu, 2e-5, "conv_up2_h2t vs the CPU test double")
+
+
 def test_coupling_pair_on_channel_slices_and_views(hip):
     """head -> tail with z / pre_aff / h_ft as channel slices of wider buffers, out of place into a slice (the engine runs in place)."""
     B, C, H, W = 2, 12, 20, 44

@@ -101,8 +101,11 @@ def test_engine_schedule_x3_mode_on_cpu_double(golden_dir, fx, scale):
     prior = registry.make({"name": "unet", "args": {"depth": 3, "dim": 64, "bilinear": True, "ops": ops},
                            "sd": synth.state_dict_from_schema(spec.srflow_prior_schema(), 4321)}, load_sd=True).eval()
     g = np.load(os.path.join(golden_dir, fx + ".npz"))
+    calls, orig = [], ops.conv_up2_h2t
+    ops.conv_up2_h2t = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
     out = lp_infer(m, prior, T(g["lr"]), return_all=True)
     assert m.netG.module.engine().rrdb.x3s
+    assert len(calls) == 2, "the level whose taps are the x2-upsampled LR taps (level 1 of the 4x model, level 2 of the 8x model) runs conv_up2_h2t twice (fFeatures, fAffine)"
     for i in (0, 1):
         assert (out["epses"][i] - T(g["eps%d" % i])).abs().max() <= 5e-5
     assert (out["sr"] - T(g["sr"])).abs().max() <= 1e-4

@@ -1,5 +1,5 @@
 """conv_h2x (fp16 two-term split, 3 products) vs conv_x3s (3xBF16, 6 products) at the RDB shapes: per-shape time and fp32-equivalent TFLOP/s.
-Usage: python tools/exp/h2x_bench.py [B H W]"""
+Usage: python tools/exp/h2x_bench.py [B H W [split]]"""
 import sys, os
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
@@ -10,7 +10,7 @@ ops = HipOps()
 g = torch.Generator().manual_seed(0)
 for B, H, W in shapes:
     tot = {}
-    for split in ("bf16x3", "f16x2"):
+    for split in ((sys.argv[4],) if len(sys.argv) > 4 else ("bf16x3", "f16x2")):
         ops.split = split
         D = ops.x3_pack(torch.randn(B, 192, H, W, device="cuda"), ops.x3_empty(B, 192, H, W))
         N = ops.x3_empty(B, 192, H, W)
@@ -34,4 +34,4 @@ for B, H, W in shapes:
             ms = e0.elapsed_time(e1) / 10
             tot[split] += ms
             print("%s B%d %dx%d %3d->%2d: %.3f ms  %.0f TFLOP/s fp32-equivalent" % (split, B, H, W, cin, cout, ms, 2.0 * 9 * cin * cout * B * H * W / ms * 1e-9))
-    print("one RDB at B%d %dx%d: bf16x3 %.3f ms, f16x2 %.3f ms (x%.2f)" % (B, H, W, tot["bf16x3"], tot["f16x2"], tot["bf16x3"] / tot["f16x2"]))
+    print("one RDB at B%d %dx%d: %s" % (B, H, W, ", ".join("%s %.3f ms" % kv for kv in tot.items())))

@@ -46,7 +46,7 @@ class BfsrConvX3Args(C.Structure):
 
 class BfsrUp2H2Args(C.Structure):
     _fields_ = [
-        ("x", C.c_void_p), ("x_bs", C.c_longlong), ("Cin", C.c_int),
+        ("x", C.c_void_p), ("x_bs", C.c_longlong), ("Cin", C.c_int), ("Ckey", C.c_int),
         ("w", C.c_void_p), ("acc_scale", C.c_float),
         ("y", C.c_void_p), ("y_bs", C.c_longlong), ("Cout", C.c_int), ("y_fmt", C.c_int),
         ("pre_add", C.c_void_p), ("pre_add_bs", C.c_longlong),
@@ -176,8 +176,9 @@ SYMBOLS = {
     "bfsr_pack_coupling_tail": (_I, [_VP, _I, _I, C.c_float, _VP]),
     "bfsr_conv3x3_h2r": (_I, [C.POINTER(BfsrConvX3Args), _VP]),
     "bfsr_conv2d_up2_h2t": (_I, [C.POINTER(BfsrUp2H2Args), _VP]),
-    "bfsr_conv_up2_h2t_packed_size": (_LL, [_I, _I]),
-    "bfsr_pack_conv_up2_h2t": (_I, [_VP, _I, _I, C.c_float, _VP]),
+    "bfsr_conv_up2_h2t_packed_size": (_LL, [_I, _I, _I]),
+    "bfsr_pack_conv_up2_h2t": (_I, [_VP, _VP, _I, _I, _I, C.c_float, _VP]),
+    "bfsr_h2_pack_s2d": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP, _VP]),
     "bfsr_squeeze2d": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
     "bfsr_unsqueeze2d": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
     "bfsr_split2d": (_I, [_VP, _LL, _VP, _LL, _VP, _LL, _I, _I, _I, _I, _I, _VP]),

@@ -50,6 +50,41 @@ constexpr unsigned OOB = 0x80000000u;
 
 struct Item { int cg, b, x0, y0; };
 
+// ---- weight-step tables.  A chunk = 16 input channels at SOURCE resolution; per chunk a list of steps, each = one weight block [32 couts][16]
+// applied to the source rows j + roff (tile rows 2w + j + roff) at column shift cs, accumulated into output parity p4 = py*2 + px.
+//   type 0, taps chunk (the upsampled tensor): 16 steps s = (px*2 + b)*4 + py*2 + a: source tap (a, b) of parity (py, px): roff = py + a,
+//           cs = px + b - 1 -- grouped by cs: -1 (4 steps), 0 (8), +1 (4).
+//   type 1 + q, key chunk of space-to-depth plane q = qy*2 + qx (channels that live at OUTPUT resolution, plane q = their pixels (2y+qy, 2x+qx)):
+//           output row 2y+py reads window row dy at output-resolution row 2y+py+dy-1 = plane-qy row y+ry; per axis and plane parity q the
+//           (p, r) pairs are  q = 0: (0,0) (1,0) (1,+1);  q = 1: (0,-1) (0,0) (1,0),  window index d = 2r + q - p + 1.  9 steps s = ci*3 + ri
+//           (ci: column pair, ri: row pair), grouped by cs = rx: qx = 0: 0 (6 steps), +1 (3); qx = 1: -1 (3), 0 (6).
+struct StepInfo { int p4, roff, cs, dy, dx; };
+constexpr int axis_p(int q, int i) { return q == 0 ? (i >= 1) : (i == 2); }
+constexpr int axis_r(int q, int i) { return q == 0 ? (i == 2 ? 1 : 0) : (i == 0 ? -1 : 0); }
+constexpr StepInfo step_info(int type, int s)
+{
+    if (type == 0) {
+        const int px = s >> 3, b = (s >> 2) & 1, py = (s >> 1) & 1, a = s & 1;
+        return StepInfo{py * 2 + px, py + a, px + b - 1, 0, 0};
+    }
+    const int q = type - 1, qy = q >> 1, qx = q & 1, ci = s / 3, ri = s % 3;
+    const int px = axis_p(qx, ci), rx = axis_r(qx, ci), py = axis_p(qy, ri), ry = axis_r(qy, ri);
+    return StepInfo{py * 2 + px, ry + 1, rx, 2 * ry + qy - py + 1, 2 * rx + qx - px + 1};
+}
+constexpr int nsteps(int type) { return type == 0 ? 16 : 9; }
+constexpr int group_of(int type, int s)          // index of the column-shift group step s belongs to
+{
+    int g = 0;
+    for (int i = 1; i <= s; ++i) g += step_info(type, i).cs != step_info(type, i - 1).cs;
+    return g;
+}
+constexpr int next_group_start(int type, int s)  // first step of the group after s's (nsteps if none)
+{
+    int i = s + 1;
+    while (i < nsteps(type) && step_info(type, i).cs == step_info(type, s).cs) ++i;
+    return i;
+}
+
 #ifndef BFSR_H2T_ABL
 #define BFSR_H2T_ABL 0                          // ablation builds only (tools/exp): bit 0 no fragment reads, 1 no MFMAs, 2 no DMA, 3 no epilogue
 #endif
@@ -65,7 +100,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_up2_h2t_kernel(BfsrUp2H2Args
     if (slot >= nitems) return;
     const int h = p.h, w = p.w_;
     const unsigned HW16 = (unsigned)(h * w) * 16u;                       // bytes of one (octet, plane) image of the source
-    const int nchunk = p.Cin >> 4;
+    const int nct = (p.Cin - 4 * p.Ckey) >> 4;                           // taps chunks; then 4 planes x Ckey/16 key chunks
+    const int nck = p.Ckey >> 4;
+    const int nchunk = nct + 4 * nck;
     const int ntiles = p.B * tiles_y * tiles_x;
 
     // items in rounds of [8 source tiles][cout groups]: the 32 workgroups of an XCD share 8 input tiles and 4 weight sets at a time
@@ -105,22 +142,25 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_up2_h2t_kernel(BfsrUp2H2Args
             vg[i] = ok ? (unsigned)(gy * w + gx) * 16u : OOB;            // out of range -> the DMA writes zeros (= the padding)
         }
     };
-    auto lstage = [&](int k, int stg) {
-        if (BFSR_H2T_ABL & 4) return;
+    // piece i (0..8: five input pieces, four weight pieces) of chunk k of the item lsetup() described, into stage stg; k < 0: nothing to stage
+    auto lpiece = [&](int i, int k, int stg) {
+        if ((BFSR_H2T_ABL & 4) || k < 0) return;
         unsigned char* base = smem + stg * STAGE;
-#pragma unroll
-        for (int i = 0; i < NXP; ++i) {
+        if (i < NXP) {
             const int piece = wave + NWV * i;
             const int si = piece / NG;                                   // sub-image: plane si>>1, k half si&1
             const unsigned soff = (unsigned)((2 * k + (si & 1)) * 2 + (si >> 1)) * HW16;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(base + piece * 1024), 16, vg[i], soff, 0, 0);
-        }
-        const unsigned wsoff = (unsigned)(ld_cg * nchunk + k) * (unsigned)W_ST;
-#pragma unroll
-        for (int i = 0; i < NWP; ++i) {
-            const int piece = wave + NWV * i;
+        } else {
+            const int piece = wave + NWV * (i - NXP);
+            if (k >= nct && (piece & 15) >= 9) return;                   // key chunk: 9 steps per weight plane
+            const unsigned wsoff = (unsigned)(ld_cg * nchunk + k) * (unsigned)W_ST;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(base + X_IN + piece * 1024), 16, (unsigned)lane * 16u + (unsigned)piece * 1024u, wsoff, 0, 0);
         }
+    };
+    auto lstage = [&](int k, int stg) {
+#pragma unroll
+        for (int i = 0; i < NXP + NWP; ++i) lpiece(i, k, stg);
     };
 
     // ---- fragments: xin[buffer][tile row 2w + r, r = 0..3][plane] for one column shift cs; wq[buffer][plane] for one weight step
@@ -154,47 +194,42 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_up2_h2t_kernel(BfsrUp2H2Args
                 wq[b][0][i] = (_Float16)(0.002f * (lane + i)); wq[b][1][i] = (_Float16)(0.0002f * (lane + i));
             }
     }
-    // step s = (px*2 + b)*4 + py*2 + a: weights of source tap (a, b) for output parity (py, px); source row of output row j = j + py + a
-    auto mfma_step = [&](auto s_, auto xb_, auto wb_) {
-        constexpr int S = decltype(s_)::value, XB = decltype(xb_)::value, WB = decltype(wb_)::value;
-        constexpr int PX = S >> 3, PY = (S >> 1) & 1, A = S & 1, P4 = PY * 2 + PX;
+    auto mfma_step = [&](auto t_, auto s_) {
+        constexpr int TYPE = decltype(t_)::value, S = decltype(s_)::value;
+        constexpr StepInfo si = step_info(TYPE, S);
+        constexpr int XB = group_of(TYPE, S) & 1, WB = S & 1;
         if (BFSR_H2T_ABL & 2) return;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             // smallest terms first: w_lo*x_hi, w_hi*x_lo, w_hi*x_hi
-            acc[P4][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[WB][1], xin[XB][j + PY + A][0], acc[P4][j], 0, 0, 0);
-            acc[P4][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[WB][0], xin[XB][j + PY + A][1], acc[P4][j], 0, 0, 0);
-            acc[P4][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[WB][0], xin[XB][j + PY + A][0], acc[P4][j], 0, 0, 0);
+            acc[si.p4][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[WB][1], xin[XB][j + si.roff][0], acc[si.p4][j], 0, 0, 0);
+            acc[si.p4][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[WB][0], xin[XB][j + si.roff][1], acc[si.p4][j], 0, 0, 0);
+            acc[si.p4][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[WB][0], xin[XB][j + si.roff][0], acc[si.p4][j], 0, 0, 0);
         }
     };
-    // one chunk: column-shift groups cs = -1 (steps 0-3, buffer 0), 0 (steps 4-11, buffer 1), +1 (steps 12-15, buffer 0 again); the
-    // fragments of the next group / step are read while the current MFMAs run
-    auto chunk_body = [&](int stg) {
-        load_x(I0(), stg, -1);
+    // one chunk: the column-shift groups alternate between the two input fragment buffers; the fragments of the next group / step are
+    // read while the current MFMAs run.  The nine LDS-DMA pieces of the next chunk (lk; into the other stage) go out one per step behind
+    // the step's MFMAs: issued in one burst behind the barrier they kept all eight waves off the matrix pipe at the same time.
+    auto step = [&](auto t_, auto s_, int stg, int lk) {
+        constexpr int TYPE = decltype(t_)::value, S = decltype(s_)::value, NS = nsteps(TYPE);
+        if constexpr (S < NS) {
+            constexpr int G = group_of(TYPE, S), NG_ = next_group_start(TYPE, S);
+            if constexpr ((S == 0 || group_of(TYPE, S - 1) != G) && NG_ < NS)      // first step of a group: prefetch the next group's rows
+                load_x(std::integral_constant<int, (G + 1) & 1>(), stg, step_info(TYPE, NG_).cs);
+            if constexpr (S + 1 < NS) load_w(std::integral_constant<int, (S + 1) & 1>(), stg, S + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(t_, s_);
+            if constexpr (S < NXP + NWP) lpiece(S, lk, stg ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto chunk_body = [&](auto t_, int stg, int lk) {
+        constexpr int TYPE = decltype(t_)::value;
+        load_x(I0(), stg, step_info(TYPE, 0).cs);
         load_w(I0(), stg, 0);
-#define STEP_(S_, XB_, PRE_)                                                                                      \
-        { PRE_;                                                                                                   \
-          if (S_ + 1 < NSTEP) load_w(std::integral_constant<int, (S_ + 1) & 1>(), stg, S_ + 1);                   \
-          __builtin_amdgcn_sched_barrier(0);                                                                      \
-          mfma_step(std::integral_constant<int, S_>(), std::integral_constant<int, XB_>(), std::integral_constant<int, S_ & 1>()); \
-          __builtin_amdgcn_sched_barrier(0); }
-        STEP_(0, 0, load_x(I1(), stg, 0))
-        STEP_(1, 0, (void)0)
-        STEP_(2, 0, (void)0)
-        STEP_(3, 0, (void)0)
-        STEP_(4, 1, load_x(I0(), stg, 1))
-        STEP_(5, 1, (void)0)
-        STEP_(6, 1, (void)0)
-        STEP_(7, 1, (void)0)
-        STEP_(8, 1, (void)0)
-        STEP_(9, 1, (void)0)
-        STEP_(10, 1, (void)0)
-        STEP_(11, 1, (void)0)
-        STEP_(12, 0, (void)0)
-        STEP_(13, 0, (void)0)
-        STEP_(14, 0, (void)0)
-        STEP_(15, 0, (void)0)
-#undef STEP_
+#define ST_(N_) step(t_, std::integral_constant<int, N_>(), stg, lk);
+        ST_(0) ST_(1) ST_(2) ST_(3) ST_(4) ST_(5) ST_(6) ST_(7) ST_(8) ST_(9) ST_(10) ST_(11) ST_(12) ST_(13) ST_(14) ST_(15)
+#undef ST_
     };
 
     const int H2 = 2 * h, W2 = 2 * w;
@@ -211,16 +246,30 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_up2_h2t_kernel(BfsrUp2H2Args
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[q][0][r] = 0.f; acc[q][1][r] = 0.f; }
-        for (int k = 0; k < nchunk; ++k) {
+        auto run_chunk = [&](auto t_, int k) {
             if (!drained) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             drained = false;
             __builtin_amdgcn_s_barrier();                                // chunk k is in stage stg; every wave is past its reads of stage stg^1
-            if (k + 1 < nchunk) lstage(k + 1, stg ^ 1);
-            else if (nxt < nitems) { lsetup(decode(nxt)); lstage(0, stg ^ 1); }
+            int lk = k + 1;
+            if (lk == nchunk) {
+                lk = -1;
+                if (nxt < nitems) { lsetup(decode(nxt)); lk = 0; }
+            }
             __builtin_amdgcn_sched_barrier(0);
-            chunk_body(stg);
+            chunk_body(t_, stg, lk);
             stg ^= 1;
-        }
+        };
+        // one loop per chunk type (a type dispatch inside one loop made hipcc spill 367 registers at the join)
+#pragma unroll 1
+        for (int k = 0; k < nct; ++k) run_chunk(I0(), k);
+#pragma unroll 1
+        for (int k = 0; k < nck; ++k) run_chunk(I1(), nct + k);
+#pragma unroll 1
+        for (int k = 0; k < nck; ++k) run_chunk(std::integral_constant<int, 2>(), nct + nck + k);
+#pragma unroll 1
+        for (int k = 0; k < nck; ++k) run_chunk(std::integral_constant<int, 3>(), nct + 2 * nck + k);
+#pragma unroll 1
+        for (int k = 0; k < nck; ++k) run_chunk(std::integral_constant<int, 4>(), nct + 3 * nck + k);
         // ---- epilogue: y = acc * acc_scale + pre_add, fp32 quad-major.  Result layout of the 32x32 MFMA: lane (l31 = pixel, lhi),
         // register r = channel (r&3) + 8*(r>>2) + 4*lhi of the 32 -> registers 4i..4i+3 are channel quad 2i + lhi: one 16-byte access.
         if (BFSR_H2T_ABL & 8) {
@@ -297,42 +346,85 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_up2_h2t_kernel(BfsrUp2H2Args
 
 std::atomic<unsigned long long> g_lds_done{0};
 
+// fp32 NCHW [B][C][2h][2w] -> h2 tensor with 4C channels at h x w: channel q*C + c = the pixels (2y+qy, 2x+qx) of channel c, q = qy*2 + qx
+// (space to depth: the form in which channels that live at the output resolution enter conv_up2_h2t_kernel as key chunks)
+__global__ void h2_pack_s2d_kernel(const float* __restrict__ x, long long x_bs, unsigned short* __restrict__ y, long long y_bs,
+                                   int C, int h, int w, long long total, unsigned* flag)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long long hw = (long long)h * w;
+    const int C8 = C >> 3;
+    const long long pix = i % hw; const long long t = i / hw;
+    const int oct = (int)(t % (4 * C8)); const int b = (int)(t / (4 * C8));
+    const int q = oct / C8, c0 = (oct - q * C8) * 8;
+    const int sy = (int)(pix / w), sx = (int)(pix - (long long)sy * w);
+    const float* xb = x + (long long)b * x_bs + (long long)c0 * 4 * hw + (long long)(2 * sy + (q >> 1)) * (2 * w) + 2 * sx + (q & 1);
+    half8 h8, l8;
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = xb[(long long)j * 4 * hw];
+        const _Float16 hi = (_Float16)v;
+        h8[j] = hi; l8[j] = (_Float16)(v - (float)hi);
+        amax = fmaxf(amax, fabsf(v));
+    }
+    unsigned short* yb = y + (long long)b * y_bs + ((long long)oct * 2 * hw + pix) * 8;
+    *reinterpret_cast<half8*>(yb) = h8;
+    *reinterpret_cast<half8*>(yb + hw * 8) = l8;
+    if (flag && !(amax < 65504.f)) atomicOr(flag, 1u);
+}
+
 }  // namespace
 
 // ---- C ABI ------------------------------------------------------------------------------------------------------------------------
-extern "C" long long bfsr_conv_up2_h2t_packed_size(int Cout, int Cin)
+extern "C" long long bfsr_conv_up2_h2t_packed_size(int Cout, int Ct, int Ck)
 {
-    if (Cout <= 0 || Cin <= 0 || Cout % 32 || Cin % 16) return -1;
-    return (long long)(Cout / 32) * (Cin / 16) * (W_ST / 2);            // fp16 elements
+    if (Cout <= 0 || Ct < 0 || Ck < 0 || Ct + Ck <= 0 || Cout % 32 || Ct % 16 || Ck % 16) return -1;
+    return (long long)(Cout / 32) * (Ct / 16 + 4 * (Ck / 16)) * (W_ST / 2);           // fp16 elements
 }
 
-// w: OIHW 3x3 fp32.  packed: [cout group of 32][16-channel chunk][plane hi, lo][step (px*2+b)*4 + py*2+a][k half][32 couts][8 channels]
-// fp16 of scale * (sum of the window taps of output parity (py, px) that fall on source tap (a, b)): rows dy in {0} | {1, 2} for
-// py = 0 and {0, 1} | {2} for py = 1, same for columns.  The sum is formed in double and split once: hi + lo carries 22 bits of it.
-extern "C" int bfsr_pack_conv_up2_h2t(const float* w, int Cout, int Cin, float scale, unsigned short* packed)
+// w_taps: OIHW 3x3 fp32 over the Ct upsampled channels; w_key (NULL when Ck = 0): OIHW 3x3 over the Ck channels at output resolution.
+// packed: [cout group of 32][chunk][plane hi, lo][step][k half][32 couts][8 channels] fp16 of scale * weight, 16 step slots per plane:
+//   taps chunk (16 channels): step (px*2+b)*4 + py*2+a = the sum of the window taps of output parity (py, px) that fall on source tap (a, b)
+//     -- rows dy in {0} | {1, 2} for py = 0 and {0, 1} | {2} for py = 1, same for columns; formed in double, split once (22 bits);
+//   key chunk (space-to-depth plane q, 16 channels): the 9 steps of step_info(1 + q, s), each ONE window tap (dy, dx); slots 9..15 zero.
+extern "C" int bfsr_pack_conv_up2_h2t(const float* w_taps, const float* w_key, int Cout, int Ct, int Ck, float scale, unsigned short* packed)
 {
-    if (!w || !packed || Cout <= 0 || Cin <= 0 || Cout % 32 || Cin % 16 || !(scale > 0.f)) return -1;
-    const int nchunk = Cin / 16;
+    if (!packed || Cout <= 0 || Ct < 0 || Ck < 0 || Ct + Ck <= 0 || Cout % 32 || Ct % 16 || Ck % 16 || !(scale > 0.f)) return -1;
+    if ((Ct > 0 && !w_taps) || (Ck > 0 && !w_key)) return -1;
+    const int nct = Ct / 16, nck = Ck / 16, nchunk = nct + 4 * nck;
     static const int lo_[2][2] = {{0, 1}, {0, 2}}, hi_[2][2] = {{0, 2}, {1, 2}};      // [parity][tap]: window index range [lo, hi]
     _Float16* out = reinterpret_cast<_Float16*>(packed);
+    auto put = [&](_Float16* blk, int s, int kh, int co, int c, double v64) {
+        const float v = (float)(v64 * (double)scale);
+        const _Float16 hi = (_Float16)v;
+        const long long e = ((long long)(s * 2 + kh) * 32 + co) * 8 + c;
+        blk[e] = hi;
+        blk[W_PL / 2 + e] = (_Float16)(v - (float)hi);
+    };
     for (int cg = 0; cg < Cout / 32; ++cg)
         for (int k = 0; k < nchunk; ++k) {
             _Float16* blk = out + ((long long)cg * nchunk + k) * (W_ST / 2);
-            for (int s = 0; s < NSTEP; ++s) {
-                const int px = s >> 3, b = (s >> 2) & 1, py = (s >> 1) & 1, a = s & 1;
+            for (int e = 0; e < W_ST / 2; ++e) blk[e] = (_Float16)0.f;
+            const int type = k < nct ? 0 : 1 + (k - nct) / nck;
+            const int kc = k < nct ? k : (k - nct) % nck;
+            for (int s = 0; s < nsteps(type); ++s) {
+                const StepInfo si = step_info(type, s);
+                const int px = si.p4 & 1, py = si.p4 >> 1, b = (s >> 2) & 1, a = s & 1;
                 for (int kh = 0; kh < 2; ++kh)
                     for (int co = 0; co < 32; ++co)
                         for (int c = 0; c < 8; ++c) {
-                            const float* wp = w + ((long long)(cg * 32 + co) * Cin + (16 * k + 8 * kh + c)) * 9;
-                            double sum = 0.0;
-                            for (int dy = lo_[py][a]; dy <= hi_[py][a]; ++dy)
-                                for (int dx = lo_[px][b]; dx <= hi_[px][b]; ++dx) sum += (double)wp[dy * 3 + dx];
-                            const float v = (float)(sum * (double)scale);
-                            const _Float16 hi = (_Float16)v;
-                            const _Float16 lo = (_Float16)(v - (float)hi);
-                            const long long e = ((long long)(s * 2 + kh) * 32 + co) * 8 + c;
-                            blk[e] = hi;
-                            blk[W_PL / 2 + e] = lo;
+                            if (type == 0) {
+                                const float* wp = w_taps + ((long long)(cg * 32 + co) * Ct + (16 * kc + 8 * kh + c)) * 9;
+                                double sum = 0.0;
+                                for (int dy = lo_[py][a]; dy <= hi_[py][a]; ++dy)
+                                    for (int dx = lo_[px][b]; dx <= hi_[px][b]; ++dx) sum += (double)wp[dy * 3 + dx];
+                                put(blk, s, kh, co, c, sum);
+                            } else {
+                                const float* wp = w_key + ((long long)(cg * 32 + co) * Ck + (16 * kc + 8 * kh + c)) * 9;
+                                put(blk, s, kh, co, c, (double)wp[si.dy * 3 + si.dx]);
+                            }
                         }
             }
         }
@@ -342,8 +434,9 @@ extern "C" int bfsr_pack_conv_up2_h2t(const float* w, int Cout, int Cin, float s
 extern "C" int bfsr_conv2d_up2_h2t(const BfsrUp2H2Args* a, void* stream)
 {
     if (!a || !a->x || !a->w || !a->y || a->B <= 0 || a->h <= 0 || a->w_ <= 0 || a->Cin <= 0 || a->Cin % 16 || a->Cout <= 0 || a->Cout % 32) return -1;
+    if (a->Ckey < 0 || a->Ckey % 16 || 4 * a->Ckey > a->Cin) return -1;
     if (a->y_fmt != 1) return -1;                                                               // quad-major fp32 only
-    if ((long long)(a->Cin / 8) * 2 * a->h * a->w_ * 16 >= (1LL << 31)) return -1;               // 32-bit buffer offsets (source, per sample)
+    if ((long long)(a->Cin / 8) * 2 * a->h * a->w_ * 16 >= (1LL << 31)) return -1;              // 32-bit buffer offsets (source, per sample)
     if (8LL * 4 * a->h * a->w_ * 16 >= (1LL << 31)) return -1;                                   // (8 output channel quads of one sample)
     const int tiles_x = (a->w_ + 31) / 32, tiles_y = (a->h + TH - 1) / TH, groups = a->Cout / 32;
     const long long nitems = (long long)a->B * tiles_x * tiles_y * groups;
@@ -353,5 +446,14 @@ extern "C" int bfsr_conv2d_up2_h2t(const BfsrUp2H2Args* a, void* stream)
     if (cus <= 0) return -2;
     const int grid = (int)(nitems < cus ? nitems : cus);
     hipLaunchKernelGGL(conv_up2_h2t_kernel, dim3(grid), dim3(NWV * 64), LDS_BYTES, static_cast<hipStream_t>(stream), *a, tiles_x, tiles_y, groups, (int)nitems);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+extern "C" int bfsr_h2_pack_s2d(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int C, int h, int w, unsigned* flag, void* stream)
+{
+    if (!x || !y || B <= 0 || C <= 0 || (C & 7) || h <= 0 || w <= 0) return -1;
+    if ((reinterpret_cast<unsigned long long>(y) & 15) || (y_bs & 7)) return -1;
+    const long long total = (long long)B * (C / 2) * h * w;
+    hipLaunchKernelGGL(h2_pack_s2d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, x_bs, y, y_bs, C, h, w, total, flag);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -520,37 +520,52 @@ class HipOps(object):
         _lib.check(self._launch(key, lambda: self.lib.bfsr_conv3x3_h2x(C.byref(a), self._stream())), "conv3x3_h2x")
         return out
 
-    def pack_conv_up2_h2t(self, w):
-        """OIHW 3x3 weights of a conv over a nearest-x2-upsampled h2 tensor -> conv_up2_h2t's packing: per output parity the window taps
-        that fall on one source pixel are summed (in double), scaled by a power of two and split into fp16 hi + lo."""
-        w = w.detach().to("cpu", torch.float32).contiguous()
-        Cout, Cin = w.shape[0], w.shape[1]
-        if Cout % 32 or Cin % 16 or tuple(w.shape[2:]) != (3, 3):
-            raise ValueError("pack_conv_up2_h2t: unsupported shape %s" % (tuple(w.shape),))
+    def h2_pack_s2d(self, x, out):
+        """fp32 [B,C,2h,2w] view -> h2 view with 4C channels at h x w (space to depth): channel q*C + c = pixels (2y+qy, 2x+qx) of channel c,
+        q = qy*2 + qx -- the form in which channels at output resolution enter conv_up2_h2t as key chunks."""
+        xp, xbs, Cc, H, W = _view(x, "h2_pack_s2d.x")
+        yp, ybs, c2, h2, w2 = self._h2view(out, "h2_pack_s2d.out")
+        assert (4 * Cc, H, W) == (c2, 2 * h2, 2 * w2) and x.shape[0] == out.shape[0]
+        _lib.check(self._launch(("h2_pack_s2d",) + tuple(x.shape), lambda: self.lib.bfsr_h2_pack_s2d(xp, xbs, yp, ybs, x.shape[0], Cc, h2, w2, self.range_flag.data_ptr(), self._stream())),
+                   "h2_pack_s2d")
+        return out
+
+    def pack_conv_up2_h2t(self, w_taps, w_key=None):
+        """OIHW 3x3 weights of the conv over cat([key at output resolution, nearest-x2-upsampled taps]) -> conv_up2_h2t's packing.  w_taps
+        [Cout,Ct,3,3]: per output parity the window taps that fall on one source pixel are summed (in double); w_key [Cout,Ck,3,3] (optional):
+        single window taps per space-to-depth plane.  Everything is scaled by one power of two and split into fp16 hi + lo."""
+        w = w_taps.detach().to("cpu", torch.float32).contiguous()
+        Cout, Ct = w.shape[0], w.shape[1]
+        wk = None if w_key is None else w_key.detach().to("cpu", torch.float32).contiguous()
+        Ck = 0 if wk is None else wk.shape[1]
+        if Cout % 32 or Ct % 16 or Ck % 16 or tuple(w.shape[2:]) != (3, 3) or (wk is not None and (wk.shape[0] != Cout or tuple(wk.shape[2:]) != (3, 3))):
+            raise ValueError("pack_conv_up2_h2t: unsupported shapes %s %s" % (tuple(w.shape), None if wk is None else tuple(wk.shape)))
         wd, sets = w.double(), ((0,), (1, 2), (0, 1), (2,))
         m = max(float(wd[:, :, list(r)][:, :, :, list(c)].sum((2, 3)).abs().max()) for r in sets for c in sets)
+        if wk is not None:
+            m = max(m, float(wk.abs().max()))
         scale = self.pow2_scale(torch.tensor([m]))
-        packed = torch.empty(self.lib.bfsr_conv_up2_h2t_packed_size(Cout, Cin), dtype=torch.int16)
-        _lib.check(self.lib.bfsr_pack_conv_up2_h2t(w.data_ptr(), Cout, Cin, scale, packed.data_ptr()), "pack_conv_up2_h2t")
-        return packed.to(self.device), 1.0 / scale, Cout, Cin
+        packed = torch.empty(self.lib.bfsr_conv_up2_h2t_packed_size(Cout, Ct, Ck), dtype=torch.int16)
+        _lib.check(self.lib.bfsr_pack_conv_up2_h2t(w.data_ptr(), 0 if wk is None else wk.data_ptr(), Cout, Ct, Ck, scale, packed.data_ptr()), "pack_conv_up2_h2t")
+        return packed.to(self.device), 1.0 / scale, Cout, Ct, Ck
 
     def conv_up2_h2t(self, x, packed, out, pre_add=None):
-        """3x3 conv over the nearest-x2 upsampling of the h2 tensor `x` [B,Cin/8,2,h,w,8] (conv_up2_h2t.hip: parity-decomposed at source
-        resolution, two-term fp16 split, three products); `out` and `pre_add` (may be `out`) are fp32 buffers of shape [B,Cout,2h,2w]
-        holding the QUAD-MAJOR layout [B][Cout/4][2h][2w][4]: out = conv + pre_add."""
-        wts, acc_scale, Cout, Cin = packed
+        """conv3x3(cat([key, nearest_up2(taps)])) at source resolution (conv_up2_h2t.hip: parity-decomposed, two-term fp16 split, three products).
+        `x`: h2 tensor [B,(Ct + 4*Ck)/8,2,h,w,8] = the taps followed by the space-to-depth planes of the key channels (h2_pack_s2d); `out` and
+        `pre_add` (may be `out`) are fp32 buffers of shape [B,Cout,2h,2w] holding the QUAD-MAJOR layout [B][Cout/4][2h][2w][4]: out = conv + pre_add."""
+        wts, acc_scale, Cout, Ct, Ck = packed
         a = _lib.BfsrUp2H2Args()
         a.x, a.x_bs, cin, h, w = self._h2view(x, "conv_up2_h2t.x")
         a.y, a.y_bs, co, H, W = _view(out, "conv_up2_h2t.out")
-        if (cin, co, 2 * h, 2 * w) != (Cin, Cout, H, W) or x.shape[0] != out.shape[0]:
-            raise ValueError("conv_up2_h2t: shape mismatch x%s out%s weight(Cout=%d,Cin=%d)" % (tuple(x.shape), tuple(out.shape), Cout, Cin))
-        a.Cin, a.Cout, a.y_fmt = Cin, Cout, 1
+        if (cin, co, 2 * h, 2 * w) != (Ct + 4 * Ck, Cout, H, W) or x.shape[0] != out.shape[0]:
+            raise ValueError("conv_up2_h2t: shape mismatch x%s out%s weight(Cout=%d,Ct=%d,Ck=%d)" % (tuple(x.shape), tuple(out.shape), Cout, Ct, Ck))
+        a.Cin, a.Ckey, a.Cout, a.y_fmt = cin, Ck, Cout, 1
         a.w, a.acc_scale = wts.data_ptr(), acc_scale
         a.B, a.h, a.w_ = out.shape[0], h, w
         if pre_add is not None:
             a.pre_add, a.pre_add_bs, c, hh, ww = _view(pre_add, "conv_up2_h2t.pre_add")
             assert (c, hh, ww) == (Cout, H, W)
-        key = ("conv_up2_h2t", Cin, Cout, out.shape[0], H, W)
+        key = ("conv_up2_h2t", Ct, Ck, Cout, out.shape[0], H, W)
         _lib.check(self._launch(key, lambda: self.lib.bfsr_conv2d_up2_h2t(C.byref(a), self._stream())), "conv2d_up2_h2t")
         return out
 

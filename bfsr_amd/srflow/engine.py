@@ -358,7 +358,8 @@ class SRFlowEngine(object):
                     # all four output parities per workgroup item): 6.4 -> 4.8 ms per launch at 8 x 160^2 -> 320^2 (tools/exp/taps_bench.py)
                     if (hz["x3s"] and getattr(ops, "split", "") == "f16x2" and hasattr(ops, "conv_up2_h2t") and hz["ffast"] and hz["pre_q4"]
                             and wf.shape[0] % 32 == 0 and wa.shape[0] % 32 == 0 and (wf.shape[1] - 64) % 16 == 0):
-                        hz["h2t"] = (ops.pack_conv_up2_h2t(wf[:, 64:].contiguous()), ops.pack_conv_up2_h2t(wa[:, 64:].contiguous()))
+                        hz["h2t"] = (ops.pack_conv_up2_h2t(wf[:, 64:].contiguous(), wf[:, :64].contiguous()),
+                                     ops.pack_conv_up2_h2t(wa[:, 64:].contiguous(), wa[:, :64].contiguous()))
                 else:
                     hz.update(ft0_taps=ops.pack_conv_up2(wf[:, 64:].contiguous()), aff0_taps=ops.pack_conv_up2(wa[:, 64:].contiguous()),
                               ft0_key=ops.pack_conv(wf[:, :64].contiguous(), 2), aff0_key=ops.pack_conv(wa[:, :64].contiguous(), 2))
@@ -529,28 +530,37 @@ class SRFlowEngine(object):
                 fq = dict(y_fmt=1) if ff else {}                       # ffast: raw conv result, quad-major (the 1x1-only head applies ActNorm + ReLU)
                 h2t = hz.get("h2t") if (ff and pq and hz["x3s"]) else None
                 if h2t is not None:
-                    key = (B,) + tuple(taps.shape[1:])
+                    # one h2 tensor at LR resolution: the 256 tap channels, then the four space-to-depth planes of the 64 key channels
+                    # (fea_up2) -- the key conv and the pre_add round trip are K chunks of the taps kernel
+                    ct = taps.shape[1]
+                    key = (B, ct + 4 * 64) + tuple(taps.shape[2:])
                     if getattr(self, "_taps_h2", None) is None or self._taps_h2[0] != key:
-                        self._taps_h2 = (key, ops.h2_empty(B, taps.shape[1], taps.shape[2], taps.shape[3]))
-                    taps_h2 = ops.h2_pack(taps, self._taps_h2[1])
-                if hz["x3s"]:
+                        self._taps_h2 = (key, ops.h2_empty(*key))
+                    taps_h2 = self._taps_h2[1]
+                    ops.h2_pack(taps, taps_h2[:, :ct // 8])
+                    ops.h2_pack_s2d(f[:, :64], taps_h2[:, ct // 8:])
+                    ops.conv_up2_h2t(taps_h2, h2t[0], hid)
+                    ops.conv_up2_h2t(taps_h2, h2t[1], pre_aff)
+                if h2t is not None:
+                    pass
+                elif hz["x3s"]:
                     f3 = ops.x3_pack(f, self._ftx3[level][1])
                     ops.conv_x3s(f3, hz["ft0_key"], hid, **fq)
                 else:
                     ops.conv_x3(f, hz["ft0_key"], hid, **fq)
                 if h2t is not None:
-                    ops.conv_up2_h2t(taps_h2, h2t[0], hid, pre_add=hid)
+                    pass
                 elif ff:
                     up(taps, hz["ft0_taps"], hid, pre_add=hid, y_fmt=1)
                 else:
                     up(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, pre_add=hid)
-                if hz["x3s"]:
+                if h2t is not None:
+                    pass
+                elif hz["x3s"]:
                     ops.conv_x3s(f3, hz["aff0_key"], pre_aff, **kq)
                 else:
                     ops.conv_x3(f, hz["aff0_key"], pre_aff, **kq)
-                if h2t is not None:
-                    ops.conv_up2_h2t(taps_h2, h2t[1], pre_aff, pre_add=pre_aff)
-                else:
+                if h2t is None:
                     up(taps, hz["aff0_taps"], pre_aff, pre_add=pre_aff, **kq)
             else:
                 ops.conv_up2(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, key=(f, hz["ft0_key"]))

@@ -273,25 +273,30 @@ int bfsr_pack_coupling_tail(const float* w4, int Cin, int Cout, float scale, uns
  * bfsr_coupling_head with Cz = 0 (w0 = NULL at pack time, z = NULL) is the matching producer: hid = relu(AN2(W2 . relu(AN0(pre_aff)))). */
 int bfsr_conv3x3_h2r(const BfsrConvX3Args* a, void* stream);
 
-/* bfsr_conv2d_up2_h2t: 3x3 'same' conv over the nearest-x2 upsampling of an h2 tensor, evaluated at the source resolution by output
- * parity (the 2x2 source taps of each parity with pre-summed weights), fp32-class accuracy (two-term fp16 split, three products).
- * Replaces F.interpolate(block_out, mode='nearest') + torch.cat + the first Conv2d of the level-1 conditioning nets for the 256 RRDB tap
- * channels (SRFlowNet_arch.py:122-137, RRDBNet_arch.py:105-109, FlowAffineCouplingsAblation.py:108-135); the channels that already live at
- * output resolution are convolved by bfsr_conv3x3_h2x first and enter through `pre_add`.
- *   x: h2 view [B][Cin/8][2][h][w][8] (x_bs in fp16 elements), Cin % 16 == 0;  w = bfsr_pack_conv_up2_h2t(w_oihw, Cout, Cin, scale),
- *   acc_scale = 1/scale (scale: the power of two that puts the largest pre-summed |w| into [2^9, 2^10));
+/* bfsr_conv2d_up2_h2t: the first 3x3 conv of a level's conditioning nets over torch.cat([key, F.interpolate(taps, mode='nearest')]) (key: Ckey
+ * channels at the output resolution 2h x 2w; taps: Ct channels at h x w -- the stacked RRDB block outputs), evaluated at the SOURCE resolution by
+ * output parity, fp32-class accuracy (two-term fp16 split, three products).  SRFlowNet_arch.py:122-137, RRDBNet_arch.py:105-109,
+ * FlowAffineCouplingsAblation.py:108-135.  Taps: the 2x2 source pixels of each parity with pre-summed window weights (16 instead of 36 tap
+ * products); key channels: as space-to-depth planes at source resolution (bfsr_h2_pack_s2d), 9 single window taps per plane.
+ *   x: h2 view [B][Cin/8][2][h][w][8] (x_bs in fp16 elements) with Cin = Ct + 4*Ckey channels: the taps first, then plane q = qy*2+qx of key
+ *      channel c at channel Ct + q*Ckey + c; Ct % 16 == 0, Ckey % 16 == 0 (Ckey = 0: no key channels -- they may instead be convolved separately
+ *      and enter through pre_add);  w = bfsr_pack_conv_up2_h2t(w_taps, w_key, Cout, Ct, Ckey, scale), acc_scale = 1/scale (scale: the power of
+ *      two that puts the largest packed |w| into [2^9, 2^10));
  *   y, pre_add: fp32 QUAD-MAJOR [B][Cout/4][2h][2w][4] (y_fmt must be 1; batch strides in floats; pre_add may be NULL or alias y), Cout % 32 == 0:
  *   y = conv / scale + pre_add.  One persistent workgroup per CU; item = 16 x 32 source pixels x 32 output channels x all four parities. */
 typedef struct BfsrUp2H2Args {
-    const unsigned short* x; long long x_bs; int Cin;
+    const unsigned short* x; long long x_bs; int Cin; int Ckey;
     const unsigned short* w; float acc_scale;
     float* y; long long y_bs; int Cout; int y_fmt;
     const float* pre_add; long long pre_add_bs;
     int B, h, w_;                                  /* SOURCE height / width (w_ : `w` is the weight pointer) */
 } BfsrUp2H2Args;
 int bfsr_conv2d_up2_h2t(const BfsrUp2H2Args* a, void* stream);
-long long bfsr_conv_up2_h2t_packed_size(int Cout, int Cin);                          /* fp16 elements */
-int bfsr_pack_conv_up2_h2t(const float* w_oihw, int Cout, int Cin, float scale, unsigned short* packed);
+long long bfsr_conv_up2_h2t_packed_size(int Cout, int Ct, int Ckey);                 /* fp16 elements */
+int bfsr_pack_conv_up2_h2t(const float* w_taps_oihw, const float* w_key_oihw, int Cout, int Ct, int Ckey, float scale, unsigned short* packed);
+/* fp32 [B][C][2h][2w] view -> h2 view with 4C channels at h x w (space to depth): channel q*C + c = pixels (2y+qy, 2x+qx) of channel c, q = qy*2+qx.
+ * flag as for bfsr_h2_pack. */
+int bfsr_h2_pack_s2d(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int C, int h, int w, unsigned* flag, void* stream);
 
 /* squeeze2d / unsqueeze2d, factor 2 (flow.py:122-152): x [B,C,H,W] <-> y [B,4C,H/2,W/2] */
 int bfsr_squeeze2d(const float* x, long long x_bs, float* y, long long y_bs, int B, int C, int H, int W,

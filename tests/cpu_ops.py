@@ -394,14 +394,25 @@ class CpuOps(object):
         w4 = packed[0]
         return self.conv(sum(self._h2_planes(x)), PackedConv(w4, 1), out, epi=epi, act=act, slope=slope, y_fmt=y_fmt)
 
-    def pack_conv_up2_h2t(self, w):
-        w = w.detach().to(torch.float32).clone()
-        return w, 1.0, w.shape[0], w.shape[1]
+    def h2_pack_s2d(self, x, out):
+        return self.h2_pack(F.pixel_unshuffle(x, 2).reshape(x.shape[0], x.shape[1], 4, x.shape[2] // 2, x.shape[3] // 2).transpose(1, 2)
+                            .reshape(x.shape[0], 4 * x.shape[1], x.shape[2] // 2, x.shape[3] // 2), out)
+
+    def pack_conv_up2_h2t(self, w_taps, w_key=None):
+        w = w_taps.detach().to(torch.float32).clone()
+        wk = None if w_key is None else w_key.detach().to(torch.float32).clone()
+        return (w, wk), 1.0, w.shape[0], w.shape[1], 0 if wk is None else wk.shape[1]
 
     def conv_up2_h2t(self, x, packed, out, pre_add=None):
-        """3x3 conv over the nearest-x2 upsampling of the h2 tensor x; out / pre_add hold the quad-major layout."""
+        """conv3x3(cat([key, nearest_up2(taps)])): x = h2 tensor of the taps followed by the space-to-depth planes of the key channels;
+        out / pre_add hold the quad-major layout."""
+        (w, wk), _, Cout, Ct, Ck = packed
         xf = sum(self._h2_planes(x))
-        y = F.conv2d(F.interpolate(xf, scale_factor=2, mode="nearest"), packed[0], None, 1, 1)
+        y = F.conv2d(F.interpolate(xf[:, :Ct], scale_factor=2, mode="nearest"), w, None, 1, 1)
+        if Ck:
+            B, _, h, ww = xf.shape
+            key = F.pixel_shuffle(xf[:, Ct:].reshape(B, 4, Ck, h, ww).transpose(1, 2).reshape(B, 4 * Ck, h, ww), 2)
+            y = y + F.conv2d(key, wk, None, 1, 1)
         if pre_add is not None:
             y = y + self.quads(pre_add, inverse=True)
         out.copy_(self.quads(y))

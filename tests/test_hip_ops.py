@@ -492,21 +492,29 @@ def test_conv_h2r(hip, Cout, hw):
     assert float(wq[:, :4].abs().max()) == 0.0 and float(wq[:, 4 + Cout:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("case", [(2, 32, 64, 16, 32), (1, 64, 32, 21, 37), (3, 16, 96, 5, 70), (2, 256, 64, 40, 40)])
+@pytest.mark.parametrize("case", [(2, 32, 0, 64, 16, 32), (1, 64, 16, 32, 21, 37), (3, 16, 32, 96, 5, 70), (2, 256, 64, 64, 40, 40), (1, 16, 16, 32, 9, 33)])
 def test_conv_up2_h2t(hip, case):
-    """bfsr_conv2d_up2_h2t: conv3x3(nearest_up2(x)) for an h2 tensor x, parity-decomposed at source resolution with pre-summed weights, two-term
-    fp16 split (three products), quad-major fp32 output with and without pre_add (also in place) -- against an fp64 conv of the SAME 22-bit
-    input with the unsplit fp32 weights (SRFlowNet_arch.py:122-137: F.interpolate(..., mode='nearest') + cat + Conv2d); ragged tiles, several
-    output-channel groups, per-channel weight magnitudes over four decades."""
-    B, Cin, Cout, h, w = case
-    x, wt = rnd(301, B, Cin, h, w), rnd(302, Cout, Cin, 3, 3, scale=1.0 / np.sqrt(Cin * 9))
-    wt = wt * torch.logspace(-3, 0, Cout).view(-1, 1, 1, 1) * 2.0
+    """bfsr_conv2d_up2_h2t: conv3x3(cat([key, nearest_up2(taps)])) evaluated at source resolution -- the taps parity-decomposed with pre-summed
+    weights, the key channels (output resolution) as space-to-depth planes (bfsr_h2_pack_s2d) --, two-term fp16 split (three products), quad-major
+    fp32 output with and without pre_add (also in place): against an fp64 conv of the SAME 22-bit inputs with the unsplit fp32 weights
+    (SRFlowNet_arch.py:122-137: F.interpolate(..., mode='nearest') + cat + Conv2d).  Ragged tiles, several output-channel groups, with and without key channels, per-channel weight magnitudes over four decades."""
+    B, Ct, Ck, Cout, h, w = case
+    x, key = rnd(301, B, max(Ct, 1), h, w)[:, :Ct], rnd(304, B, max(Ck, 1), 2 * h, 2 * w)[:, :Ck]
+    wt = rnd(302, Cout, Ct + Ck, 3, 3, scale=1.0 / np.sqrt((Ct + Ck) * 9)) * torch.logspace(-3, 0, Cout).view(-1, 1, 1, 1) * 2.0
     pre = rnd(303, B, Cout, 2 * h, 2 * w)
-    xh = hip.h2_pack(hip.to_device(x), hip.h2_empty(B, Cin, h, w))
-    x22 = hip.h2_unpack(xh, hip.empty(B, Cin, h, w)).cpu()
-    ref64 = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x22.double(), scale_factor=2, mode="nearest"), wt.double(), None, 1, 1)
+    xh = hip.h2_empty(B, Ct + 4 * Ck, h, w)
+    if Ct:
+        hip.h2_pack(hip.to_device(x), xh[:, :Ct // 8])
+    if Ck:
+        hip.h2_pack_s2d(hip.to_device(key), xh[:, Ct // 8:])
+    x22 = hip.h2_unpack(xh, hip.empty(B, Ct + 4 * Ck, h, w)).cpu()
+    k22 = torch.nn.functional.pixel_shuffle(x22[:, Ct:].reshape(B, 4, Ck, h, w).transpose(1, 2).reshape(B, 4 * Ck, h, w), 2) if Ck else key
+    if Ck:
+        assert float((k22 - key).abs().max()) <= 2.0 ** -21 * float(key.abs().max()), "h2_pack_s2d"
+    cat = torch.cat([k22.double(), torch.nn.functional.interpolate(x22[:, :Ct].double(), scale_factor=2, mode="nearest")], 1) if Ct else k22.double()
+    ref64 = torch.nn.functional.conv2d(cat, wt.double(), None, 1, 1)             # the reference's channel order: key first, then the taps
     tol = 4e-6 * float(ref64.abs().max())
-    pk = hip.pack_conv_up2_h2t(wt)
+    pk = hip.pack_conv_up2_h2t(wt[:, Ck:].contiguous(), wt[:, :Ck].contiguous() if Ck else None)
     out = hip.empty(B, Cout, 2 * h, 2 * w)
     out.fill_(float("nan"))
     hip.conv_up2_h2t(xh, pk, out)
@@ -521,7 +529,13 @@ def test_conv_up2_h2t(hip, case):
     assert float(wide[:, :4].abs().max()) == 0.0 and float(wide[:, 4 + Cout:].abs().max()) == 0.0, "wrote outside its channel slice"
     hip.conv_up2_h2t(xh, pk, pq, pre_add=pq)                           # in place
     assert torch.equal(pq.cpu(), wide[:, 4:4 + Cout].cpu().contiguous()), "in-place pre_add differs from the two-buffer call"
-    cpu = CPU.conv_up2_h2t(CPU.h2_pack(x, CPU.h2_empty(B, Cin, h, w)), CPU.pack_conv_up2_h2t(wt), torch.empty(B, Cout, 2 * h, 2 * w), pre_add=CPU.quads(pre))
+    xc = CPU.h2_empty(B, Ct + 4 * Ck, h, w)
+    if Ct:
+        CPU.h2_pack(x, xc[:, :Ct // 8])
+    if Ck:
+        CPU.h2_pack_s2d(key, xc[:, Ct // 8:])
+    cpu = CPU.conv_up2_h2t(xc, CPU.pack_conv_up2_h2t(wt[:, Ck:].contiguous(), wt[:, :Ck].contiguous() if Ck else None), torch.empty(B, Cout, 2 * h, 2 * w),
+                           pre_add=CPU.quads(pre))
     close(pq, cpu, 2e-5, "conv_up2_h2t vs the CPU test double")
 
 

@@ -137,10 +137,9 @@ def roof_entry(t, k, f, n, steps, step_ms, traffic_db):
 def load_traffic():
     """per-launch HBM-side bytes from the committed PMC passes of this round (separate --pmc runs, profiles/), keyed by launch shape"""
     db = {}
-    for name in ("r02_pmc_traffic.json", "r03_pmc_traffic.json", "r03f_pmc_traffic.json", "r03f_pmc_traffic_cfg3.json"):
-        p = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(p):
-            db.update(json.load(open(p)).get("kernels", {}))
+    import glob
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_pmc_traffic*.json"))):   # rounds in order: later passes override
+        db.update(json.load(open(p)).get("kernels", {}))
     return db
 
 

@@ -200,6 +200,7 @@ SYMBOLS = {
     "bfsr_resample_taps": (_I, [_VP, _LL, _VP, _LL, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _VP]),
     "bfsr_sqdiff_sum": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _I, _I, _F, _VP, _VP]),
     "bfsr_ssim_sum": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, C.c_double, _VP, _VP, _VP]),
+    "bfsr_ssim_sum_w": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, C.c_double, _I, _VP, C.c_double, _VP, _VP]),
     "bfsr_to_uint8": (_I, [_VP, _LL, _VP, _I, _LL, _VP]),
     "bfsr_conv2d_direct": (_I, [_VP, _LL, _VP, _VP, _VP, _LL, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _VP]),
 }

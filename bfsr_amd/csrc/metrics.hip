@@ -6,6 +6,8 @@
 //                        (calc_psnr, utils.py:132-149); PSNR = -10*log10(sum/count) on the host
 //   bfsr_ssim_sum      : per-(sample,channel) sum of the SSIM map, 11x11 Gaussian window sigma 1.5, 'valid' region,
 //                        fp64 like the reference's cv2 path (utils.py:152-171)
+//   bfsr_ssim_sum_w    : the same with a caller-given WS x WS window and covariance normalisation (WS = 7 uniform, NP/(NP-1): the
+//                        skimage.metrics.structural_similarity call of SRFlow-LP/code/Measure.py:45-48)
 //   bfsr_to_uint8      : round(clamp(x,0,1)*255) -> uint8 (round-half-even like numpy .round(), test.py:210-212)
 #include <hip/hip_runtime.h>
 #include "../../include/bfsr_hip.h"
@@ -71,13 +73,15 @@ __global__ __launch_bounds__(256) void sqdiff_sum_kernel(const float* __restrict
     block_atomic_add_d(acc, out + b);
 }
 
-// one thread per valid pixel of one (sample, channel) plane; images are scaled by `scale` (255 for [0,1] inputs) first
+// one thread per valid pixel of one (sample, channel) plane; images are scaled by `scale` (255 for [0,1] inputs) first.  WS x WS window
+// `win` (WS <= 11), 'valid' region (H-WS+1) x (W-WS+1); variances / covariance multiplied by cov_norm (1 for utils.calculate_ssim;
+// NP/(NP-1) for skimage's sample covariance).
 __global__ __launch_bounds__(256) void ssim_sum_kernel(const float* __restrict__ a, long long a_bs, const float* __restrict__ b_,
-                                                       long long b_bs, int C, int H, int W, double scale, const double* __restrict__ win,
-                                                       double* __restrict__ out)
+                                                       long long b_bs, int C, int H, int W, double scale, int WS, const double* __restrict__ win,
+                                                       double cov_norm, double* __restrict__ out)
 {
     const int bc = blockIdx.y, b = bc / C, c = bc % C;
-    const int VH = H - 10, VW = W - 10;
+    const int VH = H - WS + 1, VW = W - WS + 1;
     const float* pa = a + (long long)b * a_bs + (long long)c * H * W;
     const float* pb = b_ + (long long)b * b_bs + (long long)c * H * W;
     const double C1 = (0.01 * 255) * (0.01 * 255), C2 = (0.03 * 255) * (0.03 * 255);
@@ -85,14 +89,14 @@ __global__ __launch_bounds__(256) void ssim_sum_kernel(const float* __restrict__
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (long long)VH * VW; i += (long long)gridDim.x * 256) {
         const int vx = (int)(i % VW), vy = (int)(i / VW);
         double m1 = 0, m2 = 0, s11 = 0, s22 = 0, s12 = 0;
-        for (int dy = 0; dy < 11; ++dy)
-            for (int dx = 0; dx < 11; ++dx) {
-                const double wv = win[dy * 11 + dx];
+        for (int dy = 0; dy < WS; ++dy)
+            for (int dx = 0; dx < WS; ++dx) {
+                const double wv = win[dy * WS + dx];
                 const double p = (double)pa[(long long)(vy + dy) * W + vx + dx] * scale;
                 const double q = (double)pb[(long long)(vy + dy) * W + vx + dx] * scale;
                 m1 += wv * p; m2 += wv * q; s11 += wv * p * p; s22 += wv * q * q; s12 += wv * p * q;
             }
-        const double v1 = s11 - m1 * m1, v2 = s22 - m2 * m2, cv = s12 - m1 * m2;
+        const double v1 = cov_norm * (s11 - m1 * m1), v2 = cov_norm * (s22 - m2 * m2), cv = cov_norm * (s12 - m1 * m2);
         acc += ((2 * m1 * m2 + C1) * (2 * cv + C2)) / ((m1 * m1 + m2 * m2 + C1) * (v1 + v2 + C2));
     }
     block_atomic_add_d(acc, out + bc);
@@ -131,15 +135,22 @@ extern "C" int bfsr_sqdiff_sum(const float* a, long long a_bs, const float* b, l
     return (int)hipGetLastError();
 }
 
+extern "C" int bfsr_ssim_sum_w(const float* a, long long a_bs, const float* b, long long b_bs, int B, int C, int H, int W, double scale,
+                               int ws, const double* window, double cov_norm, double* out, void* stream)
+{
+    if (!a || !b || !out || !window || B <= 0 || C <= 0 || ws < 1 || ws > 11 || H < ws || W < ws) return -1;
+    long long blocks = ((long long)(H - ws + 1) * (W - ws + 1) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(ssim_sum_kernel, dim3((unsigned)blocks, (unsigned)(B * C)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       a, a_bs, b, b_bs, C, H, W, scale, ws, window, cov_norm, out);
+    return (int)hipGetLastError();
+}
+
 extern "C" int bfsr_ssim_sum(const float* a, long long a_bs, const float* b, long long b_bs, int B, int C, int H, int W, double scale,
                              const double* window121, double* out, void* stream)
 {
-    if (!a || !b || !out || !window121 || B <= 0 || C <= 0 || H <= 10 || W <= 10) return -1;
-    long long blocks = ((long long)(H - 10) * (W - 10) + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(ssim_sum_kernel, dim3((unsigned)blocks, (unsigned)(B * C)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       a, a_bs, b, b_bs, C, H, W, scale, window121, out);
-    return (int)hipGetLastError();
+    if (H <= 10 || W <= 10) return -1;
+    return bfsr_ssim_sum_w(a, a_bs, b, b_bs, B, C, H, W, scale, 11, window121, 1.0, out, stream);
 }
 
 extern "C" int bfsr_to_uint8(const float* x, long long x_bs, unsigned char* y, int B, long long n, void* stream)

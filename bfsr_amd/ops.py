@@ -990,6 +990,18 @@ class HipOps(object):
             ap, abs_, bp, bbs, a.shape[0], Cc, H, W, float(scale), window121.data_ptr(), out.data_ptr(), self._stream())), "ssim_sum")
         return out.view(a.shape[0], Cc)
 
+    def ssim_sum_w(self, a, b, window, cov_norm=1.0, scale=1.0):
+        """float64 [B,C]: sum of the SSIM map over the valid region for a ws x ws window (float64 [ws*ws] on the device, ws <= 11), variances and
+        covariance multiplied by cov_norm (metrics.hip, bfsr_ssim_sum_w)."""
+        ap, abs_, Cc, H, W = _view(a, "ssim_sum_w.a")
+        bp, bbs, c2, h2, w2 = _view(b, "ssim_sum_w.b")
+        ws = int(round(window.numel() ** 0.5))
+        assert (Cc, H, W) == (c2, h2, w2) and window.dtype == torch.float64 and ws * ws == window.numel()
+        out = self.zeros_f64(a.shape[0] * Cc)
+        _lib.check(self._launch(("ssim_sum_w", ws) + tuple(a.shape), lambda: self.lib.bfsr_ssim_sum_w(
+            ap, abs_, bp, bbs, a.shape[0], Cc, H, W, float(scale), ws, window.data_ptr(), float(cov_norm), out.data_ptr(), self._stream())), "ssim_sum_w")
+        return out.view(a.shape[0], Cc)
+
     def to_uint8(self, x):
         """uint8 [B,C,H,W] = round(clamp(x,0,1)*255), half-to-even."""
         xp, xbs, Cc, H, W = _view(x, "to_uint8.x")

@@ -21,5 +21,25 @@ class Measure(object):
             return float("inf")
         return float(10.0 * np.log10(255.0 ** 2 / mse))
 
-    def measure(self, imgA, imgB):
-        raise NotImplementedError("Measure.measure also needs SSIM (skimage) and LPIPS (pretrained AlexNet): outside the path")
+    def ssim(self, imgA, imgB):
+        """imgA, imgB: uint8 HWC arrays -> float, Measure.py:45-48: skimage.metrics.structural_similarity(imgA, imgB, full=True,
+        multichannel=True) for uint8 inputs = uniform 7x7 filter, sample covariance (x 49/48), K1 = 0.01, K2 = 0.03, data_range 255, the SSIM
+        map averaged over the image cropped by 3 pixels, then over the channels.  On the device: bfsr_ssim_sum_w (metrics.hip)."""
+        ops = self.ops
+        f = lambda im: ops.to_device(torch.as_tensor(np.asarray(im)).permute(2, 0, 1).unsqueeze(0).to(torch.float32).contiguous())
+        a, b = f(imgA), f(imgB)
+        if a.shape != b.shape or a.shape[2] < 7 or a.shape[3] < 7:
+            raise ValueError("Measure.ssim: images must have the same shape and be at least 7x7 (skimage raises for smaller images)")
+        win = torch.full((49,), 1.0 / 49.0, dtype=torch.float64, device=a.device)
+        s = ops.ssim_sum_w(a, b, win, cov_norm=49.0 / 48.0, scale=1.0)                 # float64 [1, C] sums over the (H-6) x (W-6) region
+        return float(s.sum()) / (a.shape[1] * (a.shape[2] - 6) * (a.shape[3] - 6))
+
+    def lpips(self, imgA, imgB, model=None):
+        raise NotImplementedError("Measure.lpips needs the pretrained AlexNet LPIPS weights (lpips package): outside the path, not in this image")
+
+    def measure(self, imgA, imgB, with_lpips=True):
+        """Measure.py:37-38: [psnr, ssim, lpips].  LPIPS cannot be computed here (pretrained network); with_lpips=False returns [psnr, ssim]."""
+        out = [float(self.psnr(imgA, imgB)), float(self.ssim(imgA, imgB))]
+        if with_lpips:
+            out.append(float(self.lpips(imgA, imgB)))
+        return out

@@ -60,6 +60,17 @@ def pad_lr_to_even(lr):
     return np.pad(lr, [(0, int(np.ceil(h / 2) * 2 - h)), (0, int(np.ceil(w / 2) * 2 - w)), (0, 0)], 'reflect')
 
 
+def pad_lr_to_even_t(lr_t):
+    """The same pad (test.py:126-130) on an uploaded [B,3,h,w] tensor: at most one reflected row / column (numpy's 'reflect' excludes the
+    edge: the appended row is row h-2), by slicing on the device -- no host round trip between the image upload and the engine."""
+    h, w = lr_t.shape[2], lr_t.shape[3]
+    if h % 2:
+        lr_t = torch.cat([lr_t, lr_t[:, :, h - 2:h - 1] if h > 1 else lr_t], 2)
+    if w % 2:
+        lr_t = torch.cat([lr_t, lr_t[:, :, :, w - 2:w - 1] if w > 1 else lr_t], 3)
+    return lr_t.contiguous()
+
+
 def _lp_lane(eng, prior_eng, lr, scale, sr_out, keep=None):
     """The LP block (test.py:126-151) on engine level; writes clamp(sr) into sr_out."""
     ops = eng.ops
@@ -108,7 +119,8 @@ def main(argv=None):
     for idx, p in enumerate(lr_paths):
         lr = np.asarray(Image.open(p).convert('RGB'))
         h, w, _ = lr.shape
-        lr_t = torch.from_numpy(pad_lr_to_even(lr).transpose(2, 0, 1)[None].astype(np.float32)) / 255
+        ops = model.netG.module.engine().ops
+        lr_t = pad_lr_to_even_t(ops.to_device(torch.from_numpy(lr.transpose(2, 0, 1)[None].astype(np.float32)) / 255))
         sr = lp_infer(model, prior, lr_t)
         img = (np.clip(sr[0].cpu().numpy().transpose(1, 2, 0), 0, 1) * 255).astype(np.uint8)[:h * scale, :w * scale]
         Image.fromarray(img).save(os.path.join(out_dir, "{:06d}.png".format(idx)))

@@ -437,6 +437,12 @@ int bfsr_sqdiff_sum(const float* a, long long a_bs, const float* b, long long b_
                     int luma, float rgb_range, double* out, void* stream);
 int bfsr_ssim_sum(const float* a, long long a_bs, const float* b, long long b_bs, int B, int C, int H, int W, double scale,
                   const double* window121, double* out, void* stream);
+/* bfsr_ssim_sum_w: bfsr_ssim_sum with a caller-given ws x ws window (ws <= 11, 'valid' region (H-ws+1) x (W-ws+1)) and the variances /
+ * covariance multiplied by cov_norm -- ws = 7, window = 1/49, cov_norm = 49/48 on 0..255 images (scale 1) is
+ * skimage.metrics.structural_similarity(imgA, imgB, multichannel=True) for uint8 inputs (uniform 7x7 filter, sample covariance, data_range 255,
+ * mean over the image cropped by 3), the call of SRFlow-LP/code/Measure.py:45-48. */
+int bfsr_ssim_sum_w(const float* a, long long a_bs, const float* b, long long b_bs, int B, int C, int H, int W, double scale,
+                    int ws, const double* window, double cov_norm, double* out, void* stream);
 int bfsr_to_uint8(const float* x, long long x_bs, unsigned char* y, int B, long long n, void* stream);
 
 #ifdef __cplusplus

@@ -9,6 +9,10 @@ metrics right after the LINF-LP hot path.
       filter2D), which this image does not have, so it cannot be run here: PARITY UNPINNED for SSIM; the restatement follows
       the published formula (11x11 Gaussian sigma 1.5, 'valid' region, C1/C2 of the [0,255] range) and is held to
       known-answer properties in the tests.
+  skimage_ssim                     : SRFlow-LP/code/Measure.py:45-48 calls skimage.metrics.structural_similarity(imgA, imgB, full=True,
+      multichannel=True) on uint8 images -- a third-party dependency (scikit-image, unpinned in the reference's requirements; the
+      algorithm below is the one of scikit-image 0.16-0.19, `skimage/metrics/_structural_similarity.py`) that is NOT in this image:
+      PARITY UNPINNED; restated from the published algorithm and held to known-answer properties in the tests.
 """
 from math import ceil
 
@@ -98,3 +102,23 @@ def ssim(img1, img2):
 def calculate_ssim(img1, img2):
     """utils.py:174-193 for HxWx3 [0,255] images: mean over the 3 channels."""
     return float(np.mean([ssim(img1[:, :, i], img2[:, :, i]) for i in range(img1.shape[2])]))
+
+
+def skimage_ssim(imgA, imgB):
+    """skimage.metrics.structural_similarity(imgA, imgB, multichannel=True) for uint8 HxWxC images with its defaults (Measure.py:45-48):
+    win_size 7, uniform filter, use_sample_covariance (cov_norm = 49/48), K1 = 0.01, K2 = 0.03, data_range 255 (the uint8 dtype range),
+    images cast to float64 unscaled; per channel the SSIM map is averaged over the image cropped by (win_size - 1) // 2 = 3 pixels, then
+    the channel means are averaged."""
+    from scipy.ndimage import uniform_filter
+    a, b = np.asarray(imgA), np.asarray(imgB)
+    assert a.shape == b.shape and a.dtype == np.uint8 and b.dtype == np.uint8 and a.ndim == 3 and min(a.shape[:2]) >= 7
+    C1, C2, cov_norm = (0.01 * 255) ** 2, (0.03 * 255) ** 2, 49.0 / 48.0
+    vals = []
+    for c in range(a.shape[2]):
+        x, y = a[:, :, c].astype(np.float64), b[:, :, c].astype(np.float64)
+        ux, uy = uniform_filter(x, size=7), uniform_filter(y, size=7)
+        uxx, uyy, uxy = uniform_filter(x * x, size=7), uniform_filter(y * y, size=7), uniform_filter(x * y, size=7)
+        vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+        S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
+        vals.append(S[3:-3, 3:-3].mean())
+    return float(np.mean(vals))

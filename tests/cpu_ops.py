@@ -480,6 +480,18 @@ class CpuOps(object):
         smap = ((2 * m1 * m2 + C1) * (2 * cv + C2)) / ((m1 * m1 + m2 * m2 + C1) * (v1 + v2 + C2))
         return smap.sum(dim=(1, 2, 3)).view(B, Cc)
 
+    def ssim_sum_w(self, a, b, window, cov_norm=1.0, scale=1.0):
+        ws = int(round(window.numel() ** 0.5))
+        k = window.view(1, 1, ws, ws)
+        B, Cc, H, W = a.shape
+        p, q = (a.double() * scale).reshape(B * Cc, 1, H, W), (b.double() * scale).reshape(B * Cc, 1, H, W)
+        f = lambda t: F.conv2d(t, k)
+        m1, m2 = f(p), f(q)
+        v1, v2, cv = cov_norm * (f(p * p) - m1 * m1), cov_norm * (f(q * q) - m2 * m2), cov_norm * (f(p * q) - m1 * m2)
+        C1, C2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+        smap = ((2 * m1 * m2 + C1) * (2 * cv + C2)) / ((m1 * m1 + m2 * m2 + C1) * (v1 + v2 + C2))
+        return smap.sum(dim=(1, 2, 3)).view(B, Cc)
+
     def to_uint8(self, x):
         return torch.round(torch.clamp(x, 0, 1) * 255.0).to(torch.uint8)
 

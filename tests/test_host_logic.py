@@ -330,3 +330,14 @@ def test_fp16_pair_packers_layout_and_accuracy():
         ref = ws[1][row, kidx].double() * sc[1]
         assert abs(got - ref) <= tol(ref)
     assert lib.bfsr_pack_linf_mlp(ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), ws[3].data_ptr(), HD, Co4, 2, p.data_ptr()) != 0     # needs the scales
+
+
+def test_pad_lr_to_even_on_tensor_equals_numpy_reflect():
+    """test.py:126-130's np.pad(..., 'reflect') up to even H and W, done by slicing on the uploaded tensor"""
+    from bfsr_amd.srflow.test import pad_lr_to_even, pad_lr_to_even_t
+    g = np.random.Generator(np.random.PCG64(4))
+    for h, w in ((7, 9), (8, 5), (6, 4), (3, 3)):
+        lr = g.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        ref = pad_lr_to_even(lr).transpose(2, 0, 1)[None].astype(np.float32) / 255
+        got = pad_lr_to_even_t(torch.from_numpy(lr.transpose(2, 0, 1)[None].astype(np.float32)) / 255)
+        assert got.shape == ref.shape and np.array_equal(got.numpy(), ref)

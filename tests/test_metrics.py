@@ -78,6 +78,21 @@ def _check_ssim_and_measure(ops, golden_dir):
     from bfsr_amd.srflow.Measure import Measure
     m = np.load(os.path.join(golden_dir, "srflow_measure.npz"))
     assert abs(Measure(ops).psnr(m["a"], m["b"]) - float(m["psnr"])) <= 1e-6
+    # Measure.ssim (skimage's structural_similarity, restated in oracle/metrics_ref.skimage_ssim: scikit-image is not in this image, parity unpinned)
+    me = Measure(ops)
+    a, b = m["a"], m["b"]
+    assert abs(me.ssim(a, b) - O.skimage_ssim(a, b)) <= 1e-9
+    assert abs(me.ssim(a, a) - 1.0) <= 1e-12 and abs(me.ssim(a, b) - me.ssim(b, a)) <= 1e-12
+    g = np.random.Generator(np.random.PCG64(9))
+    r1 = g.integers(0, 256, size=(23, 31, 3), dtype=np.uint8)
+    r2 = np.clip(r1.astype(np.int32) + g.integers(-20, 21, size=r1.shape), 0, 255).astype(np.uint8)
+    assert abs(me.ssim(r1, r2) - O.skimage_ssim(r1, r2)) <= 1e-9
+    flat = np.full((9, 9, 3), 100, np.uint8)                   # constant images: means only, SSIM = (2 m1 m2 + C1) / (m1^2 + m2^2 + C1)
+    flat2 = np.full((9, 9, 3), 110, np.uint8)
+    assert abs(me.ssim(flat, flat2) - (2 * 100 * 110 + 6.5025) / (100 ** 2 + 110 ** 2 + 6.5025)) <= 1e-12
+    assert me.measure(a, b, with_lpips=False) == [me.psnr(a, b), me.ssim(a, b)]
+    with pytest.raises(NotImplementedError):
+        me.measure(a, b)
 
 
 def test_ssim_and_measure_on_cpu_double(golden_dir):

@@ -105,26 +105,74 @@ def lp_infer(model, prior_model, lr_t, return_all=False, check_range=True):
     return keep if return_all else sr
 
 
+def format_measurements(meas):
+    """test.py:176-182."""
+    return ", ".join("%s: %s" % (k, ("%0.4f" % v) if isinstance(v, float) else v) for k, v in meas.items())
+
+
+def lr_reconstruct_uint8(ops, sr_u8, scale):
+    """test.py:159 `imresize(sr, 1 / scale)` for a uint8 HWC image: MATLAB-style antialiased bicubic, rows then columns, the result of EACH pass
+    clipped and rounded to uint8 (imresize.py:113-125, :166-168) -- on the device: resample_taps + to_uint8 per pass (fp32 taps; the
+    reference accumulates in float64, so a value within ~1e-5 of a rounding tie may land on the other side)."""
+    from ..linf import metrics
+    x = ops.to_device(torch.as_tensor(np.asarray(sr_u8)).permute(2, 0, 1).unsqueeze(0).to(torch.float32) / 255.0)
+    B, C, H, W = x.shape
+    oh, ow = int(np.ceil(H / scale)), int(np.ceil(W / scale))
+    tabs = []
+    for n_in, n_out in ((H, oh), (W, ow)):
+        w, i = metrics.imresize_tables(n_in, n_out, 1.0 / scale)
+        tabs.append((torch.from_numpy(np.ascontiguousarray(i)).to(x.device), torch.from_numpy(np.ascontiguousarray(w.astype(np.float32))).to(x.device)))
+    mid = ops.to_uint8(ops.resample_taps(x, ops.empty(B, C, oh, W), tabs[0][0], tabs[0][1], 0)).to(torch.float32) / 255.0
+    out = ops.to_uint8(ops.resample_taps(mid.contiguous(), ops.empty(B, C, oh, ow), tabs[1][0], tabs[1][1], 1))
+    return out[0].permute(1, 2, 0).cpu().numpy()
+
+
 def main(argv=None):
+    """test.py:85-174: every LR image of `dataroot_LR` through the LP pipeline, SR images to ../results/SRFlow-LP/; when `dataroot_GT` holds the
+    HR images, PSNR / SSIM / LR-consistency PSNR per image into measure_full.csv like the reference (the LPIPS column stays empty: its
+    pretrained network is not available here)."""
     argv = argv if argv is not None else sys.argv[1:]
     if len(argv) != 1:
         raise SystemExit("usage: python -m bfsr_amd.srflow.test <conf.yml>")
+    from collections import OrderedDict
     from PIL import Image
+    from .Measure import Measure
     model, opt = load_model(argv[0])
     prior = load_prior(opt)
     scale = opt['scale']
+    conf = os.path.basename(argv[0]).replace('.yml', '')
     lr_paths = natsorted(glob.glob(os.path.join(opt['dataroot_LR'], '*.png')))     # test.py:37-38 uses natsort
+    hr_dir = opt.get('dataroot_GT') if hasattr(opt, 'get') else None
+    hr_paths = natsorted(glob.glob(os.path.join(hr_dir, '*.png'))) if hr_dir else []
     out_dir = os.path.join(os.path.dirname(os.path.abspath(argv[0])), '..', 'results', 'SRFlow-LP')
     os.makedirs(out_dir, exist_ok=True)
+    ops = model.netG.module.engine().ops
+    measure, rows = Measure(ops), []
     for idx, p in enumerate(lr_paths):
         lr = np.asarray(Image.open(p).convert('RGB'))
         h, w, _ = lr.shape
-        ops = model.netG.module.engine().ops
         lr_t = pad_lr_to_even_t(ops.to_device(torch.from_numpy(lr.transpose(2, 0, 1)[None].astype(np.float32)) / 255))
         sr = lp_infer(model, prior, lr_t)
         img = (np.clip(sr[0].cpu().numpy().transpose(1, 2, 0), 0, 1) * 255).astype(np.uint8)[:h * scale, :w * scale]
         Image.fromarray(img).save(os.path.join(out_dir, "{:06d}.png".format(idx)))
-        print("wrote %06d.png" % idx)
+        if idx < len(hr_paths):
+            hr = np.asarray(Image.open(hr_paths[idx]).convert('RGB'))
+            meas = OrderedDict(conf=conf, name=idx)
+            meas['PSNR'], meas['SSIM'] = measure.measure(img, hr, with_lpips=False)
+            meas['LPIPS'] = float('nan')
+            meas['LRC PSNR'] = measure.psnr(lr, lr_reconstruct_uint8(ops, img, scale))
+            rows.append(meas)
+            print(format_measurements(meas))
+        else:
+            print("wrote %06d.png" % idx)
+    if rows:
+        import pandas as pd
+        df = pd.DataFrame(rows[::-1])                                 # the reference prepends each row (test.py:166)
+        path = os.path.join(out_dir, 'measure_full.csv')
+        df.to_csv(path + "_", index=False)
+        os.replace(path + "_", path)
+        print("Results in: %s" % path)
+        print("Mean: " + format_measurements(OrderedDict((k, float(v)) for k, v in df.drop(columns=['conf']).mean().items())))
 
 
 if __name__ == "__main__":

@@ -341,3 +341,42 @@ def test_pad_lr_to_even_on_tensor_equals_numpy_reflect():
         ref = pad_lr_to_even(lr).transpose(2, 0, 1)[None].astype(np.float32) / 255
         got = pad_lr_to_even_t(torch.from_numpy(lr.transpose(2, 0, 1)[None].astype(np.float32)) / 255)
         assert got.shape == ref.shape and np.array_equal(got.numpy(), ref)
+
+
+def test_cli_writes_images_and_measures_csv(tmp_path, monkeypatch):
+    """`python -m bfsr_amd.srflow.test conf.yml` on two tiny images (odd sizes -> reflect pad) with the CPU double: SR PNGs cropped to
+    scale * (h, w) and measure_full.csv with the reference's columns (test.py:150-171); PSNR / SSIM rows equal Measure's own values."""
+    import pandas as pd
+    from PIL import Image
+    from bfsr_amd.srflow import test as cli
+    from bfsr_amd.srflow.Measure import Measure
+    from bfsr_amd.srflow.models import create_model, models as registry
+    ops = CpuOpsX3()
+    opt = options.load(options.DEFAULT_CONF)
+    m = create_model(opt, ops=ops)
+    m.load_network(synth.state_dict_from_schema(spec.srflownet_schema(opt), 1234))
+    prior = registry.make({"name": "unet", "args": {"depth": 3, "dim": 64, "bilinear": True, "ops": ops},
+                           "sd": synth.state_dict_from_schema(spec.srflow_prior_schema(), 4321)}, load_sd=True).eval()
+    lr_dir, hr_dir, conf_dir = tmp_path / "lr", tmp_path / "hr", tmp_path / "confs"
+    for d in (lr_dir, hr_dir, conf_dir):
+        d.mkdir()
+    g = np.random.Generator(np.random.PCG64(2))
+    sizes = [(17, 20), (18, 19)]
+    for i, (h, w) in enumerate(sizes):
+        Image.fromarray(g.integers(0, 256, size=(h, w, 3), dtype=np.uint8)).save(str(lr_dir / ("%d.png" % i)))
+        Image.fromarray(g.integers(0, 256, size=(4 * h, 4 * w, 3), dtype=np.uint8)).save(str(hr_dir / ("%d.png" % i)))
+    opt["dataroot_LR"], opt["dataroot_GT"] = str(lr_dir), str(hr_dir)
+    monkeypatch.setattr(cli, "load_model", lambda path: (m, opt))
+    monkeypatch.setattr(cli, "load_prior", lambda o: prior)
+    cli.main([str(conf_dir / "SRFlow-LP_test.yml")])
+    out = tmp_path / "results" / "SRFlow-LP"
+    df = pd.read_csv(str(out / "measure_full.csv"))
+    assert list(df.columns) == ["conf", "name", "PSNR", "SSIM", "LPIPS", "LRC PSNR"] and len(df) == 2 and set(df["name"]) == {0, 1}
+    me = Measure(ops)
+    for i, (h, w) in enumerate(sizes):
+        sr = np.asarray(Image.open(str(out / ("%06d.png" % i))))
+        assert sr.shape == (4 * h, 4 * w, 3)
+        hr = np.asarray(Image.open(str(hr_dir / ("%d.png" % i))))
+        row = df[df["name"] == i].iloc[0]
+        assert abs(row["PSNR"] - me.psnr(sr, hr)) <= 1e-9 and abs(row["SSIM"] - me.ssim(sr, hr)) <= 1e-9 and np.isnan(row["LPIPS"])
+        assert 5.0 < row["LRC PSNR"] < 100.0

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_up2_h2t_kernel(BfsrUp2H2Args
             if constexpr ((S == 0 || group_of(TYPE, S - 1) != G) && NG_ < NS)      // first step of a group: prefetch the next group's rows
                 load_x(std::integral_constant<int, (G + 1) & 1>(), stg, step_info(TYPE, NG_).cs);
             if constexpr (S + 1 < NS) load_w(std::integral_constant<int, (S + 1) & 1>(), stg, S + 1);
-            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);                           // (without the fences: 6.58 vs 6.67 ms; s_setprio 1 / 3 around the MFMAs: 6.77 -- noise)
             mfma_step(t_, s_);
             if constexpr (S < NXP + NWP) lpiece(S, lk, stg ^ 1);
             __builtin_amdgcn_sched_barrier(0);

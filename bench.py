@@ -291,10 +291,13 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + 1 + i)
-    gatherer.finish()
+    gathered = gatherer.finish()
     torch.cuda.synchronize()
     bdist.barrier()
     dt = time.perf_counter() - t0
+    if torch.distributed.is_initialized() and (gathered is None or gathered.shape[0] != global_B):
+        raise SystemExit("bench: the gathered output of the last step has %s rows, expected the global batch %d"
+                         % (None if gathered is None else gathered.shape[0], global_B))
     ops.profile_keys = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)

@@ -331,7 +331,8 @@ class SRFlowEngine(object):
                 return (pv is not None and pv.type == "step" and pv.coupled and pv.level == level
                         and getattr(self.steps[pv.index], "fused", False))
             hz["hft_q4"] = set(i for i in idxs if getattr(self.steps[i], "fused", False) and _prev_is_fused_step(i))
-            hz["ffast"] = fused_all and all(self.steps[i].fthead is not None for i in idxs) and self._taps_up2(level) in (0, 1)
+            # (the x4 taps kernel has no quad-major epilogue: at that level the raw fFeatures.0 result stays NCHW and the 1x1-only head reads it so)
+            hz["ffast"] = fused_all and all(self.steps[i].fthead is not None for i in idxs) and self._taps_up2(level) in (0, 1, 2)
             hz["pre_q4"] = fused_all and (self._taps_up2(level) in (0, 1, False, None)) and getattr(ops, "conv_mode", "f32") == "x3"
             # Round 3: the 64 -> 16*64 key convs of the finer levels run on conv_x3s (LDS-DMA staging by loader waves, persistent) over
             # an x3 copy of the key channels instead of the register-staged conv_bf16x3 kernel: 5.51 -> 4.80 ms at 8 x 320^2
@@ -523,11 +524,12 @@ class SRFlowEngine(object):
         hq = {i: int(quads and i in hz.get("hft_q4", ())) for i in hz["idxs"]}
         kq = dict(y_fmt=1) if pq else {}
         ff = bool(hz.get("ffast")) and hz.get("x3", True) is not False
+        ffq = int(ff and not (hz["up2"] and hz.get("up") == 2))     # layout of the raw fFeatures.0 result the 1x1-only head reads: 1 quad-major, 0 NCHW
         if hz["up2"]:
             taps = ft[self._lr_level()][:, 64:]
             if hz["x3"]:
                 up = ops.conv_up4_x3 if hz["up"] == 2 else ops.conv_up2_x3
-                fq = dict(y_fmt=1) if ff else {}                       # ffast: raw conv result, quad-major (the 1x1-only head applies ActNorm + ReLU)
+                fq = dict(y_fmt=1) if ffq else {}                      # ffast: raw conv result, quad-major where the kernels can (the 1x1-only head applies ActNorm + ReLU)
                 h2t = hz.get("h2t") if (ff and pq and hz["x3s"]) else None
                 if h2t is not None:
                     # one h2 tensor at LR resolution: the 256 tap channels, then the four space-to-depth planes of the 64 key channels
@@ -551,7 +553,7 @@ class SRFlowEngine(object):
                 if h2t is not None:
                     pass
                 elif ff:
-                    up(taps, hz["ft0_taps"], hid, pre_add=hid, y_fmt=1)
+                    up(taps, hz["ft0_taps"], hid, pre_add=hid, **fq)
                 else:
                     up(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, pre_add=hid)
                 if h2t is not None:
@@ -579,7 +581,7 @@ class SRFlowEngine(object):
                 h2 = self._hid.get(key)
                 if h2 is None or tuple(h2.shape) != (B, 8, 2, hk.shape[2], hk.shape[3], 8):
                     h2 = self._hid[key] = ops.h2_empty(B, 64, hk.shape[2], hk.shape[3])
-                ops.coupling_head(None, st.fthead, hk, h2, pre_fmt=1)
+                ops.coupling_head(None, st.fthead, hk, h2, pre_fmt=ffq)
                 for pk, epi, g0, g1 in st.ft4r:
                     ops.conv_h2r(h2, pk, h_ft[:, 2 * Cz * k + g0: 2 * Cz * k + g1], epi=epi, y_fmt=hq[i])
                 continue

@@ -248,7 +248,7 @@ def test_end_to_end_error_vs_fp64(hip):
     opt = options.load(options.DEFAULT_CONF)
     sd = synth.state_dict_from_schema(spec.srflownet_schema(opt), 1234)
     psd = synth.state_dict_from_schema(spec.srflow_prior_schema(), 4321)
-    lr = synth.smooth_lr_batch(3, 1, 24, 24)              # the two CPU oracle runs (fp64, fp32) dominate this test's time
+    lr = synth.smooth_lr_batch(3, 1, 16, 16)              # the two CPU oracle runs (fp64, fp32) dominate this test's time
     dbl = lambda m: {k: (v.double() if v.is_floating_point() else v) for k, v in m.items()}
     truth = O.lp_pipeline(lr.double(), dbl(sd), dbl(psd), opt, 23, return_all=True)
     cpu32 = O.lp_pipeline(lr, sd, psd, opt, 23, return_all=True)

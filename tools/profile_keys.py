@@ -1,5 +1,5 @@
 """Per-launch-shape time table of one SRFlow-LP pass (cfg2) from in-situ HIP events on every launch.
-Usage (GPU box): python tools/profile_keys.py [--batch 8] [--lr 160] [--top 40]"""
+Usage (GPU box): python tools/profile_keys.py [--batch 8] [--lr 160] [--scale 4|8] [--top 40]   (config 4: --scale 8 --batch 64 --lr 96)"""
 import argparse
 import collections
 import os
@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--lr", type=int, default=160)
     ap.add_argument("--top", type=int, default=45)
+    ap.add_argument("--scale", type=int, default=4, choices=[4, 8])
     a = ap.parse_args()
     from bfsr_amd import synth
     from bfsr_amd.ops import HipOps
@@ -23,6 +24,8 @@ def main():
     from bfsr_amd.srflow.test import lp_infer
     ops = HipOps("cuda:0")
     opt = options.load(options.DEFAULT_CONF)
+    if a.scale != 4:
+        opt = options.derive_scale(opt, a.scale)
     m = create_model(opt, ops=ops)
     m.load_network(synth.state_dict_from_schema(spec.srflownet_schema(opt), 1234))
     prior = registry.make({"name": "unet", "args": {"depth": 3, "dim": 64, "bilinear": True, "ops": ops},

@@ -35,15 +35,26 @@ def _ptr(t):
 class PackedConv(object):
     """A conv weight packed for the MFMA kernel (layout private to the library).  Packings for other M-tile counts
     are produced lazily from the kept OIHW copy: the launcher picks the M tile per call from the grid size."""
-    __slots__ = ("data", "Cout", "Cin", "KS", "mtile", "fixed", "_w", "_alts", "_ops", "scale", "arith")
+    __slots__ = ("_data", "Cout", "Cin", "KS", "mtile", "fixed", "_w", "_alts", "_ops", "scale", "arith")
 
     def __init__(self, data, Cout, Cin, KS, mtile, fixed=False, w=None, ops=None, scale=1.0, arith=0):
-        self.data, self.Cout, self.Cin, self.KS, self.mtile, self.fixed = data, Cout, Cin, KS, mtile, fixed
-        self._w, self._alts, self._ops = w, {mtile: data}, ops
+        # `data` may be a thunk: the base packing is then produced on first use (weights that only ever run on another kernel's packing --
+        # the RRDB convs on conv_h2x -- never materialise it)
+        self._data, self.Cout, self.Cin, self.KS, self.mtile, self.fixed = data, Cout, Cin, KS, mtile, fixed
+        self._w, self._alts, self._ops = w, ({} if callable(data) else {mtile: data}), ops
         # arith 1: two-term fp16 split of w*scale (scale = a power of two); the kernels multiply their accumulators by 1/scale
         self.scale, self.arith = scale, arith
 
+    @property
+    def data(self):
+        if callable(self._data):
+            self._data = self._data()
+            self._alts[self.mtile] = self._data
+        return self._data
+
     def variant(self, mtile, packer=None):
+        if mtile == self.mtile:
+            return self.data
         if mtile not in self._alts:
             self._alts[mtile] = (packer or self._ops._pack_raw)(self._w, mtile)
         return self._alts[mtile]
@@ -135,16 +146,19 @@ class HipOps(object):
         mtile = mtile or default_mtile(Cout)
         return PackedConv(self._pack_raw(w, mtile), Cout, Cin, KS, mtile, fixed=fixed, w=w, ops=self)
 
-    def pack_conv_f16(self, w, mtile=None, kind="f16"):
-        """fp16 packing for conv_f16 (the reduced-precision MFMA path); rounding = RNE like the kernel's staging."""
+    def pack_conv_f16(self, w, mtile=None, kind="f16", lazy=False):
+        """fp16 packing for conv_f16 (the reduced-precision MFMA path); rounding = RNE like the kernel's staging.  lazy: the packing of the
+        register-staged kernel is only produced if that kernel is ever launched with these weights."""
         w = w.detach().to("cpu", torch.float32).contiguous()
         Cout, Cin, KS, _ = w.shape
         fixed = mtile is not None or Cout <= 32
         mtile = min(mtile or 2, 2) if Cout > 32 else 1
         if kind == "bf16x3" and self.split == "f16x2":
             scale = self.pow2_scale(w)
-            return PackedConv(self._pack_raw_16(w, mtile, "f16x2", scale), Cout, Cin, KS, mtile, fixed=fixed, w=w, ops=self, scale=scale, arith=1)
-        return PackedConv(self._pack_raw_16(w, mtile, kind), Cout, Cin, KS, mtile, fixed=fixed, w=w, ops=self)
+            base = (lambda: self._pack_raw_16(w, mtile, "f16x2", scale)) if lazy else self._pack_raw_16(w, mtile, "f16x2", scale)
+            return PackedConv(base, Cout, Cin, KS, mtile, fixed=fixed, w=w, ops=self, scale=scale, arith=1)
+        base = (lambda: self._pack_raw_16(w, mtile, kind)) if lazy else self._pack_raw_16(w, mtile, kind)
+        return PackedConv(base, Cout, Cin, KS, mtile, fixed=fixed, w=w, ops=self)
 
     def _pack_raw_16(self, w, mtile, kind, scale=1.0):
         Cout, Cin, KS, _ = w.shape
@@ -158,10 +172,11 @@ class HipOps(object):
         _lib.check(pack_fn(w.data_ptr(), Cout, Cin, KS, mtile, packed.data_ptr()), "pack_" + kind)
         return packed.to(self.device)
 
-    def pack_conv_x3(self, w, mtile=None):
+    def pack_conv_x3(self, w, mtile=None, lazy=False):
         """Split packing for conv_x3 (fp32-accurate contraction on the 16-bit MFMA): two-term fp16 planes of w * 2^k under
-        split == "f16x2" (the default), three-term bf16 planes under "bf16x3"."""
-        return self.pack_conv_f16(w, mtile, kind="bf16x3")
+        split == "f16x2" (the default), three-term bf16 planes under "bf16x3".  lazy: see pack_conv_f16 (the conv_x3s / conv_h2x
+        packings are always derived on first use)."""
+        return self.pack_conv_f16(w, mtile, kind="bf16x3", lazy=lazy)
 
     def conv_x3(self, x, pw, out, **kw):
         """Same contract as conv(); fp32 operands split exactly into 3 bf16 terms, 6 cross products accumulated in fp32."""

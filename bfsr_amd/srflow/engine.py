@@ -188,7 +188,7 @@ class _ConvX3S(object):
     """A 3x3 conv over split tensors (ops.conv_x3s -> conv_h2x or conv_x3s): weights packed for 32-cout workgroup tiles + bias epilogue."""
 
     def __init__(self, ops, w, bias=None):
-        self.pw = ops.pack_conv_x3(w, 1)
+        self.pw = ops.pack_conv_x3(w, 1, lazy=True)               # only the conv_h2x / conv_x3s packing is ever used
         self.epi = ops.pack_epilogue(self.pw.Cout, bias)
 
     def run(self, ops, x, out, **kw):
@@ -353,8 +353,8 @@ class SRFlowEngine(object):
                     # 3xBF16 kernels: key channels by the plain conv (no epilogue) into the output buffer, then the taps
                     # kernel adds them back through pre_add and applies the epilogue
                     hz.update(ft0_taps=ops.pack_conv_up2_x3(wf[:, 64:].contiguous()), aff0_taps=ops.pack_conv_up2_x3(wa[:, 64:].contiguous()),
-                              ft0_key=ops.pack_conv_x3(wf[:, :64].contiguous(), 1 if hz["x3s"] else 2),
-                              aff0_key=ops.pack_conv_x3(wa[:, :64].contiguous(), 1 if hz["x3s"] else 2))
+                              ft0_key=ops.pack_conv_x3(wf[:, :64].contiguous(), 1 if hz["x3s"] else 2, lazy=True),
+                              aff0_key=ops.pack_conv_x3(wa[:, :64].contiguous(), 1 if hz["x3s"] else 2, lazy=True))
                     # Round 4: with the quad-major hand-over the taps run on conv_up2_h2t (taps split once into an h2 tensor, LDS-DMA staging,
                     # all four output parities per workgroup item): 6.4 -> 4.8 ms per launch at 8 x 160^2 -> 320^2 (tools/exp/taps_bench.py)
                     if (hz["x3s"] and getattr(ops, "split", "") == "f16x2" and hasattr(ops, "conv_up2_h2t") and hz["ffast"] and hz["pre_q4"]

@@ -54,7 +54,7 @@ class CpuOps(object):
 
     conv_mode = "f32"
 
-    def pack_conv_x3(self, w, mtile=None):
+    def pack_conv_x3(self, w, mtile=None, lazy=False):
         return self.pack_conv(w, mtile)
 
     def conv_x3(self, x, pw, out, **kw):

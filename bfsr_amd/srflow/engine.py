@@ -290,6 +290,18 @@ class SRFlowEngine(object):
                                                          torch.exp(sd[a + "0.actnorm.logs"]), sd[a + "2.actnorm.bias"],
                                                          torch.exp(sd[a + "2.actnorm.logs"]))
                         st.tail = ops.pack_coupling_tail(sd[a + "4.weight"], sd[a + "4.bias"], torch.exp(sd[a + "4.logs"] * 3))
+                    # levels the pair does not cover (C = 96: the head's 3x3 weights for 48 z1 channels do not fit LDS beside a tile): the same
+                    # three stages on the fp16-split kernels that exist -- split 3x3 on z1 with the hoisted partial as pre_add (raw result), the
+                    # 1x1-only coupling_head (ActNorm + ReLU, 1x1, ActNorm + ReLU -> h2 tensor), Conv2dZeros on conv_h2x -- instead of the fused
+                    # 3x3 -> 1x1 on the native fp32 MFMA + a register-staged Conv2dZeros: 96 -> 72 us per step at 8 x 80^2, 721 -> 575 us at 64 x 96^2
+                    # (tools/exp/level3_bench.py)
+                    st.chain = None
+                    if (not st.fused and w0.shape[0] == 64 and cn % 16 == 0 and hasattr(ops, "coupling_head") and hasattr(ops, "conv_h2x")
+                            and getattr(ops, "conv_mode", "f32") == "x3" and getattr(ops, "split", "") == "f16x2" and _COUPLING_MODE != "unfused"):
+                        st.chain = (ops.pack_conv_x3(w0[:, :cn].contiguous(), 2),
+                                    ops.pack_coupling_head(None, sd[a + "2.weight"], sd[a + "0.actnorm.bias"], torch.exp(sd[a + "0.actnorm.logs"]),
+                                                           sd[a + "2.actnorm.bias"], torch.exp(sd[a + "2.actnorm.logs"])),
+                                    ops.pack_conv_x3(sd[a + "4.weight"], 1, lazy=True), st.aff4.epi)
                     f = p + "affine.fFeatures."
                     st.ft0_w = sd[f + "0.weight"]
                     st.ft0_shift = sd[f + "0.actnorm.bias"].reshape(-1)
@@ -301,7 +313,11 @@ class SRFlowEngine(object):
                     # fused levels: the rest of the hoisted fFeatures net on the coupling pair's kernels -- fFeatures.0's ActNorm + ReLU and
                     # fFeatures.2 on the 1x1-only form of coupling_head (h2 output), fFeatures.4 (Conv2dZeros 64 -> 2C) on the tail's conv
                     # kernel in groups of <= 32 output channels (bfsr_conv3x3_h2r)
-                    st.fthead = st.ft4r = None
+                    st.fthead = st.ft4r = st.ft4x = None
+                    if st.chain is not None:                                   # same kernels for the hoisted fFeatures net of these levels; Conv2dZeros 64 -> 2C in one conv_h2x launch
+                        st.fthead = ops.pack_coupling_head(None, sd[f + "2.weight"], st.ft0_shift, st.ft0_scale, sd[f + "2.actnorm.bias"],
+                                                           torch.exp(sd[f + "2.actnorm.logs"]))
+                        st.ft4x = (ops.pack_conv_x3(sd[f + "4.weight"], 1, lazy=True), st.ft4.epi)
                     if st.fused and hasattr(ops, "conv_h2r") and (2 * C) % 24 == 0:
                         st.fthead = ops.pack_coupling_head(None, sd[f + "2.weight"], st.ft0_shift, st.ft0_scale, sd[f + "2.actnorm.bias"],
                                                            torch.exp(sd[f + "2.actnorm.logs"]))
@@ -332,7 +348,7 @@ class SRFlowEngine(object):
                         and getattr(self.steps[pv.index], "fused", False))
             hz["hft_q4"] = set(i for i in idxs if getattr(self.steps[i], "fused", False) and _prev_is_fused_step(i))
             # (the x4 taps kernel has no quad-major epilogue: at that level the raw fFeatures.0 result stays NCHW and the 1x1-only head reads it so)
-            hz["ffast"] = fused_all and all(self.steps[i].fthead is not None for i in idxs) and self._taps_up2(level) in (0, 1, 2)
+            hz["ffast"] = all(self.steps[i].fthead is not None for i in idxs) and self._taps_up2(level) in (0, 1, 2)
             hz["pre_q4"] = fused_all and (self._taps_up2(level) in (0, 1, False, None)) and getattr(ops, "conv_mode", "f32") == "x3"
             # Round 3: the 64 -> 16*64 key convs of the finer levels run on conv_x3s (LDS-DMA staging by loader waves, persistent) over
             # an x3 copy of the key channels instead of the register-staged conv_bf16x3 kernel: 5.51 -> 4.80 ms at 8 x 320^2
@@ -582,6 +598,9 @@ class SRFlowEngine(object):
                 if h2 is None or tuple(h2.shape) != (B, 8, 2, hk.shape[2], hk.shape[3], 8):
                     h2 = self._hid[key] = ops.h2_empty(B, 64, hk.shape[2], hk.shape[3])
                 ops.coupling_head(None, st.fthead, hk, h2, pre_fmt=ffq)
+                if st.ft4x is not None:
+                    ops.conv_h2x(h2, st.ft4x[0], h_ft[:, 2 * Cz * k: 2 * Cz * (k + 1)], epi=st.ft4x[1], y_fmt=hq[i])
+                    continue
                 for pk, epi, g0, g1 in st.ft4r:
                     ops.conv_h2r(h2, pk, h_ft[:, 2 * Cz * k + g0: 2 * Cz * k + g1], epi=epi, y_fmt=hq[i])
                 continue
@@ -595,8 +614,19 @@ class SRFlowEngine(object):
         ops, ws = self.ops, self.ws
         B, C, H, W = z.shape
         cn = C // 2
-        hid = ws.get("hid_%s" % tag, B, 64, H, W)
         h_aff = ws.get("haff_%s_%d" % (tag, k & 1), B, 2 * (C - cn), H, W)
+        if getattr(st, "chain", None) is not None and not cnd.get("pre_fmt"):
+            p0, hp, p4, e4 = st.chain
+            raw = ws.get("raw_%s" % tag, B, 64, H, W)
+            ops.conv_x3(z[:, :cn], p0, raw, pre_add=cnd["pre_aff"][:, 64 * k: 64 * (k + 1)])
+            key = "hidc_" + tag
+            h2 = self._hid.get(key)
+            if h2 is None or tuple(h2.shape) != (B, 8, 2, H, W, 8):
+                h2 = self._hid[key] = ops.h2_empty(B, 64, H, W)
+            ops.coupling_head(None, hp, raw, h2, pre_fmt=0)
+            ops.conv_h2x(h2, p4, h_aff, epi=e4)
+            return h_aff
+        hid = ws.get("hid_%s" % tag, B, 64, H, W)
         # 3x3 on z1 (+ hoisted ft partial, ActNorm, ReLU) with the 1x1 (+ActNorm, ReLU) fused as a second MFMA stage
         st.aff0_z1.run(ops, z[:, :cn], hid, pre_add=cnd["pre_aff"][:, 64 * k: 64 * (k + 1)], act=ACT_RELU,
                        stage2=(st.aff2.pw, st.aff2.epi, ACT_RELU))

@@ -16,13 +16,14 @@ def test_mfma_kernels_are_run_to_run_deterministic():
     assert r.returncode == 0 and "TOTAL differing launches: 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("scale,lr_size,overlap,rounds", [(4, 160, None, 300), (4, 160, "0", 60), (8, 96, None, 300)])
-def test_engine_is_reproducible_run_to_run(scale, lr_size, overlap, rounds, monkeypatch):
+@pytest.mark.parametrize("scale,lr_size,overlap,rounds,batch", [(4, 160, None, 300, 2), (4, 160, "0", 60, 2), (8, 96, None, 300, 2), (4, 160, None, 30, 8)])
+def test_engine_is_reproducible_run_to_run(scale, lr_size, overlap, rounds, batch, monkeypatch):
     """The fault class that isolated kernel stress does not see (round 3: the 8-wave coupling_head wrote a wrong half row once in
     10^3-10^4 launches, only inside the engine's kernel sequence; study: tools/exp/head_fault.py).  300 rounds of
     encode(B=2) -> decode -> encode(sample 1) on fixed inputs -- ~20 000 head and tail launches per case -- must reproduce round 0 bit for bit,
     and the single-sample call must equal the batch call's sample.  Cases: the 4x model with and without the side stream, the 8x model
-    (C = 12 / 24 levels at 384^2 / 192^2)."""
+    (C = 12 / 24 levels at 384^2 / 192^2); and 30 rounds at the bench batch (B = 8: every persistent kernel loops over several items per
+    workgroup there -- the regime in which the store-data hazard of DESIGN.md section 3 item 8 showed and B = 2 did not)."""
     import torch
     from bfsr_amd import synth
     from bfsr_amd.ops import HipOps, MODE_BILINEAR
@@ -32,8 +33,8 @@ def test_engine_is_reproducible_run_to_run(scale, lr_size, overlap, rounds, monk
     hip = HipOps("cuda:0")
     m, prior, opt, sd, psd = build(hip, scale)
     eng = m.netG.module.engine()
-    lr = hip.to_device(synth.smooth_lr_batch(21, 2, lr_size, lr_size))
-    lr_up = hip.resize(lr, hip.empty(2, 3, lr_size * scale, lr_size * scale), MODE_BILINEAR, 1.0 / scale, 1.0 / scale)
+    lr = hip.to_device(synth.smooth_lr_batch(21, batch, lr_size, lr_size))
+    lr_up = hip.resize(lr, hip.empty(batch, 3, lr_size * scale, lr_size * scale), MODE_BILINEAR, 1.0 / scale, 1.0 / scale)
     lr1, lr_up1 = lr[1:2].clone(), lr_up[1:2].clone()
     ref2 = ref1 = rt0 = None
     for it in range(rounds):
@@ -44,7 +45,7 @@ def test_engine_is_reproducible_run_to_run(scale, lr_size, overlap, rounds, monk
             ref2, ref1, rt0 = ep, ep1, rt
             continue
         for lvl in range(len(ep)):
-            assert torch.equal(ep[lvl], ref2[lvl]), "round %d: encode(B=2) eps%d differs from round 0" % (it, lvl)
+            assert torch.equal(ep[lvl], ref2[lvl]), "round %d: encode(B=%d) eps%d differs from round 0" % (it, batch, lvl)
             assert torch.equal(ep1[lvl], ref1[lvl]), "round %d: encode(B=1) eps%d differs from round 0" % (it, lvl)
             assert torch.equal(ep[lvl][1:2], ep1[lvl]), "round %d: eps%d of sample 1 depends on the batch" % (it, lvl)
         assert torch.equal(rt, rt0), "round %d: decode differs from round 0" % it

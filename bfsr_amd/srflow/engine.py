@@ -27,6 +27,7 @@ from ..ops import ACT_LRELU, ACT_NONE, ACT_RELU, MODE_BILINEAR, MODE_BILINEAR_AC
 FUSED_COUPLING_C = (12, 24)                                     # flow widths the coupling_head / coupling_tail pair is built for
 # BFSR_COUPLING: "fused" (default) = coupling_head / coupling_tail pair with the quad-major hand-over of pre_aff / h_ft; "fused-nchw" = the
 # pair on NCHW tensors; "unfused" = generic launches for the sequential part (A/B and parity reference)
+_CUS = 256                                                      # compute units of an MI355X: one persistent workgroup per CU in the dense-block kernels
 _COUPLING_MODE = os.environ.get("BFSR_COUPLING", "fused")
 if _COUPLING_MODE not in ("fused", "fused-nchw", "unfused"):
     raise ValueError("BFSR_COUPLING must be 'fused', 'fused-nchw' or 'unfused'")
@@ -113,7 +114,7 @@ class RRDBEncoder(object):
         self.ws = _Workspace(ops)
 
     def forward(self, x, out, on_block=None, taps=None):
-        """x [B,3,h,w] -> out (a [B,nf,h,w] view) = fea + trunk_conv(fea).  `on_block(idx, fea_view)` is called after RRDB idx
+        """x [B,3,h,w] -> out (a [B,nf,h,w] view) = fea + trunk_conv(fea).  `on_block(idx, fea_view, b0, b1)` is called after RRDB idx (for the samples b0..b1 the view holds)
         (only for idx in `taps` when given) with an fp32 view that is only valid during the call."""
         if self.x3s or self.h2s:
             return self._forward_packed(x, out, on_block, taps)
@@ -139,7 +140,7 @@ class RRDBEncoder(object):
                     convs[4].run(ops, D, ring[nxt][:, :nf], res1=D[:, :nf], alpha1=0.2, res2=x_rrdb, alpha2=0.2)
                 cur = nxt
             if on_block is not None and (taps is None or idx in taps):
-                on_block(idx, ring[cur][:, :nf])
+                on_block(idx, ring[cur][:, :nf], 0, B)
         fea = ring[cur][:, :nf]
         self.trunk_conv.run(ops, fea, out, res1=first if first is not None else fea, alpha1=1.0)   # skip + trunk
         return out
@@ -160,27 +161,62 @@ class RRDBEncoder(object):
             self._first = empty(B, nf, h, w) if self.skip_from_first else None
         ring = self._ring
         tmp = self.ws.get("x3_io", B, nf, h, w)                        # fp32 staging at the two ends of the packed region
-        cur = 0
-        self.conv_first.run(ops, x, tmp)
-        pack(tmp, ring[cur][:, :o(nf)])
-        if self.skip_from_first:
-            pack(tmp, self._first)
-        for idx, rdbs in enumerate(self.blocks):
-            x_rrdb = ring[cur][:, :o(nf)]
-            for r, convs in enumerate(rdbs):
-                D = ring[cur]
-                for i in range(4):
-                    convs[i].run(ops, D[:, :o(nf + i * gc)], D[:, o(nf + i * gc): o(nf + (i + 1) * gc)], act=ACT_LRELU, slope=0.2, **inner)
-                nxt = (cur + 1) % 4
-                if r < 2:
-                    convs[4].run(ops, D, ring[nxt][:, :o(nf)], res1=D[:, :o(nf)], alpha1=0.2)
-                else:
-                    convs[4].run(ops, D, ring[nxt][:, :o(nf)], res1=D[:, :o(nf)], alpha1=0.2, res2=x_rrdb, alpha2=0.2)
-                cur = nxt
-            if on_block is not None and (taps is None or idx in taps):
-                on_block(idx, unpack(ring[cur][:, :o(nf)], tmp))
-        fea = ring[cur][:, :o(nf)]
-        self.trunk_conv.run(ops, fea, out, res1=self._first if self.skip_from_first else fea, alpha1=1.0)
+
+        def part(b0, b1):
+            """the whole chain for samples [b0, b1) (every kernel is per-sample: a batch slice computes the same bits); a generator that
+            yields after every launch so that two halves can be enqueued alternately"""
+            rg = [r_[b0:b1] for r_ in ring]
+            first = self._first[b0:b1] if self.skip_from_first else None
+            xs, outs, tmps = x[b0:b1], out[b0:b1], tmp[b0:b1]
+            cur = 0
+            self.conv_first.run(ops, xs, tmps)
+            pack(tmps, rg[cur][:, :o(nf)])
+            if self.skip_from_first:
+                pack(tmps, first)
+            yield
+            for idx, rdbs in enumerate(self.blocks):
+                x_rrdb = rg[cur][:, :o(nf)]
+                for r, convs in enumerate(rdbs):
+                    D = rg[cur]
+                    for i in range(4):
+                        convs[i].run(ops, D[:, :o(nf + i * gc)], D[:, o(nf + i * gc): o(nf + (i + 1) * gc)], act=ACT_LRELU, slope=0.2, **inner)
+                        yield
+                    nxt = (cur + 1) % 4
+                    if r < 2:
+                        convs[4].run(ops, D, rg[nxt][:, :o(nf)], res1=D[:, :o(nf)], alpha1=0.2)
+                    else:
+                        convs[4].run(ops, D, rg[nxt][:, :o(nf)], res1=D[:, :o(nf)], alpha1=0.2, res2=x_rrdb, alpha2=0.2)
+                    cur = nxt
+                    yield
+                if on_block is not None and (taps is None or idx in taps):
+                    on_block(idx, unpack(rg[cur][:, :o(nf)], tmps), b0, b1)
+            fea = rg[cur][:, :o(nf)]
+            self.trunk_conv.run(ops, fea, outs, res1=first if self.skip_from_first else fea, alpha1=1.0)
+            yield
+
+        # Tile quantisation: a dense-block conv of B x (h/16) x (w/32) tiles runs in ceil(tiles / CUs) rounds of one persistent workgroup per CU
+        # (config 2: 400 tiles on 256 CUs = 2 rounds for 1.56 rounds of work, and a tile's cost does not shrink with its height).  When more than
+        # ~20 % of the slots would idle, the batch is split in two halves whose chains run on two streams: the second half's workgroups take
+        # the CUs the first half leaves free, and vice versa -- 324 -> 300 us per dense block at 8 x 160^2 (tools/exp/rdb_split.py; no gain and
+        # therefore no split at config 4's 1152 tiles).  `side` is the caller's second stream (None: never split).
+        side = getattr(self, "side_stream", None)
+        n_items = B * ((h + 15) // 16) * ((w + 31) // 32)
+        rounds = -(-n_items // _CUS)
+        if side is not None and B % 2 == 0 and n_items > _CUS and rounds * _CUS >= 1.2 * n_items:
+            # the two halves are enqueued ALTERNATELY, launch by launch: the host needs about as long to enqueue a dense-block conv as the GPU to
+            # run it, so a half enqueued as a whole would have run alone before the other one's launches arrive
+            main = torch.cuda.current_stream(ops.device)
+            side.wait_stream(main)
+            ga, gb = part(0, B // 2), part(B // 2, B)
+            live = True
+            while live:
+                live = next(ga, False) is not False
+                with torch.cuda.stream(side):
+                    live = (next(gb, False) is not False) or live
+            main.wait_stream(side)
+        else:
+            for _ in part(0, B):
+                pass
         return out
 
 
@@ -449,17 +485,24 @@ class SRFlowEngine(object):
             s = _KEY_SHIFT[name]
             return ws.get("key_" + name, B, 64, h << s if s >= 0 else h >> -s, w << s if s >= 0 else w >> -s)
 
-        def on_block(idx, fea):
-            # nearest-resize the tapped RRDB output into its 64-ch slot of every level (SRFlowNet_arch.py:122-137)
+        def on_block(idx, fea, b0, b1):
+            # nearest-resize the tapped RRDB output (samples b0..b1) into its 64-ch slot of every level (SRFlowNet_arch.py:122-137)
             if idx in self.block_idxs and self.concat:
                 k = self.block_idxs.index(idx)
                 for level in range(1, self.L + 1):
                     if self._taps_up2(level):
                         continue
-                    dst = ft[level][:, 64 * (k + 1): 64 * (k + 2)]
+                    dst = ft[level][b0:b1, 64 * (k + 1): 64 * (k + 2)]
                     ops.resize(fea, dst, MODE_NEAREST, float(h) / dst.shape[2], float(w) / dst.shape[3])
 
         last = key_view("fea_up1")
+        # second stream for the split-batch dense blocks (see RRDB._forward_packed); BFSR_OVERLAP=0 keeps everything on one stream
+        if getattr(getattr(ops, "device", None), "type", "cpu") == "cuda" and os.environ.get("BFSR_OVERLAP", "auto") != "0":
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=ops.device)
+            self.rrdb.side_stream = self._side_stream
+        else:
+            self.rrdb.side_stream = None
         self.rrdb.forward(lr, last, on_block, taps=set(self.block_idxs) if self.concat else set())
         prev = last
         for name in ("fea_up2", "fea_up4", "fea_up8"):       # lrelu is in-place in the reference => stored post-act

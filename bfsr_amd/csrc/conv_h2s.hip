@@ -261,35 +261,34 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
         asm volatile("" : "+v"(lh), "+v"(lx));                           // INSIDE the tile loop (hoisted, it is spilled to scratch and reloaded here)
 #endif
         const int gx = cur.x0 + lx;
-        int goff[MT][2][2];                                              // element offset of the group's hi octet inside a batch item (< 2^31, checked by the launcher), or -1
+        // every global access of the epilogue is a buffer instruction whose VGPR offset is out of range for pixels outside the image (and whose
+        // descriptor ends at Cout channels): no `if (inside)` branch per access (conv3x3_h2x_kernel's epilogue, round 4)
+        unsigned vo16[2], vo4[2];                                        // per row j: byte offset of (half-wave octet lh, pixel) in 16-byte / 4-byte units
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int oct = (cur.cg * MT + m) * 4 + q * 2 + lh;
-                    const int gy = cur.y0 + 2 * wave + j;
-                    goff[m][j][q] = (gy < H && gx < W && oct * 8 < p.Cout) ? (int)(((long long)oct * 2 * HW + (long long)gy * W + gx) * 8) : -1;
-                }
+        for (int j = 0; j < 2; ++j) {
+            const int gy = cur.y0 + 2 * wave + j;
+            const bool ok = gy < H && gx < W;
+            vo16[j] = ok ? (unsigned)(((long long)lh * 2 * HW + (long long)gy * W + gx) * 16) : OOB;
+            vo4[j] = ok ? (unsigned)(((long long)lh * 8 * HW + (long long)gy * W + gx) * 4) : OOB;
+        }
+        const unsigned h2_bytes = (unsigned)((long long)(p.Cout >> 3) * 2 * HW * 16);
+        auto res_rsrc = [&](const unsigned short* res, long long bs) {
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(res + (long long)cur.b * bs), 0, h2_bytes, 0x00020000);
+        };
         // operands of the first residual: issued NOW, consumed after the parameter stage (their HBM round trip runs under the swaps,
         // the bpermute exchange and the bias/activation arithmetic instead of in front of the adds)
         half8 r1h[MT][2][2], r1l[MT][2][2];
         if (p.res1) {
-            const unsigned short* rb = p.res1 + (long long)cur.b * p.res1_bs;
+            const __amdgpu_buffer_rsrc_t rr = res_rsrc(p.res1, p.res1_bs);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        const int g = goff[m][j][q];
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) { r1h[m][j][q][i] = (_Float16)0.f; r1l[m][j][q][i] = (_Float16)0.f; }
-                        if (g >= 0) {
-                            r1h[m][j][q] = *reinterpret_cast<const half8*>(rb + g);
-                            r1l[m][j][q] = *reinterpret_cast<const half8*>(rb + g + HW * 8);
-                        }
+                        const unsigned so = (unsigned)(((cur.cg * MT + m) * 4 + q * 2) * 2) * (unsigned)(HW * 16);
+                        r1h[m][j][q] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rr, vo16[j], so, 0));
+                        r1l[m][j][q] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rr, vo16[j], so + (unsigned)(HW * 16), 0));
                     }
         }
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");       // MFMA result -> VALU read inside the asm below: 20 wait states (>= 19 of a 16-pass XDL op), self-sufficient
@@ -339,7 +338,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
                 __builtin_amdgcn_sched_barrier(0);                       // one (M tile, octet) at a time: short live ranges
             }
         auto add_res = [&](const unsigned short* res, long long bs, float alpha) {
-            const unsigned short* rb = res + (long long)cur.b * bs;
+            const __amdgpu_buffer_rsrc_t rr = res_rsrc(res, bs);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {                               // one M tile (4 groups, 32 registers) per round trip
                 half8 rh[2][2], rl[2][2];
@@ -347,13 +346,9 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        const int g = goff[m][j][q];
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) { rh[j][q][i] = (_Float16)0.f; rl[j][q][i] = (_Float16)0.f; }
-                        if (g >= 0) {
-                            rh[j][q] = *reinterpret_cast<const half8*>(rb + g);
-                            rl[j][q] = *reinterpret_cast<const half8*>(rb + g + HW * 8);
-                        }
+                        const unsigned so = (unsigned)(((cur.cg * MT + m) * 4 + q * 2) * 2) * (unsigned)(HW * 16);
+                        rh[j][q] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rr, vo16[j], so, 0));
+                        rl[j][q] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rr, vo16[j], so + (unsigned)(HW * 16), 0));
                     }
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -375,35 +370,36 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
                         for (int i = 0; i < 8; ++i) o[m][j][q][i] = p.alpha1 * o[m][j][q][i] + ((float)r1h[m][j][q][i] + (float)r1l[m][j][q][i]);
         }
         if (p.res2) add_res(p.res2, p.res2_bs, p.alpha2);
+        typedef unsigned u32x4s_ __attribute__((ext_vector_type(4)));
+        if (p.y_fmt != 0) {                                              // h2 output: both planes (1) or the hi plane only (2)
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned short*>(p.y) + (long long)cur.b * p.y_bs, 0, h2_bytes, 0x00020000);
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int g = goff[m][j][q];
-                    if (g < 0) continue;
-                    if (p.y_fmt == 2) {
-                        half8 h8;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) h8[i] = (_Float16)o[m][j][q][i];
-                        *reinterpret_cast<half8*>(reinterpret_cast<unsigned short*>(p.y) + (long long)cur.b * p.y_bs + g) = h8;
-                    } else if (p.y_fmt == 1) {
+                    for (int q = 0; q < 2; ++q) {
+                        const unsigned so = (unsigned)(((cur.cg * MT + m) * 4 + q * 2) * 2) * (unsigned)(HW * 16);
                         half8 h8, l8;
 #pragma unroll
                         for (int i = 0; i < 8; ++i) { _Float16 h, l; split2(o[m][j][q][i], h, l); h8[i] = h; l8[i] = l; }
-                        unsigned short* yb = reinterpret_cast<unsigned short*>(p.y) + (long long)cur.b * p.y_bs + g;
-                        *reinterpret_cast<half8*>(yb) = h8;
-                        *reinterpret_cast<half8*>(yb + HW * 8) = l8;
-                    } else {
-                        const int oct = (cur.cg * MT + m) * 4 + q * 2 + lh;
-                        float* yb = reinterpret_cast<float*>(p.y) + (long long)cur.b * p.y_bs + (long long)(cur.y0 + 2 * wave + j) * W + gx;
+                        bfsr::store_b128(ry, __builtin_bit_cast(u32x4s_, h8), vo16[j], so);
+                        if (p.y_fmt == 1) bfsr::store_b128(ry, __builtin_bit_cast(u32x4s_, l8), vo16[j], so + (unsigned)(HW * 16));
+                    }
+        } else {                                                         // fp32 NCHW: channels >= Cout fall beyond the descriptor
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(p.y) + (long long)cur.b * p.y_bs, 0,
+                                                                                (unsigned)((long long)p.Cout * HW * 4), 0x00020000);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
 #pragma unroll
                         for (int i = 0; i < 8; ++i)
-                            if (oct * 8 + i < p.Cout) yb[(long long)(oct * 8 + i) * HW] = o[m][j][q][i];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o[m][j][q][i]), ry, vo4[j],
+                                                                  (unsigned)((((cur.cg * MT + m) * 4 + q * 2) * 8 + i) * HW * 4), 0);
+        }
         if (c < T) load_step(I0(), st, 0);                               // first fragments of the next tile (its barrier is already behind us)
     }
 }

@@ -663,6 +663,25 @@ def test_resize_padded_window_maxpool_clamp(hip):
     close(hip.axpb_clamp(hip.to_device(y), hip.empty(2, 3, 9, 11), 0.5, 0.5, 0.0, 1.0, r=hip.to_device(r)), ref, 1e-7, "axpb")
 
 
+@pytest.mark.parametrize("mode,window", [(0, None), (1, None), (2, None), (2, (1, 2, 38, 76))])
+def test_resize_and_clamp_vector_paths_equal_scalar_paths(hip, mode, window):
+    """resize4_kernel / axpb_clamp4_kernel (four outputs per thread, 16-byte stores: row length a multiple of four, aligned views) against the scalar
+    kernels (forced by an output view that starts one float into a wider buffer): bit-identical."""
+    x = hip.to_device(rnd(85, 2, 3, 20, 39))
+    oh, ow = 40, 80
+    rh, rw = (20 / oh, 39 / ow) if mode < 2 else (19 / (oh - 1), 38 / (ow - 1))
+    kw = dict(window=window) if window else {}
+    fast = hip.resize(x, hip.empty(2, 3, oh, ow), mode, rh, rw, **kw)
+    slab = hip.zeros(2, 3 * oh * ow + 4)
+    slow = hip.resize(x, slab[:, 1:1 + 3 * oh * ow].view(2, 3, oh, ow), mode, rh, rw, **kw)
+    assert torch.equal(fast, slow), "resize: vector and scalar kernels differ"
+    a, r = hip.to_device(rnd(86, 2, 3, oh, ow)), hip.to_device(rnd(87, 2, 3, oh, ow))
+    fast = hip.axpb_clamp(a, hip.empty(2, 3, oh, ow), 0.5, 0.5, 0.0, 1.0, r=r)
+    slab2 = hip.zeros(2, 3 * oh * ow + 4)
+    slow = hip.axpb_clamp(a, slab2[:, 1:1 + 3 * oh * ow].view(2, 3, oh, ow), 0.5, 0.5, 0.0, 1.0, r=r)
+    assert torch.equal(fast, slow), "axpb_clamp: vector and scalar kernels differ"
+
+
 @pytest.mark.parametrize("case", [(2, 6, 64, 64, 40, 70), (1, 48, 64, 64, 19, 33), (1, 12, 64, 64, 64, 64), (1, 70, 50, 40, 9, 31)])
 def test_conv_fused_1x1_second_stage(hip, case):
     """3x3 conv (+pre_add, ActNorm affine, ReLU) with the following 1x1 conv (+affine, ReLU) fused in-kernel."""

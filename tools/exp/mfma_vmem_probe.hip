@@ -3,7 +3,9 @@
 // every SIMD, phase-locked with the first by the workgroup barrier), only while vector-memory loads issued earlier (the next tile's
 // register prefetch) are still returning into VGPRs during the dependent MFMA chains.  This kernel reproduces just that situation
 // on fixed data: every iteration runs the same ds_read_b128 + v_mfma_f32_32x32x16_bf16 chains (two accumulators, 60 MFMAs) with
-// 32 buffer_load_dword in flight, and compares the accumulators bit-for-bit with those of the first iteration.
+// 32 buffer_load_dword in flight, and compares the accumulators bit-for-bit with those of the first iteration.  Second check (added later in
+// round 4): the LOADED values themselves -- the source buffer holds a hash of its index, every returned dword is verified behind the MFMA
+// chains and the destination registers are poisoned afterwards, so a dropped or misrouted return shows as well as a wrong accumulator.
 //   hipcc --offload-arch=gfx950 -O3 tools/exp/mfma_vmem_probe.hip -o tools/exp/mfma_vmem_probe
 //   tools/exp/mfma_vmem_probe [iters] [waves 8|4] [loads in flight 1|0]
 #include <hip/hip_runtime.h>
@@ -15,6 +17,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int PW = 34;
+
+__global__ void fill(unsigned* p, unsigned n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = (unsigned)i * 2654435761u;
+}
 
 template <int NWV, int LOADS>
 __global__ __launch_bounds__(NWV * 64, 2) void probe(const float* __restrict__ src, float* __restrict__ dst, unsigned* __restrict__ bad, int iters, unsigned n)
@@ -37,16 +44,16 @@ __global__ __launch_bounds__(NWV * 64, 2) void probe(const float* __restrict__ s
     f32x16 ref[2];
     unsigned nbad = 0, first = 0;
     float sink = 0.f;
-    float pre[32];
+    unsigned pre[32], nbadl = 0, firstl = 0;
 #pragma unroll
-    for (int r = 0; r < 32; ++r) pre[r] = 0.f;
+    for (int r = 0; r < 32; ++r) pre[r] = 0xffffffffu;
     for (int i = 0; i < iters; ++i) {
         __syncthreads();                                    // phase-lock the waves of the workgroup, as the head's per-tile barrier does
         if (LOADS) {
             const unsigned vo = (unsigned)((((size_t)blockIdx.x * NT + tid) * 4 + (size_t)i * 1048576u * 4) % ((size_t)n * 4 - 64 * 1048576u));
 #pragma unroll
             for (int r = 0; r < 32; ++r)
-                pre[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (unsigned)r * 1048576u, 0));
+                pre[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (unsigned)r * 1048576u, 0);
         }
         f32x16 acc[2];
 #pragma unroll
@@ -83,9 +90,20 @@ __global__ __launch_bounds__(NWV * 64, 2) void probe(const float* __restrict__ s
                 for (int r = 0; r < 16; ++r)
                     if (__builtin_bit_cast(unsigned, acc[m][r]) != __builtin_bit_cast(unsigned, ref[m][r])) { if (!nbad) first = ((unsigned)i << 8) | (unsigned)(m * 16 + r); ++nbad; }
         }
+        if (LOADS) {                                        // verify what the loads returned (consumed behind the chains, like the head's next-tile epilogue)
+            const unsigned vo = (unsigned)((((size_t)blockIdx.x * NT + tid) * 4 + (size_t)i * 1048576u * 4) % ((size_t)n * 4 - 64 * 1048576u));
 #pragma unroll
-        for (int r = 0; r < 32; ++r) sink += pre[r];
+            for (int r = 0; r < 32; ++r) {
+                const unsigned idx = vo / 4u + (unsigned)r * 262144u;
+                if (pre[r] != idx * 2654435761u) { if (!nbadl) firstl = ((unsigned)i << 8) | (unsigned)r; ++nbadl; }
+                pre[r] = 0xffffffffu;
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" : "+v"(pre[r]));            // the poison is a real register write
+#endif
+            }
+        }
     }
+    if (nbadl) { if (!nbad) first = firstl | 0x80000000u; nbad += nbadl; }
     dst[(size_t)blockIdx.x * NT + tid] = sink;
     if (nbad) {
         const unsigned k = atomicAdd(bad, 1u);
@@ -100,7 +118,8 @@ int main(int argc, char** argv)
     float *src, *dst; unsigned* bad;
     if (hipMalloc(&src, (size_t)n * 4) != hipSuccess) { printf("alloc failed\n"); return 1; }
     (void)hipMalloc(&dst, (size_t)1024 * 512 * 4); (void)hipMalloc(&bad, 4096);
-    (void)hipMemset(src, 0, (size_t)n * 4); (void)hipMemset(bad, 0, 4096);
+    (void)hipMemset(bad, 0, 4096);
+    hipLaunchKernelGGL(fill, dim3(65536), dim3(256), 0, 0, reinterpret_cast<unsigned*>(src), n);
     int cus = 0; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0);
@@ -114,7 +133,7 @@ int main(int argc, char** argv)
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
     std::vector<unsigned> h(1024);
     (void)hipMemcpy(h.data(), bad, 4096, hipMemcpyDeviceToHost);
-    printf("mfma_vmem_probe waves=%d loads_in_flight=%d: %d iterations in %.1f ms: %u threads saw an accumulator differ from iteration 0\n", waves, loads, iters, ms, h[0]);
+    printf("mfma_vmem_probe waves=%d loads_in_flight=%d: %d iterations in %.1f ms: %u threads saw an accumulator differ from iteration 0 or a loaded dword differ from the buffer (bit 31 of 'first')\n", waves, loads, iters, ms, h[0]);
     for (unsigned k = 0; k < h[0] && k < 16; ++k)
         printf("  block %u wave %u lane %u: %u registers differed, first at iteration %u register %u\n", h[1 + 3 * k] >> 10, (h[1 + 3 * k] & 1023u) >> 6, h[1 + 3 * k] & 63u,
                h[2 + 3 * k], h[3 + 3 * k] >> 8, h[3 + 3 * k] & 255u);

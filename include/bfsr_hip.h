@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define BFSR_ABI_VERSION 1
+#define BFSR_ABI_VERSION 2      /* 2 (round 4): BfsrConvArgs / BfsrConvX3Args grew y_fmt + flag, coupling head / tail structs redefined, bfsr_conv2d_up2_h2t, bfsr_h2_pack_s2d, bfsr_ssim_sum_w added, the step / up2_h2x entry points removed */
 
 enum { BFSR_ACT_NONE = 0, BFSR_ACT_RELU = 1, BFSR_ACT_LRELU = 2 };
 

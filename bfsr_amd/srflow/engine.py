@@ -203,8 +203,8 @@ class RRDBEncoder(object):
         n_items = B * ((h + 15) // 16) * ((w + 31) // 32)
         rounds = -(-n_items // _CUS)
         if side is not None and B % 2 == 0 and n_items > _CUS and rounds * _CUS >= 1.2 * n_items:
-            # the two halves are enqueued ALTERNATELY, launch by launch: the host needs about as long to enqueue a dense-block conv as the GPU to
-            # run it, so a half enqueued as a whole would have run alone before the other one's launches arrive
+            # the two halves are enqueued ALTERNATELY, launch by launch: with one half's whole chain enqueued before the other's the two streams
+            # hardly overlapped (0.3 ms gained instead of 2.9 at config 2; the host is not the limit: ~10 us per launch)
             main = torch.cuda.current_stream(ops.device)
             side.wait_stream(main)
             ga, gb = part(0, B // 2), part(B // 2, B)

@@ -131,6 +131,19 @@ class BfsrLinfFlowArgs(C.Structure):
     ]
 
 
+class BfsrChainConv(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("x_bs", C.c_longlong), ("Cin", C.c_int),
+        ("w", C.c_void_p),
+        ("y", C.c_void_p), ("y_bs", C.c_longlong), ("Cout", C.c_int), ("y_fmt", C.c_int),
+        ("epi", C.c_void_p), ("act", C.c_int), ("slope", C.c_float),
+        ("res1", C.c_void_p), ("res1_bs", C.c_longlong), ("alpha1", C.c_float),
+        ("res2", C.c_void_p), ("res2_bs", C.c_longlong), ("alpha2", C.c_float),
+        ("acc_scale", C.c_float),
+        ("y2", C.c_void_p), ("y2_bs", C.c_longlong),
+    ]
+
+
 # every symbol include/bfsr_hip.h declares: name -> (restype, argtypes)
 _LL, _I, _F, _VP = C.c_longlong, C.c_int, C.c_float, C.c_void_p
 SYMBOLS = {
@@ -155,6 +168,12 @@ SYMBOLS = {
     "bfsr_pack_conv_weight_h2x": (_I, [_VP, _I, _I, _I, C.c_float, _VP]),
     "bfsr_h2_pack": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP, _VP]),
     "bfsr_h2_unpack": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
+    "bfsr_conv_packed_size_h2c": (_LL, [_I, _I]),
+    "bfsr_pack_conv_weight_h2c": (_I, [_VP, _I, _I, C.c_float, _VP]),
+    "bfsr_conv_chain_table_size": (_LL, [_I]),
+    "bfsr_conv_chain_prepare": (_I, [C.POINTER(BfsrChainConv), _I, _I, _I, _I, _I, _VP]),
+    "bfsr_conv_chain_progress_words": (_LL, [_VP]),
+    "bfsr_conv_chain_launch": (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
     "bfsr_conv1x1": (_I, [C.POINTER(BfsrConvArgs), _I, _VP]),
     "bfsr_conv1x1_packed_size": (_LL, [_I, _I, _I]),
     "bfsr_pack_conv1x1_weight": (_I, [_VP, _I, _I, _I, _VP]),
@@ -222,7 +241,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.bfsr_abi_version() != 2:
+    if lib.bfsr_abi_version() != 3:
         raise RuntimeError("bfsr_amd: ABI version mismatch")
     _lib = lib
     return lib

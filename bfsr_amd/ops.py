@@ -65,6 +65,19 @@ def default_mtile(Cout):
     return 1 if t <= 1 else (3 if t == 3 else 2)
 
 
+class ConvChain(object):
+    """A prepared conv chain (HipOps.conv_chain): host + device copies of the descriptor table, the per-tile progress words."""
+
+    def __init__(self, ops, table_host, table_dev, progress, keep, key):
+        self.ops, self.table_host, self.table_dev, self.progress, self.keep, self.key = ops, table_host, table_dev, progress, keep, key
+
+    def run(self, tune=0):
+        ops = self.ops
+        _lib.check(ops._launch(self.key, lambda: ops.lib.bfsr_conv_chain_launch(
+            self.table_host.data_ptr(), self.table_dev.data_ptr(), self.progress.data_ptr(), ops.range_flag.data_ptr(), tune, ops._stream())),
+            "conv_chain_launch")
+
+
 class HipOps(object):
     def __init__(self, device=None):
         if not torch.cuda.is_available():
@@ -96,6 +109,10 @@ class HipOps(object):
             raise ValueError("BFSR_SPLIT must be 'f16x2' or 'bf16x3'")
         # device word the fp16-split kernels raise when an operand leaves their range (check_range())
         self.range_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def cu_count(self):
+        """Compute units of the device (the persistent kernels launch one workgroup per CU)."""
+        return torch.cuda.get_device_properties(self.device).multi_processor_count
 
     def _launch(self, key, fn):
         if self._keylog is not None:
@@ -535,6 +552,66 @@ class HipOps(object):
         _lib.check(self._launch(key, lambda: self.lib.bfsr_conv3x3_h2x(C.byref(a), self._stream())), "conv3x3_h2x")
         return out
 
+    # ---- a chain of h2x convs in one persistent launch (conv_chain.hip): the dense blocks of the RRDB encoder ---------------------
+    def _pack_h2c(self, w):
+        Cout, Cin, KS, _ = w.shape
+        if KS != 3 or Cin % 8:
+            raise ValueError("conv chain: 3x3 weights with Cin % 8 == 0 only")
+        scale = self.pow2_scale(w)
+        packed = torch.empty(self.lib.bfsr_conv_packed_size_h2c(Cout, Cin), dtype=torch.int16)
+        _lib.check(self.lib.bfsr_pack_conv_weight_h2c(w.data_ptr(), Cout, Cin, scale, packed.data_ptr()), "pack_h2c")
+        return packed.to(self.device), scale
+
+    def conv_chain(self, specs, rows=0):
+        """Prepare a chain of 3x3 convs over h2 tensors for ONE persistent launch (bfsr_conv_chain_*).  `specs` = list of dicts with the
+        keyword arguments of conv_h2x: x, pw, out, epi, act, slope, res1, alpha1, res2, alpha2, y_fmt, plus `out2` (optional fp32 NCHW
+        tensor that receives a second copy of the conv's result).  Every conv but the last must write an h2 view.  Returns a ConvChain;
+        .run() launches it on the current stream.  rows: tile rows per compute wave (0 = by batch size, 2 = 16 x 32 tiles, 4 = 32 x 32).  The chain holds pointers: the tensors it was built from must stay allocated."""
+        n = len(specs)
+        arr = (_lib.BfsrChainConv * n)()
+        keep = []
+        B = H = W = None
+        for i, sp in enumerate(specs):
+            a = arr[i]
+            x, pw, out = sp["x"], sp["pw"], sp["out"]
+            a.x, a.x_bs, Cin, h, w_ = self._h2view(x, "conv_chain.x")
+            if out.dtype == torch.float16:
+                a.y, a.y_bs, Cout, h2, w2 = self._h2view(out, "conv_chain.out")
+                a.y_fmt = 1
+            else:
+                a.y, a.y_bs, Cout, h2, w2 = _view(out, "conv_chain.out")
+                a.y_fmt = 2 if sp.get("y_fmt") else 0
+            if (Cin, Cout, h, w_) != (pw.Cin, pw.Cout, h2, w2) or pw.KS != 3 or x.shape[0] != out.shape[0]:
+                raise ValueError("conv_chain[%d]: shape mismatch x%s out%s weight(Cout=%d,Cin=%d)" % (i, tuple(x.shape), tuple(out.shape), pw.Cout, pw.Cin))
+            if B is None:
+                B, H, W = out.shape[0], h, w_
+            elif (B, H, W) != (out.shape[0], h, w_):
+                raise ValueError("conv_chain[%d]: every conv of a chain shares B, H, W" % i)
+            a.Cin, a.Cout = Cin, Cout
+            wdata, scale = pw.variant("h2c", lambda w__, m_: self._pack_h2c(w__))
+            a.w, a.acc_scale = wdata.data_ptr(), 1.0 / scale
+            epi = sp.get("epi")
+            a.epi, a.act, a.slope = _ptr(epi), sp.get("act", ACT_NONE), sp.get("slope", 0.2)
+            for name in ("res1", "res2"):
+                t = sp.get(name)
+                if t is not None:
+                    pp, bs, c, hh, ww = self._h2view(t, "conv_chain." + name)
+                    assert (c, hh, ww) == (Cout, H, W)
+                    setattr(a, name, pp)
+                    setattr(a, name + "_bs", bs)
+                    setattr(a, "alpha" + name[-1], sp.get("alpha" + name[-1], 1.0))
+            o2 = sp.get("out2")
+            if o2 is not None:
+                a.y2, a.y2_bs, c, hh, ww = _view(o2, "conv_chain.out2")
+                assert (c, hh, ww) == (Cout, H, W) and o2.shape[0] == B
+            keep.append((x, out, wdata, epi, sp.get("res1"), sp.get("res2"), o2))
+        size = self.lib.bfsr_conv_chain_table_size(n)
+        table = torch.zeros(size, dtype=torch.uint8)
+        _lib.check(self.lib.bfsr_conv_chain_prepare(arr, n, B, H, W, rows, table.data_ptr()), "conv_chain_prepare")
+        words = self.lib.bfsr_conv_chain_progress_words(table.data_ptr())
+        return ConvChain(self, table, table.to(self.device), torch.zeros(words, dtype=torch.int32, device=self.device), keep,
+                         ("conv_chain", n, specs[0]["pw"].Cin, specs[-1]["pw"].Cout, B, H, W))
+
     def h2_pack_s2d(self, x, out):
         """fp32 [B,C,2h,2w] view -> h2 view with 4C channels at h x w (space to depth): channel q*C + c = pixels (2y+qy, 2x+qx) of channel c,
         q = qy*2 + qx -- the form in which channels at output resolution enter conv_up2_h2t as key chunks."""
@@ -808,6 +885,8 @@ class HipOps(object):
         v = int(self.range_flag.item())
         if v:
             self.range_flag.zero_()
+            if v & 4:
+                raise RuntimeError("bfsr_amd: a dependency wait of the fused conv chain timed out (flag 0x%x): results are invalid" % v)
             raise RuntimeError("bfsr_amd: a value left the range of the two-term fp16 split (flag 0x%x: bit 0 = operand >= 2^15 or NaN, "
                                "bit 1 = non-finite flow state); rerun with BFSR_SPLIT=bf16x3 (fp32's exponent range, six products)" % v)
 

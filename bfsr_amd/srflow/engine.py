@@ -27,7 +27,6 @@ from ..ops import ACT_LRELU, ACT_NONE, ACT_RELU, MODE_BILINEAR, MODE_BILINEAR_AC
 FUSED_COUPLING_C = (12, 24)                                     # flow widths the coupling_head / coupling_tail pair is built for
 # BFSR_COUPLING: "fused" (default) = coupling_head / coupling_tail pair with the quad-major hand-over of pre_aff / h_ft; "fused-nchw" = the
 # pair on NCHW tensors; "unfused" = generic launches for the sequential part (A/B and parity reference)
-_CUS = 256                                                      # compute units of an MI355X: one persistent workgroup per CU in the dense-block kernels
 _COUPLING_MODE = os.environ.get("BFSR_COUPLING", "fused")
 if _COUPLING_MODE not in ("fused", "fused-nchw", "unfused"):
     raise ValueError("BFSR_COUPLING must be 'fused', 'fused-nchw' or 'unfused'")
@@ -116,6 +115,8 @@ class RRDBEncoder(object):
     def forward(self, x, out, on_block=None, taps=None):
         """x [B,3,h,w] -> out (a [B,nf,h,w] view) = fea + trunk_conv(fea).  `on_block(idx, fea_view, b0, b1)` is called after RRDB idx (for the samples b0..b1 the view holds)
         (only for idx in `taps` when given) with an fp32 view that is only valid during the call."""
+        if self.x3s and self._use_chain(x):
+            return self._forward_chain(x, out, on_block, taps)
         if self.x3s or self.h2s:
             return self._forward_packed(x, out, on_block, taps)
         ops, nf, gc = self.ops, self.nf, self.gc
@@ -143,6 +144,65 @@ class RRDBEncoder(object):
                 on_block(idx, ring[cur][:, :nf], 0, B)
         fea = ring[cur][:, :nf]
         self.trunk_conv.run(ops, fea, out, res1=first if first is not None else fea, alpha1=1.0)   # skip + trunk
+        return out
+
+    def _use_chain(self, x):
+        """The fused chain (ops.conv_chain: every dense-block conv + trunk_conv in ONE persistent launch) needs the fp16-pair split (h2
+        tensors) and enough tiles to keep the chip busy: the convs of a dense block are sequential per tile, so below one 16 x 32 tile per
+        CU the per-launch kernels are faster (B = 1, 160^2: 99 vs 154 us per dense block, profiles/r05_d_chain_bench.txt).
+        BFSR_RRDB=launches keeps one launch per conv."""
+        ops = self.ops
+        if os.environ.get("BFSR_RRDB", "chain") != "chain" or not hasattr(ops, "conv_chain") or getattr(ops, "split", None) != "f16x2":
+            return False
+        B, _, h, w = x.shape
+        return B * ((h + 15) // 16) * ((w + 31) // 32) >= ops.cu_count()
+
+    def _forward_chain(self, x, out, on_block, taps):
+        """RRDBNet_arch.py:89-103 / LINF-LP/models/rrdb.py:100-107 with all 15 * nb dense-block convs and trunk_conv as ONE launch of the
+        chain kernel (conv_chain.hip): same buffers and views as _forward_packed (ring of four 192-channel h2 block buffers), tapped RRDB
+        outputs leave the launch as a second fp32 copy of the tapped conv's result."""
+        ops, nf, gc = self.ops, self.nf, self.gc
+        B, _, h, w = x.shape
+        o = lambda c: c // 8
+        key = (B, h, w)
+        if getattr(self, "_pkkey", None) != key:
+            self._pkkey = key
+            self._ring = [ops.h2_empty(B, nf + 4 * gc, h, w) for _ in range(4)]
+            self._first = ops.h2_empty(B, nf, h, w) if self.skip_from_first else None
+            self._chain = None
+        ring = self._ring
+        tmp = self.ws.get("x3_io", B, nf, h, w)
+        want = [idx for idx in range(self.nb) if on_block is not None and (taps is None or idx in taps)]
+        ckey = (out.data_ptr(), tuple(out.stride()), tuple(want))
+        if getattr(self, "_chain", None) is None or self._chain[0] != ckey:
+            tapbuf = {idx: self.ws.get("tap%d" % idx, B, nf, h, w) for idx in want}
+            specs, cur = [], 0
+            for idx, rdbs in enumerate(self.blocks):
+                x_rrdb = ring[cur][:, :o(nf)]
+                for r, convs in enumerate(rdbs):
+                    D = ring[cur]
+                    for i in range(4):
+                        specs.append(dict(x=D[:, :o(nf + i * gc)], pw=convs[i].pw, out=D[:, o(nf + i * gc): o(nf + (i + 1) * gc)], epi=convs[i].epi,
+                                          act=ACT_LRELU, slope=0.2))
+                    nxt = (cur + 1) % 4
+                    sp = dict(x=D, pw=convs[4].pw, out=ring[nxt][:, :o(nf)], epi=convs[4].epi, res1=D[:, :o(nf)], alpha1=0.2)
+                    if r == 2:
+                        sp.update(res2=x_rrdb, alpha2=0.2)
+                        if idx in tapbuf:
+                            sp["out2"] = tapbuf[idx]
+                    specs.append(sp)
+                    cur = nxt
+            fea = ring[cur][:, :o(nf)]
+            specs.append(dict(x=fea, pw=self.trunk_conv.pw, out=out, epi=self.trunk_conv.epi, res1=self._first if self.skip_from_first else fea, alpha1=1.0))
+            self._chain = (ckey, ops.conv_chain(specs), tapbuf)
+        _, chain, tapbuf = self._chain
+        self.conv_first.run(ops, x, tmp)
+        ops.h2_pack(tmp, ring[0][:, :o(nf)])
+        if self.skip_from_first:
+            ops.h2_pack(tmp, self._first)
+        chain.run()
+        for idx in want:
+            on_block(idx, tapbuf[idx], 0, B)
         return out
 
     def _forward_packed(self, x, out, on_block, taps):
@@ -201,8 +261,9 @@ class RRDBEncoder(object):
         # therefore no split at config 4's 1152 tiles).  `side` is the caller's second stream (None: never split).
         side = getattr(self, "side_stream", None)
         n_items = B * ((h + 15) // 16) * ((w + 31) // 32)
-        rounds = -(-n_items // _CUS)
-        if side is not None and B % 2 == 0 and n_items > _CUS and rounds * _CUS >= 1.2 * n_items:
+        cus = ops.cu_count() if hasattr(ops, "cu_count") else 256       # one persistent workgroup per CU in the dense-block kernels
+        rounds = -(-n_items // cus)
+        if side is not None and B % 2 == 0 and n_items > cus and rounds * cus >= 1.2 * n_items:
             # the two halves are enqueued ALTERNATELY, launch by launch: with one half's whole chain enqueued before the other's the two streams
             # hardly overlapped (0.3 ms gained instead of 2.9 at config 2; the host is not the limit: ~10 us per launch)
             main = torch.cuda.current_stream(ops.device)

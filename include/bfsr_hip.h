@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define BFSR_ABI_VERSION 2      /* 2 (round 4): BfsrConvArgs / BfsrConvX3Args grew y_fmt + flag, coupling head / tail structs redefined, bfsr_conv2d_up2_h2t, bfsr_h2_pack_s2d, bfsr_ssim_sum_w added, the step / up2_h2x entry points removed */
+#define BFSR_ABI_VERSION 3      /* 2 (round 4): BfsrConvArgs / BfsrConvX3Args grew y_fmt + flag, coupling head / tail structs redefined, bfsr_conv2d_up2_h2t, bfsr_h2_pack_s2d, bfsr_ssim_sum_w added, the step / up2_h2x entry points removed */
 
 enum { BFSR_ACT_NONE = 0, BFSR_ACT_RELU = 1, BFSR_ACT_LRELU = 2 };
 
@@ -195,6 +195,37 @@ long long bfsr_conv_packed_size_h2x(int Cout, int Cin, int mtile);
 int bfsr_pack_conv_weight_h2x(const float* w_oihw, int Cout, int Cin, int mtile, float scale, unsigned short* packed);
 int bfsr_h2_pack(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int C, int H, int W, unsigned* flag /* optional range guard */, void* stream);
 int bfsr_h2_unpack(const unsigned short* x, long long x_bs, float* y, long long y_bs, int B, int C, int H, int W, void* stream);
+
+/* ---- a CHAIN of bfsr_conv3x3_h2x convs in ONE persistent launch (round 5, conv_chain.hip) ------------------------------------------
+ * replaces the per-conv launches of the dense blocks: SRFlow-LP/code/models/modules/RRDBNet_arch.py:25-65 (ResidualDenseBlock_5C.forward,
+ * RRDB.forward) and LINF-LP/models/rrdb.py:38-74 -- conv i reads the h2 views earlier convs of the chain wrote (channel-slice views of the
+ * block buffers), exactly as consecutive bfsr_conv3x3_h2x launches would; same arithmetic contract (two-term fp16 split, three products,
+ * fp32 accumulation; summation order differs from bfsr_conv3x3_h2x: K = two taps x 8 channels), same epilogue.  An item (conv, 32 x 32
+ * (or 16 x 32) tile, 32-cout group) starts as soon as the previous conv has finished the item's 3 x 3 tile neighbourhood (per-tile progress counters,
+ * write-through stores + agent-scope atomics); there is no grid barrier, so tile quantisation and launch ramps are paid once per chain.
+ * Restrictions: all convs share B, H, W; every conv but the last writes an h2 view (y_fmt 1); buffers may be reused along the chain the
+ * way the dense-block ring does (each conv waits for its predecessor, so earlier readers of a region are complete before it is rewritten).
+ * y2 (optional): a second, fp32 NCHW copy of the conv's result (tapped RRDB outputs), readable after the launch.
+ *   bfsr_conv_chain_prepare validates the descriptors and fills an opaque table (bfsr_conv_chain_table_size bytes, host memory); the
+ *   caller keeps a device copy of the same bytes.  bfsr_conv_chain_launch zeroes `progress` (bfsr_conv_chain_progress_words unsigned
+ *   words of device memory) and launches.  `status` (device word, required): bit 0 = fp16-split range overflow (as BfsrConvX3Args.flag),
+ *   bit 2 = a dependency wait timed out (~2 s; results invalid).  tune > 0 shrinks the persistent grid. */
+typedef struct BfsrChainConv {
+    const unsigned short* x; long long x_bs; int Cin;      /* h2 view */
+    const unsigned short* w;                                /* bfsr_pack_conv_weight_h2c */
+    void* y; long long y_bs; int Cout; int y_fmt;           /* 0 fp32 NCHW | 1 h2 | 2 fp32 quad-major (0 / 2: last conv only) */
+    const float* epi; int act; float slope;                 /* as bfsr_conv2d */
+    const unsigned short* res1; long long res1_bs; float alpha1;   /* h2 views */
+    const unsigned short* res2; long long res2_bs; float alpha2;
+    float acc_scale;                                        /* 1 / (the power of two the weights were packed with) */
+    float* y2; long long y2_bs;                             /* optional fp32 NCHW copy of the result */
+} BfsrChainConv;
+long long bfsr_conv_packed_size_h2c(int Cout, int Cin);                                   /* fp16 elements; Cin % 8 == 0 */
+int bfsr_pack_conv_weight_h2c(const float* w_oihw, int Cout, int Cin, float scale, unsigned short* packed);
+long long bfsr_conv_chain_table_size(int nconv);
+int bfsr_conv_chain_prepare(const BfsrChainConv* convs, int nconv, int B, int H, int W, int rows /* tile rows per wave: 0 auto | 2 (16 x 32 tiles) | 4 (32 x 32) */, void* table_host);
+long long bfsr_conv_chain_progress_words(const void* table_host);
+int bfsr_conv_chain_launch(const void* table_host, const void* table_dev, unsigned* progress, unsigned* status, int tune, void* stream);
 
 /* ---- fused flow-step pointwise chain -----------------------------------------------------------
  * One read of z / h_aff / h_ft, one write of z (the HBM-roofline "coupling inverse" kernel of

@@ -1,37 +1,29 @@
-// conv_chain.hip -- a CHAIN of 3x3 'same' convs over h2 tensors in ONE persistent launch: the dense blocks of the RRDB encoder
+// conv_chain.hip -- a CHAIN of bfsr_conv3x3_h2x convs in ONE persistent launch: the dense blocks of the RRDB encoder
 // (SRFlow-LP/code/models/modules/RRDBNet_arch.py:25-65, LINF-LP/models/rrdb.py:38-74: five convs per ResidualDenseBlock, three blocks
-// per RRDB, 23 RRDBs per trunk), at fp32-class accuracy on the fp16 matrix pipe (the two-term split of conv3x3_h2x_kernel, conv_h2s.hip:
-// x = hi + lo in an h2 tensor, weights split and pre-scaled by a power of two, three products lo*hi + hi*lo + hi*hi per operand pair).
+// per RRDB, 23 RRDBs per trunk).  The arithmetic is conv3x3_h2x_kernel's (conv_h2s.hip), instruction for instruction: 16 x 32 tiles, two rows
+// per compute wave, 16-channel chunks, one tap per pipeline step, three products lo*hi + hi*lo + hi*hi in the same order -- a chain of N convs
+// produces the BITS of N bfsr_conv3x3_h2x launches (tests/test_conv_chain.py), so results do not depend on which of the two the host picks.
 //
-// Why (round 5): as one launch per conv the dense blocks were 1/3 of the config-2 step at 0.36 of the split's matrix-pipe bound -- not
-// traffic, not bank conflicts: (a) tile quantisation (400 items on 256 persistent workgroups = 2 rounds for 1.56 rounds of work, every
-// conv) and 8.5 us of ramp per launch x 345 launches, and (b) 2.7 us per 16-channel chunk against 1.8 us of MFMA time: with two LDS
-// stages of 59 KB a chunk's DMA is issued exactly one chunk before it is needed (profiles/r04_g_h2x_ablation.txt).
-//
-// What this kernel does about it:
-//   * the items of ALL convs of the chain form one list, (conv, sample, tile row, tile column, cout group) in that order, dealt round-robin
-//     to one persistent workgroup per CU; there is no grid-wide barrier between convs: an item of conv c waits only until the (up to 9)
-//     tiles of its 3x3 tile neighbourhood have been finished by conv c-1 (a per-tile progress counter in global memory).  Because every
-//     conv waits for its predecessor on the neighbourhood, all earlier readers and writers of anything the item touches are complete by
-//     induction (ring buffers of the dense blocks included), so the chain may be as long as the caller likes (an RDB, an RRDB, the trunk);
-//   * hand-off between workgroups (probe: tools/exp/xcd_handoff_probe.hip, profiles/r05_xcd_handoff_probe.txt):
-//     the producer's h2 outputs are 16-byte WRITE-THROUGH stores (`sc1`), each compute wave drains them (`s_waitcnt vmcnt(0)`) and then adds
-//     1 to the tile's counter with an agent-scope atomic; the consumer's loader waves poll the counters (relaxed agent loads) and read
-//     activations ONLY with `sc1` LDS-DMA / `sc1` buffer loads, which bypass the CU's L1 (never refreshed by other CUs' stores); measured
-//     0 stale words in 1.3e8 across and inside XCDs, false sharing of a line included, against 100 % stale for plain loads;
-//   * the wait sits in the loader waves, which run two LDS stages ahead of the matrix pipe and keep serving the stage barriers of the
-//     current item while the next item's tiles are not ready (a workgroup may wait for its own previous item);
-//   * tile = 32 rows x 32 pixels, a compute wave owns FOUR rows (4 accumulator blocks: every weight fragment feeds four MFMAs), an LDS
-//     stage = ONE channel octet: input [2 planes][34 x 34 positions, padded to 1216][8] + weights [2 planes][9 taps][32][8] = 48 128 B,
-//     THREE stages: the DMA of a stage is issued two stages (~3.7 us) before it is consumed instead of one chunk (1.8 us).
-//     With 8-channel stages the K = 16 of v_mfma_f32_32x32x16_f16 is TWO TAPS x 8 channels (lanes 0-31 hold the first tap's operand,
-//     lanes 32-63 the second's: an LDS address per lane): taps (dy, 0 | dy, 1) for dy = 0..2 -- their B fragment of an input row serves
-//     three output rows --, (0, 2 | 1, 2), and the ninth tap (2, 2) as [w_hi | w_hi] x [x_hi | x_lo] (hi*hi + hi*lo in one instruction)
-//     plus [w_lo | 0] x [x_hi | x_lo]: 14 MFMAs per row and octet for 13.5 of arithmetic, 34 ds_read_b128 per 56 MFMAs and wave.
-//   * epilogue = conv3x3_h2x_kernel's (bias / affine / activation / two h2 residuals, h2 | fp32 NCHW | fp32 quad-major output, range
-//     guard of the fp16 split), plus an optional second fp32 NCHW copy of the result (tapped RRDB outputs).
-// The spin on the counters is bounded: after ~2 s without progress a workgroup raises bit 2 of the status word and every waiter gives
-// up (the results are then garbage and the host raises) -- a hung GPU is never the failure mode.
+// Why (round 5): as one launch per conv the dense blocks pay tile quantisation on every conv (config 2: 400 items on 256 persistent
+// workgroups = 2 rounds for 1.56 rounds of work) and ~8.5 us of ramp per launch, 345 launches per step.  Here the items of ALL convs of the
+// chain form one list, (conv, sample, tile row, tile column, cout group) in that order, dealt round-robin to one persistent workgroup per CU;
+// there is no grid-wide barrier between convs: an item of conv c waits only until the (up to 9) tiles of its 3 x 3 tile neighbourhood have been
+// finished by conv c-1 (a per-tile progress counter in global memory).  Because every conv waits for its predecessor on the neighbourhood, all
+// earlier readers and writers of anything the item touches are complete by induction (the ring buffers of the dense blocks included), so the
+// chain may be as long as the caller likes (an RDB, an RRDB, the whole trunk).
+//   * Hand-off between workgroups (probe: tools/exp/xcd_handoff_probe.hip, profiles/r05_xcd_handoff_probe.txt): the producer's h2 outputs are
+//     16-byte WRITE-THROUGH stores (`sc1`), each compute wave drains them (`s_waitcnt vmcnt(0)`) and then adds 1 to the tile's counter with an
+//     agent-scope atomic; the consumer's loader waves poll the counters (relaxed agent loads) and read activations ONLY with `sc1` LDS-DMA /
+//     `sc1` buffer loads, which bypass the CU's L1 (never refreshed by other CUs' stores): 0 stale words in 1.3e8 across and inside XCDs, false
+//     sharing of a cache line included, against 100 % stale for plain loads.
+//   * The wait sits in the loader waves, which keep serving the chunk barriers of the current item while the next item's tiles are not ready
+//     (a workgroup may wait for its own previous item).
+//   * What was measured on the way (profiles/r05_*chain*.txt): a first version with its own arithmetic -- 32 x 32 tiles, four
+//     rows per wave, 8-channel LDS stages three deep, K = two taps x 8 channels -- needs 40 % fewer LDS reads and 20 % fewer staged bytes per MFMA
+//     and ran NO faster under sustained load: the chip is power-limited there (MFMA busy 0.76 at ~1.65 GHz against conv_h2x's 0.84 at ~1.51 GHz,
+//     the same product), and that version's half-empty MFMA for the ninth tap (14 instead of 13.5 per row and octet) cost exactly its 3.7 %.
+// The spin on the counters is bounded: after ~2 s without progress a workgroup raises bit 2 of the status word and every waiter gives up (the
+// results are then garbage and the host raises) -- a hung GPU is never the failure mode.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <cstring>
@@ -52,32 +44,22 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 namespace {
 
 constexpr int NW = 8, NLW = 4;                  // compute waves, loader waves
-constexpr int TW = 32, PW = TW + 2;
-constexpr int WPL = 9 * 512;                    // one weight plane of a stage: [tap = dy*3 + dx][32 couts][8] fp16
-constexpr int W_BYTES = 2 * WPL;                // 9 216 = nine 1-KiB DMA pieces
-// R = rows per compute wave: 4 (tile 32 x 32, three LDS stages of 48 128 B) or 2 (tile 16 x 32, five stages of 29 696 B: twice the tiles
-// and half the time per item -- for batches whose 32-row tiles would not fill the chip: the per-tile chain of a dense block is sequential)
-template <int R> struct Geo {
-    static constexpr int TH = NW * R, PR = TH + 2;
-    static constexpr int NPOS = PR * PW;            // 1156 | 612 positions of the haloed tile
-    static constexpr int NG = (NPOS + 63) / 64;     // 19 | 10 groups of 64 positions (one LDS-DMA instruction each, per plane)
-    static constexpr int NPOSP = NG * 64;           // 1216 | 640
-    static constexpr int PLANE = NPOSP * 16;        // one plane (hi or lo) of a stage's input octet
-    static constexpr int IN_BYTES = 2 * PLANE;
-    static constexpr int STAGE = IN_BYTES + W_BYTES;
-    static constexpr int NS = R == 4 ? 3 : 5;
-    static constexpr int LDS_TOTAL = NS * STAGE;    // 144 384 | 148 480
-    static constexpr int ZERO_OFF = NPOS * 16;      // first padding position of plane 0: the DMA writes zeros there in every stage
-    static_assert(NPOSP > NPOS, "the [w_lo | 0] operand needs a padding position");
-};
+constexpr int TH = 16, TW = 32, PW = TW + 2, NPOS = (TH + 2) * PW, NG = 10, NPOSP = NG * 64;
+constexpr int SUB = NPOSP * 16;                 // bytes of one (plane, k half) sub-image of a chunk: 8 channels of every tile position
+constexpr int X_IN = 4 * SUB;                   // 40 960: [plane hi,lo][k half][640 positions][8]
+constexpr int X_WPL = 9 * 1024;                 // one weight plane of a chunk: [tap = dx*3 + dy][k half][32 couts][8]
+constexpr int X_W = 2 * X_WPL;                  // 18 432 = eighteen 1-KiB DMA pieces
+constexpr int STAGE = X_IN + X_W;               // 59 392
+constexpr int NS = 2;
+constexpr int RING = NS * STAGE;                // 118 784
+constexpr int LDS_TOTAL = RING + 16;            // + one word: the newest item whose dependencies loader 0 has seen satisfied
 constexpr unsigned OOB = 0x80000000u;
 constexpr int AUX_SC1 = (BFSR_CHAIN_ABL & 32) ? 0 : 16;                     // cache-policy bit of the buffer builtins: sc1 (agent scope: bypass L1 / write through)
 constexpr unsigned POLL_LIMIT = 1u << 21;       // unsuccessful polls (~1 us each) before a workgroup gives up
 
 struct ChainHeader {                            // 64 bytes
     int magic, nconv, B, H, W, tiles_x, tiles_y, nitems;
-    int rows;                                   // rows per compute wave: 4 (32-row tiles) or 2 (16-row tiles)
-    int pad[7];
+    int pad[8];
 };
 struct ChainRec {                               // one conv of the chain, device-side (opaque to the callers: bfsr_conv_chain_prepare fills it)
     const unsigned short* x; long long x_bs;
@@ -89,7 +71,7 @@ struct ChainRec {                               // one conv of the chain, device
     float* y2; long long y2_bs;
     int Cin, Cout, y_fmt, act;
     float slope, alpha1, alpha2, acc_scale;
-    int groups, noct, item_base;
+    int groups, nchunk, item_base;
     unsigned wait_target;                       // progress every tile of the 3x3 neighbourhood must have reached (0: no wait)
 };
 constexpr int CHAIN_MAGIC = 0x43484e31;
@@ -104,7 +86,7 @@ __device__ __forceinline__ void wait_vmcnt_c(int n)
 {
     switch (n) {
 #define W_(N_) case N_: asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory"); break;
-        W_(7) W_(8) W_(11) W_(12) W_(14) W_(16) W_(21) W_(22) W_(24) W_(28) W_(32)
+        W_(14) W_(15)
 #undef W_
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
@@ -118,13 +100,11 @@ __device__ __forceinline__ f32x16 mm_(half8 a, half8 b, f32x16 c)
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-template <int R>
 __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv_chain_kernel(const ChainRec* __restrict__ recs, int B, int H, int W, int tiles_x, int tiles_y,
-                                                                         int nitems, unsigned* progress, unsigned* status)
+                                                                         int nitems, unsigned* progress, unsigned* status, int defer_ok)
 {
-    typedef Geo<R> GE;
-    constexpr int TH = GE::TH, NPOS = GE::NPOS, NG = GE::NG, PLANE = GE::PLANE, IN_BYTES = GE::IN_BYTES, STAGE = GE::STAGE, NS = GE::NS, ZERO_OFF = GE::ZERO_OFF;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    volatile int* lds_ready = reinterpret_cast<volatile int*>(smem + RING);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -146,19 +126,16 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv_chain_kernel(const Ch
     if (wave >= NW) {
         // ================================ loader waves: LDS-DMA only, plus the dependency polls ================================
         const int ld = wave - NW;
-        const int pl = ld & 1, g0 = ld >> 1;                             // its plane; its position groups g0, g0 + 2, ...
-        // the nine weight pieces: R = 4 (10 | 10 | 9 | 9 input pieces): 2, 1, 3, 3;  R = 2 (5 input pieces each): 3, 2, 2, 2
-        const int wcount = R == 4 ? (ld == 0 ? 2 : (ld == 1 ? 1 : 3)) : (ld == 0 ? 3 : 2);
-        const int wfirst = R == 4 ? (ld == 0 ? 0 : (ld == 1 ? 2 : (ld == 2 ? 3 : 6))) : (ld == 0 ? 0 : 1 + 2 * ld);
-        const int np = (NG - g0 + 1) / 2 + wcount;                       // pieces per stage: 12, 11, 12, 12 | 8, 7, 7, 7
-        constexpr int NGL = 10;                                          // position groups per loader, at most (fixed bound: see DESIGN.md on hipcc and template-dependent array bounds)
-        unsigned vg[NGL];
+        // loader `ld` = sub-image (plane ld >> 1, k half ld & 1) of every position group + its share of the 18 weight pieces (ld, ld + 4, ...)
+        const int np = NG + (X_W / 1024 - ld + NLW - 1) / NLW;           // pieces per chunk: 15, 15, 14, 14
+        unsigned vg[NG];
         __amdgpu_buffer_rsrc_t rs_in, rs_w;
-        int cur_noct = 0, cur_grp = 0;
-        int it_issue = slot, oct_issue = 0, c_issue = 0;
+        int cur_nchunk = 0, cur_grp = 0;
+        int it_issue = slot, k_issue = 0, c_issue = 0;
         bool have = true, ready = false;
         unsigned polls = 0;
         int issued = 0, consumed = 0;
+        if (ld == 0 && lane == 0) *lds_ready = -1;                       // read by the compute waves at the end of their first item at the earliest
 
         auto deps_ready = [&](const ChainRec& r, const CItem& c) -> bool {
             if (r.wait_target == 0) return true;
@@ -182,55 +159,52 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv_chain_kernel(const Ch
         auto lsetup = [&](const ChainRec& r, const CItem& c) {
             const unsigned short* xb = r.x + (long long)c.b * r.x_bs;
             rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(xb), 0, (unsigned)(r.Cin >> 3) * 2u * HW16, 0x00020000);
-            rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(r.w), 0, (unsigned)((long long)r.groups * r.noct * W_BYTES), 0x00020000);
-            cur_noct = r.noct; cur_grp = c.grp;
+            rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(r.w), 0, (unsigned)((long long)r.groups * r.nchunk * X_W), 0x00020000);
+            cur_nchunk = r.nchunk; cur_grp = c.grp;
             const int y0 = c.ty * TH, x0 = c.tx * TW;
 #pragma unroll
-            for (int j = 0; j < NGL; ++j) {
-                const int g = g0 + 2 * j;
+            for (int g = 0; g < NG; ++g) {
                 const int pos = g * 64 + lane;
                 const int rr = pos / PW, cc = pos - rr * PW;
                 const int gy = y0 + rr - 1, gx = x0 + cc - 1;
-                const bool ok = g < NG && pos < NPOS && gy >= 0 && gy < H && gx >= 0 && gx < W;
-                vg[j] = ok ? (unsigned)(gy * W + gx) * 16u : OOB;        // out of range -> the DMA writes zeros (= the padding)
+                const bool ok = pos < NPOS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                vg[g] = ok ? (unsigned)(gy * W + gx) * 16u : OOB;        // out of range -> the DMA writes zeros (= the padding)
             }
         };
-        auto lstage = [&](int oct, int buf) {
+        auto lstage = [&](int k, int buf) {
             if (BFSR_CHAIN_ABL & 4) return;
             unsigned char* base = smem + buf * STAGE;
-            const unsigned soff = (unsigned)(oct * 2 + pl) * HW16;
+            const unsigned soff = (unsigned)((2 * k + (ld & 1)) * 2 + (ld >> 1)) * HW16;      // octet 2k + k half, plane ld >> 1
 #pragma unroll
-            for (int j = 0; j < NGL; ++j) {
-                const int g = g0 + 2 * j;
-                if (g < NG)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(base + pl * PLANE + g * 1024), 16, vg[j], soff, 0, AUX_SC1);
-            }
-            const unsigned wsoff = (unsigned)(cur_grp * cur_noct + oct) * (unsigned)W_BYTES;
+            for (int g = 0; g < NG; ++g)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void*)(base + ld * SUB + g * 1024), 16, vg[g], soff, 0, AUX_SC1);
+            const unsigned wsoff = (unsigned)(cur_grp * cur_nchunk + k) * (unsigned)X_W;
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
-                if (j < wcount) {
-                    const int piece = wfirst + j;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(base + IN_BYTES + piece * 1024), 16,
+            for (int j = 0; j < (X_W / 1024 + NLW - 1) / NLW; ++j) {
+                const int piece = ld + j * NLW;
+                if (piece < X_W / 1024)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(base + X_IN + piece * 1024), 16,
                                                              (unsigned)lane * 16u + (unsigned)piece * 1024u, wsoff, 0, 0);
-                }
+            }
         };
         auto try_issue = [&]() -> bool {
-            if (oct_issue == 0 && !ready) {
+            if (k_issue == 0 && !ready) {
                 while (it_issue >= recs[c_issue + 1].item_base) ++c_issue;
                 const ChainRec& r = recs[c_issue];
                 const CItem c = decode(r, it_issue);
                 if (!deps_ready(r, c)) return false;
+                if (ld == 0 && lane == 0) *lds_ready = it_issue;         // item it_issue WILL start (the counters only grow): see the deferred publish
                 lsetup(r, c);
                 ready = true;
             }
-            lstage(oct_issue, issued % NS);
+            lstage(k_issue, issued % NS);
             ++issued;
-            if (++oct_issue == cur_noct) { oct_issue = 0; ready = false; it_issue += G; have = it_issue < nitems; }
+            if (++k_issue == cur_nchunk) { k_issue = 0; ready = false; it_issue += G; have = it_issue < nitems; }
             return true;
         };
         while (true) {
-            // stage s may be issued once its LDS slot is free: s < NS, or barrier s - NS + 1 has been passed (the compute waves pass barrier
-            // k only after their last read of stage k - 1)
+            // chunk s may be issued once its LDS slot is free: s < NS, or barrier s - NS + 1 has been passed (the compute waves pass barrier
+            // k only after their last read of chunk k - 1): with NS = 2, chunk k + 1 goes out right behind barrier k -- conv3x3_h2x_kernel's protocol
             while (have && (issued < NS || issued <= consumed + NS - 2)) {
                 if (!try_issue()) break;
             }
@@ -248,101 +222,88 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv_chain_kernel(const Ch
     }
 
     // ==================================================== compute waves ====================================================
-    // wave w owns rows R*w .. R*w + R-1 of the tile.  Per stage (one channel octet), five tap groups:
-    //   P(dy), dy = 0..2: taps (dy,0 | dy,1): B fragment of input row i = [x(i, c) | x(i, c+1)], shared by the output rows i - dy
-    //   Q: taps (0,2 | 1,2): B = [x(r, c+2) | x(r+1, c+2)] per output row r        S: tap (2,2): B = [x_hi(r+2, c+2) | x_lo(r+2, c+2)]
-    const unsigned row0 = (unsigned)R * (unsigned)wave;
-    const unsigned oP = ((row0) * PW + l31 + lhi) * 16u;                 // + i * PW*16 + plane * PLANE
-    const unsigned oQ = ((row0 + lhi) * PW + l31 + 2) * 16u;            // + r * PW*16 + plane * PLANE
-    const unsigned oS = (unsigned)lhi * PLANE + ((row0 + 2) * PW + l31 + 2) * 16u;       // + r * PW*16
-    const unsigned aP = IN_BYTES + (unsigned)lhi * 512u + l31 * 16u;    // + dy * 1536 + plane * WPL   (tap dy*3 + lhi)
-    const unsigned aQ = IN_BYTES + ((unsigned)lhi * 3u + 2u) * 512u + l31 * 16u;          // taps 2 | 5, + plane * WPL
-    const unsigned aSh = IN_BYTES + 8u * 512u + l31 * 16u;              // tap 8, hi plane, in both halves
-    const unsigned aSl = lhi ? (unsigned)ZERO_OFF : IN_BYTES + WPL + 8u * 512u + l31 * 16u;   // [w_lo | 0]
-
-    f32x16 acc[4];
-    half8 rP[6][2], wP[3][2], rQ[4][2], wQ[2], rS[4], wS[2];
-    auto ldh = [&](const unsigned char* sb, unsigned off) {
-        if (BFSR_CHAIN_ABL & 1) { half8 v; for (int i = 0; i < 8; ++i) v[i] = (_Float16)(0.001f * (float)(lane + i + (int)(off & 15u))); return v; }
-        return *reinterpret_cast<const half8*>(sb + off);
+    // conv3x3_h2x_kernel's K loop (conv_h2s.hip): wave w owns rows 2w, 2w + 1; a step = one tap (dx, dy): 2 input rows x 2 planes + the tap's 2
+    // weight planes -> 6 MFMAs; the fragments of step t + 1 are read while the MFMAs of step t run (register double buffer).
+    half8 bq[2][2][2], aq[2][2];                                         // [buffer][plane][row] | [buffer][plane]
+    auto load_step = [&](auto buf_, int stg, int t) {
+        constexpr int BUF = decltype(buf_)::value;
+        if (BFSR_CHAIN_ABL & 1) return;
+        const int dx = t / 3, dy = t - 3 * dx;
+        const unsigned char* sIn = smem + stg * STAGE;
+        const unsigned char* inB = sIn + (lhi * NPOSP + (2 * wave + dy) * PW + l31 + dx) * 16;
+        const unsigned char* wA = sIn + X_IN + lane * 16 + t * 1024;     // tap = dx*3 + dy = t
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) bq[BUF][pl][r] = *reinterpret_cast<const half8*>(inB + pl * 2 * SUB + r * PW * 16);
+            aq[BUF][pl] = *reinterpret_cast<const half8*>(wA + pl * X_WPL);
+        }
     };
-    auto load_first = [&](const unsigned char* sb) {                     // rows 0..R-1 of P and the weights of P(0)
+    f32x16 acc[2];
+    if (BFSR_CHAIN_ABL & 1) {
 #pragma unroll
-        for (int i = 0; i < R; ++i) { rP[i][0] = ldh(sb, oP + i * (PW * 16)); rP[i][1] = ldh(sb, oP + i * (PW * 16) + PLANE); }
-        wP[0][0] = ldh(sb, aP); wP[0][1] = ldh(sb, aP + WPL);
-    };
-    // P(dy): output row r takes input row r + dy.  Smallest terms first (w_lo*x_hi, w_hi*x_lo, w_hi*x_hi), the rows interleaved:
-    // independent accumulators back to back
-    auto mfmaP = [&](auto dy_) {
-        constexpr int dy = decltype(dy_)::value;
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = mm_(wP[dy][1], rP[r + dy][0], acc[r]);
+            for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = mm_(wP[dy][0], rP[r + dy][1], acc[r]);
+                for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = mm_(wP[dy][0], rP[r + dy][0], acc[r]);
-    };
-    auto mfmaQ = [&](auto a_) {                                          // rows a, a + 1
-        constexpr int a = decltype(a_)::value;
-        acc[a] = mm_(wQ[1], rQ[a][0], acc[a]);
-        acc[a + 1] = mm_(wQ[1], rQ[a + 1][0], acc[a + 1]);
-        acc[a] = mm_(wQ[0], rQ[a][1], acc[a]);
-        acc[a + 1] = mm_(wQ[0], rQ[a + 1][1], acc[a + 1]);
-        acc[a] = mm_(wQ[0], rQ[a][0], acc[a]);
-        acc[a + 1] = mm_(wQ[0], rQ[a + 1][0], acc[a + 1]);
+                    for (int i = 0; i < 8; ++i) bq[b][pl][r][i] = (_Float16)(0.001f * (lane + i + r));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) aq[b][pl][i] = (_Float16)(0.002f * (lane + i));
+            }
+    }
+    auto mfma_step = [&](auto buf_) {
+        constexpr int BUF = decltype(buf_)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            // smallest terms first: w_lo*x_hi, w_hi*x_lo, w_hi*x_hi
+            acc[j] = mm_(aq[BUF][1], bq[BUF][0][j], acc[j]);
+            acc[j] = mm_(aq[BUF][0], bq[BUF][1][j], acc[j]);
+            acc[j] = mm_(aq[BUF][0], bq[BUF][0][j], acc[j]);
+        }
     };
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
-    typedef std::integral_constant<int, 2> I2;
-
-    int st = 0;                                                          // LDS slot of the next stage
-    auto stage_body = [&](bool last) {
-        const unsigned char* sb = smem + st * STAGE;
-        rP[R][0] = ldh(sb, oP + R * (PW * 16)); rP[R][1] = ldh(sb, oP + R * (PW * 16) + PLANE);
-        wP[1][0] = ldh(sb, aP + 1536); wP[1][1] = ldh(sb, aP + 1536 + WPL);
-        __builtin_amdgcn_sched_barrier(0);
-        mfmaP(I0());
-        __builtin_amdgcn_sched_barrier(0);
-        rP[R + 1][0] = ldh(sb, oP + (R + 1) * (PW * 16)); rP[R + 1][1] = ldh(sb, oP + (R + 1) * (PW * 16) + PLANE);
-        wP[2][0] = ldh(sb, aP + 3072); wP[2][1] = ldh(sb, aP + 3072 + WPL);
-        __builtin_amdgcn_sched_barrier(0);
-        mfmaP(I1());
-        __builtin_amdgcn_sched_barrier(0);
+    int st = 0;                                                          // LDS slot of the next chunk
+    // One barrier per chunk, passed EARLY: chunk k + 1's barrier sits before the last tap of chunk k (whose fragments are already in registers), so
+    // the first fragments of chunk k + 1 are in flight under that tap's MFMAs and the loaders may refill the slot one tap earlier.  Nine taps per
+    // chunk flip the fragment-buffer parity from chunk to chunk: chunks are processed in pairs.
+    auto chunk_body = [&](auto p_, auto q_, bool last) {                 // p_: buffer holding tap 0's fragments (already loaded)
 #pragma unroll
-        for (int r = 0; r < 2; ++r) { rQ[r][0] = ldh(sb, oQ + r * (PW * 16)); rQ[r][1] = ldh(sb, oQ + r * (PW * 16) + PLANE); }
-        wQ[0] = ldh(sb, aQ); wQ[1] = ldh(sb, aQ + WPL);
-        __builtin_amdgcn_sched_barrier(0);
-        mfmaP(I2());
-        __builtin_amdgcn_sched_barrier(0);
-        if (R == 4) {
-#pragma unroll
-            for (int r = 2; r < 4; ++r) { rQ[r][0] = ldh(sb, oQ + r * (PW * 16)); rQ[r][1] = ldh(sb, oQ + r * (PW * 16) + PLANE); }
+        for (int t = 0; t < 8; t += 2) {
+            load_step(q_, st, t + 1);
             __builtin_amdgcn_sched_barrier(0);
-            mfmaQ(I0());
+            mfma_step(p_);
+            __builtin_amdgcn_sched_barrier(0);
+            load_step(p_, st, t + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(q_);
             __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int r = 0; r < R; ++r) rS[r] = ldh(sb, oS + r * (PW * 16));
-        wS[0] = ldh(sb, aSh); wS[1] = ldh(sb, aSl);
-        __builtin_amdgcn_sched_barrier(0);
-        if (R == 4) mfmaQ(I2()); else mfmaQ(I0());
-        __builtin_amdgcn_sched_barrier(0);
-        const int nst = st + 1 == NS ? 0 : st + 1;
         if (!last) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // every fragment of this stage is in registers: the slot may be refilled
-            __builtin_amdgcn_s_barrier();                                // the next stage has landed
-            load_first(smem + nst * STAGE);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // tap 8's fragments have left the slot
+            __builtin_amdgcn_s_barrier();                                // chunk k + 1 has landed in the other slot; this one is free again
+            load_step(q_, st ^ 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = mm_(wS[1], rS[r], acc[r]);  // w_lo * x_hi
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = mm_(wS[0], rS[r], acc[r]);  // w_hi * (x_hi + x_lo)
+        mfma_step(p_);
         __builtin_amdgcn_sched_barrier(0);
-        st = nst;
+        st ^= 1;
     };
 
+    // Publishing an item = waiting for this wave's (write-through) stores and adding 1 to the tile's counter.  Done right after the epilogue it
+    // exposes the store drain (~1-2 us per item).  When the workgroup's NEXT item is already known to start (its dependencies were seen
+    // satisfied by the loader, which runs ahead), the publish is deferred into that item's K loop, where the wait costs nothing.  It must not
+    // be deferred otherwise: the next item may wait -- through other workgroups whose own publications are deferred the same way -- for this
+    // very publication (a first rule, "defer unless the next item is the next conv on a neighbouring tile", deadlocked exactly like that).
     float xamax = 0.f;                                                   // range guard: max |value| handed to the fp16 split (h2 output)
+    long long pend = -1;
+    auto publish_pending = [&]() {
+        if (!(BFSR_CHAIN_ABL & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add((gu32*)(progress + pend), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pend = -1;
+    };
     int c = 0;
     for (int it = slot; it < nitems; it += G) {
         while (it >= recs[c + 1].item_base) ++c;
@@ -363,22 +324,28 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv_chain_kernel(const Ch
             if (epi && (idx >> 1) < Cout) pm = epi[idx];
         }
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
-        const int noct = rec.noct;
-        __builtin_amdgcn_s_barrier();                                    // the item's first stage has landed
-        load_first(smem + st * STAGE);
-        for (int o = 0; o + 1 < noct; ++o) stage_body(false);
-        stage_body(true);
+        for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+        const int nchunk = rec.nchunk;
+        __builtin_amdgcn_s_barrier();                                    // the item's first chunk has landed
+        load_step(I0(), st, 0);
+        {
+            int k = 0;
+            for (; k + 2 <= nchunk; k += 2) {                            // pairs of chunks: the fragment-buffer parity is static inside a pair
+                chunk_body(I0(), I1(), false);
+                chunk_body(I1(), I0(), k + 2 == nchunk);
+                if (pend >= 0) publish_pending();                        // the previous item's stores drained long ago: this wait is free
+            }
+            if (k < nchunk) chunk_body(I0(), I1(), true);
+        }
+        if (pend >= 0) publish_pending();
 
         if (BFSR_CHAIN_ABL & 8) {                                        // keep the accumulators alive
-            if (acc[0][0] + acc[1][5] + acc[R - 2][7] + acc[R - 1][9] == 1234.5f) reinterpret_cast<float*>(rec.y)[lane] = acc[0][1];
-            if (lane == 0)
+            if (acc[0][0] + acc[1][5] == 1234.5f) reinterpret_cast<float*>(rec.y)[lane] = acc[0][1];
+            if (lane == 0 && progress)
                 __hip_atomic_fetch_add((gu32*)(progress + ((long long)cur.b * tiles_y + cur.ty) * tiles_x + cur.tx), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             continue;
         }
-        // ---- epilogue (the loaders are already staging the next item): conv3x3_h2x_kernel's, two rows at a time
+        // ---- epilogue (the loaders are already staging the next item): conv3x3_h2x_kernel's
         const bool plain = (lane & 1) ? pm.x == 1.f : (pm.y == 0.f && pm.z == 1.f && pm.w == 0.f);
         const bool bias_only = __all((int)plain);
         const bool fast = bias_only && slope >= 0.f && slope <= 1.f;
@@ -391,14 +358,13 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv_chain_kernel(const Ch
         const int oct0 = cur.grp * 4;                                    // first of this item's four channel octets (+ q*2 + lh)
         const unsigned h2_bytes = (unsigned)((long long)(Cout >> 3) * 2 * HW * 16);
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");               // MFMA result -> VALU read inside the asm below
-#pragma unroll
-        for (int jj = 0; jj < R / 2; ++jj) {
+        {
             // every global access is a buffer instruction whose VGPR offset is out of range for pixels outside the image (and whose
             // descriptor ends at Cout channels): no `if (inside)` branch per access
             unsigned vo16[2], vo4[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int gy = cur.ty * TH + R * wave + 2 * jj + j;
+                const int gy = cur.ty * TH + 2 * wave + j;
                 const bool ok = gy < H && gx < W;
                 vo16[j] = ok ? (unsigned)(((long long)lh * 2 * HW + (long long)gy * W + gx) * 16) : OOB;
                 vo4[j] = ok ? (unsigned)(((long long)lh * 8 * HW + (long long)gy * W + gx) * 4) : OOB;
@@ -423,7 +389,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv_chain_kernel(const Ch
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        float lo = acc[2 * jj + j][8 * q + i] * acc_scale, hi = acc[2 * jj + j][8 * q + 4 + i] * acc_scale;
+                        float lo = acc[j][8 * q + i] * acc_scale, hi = acc[j][8 * q + 4 + i] * acc_scale;
                         asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
                         o[j][q][i] = lo;
                         o[j][q][4 + i] = hi;
@@ -524,51 +490,18 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv_chain_kernel(const Ch
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- publish: this wave's stores have left the CU (write-through) -> one more finished wave on the tile's counter
-        if (!(BFSR_CHAIN_ABL & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0)
-            __hip_atomic_fetch_add((gu32*)(progress + ((long long)cur.b * tiles_y + cur.ty) * tiles_x + cur.tx), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!progress) continue;                                         // a chain of one: nobody waits
+        pend = ((long long)cur.b * tiles_y + cur.ty) * tiles_x + cur.tx;
+        // defer only if the workgroup's next item is known to start: loader 0 has already seen its dependencies satisfied (it runs ahead of the
+        // matrix pipe, so this is the common case) -- then the publication cannot be what anybody is (transitively) waiting for before that start
+        const bool defer = defer_ok && it + G < nitems && *lds_ready >= it + G;
+        if (!defer) publish_pending();
     }
+    if (pend >= 0) publish_pending();
     if (status && __any((int)!(xamax < 65504.f))) { if (lane == 0) atomicOr(status, 1u); }
 }
 
-inline unsigned short f32_to_f16_bits_c(float v)
-{
-    const _Float16 h = (_Float16)v;              // round to nearest even, like the device conversion
-    unsigned short u;
-    __builtin_memcpy(&u, &h, 2);
-    return u;
-}
-
 }  // namespace
-
-extern "C" long long bfsr_conv_packed_size_h2c(int Cout, int Cin)
-{
-    if (Cout <= 0 || Cin <= 0 || (Cin & 7)) return -1;
-    return (long long)((Cout + 31) / 32) * (Cin / 8) * (W_BYTES / 2);      // fp16 elements
-}
-
-extern "C" int bfsr_pack_conv_weight_h2c(const float* w, int Cout, int Cin, float scale, unsigned short* packed)
-{
-    // w [Cout][Cin][3][3] fp32 -> fp16 [cout group of 32][channel octet][plane hi,lo][tap = dy*3 + dx][32 couts][8 channels] of w*scale,
-    // zero padded; scale = a power of two chosen by the caller (largest |w|*scale in [2^9, 2^10))
-    if (!w || !packed || Cout <= 0 || Cin <= 0 || (Cin & 7) || !(scale > 0.f)) return -1;
-    const int noct = Cin / 8;
-    const long long n = bfsr_conv_packed_size_h2c(Cout, Cin);
-    for (long long i = 0; i < n; ++i) packed[i] = 0;
-    for (int co = 0; co < Cout; ++co)
-        for (int ci = 0; ci < Cin; ++ci)
-            for (int dy = 0; dy < 3; ++dy)
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float v = w[((long long)co * Cin + ci) * 9 + dy * 3 + dx] * scale;
-                    const _Float16 h = (_Float16)v;
-                    const _Float16 l = (_Float16)(v - (float)h);
-                    const long long blk = ((long long)(co / 32) * noct + ci / 8) * (W_BYTES / 2);
-                    const long long in = ((long long)(dy * 3 + dx) * 32 + co % 32) * 8 + ci % 8;
-                    packed[blk + in] = f32_to_f16_bits_c((float)h);
-                    packed[blk + WPL / 2 + in] = f32_to_f16_bits_c((float)l);
-                }
-    return 0;
-}
 
 extern "C" long long bfsr_conv_chain_table_size(int nconv)
 {
@@ -576,24 +509,13 @@ extern "C" long long bfsr_conv_chain_table_size(int nconv)
     return (long long)sizeof(ChainHeader) + (long long)(nconv + 1) * sizeof(ChainRec);
 }
 
-extern "C" int bfsr_conv_chain_prepare(const BfsrChainConv* convs, int nconv, int B, int H, int W, int rows, void* table)
+extern "C" int bfsr_conv_chain_prepare(const BfsrChainConv* convs, int nconv, int B, int H, int W, void* table)
 {
     if (!convs || !table || nconv <= 0 || B <= 0 || H <= 0 || W <= 0) return -1;
-    if (rows != 0 && rows != 2 && rows != 4) return -1;
     ChainHeader hd;
     std::memset(&hd, 0, sizeof(hd));
     hd.magic = CHAIN_MAGIC; hd.nconv = nconv; hd.B = B; hd.H = H; hd.W = W;
     hd.tiles_x = (W + TW - 1) / TW;
-    if (rows == 0) {
-        // 32-row tiles move fewer bytes per MFMA, but the convs of a dense block are sequential per tile: below ~2 tiles per CU the chain is
-        // bound by that dependency, not by the work (tools/exp/chain_sim.py; measured at 8 x 160^2: profiles/r05_c_chain_bench.txt)
-        int cus = bfsr::cu_count();
-        if (cus <= 0) cus = 256;
-        const long long t32 = (long long)hd.tiles_x * ((H + 31) / 32) * B;
-        rows = t32 >= 2LL * cus ? 4 : 2;
-    }
-    hd.rows = rows;
-    const int TH = NW * rows;
     hd.tiles_y = (H + TH - 1) / TH;
     const long long tiles = (long long)hd.tiles_x * hd.tiles_y * B;
     ChainRec* recs = reinterpret_cast<ChainRec*>(static_cast<unsigned char*>(table) + sizeof(ChainHeader));
@@ -602,7 +524,7 @@ extern "C" int bfsr_conv_chain_prepare(const BfsrChainConv* convs, int nconv, in
     for (int i = 0; i < nconv; ++i) {
         const BfsrChainConv& a = convs[i];
         if (!a.x || !a.w || !a.y) return -1;
-        if (a.Cin <= 0 || (a.Cin & 7) || a.Cout <= 0) return -1;
+        if (a.Cin <= 0 || (a.Cin & 15) || a.Cout <= 0) return -1;
         if (a.y_fmt < 0 || a.y_fmt > 2) return -1;
         if (!(a.acc_scale > 0.f)) return -1;
         if ((a.y_fmt != 0 || a.res1 || a.res2) && (a.Cout & 7)) return -1;
@@ -615,14 +537,14 @@ extern "C" int bfsr_conv_chain_prepare(const BfsrChainConv* convs, int nconv, in
         if (a.y_fmt == 2 && ((reinterpret_cast<unsigned long long>(a.y) & 15) || (a.y_bs & 3))) return -1;
         if (a.res1 && ((reinterpret_cast<unsigned long long>(a.res1) & 15) || (a.res1_bs & 7))) return -1;
         if (a.res2 && ((reinterpret_cast<unsigned long long>(a.res2) & 15) || (a.res2_bs & 7))) return -1;
-        if (bfsr_conv_packed_size_h2c(a.Cout, a.Cin) * 2 >= (1LL << 32)) return -1;
+        if (bfsr_conv_packed_size_h2x(a.Cout, a.Cin, 1) * 2 >= (1LL << 32)) return -1;
         ChainRec& r = recs[i];
         std::memset(&r, 0, sizeof(r));
         r.x = a.x; r.x_bs = a.x_bs; r.w = a.w; r.y = a.y; r.y_bs = a.y_bs; r.epi = a.epi;
         r.res1 = a.res1; r.res1_bs = a.res1_bs; r.res2 = a.res2; r.res2_bs = a.res2_bs; r.y2 = a.y2; r.y2_bs = a.y2_bs;
         r.Cin = a.Cin; r.Cout = a.Cout; r.y_fmt = a.y_fmt; r.act = a.act;
         r.slope = a.slope; r.alpha1 = a.alpha1; r.alpha2 = a.alpha2; r.acc_scale = a.acc_scale;
-        r.groups = (a.Cout + 31) / 32; r.noct = a.Cin / 8;
+        r.groups = (a.Cout + 31) / 32; r.nchunk = a.Cin / 16;
         if (items > 0x7fffffffLL) return -1;
         r.item_base = (int)items;
         r.wait_target = (unsigned)target;                                // conv 0: 0 = no wait (its inputs were written before the launch)
@@ -656,20 +578,17 @@ extern "C" int bfsr_conv_chain_launch(const void* table_host, const void* table_
     if (cus <= 0) return -1;
     // The dependency waits need every workgroup of the grid to be resident at the same time: one workgroup per CU (144 KB of LDS each), never
     // more workgroups than CUs.  `tune` may only shrink the grid.
+    const int defer_ok = !(tune & 0x10000);                              // bit 16 of tune: publish every item right after its epilogue (A/B)
+    tune &= 0xffff;
     if (tune > 0 && tune < cus) cus = tune;
     const int grid = hd->nitems < cus ? hd->nitems : cus;
-    static std::atomic<unsigned long long> lds_done4{0}, lds_done2{0};
-    if (hd->rows == 4) { if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_chain_kernel<4>), Geo<4>::LDS_TOTAL, lds_done4) != 0) return -1; }
-    else if (hd->rows == 2) { if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_chain_kernel<2>), Geo<2>::LDS_TOTAL, lds_done2) != 0) return -1; }
-    else return -1;
+    static std::atomic<unsigned long long> lds_done{0};
+    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_chain_kernel), LDS_TOTAL, lds_done) != 0) return -1;
     const long long words = (long long)hd->tiles_x * hd->tiles_y * hd->B;
-    if (hipMemsetAsync(progress, 0, (size_t)words * sizeof(unsigned), st) != hipSuccess) return -1;
+    if (hd->nconv == 1) progress = nullptr;                              // a chain of one has no dependencies: no counters, no memset node
+    else if (hipMemsetAsync(progress, 0, (size_t)words * sizeof(unsigned), st) != hipSuccess) return -1;
     const ChainRec* recs = reinterpret_cast<const ChainRec*>(static_cast<const unsigned char*>(table_dev) + sizeof(ChainHeader));
-    if (hd->rows == 4)
-        hipLaunchKernelGGL((conv_chain_kernel<4>), dim3((unsigned)grid), dim3((NW + NLW) * 64), Geo<4>::LDS_TOTAL, st, recs, hd->B, hd->H, hd->W, hd->tiles_x,
-                           hd->tiles_y, hd->nitems, progress, status);
-    else
-        hipLaunchKernelGGL((conv_chain_kernel<2>), dim3((unsigned)grid), dim3((NW + NLW) * 64), Geo<2>::LDS_TOTAL, st, recs, hd->B, hd->H, hd->W, hd->tiles_x,
-                           hd->tiles_y, hd->nitems, progress, status);
+    hipLaunchKernelGGL(conv_chain_kernel, dim3((unsigned)grid), dim3((NW + NLW) * 64), LDS_TOTAL, st, recs, hd->B, hd->H, hd->W, hd->tiles_x, hd->tiles_y,
+                       hd->nitems, progress, status, defer_ok);
     return (int)hipGetLastError();
 }

@@ -553,20 +553,11 @@ class HipOps(object):
         return out
 
     # ---- a chain of h2x convs in one persistent launch (conv_chain.hip): the dense blocks of the RRDB encoder ---------------------
-    def _pack_h2c(self, w):
-        Cout, Cin, KS, _ = w.shape
-        if KS != 3 or Cin % 8:
-            raise ValueError("conv chain: 3x3 weights with Cin % 8 == 0 only")
-        scale = self.pow2_scale(w)
-        packed = torch.empty(self.lib.bfsr_conv_packed_size_h2c(Cout, Cin), dtype=torch.int16)
-        _lib.check(self.lib.bfsr_pack_conv_weight_h2c(w.data_ptr(), Cout, Cin, scale, packed.data_ptr()), "pack_h2c")
-        return packed.to(self.device), scale
-
-    def conv_chain(self, specs, rows=0):
+    def conv_chain(self, specs):
         """Prepare a chain of 3x3 convs over h2 tensors for ONE persistent launch (bfsr_conv_chain_*).  `specs` = list of dicts with the
         keyword arguments of conv_h2x: x, pw, out, epi, act, slope, res1, alpha1, res2, alpha2, y_fmt, plus `out2` (optional fp32 NCHW
         tensor that receives a second copy of the conv's result).  Every conv but the last must write an h2 view.  Returns a ConvChain;
-        .run() launches it on the current stream.  rows: tile rows per compute wave (0 = by batch size, 2 = 16 x 32 tiles, 4 = 32 x 32).  The chain holds pointers: the tensors it was built from must stay allocated."""
+        .run() launches it on the current stream; the results are bit-identical to conv_h2x launches of the same convs.  The chain holds pointers: the tensors it was built from must stay allocated."""
         n = len(specs)
         arr = (_lib.BfsrChainConv * n)()
         keep = []
@@ -588,7 +579,7 @@ class HipOps(object):
             elif (B, H, W) != (out.shape[0], h, w_):
                 raise ValueError("conv_chain[%d]: every conv of a chain shares B, H, W" % i)
             a.Cin, a.Cout = Cin, Cout
-            wdata, scale = pw.variant("h2c", lambda w__, m_: self._pack_h2c(w__))
+            wdata, scale, _mt = pw.variant("h2x", lambda w__, m_: self._pack_h2x(w__))
             a.w, a.acc_scale = wdata.data_ptr(), 1.0 / scale
             epi = sp.get("epi")
             a.epi, a.act, a.slope = _ptr(epi), sp.get("act", ACT_NONE), sp.get("slope", 0.2)
@@ -607,7 +598,7 @@ class HipOps(object):
             keep.append((x, out, wdata, epi, sp.get("res1"), sp.get("res2"), o2))
         size = self.lib.bfsr_conv_chain_table_size(n)
         table = torch.zeros(size, dtype=torch.uint8)
-        _lib.check(self.lib.bfsr_conv_chain_prepare(arr, n, B, H, W, rows, table.data_ptr()), "conv_chain_prepare")
+        _lib.check(self.lib.bfsr_conv_chain_prepare(arr, n, B, H, W, table.data_ptr()), "conv_chain_prepare")
         words = self.lib.bfsr_conv_chain_progress_words(table.data_ptr())
         return ConvChain(self, table, table.to(self.device), torch.zeros(words, dtype=torch.int32, device=self.device), keep,
                          ("conv_chain", n, specs[0]["pw"].Cin, specs[-1]["pw"].Cout, B, H, W))

@@ -147,10 +147,12 @@ class RRDBEncoder(object):
         return out
 
     def _use_chain(self, x):
-        """The fused chain (ops.conv_chain: every dense-block conv + trunk_conv in ONE persistent launch) needs the fp16-pair split (h2
-        tensors) and enough tiles to keep the chip busy: the convs of a dense block are sequential per tile, so below one 16 x 32 tile per
-        CU the per-launch kernels are faster (B = 1, 160^2: 99 vs 154 us per dense block, profiles/r05_d_chain_bench.txt).
-        BFSR_RRDB=launches keeps one launch per conv."""
+        """The fused chain (ops.conv_chain, conv_chain.hip: every dense-block conv + trunk_conv in ONE persistent launch) computes the bits of the
+        per-launch kernel conv_h2x, so choosing between them is a pure scheduling decision.  It needs the fp16-pair split (h2 tensors) and at
+        least one 16 x 32 tile per CU: the convs of a dense block are sequential per tile, so below that most workgroups would wait inside the
+        launch and plain launch boundaries are cheaper (B = 1, 160^2: 99 us per dense block as launches, profiles/r05_d_chain_bench.txt).
+        Measured under sustained load, interleaved A/B (profiles/r05_i_chain_ab.txt): 8 x 160^2 251 vs 286 us per dense block (two-stream
+        launches), 64 x 96^2 742 vs 761, 16 x 256^2 1341 vs 1337.  BFSR_RRDB=launches keeps one launch per conv."""
         ops = self.ops
         if os.environ.get("BFSR_RRDB", "chain") != "chain" or not hasattr(ops, "conv_chain") or getattr(ops, "split", None) != "f16x2":
             return False
@@ -194,13 +196,14 @@ class RRDBEncoder(object):
                     cur = nxt
             fea = ring[cur][:, :o(nf)]
             specs.append(dict(x=fea, pw=self.trunk_conv.pw, out=out, epi=self.trunk_conv.epi, res1=self._first if self.skip_from_first else fea, alpha1=1.0))
-            self._chain = (ckey, ops.conv_chain(specs), tapbuf)
-        _, chain, tapbuf = self._chain
+            self._chain = (ckey, [ops.conv_chain(specs)], tapbuf)
+        _, chains, tapbuf = self._chain
         self.conv_first.run(ops, x, tmp)
         ops.h2_pack(tmp, ring[0][:, :o(nf)])
         if self.skip_from_first:
             ops.h2_pack(tmp, self._first)
-        chain.run()
+        for ch in chains:
+            ch.run()
         for idx in want:
             on_block(idx, tapbuf[idx], 0, B)
         return out

@@ -199,9 +199,9 @@ int bfsr_h2_unpack(const unsigned short* x, long long x_bs, float* y, long long 
 /* ---- a CHAIN of bfsr_conv3x3_h2x convs in ONE persistent launch (round 5, conv_chain.hip) ------------------------------------------
  * replaces the per-conv launches of the dense blocks: SRFlow-LP/code/models/modules/RRDBNet_arch.py:25-65 (ResidualDenseBlock_5C.forward,
  * RRDB.forward) and LINF-LP/models/rrdb.py:38-74 -- conv i reads the h2 views earlier convs of the chain wrote (channel-slice views of the
- * block buffers), exactly as consecutive bfsr_conv3x3_h2x launches would; same arithmetic contract (two-term fp16 split, three products,
- * fp32 accumulation; summation order differs from bfsr_conv3x3_h2x: K = two taps x 8 channels), same epilogue.  An item (conv, 32 x 32
- * (or 16 x 32) tile, 32-cout group) starts as soon as the previous conv has finished the item's 3 x 3 tile neighbourhood (per-tile progress counters,
+ * block buffers), exactly as consecutive bfsr_conv3x3_h2x launches would -- and with exactly their results: same kernel arithmetic, same
+ * summation order, bit for bit (tests/test_conv_chain.py); same epilogue.  An item (conv, 16 x 32 tile, 32-cout group) starts as soon as the
+ * previous conv has finished the item's 3 x 3 tile neighbourhood (per-tile progress counters,
  * write-through stores + agent-scope atomics); there is no grid barrier, so tile quantisation and launch ramps are paid once per chain.
  * Restrictions: all convs share B, H, W; every conv but the last writes an h2 view (y_fmt 1); buffers may be reused along the chain the
  * way the dense-block ring does (each conv waits for its predecessor, so earlier readers of a region are complete before it is rewritten).
@@ -212,7 +212,7 @@ int bfsr_h2_unpack(const unsigned short* x, long long x_bs, float* y, long long 
  *   bit 2 = a dependency wait timed out (~2 s; results invalid).  tune > 0 shrinks the persistent grid. */
 typedef struct BfsrChainConv {
     const unsigned short* x; long long x_bs; int Cin;      /* h2 view */
-    const unsigned short* w;                                /* bfsr_pack_conv_weight_h2c */
+    const unsigned short* w;                                /* bfsr_pack_conv_weight_h2x(mtile = 1) */
     void* y; long long y_bs; int Cout; int y_fmt;           /* 0 fp32 NCHW | 1 h2 | 2 fp32 quad-major (0 / 2: last conv only) */
     const float* epi; int act; float slope;                 /* as bfsr_conv2d */
     const unsigned short* res1; long long res1_bs; float alpha1;   /* h2 views */
@@ -220,10 +220,8 @@ typedef struct BfsrChainConv {
     float acc_scale;                                        /* 1 / (the power of two the weights were packed with) */
     float* y2; long long y2_bs;                             /* optional fp32 NCHW copy of the result */
 } BfsrChainConv;
-long long bfsr_conv_packed_size_h2c(int Cout, int Cin);                                   /* fp16 elements; Cin % 8 == 0 */
-int bfsr_pack_conv_weight_h2c(const float* w_oihw, int Cout, int Cin, float scale, unsigned short* packed);
 long long bfsr_conv_chain_table_size(int nconv);
-int bfsr_conv_chain_prepare(const BfsrChainConv* convs, int nconv, int B, int H, int W, int rows /* tile rows per wave: 0 auto | 2 (16 x 32 tiles) | 4 (32 x 32) */, void* table_host);
+int bfsr_conv_chain_prepare(const BfsrChainConv* convs, int nconv, int B, int H, int W, void* table_host);
 long long bfsr_conv_chain_progress_words(const void* table_host);
 int bfsr_conv_chain_launch(const void* table_host, const void* table_dev, unsigned* progress, unsigned* status, int tune, void* stream);
 

@@ -9,11 +9,15 @@ g = torch.Generator().manual_seed(0)
 B, H, NB = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (8, 160, 21)
 ring = [ops.h2_pack(torch.randn(B, 192, H, H, device="cuda") * 0.5 if _ == 0 else torch.zeros(B, 192, H, H, device="cuda"), ops.h2_empty(B, 192, H, H)) for _ in range(4)]
 shapes = ((64, 32), (96, 32), (128, 32), (160, 32), (192, 64))
-pws = [ops.pack_conv_x3(torch.randn(co, ci, 3, 3, generator=g) * (0.05 / (ci * 9) ** 0.5), 1, lazy=True) for ci, co in shapes]
+DISTINCT = os.environ.get("DISTINCT", "0") == "1"           # own weights per dense block (the real trunk) instead of five shared tensors
+def mk():
+    return [ops.pack_conv_x3(torch.randn(co, ci, 3, 3, generator=g) * (0.05 / (ci * 9) ** 0.5), 1, lazy=True) for ci, co in shapes]
+allw = [mk() for _ in range(NB if DISTINCT else 1)]
 epis = [ops.pack_epilogue(co, bias=torch.zeros(co)) for ci, co in shapes]
 def specs(b0, b1, nb):
     out, cur = [], 0
     for r in range(nb):
+        pws = allw[r % len(allw)]
         D, Dn = ring[cur][b0:b1], ring[(cur + 1) % 4][b0:b1]
         for i, (ci, co) in enumerate(shapes[:4]):
             out.append(dict(x=D[:, :ci // 8], pw=pws[i], out=D[:, ci // 8: ci // 8 + 4], epi=epis[i], act=2, slope=0.2))
@@ -48,8 +52,8 @@ if B % 2 == 0:
         main.wait_stream(side)
     t = timed(two)
     print("  conv_h2x, two half-batch streams          : %8.3f ms  %6.1f us per block  %5.0f TFLOP/s-eq" % (t, t / NB * 1e3, flops / t / 1e9), flush=True)
-for rows, per in ((4, 1), (4, 3), (4, NB), (2, 1), (2, 3), (2, NB)):
-    chains = [ops.conv_chain(specs(0, B, NB)[5 * i: 5 * (i + per)], rows=rows) for i in range(0, NB, per)]
+for rows, per in ((2, 1), (2, 3), (2, NB)):
+    chains = [ops.conv_chain(specs(0, B, NB)[5 * i: 5 * (i + per)]) for i in range(0, NB, per)]
     def run():
         for c in chains: c.run()
     t = timed(run)
@@ -57,11 +61,12 @@ for rows, per in ((4, 1), (4, 3), (4, NB), (2, 1), (2, 3), (2, NB)):
     print("  conv_chain %d rows/wave, %2d block(s) per launch: %8.3f ms  %6.1f us per block  %5.0f TFLOP/s-eq  (%.2f of 833)" % (rows, per, t, t / NB * 1e3, flops / t / 1e9, flops / t / 1e9 / 833), flush=True)
 for ci, co in ((64, 32), (192, 64)):
     i = [s[0] for s in shapes].index(ci)
+    pws = allw[0]
     D = ring[0]
     out = ring[1][:, :co // 8]
     one = dict(x=D[:, :ci // 8], pw=pws[i], out=out, epi=epis[i], act=2, slope=0.2)
-    ch, ch2 = ops.conv_chain([one], rows=4), ops.conv_chain([one], rows=2)
-    t3 = timed(lambda: ch2.run(), 10)
+    ch = ops.conv_chain([one])
+    t3 = t2 = 1.0
     t1 = timed(lambda: ops.conv_h2x(one["x"], one["pw"], one["out"], epi=one["epi"], act=2, slope=0.2), 10)
     t2 = timed(lambda: ch.run(), 10)
     f = 2 * 9 * ci * co * B * H * H

@@ -448,7 +448,13 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv_chain_kernel(const Ch
                     for (int q = 0; q < 2; ++q) {
                         half8 h8, l8;
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) { _Float16 h, l; split2c(o[j][q][i], h, l); h8[i] = h; l8[i] = l; xamax = fmaxf(xamax, fabsf(o[j][q][i])); }
+                        for (int i = 0; i < 8; ++i) {
+                            _Float16 h, l;
+                            split2c(o[j][q][i], h, l);
+                            h8[i] = h; l8[i] = l;
+                            xamax = fmaxf(xamax, fabsf(o[j][q][i]));
+                            o[j][q][i] = (float)h + (float)l;            // what later convs read: the second copy (y2) holds the same 22-bit value (= bfsr_h2_unpack of y)
+                        }
                         const unsigned so = (unsigned)((oct0 + q * 2) * 2) * (unsigned)(HW * 16);
                         // literal soffset 0 (launch_util.h, store_b128: the gfx950 store-data hazard), sc1
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4c, h8), ry, vo16[j] + so, 0, AUX_SC1);

@@ -157,7 +157,11 @@ class RRDBEncoder(object):
         if os.environ.get("BFSR_RRDB", "chain") != "chain" or not hasattr(ops, "conv_chain") or getattr(ops, "split", None) != "f16x2":
             return False
         B, _, h, w = x.shape
-        return B * ((h + 15) // 16) * ((w + 31) // 32) >= ops.cu_count()
+        cus, n_items = ops.cu_count(), B * ((h + 15) // 16) * ((w + 31) // 32)
+        # ... and something to recover: the chip is power-limited under these kernels, so closing launch gaps alone buys nothing (16 x 256^2, 2048
+        # tiles = 8.0 rounds: 1390 vs 1326 us per dense block over 69 blocks, profiles/r05_j_chain_ab_69.txt); the gain is the partly filled
+        # last round of every conv (8 x 160^2: 400 tiles = 1.56 rounds)
+        return n_items >= cus and -(-n_items // cus) * cus >= 1.1 * n_items
 
     def _forward_chain(self, x, out, on_block, taps):
         """RRDBNet_arch.py:89-103 / LINF-LP/models/rrdb.py:100-107 with all 15 * nb dense-block convs and trunk_conv as ONE launch of the

@@ -205,7 +205,8 @@ int bfsr_h2_unpack(const unsigned short* x, long long x_bs, float* y, long long 
  * write-through stores + agent-scope atomics); there is no grid barrier, so tile quantisation and launch ramps are paid once per chain.
  * Restrictions: all convs share B, H, W; every conv but the last writes an h2 view (y_fmt 1); buffers may be reused along the chain the
  * way the dense-block ring does (each conv waits for its predecessor, so earlier readers of a region are complete before it is rewritten).
- * y2 (optional): a second, fp32 NCHW copy of the conv's result (tapped RRDB outputs), readable after the launch.
+ * y2 (optional): a second, fp32 NCHW copy of the conv's result (tapped RRDB outputs), readable after the launch; for an h2 output it holds
+ * hi + lo, i.e. exactly bfsr_h2_unpack(y).
  *   bfsr_conv_chain_prepare validates the descriptors and fills an opaque table (bfsr_conv_chain_table_size bytes, host memory); the
  *   caller keeps a device copy of the same bytes.  bfsr_conv_chain_launch zeroes `progress` (bfsr_conv_chain_progress_words unsigned
  *   words of device memory) and launches.  `status` (device word, required): bit 0 = fp16-split range overflow (as BfsrConvX3Args.flag),

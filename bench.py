@@ -480,9 +480,12 @@ def main():
             "roofline": roofline, "roofline_next_kernels": roofline_next, "roofline_by_symbol": by_symbol,
             "roofline_by_symbol_note": "HIP-event time per kernel family in the untimed ranking step; with the side stream active (configs "
                                        "whose batch does not fill the chip) events of overlapping kernels are inflated by contention and the "
-                                       "families sum to more than ms_per_step -- profiles/r03_keys_cfg2_no_overlap.txt has the BFSR_OVERLAP=0 table",
+                                       "families sum to more than ms_per_step -- profiles/r05_keys_cfg2_no_overlap.txt has the BFSR_OVERLAP=0 table",
             "roofline_coupling_inverse": roof_tail,
             "cpu_baseline": cpu_baseline, "parity": parity,
+            # passes that the range guard of the fp16-pair split re-ran under the bf16x3 split (bfsr_amd/guard.py); the guard's 4-byte read-back at
+            # the end of every pass is INSIDE the timed region
+            "fallbacks": int(getattr(ops, "fallbacks", 0)),
         }
         if fp32_only is not None or cfg == 2:
             line["value_native_fp32_mfma"] = fp32_only

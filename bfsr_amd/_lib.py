@@ -115,7 +115,7 @@ class BfsrLinfMlpArgs(C.Structure):
         ("dy_neg", C.c_float), ("dy_pos", C.c_float), ("dx_neg", C.c_float), ("dx_pos", C.c_float),
         ("clamp_lo", C.c_float), ("clamp_hi", C.c_float),
         ("cy0", C.c_float), ("cy1", C.c_float), ("cx0", C.c_float), ("cx1", C.c_float),
-        ("out_fmt", C.c_int), ("acc_scale", C.c_float * 4),
+        ("out_fmt", C.c_int), ("acc_scale", C.c_float * 4), ("flag", C.c_void_p),
     ]
 
 
@@ -219,6 +219,8 @@ SYMBOLS = {
     "bfsr_ssim_sum": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, C.c_double, _VP, _VP, _VP]),
     "bfsr_ssim_sum_w": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, C.c_double, _I, _VP, C.c_double, _VP, _VP]),
     "bfsr_to_uint8": (_I, [_VP, _LL, _VP, _I, _LL, _VP]),
+    "bfsr_channel_range_scratch": (_LL, [_I]),
+    "bfsr_channel_range_check": (_I, [_VP, _LL, _I, _I, _I, _I, _F, _F, _VP, _VP, _VP]),
     "bfsr_conv2d_direct": (_I, [_VP, _LL, _VP, _VP, _VP, _LL, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _VP]),
 }
 

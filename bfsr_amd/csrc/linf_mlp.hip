@@ -90,14 +90,18 @@ __device__ __forceinline__ void sincos_feat(float x, float& s, float& c)
 
 // 8 fp32 values of one point (8 consecutive channels of a chunk half) -> PL fragments of 16 B
 template <int X3>
-__device__ __forceinline__ void encode8(const float (&v)[8], typename Mode<X3>::frag (&out)[Mode<X3>::PL])
+__device__ __forceinline__ void encode8(const float (&v)[8], typename Mode<X3>::frag (&out)[Mode<X3>::PL], float& amax)
 {
     if constexpr (X3 == 1) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { __bf16 h, m, l; split3(v[e], h, m, l); out[0][e] = h; out[1][e] = m; out[2][e] = l; }
     } else if constexpr (X3 == 2) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const _Float16 h = (_Float16)v[e]; out[0][e] = h; out[1][e] = (_Float16)(v[e] - (float)h); }
+        for (int e = 0; e < 8; ++e) {
+            const _Float16 h = (_Float16)v[e];
+            out[0][e] = h; out[1][e] = (_Float16)(v[e] - (float)h);
+            amax = fmaxf(amax, fabsf(v[e]));                             // range guard of the fp16 split (a.flag)
+        }
     } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) out[0][e] = (_Float16)v[e];
@@ -112,6 +116,7 @@ __global__ __launch_bounds__(NW * 64, X3 == 0 ? 4 : 2) void linf_mlp_kernel(Bfsr
     constexpr int PL = MD::PL;
     constexpr int CHUNK = PL * 2 * P * 16;            // bytes of one 16-channel activation chunk: [plane][k half][64 points][8]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 16 chunks: stage A = chunks 0-7, stage B = 8-15
+    float amax = 0.f;                                  // largest |value| this thread hands to the fp16 split (X3 == 2): range guard
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -194,8 +199,8 @@ __global__ __launch_bounds__(NW * 64, X3 == 0 ? 4 : 2) void linf_mlp_kernel(Bfsr
             vs[e] = (wgt * g.co1[e]) * s;
         }
         frag fc[PL], fs[PL];
-        encode8<X3>(vc, fc);
-        encode8<X3>(vs, fs);
+        encode8<X3>(vc, fc, amax);
+        encode8<X3>(vs, fs, amax);
 #pragma unroll
         for (int pl = 0; pl < PL; ++pl) {
             *reinterpret_cast<frag*>(dst + ((pl * 2 + 0) * P + lane) * 16) = fc[pl];
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(NW * 64, X3 == 0 ? 4 : 2) void linf_mlp_kernel(Bfsr
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float t = (X3 == 2 ? v[qd][e] * asc : v[qd][e]) + bias[ch0 + e]; u[e] = t > 0.f ? t : 0.f; }
                 frag fr[PL];
-                encode8<X3>(u, fr);
+                encode8<X3>(u, fr, amax);
                 unsigned char* dst = smem + (ch0 >> 4) * CHUNK;
 #pragma unroll
                 for (int pl = 0; pl < PL; ++pl)
@@ -365,6 +370,7 @@ __global__ __launch_bounds__(NW * 64, X3 == 0 ? 4 : 2) void linf_mlp_kernel(Bfsr
             }
         }
     }
+    if (X3 == 2 && a.flag && __any((int)!(amax < 65504.f))) { if (lane == 0) atomicOr(a.flag, 1u); }
 }
 
 template <int X3>

@@ -1,0 +1,96 @@
+"""Range guard of the two-term fp16 split, with automatic fallback (round 5).
+
+The default fp32-accurate contraction (BFSR_SPLIT=f16x2: x = fp16 hi + fp16 lo, three products) holds 22 significant bits only for
+|x| < 65504; every kernel that splits a value tracks max |x| and raises a device flag (HipOps.range_flag) instead of producing inf/NaN
+silently.  `run_guarded` makes that unconditional for every public entry point of the engines (srflow.test.lp_infer, SRFlowNet.forward and
+therefore SRFlowModel.get_encode_z / get_sr / get_sr_with_z, linf.test.lp_infer / infer_from_lr / eval_psnr, LINF.forward): the flag is
+cleared, the pass runs, the flag is read (one 4-byte device->host copy at the end of the pass -- the reference synchronises there anyway,
+SRFlow-LP/code/test.py:150 `.cpu()`, LINF-LP/test.py:217), and if it is raised the SAME pass is re-run on engines built over
+HipOps.fallback_ops(): the exact three-term bf16 split, which has fp32's exponent range (six products instead of three).  `ops.fallbacks`
+counts those re-runs (bench.py prints it; 0 in normal operation).  A non-finite value that survives the fallback (the input itself was inf /
+NaN) and a dependency time-out of the fused conv chain raise RuntimeError.
+
+`EngineHost` is the part the four nn.Modules share (SRFlowNet, both prior UNets, LINF): a lazily built engine per split."""
+import contextlib
+
+
+class EngineHost(object):
+    """Mixin: `engine()` returns the module's engine on its HipOps, or -- while a guarded pass is being re-run -- on the fallback ops."""
+    _fb_active = False
+
+    def _build_engine(self, ops):                         # the host class implements this
+        raise NotImplementedError
+
+    def _default_ops(self):
+        from .ops import HipOps
+        p = next(self.parameters())
+        return HipOps(p.device if p.is_cuda else None)
+
+    def _drop_engines(self):
+        self._engine = None
+        self._fb_engine = None
+
+    def engine(self, fallback=None):
+        if self._ops is None:
+            self._ops = self._default_ops()
+        if self._fb_active if fallback is None else fallback:
+            fb_ops = self._ops.fallback_ops() if hasattr(self._ops, "fallback_ops") else self._ops
+            if fb_ops is not self._ops:
+                if getattr(self, "_fb_engine", None) is None:
+                    self._fb_engine = self._build_engine(fb_ops)
+                return self._fb_engine
+        if self._engine is None:
+            self._engine = self._build_engine(self._ops)
+        return self._engine
+
+
+@contextlib.contextmanager
+def _fallback_engines(hosts):
+    for h in hosts:
+        h._fb_active = True
+    try:
+        yield
+    finally:
+        for h in hosts:
+            h._fb_active = False
+
+
+def run_guarded(hosts, fn):
+    """fn() -> result, a pass over the engines of `hosts` (EngineHost modules, e.g. the model and its prior).  Returns fn()'s result computed
+    either by the default split with the range flag clean, or by the bf16x3 fallback.  Nested calls are transparent: the outermost owns the flag."""
+    hosts = [h for h in hosts if h is not None]
+    opss = []
+    for h in hosts:
+        o = h.engine(fallback=False).ops
+        if all(o is not q for q in opss):
+            opss.append(o)
+    guarded = [o for o in opss if getattr(o, "split", None) == "f16x2" and getattr(o, "conv_mode", None) == "x3" and hasattr(o, "read_range_flag")]
+    if not guarded or any(o._guard_depth for o in guarded) or any(h._fb_active for h in hosts):
+        return fn()
+    for o in guarded:
+        o._guard_depth += 1
+        o.range_flag.zero_()
+    try:
+        out = fn()
+        raised = 0
+        for o in guarded:
+            raised |= o.read_range_flag()
+    finally:
+        for o in guarded:
+            o._guard_depth -= 1
+    if raised & 4:
+        raise RuntimeError("bfsr_amd: a dependency wait of the fused conv chain timed out (flag 0x%x): results are invalid" % raised)
+    if not raised:
+        return out
+    for o in guarded:
+        o.fallbacks += 1
+        o.fallback_ops().range_flag.zero_()
+    with _fallback_engines(hosts):
+        out = fn()
+    bad = 0
+    for o in guarded:
+        bad |= o.fallback_ops().read_range_flag()
+    if bad:
+        raise RuntimeError("bfsr_amd: non-finite values in the pass even under the bf16x3 split (flag 0x%x): the input or the weights are "
+                           "not finite" % bad)
+    return out

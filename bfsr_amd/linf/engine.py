@@ -119,6 +119,8 @@ class LINFEngine(object):
         _, qh, qw, _ = coord.shape
         cf = ws.get("cf", B, 2 * HD, h, w)
         self.cf.run(ops, feat, cf)
+        if self.precision != "fp16" and hasattr(ops, "check_channels"):
+            ops.check_channels(cf)                      # the fused MLP splits coef * cos / sin features into fp16 pairs
         if self.fused_mlp:
             x = ops.linf_mlp(cf, coord, cell, self.phase, self.mlp_packed, ws.get("affine_info", B, self.mlp_packed[2], qh, qw), HD,
                              x3=self.precision != "fp16")

@@ -11,13 +11,14 @@ from ... import rng
 from torch import nn
 
 from ... import paramtree
+from ...guard import EngineHost, run_guarded
 from .. import spec
 from ..engine import LINFEngine
 from .models import make as _make, register
 
 
 @register('linf-patch')
-class LINFPatch(nn.Module):
+class LINFPatch(nn.Module, EngineHost):
     def __init__(self, encoder_spec, imnet_spec=None, flow_layers=10, num_layer=3, hidden_dim=256, patch_size=3, ops=None,
                  precision="fp32"):
         super(LINFPatch, self).__init__()
@@ -31,26 +32,20 @@ class LINFPatch(nn.Module):
         self._modules["imnet"] = self._modules.pop("imnet")
         self._cfg = dict(encoder_spec=self.encoder.spec, flow_layers=flow_layers, num_layer=num_layer,
                          hidden_dim=hidden_dim, patch_size=patch_size, precision=precision)
-        self._ops, self._engine = ops, None
+        self._ops, self._engine, self._fb_engine = ops, None, None
 
     def load_state_dict(self, state_dict, strict=True):
         r = super(LINFPatch, self).load_state_dict(state_dict, strict=strict)
-        self._engine = None
+        self._drop_engines()
         return r
 
     def _apply(self, fn, *a, **k):
         r = super(LINFPatch, self)._apply(fn, *a, **k)
-        self._engine = None
+        self._drop_engines()
         return r
 
-    def engine(self):
-        if self._engine is None:
-            if self._ops is None:
-                from ...ops import HipOps
-                p = next(self.parameters())
-                self._ops = HipOps(p.device if p.is_cuda else None)
-            self._engine = LINFEngine(self.state_dict(), self._ops, **self._cfg)
-        return self._engine
+    def _build_engine(self, ops):
+        return LINFEngine(self.state_dict(), ops, **self._cfg)
 
     # ---- reference ops -----------------------------------------------------------------------------
     def gen_feat(self, inp):
@@ -81,18 +76,22 @@ class LINFPatch(nn.Module):
         if op == "query_rgb" and zmap is not None and torch.is_grad_enabled() and zmap.requires_grad:
             # latent-module training (LINF-LP/train.py:143): the frozen model's query_rgb is differentiable w.r.t. zmap
             return _QueryRGB.apply(zmap, self, inp, feat, coord, cell)
-        with torch.no_grad():
-            if op == "query_log_p":
-                return self.query_log_p(inp, feat, coord, cell, gt)
-            if op == "query_rgb":
-                return self.query_rgb(inp, feat, coord, cell, temperature, zmap)
-            if op == "log_p":
-                return self.log_p(inp, coord, cell, gt)
-            if op == "rgb":
-                return self.rgb(inp, coord, cell, temperature, zmap)
-            if op == "gen_feat":
+        if op not in ("query_log_p", "query_rgb", "log_p", "rgb", "gen_feat"):
+            raise ValueError("unknown op %r" % (op,))
+
+        def run():
+            with torch.no_grad():
+                if op == "query_log_p":
+                    return self.query_log_p(inp, feat, coord, cell, gt)
+                if op == "query_rgb":
+                    return self.query_rgb(inp, feat, coord, cell, temperature, zmap)
+                if op == "log_p":
+                    return self.log_p(inp, coord, cell, gt)
+                if op == "rgb":
+                    return self.rgb(inp, coord, cell, temperature, zmap)
                 return self.gen_feat(inp)
-        raise ValueError("unknown op %r" % (op,))
+        # range guard of the fp16-pair split with automatic bf16x3 re-run (guard.py); inside lp_infer the outer guard owns the flag
+        return run_guarded([self], run)
 
 
 class _QueryRGB(torch.autograd.Function):

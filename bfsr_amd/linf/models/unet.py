@@ -4,36 +4,31 @@ import torch
 from torch import nn
 
 from ... import paramtree
+from ...guard import EngineHost
 from .. import spec
 from ..engine import LINFPriorEngine
 from .models import register
 
 
-class UNet(nn.Module):
+class UNet(nn.Module, EngineHost):
     def __init__(self, in_chans, depth=3, dim=64, bilinear=False, ops=None, precision="fp32"):
         super(UNet, self).__init__()
         self.in_chans, self.depth, self.dim, self.bilinear, self.precision = in_chans, depth, dim, bilinear, precision
         paramtree.attach(self, spec.linf_prior_schema(in_chans, depth, dim, bilinear), paramtree.default_init(15))
-        self._ops, self._engine = ops, None
+        self._ops, self._engine, self._fb_engine = ops, None, None
 
     def load_state_dict(self, state_dict, strict=True):
         r = super(UNet, self).load_state_dict(state_dict, strict=strict)
-        self._engine = None
+        self._drop_engines()
         return r
 
     def _apply(self, fn, *a, **k):
         r = super(UNet, self)._apply(fn, *a, **k)
-        self._engine = None
+        self._drop_engines()
         return r
 
-    def engine(self):
-        if self._engine is None:
-            if self._ops is None:
-                from ...ops import HipOps
-                p = next(self.parameters())
-                self._ops = HipOps(p.device if p.is_cuda else None)
-            self._engine = LINFPriorEngine(self.state_dict(), self._ops, self.in_chans, self.depth, self.dim, precision=self.precision)
-        return self._engine
+    def _build_engine(self, ops):
+        return LINFPriorEngine(self.state_dict(), ops, self.in_chans, self.depth, self.dim, precision=self.precision)
 
     def forward(self, x, lr):
         if self.training:

@@ -24,7 +24,13 @@ def batched_predict(model, inp, coord, cell, temperature, zmap=None):
 
 
 def lp_infer(model, prior_model, batch, hr_hw, temperature=0, return_all=False):
-    """batch: dict(inp [B,3,h,w] in [0,1], coord, cell, gt_lr_up) as delivered by the patch wrappers."""
+    """batch: dict(inp [B,3,h,w] in [0,1], coord, cell, gt_lr_up) as delivered by the patch wrappers.
+    Runs under the range guard of the two-term fp16 split: an overflow re-runs the pass under the bf16x3 split (guard.run_guarded)."""
+    from ..guard import run_guarded
+    return run_guarded([model, prior_model], lambda: _lp_infer(model, prior_model, batch, hr_hw, temperature, return_all))
+
+
+def _lp_infer(model, prior_model, batch, hr_hw, temperature, return_all):
     eng = model.engine()
     ops = eng.ops
     d = ops.to_device
@@ -108,6 +114,11 @@ def eval_psnr(loader, model, prior_model=None, eval_type=None, patch=True, tempe
     def one(batch, H, W):
         if prior_model is not None:
             return lp_infer(model, prior_model, batch, (H, W), temperature)
+        from ..guard import run_guarded
+        return run_guarded([model], lambda: tau(batch, H, W))
+
+    def tau(batch, H, W):
+        ops = model.engine().ops
         d = ops.to_device
         inp01 = d(batch['inp'])
         B, _, h, w = inp01.shape

@@ -109,6 +109,8 @@ class HipOps(object):
             raise ValueError("BFSR_SPLIT must be 'f16x2' or 'bf16x3'")
         # device word the fp16-split kernels raise when an operand leaves their range (check_range())
         self.range_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # guard.run_guarded: passes re-run under the bf16x3 split because the fp16 pair met a value outside its range (0 in normal operation)
+        self.fallbacks, self._fallback, self._guard_depth, self._range_scratch = 0, None, 0, None
 
     def cu_count(self):
         """Compute units of the device (the persistent kernels launch one workgroup per CU)."""
@@ -878,8 +880,43 @@ class HipOps(object):
             self.range_flag.zero_()
             if v & 4:
                 raise RuntimeError("bfsr_amd: a dependency wait of the fused conv chain timed out (flag 0x%x): results are invalid" % v)
-            raise RuntimeError("bfsr_amd: a value left the range of the two-term fp16 split (flag 0x%x: bit 0 = operand >= 2^15 or NaN, "
-                               "bit 1 = non-finite flow state); rerun with BFSR_SPLIT=bf16x3 (fp32's exponent range, six products)" % v)
+            raise RuntimeError("bfsr_amd: a value left the range of the two-term fp16 split (flag 0x%x: bit 0 = operand >= 65504 or NaN, "
+                               "bit 1 = non-finite flow state, bit 3 = a channel that is tiny everywhere); the guarded entry points re-run such "
+                               "a pass under BFSR_SPLIT=bf16x3 (fp32's exponent range, six products) automatically" % v)
+
+    def check_channels(self, x, tiny=2.0 ** -7, huge=65504.0):
+        """Per-channel dynamic-range check of an fp32 tensor that enters a region computed with the fp16-pair split (range_check.hip): raises
+        bit 3 of the range flag when a channel is tiny everywhere (0 < max |x| < tiny: the pair would keep fewer than 18 significant bits of
+        it), bit 0 when a channel reaches `huge`.  Asynchronous; guard.run_guarded reads the flag at the end of the pass.  No-op under the
+        bf16x3 split and the native fp32 MFMA."""
+        if self.conv_mode != "x3" or self.split != "f16x2":
+            return
+        xp, xbs, Cc, H, W = _view(x, "check_channels.x")
+        n = self.lib.bfsr_channel_range_scratch(Cc)
+        if self._range_scratch is None or self._range_scratch.numel() < n:
+            self._range_scratch = torch.empty(n, dtype=torch.float32, device=self.device)
+        _lib.check(self._launch(("range_check", Cc, x.shape[0], H, W), lambda: self.lib.bfsr_channel_range_check(
+            xp, xbs, x.shape[0], Cc, H, W, tiny, huge, self._range_scratch.data_ptr(), self.range_flag.data_ptr(), self._stream())), "channel_range_check")
+
+    def read_range_flag(self):
+        """The flag word (and clear it).  One 4-byte device->host copy: synchronises the current stream."""
+        v = int(self.range_flag.item())
+        if v:
+            self.range_flag.zero_()
+        return v
+
+    def fallback_ops(self):
+        """A second HipOps on the same device whose fp32-accurate contraction mode is the exact three-term bf16 split (BFSR_SPLIT=bf16x3: fp32's
+        exponent range, six products) -- what guard.run_guarded re-runs a pass on when the fp16-pair split met a value outside its range.
+        Returns self when this object already runs that split (or the native fp32 MFMA)."""
+        if self.conv_mode != "x3" or self.split != "f16x2":
+            return self
+        if self._fallback is None:
+            fb = HipOps(self.device)
+            fb.split, fb.conv_mode = "bf16x3", self.conv_mode
+            fb.profile_keys, fb.profile, fb._keylog = self.profile_keys, self.profile, self._keylog
+            self._fallback = fb
+        return self._fallback
 
     def squeeze2d(self, x, y):
         xp, xbs, Cc, H, W = _view(x)
@@ -1001,6 +1038,7 @@ class HipOps(object):
             mode = 2
             for i in range(4):
                 a.acc_scale[i] = 1.0 / scales[i]
+            a.flag = self.range_flag.data_ptr()
         a.out_fmt = fmt
         a.cf, a.cf_bs, c2, h, w = _view(cf, "linf_mlp.cf")
         a.out, a.out_bs, co, qh, qw = _view(out, "linf_mlp.out")

@@ -66,6 +66,14 @@ class _ConvP(object):
         return ops.conv(x, self.pw, out, epi=self.epi, **kw)
 
 
+def _chk(ops, t):
+    """Per-channel dynamic-range check of an fp32 tensor that enters an fp16-pair region (ops.check_channels; a no-op on other splits / backends)."""
+    f = getattr(ops, "check_channels", None)
+    if f is not None:
+        f(t)
+    return t
+
+
 class _Workspace(object):
     """Named scratch buffers, reallocated only when the requested shape changes."""
 
@@ -203,6 +211,7 @@ class RRDBEncoder(object):
             self._chain = (ckey, [ops.conv_chain(specs)], tapbuf)
         _, chains, tapbuf = self._chain
         self.conv_first.run(ops, x, tmp)
+        _chk(ops, tmp)
         ops.h2_pack(tmp, ring[0][:, :o(nf)])
         if self.skip_from_first:
             ops.h2_pack(tmp, self._first)
@@ -210,6 +219,7 @@ class RRDBEncoder(object):
             ch.run()
         for idx in want:
             on_block(idx, tapbuf[idx], 0, B)
+        _chk(ops, out)
         return out
 
     def _forward_packed(self, x, out, on_block, taps):
@@ -237,6 +247,8 @@ class RRDBEncoder(object):
             xs, outs, tmps = x[b0:b1], out[b0:b1], tmp[b0:b1]
             cur = 0
             self.conv_first.run(ops, xs, tmps)
+            if self.x3s:
+                _chk(ops, tmps)
             pack(tmps, rg[cur][:, :o(nf)])
             if self.skip_from_first:
                 pack(tmps, first)
@@ -259,6 +271,8 @@ class RRDBEncoder(object):
                     on_block(idx, unpack(rg[cur][:, :o(nf)], tmps), b0, b1)
             fea = rg[cur][:, :o(nf)]
             self.trunk_conv.run(ops, fea, outs, res1=first if self.skip_from_first else fea, alpha1=1.0)
+            if self.x3s:
+                _chk(ops, outs)
             yield
 
         # Tile quantisation: a dense-block conv of B x (h/16) x (w/32) tiles runs in ceil(tiles / CUs) rounds of one persistent workgroup per CU
@@ -556,6 +570,7 @@ class SRFlowEngine(object):
         def on_block(idx, fea, b0, b1):
             # nearest-resize the tapped RRDB output (samples b0..b1) into its 64-ch slot of every level (SRFlowNet_arch.py:122-137)
             if idx in self.block_idxs and self.concat:
+                _chk(ops, fea)
                 k = self.block_idxs.index(idx)
                 for level in range(1, self.L + 1):
                     if self._taps_up2(level):
@@ -577,6 +592,7 @@ class SRFlowEngine(object):
             if name in self.upconvs:
                 cur = key_view(name)
                 self.upconvs[name].run(ops, prev, cur, in_shift=1, act=ACT_LRELU, slope=0.2)
+                _chk(ops, cur)
                 prev = cur
         if "fea_up0" in self.need_keys:
             dst = key_view("fea_up0")       # bilinear 1/2, align_corners=False, recompute_scale_factor=True
@@ -774,7 +790,7 @@ class SRFlowEngine(object):
                     ops.flow_pointwise(z, z, False, h_aff=pending)
                     pending = None
                 out = ws.get("enc_z%d" % ly.level, B, ly.C, H // 2, W // 2)
-                z = ops.squeeze2d(z, out)
+                z = _chk(ops, ops.squeeze2d(z, out))        # the coupling heads split z1 into fp16 pairs
             elif ly.type == "step":
                 st = self.steps[ly.index]
                 if ly.coupled:
@@ -844,7 +860,7 @@ class SRFlowEngine(object):
         B = zin.shape[0]
         cur = ws.get("dec_z_top", *zin.shape)
         ops.axpb_clamp(zin, cur)
-        z = cur
+        z = _chk(ops, cur)                                   # the coupling heads split z1 into fp16 pairs
         # the buffer the next (lower-index) split layer concatenates into is prepared when we reach a squeeze
         for pos in reversed(range(len(self.layers))):
             ly = self.layers[pos]

@@ -16,12 +16,13 @@ import torch
 from torch import nn
 
 from .... import paramtree
+from ....guard import EngineHost, run_guarded
 from ... import spec
 from ...engine import SRFlowEngine
 from ...options import opt_get
 
 
-class SRFlowNet(nn.Module):
+class SRFlowNet(nn.Module, EngineHost):
     def __init__(self, in_nc, out_nc, nf, nb, gc=32, scale=4, K=None, opt=None, step=None, ops=None):
         super(SRFlowNet, self).__init__()
         self.opt = opt
@@ -38,27 +39,21 @@ class SRFlowNet(nn.Module):
         n_sq = sum(1 for ly in spec.flow_layers(opt) if ly.type == "squeeze")
         fu.scaleH = fu.scaleW = float(1 << n_sq)              # 160 / H_final (FlowUpsamplerNet.py:112-115)
         self.RRDB_training = True
-        self._ops, self._engine = ops, None
+        self._ops, self._engine, self._fb_engine = ops, None, None
 
     # ---- engine lifecycle -------------------------------------------------------------------
     def load_state_dict(self, state_dict, strict=True):
         r = super(SRFlowNet, self).load_state_dict(state_dict, strict=strict)
-        self._engine = None
+        self._drop_engines()
         return r
 
     def _apply(self, fn, *a, **k):
         r = super(SRFlowNet, self)._apply(fn, *a, **k)
-        self._engine = None
+        self._drop_engines()
         return r
 
-    def engine(self):
-        if self._engine is None:
-            if self._ops is None:
-                from ....ops import HipOps
-                p = next(self.parameters())
-                self._ops = HipOps(p.device if p.is_cuda else None)
-            self._engine = SRFlowEngine(self.opt, self.state_dict(), self._ops, nb=self.nb)
-        return self._engine
+    def _build_engine(self, ops):
+        return SRFlowEngine(self.opt, self.state_dict(), ops, nb=self.nb)
 
     def set_rrdb_training(self, trainable):
         self.RRDB_training = trainable
@@ -67,13 +62,21 @@ class SRFlowNet(nn.Module):
     # ---- reference API --------------------------------------------------------------------------
     def forward(self, gt=None, lr=None, z=None, eps_std=None, reverse=False, epses=None, reverse_with_grad=False,
                 lr_enc=None, add_gt_noise=False, step=None, y_label=None):
-        eng = self.engine()
-        dev = eng.ops.to_device
-        with torch.no_grad():
-            if not reverse:
-                return self.normal_flow(dev(gt), dev(lr), epses=epses, add_gt_noise=add_gt_noise)
-            assert lr.shape[1] == 3
-            return self.reverse_flow(dev(lr), z, eps_std=eps_std, epses=epses, add_gt_noise=add_gt_noise)
+        # range guard of the fp16-pair split with automatic bf16x3 re-run (guard.py); the caller's `epses` list is only extended by the pass
+        # whose result is returned, and a sampled z is drawn once (SRFlowModel.get_z) -- a re-run sees the same inputs
+        n_eps = len(epses) if isinstance(epses, list) else None
+
+        def run():
+            eng = self.engine()
+            dev = eng.ops.to_device
+            if n_eps is not None:
+                del epses[n_eps:]
+            with torch.no_grad():
+                if not reverse:
+                    return self.normal_flow(dev(gt), dev(lr), epses=epses, add_gt_noise=add_gt_noise)
+                assert lr.shape[1] == 3
+                return self.reverse_flow(dev(lr), z, eps_std=eps_std, epses=epses, add_gt_noise=add_gt_noise)
+        return run_guarded([self], run)
 
     def normal_flow(self, gt, lr, y_onehot=None, epses=None, lr_enc=None, add_gt_noise=True, step=None):
         eng = self.engine()

@@ -7,20 +7,21 @@ import torch
 from torch import nn
 
 from ... import paramtree
+from ...guard import EngineHost
 from .. import spec
 from ..unet_engine import SRFlowPriorEngine
 from .models import register
 
 
-class UNet(nn.Module):
+class UNet(nn.Module, EngineHost):
     def __init__(self, depth=3, dim=64, bilinear=True, ops=None):
         super(UNet, self).__init__()
         self.depth, self.dim, self.bilinear = depth, dim, bilinear
         paramtree.attach(self, spec.srflow_prior_schema(depth, dim, bilinear), paramtree.default_init(1))
-        self._ops, self._engine = ops, None
+        self._ops, self._engine, self._fb_engine = ops, None, None
 
     def _invalidate(self, *a, **k):
-        self._engine = None
+        self._drop_engines()
 
     def load_state_dict(self, state_dict, strict=True):
         r = super(UNet, self).load_state_dict(state_dict, strict=strict)
@@ -32,13 +33,8 @@ class UNet(nn.Module):
         self._invalidate()
         return r
 
-    def engine(self):
-        if self._engine is None:
-            if self._ops is None:
-                from ...ops import HipOps
-                self._ops = HipOps(next(self.parameters()).device if next(self.parameters()).is_cuda else None)
-            self._engine = SRFlowPriorEngine(self.state_dict(), self._ops, self.depth)
-        return self._engine
+    def _build_engine(self, ops):
+        return SRFlowPriorEngine(self.state_dict(), ops, self.depth)
 
     def forward(self, epses):
         if self.training:

@@ -88,21 +88,27 @@ def _lp_lane(eng, prior_eng, lr, scale, sr_out, keep=None):
 
 def lp_infer(model, prior_model, lr_t, return_all=False, check_range=True):
     """lr_t [B,3,h,w] in [0,1] (h, w even) -> sr [B,3,s*h,s*w] clamped to [0,1].
-    check_range: raise if a kernel of the two-term fp16 split met a value outside its range during the pass (ops.check_range(): one
-    4-byte device->host read = a stream synchronisation; the reference's loop synchronises here anyway, test.py:150 `.cpu()`)."""
+    check_range (default): the pass runs under the range guard of the two-term fp16 split (guard.run_guarded): if a kernel met a value the
+    split cannot hold, the whole pass is re-run under the bf16x3 split (fp32's exponent range) and that result is returned -- never inf / NaN
+    from an overflow, never a silently wrong value.  Cost: one 4-byte device->host read at the end of the pass (the reference's loop
+    synchronises there anyway, test.py:150 `.cpu()`).  False skips the guard (and the synchronisation)."""
     net = model.netG.module
-    eng = net.engine()
-    ops = eng.ops
     scale = model.opt['scale']
-    with torch.no_grad():
-        lr = ops.to_device(lr_t)
-        B, _, h, w = lr.shape
-        sr = ops.empty(B, 3, h * scale, w * scale)
-        keep = {} if return_all else None
-        _lp_lane(eng, prior_model.engine(), lr, scale, sr, keep)
-        if check_range and hasattr(ops, "check_range"):
-            ops.check_range()
-    return keep if return_all else sr
+
+    def run():
+        eng = net.engine()
+        ops = eng.ops
+        with torch.no_grad():
+            lr = ops.to_device(lr_t)
+            B, _, h, w = lr.shape
+            sr = ops.empty(B, 3, h * scale, w * scale)
+            keep = {} if return_all else None
+            _lp_lane(eng, prior_model.engine(), lr, scale, sr, keep)
+        return keep if return_all else sr
+    if not check_range:
+        return run()
+    from ..guard import run_guarded
+    return run_guarded([net, prior_model], run)
 
 
 def format_measurements(meas):

@@ -226,6 +226,15 @@ int bfsr_conv_chain_prepare(const BfsrChainConv* convs, int nconv, int B, int H,
 long long bfsr_conv_chain_progress_words(const void* table_host);
 int bfsr_conv_chain_launch(const void* table_host, const void* table_dev, unsigned* progress, unsigned* status, int tune, void* stream);
 
+/* ---- per-channel dynamic-range check of a tensor entering an fp16-split region (round 5, range_check.hip; bfsr_amd/guard.py) -----------
+ * The two-term fp16 split of the default path (bfsr_conv3x3_h2x and friends) holds 22 significant bits for 2^-3 <= |x| < 65504.  Replaces
+ * nothing in the reference: it is what lets the engine keep the reference's fp32 contract (RRDBNet_arch.py:39-45, LINF-LP/models/rrdb.py:52-58
+ * contract in true fp32) -- a pass whose tensors leave that range is re-run under the bf16x3 split.  Raises in *flag: bit 3 when a channel's
+ * max |x| over the whole [B,C,H,W] view is in (0, tiny), bit 0 when it is >= huge or not finite.  scratch: bfsr_channel_range_scratch(C) floats. */
+long long bfsr_channel_range_scratch(int C);
+int bfsr_channel_range_check(const float* x, long long x_bs, int B, int C, int H, int W, float tiny, float huge, float* scratch,
+                             unsigned* flag, void* stream);
+
 /* ---- fused flow-step pointwise chain -----------------------------------------------------------
  * One read of z / h_aff / h_ft, one write of z (the HBM-roofline "coupling inverse" kernel of
  * BASELINE.json).  replaces, per FlowStep (SRFlow-LP/code/models/modules/):
@@ -408,6 +417,7 @@ typedef struct BfsrLinfMlpArgs {
                                     * four consecutive output rows of a query point stores them as ONE 16-byte word (4x fewer store
                                     * instructions, full 64-byte sectors); read by bfsr_linf_flow with ai_fmt = 1 */
     float acc_scale[4];            /* x3 == 2 only: 1 / (the power of two layer i's weights were packed with, bfsr_pack_linf_mlp_f16x2) */
+    unsigned* flag;                /* x3 == 2 only, optional device word: bit 0 is set when a feature or hidden activation handed to the fp16 split is >= 65504 (ABI 3) */
 } BfsrLinfMlpArgs;
 /* x3: 0 = operands rounded to fp16 (LINF precision='fp16'); 1 = exact three-term bf16 split, six products; 2 = two-term fp16 split of
  * both operands, three products (fp32-class accuracy at half the matrix instructions of 1; weights from bfsr_pack_linf_mlp_f16x2) */

@@ -1,0 +1,170 @@
+"""-m gpu: the range guard of the two-term fp16 split is unconditional (bfsr_amd/guard.py): every public entry point
+either returns the right answer or raises -- never inf / NaN from an overflow, never a silently wrong value.
+
+The hostile models are EXACT rescalings of the seeded synthetic ones (powers of two, so the rescaled network is the same function up to
+rounding): the RRDB trunk's activations are multiplied by S = 2^17 (beyond fp16's 65504: the fp16 pair cannot hold them) or by 2^-17 (far
+below the 2^-3 at which the lo term of the pair goes subnormal) and every consumer of the trunk's outputs is divided by S.  An arithmetic
+with fp32's exponent range does not care; the fp16 pair must notice and the pass must be re-run under the bf16x3 split.  Truth = the CPU
+oracle on the same rescaled weights."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from bfsr_amd import synth                      # noqa: E402
+from bfsr_amd.srflow import options, spec       # noqa: E402
+
+
+def rescale_trunk(sd, opt, S):
+    """RRDB trunk activations x S (conv_first and every bias of the trunk; LeakyReLU and the residual sums are positively homogeneous), the
+    consumers / S: upconv1 (-> fea_up2 at its old scale) and the conditioning rows of fFeatures.0 / fAffine.0 that read trunk outputs -- the 256
+    stacked tap channels at every level, and the 64 key channels at the levels whose key IS the trunk output (fea_up1, fea_up0)."""
+    sd = {k: v.clone() for k, v in sd.items()}
+    for k in sd:
+        if k in ("RRDB.conv_first.weight", "RRDB.conv_first.bias", "RRDB.trunk_conv.bias") or (k.startswith("RRDB.RRDB_trunk.") and k.endswith(".bias")):
+            sd[k] = sd[k] * S
+    sd["RRDB.upconv1.weight"] = sd["RRDB.upconv1.weight"] / S
+    names = spec.level_to_name(opt["scale"])
+    for ly in spec.flow_layers(opt):
+        if ly.type != "step" or not ly.coupled:
+            continue
+        lo = 64 if names[ly.level] in ("fea_up2", "fea_up4", "fea_up8") else 0          # keys produced by the upconv chain keep their scale
+        p = "flowUpsamplerNet.layers.%d.affine." % ly.index
+        wf, wa = sd[p + "fFeatures.0.weight"], sd[p + "fAffine.0.weight"]
+        nz = wa.shape[1] - 320
+        wf[:, lo:] /= S
+        wa[:, nz + lo:] /= S
+    return sd
+
+
+def rescale_key_channels(sd, opt, chans, s):
+    """A few channels of fea_up2 (upconv1's output, the 64 key channels of level 1) sit a factor s below the rest: those rows of upconv1
+    (weight and bias; the LeakyReLU behind it is positively homogeneous) x s, the rows of the level-1 conditioning convs that read them / s."""
+    sd = {k: v.clone() for k, v in sd.items()}
+    idx = torch.tensor(list(chans))
+    sd["RRDB.upconv1.weight"][idx] *= s
+    sd["RRDB.upconv1.bias"][idx] *= s
+    for ly in spec.flow_layers(opt):
+        if ly.type == "step" and ly.coupled and spec.level_to_name(opt["scale"])[ly.level] == "fea_up2":
+            p = "flowUpsamplerNet.layers.%d.affine." % ly.index
+            wf, wa = sd[p + "fFeatures.0.weight"], sd[p + "fAffine.0.weight"]
+            nz = wa.shape[1] - 320
+            wf[:, idx] /= s
+            wa[:, nz + idx] /= s
+    return sd
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from bfsr_amd.ops import HipOps
+    return HipOps("cuda:0")
+
+
+def _models(ops, opt, sd, psd):
+    from bfsr_amd.srflow.models import create_model, models as registry
+    m = create_model(opt, ops=ops)
+    m.load_network(sd)
+    prior = registry.make({"name": "unet", "args": {"depth": 3, "dim": 64, "bilinear": True, "ops": ops}, "sd": psd}, load_sd=True).eval()
+    return m, prior
+
+
+@pytest.mark.parametrize("S", [2.0 ** 17, 2.0 ** -17, 2.0 ** -10, "channels", 1.0])
+def test_srflow_lp_pass_on_rescaled_trunk(S):
+    """lp_infer and the SRFlowModel call sequence of test.py:139-148 on the rescaled model against the CPU oracle (fp32) on the same weights:
+    <= 1e-4 on sr -- through the bf16x3 re-run for S = 2^17 (ops.fallbacks counts it), and for S = 2^-17 either way.  S = 1: no fallback."""
+    import oracle.srflow_ref as O
+    from bfsr_amd.ops import HipOps
+    from bfsr_amd.srflow.test import lp_infer
+    opt = options.load(options.DEFAULT_CONF)
+    sd0 = synth.state_dict_from_schema(spec.srflownet_schema(opt), 1234)
+    if S == "channels":         # three key channels 2^-13 (1.2e-4) below the rest, the weights that read them 2^13 above
+        sd, S = rescale_key_channels(sd0, opt, (3, 17, 40), 2.0 ** -13), 0.5
+    else:
+        sd = rescale_trunk(sd0, opt, S)
+    psd = synth.state_dict_from_schema(spec.srflow_prior_schema(), 4321)
+    lr = synth.smooth_lr_batch(5, 1, 16, 16)
+    truth = O.lp_pipeline(lr, sd, psd, opt, 23, return_all=True)
+    if S in (2.0 ** 17, 0.5):        # (one oracle run more: only where a new kind of rescaling is introduced)
+        base = O.lp_pipeline(lr, sd0, psd, opt, 23, return_all=True)
+        assert float((truth["sr"] - base["sr"]).abs().max()) <= 2e-5, "the rescaling is not function-preserving"
+    ops = HipOps("cuda:0")
+    m, prior = _models(ops, opt, sd, psd)
+    out = lp_infer(m, prior, lr, return_all=True)
+    for k in ("sr_raw", "sr"):
+        got = out[k].cpu()
+        assert torch.isfinite(got).all(), k
+        err = float((got - truth[k]).abs().max())
+        assert err <= 1e-4, "S = %g: %s max-abs %.3e (fallbacks %d)" % (S, k, err, ops.fallbacks)
+    print("S = %g: fallbacks %d" % (S, ops.fallbacks))
+    if S > 1:
+        assert ops.fallbacks == 1, "an overflow of the fp16 pair must re-run the pass under bf16x3"
+    if S == 1:
+        assert ops.fallbacks == 0
+    # the wrapper API: get_encode_z -> standardise -> prior -> get_sr, each call guarded on its own
+    n0 = ops.fallbacks
+    import torch.nn.functional as F
+    lr_up = F.interpolate(lr, scale_factor=opt["scale"], mode="bilinear", align_corners=False)
+    eps = m.get_encode_z(lr, lr_up, epses=[], add_gt_noise=False)
+    assert len(eps) == 2
+    eps = [(e - e.mean(dim=1, keepdim=True)) / (e.std(dim=1, keepdim=True) + 1e-8) for e in eps]
+    sr = m.get_sr(lq=lr, epses=prior(eps))
+    assert torch.isfinite(sr).all()
+    assert float((sr.cpu() - truth["sr_raw"]).abs().max()) <= 1e-4
+    if S > 1:
+        assert ops.fallbacks >= n0 + 2, "get_encode_z and get_sr each overflow and each fall back"
+
+
+def test_guard_is_off_only_when_asked(hip):
+    """check_range=False skips the guard (and its synchronisation): the overflow then stays visible in the flag word."""
+    from bfsr_amd.ops import HipOps
+    from bfsr_amd.srflow.test import lp_infer
+    opt = options.load(options.DEFAULT_CONF)
+    sd = rescale_trunk(synth.state_dict_from_schema(spec.srflownet_schema(opt), 1234), opt, 2.0 ** 17)
+    psd = synth.state_dict_from_schema(spec.srflow_prior_schema(), 4321)
+    ops = HipOps("cuda:0")
+    m, prior = _models(ops, opt, sd, psd)
+    lp_infer(m, prior, synth.smooth_lr_batch(5, 1, 16, 16), check_range=False)
+    assert ops.fallbacks == 0
+    with pytest.raises(RuntimeError, match="range of the two-term fp16 split"):
+        ops.check_range()
+
+
+@pytest.mark.parametrize("S", [2.0 ** 17, 2.0 ** -17])
+def test_linf_pass_on_rescaled_encoder(S):
+    """The LINF side: the RRDB encoder's activations x S (conv_first + every encoder bias), its consumers (the coef | freq convs) / S.  lp_infer and
+    infer_from_lr agree with the oracle; S = 2^17 overflows inside the encoder and goes through the fallback."""
+    import oracle.linf_ref as OL
+    from bfsr_amd.ops import HipOps
+    from bfsr_amd.linf.models import make
+    from bfsr_amd.linf.test import lp_infer, infer_from_lr
+    from test_linf_cpu import mspec, weights
+    sd, psd = weights("rrdb", 2024)
+    base = {k: v.clone() for k, v in sd.items()}
+    for k in sd:
+        if k in ("encoder.conv_first.weight", "encoder.conv_first.bias", "encoder.trunk_conv.bias") or (k.startswith("encoder.RRDB_trunk.") and k.endswith(".bias")):
+            sd[k] = sd[k] * S
+    for n in ("coef.weight", "freq.weight"):
+        sd[n] = sd[n] / S
+    ops = HipOps("cuda:0")
+    m = make(mspec("rrdb"), args={"ops": ops}).eval()
+    m.load_state_dict(sd)
+    prior = make({"name": "unet", "args": {"in_chans": 27, "depth": 3, "dim": 64, "bilinear": True}}, args={"ops": ops}).eval()
+    prior.load_state_dict(psd)
+    lr = synth.smooth_lr_batch(9, 1, 24, 24)
+    H = W = 96
+    batch = OL.batch_prep(lr, (H, W))
+    truth = OL.lp_pipeline(batch, sd, psd, mspec("rrdb"), (H, W), return_all=True)
+    if S > 1:
+        ref0 = OL.lp_pipeline(batch, base, psd, mspec("rrdb"), (H, W), return_all=True)
+        assert float((truth["pred"] - ref0["pred"]).abs().max()) <= 2e-5, "the rescaling is not function-preserving"
+    out = lp_infer(m, prior, batch, (H, W), return_all=True)
+    for k in ("z_lr", "pred"):
+        got = out[k].cpu()
+        assert torch.isfinite(got).all(), k
+        err = float((got - truth[k]).abs().max())
+        assert err <= 1e-4 * max(1.0, float(truth[k].abs().max())), "S = %g: %s max-abs %.3e (fallbacks %d)" % (S, k, err, ops.fallbacks)
+    if S > 1:
+        assert ops.fallbacks == 1, "an overflow inside the encoder must re-run the pass under bf16x3"
+    again = infer_from_lr(m, prior, lr, 4)
+    assert float((again.cpu() - truth["pred"]).abs().max()) <= 1e-4

@@ -436,6 +436,10 @@ extern "C" int bfsr_conv2d_up2_h2t(const BfsrUp2H2Args* a, void* stream)
     if (!a || !a->x || !a->w || !a->y || a->B <= 0 || a->h <= 0 || a->w_ <= 0 || a->Cin <= 0 || a->Cin % 16 || a->Cout <= 0 || a->Cout % 32) return -1;
     if (a->Ckey < 0 || a->Ckey % 16 || 4 * a->Ckey > a->Cin) return -1;
     if (a->y_fmt != 1) return -1;                                                               // quad-major fp32 only
+    // 16-byte accesses on y / pre_add (quad-major) and LDS-DMA on x: misaligned views are refused, not faulted on
+    if ((reinterpret_cast<unsigned long long>(a->x) & 15) || (a->x_bs & 7)) return -1;
+    if ((reinterpret_cast<unsigned long long>(a->y) & 15) || (a->y_bs & 3)) return -1;
+    if (a->pre_add && ((reinterpret_cast<unsigned long long>(a->pre_add) & 15) || (a->pre_add_bs & 3))) return -1;
     if ((long long)(a->Cin / 8) * 2 * a->h * a->w_ * 16 >= (1LL << 31)) return -1;              // 32-bit buffer offsets (source, per sample)
     if (8LL * 4 * a->h * a->w_ * 16 >= (1LL << 31)) return -1;                                   // (8 output channel quads of one sample)
     const int tiles_x = (a->w_ + 31) / 32, tiles_y = (a->h + TH - 1) / TH, groups = a->Cout / 32;

@@ -1,7 +1,8 @@
 """Counterpart of the reference's `Measure` (SRFlow-LP/code/Measure.py:31-53) for the metrics that can run without pretrained
-networks: PSNR on uint8 HWC images, computed on the device.  `Measure.psnr` there is skimage's
-`peak_signal_noise_ratio(imgA, imgB)` = 10 log10(255^2 / mse) for uint8 inputs.  SSIM (skimage's 7x7 uniform-window variant)
-and LPIPS (pretrained AlexNet) are outside the accelerated path."""
+networks, computed on the device from uint8 HWC images: `psnr` (skimage's `peak_signal_noise_ratio` = 10 log10(255^2 / mse) for uint8
+inputs) and `ssim` (skimage's 7x7 uniform-window `structural_similarity`; the restatement it is tested against is unpinned -- scikit-image
+is not in this image, oracle/metrics_ref.py says so).  LPIPS needs the pretrained AlexNet weights (a download): `measure` keeps the
+reference's three-element return value with NaN in the LPIPS slot (INTEGRATION.md lists the deviation); `lpips` itself raises."""
 import numpy as np
 import torch
 
@@ -38,8 +39,9 @@ class Measure(object):
         raise NotImplementedError("Measure.lpips needs the pretrained AlexNet LPIPS weights (lpips package): outside the path, not in this image")
 
     def measure(self, imgA, imgB, with_lpips=True):
-        """Measure.py:37-38: [psnr, ssim, lpips].  LPIPS cannot be computed here (pretrained network); with_lpips=False returns [psnr, ssim]."""
+        """Measure.py:37-38: [psnr, ssim, lpips] -- the reference's return value; the LPIPS entry is NaN (no pretrained network offline),
+        so drop-in callers that unpack three values keep working.  with_lpips=False returns [psnr, ssim]."""
         out = [float(self.psnr(imgA, imgB)), float(self.ssim(imgA, imgB))]
         if with_lpips:
-            out.append(float(self.lpips(imgA, imgB)))
+            out.append(float("nan"))
         return out

@@ -653,6 +653,18 @@ class SRFlowEngine(object):
                 self._ftx3 = {}
             if level not in self._ftx3 or self._ftx3[level][0] != key:
                 self._ftx3[level] = (key, self.ops.x3_empty(B, cx, hl, wl))
+        # h2 tensors the level's hoists fill (possibly on the side stream): allocated HERE, per level, like every other hoist buffer
+        if hz.get("ffast"):
+            h2 = self._hid.get("ffh%d" % level)
+            if h2 is None or tuple(h2.shape) != (B, 8, 2, hl, wl, 8):
+                self._hid["ffh%d" % level] = self.ops.h2_empty(B, 64, hl, wl)
+        if hz.get("up2") and hz.get("h2t") is not None:
+            taps = ft[self._lr_level()][:, 64:]
+            key = (B, taps.shape[1] + 4 * 64) + tuple(taps.shape[2:])
+            if getattr(self, "_taps_h2", None) is None:
+                self._taps_h2 = {}
+            if level not in self._taps_h2 or self._taps_h2[level][0] != key:
+                self._taps_h2[level] = (key, self.ops.h2_empty(*key))
         return (ws.get("hoist_hid%d" % level, B, K * 64, hl, wl), ws.get("pre_aff%d" % level, B, K * 64, hl, wl),
                 ws.get("h_ft%d" % level, B, K * 2 * Cz, hl, wl), Cz)
 
@@ -678,10 +690,7 @@ class SRFlowEngine(object):
                     # one h2 tensor at LR resolution: the 256 tap channels, then the four space-to-depth planes of the 64 key channels
                     # (fea_up2) -- the key conv and the pre_add round trip are K chunks of the taps kernel
                     ct = taps.shape[1]
-                    key = (B, ct + 4 * 64) + tuple(taps.shape[2:])
-                    if getattr(self, "_taps_h2", None) is None or self._taps_h2[0] != key:
-                        self._taps_h2 = (key, ops.h2_empty(*key))
-                    taps_h2 = self._taps_h2[1]
+                    taps_h2 = self._taps_h2[level][1]                  # allocated by _hoist_buffers on the caller's stream
                     ops.h2_pack(taps, taps_h2[:, :ct // 8])
                     ops.h2_pack_s2d(f[:, :64], taps_h2[:, ct // 8:])
                     ops.conv_up2_h2t(taps_h2, h2t[0], hid)
@@ -720,10 +729,7 @@ class SRFlowEngine(object):
             st = self.steps[i]
             hk = hid[:, 64 * k: 64 * (k + 1)]
             if ff:
-                key = "ffh%d" % level
-                h2 = self._hid.get(key)
-                if h2 is None or tuple(h2.shape) != (B, 8, 2, hk.shape[2], hk.shape[3], 8):
-                    h2 = self._hid[key] = ops.h2_empty(B, 64, hk.shape[2], hk.shape[3])
+                h2 = self._hid["ffh%d" % level]                       # allocated by _hoist_buffers on the caller's stream
                 ops.coupling_head(None, st.fthead, hk, h2, pre_fmt=ffq)
                 if st.ft4x is not None:
                     ops.conv_h2x(h2, st.ft4x[0], h_ft[:, 2 * Cz * k: 2 * Cz * (k + 1)], epi=st.ft4x[1], y_fmt=hq[i])

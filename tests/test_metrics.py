@@ -91,8 +91,10 @@ def _check_ssim_and_measure(ops, golden_dir):
     flat2 = np.full((9, 9, 3), 110, np.uint8)
     assert abs(me.ssim(flat, flat2) - (2 * 100 * 110 + 6.5025) / (100 ** 2 + 110 ** 2 + 6.5025)) <= 1e-12
     assert me.measure(a, b, with_lpips=False) == [me.psnr(a, b), me.ssim(a, b)]
+    full = me.measure(a, b)                                # the reference's three-element return value; LPIPS (pretrained AlexNet) is NaN here
+    assert len(full) == 3 and full[:2] == [me.psnr(a, b), me.ssim(a, b)] and full[2] != full[2]
     with pytest.raises(NotImplementedError):
-        me.measure(a, b)
+        me.lpips(a, b)
 
 
 def test_ssim_and_measure_on_cpu_double(golden_dir):

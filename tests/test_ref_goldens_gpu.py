@@ -132,3 +132,65 @@ def test_flowstep_goldens(hip, golden_dir, li):
     hip.flow_pointwise(z, z, True, h_aff=h_aff(z) if coupled else None, h_ft=h_ft, w=hip.vec(Winv), wt=hip.vec(Winv.t().contiguous()),
                        an_escale=hip.vec(torch.exp(-logs)), **an)
     close(z, T(g["step%d_rev" % li]), 2e-5, "FlowStep %d reverse" % li)
+
+
+@pytest.mark.parametrize("tag,la,lb", [("l1", 3, 4), ("l2", 23, 24)])
+@pytest.mark.parametrize("quads", [True, False])
+def test_flowstep_goldens_through_the_fused_pair(hip, golden_dir, tag, la, lb, quads):
+    """Reference goldens of two CONSECUTIVE coupled FlowSteps (FlowStep.py:88-129 on the genuine modules, tests/golden/make_golden_steps_fused.py)
+    through the engine's DEFAULT hot path, not the generic composition above: the level's hoist producers (level 1: conv_up2_h2t over the h2
+    taps + space-to-depth key planes, the 1x1-only coupling_head, conv_h2r; level 2: the batched 320 -> 1024 hoists) -> coupling_head ->
+    coupling_tail, in decode order (b then a) and in encode order (a then b: the tail of step a applies the head of step b), with the
+    quad-major hand-over of pre_aff / h_ft (the default) and with NCHW tensors.  B = 2, 36 x 40 / 18 x 20: several 16 x 32 tiles, ragged."""
+    from test_srflow_gpu import build
+    m, prior, opt, sd, psd = build(hip, 4)
+    g = np.load(os.path.join(golden_dir, "srflow_steps_fused.npz"))
+    if bytes(g["weights_sha256"]).decode() != synth.digest(sd):
+        pytest.skip("synthetic weights differ on this machine (numpy/LAPACK build)")
+    eng = m.netG.module.engine()
+    ops, d = eng.ops, hip.to_device
+    z0 = d(T(g[tag + "_z"]))
+    B, C, H, W = z0.shape
+    level = [ly.level for ly in eng.layers if ly.index == la][0]
+    ft = {}
+    if tag == "l1":
+        assert eng._taps_up2(level) == 1
+        ft[level] = d(T(g["l1_key"]))                                    # this level keeps its 64 key channels only; the taps live at LR resolution
+        lrl = eng._lr_level()
+        ft[lrl] = hip.zeros(B, 320, H // 2, W // 2)
+        ft[lrl][:, 64:].copy_(d(T(g["l1_taps"])))
+    else:
+        ft[level] = d(T(g["l2_ft"]))
+    hz = eng.hoist[level]
+    eng._hoist_buffers(level, hz, ft, B)
+    cnd = eng._hoist_level(level, hz, ft, B, quads)
+    assert cnd["pre_fmt"] == int(quads) or not quads
+    sa, sb = eng.steps[la], eng.steps[lb]
+    assert getattr(sa, "fused", False) and getattr(sb, "fused", False), "the default path of levels 1 and 2 is the fused pair"
+
+    def hft(idx):
+        k = cnd["slot"][idx]
+        return cnd["h_ft"][:, 2 * C * k: 2 * C * (k + 1)]
+
+    def pre(idx):
+        k = cnd["slot"][idx]
+        return cnd["pre_aff"][:, 64 * k: 64 * (k + 1)]
+
+    # ---- decode order: step b reversed, then step a (engine.decode)
+    z = z0.clone()
+    for st, idx, ref in ((sb, lb, "_rev_b"), (sa, la, "_rev_ba")):
+        kw = dict(h_ft=hft(idx), h_ft_fmt=cnd["h_ft_fmt"][idx], w=st.w_inv, an_bias=st.an_bias, an_escale=st.an_expneg)
+        z = eng._pair(st, z, pre(idx), "gold_dec", True, kw, cnd["pre_fmt"])
+        close(z, T(g[tag + ref]), 2e-5, "fused pair, reverse, step %d (quads %s)" % (idx, quads))
+    # ---- encode order (engine.encode): the head of step a on the generic kernel (its h_ft slot stays NCHW: step a is the level's first coupled
+    # step), then pair(a) whose tail applies step b's ActNorm, W and feature-conditional affine, then pair(b)
+    assert cnd["h_ft_fmt"][la] == 0
+    z = z0.clone()
+    ops.flow_pointwise(z, z, False, an_bias=sa.an_bias, an_escale=sa.an_exp, w=sa.w_fwd, wt=sa.w_fwd_t, h_ft=hft(la))
+    z1 = eng._pair(sa, z.clone(), pre(la), "gold_enc", False, {}, cnd["pre_fmt"])
+    close(z1, T(g[tag + "_fwd_a"]), 2e-5, "fused pair, forward, step %d alone (quads %s)" % (la, quads))
+    kw = dict(an_bias=sb.an_bias, an_escale=sb.an_exp, w=sb.w_fwd, h_ft=hft(lb), h_ft_fmt=cnd["h_ft_fmt"][lb])
+    z = eng._pair(sa, z, pre(la), "gold_enc", False, kw, cnd["pre_fmt"])
+    z = eng._pair(sb, z, pre(lb), "gold_enc", False, {}, cnd["pre_fmt"])
+    close(z, T(g[tag + "_fwd_ab"]), 2e-5, "fused pairs, forward, steps %d + %d (quads %s)" % (la, lb, quads))
+    ops.check_range()

@@ -52,9 +52,10 @@ def test_engine_is_reproducible_run_to_run(scale, lr_size, overlap, rounds, batc
     hip.check_range()
 
 
-def test_linf_pipeline_is_reproducible_run_to_run():
-    """The same guard for the LINF-LP path (fp32-accurate mode: conv_h2x encoder, fused MLP, flow): 25 LP passes over a fixed
-    batch reproduce the first one bit for bit."""
+@pytest.mark.parametrize("precision,rounds", [("fp32", 25), ("fp16", 15)])
+def test_linf_pipeline_is_reproducible_run_to_run(precision, rounds):
+    """The same guard for the LINF-LP path, in the fp32-accurate mode (conv_h2x encoder, fused MLP on the fp16 pair, flow) and on the fp16 MFMA
+    path of BASELINE config 5 (conv_h2s encoder, linf_mlp<fp16>, conv_f16): LP passes over a fixed batch reproduce the first one bit for bit."""
     import torch
     from bfsr_amd import synth
     from bfsr_amd.ops import HipOps
@@ -62,11 +63,11 @@ def test_linf_pipeline_is_reproducible_run_to_run():
     from bfsr_amd.linf.test import lp_infer
     from test_linf_gpu import _bench_size_models
     hip = HipOps("cuda:0")
-    m, prior, sd, psd = _bench_size_models(hip, "fp32")
+    m, prior, sd, psd = _bench_size_models(hip, precision)
     lr = hip.to_device(synth.smooth_lr_batch(44, 4, 96, 96))
     batch = prep.prepare_batch(hip, lr, (384, 384), 3, True)
     ref = None
-    for it in range(25):
+    for it in range(rounds):
         out = lp_infer(m, prior, batch, (384, 384), return_all=True)
         cur = {k: out[k].clone() for k in ("z_lr", "z_learned", "pred")}
         if ref is None:

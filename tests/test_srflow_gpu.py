@@ -156,6 +156,23 @@ def test_roundtrip_and_batch_invariance_at_bench_size(model4, hip):
                                  % (lvl, float(df.max()), idx.shape[0], df.numel(), idx[0].tolist(), sorted(set(idx[:, 1].tolist()))[:12]))
 
 
+def test_lp_pass_at_bench_batch_vs_oracle(model4, hip):
+    """The parity check bench.py makes, inside pytest: the LP pass over the BASELINE config-2 batch (B = 8 crops of 160 x 160 -> 640 x 640: the
+    fused dense-block chain, the side stream and every persistent kernel looping over several items per workgroup are active only at this
+    size) against the pinned oracle on ONE of the crops (the CPU oracle needs ~6 s per crop), <= 1e-4 max-abs on sr (north_star)."""
+    import oracle.srflow_ref as O
+    from bfsr_amd.srflow.test import lp_infer
+    m, prior, opt, sd, psd = model4
+    lr = synth.smooth_lr_batch(77, 8, 160, 160)
+    out = lp_infer(m, prior, lr, return_all=True)
+    pick = 5
+    ref = O.lp_pipeline(lr[pick:pick + 1], sd, psd, opt, 23, return_all=True)
+    for k in ("sr_raw", "sr"):
+        err = float((out[k][pick:pick + 1].cpu() - ref[k]).abs().max())
+        assert err <= 1e-4, "%s of crop %d in the B = 8 batch: max-abs %.3e vs the oracle" % (k, pick, err)
+    assert m.netG.module.engine().ops.fallbacks == 0
+
+
 def test_roundtrip_and_batch_invariance_at_config4_size(hip):
     """BASELINE config 4's per-GPU batch on the 8x model (B = 8, 96x96 LR -> 768x768): decode(encode(x)) = x within 1e-4, the LP pass is
     finite, and a shard of the batch gives bit-identical latents (what the data-parallel split of the 64-crop batch relies on)."""

@@ -15,6 +15,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _cpu_threads():
+    """The CPU oracle runs in many tests; on the 256-thread hosts of the GPU boxes torch's default (all threads) is 3-5x SLOWER than 16
+    (profiles/r03_cpu_thread_sweep.json: 5.7 s at 16 threads, 16 s at 64, 30 s at 128 for one 160 x 160 crop)."""
+    import torch
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

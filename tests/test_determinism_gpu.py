@@ -1,5 +1,5 @@
 """-m gpu: run-to-run bitwise determinism -- of every MFMA kernel alone (tools/determinism_stress.py, 30 launches each) and of the
-engines' whole kernel sequences (300 rounds): timing-dependent faults show in a fraction of the launches, which one parity run can miss
+engines' whole kernel sequences (100 rounds; the opt-in soak test_soak_* runs 10^5 launches): timing-dependent faults show in a fraction of the launches, which one parity run can miss
 ("the head fault")."""
 import os
 import subprocess
@@ -16,11 +16,11 @@ def test_mfma_kernels_are_run_to_run_deterministic():
     assert r.returncode == 0 and "TOTAL differing launches: 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("scale,lr_size,overlap,rounds,batch", [(4, 160, None, 300, 2), (4, 160, "0", 60, 2), (8, 96, None, 300, 2), (4, 160, None, 30, 8)])
+@pytest.mark.parametrize("scale,lr_size,overlap,rounds,batch", [(4, 160, None, 100, 2), (4, 160, "0", 40, 2), (8, 96, None, 100, 2), (4, 160, None, 30, 8)])
 def test_engine_is_reproducible_run_to_run(scale, lr_size, overlap, rounds, batch, monkeypatch):
     """The fault class that isolated kernel stress does not see (round 3: the 8-wave coupling_head wrote a wrong half row once in
-    10^3-10^4 launches, only inside the engine's kernel sequence; study: tools/exp/head_fault.py).  300 rounds of
-    encode(B=2) -> decode -> encode(sample 1) on fixed inputs -- ~20 000 head and tail launches per case -- must reproduce round 0 bit for bit,
+    10^3-10^4 launches, only inside the engine's kernel sequence; study: tools/exp/head_fault.py).  100 rounds of
+    encode(B=2) -> decode -> encode(sample 1) on fixed inputs -- ~6 500 head and tail launches per case; the opt-in soak below runs 2 x 10^5 -- must reproduce round 0 bit for bit,
     and the single-sample call must equal the batch call's sample.  Cases: the 4x model with and without the side stream, the 8x model
     (C = 12 / 24 levels at 384^2 / 192^2); and 30 rounds at the bench batch (B = 8: every persistent kernel loops over several items per
     workgroup there -- the regime in which the store-data hazard of DESIGN.md section 3 item 8 showed and B = 2 did not)."""
@@ -74,3 +74,39 @@ def test_linf_pipeline_is_reproducible_run_to_run(precision, rounds):
             ref = cur
         for k in cur:
             assert torch.equal(cur[k], ref[k]), "round %d: %s differs from round 0" % (it, k)
+
+
+@pytest.mark.skipif(not os.environ.get("BFSR_SOAK"), reason="opt-in soak (BFSR_SOAK=<rounds>, minutes of GPU time): see DESIGN.md section 5, round 5")
+def test_soak_coupling_pair_inside_the_engine_sequence():
+    """coupling_tail_kernel<0,12,*> has the two ingredients of the round-3 head fault's signature (VGPR-returning loads
+    landing under a dependent MFMA chain; two barrier-locked waves per SIMD).  300 engine rounds are evidence for ~2 x 10^4 launches; the round-3
+    fault needed 10^3-10^4 launches per event.  This soak runs BFSR_SOAK rounds (default use: 6500 = 2 x 10^5 level-1 tail launches and as many
+    head launches, the same again at level 2) of encode + decode on fixed inputs INSIDE the engine's kernel sequence and compares every round's
+    latents and image with round 0 on the device, bit for bit.  Results per box: profiles/r05_soak_*.txt."""
+    import torch
+    from bfsr_amd import synth
+    from bfsr_amd.ops import HipOps, MODE_BILINEAR
+    from test_srflow_gpu import build
+    rounds = int(os.environ["BFSR_SOAK"])
+    hip = HipOps("cuda:0")
+    m, prior, opt, sd, psd = build(hip, 4)
+    eng = m.netG.module.engine()
+    lr = hip.to_device(synth.smooth_lr_batch(21, 2, 160, 160))
+    lr_up = hip.resize(lr, hip.empty(2, 3, 640, 640), MODE_BILINEAR, 0.25, 0.25)
+    ref_ep = ref_rt = None
+    bad = 0
+    for it in range(rounds):
+        ep = eng.encode(lr_up, lr)
+        rt = eng.decode(lr, epses=ep)
+        if ref_ep is None:
+            ref_ep, ref_rt = [e.clone() for e in ep], rt.clone()
+            continue
+        same = torch.equal(rt, ref_rt) and all(torch.equal(a, b) for a, b in zip(ep, ref_ep))
+        if not same:
+            bad += 1
+            print("round %d differs from round 0" % it, flush=True)
+    n_pair = sum(1 for ly in eng.layers if ly.type == "step" and ly.coupled and getattr(eng.steps[ly.index], "fused", False))
+    print("soak: %d rounds, %d fused coupled steps per direction -> %d head and %d tail launches; %d rounds differ" % (
+        rounds, n_pair, 2 * n_pair * rounds, 2 * n_pair * rounds, bad), flush=True)
+    hip.check_range()
+    assert bad == 0

@@ -51,6 +51,7 @@ FAMILIES = {
     "conv_up4_x3": ("conv_up4_bf16x3_kernel", PEAK_16BIT_MFMA_TFLOPS, 6, "3xBF16 split, phase-decomposed conv over nearest-x4 input"),
     "conv_f16x2": ("conv_bf16x3_kernel<PL=2>", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split (22-bit operands, power-of-two weight scale), 3 products on v_mfma_f32_32x32x16_f16"),
     "conv_h2x": ("conv3x3_h2x_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split, 3 products on v_mfma_f32_32x32x16_f16, h2-tensor input by LDS-DMA"),
+    "conv_chain": ("conv_chain_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, "the RRDB trunk (all dense-block convs + trunk_conv) as ONE persistent launch with per-tile dependency counters; conv3x3_h2x_kernel's arithmetic: two-term fp16 split, 3 products on v_mfma_f32_32x32x16_f16, h2-tensor input by LDS-DMA"),
     "conv_up2_f2": ("conv_up2_bf16x3_kernel<PL=2>", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split, parity-decomposed conv over nearest-x2 input"),
     "conv_up2_h2t": ("conv_up2_h2t_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split, conv over cat[key, nearest-x2 taps] at source resolution (parity-decomposed taps, space-to-depth key chunks), h2 input by LDS-DMA"),
     "conv_h2r": ("coupling_tail_kernel<plain conv>", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split, 3x3 conv 64 -> <=32 channels over an h2 tensor on the coupling tail's ring kernel"),
@@ -97,6 +98,9 @@ def launch_flop(k):
     if f in ("conv_x3s", "conv_h2s", "conv_h2x", "conv_h2r"):
         _, Cin, Cout, b_, hh, ww, _fmt = k
         return 2.0 * Cin * 9 * Cout * b_ * hh * ww
+    if f == "conv_chain":                                               # key: number of convs, sum over them of Cin x Cout, batch, H, W
+        _, _n, cc, b_, hh, ww = k
+        return 2.0 * 9 * cc * b_ * hh * ww
     if f in ("linf_mlp_x3", "linf_mlp_f16", "linf_mlp_f2"):           # layer 1 (4 neighbours x 256 features) + two hidden layers + output layer
         _, hid, Cout, b_, qh, qw = k
         return 2.0 * (4 * hid * hid + 2 * hid * hid + hid * Cout) * b_ * qh * qw

@@ -603,7 +603,7 @@ class HipOps(object):
         _lib.check(self.lib.bfsr_conv_chain_prepare(arr, n, B, H, W, table.data_ptr()), "conv_chain_prepare")
         words = self.lib.bfsr_conv_chain_progress_words(table.data_ptr())
         return ConvChain(self, table, table.to(self.device), torch.zeros(words, dtype=torch.int32, device=self.device), keep,
-                         ("conv_chain", n, specs[0]["pw"].Cin, specs[-1]["pw"].Cout, B, H, W))
+                         ("conv_chain", n, sum(sp["pw"].Cin * sp["pw"].Cout for sp in specs), B, H, W))      # key: convs, sum of Cin x Cout (-> flops), shape
 
     def h2_pack_s2d(self, x, out):
         """fp32 [B,C,2h,2w] view -> h2 view with 4C channels at h x w (space to depth): channel q*C + c = pixels (2y+qy, 2x+qx) of channel c,

@@ -665,6 +665,16 @@ class SRFlowEngine(object):
                 self._taps_h2 = {}
             if level not in self._taps_h2 or self._taps_h2[level][0] != key:
                 self._taps_h2[level] = (key, self.ops.h2_empty(*key))
+        if (not hz.get("up2") and getattr(self.ops, "conv_mode", "f32") == "x3" and getattr(self.ops, "split", "") == "f16x2"
+                and hasattr(self.ops, "conv_h2x") and ft[level].shape[1] % 16 == 0 and os.environ.get("BFSR_HOIST", "h2x") == "h2x"
+                and hz.get("aff0") is not None and getattr(hz["aff0"], "mode", "") == "x3"):
+            key = (B, ft[level].shape[1], hl, wl)
+            if getattr(self, "_ft_h2", None) is None:
+                self._ft_h2 = {}
+            if level not in self._ft_h2 or self._ft_h2[level][0] != key:
+                self._ft_h2[level] = (key, self.ops.h2_empty(*key))
+        elif getattr(self, "_ft_h2", None):
+            self._ft_h2.pop(level, None)
         return (ws.get("hoist_hid%d" % level, B, K * 64, hl, wl), ws.get("pre_aff%d" % level, B, K * 64, hl, wl),
                 ws.get("h_ft%d" % level, B, K * 2 * Cz, hl, wl), Cz)
 
@@ -719,6 +729,16 @@ class SRFlowEngine(object):
             else:
                 ops.conv_up2(taps, hz["ft0_taps"], hid, epi=hz["ft0_epi"], act=ACT_RELU, key=(f, hz["ft0_key"]))
                 ops.conv_up2(taps, hz["aff0_taps"], pre_aff, key=(f, hz["aff0_key"]))
+        elif level in getattr(self, "_ft_h2", {}):
+            # levels 2 / 3 (the conditional IS the stacked features, no upsampling): the two batched 320 -> 16*64 hoists on the LDS-DMA kernel
+            # conv_h2x over ONE h2 copy of the level's features instead of the register-staged split conv (round 5; measured on the round-4
+            # build, tools/exp/hoist2_bench.py: 3.38 -> 0.09 pack + 3.13 ms at 8 x 160^2, 1.13 -> 0.02 + 0.98 ms at 8 x 80^2 per conv)
+            fh = ops.h2_pack(f, self._ft_h2[level][1])
+            if ff:
+                ops.conv_h2x(fh, hz["ft0_raw"].pw, hid, epi=hz["ft0_raw"].epi, y_fmt=1)
+            else:
+                ops.conv_h2x(fh, hz["ft0"].pw, hid, epi=hz["ft0"].epi, act=ACT_RELU)
+            ops.conv_h2x(fh, hz["aff0"].pw, pre_aff, epi=hz["aff0"].epi, **kq)
         else:
             if ff:
                 hz["ft0_raw"].run(ops, f, hid, y_fmt=1)

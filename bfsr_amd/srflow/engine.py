@@ -797,10 +797,12 @@ class SRFlowEngine(object):
         ops.coupling_head(z, st.head, pre_k, hid, pre_fmt=pre_fmt)
         return ops.coupling_tail(hid, st.tail, z, z, reverse, **kw)
 
-    def encode(self, gt, lr, logdet=None):
+    def encode(self, gt, lr, logdet=None, on_eps=None):
         """normal flow (FlowUpsamplerNet.encode :217-251): gt [B,3,H,W] -> [eps_split..., z_final].
         logdet: optional float64 [B] accumulator that receives the flow's log-determinant (actnorm + invconv constants,
-        sum log(scale) of both couplings per step, Split2d log-likelihood) -- the reference's `logdet` return value."""
+        sum log(scale) of both couplings per step, Split2d log-likelihood) -- the reference's `logdet` return value.
+        on_eps(i, eps_i): called as soon as the split that produces latent i has been enqueued (the LP harness starts that latent's branch of
+        the prior on the side stream while the remaining levels of the chain run, srflow/test.py)."""
         ops, ws = self.ops, self.ws
         cond = self.conditioning(lr, quads=logdet is None)
         z = gt
@@ -865,6 +867,8 @@ class SRFlowEngine(object):
                 if logdet is not None:
                     ops.gaussian_logp(z[:, ly.C_pass:], logdet, h=h, coef=1.0)
                 epses.append(e)
+                if on_eps is not None:
+                    on_eps(len(epses) - 1, e)
                 z = z[:, :ly.C_pass]
         if pending is not None:
             ops.flow_pointwise(z, z, False, h_aff=pending)
@@ -875,9 +879,10 @@ class SRFlowEngine(object):
             logdet += ld_const
         return epses
 
-    def decode(self, lr, epses=None, z=None, eps_std=None, logdet=None):
+    def decode(self, lr, epses=None, z=None, eps_std=None, logdet=None, eps_ready=None):
         """reverse flow (FlowUpsamplerNet.decode :267-296): [eps_split..., z_final] -> sr [B,3,H,W].
-        logdet: optional float64 [B] accumulator (every term of encode() enters with the opposite sign)."""
+        logdet: optional float64 [B] accumulator (every term of encode() enters with the opposite sign).
+        eps_ready: optional {index into epses: event}: the current stream waits for the event right before that latent is consumed."""
         ops, ws = self.ops, self.ws
         cond = self.conditioning(lr, reverse=True, quads=logdet is None)
         ld_const, ld_levels = 0.0, set()
@@ -931,6 +936,8 @@ class SRFlowEngine(object):
                 h = ws.get("split_h%d" % ly.index, B, 2 * ly.C_consume, H, W)
                 self.splits[ly.index].run(ops, z, h)
                 if epses is not None:
+                    if eps_ready and (len(epses) - 1) in eps_ready:
+                        torch.cuda.current_stream(ops.device).wait_event(eps_ready[len(epses) - 1])
                     e = epses.pop()
                 else:   # tau path: eps ~ N(0, eps_std) sampled on device (plumbing)
                     e = rng.randn((B, ly.C_consume, H, W), z.device) * float(eps_std or 1)

@@ -72,15 +72,47 @@ def pad_lr_to_even_t(lr_t):
 
 
 def _lp_lane(eng, prior_eng, lr, scale, sr_out, keep=None):
-    """The LP block (test.py:126-151) on engine level; writes clamp(sr) into sr_out."""
+    """The LP block (test.py:126-151) on engine level; writes clamp(sr) into sr_out.
+
+    Overlap (round 5): the prior's two branches are independent (models/unet.py:154-181).  Branch 0 works on eps0 -- 6 channels at half the HR
+    resolution, 3/4 of the prior's convolutions -- which exists as soon as level 1's split has run in encode, and its output is needed only at
+    decode's level-1 split, at the very end.  It is enqueued on the engine's side stream at that point and runs under the level-2/3 chains of
+    encode, branch 1 and the level-3/2 chains of decode: short, HBM- or latency-bound launches that leave the matrix pipes idle.  Same kernels,
+    same results; BFSR_OVERLAP=0 keeps everything on one stream."""
     ops = eng.ops
     B, _, h, w = lr.shape
     lr_up = eng.ws.get("lr_up", B, 3, h * scale, w * scale)
     ops.resize(lr, lr_up, MODE_BILINEAR, 1.0 / scale, 1.0 / scale)               # test.py:137
-    epses_lr = eng.encode(lr_up, lr)                                             # test.py:139 (add_gt_noise=False)
-    epses = [ops.standardize(e, ops.empty(*e.shape)) for e in epses_lr]          # test.py:141-145
-    epses_learned = prior_eng.forward(epses)                                     # test.py:147
-    sr_raw = eng.decode(lr, epses=epses_learned)                                 # test.py:148
+    side = None
+    if getattr(getattr(ops, "device", None), "type", "cpu") == "cuda" and os.environ.get("BFSR_OVERLAP", "auto") != "0" and os.environ.get("BFSR_PRIOR_OVERLAP", "1") != "0" and hasattr(prior_eng, "forward_branch"):
+        if eng._side_stream is None:
+            eng._side_stream = torch.cuda.Stream(device=ops.device)
+        side = eng._side_stream
+    early = {}
+
+    def on_eps(i, e):
+        if side is None or i != 0:
+            return
+        main = torch.cuda.current_stream(ops.device)
+        n0, o0 = ops.empty(*e.shape), ops.empty(*e.shape)       # allocated on the caller's stream (they outlive the side stream's work)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ops.standardize(e, n0)
+            prior_eng.forward_branch(0, n0, out=o0)
+            early[0] = (n0, o0, side.record_event())
+
+    epses_lr = eng.encode(lr_up, lr, on_eps=on_eps)                              # test.py:139 (add_gt_noise=False)
+    if 0 in early:                                                               # test.py:141-147 with branch 0 already in flight
+        n0, o0, ev = early[0]
+        epses = [n0] + [ops.standardize(e, ops.empty(*e.shape)) for e in epses_lr[1:]]
+        epses_learned = [o0] + [prior_eng.forward_branch(b, epses[b]) for b in range(1, len(epses))]
+        sr_raw = eng.decode(lr, epses=epses_learned, eps_ready={0: ev})          # test.py:148
+        if keep is not None:
+            torch.cuda.current_stream(ops.device).wait_event(ev)
+    else:
+        epses = [ops.standardize(e, ops.empty(*e.shape)) for e in epses_lr]      # test.py:141-145
+        epses_learned = prior_eng.forward(epses)                                 # test.py:147
+        sr_raw = eng.decode(lr, epses=epses_learned)                             # test.py:148
     ops.axpb_clamp(sr_raw, sr_out, 1.0, 0.0, 0.0, 1.0)                           # test.py:150
     if keep is not None:
         keep.update(lr_up=lr_up, epses=epses_lr, epses_norm=epses, epses_learned=epses_learned, sr_raw=sr_raw, sr=sr_out)

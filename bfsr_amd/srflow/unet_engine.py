@@ -115,14 +115,16 @@ class SRFlowPriorEngine(object):
         self.proj = [DenseBlock(ops, sd, "input_proj0"), DenseBlock(ops, sd, "input_proj1")]
         self.body = [UNetBody(ops, sd, "0", depth), UNetBody(ops, sd, "1", depth)]
 
-    def forward(self, epses):
-        outs = []
-        for b in (0, 1):
-            e = epses[b]
-            B, C, H, W = e.shape
-            p = self.ws.get("proj%d" % b, B, self.proj[b].out, H, W)
-            self.proj[b].run(self.ops, self.ws, "proj%d" % b, e, p)
+    def forward_branch(self, b, e, out=None):
+        """Branch b of the prior on latent b (the two branches share nothing, models/unet.py:154-181); `out` may be preallocated by the caller
+        (e.g. on another stream than the one this call is enqueued on)."""
+        B, C, H, W = e.shape
+        p = self.ws.get("proj%d" % b, B, self.proj[b].out, H, W)
+        self.proj[b].run(self.ops, self.ws, "proj%d" % b, e, p)
+        if out is None:
             out = self.ops.empty(B, self.body[b].outc.pw.Cout, H, W)
-            self.body[b].run(self.ws, p, out, "u%d" % b)
-            outs.append(out)
-        return outs
+        self.body[b].run(self.ws, p, out, "u%d" % b)
+        return out
+
+    def forward(self, epses):
+        return [self.forward_branch(b, epses[b]) for b in (0, 1)]

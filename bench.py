@@ -337,7 +337,7 @@ def main():
         a = tail_bytes / (tail_ms * 1e-3) / 1e9
         a_s = survey_bytes / (tail_ms * 1e-3) / 1e9
         roof_tail = {"bound": "hbm",
-                     "kernel": ("coupling tail = conv3x3_h2x_kernel<coupling epilogue, C=12> reverse: Conv2dZeros 64->12 over the h2 hidden tensor (LDS-DMA, "
+                     "kernel": ("coupling_tail_kernel<0, 12, reverse> (coupling_tail.hip): Conv2dZeros 64->12 over the h2 hidden tensor (LDS-DMA, "
                                 "two-term fp16 split) + level-1 FlowStep inverse tail as its epilogue" if fused
                                 else "flow_pointwise_kernel<12,4> reverse (level-1 FlowStep inverse tail)"),
                      "achieved": round(a, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(a / PEAK_HBM_GBS, 4),
@@ -484,7 +484,7 @@ def main():
             "roofline": roofline, "roofline_next_kernels": roofline_next, "roofline_by_symbol": by_symbol,
             "roofline_by_symbol_note": "HIP-event time per kernel family in the untimed ranking step; with the side stream active (configs "
                                        "whose batch does not fill the chip) events of overlapping kernels are inflated by contention and the "
-                                       "families sum to more than ms_per_step -- profiles/r05_keys_cfg2_no_overlap.txt has the BFSR_OVERLAP=0 table",
+                                       "families sum to more than ms_per_step -- profiles/r05b_keys_cfg2_no_overlap.txt has the BFSR_OVERLAP=0 table",
             "roofline_coupling_inverse": roof_tail,
             "cpu_baseline": cpu_baseline, "parity": parity,
             # passes that the range guard of the fp16-pair split re-ran under the bf16x3 split (bfsr_amd/guard.py); the guard's 4-byte read-back at

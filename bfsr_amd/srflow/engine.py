@@ -797,6 +797,87 @@ class SRFlowEngine(object):
         ops.coupling_head(z, st.head, pre_k, hid, pre_fmt=pre_fmt)
         return ops.coupling_tail(hid, st.tail, z, z, reverse, **kw)
 
+    # ---- two half-batch lanes for the unfused (level-3, C = 96) steps -------------------------------------------------------------
+    def _lane_run(self, pos, step, B, H, W, logdet):
+        """The maximal run of consecutive unfused step layers starting at self.layers[pos] (walking in direction `step`), if it should be
+        executed as two half-batch lanes on two streams: the C = 96 steps are four short launches each (split 3x3, 1x1-only head, Conv2dZeros,
+        pointwise) that fill < 1/4 of the chip at config 2 (8 x 80^2: 120 tiles) and are bound by their own latency chain, not by any
+        throughput -- two independent half batches in flight overlap those latencies (every kernel is per-sample, so
+        the results are bit-identical).  None when the lanes would not help (large batches) or cannot be used."""
+        if (logdet is not None or B < 2 or B % 2 or B * H * W > 100000 or os.environ.get("BFSR_LANES", "1") == "0"
+                or os.environ.get("BFSR_OVERLAP", "auto") == "0" or getattr(getattr(self.ops, "device", None), "type", "cpu") != "cuda"):
+            return None
+        run, p = [], pos
+        while 0 <= p < len(self.layers):
+            ly = self.layers[p]
+            if ly.type != "step" or (ly.coupled and getattr(self.steps[ly.index], "fused", False)):
+                break
+            run.append(ly)
+            p += step
+        return run if len(run) >= 4 else None
+
+    def _lanes(self, make_gen, B):
+        """Run make_gen(b0, b1, lane) for the two halves of the batch, enqueued alternately on the current and the side stream."""
+        ops = self.ops
+        main = torch.cuda.current_stream(ops.device)
+        if getattr(self, "_lane_stream", None) is None:         # its own stream: the side stream may be busy with the prior's branch 0 or the hoists
+            self._lane_stream = torch.cuda.Stream(device=ops.device)
+        side = self._lane_stream
+        ga, gb = make_gen(0, B // 2, 0), make_gen(B // 2, B, 1)
+        side.wait_stream(main)
+        live = True
+        while live:
+            live = next(ga, False) is not False
+            with torch.cuda.stream(side):
+                live = (next(gb, False) is not False) or live
+        main.wait_stream(side)
+
+    def _lane_cond(self, cnd, b0, b1):
+        c = dict(cnd)
+        c["pre_aff"], c["h_ft"] = cnd["pre_aff"][b0:b1], cnd["h_ft"][b0:b1]
+        return c
+
+    def _steps_fwd_lane(self, run, z, cond, b0, b1, lane):
+        """encode's unfused step sequence (the `pending` protocol of encode()) on the samples b0..b1; yields after every group of launches."""
+        ops = self.ops
+        zl, pending = z[b0:b1], None
+        for ly in run:
+            st = self.steps[ly.index]
+            if ly.coupled:
+                cnd = self._lane_cond(self._await(cond[ly.level]), b0, b1)
+                k = cnd["slot"][ly.index]
+                ops.flow_pointwise(zl, zl, False, h_aff=pending, an_bias=st.an_bias, an_escale=st.an_exp, w=st.w_fwd, wt=st.w_fwd_t,
+                                   h_ft=cnd["h_ft"][:, 2 * ly.C * k: 2 * ly.C * (k + 1)])
+                yield
+                pending = self._self_cond(st, zl, cnd, k, "enc%d_l%d" % (ly.level, lane))
+                yield
+            else:
+                ops.flow_pointwise(zl, zl, False, h_aff=pending, an_bias=st.an_bias, an_escale=st.an_exp, w=st.w_fwd, wt=st.w_fwd_t)
+                pending = None
+                yield
+        if pending is not None:
+            ops.flow_pointwise(zl, zl, False, h_aff=pending)
+            yield
+
+    def _steps_rev_lane(self, run, z, cond, b0, b1, lane):
+        """decode's unfused step sequence on the samples b0..b1."""
+        ops = self.ops
+        zl = z[b0:b1]
+        C = zl.shape[1]
+        for ly in run:
+            st = self.steps[ly.index]
+            if ly.coupled:
+                cnd = self._lane_cond(self._await(cond[ly.level]), b0, b1)
+                k = cnd["slot"][ly.index]
+                h_aff = self._self_cond(st, zl, cnd, k, "dec%d_l%d" % (ly.level, lane))
+                yield
+                ops.flow_pointwise(zl, zl, True, h_aff=h_aff, h_ft=cnd["h_ft"][:, 2 * C * k: 2 * C * (k + 1)],
+                                   w=st.w_inv, wt=st.w_inv_t, an_bias=st.an_bias, an_escale=st.an_expneg)
+                yield
+            else:
+                ops.flow_pointwise(zl, zl, True, w=st.w_inv, wt=st.w_inv_t, an_bias=st.an_bias, an_escale=st.an_expneg)
+                yield
+
     def encode(self, gt, lr, logdet=None, on_eps=None):
         """normal flow (FlowUpsamplerNet.encode :217-251): gt [B,3,H,W] -> [eps_split..., z_final].
         logdet: optional float64 [B] accumulator that receives the flow's log-determinant (actnorm + invconv constants,
@@ -811,8 +892,17 @@ class SRFlowEngine(object):
         ld_const, ld_levels = 0.0, set()
         head_done = False        # the current step's head (actnorm, W, feature-conditional affine) was already applied by the
                                  # previous step's fused tail kernel
+        skip_to = -1
         for pos, ly in enumerate(self.layers):
+            if pos < skip_to:
+                continue
             B, _, H, W = z.shape
+            if ly.type == "step" and pending is None and not head_done:
+                run = self._lane_run(pos, +1, B, H, W, logdet)
+                if run is not None:
+                    self._lanes(lambda b0, b1, lane, run=run, z=z: self._steps_fwd_lane(run, z, cond, b0, b1, lane), B)
+                    skip_to = pos + len(run)
+                    continue
             if ly.type == "squeeze":
                 if pending is not None:
                     ops.flow_pointwise(z, z, False, h_aff=pending)
@@ -893,9 +983,18 @@ class SRFlowEngine(object):
         ops.axpb_clamp(zin, cur)
         z = _chk(ops, cur)                                   # the coupling heads split z1 into fp16 pairs
         # the buffer the next (lower-index) split layer concatenates into is prepared when we reach a squeeze
+        skip_to = len(self.layers)
         for pos in reversed(range(len(self.layers))):
+            if pos > skip_to:
+                continue
             ly = self.layers[pos]
             _, C, H, W = z.shape
+            if ly.type == "step":
+                run = self._lane_run(pos, -1, B, H, W, logdet)
+                if run is not None:
+                    self._lanes(lambda b0, b1, lane, run=run, z=z: self._steps_rev_lane(run, z, cond, b0, b1, lane), B)
+                    skip_to = pos - len(run)
+                    continue
             if ly.type == "step":
                 st = self.steps[ly.index]
                 if ly.coupled:

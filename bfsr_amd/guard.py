@@ -8,7 +8,8 @@ cleared, the pass runs, the flag is read (one 4-byte device->host copy at the en
 SRFlow-LP/code/test.py:150 `.cpu()`, LINF-LP/test.py:217), and if it is raised the SAME pass is re-run on engines built over
 HipOps.fallback_ops(): the exact three-term bf16 split, which has fp32's exponent range (six products instead of three).  `ops.fallbacks`
 counts those re-runs (bench.py prints it; 0 in normal operation).  A non-finite value that survives the fallback (the input itself was inf /
-NaN) and a dependency time-out of the fused conv chain raise RuntimeError.
+NaN) raises RuntimeError.  A dependency time-out of the fused RRDB launch (its workgroups were not all resident: a co-tenant holds compute
+units) disables that launch for the HipOps, repeats the pass on per-conv launches (identical bits) and counts `ops.chain_timeouts`.
 
 `EngineHost` is the part the four nn.Modules share (SRFlowNet, both prior UNets, LINF): a lazily built engine per split."""
 import contextlib
@@ -79,7 +80,19 @@ def run_guarded(hosts, fn):
         for o in guarded:
             o._guard_depth -= 1
     if raised & 4:
-        raise RuntimeError("bfsr_amd: a dependency wait of the fused conv chain timed out (flag 0x%x): results are invalid" % raised)
+        # a dependency wait of the fused RRDB launch timed out (conv_chain.hip bounds its spins at ~2 s): its workgroups were not all resident
+        # -- e.g. another process holds compute units with a persistent kernel of its own.  Degrade instead of failing: from now on this
+        # HipOps runs the trunk as one launch per conv (identical bits), and the pass is repeated once.
+        for o in guarded:
+            o.chain_disabled = True
+            o.chain_timeouts = getattr(o, "chain_timeouts", 0) + 1
+            o.range_flag.zero_()
+        out = fn()
+        raised = 0
+        for o in guarded:
+            raised |= o.read_range_flag()
+        if raised & 4:
+            raise RuntimeError("bfsr_amd: a dependency wait timed out again with the fused conv chain disabled (flag 0x%x)" % raised)
     if not raised:
         return out
     for o in guarded:

@@ -162,7 +162,8 @@ class RRDBEncoder(object):
         Measured under sustained load, interleaved A/B (profiles/r05_i_chain_ab.txt): 8 x 160^2 251 vs 286 us per dense block (two-stream
         launches), 64 x 96^2 742 vs 761, 16 x 256^2 1341 vs 1337.  BFSR_RRDB=launches keeps one launch per conv."""
         ops = self.ops
-        if os.environ.get("BFSR_RRDB", "chain") != "chain" or not hasattr(ops, "conv_chain") or getattr(ops, "split", None) != "f16x2":
+        if (os.environ.get("BFSR_RRDB", "chain") != "chain" or not hasattr(ops, "conv_chain") or getattr(ops, "split", None) != "f16x2"
+                or getattr(ops, "chain_disabled", False)):      # (set by guard.run_guarded after a dependency time-out)
             return False
         B, _, h, w = x.shape
         cus, n_items = ops.cu_count(), B * ((h + 15) // 16) * ((w + 31) // 32)
@@ -187,7 +188,10 @@ class RRDBEncoder(object):
         ring = self._ring
         tmp = self.ws.get("x3_io", B, nf, h, w)
         want = [idx for idx in range(self.nb) if on_block is not None and (taps is None or idx in taps)]
-        ckey = (out.data_ptr(), tuple(out.stride()), tuple(want))
+        # the chain holds raw pointers: its last conv writes a buffer the encoder owns (`out` may be a fresh tensor on every call, e.g. LINF's
+        # gen_feat) and one copy hands the result over
+        trunk_out = self.ws.get("chain_out", B, nf, h, w)
+        ckey = (trunk_out.data_ptr(), tuple(want))
         if getattr(self, "_chain", None) is None or self._chain[0] != ckey:
             tapbuf = {idx: self.ws.get("tap%d" % idx, B, nf, h, w) for idx in want}
             specs, cur = [], 0
@@ -207,7 +211,7 @@ class RRDBEncoder(object):
                     specs.append(sp)
                     cur = nxt
             fea = ring[cur][:, :o(nf)]
-            specs.append(dict(x=fea, pw=self.trunk_conv.pw, out=out, epi=self.trunk_conv.epi, res1=self._first if self.skip_from_first else fea, alpha1=1.0))
+            specs.append(dict(x=fea, pw=self.trunk_conv.pw, out=trunk_out, epi=self.trunk_conv.epi, res1=self._first if self.skip_from_first else fea, alpha1=1.0))
             self._chain = (ckey, [ops.conv_chain(specs)], tapbuf)
         _, chains, tapbuf = self._chain
         self.conv_first.run(ops, x, tmp)
@@ -217,6 +221,7 @@ class RRDBEncoder(object):
             ops.h2_pack(tmp, self._first)
         for ch in chains:
             ch.run()
+        ops.axpb_clamp(trunk_out, out)
         for idx in want:
             on_block(idx, tapbuf[idx], 0, B)
         _chk(ops, out)

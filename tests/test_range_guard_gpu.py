@@ -169,3 +169,34 @@ def test_linf_pass_on_rescaled_encoder(S):
         assert ops.fallbacks == 1, "an overflow inside the encoder must re-run the pass under bf16x3"
     again = infer_from_lr(m, prior, lr, 4)
     assert float((again.cpu() - truth["pred"]).abs().max()) <= 1e-4
+
+
+def test_chain_timeout_degrades_to_launches(hip):
+    """A dependency time-out of the fused RRDB launch (status bit 2: its workgroups were not all resident, e.g. a co-tenant holds compute units)
+    must not fail the pass: the guard disables the fused launch for this HipOps, repeats the pass on per-conv launches and returns the SAME bits.
+    The time-out itself is injected (the first flag read-back reports bit 2); the kernel-side bound is ~2 s of spinning."""
+    from bfsr_amd.ops import HipOps
+    from bfsr_amd.srflow.test import lp_infer
+    opt = options.load(options.DEFAULT_CONF)
+    sd = synth.state_dict_from_schema(spec.srflownet_schema(opt), 1234)
+    psd = synth.state_dict_from_schema(spec.srflow_prior_schema(), 4321)
+    ops = HipOps("cuda:0")
+    m, prior = _models(ops, opt, sd, psd)
+    lr = synth.smooth_lr_batch(31, 6, 160, 160)               # 300 tiles of 16 x 32: the fused launch is active
+    eng = m.netG.module.engine()
+    assert eng.rrdb._use_chain(ops.to_device(lr))
+    ref = lp_infer(m, prior, lr).clone()
+    real, state = ops.read_range_flag, {"n": 0}
+
+    def injected():
+        v = real()
+        state["n"] += 1
+        return v | 4 if state["n"] == 1 else v
+    ops.read_range_flag = injected
+    try:
+        out = lp_infer(m, prior, lr)
+    finally:
+        ops.read_range_flag = real
+    assert getattr(ops, "chain_timeouts", 0) == 1 and ops.chain_disabled
+    assert not eng.rrdb._use_chain(ops.to_device(lr))
+    assert torch.equal(out, ref), "the per-conv launches must reproduce the fused launch bit for bit"

@@ -802,27 +802,27 @@ class SRFlowEngine(object):
         ops.coupling_head(z, st.head, pre_k, hid, pre_fmt=pre_fmt)
         return ops.coupling_tail(hid, st.tail, z, z, reverse, **kw)
 
-    # ---- two half-batch lanes for the unfused (level-3, C = 96) steps -------------------------------------------------------------
+    # ---- two half-batch lanes for the short levels of the chain --------------------------------------------------------------------
     def _lane_run(self, pos, step, B, H, W, logdet):
-        """The maximal run of consecutive unfused step layers starting at self.layers[pos] (walking in direction `step`), if it should be
-        executed as two half-batch lanes on two streams: the C = 96 steps are four short launches each (split 3x3, 1x1-only head, Conv2dZeros,
-        pointwise) that fill < 1/4 of the chip at config 2 (8 x 80^2: 120 tiles) and are bound by their own latency chain, not by any
-        throughput -- two independent half batches in flight overlap those latencies (every kernel is per-sample, so
-        the results are bit-identical).  None when the lanes would not help (large batches) or cannot be used."""
+        """The maximal run of consecutive step layers of one level starting at self.layers[pos] (walking in direction `step`), if it should be
+        executed as two half-batch lanes on two streams.  Level 3 (C = 96): four short launches per coupled step (split 3x3, 1x1-only head,
+        Conv2dZeros, pointwise) that fill < 1/4 of the chip at config 2 (8 x 80^2: 120 tiles) and are bound by their own latency chain: two
+        independent half batches in flight overlap those latencies (every kernel is per-sample, so the results are
+        bit-identical; -0.6 ms per config-2 step).  The generators below also handle the fused pair (levels 1 / 2): measured with level 2 of
+        config 2 included (8 x 160^2, 400 tiles per launch) the gain is the same 0.5-0.6 ms, i.e. level 2 adds nothing, so the bound stays at
+        100 000 pixels per level -- larger levels keep one lane; small inputs run every level in lanes (covered by the B = 2 tests).
+        None when the lanes would not help or cannot be used."""
         if (logdet is not None or B < 2 or B % 2 or B * H * W > 100000 or os.environ.get("BFSR_LANES", "1") == "0"
                 or os.environ.get("BFSR_OVERLAP", "auto") == "0" or getattr(getattr(self.ops, "device", None), "type", "cpu") != "cuda"):
             return None
-        run, p = [], pos
-        while 0 <= p < len(self.layers):
-            ly = self.layers[p]
-            if ly.type != "step" or (ly.coupled and getattr(self.steps[ly.index], "fused", False)):
-                break
-            run.append(ly)
+        run, p, level = [], pos, self.layers[pos].level
+        while 0 <= p < len(self.layers) and self.layers[p].type == "step" and self.layers[p].level == level:
+            run.append(self.layers[p])
             p += step
         return run if len(run) >= 4 else None
 
     def _lanes(self, make_gen, B):
-        """Run make_gen(b0, b1, lane) for the two halves of the batch, enqueued alternately on the current and the side stream."""
+        """Run make_gen(b0, b1, lane) for the two halves of the batch, enqueued alternately on the current and the lane stream."""
         ops = self.ops
         main = torch.cuda.current_stream(ops.device)
         if getattr(self, "_lane_stream", None) is None:         # its own stream: the side stream may be busy with the prior's branch 0 or the hoists
@@ -843,42 +843,67 @@ class SRFlowEngine(object):
         return c
 
     def _steps_fwd_lane(self, run, z, cond, b0, b1, lane):
-        """encode's unfused step sequence (the `pending` protocol of encode()) on the samples b0..b1; yields after every group of launches."""
+        """encode()'s step sequence of one level (its `pending` / `head_done` protocol) on the samples b0..b1; yields after every group of launches."""
         ops = self.ops
-        zl, pending = z[b0:b1], None
-        for ly in run:
+        zl, pending, head_done = z[b0:b1], None, False
+        for n, ly in enumerate(run):
             st = self.steps[ly.index]
+            tag = "enc%d_l%d" % (ly.level, lane)
             if ly.coupled:
                 cnd = self._lane_cond(self._await(cond[ly.level]), b0, b1)
                 k = cnd["slot"][ly.index]
-                ops.flow_pointwise(zl, zl, False, h_aff=pending, an_bias=st.an_bias, an_escale=st.an_exp, w=st.w_fwd, wt=st.w_fwd_t,
-                                   h_ft=cnd["h_ft"][:, 2 * ly.C * k: 2 * ly.C * (k + 1)])
-                yield
-                pending = self._self_cond(st, zl, cnd, k, "enc%d_l%d" % (ly.level, lane))
+                if not head_done:
+                    ops.flow_pointwise(zl, zl, False, h_aff=pending, an_bias=st.an_bias, an_escale=st.an_exp, w=st.w_fwd, wt=st.w_fwd_t,
+                                       h_ft=cnd["h_ft"][:, 2 * ly.C * k: 2 * ly.C * (k + 1)])
+                    pending = None
+                    yield
+                head_done = False
+                if getattr(st, "fused", False):
+                    nxt = run[n + 1] if n + 1 < len(run) else None      # (the layer behind a whole-level run is never a step)
+                    kw = {}
+                    if nxt is not None:
+                        sn = self.steps[nxt.index]
+                        kw = dict(an_bias=sn.an_bias, an_escale=sn.an_exp, w=sn.w_fwd)
+                        if nxt.coupled:
+                            kn = cnd["slot"][nxt.index]
+                            kw["h_ft"] = cnd["h_ft"][:, 2 * ly.C * kn: 2 * ly.C * (kn + 1)]
+                            kw["h_ft_fmt"] = cnd["h_ft_fmt"][nxt.index]
+                        head_done = True
+                    self._pair(st, zl, cnd["pre_aff"][:, 64 * k: 64 * (k + 1)], tag, False, kw, cnd["pre_fmt"])
+                else:
+                    pending = self._self_cond(st, zl, cnd, k, tag)
                 yield
             else:
-                ops.flow_pointwise(zl, zl, False, h_aff=pending, an_bias=st.an_bias, an_escale=st.an_exp, w=st.w_fwd, wt=st.w_fwd_t)
-                pending = None
-                yield
+                if not head_done:
+                    ops.flow_pointwise(zl, zl, False, h_aff=pending, an_bias=st.an_bias, an_escale=st.an_exp, w=st.w_fwd, wt=st.w_fwd_t)
+                    yield
+                pending, head_done = None, False
         if pending is not None:
             ops.flow_pointwise(zl, zl, False, h_aff=pending)
             yield
 
     def _steps_rev_lane(self, run, z, cond, b0, b1, lane):
-        """decode's unfused step sequence on the samples b0..b1."""
+        """decode()'s step sequence of one level on the samples b0..b1."""
         ops = self.ops
         zl = z[b0:b1]
         C = zl.shape[1]
         for ly in run:
             st = self.steps[ly.index]
+            tag = "dec%d_l%d" % (ly.level, lane)
             if ly.coupled:
                 cnd = self._lane_cond(self._await(cond[ly.level]), b0, b1)
                 k = cnd["slot"][ly.index]
-                h_aff = self._self_cond(st, zl, cnd, k, "dec%d_l%d" % (ly.level, lane))
-                yield
-                ops.flow_pointwise(zl, zl, True, h_aff=h_aff, h_ft=cnd["h_ft"][:, 2 * C * k: 2 * C * (k + 1)],
-                                   w=st.w_inv, wt=st.w_inv_t, an_bias=st.an_bias, an_escale=st.an_expneg)
-                yield
+                if getattr(st, "fused", False):
+                    kw = dict(h_ft=cnd["h_ft"][:, 2 * C * k: 2 * C * (k + 1)], h_ft_fmt=cnd["h_ft_fmt"][ly.index], w=st.w_inv,
+                              an_bias=st.an_bias, an_escale=st.an_expneg)
+                    self._pair(st, zl, cnd["pre_aff"][:, 64 * k: 64 * (k + 1)], tag, True, kw, cnd["pre_fmt"])
+                    yield
+                else:
+                    h_aff = self._self_cond(st, zl, cnd, k, tag)
+                    yield
+                    ops.flow_pointwise(zl, zl, True, h_aff=h_aff, h_ft=cnd["h_ft"][:, 2 * C * k: 2 * C * (k + 1)],
+                                       w=st.w_inv, wt=st.w_inv_t, an_bias=st.an_bias, an_escale=st.an_expneg)
+                    yield
             else:
                 ops.flow_pointwise(zl, zl, True, w=st.w_inv, wt=st.w_inv_t, an_bias=st.an_bias, an_escale=st.an_expneg)
                 yield

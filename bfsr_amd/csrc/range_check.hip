@@ -14,17 +14,28 @@ namespace {
 
 constexpr int SLICES = 32;
 
-__global__ __launch_bounds__(256) void channel_absmax_kernel(const float* __restrict__ x, long long x_bs, int B, long long HW, float* __restrict__ part)
+__global__ __launch_bounds__(256) void channel_absmax_kernel(const float* __restrict__ x, long long x_bs, int B, long long HW, float* __restrict__ part, int vec4)
 {
     const int c = blockIdx.x, s = blockIdx.y;
     const long long n = (long long)B * HW;
     float m = 0.f;
     bool bad = false;
-    for (long long i = (long long)s * 256 + threadIdx.x; i < n; i += (long long)SLICES * 256) {
-        const long long b = i / HW, p = i - b * HW;
-        const float v = fabsf(x[b * x_bs + (long long)c * HW + p]);
-        bad = bad || !(v <= 3.0e38f);                                  // inf or NaN
-        m = fmaxf(m, v);
+    if (vec4) {                                                          // HW % 4 == 0 and 16-byte aligned planes: one float4 per lane and load
+        const long long HW4 = HW >> 2, n4 = (long long)B * HW4;
+        for (long long i = (long long)s * 256 + threadIdx.x; i < n4; i += (long long)SLICES * 256) {
+            const long long b = i / HW4, p = i - b * HW4;
+            const float4 q = reinterpret_cast<const float4*>(x + b * x_bs + (long long)c * HW)[p];
+            const float v = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), fabsf(q.w)));
+            bad = bad || !(fabsf(q.x) <= 3.0e38f) || !(fabsf(q.y) <= 3.0e38f) || !(fabsf(q.z) <= 3.0e38f) || !(fabsf(q.w) <= 3.0e38f);
+            m = fmaxf(m, v);
+        }
+    } else {
+        for (long long i = (long long)s * 256 + threadIdx.x; i < n; i += (long long)SLICES * 256) {
+            const long long b = i / HW, p = i - b * HW;
+            const float v = fabsf(x[b * x_bs + (long long)c * HW + p]);
+            bad = bad || !(v <= 3.0e38f);                                  // inf or NaN
+            m = fmaxf(m, v);
+        }
     }
     if (bad) m = __builtin_inff();
 #pragma unroll
@@ -56,7 +67,9 @@ extern "C" int bfsr_channel_range_check(const float* x, long long x_bs, int B, i
 {
     if (!x || !scratch || !flag || B <= 0 || C <= 0 || C > 65535 || H <= 0 || W <= 0 || !(tiny >= 0.f) || !(huge > tiny)) return -1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(channel_absmax_kernel, dim3((unsigned)C, SLICES), dim3(256), 0, st, x, x_bs, B, (long long)H * W, scratch);
+    const long long HW = (long long)H * W;
+    const int vec4 = (HW % 4 == 0) && (x_bs % 4 == 0) && ((reinterpret_cast<unsigned long long>(x) & 15) == 0);
+    hipLaunchKernelGGL(channel_absmax_kernel, dim3((unsigned)C, SLICES), dim3(256), 0, st, x, x_bs, B, HW, scratch, vec4);
     hipLaunchKernelGGL(channel_range_test_kernel, dim3(1), dim3(256), 0, st, scratch, C, tiny, huge, flag);
     return (int)hipGetLastError();
 }

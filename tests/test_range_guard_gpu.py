@@ -200,3 +200,33 @@ def test_chain_timeout_degrades_to_launches(hip):
     assert getattr(ops, "chain_timeouts", 0) == 1 and ops.chain_disabled
     assert not eng.rrdb._use_chain(ops.to_device(lr))
     assert torch.equal(out, ref), "the per-conv launches must reproduce the fused launch bit for bit"
+
+
+@pytest.mark.parametrize("shape", [(3, 20, 16, 24), (2, 7, 9, 13)])          # 16-byte vector path (H*W % 4 == 0) | scalar path
+def test_channel_range_check_bits(hip, shape):
+    """bfsr_channel_range_check on a channel-slice view: bit 3 iff some channel is tiny EVERYWHERE (0 < max |x| < 2^-7), bit 0 iff a channel reaches
+    65504 or is not finite; an all-zero channel and a channel with a few tiny elements among normal ones raise nothing."""
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(7)
+    base = torch.randn(B, C + 3, H, W, generator=g)
+    base[:, 1] = 0.0                                       # exact zeros are exact in any format
+    base[0, 2, 3, 4] = 1.0e-6                              # one tiny element among normal ones
+    x = hip.to_device(base)
+    view = x[:, 1:C + 1]                                   # a channel slice of a wider buffer (batch stride != C*H*W)
+    hip.read_range_flag()
+    hip.check_channels(view)
+    assert hip.read_range_flag() == 0
+    x[:, 3] *= 1.0e-4                                      # channel 2 of the view: max ~ 4e-4 < 2^-7
+    hip.check_channels(view)
+    assert hip.read_range_flag() == 8
+    x[:, 3] *= 1.0e4
+    x[B - 1, C, H - 1, W - 1] = 7.0e4                      # last channel of the view
+    hip.check_channels(view)
+    assert hip.read_range_flag() == 1
+    x[B - 1, C, H - 1, W - 1] = float("nan")
+    hip.check_channels(view)
+    assert hip.read_range_flag() == 1
+    x[B - 1, C, H - 1, W - 1] = 1.0
+    x[:, C + 1] = 1.0e5                                    # outside the view: not looked at
+    hip.check_channels(view)
+    assert hip.read_range_flag() == 0

@@ -7,6 +7,8 @@ BatchNorm runs in eval mode and is folded into the conv epilogue as (v - mean) *
 The `cat([skip, up])` buffers are allocated up front: the encoder writes its skip features straight into
 the first half, the upsampler into the second half.
 """
+import os
+
 import torch
 
 from ..ops import ACT_LRELU, ACT_NONE, MODE_BILINEAR_AC
@@ -32,15 +34,53 @@ class _DoubleConv(object):
         self.c2.run(ops, mid, out, act=ACT_LRELU, slope=0.2)
         return out
 
+    def run_h2(self, ops, hb, tag, x_h2, out):
+        """Both convs on conv_h2x: x_h2 an h2 view, `out` an h2 view or an fp32 tensor."""
+        B, H, W = x_h2.shape[0], x_h2.shape[3], x_h2.shape[4]
+        mid = hb(tag + "_mid_h2", "h2", B, self.mid, H, W)
+        ops.conv_h2x(x_h2, self.c1.pw, mid, epi=self.c1.epi, act=ACT_LRELU, slope=0.2)
+        ops.conv_h2x(mid, self.c2.pw, out, epi=self.c2.epi, act=ACT_LRELU, slope=0.2)
+        return out
+
 
 class DenseBlock(object):
     """DenseBlock_5C (unet.py:10-36): five 3x3 convs over a growing concat, no residual."""
 
     def __init__(self, ops, sd, p, f16=False):
         self.convs = [_ConvP(ops, sd["%s.conv%d.weight" % (p, i)], sd["%s.conv%d.bias" % (p, i)], f16=f16) for i in range(1, 6)]
+        self._raw = [(sd["%s.conv%d.weight" % (p, i)], sd["%s.conv%d.bias" % (p, i)]) for i in range(1, 6)]
         self.nf = self.convs[0].pw.Cin
         self.gc = self.convs[0].pw.Cout
         self.out = self.convs[4].pw.Cout
+
+    def h2_ready(self, ops):
+        """Padded packings for the h2 path (run_h2): the block's nf input channels padded to a multiple of 16 (zero weights for the pad)."""
+        if getattr(self, "_h2", None) is None:
+            nfp = -(-self.nf // 16) * 16
+            pws = []
+            for i, c in enumerate(self._raw):
+                w, b = c[0].detach().to("cpu", torch.float32), c[1]
+                wp = torch.zeros(w.shape[0], nfp + i * self.gc, 3, 3)
+                wp[:, :self.nf] = w[:, :self.nf]
+                wp[:, nfp:] = w[:, self.nf:]
+                pws.append((ops.pack_conv_x3(wp, 1, lazy=True), ops.pack_epilogue(w.shape[0], b)))
+            self._h2 = (nfp, pws)
+        return self._h2
+
+    def run_h2(self, ops, ws, hb, tag, x, out_h2):
+        """The same block on h2 tensors and the LDS-DMA kernel conv_h2x (round 5: the full-resolution convs of the prior's big branch): x fp32
+        [B,nf,H,W] -> out_h2 (h2 view, 64 channels).  The growing concat is one h2 buffer of nfp + 4*gc channels."""
+        B, _, H, W = x.shape
+        nfp, pws = self.h2_ready(ops)
+        gc, o = self.gc, (lambda c: c // 8)
+        x16 = hb(tag + "_x16", "f32z", B, nfp, H, W)               # zero-initialised once: the pad channels stay zero
+        ops.axpb_clamp(x, x16[:, :self.nf])
+        D = hb(tag + "_dense_h2", "h2", B, nfp + 4 * gc, H, W)
+        ops.h2_pack(x16, D[:, :o(nfp)])
+        for i in range(4):
+            ops.conv_h2x(D[:, :o(nfp + i * gc)], pws[i][0], D[:, o(nfp + i * gc): o(nfp + (i + 1) * gc)], epi=pws[i][1], act=ACT_LRELU, slope=0.2)
+        ops.conv_h2x(D, pws[4][0], out_h2, epi=pws[4][1])
+        return out_h2
 
     def run(self, ops, ws, tag, x, out):
         B, _, H, W = x.shape
@@ -63,10 +103,11 @@ class UNetBody(object):
         self.ups = [_DoubleConv(ops, sd, "up_layers%s.%d.conv" % (tag, i), f16=f16) for i in range(depth)]
         self.outc = _ConvP(ops, sd["outc%s.conv.weight" % tag], sd["outc%s.conv.bias" % tag])
 
-    def run(self, ws, x, out, name):
-        """x [B,dim,H,W] -> out [B,Cout,H,W]."""
+    def run(self, ws, x, out, name, top_h2=None):
+        """x [B,dim,H,W] -> out [B,Cout,H,W].  top_h2 = (x_h2, hb): the FULL-resolution convs (inc, the last up layer) run on conv_h2x over h2
+        tensors (x_h2 = the input as an h2 view, hb = the engine's buffer factory); everything below the first pooling stays as it is."""
         ops, depth = self.ops, self.depth
-        B, _, H, W = x.shape
+        B, _, H, W = (x.shape if top_h2 is None else (top_h2[0].shape[0], None, top_h2[0].shape[3], top_h2[0].shape[4]))
         sizes = [(H, W)]
         for i in range(depth):
             sizes.append((sizes[-1][0] // 2, sizes[-1][1] // 2))
@@ -80,7 +121,13 @@ class UNetBody(object):
             cat = ws.get("%s_cat%d" % (name, i), B, up.c1.pw.Cin, sizes[i][0], sizes[i][1])
             feats.append(cat)
         bottom = ws.get("%s_bottom" % name, B, chans[depth], sizes[depth][0], sizes[depth][1])
-        self.inc.run(ops, ws, "%s_inc" % name, x, feats[0][:, :chans[0]])
+        if top_h2 is not None:
+            x_h2, hb = top_h2
+            cat_h2 = hb("%s_cat0_h2" % name, "h2", B, self.ups[depth - 1].c1.pw.Cin, H, W)
+            self.inc.run_h2(ops, hb, "%s_inc" % name, x_h2, cat_h2[:, :chans[0] // 8])
+            ops.h2_unpack(cat_h2[:, :chans[0] // 8], feats[0][:, :chans[0]])          # the pooling below reads fp32
+        else:
+            self.inc.run(ops, ws, "%s_inc" % name, x, feats[0][:, :chans[0]])
         cur = feats[0][:, :chans[0]]
         for i in range(depth):
             pooled = ws.get("%s_pool%d" % (name, i), B, chans[i], sizes[i + 1][0], sizes[i + 1][1])
@@ -100,7 +147,11 @@ class UNetBody(object):
             r_w = float(w1 - 1) / float(uw - 1) if uw > 1 else 0.0
             ops.resize(cur, cat[:, cs:], MODE_BILINEAR_AC, r_h, r_w, window=(dy // 2, dx // 2, uh, uw))
             o = ws.get("%s_up%d" % (name, j), B, self.ups[j].out, Hs, Ws)
-            self.ups[j].run(ops, ws, "%s_upc%d" % (name, j), cat, o)
+            if top_h2 is not None and i == 0:
+                ops.h2_pack(cat[:, cs:], cat_h2[:, cs // 8:])                     # the upsampled half joins the skip half (already h2)
+                self.ups[j].run_h2(ops, hb, "%s_upc%d" % (name, j), cat_h2, o)
+            else:
+                self.ups[j].run(ops, ws, "%s_upc%d" % (name, j), cat, o)
             cur = o
         self.outc.run(ops, cur, out)
         return out
@@ -111,18 +162,41 @@ class SRFlowPriorEngine(object):
 
     def __init__(self, sd, ops, depth=3):
         sd = {k: v.detach().to("cpu", torch.float32) for k, v in sd.items() if v.dtype.is_floating_point}
-        self.ops, self.ws = ops, _Workspace(ops)
+        self.ops, self.ws, self._h2bufs = ops, _Workspace(ops), {}
         self.proj = [DenseBlock(ops, sd, "input_proj0"), DenseBlock(ops, sd, "input_proj1")]
         self.body = [UNetBody(ops, sd, "0", depth), UNetBody(ops, sd, "1", depth)]
+
+    def _hb(self, name, kind, *shape):
+        """Named h2 / zero-initialised fp32 buffers of the h2 path (h2 tensors are not fp32: kept outside _Workspace)."""
+        t = self._h2bufs.get(name)
+        want = (kind,) + tuple(shape)
+        if t is None or t[0] != want:
+            buf = self.ops.h2_empty(*shape) if kind == "h2" else self.ops.zeros(*shape)
+            t = self._h2bufs[name] = (want, buf)
+        return t[1]
+
+    def _use_h2(self, e):
+        """The full-resolution convolutions of a branch (DenseBlock_5C projection, `inc`, the last up layer: 9 of its convs and ~3/4 of its
+        arithmetic) on conv_h2x instead of the register-staged split conv (0.45 against 0.30 of the split's matrix-pipe bound) -- when the
+        fp16-pair split is active and the latent is big enough for the persistent kernel (branch 0: 6 channels at half the HR resolution)."""
+        ops = self.ops
+        B, C, H, W = e.shape
+        return (getattr(ops, "conv_mode", "f32") == "x3" and getattr(ops, "split", "") == "f16x2" and hasattr(ops, "conv_h2x")
+                and os.environ.get("BFSR_PRIOR", "h2x") == "h2x" and B * ((H + 15) // 16) * ((W + 31) // 32) >= 256)
 
     def forward_branch(self, b, e, out=None):
         """Branch b of the prior on latent b (the two branches share nothing, models/unet.py:154-181); `out` may be preallocated by the caller
         (e.g. on another stream than the one this call is enqueued on)."""
         B, C, H, W = e.shape
-        p = self.ws.get("proj%d" % b, B, self.proj[b].out, H, W)
-        self.proj[b].run(self.ops, self.ws, "proj%d" % b, e, p)
         if out is None:
             out = self.ops.empty(B, self.body[b].outc.pw.Cout, H, W)
+        if self._use_h2(e):
+            p_h2 = self._hb("proj%d_h2" % b, "h2", B, self.proj[b].out, H, W)
+            self.proj[b].run_h2(self.ops, self.ws, self._hb, "proj%d" % b, e, p_h2)
+            self.body[b].run(self.ws, None, out, "u%d" % b, top_h2=(p_h2, self._hb))
+            return out
+        p = self.ws.get("proj%d" % b, B, self.proj[b].out, H, W)
+        self.proj[b].run(self.ops, self.ws, "proj%d" % b, e, p)
         self.body[b].run(self.ws, p, out, "u%d" % b)
         return out
 

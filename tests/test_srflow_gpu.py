@@ -117,6 +117,28 @@ def test_golden_rrdb_and_prior(model4, hip, golden_dir):
         _chk(d, out[1], torch.from_numpy(p[d]), 2e-5)
 
 
+def test_prior_full_resolution_convs_on_h2x_vs_oracle(model4, hip, monkeypatch):
+    """The prior's big branch with its nine full-resolution convs on conv_h2x (unet_engine.SRFlowPriorEngine._use_h2: active from 256 tiles of
+    16 x 32) against the pinned oracle and against the register-staged path (BFSR_PRIOR=reg) on the same latents; odd sizes exercise the
+    pad / window of the up path next to the h2 buffers."""
+    import oracle.srflow_ref as O
+    m, prior, opt, sd, psd = model4
+    g = torch.Generator().manual_seed(5)
+    e0, e1 = torch.randn(2, 6, 250, 290, generator=g), torch.randn(2, 96, 62, 72, generator=g)
+    eng = prior.engine()
+    assert eng._use_h2(hip.to_device(e0)) and not eng._use_h2(hip.to_device(e1))
+    got = [t.cpu() for t in prior([e0, e1])]
+    ref = O.srflow_prior([e0, e1], psd)
+    for k in range(2):
+        _chk("z%d" % k, got[k], ref[k], 2e-5)
+    monkeypatch.setenv("BFSR_PRIOR", "reg")
+    assert not eng._use_h2(hip.to_device(e0))
+    reg = [t.cpu() for t in prior([e0, e1])]
+    assert float((reg[0] - got[0]).abs().max()) <= 2e-5 * float(ref[0].abs().max())
+    assert torch.equal(reg[1], got[1])
+    assert hip.fallbacks == 0
+
+
 def test_vs_oracle_fresh_input_and_roundtrip(model4, hip):
     import oracle.srflow_ref as O
     from bfsr_amd.srflow.test import lp_infer

@@ -9,11 +9,13 @@
     flow.py:120); log-determinants are not computed (discarded by the LP harness, test.py:43).
   * 256-row query chunking (test.py:26-32) is result-preserving and replaced by the kernel grid.
 """
+import os
+
 import torch
 
 from ..ops import ACT_LRELU, ACT_NONE, ACT_RELU, MODE_BILINEAR
-from ..srflow.engine import RRDBEncoder, _ConvP, _Workspace
-from ..srflow.unet_engine import DenseBlock, UNetBody
+from ..srflow.engine import RRDBEncoder, _ConvP, _Workspace, h2_mode
+from ..srflow.unet_engine import DenseBlock, H2Buffers, UNetBody
 
 
 class EDSREncoder(object):
@@ -64,7 +66,7 @@ class LINFEngine(object):
             raise ValueError("precision must be 'fp32' or 'fp16'")
         f16 = precision == "fp16"
         self.precision = precision
-        self.ops, self.ws = ops, _Workspace(ops)
+        self.ops, self.ws, self._hb = ops, _Workspace(ops), H2Buffers(ops)
         sd = {k: v.detach().to("cpu", torch.float32) for k, v in sd.items()}
         self.hidden, self.ps, self.L = hidden_dim, patch_size, flow_layers
         self.D = 3 * patch_size * patch_size
@@ -118,7 +120,14 @@ class LINFEngine(object):
         B, _, h, w = feat.shape
         _, qh, qw, _ = coord.shape
         cf = ws.get("cf", B, 2 * HD, h, w)
-        self.cf.run(ops, feat, cf)
+        if (h2_mode(ops, self.precision == "fp16") is not None and self.cf.mode in ("f16", "x3") and os.environ.get("BFSR_CF", "h2") != "reg"
+                and ((h + 15) // 16) * ((w + 31) // 32) >= 32):
+            # round 5: on the LDS-DMA kernel of the contraction mode over an h2 copy of feat (conv_h2s: 2.4x conv_f16's rate)
+            fh = self._hb("feat_h2", "h2", B, self.nf, h, w)
+            ops.h2_pack(feat, fh)
+            self.cf.run_h2(ops, fh, cf)
+        else:
+            self.cf.run(ops, feat, cf)
         if self.precision != "fp16" and hasattr(ops, "check_channels"):
             ops.check_channels(cf)                      # the fused MLP splits coef * cos / sin features into fp16 pairs
         if self.fused_mlp:
@@ -186,7 +195,7 @@ class LINFPriorEngine(object):
             raise ValueError("precision must be 'fp32' or 'fp16'")
         f16 = precision == "fp16"
         sd = {k: v.detach().to("cpu", torch.float32) for k, v in sd.items() if v.dtype.is_floating_point}
-        self.ops, self.ws, self.in_chans, self.dim = ops, _Workspace(ops), in_chans, dim
+        self.ops, self.ws, self.in_chans, self.dim, self.f16, self._hb = ops, _Workspace(ops), in_chans, dim, f16, H2Buffers(ops)
         self.input_proj = DenseBlock(ops, sd, "input_proj", f16=f16)
         self.lr_w = ops.to_device(sd["lr_proj.0.weight"])
         self.lr_b = ops.vec(sd["lr_proj.0.bias"])
@@ -195,6 +204,8 @@ class LINFPriorEngine(object):
 
     def forward(self, x, lr):
         ops, ws = self.ops, self.ws
+        if self._use_h2(x):
+            return self._forward_h2(x, lr)
         B, C, H, W = x.shape
         half = self.dim // 2
         cat = ws.get("cat", B, self.dim, H, W)
@@ -211,3 +222,35 @@ class LINFPriorEngine(object):
             ops.resize(e1, cat[:, half:], MODE_BILINEAR, float(oh) / H, float(ow) / W)   # size= given => r = in/out
         out = ops.empty(B, self.in_chans, H, W)
         return self.body.run(ws, cat, out, "u")
+
+    def _use_h2(self, x):
+        """The full-resolution 3x3 convs (both DenseBlock_5C projections, `inc`, the last up layer) on the LDS-DMA kernel of the contraction
+        mode over h2 tensors instead of the register-staged kernels (precision fp16: conv_h2s runs at 2.4x conv_f16's rate, profiles/README.md) --
+        from 32 tiles of 16 x 32 per sample on."""
+        B, C, H, W = x.shape
+        return (h2_mode(self.ops, self.f16) is not None and os.environ.get("BFSR_PRIOR", "h2") != "reg"
+                and ((H + 15) // 16) * ((W + 31) // 32) >= 32)          # per SAMPLE: the kernel choice must not depend on the batch
+
+    def _forward_h2(self, x, lr):
+        ops, ws, hb = self.ops, self.ws, self._hb
+        B, C, H, W = x.shape
+        half = self.dim // 2
+        cat_h2 = hb("cat_h2", "h2", B, self.dim, H, W)
+        self.input_proj.run_h2(ops, ws, hb, "ip", x, cat_h2[:, :half // 8])
+        _, _, h, w = lr.shape
+        oh, ow = (h + 2 - 3) // 3 + 1, (w + 2 - 3) // 3 + 1
+        e0 = ws.get("lr0", B, self.in_chans, oh, ow)
+        ops.conv_direct(lr, self.lr_w, self.lr_b, e0, 3, 1, act=ACT_LRELU, slope=0.2)
+        if (oh, ow) == (H, W):
+            self.lr_dense.run_h2(ops, ws, hb, "lp", e0, cat_h2[:, half // 8:])
+        else:
+            e1 = ws.get("lr1", B, half, oh, ow)
+            if ((oh + 15) // 16) * ((ow + 31) // 32) >= 32:
+                self.lr_dense.run_h2(ops, ws, hb, "lp", e0, e1)
+            else:
+                self.lr_dense.run(ops, ws, "lp", e0, e1)
+            e2 = ws.get("lr2", B, half, H, W)
+            ops.resize(e1, e2, MODE_BILINEAR, float(oh) / H, float(ow) / W)
+            ops.h2_pack(e2, cat_h2[:, half // 8:])
+        out = ops.empty(B, self.in_chans, H, W)
+        return self.body.run(ws, None, out, "u", top_h2=(cat_h2, hb))

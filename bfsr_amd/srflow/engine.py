@@ -65,6 +65,28 @@ class _ConvP(object):
             return ops.conv_x3(x, self.pw, out, epi=self.epi, **kw)
         return ops.conv(x, self.pw, out, epi=self.epi, **kw)
 
+    def run_h2(self, ops, x_h2, out, **kw):
+        """The same conv over an h2 view of its input on the LDS-DMA kernels: conv_h2x for the split contraction, conv_h2s (reads the hi plane =
+        the fp16 rounding of the activation, what conv_f16 stages) for precision='fp16'; `out`: an h2 view or an fp32 NCHW view.  `lo=True` keeps the
+        lo plane of an fp16-mode h2 output (for an output that is unpacked to fp32 again)."""
+        lo = kw.pop("lo", False)
+        if self.mode == "f16":
+            if getattr(self, "_h2s", None) is None:
+                self._h2s = ops.pack_conv_h2s(self.pw._w)
+            return ops.conv_h2s(x_h2, self._h2s, out, epi=self.epi, hi_only=(out.dtype == torch.float16 and not lo), **kw)
+        if self.mode != "x3":
+            raise ValueError("run_h2: no h2 kernel for contraction mode %r" % self.mode)
+        return ops.conv_h2x(x_h2, self.pw, out, epi=self.epi, **kw)
+
+
+def h2_mode(ops, f16):
+    """Which LDS-DMA conv family a module's 3x3 convs can use over h2 tensors: 'h2s' (precision fp16), 'h2x' (fp16-pair split) or None."""
+    if f16:
+        return "h2s" if hasattr(ops, "conv_h2s") else None
+    if getattr(ops, "conv_mode", "f32") == "x3" and getattr(ops, "split", "") == "f16x2" and hasattr(ops, "conv_h2x"):
+        return "h2x"
+    return None
+
 
 def _chk(ops, t):
     """Per-channel dynamic-range check of an fp32 tensor that enters an fp16-pair region (ops.check_channels; a no-op on other splits / backends)."""

@@ -12,7 +12,7 @@ import os
 import torch
 
 from ..ops import ACT_LRELU, ACT_NONE, MODE_BILINEAR_AC
-from .engine import _ConvP, _Workspace
+from .engine import _ConvP, _Workspace, h2_mode
 
 
 def _bn_conv(ops, sd, wkey, bnp, eps=1e-5, f16=False):
@@ -34,12 +34,12 @@ class _DoubleConv(object):
         self.c2.run(ops, mid, out, act=ACT_LRELU, slope=0.2)
         return out
 
-    def run_h2(self, ops, hb, tag, x_h2, out):
-        """Both convs on conv_h2x: x_h2 an h2 view, `out` an h2 view or an fp32 tensor."""
+    def run_h2(self, ops, hb, tag, x_h2, out, lo=False):
+        """Both convs on the LDS-DMA kernel of the contraction mode (_ConvP.run_h2): x_h2 an h2 view, `out` an h2 view or an fp32 tensor."""
         B, H, W = x_h2.shape[0], x_h2.shape[3], x_h2.shape[4]
         mid = hb(tag + "_mid_h2", "h2", B, self.mid, H, W)
-        ops.conv_h2x(x_h2, self.c1.pw, mid, epi=self.c1.epi, act=ACT_LRELU, slope=0.2)
-        ops.conv_h2x(mid, self.c2.pw, out, epi=self.c2.epi, act=ACT_LRELU, slope=0.2)
+        self.c1.run_h2(ops, x_h2, mid, act=ACT_LRELU, slope=0.2)
+        self.c2.run_h2(ops, mid, out, act=ACT_LRELU, slope=0.2, lo=lo)
         return out
 
 
@@ -49,38 +49,41 @@ class DenseBlock(object):
     def __init__(self, ops, sd, p, f16=False):
         self.convs = [_ConvP(ops, sd["%s.conv%d.weight" % (p, i)], sd["%s.conv%d.bias" % (p, i)], f16=f16) for i in range(1, 6)]
         self._raw = [(sd["%s.conv%d.weight" % (p, i)], sd["%s.conv%d.bias" % (p, i)]) for i in range(1, 6)]
+        self.f16 = f16
         self.nf = self.convs[0].pw.Cin
         self.gc = self.convs[0].pw.Cout
         self.out = self.convs[4].pw.Cout
 
     def h2_ready(self, ops):
-        """Padded packings for the h2 path (run_h2): the block's nf input channels padded to a multiple of 16 (zero weights for the pad)."""
+        """Padded convs for the h2 path (run_h2): the block's nf input channels padded to the K chunk of the kernel family (16 channels for
+        conv_h2x, 32 for conv_h2s) with zero weights."""
         if getattr(self, "_h2", None) is None:
-            nfp = -(-self.nf // 16) * 16
-            pws = []
-            for i, c in enumerate(self._raw):
-                w, b = c[0].detach().to("cpu", torch.float32), c[1]
+            q = 32 if self.f16 else 16
+            nfp = -(-self.nf // q) * q
+            cs = []
+            for i, (w, b) in enumerate(self._raw):
+                w = w.detach().to("cpu", torch.float32)
                 wp = torch.zeros(w.shape[0], nfp + i * self.gc, 3, 3)
                 wp[:, :self.nf] = w[:, :self.nf]
                 wp[:, nfp:] = w[:, self.nf:]
-                pws.append((ops.pack_conv_x3(wp, 1, lazy=True), ops.pack_epilogue(w.shape[0], b)))
-            self._h2 = (nfp, pws)
+                cs.append(_ConvP(ops, wp, b, f16=self.f16, x3=None if self.f16 else True))
+            self._h2 = (nfp, cs)
         return self._h2
 
-    def run_h2(self, ops, ws, hb, tag, x, out_h2):
-        """The same block on h2 tensors and the LDS-DMA kernel conv_h2x (round 5: the full-resolution convs of the prior's big branch): x fp32
-        [B,nf,H,W] -> out_h2 (h2 view, 64 channels).  The growing concat is one h2 buffer of nfp + 4*gc channels."""
+    def run_h2(self, ops, ws, hb, tag, x, out):
+        """The same block on h2 tensors and the LDS-DMA kernels (round 5: the full-resolution convs of the learned priors): x fp32 [B,nf,H,W] ->
+        out (h2 view or fp32 NCHW view).  The growing concat is one h2 buffer of nfp + 4*gc channels."""
         B, _, H, W = x.shape
-        nfp, pws = self.h2_ready(ops)
+        nfp, cs = self.h2_ready(ops)
         gc, o = self.gc, (lambda c: c // 8)
-        x16 = hb(tag + "_x16", "f32z", B, nfp, H, W)               # zero-initialised once: the pad channels stay zero
-        ops.axpb_clamp(x, x16[:, :self.nf])
+        xp = hb(tag + "_xpad", "f32z", B, nfp, H, W)               # zero-initialised once: the pad channels stay zero
+        ops.axpb_clamp(x, xp[:, :self.nf])
         D = hb(tag + "_dense_h2", "h2", B, nfp + 4 * gc, H, W)
-        ops.h2_pack(x16, D[:, :o(nfp)])
+        ops.h2_pack(xp, D[:, :o(nfp)])
         for i in range(4):
-            ops.conv_h2x(D[:, :o(nfp + i * gc)], pws[i][0], D[:, o(nfp + i * gc): o(nfp + (i + 1) * gc)], epi=pws[i][1], act=ACT_LRELU, slope=0.2)
-        ops.conv_h2x(D, pws[4][0], out_h2, epi=pws[4][1])
-        return out_h2
+            cs[i].run_h2(ops, D[:, :o(nfp + i * gc)], D[:, o(nfp + i * gc): o(nfp + (i + 1) * gc)], act=ACT_LRELU, slope=0.2)
+        cs[4].run_h2(ops, D, out)
+        return out
 
     def run(self, ops, ws, tag, x, out):
         B, _, H, W = x.shape
@@ -124,7 +127,7 @@ class UNetBody(object):
         if top_h2 is not None:
             x_h2, hb = top_h2
             cat_h2 = hb("%s_cat0_h2" % name, "h2", B, self.ups[depth - 1].c1.pw.Cin, H, W)
-            self.inc.run_h2(ops, hb, "%s_inc" % name, x_h2, cat_h2[:, :chans[0] // 8])
+            self.inc.run_h2(ops, hb, "%s_inc" % name, x_h2, cat_h2[:, :chans[0] // 8], lo=True)
             ops.h2_unpack(cat_h2[:, :chans[0] // 8], feats[0][:, :chans[0]])          # the pooling below reads fp32
         else:
             self.inc.run(ops, ws, "%s_inc" % name, x, feats[0][:, :chans[0]])
@@ -157,32 +160,36 @@ class UNetBody(object):
         return out
 
 
+class H2Buffers(object):
+    """Named h2 / zero-initialised fp32 buffers of the h2 paths (h2 tensors are not fp32: kept outside _Workspace); reallocated on a shape change."""
+
+    def __init__(self, ops):
+        self.ops, self.bufs = ops, {}
+
+    def __call__(self, name, kind, *shape):
+        t = self.bufs.get(name)
+        want = (kind,) + tuple(shape)
+        if t is None or t[0] != want:
+            t = self.bufs[name] = (want, self.ops.h2_empty(*shape) if kind == "h2" else self.ops.zeros(*shape))
+        return t[1]
+
+
 class SRFlowPriorEngine(object):
     """SRFlow-LP prior `UNet.forward(epses) -> [z0, z1]` (models/unet.py:154-181)."""
 
     def __init__(self, sd, ops, depth=3):
         sd = {k: v.detach().to("cpu", torch.float32) for k, v in sd.items() if v.dtype.is_floating_point}
-        self.ops, self.ws, self._h2bufs = ops, _Workspace(ops), {}
+        self.ops, self.ws, self._hb = ops, _Workspace(ops), H2Buffers(ops)
         self.proj = [DenseBlock(ops, sd, "input_proj0"), DenseBlock(ops, sd, "input_proj1")]
         self.body = [UNetBody(ops, sd, "0", depth), UNetBody(ops, sd, "1", depth)]
-
-    def _hb(self, name, kind, *shape):
-        """Named h2 / zero-initialised fp32 buffers of the h2 path (h2 tensors are not fp32: kept outside _Workspace)."""
-        t = self._h2bufs.get(name)
-        want = (kind,) + tuple(shape)
-        if t is None or t[0] != want:
-            buf = self.ops.h2_empty(*shape) if kind == "h2" else self.ops.zeros(*shape)
-            t = self._h2bufs[name] = (want, buf)
-        return t[1]
 
     def _use_h2(self, e):
         """The full-resolution convolutions of a branch (DenseBlock_5C projection, `inc`, the last up layer: 9 of its convs and ~3/4 of its
         arithmetic) on conv_h2x instead of the register-staged split conv (0.45 against 0.30 of the split's matrix-pipe bound) -- when the
-        fp16-pair split is active and the latent is big enough for the persistent kernel (branch 0: 6 channels at half the HR resolution)."""
-        ops = self.ops
+        fp16-pair split is active and the latent has at least 32 tiles of 16 x 32 per sample (branch 0: 6 channels at half the HR resolution)."""
         B, C, H, W = e.shape
-        return (getattr(ops, "conv_mode", "f32") == "x3" and getattr(ops, "split", "") == "f16x2" and hasattr(ops, "conv_h2x")
-                and os.environ.get("BFSR_PRIOR", "h2x") == "h2x" and B * ((H + 15) // 16) * ((W + 31) // 32) >= 256)
+        return (h2_mode(self.ops, False) == "h2x" and os.environ.get("BFSR_PRIOR", "h2x") == "h2x"
+                and ((H + 15) // 16) * ((W + 31) // 32) >= 32)          # per SAMPLE: the kernel choice must not depend on the batch (bit-identical shards)
 
     def forward_branch(self, b, e, out=None):
         """Branch b of the prior on latent b (the two branches share nothing, models/unet.py:154-181); `out` may be preallocated by the caller

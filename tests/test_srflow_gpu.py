@@ -118,8 +118,8 @@ def test_golden_rrdb_and_prior(model4, hip, golden_dir):
 
 
 def test_prior_full_resolution_convs_on_h2x_vs_oracle(model4, hip, monkeypatch):
-    """The prior's big branch with its nine full-resolution convs on conv_h2x (unet_engine.SRFlowPriorEngine._use_h2: active from 256 tiles of
-    16 x 32) against the pinned oracle and against the register-staged path (BFSR_PRIOR=reg) on the same latents; odd sizes exercise the
+    """The prior's big branch with its nine full-resolution convs on conv_h2x (unet_engine.SRFlowPriorEngine._use_h2: active from 32 tiles of
+    16 x 32 per sample) against the pinned oracle and against the register-staged path (BFSR_PRIOR=reg) on the same latents; odd sizes exercise the
     pad / window of the up path next to the h2 buffers."""
     import oracle.srflow_ref as O
     m, prior, opt, sd, psd = model4

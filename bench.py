@@ -55,6 +55,7 @@ FAMILIES = {
     "conv_up2_f2": ("conv_up2_bf16x3_kernel<PL=2>", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split, parity-decomposed conv over nearest-x2 input"),
     "conv_up2_h2t": ("conv_up2_h2t_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split, conv over cat[key, nearest-x2 taps] at source resolution (parity-decomposed taps, space-to-depth key chunks), h2 input by LDS-DMA"),
     "conv_h2r": ("coupling_tail_kernel<plain conv>", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split, 3x3 conv 64 -> <=32 channels over an h2 tensor on the coupling tail's ring kernel"),
+    "conv_up4_h2t": ("conv_up4_h2t_kernel", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split, conv over nearest-x4 taps at source resolution (25 pre-summed phase blocks), h2 input by LDS-DMA, quad-major output"),
     "conv_up4_f2": ("conv_up4_bf16x3_kernel<PL=2>", PEAK_16BIT_MFMA_TFLOPS, 3, "two-term fp16 split, phase-decomposed conv over nearest-x4 input"),
     "conv_f16": ("conv_f16_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, "fp16 MFMA (v_mfma_f32_32x32x16_f16), fp32 accumulate"),
     "conv_h2s": ("conv3x3_h2s_kernel", PEAK_16BIT_MFMA_TFLOPS, 1, "fp16 MFMA, fp16-stored (h2) input by LDS-DMA, fp32 accumulate"),
@@ -113,6 +114,9 @@ def launch_flop(k):
     if f == "conv_up2_h2t":                                              # Ct taps channels: 2x2 source taps per output pixel; Ck key channels: 9 taps
         _, ct, ck, Cout, b_, hh, ww = k
         return 2.0 * (ct * 4 + ck * 9) * Cout * b_ * hh * ww
+    if f == "conv_up4_h2t":                                              # 25 pre-summed matrices per 16 output pixels
+        _, ct, _, Cout, b_, hh, ww = k
+        return 2.0 * ct * 25.0 / 16.0 * Cout * b_ * hh * ww
     if f in ("conv_up4_x3", "conv_up4_f2"):                             # 25 pre-summed matrices per 16 output pixels
         _, _, Cin, Cout, b_, hh, ww, _ = k
         return 2.0 * Cin * 25.0 / 16.0 * Cout * b_ * hh * ww

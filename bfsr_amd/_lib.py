@@ -195,6 +195,9 @@ SYMBOLS = {
     "bfsr_conv2d_up2_h2t": (_I, [C.POINTER(BfsrUp2H2Args), _VP]),
     "bfsr_conv_up2_h2t_packed_size": (_LL, [_I, _I, _I]),
     "bfsr_pack_conv_up2_h2t": (_I, [_VP, _VP, _I, _I, _I, C.c_float, _VP]),
+    "bfsr_conv2d_up4_h2t": (_I, [C.POINTER(BfsrUp2H2Args), _VP]),
+    "bfsr_conv_up4_h2t_packed_size": (_LL, [_I, _I]),
+    "bfsr_pack_conv_up4_h2t": (_I, [_VP, _I, _I, C.c_float, _VP]),
     "bfsr_h2_pack_s2d": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP, _VP]),
     "bfsr_squeeze2d": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
     "bfsr_unsqueeze2d": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),

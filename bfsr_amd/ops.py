@@ -654,6 +654,38 @@ class HipOps(object):
         _lib.check(self._launch(key, lambda: self.lib.bfsr_conv2d_up2_h2t(C.byref(a), self._stream())), "conv2d_up2_h2t")
         return out
 
+    def pack_conv_up4_h2t(self, w_taps):
+        """OIHW 3x3 weights over the nearest-x4-upsampled tap channels -> conv_up4_h2t's packing (25 pre-summed blocks per 16-channel chunk)."""
+        w = w_taps.detach().to("cpu", torch.float32).contiguous()
+        Cout, Ct = w.shape[0], w.shape[1]
+        if w.shape[2:] != (3, 3) or Cout % 32 or Ct % 16:
+            raise ValueError("pack_conv_up4_h2t: unsupported shape %s" % (tuple(w.shape),))
+        wd, sets = w.double(), ((0,), (1, 2), (0, 1, 2), (0, 1), (2,))
+        m = max(float(wd[:, :, list(r)][:, :, :, list(c)].sum((2, 3)).abs().max()) for r in sets for c in sets)
+        scale = self.pow2_scale(torch.tensor([m]))          # the largest pre-summed block entry into [2^9, 2^10)
+        packed = torch.empty(self.lib.bfsr_conv_up4_h2t_packed_size(Cout, Ct), dtype=torch.int16)
+        _lib.check(self.lib.bfsr_pack_conv_up4_h2t(w.data_ptr(), Cout, Ct, scale, packed.data_ptr()), "pack_conv_up4_h2t")
+        return packed.to(self.device), 1.0 / scale, Cout, Ct
+
+    def conv_up4_h2t(self, x, packed, out, pre_add=None):
+        """conv3x3(nearest_up4(taps)) + pre_add at source resolution (conv_up4_h2t.hip: phase-decomposed, two-term fp16 split, three products).
+        `x`: h2 tensor [B,Ct/8,2,h,w,8]; `out` and `pre_add` (may be `out`) are fp32 buffers of shape [B,Cout,4h,4w] holding the QUAD-MAJOR layout."""
+        wts, acc_scale, Cout, Ct = packed
+        a = _lib.BfsrUp2H2Args()
+        a.x, a.x_bs, cin, h, w = self._h2view(x, "conv_up4_h2t.x")
+        a.y, a.y_bs, co, H, W = _view(out, "conv_up4_h2t.out")
+        if (cin, co, 4 * h, 4 * w) != (Ct, Cout, H, W) or x.shape[0] != out.shape[0]:
+            raise ValueError("conv_up4_h2t: shape mismatch x%s out%s weight(Cout=%d,Ct=%d)" % (tuple(x.shape), tuple(out.shape), Cout, Ct))
+        a.Cin, a.Ckey, a.Cout, a.y_fmt = cin, 0, Cout, 1
+        a.w, a.acc_scale = wts.data_ptr(), acc_scale
+        a.B, a.h, a.w_ = out.shape[0], h, w
+        if pre_add is not None:
+            a.pre_add, a.pre_add_bs, c, hh, ww = _view(pre_add, "conv_up4_h2t.pre_add")
+            assert (c, hh, ww) == (Cout, H, W)
+        key = ("conv_up4_h2t", Ct, 0, Cout, out.shape[0], H, W)
+        _lib.check(self._launch(key, lambda: self.lib.bfsr_conv2d_up4_h2t(C.byref(a), self._stream())), "conv2d_up4_h2t")
+        return out
+
     def pack_conv_h2s(self, w):
         """OIHW 3x3 fp32 weights -> fp16 packing of conv_h2s (32- or 64-cout workgroup tiles, 16-channel chunks)."""
         w = w.detach().to("cpu", torch.float32).contiguous()

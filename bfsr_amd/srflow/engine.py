@@ -492,9 +492,13 @@ class SRFlowEngine(object):
                 return (pv is not None and pv.type == "step" and pv.coupled and pv.level == level
                         and getattr(self.steps[pv.index], "fused", False))
             hz["hft_q4"] = set(i for i in idxs if getattr(self.steps[i], "fused", False) and _prev_is_fused_step(i))
-            # (the x4 taps kernel has no quad-major epilogue: at that level the raw fFeatures.0 result stays NCHW and the 1x1-only head reads it so)
+            # (the register-staged x4 taps kernel has no quad-major epilogue: without conv_up4_h2t the raw fFeatures.0 result of that level stays
+            # NCHW and the 1x1-only head reads it so)
+            h4t_ok = (self._taps_up2(level) == 2 and getattr(ops, "conv_mode", "f32") == "x3" and getattr(ops, "split", "") == "f16x2"
+                      and hasattr(ops, "conv_up4_h2t") and bool(getattr(self.rrdb, "x3s", False)) and os.environ.get("BFSR_UP4", "h2t") == "h2t"
+                      and wf.shape[0] % 32 == 0 and wa.shape[0] % 32 == 0 and (wf.shape[1] - 64) % 16 == 0)
             hz["ffast"] = all(self.steps[i].fthead is not None for i in idxs) and self._taps_up2(level) in (0, 1, 2)
-            hz["pre_q4"] = fused_all and (self._taps_up2(level) in (0, 1, False, None)) and getattr(ops, "conv_mode", "f32") == "x3"
+            hz["pre_q4"] = (fused_all and (self._taps_up2(level) in (0, 1, False, None) or h4t_ok) and getattr(ops, "conv_mode", "f32") == "x3")
             # Round 3: the 64 -> 16*64 key convs of the finer levels run on conv_x3s (LDS-DMA staging by loader waves, persistent) over
             # an x3 copy of the key channels instead of the register-staged conv_bf16x3 kernel: 5.51 -> 4.80 ms at 8 x 320^2
             # (175 -> 201 TFLOP/s-equivalent).  The 320 -> 1024 hoists of the coarser levels were measured too and are NOT moved:
@@ -510,6 +514,10 @@ class SRFlowEngine(object):
                 if hz["up"] == 2:       # x4: 25 pre-summed matrices (25 instead of 144 tap products per source pixel)
                     hz.update(ft0_taps=ops.pack_conv_up4_x3(wf[:, 64:].contiguous()), aff0_taps=ops.pack_conv_up4_x3(wa[:, 64:].contiguous()),
                               ft0_key=ops.pack_conv_x3(wf[:, :64].contiguous(), 2), aff0_key=ops.pack_conv_x3(wa[:, :64].contiguous(), 2))
+                    # Round 5: the same 25 blocks on conv_up4_h2t (conv_up2_h2t's structure: taps split once into an h2 tensor, LDS-DMA staging,
+                    # all nine phase classes per workgroup item, quad-major output -> the level gets the quad-major hand-over of the x2 levels)
+                    if h4t_ok and hz["ffast"] and hz["pre_q4"]:
+                        hz["h4t"] = (ops.pack_conv_up4_h2t(wf[:, 64:].contiguous()), ops.pack_conv_up4_h2t(wa[:, 64:].contiguous()))
                 elif hz["x3"]:
                     # 3xBF16 kernels: key channels by the plain conv (no epilogue) into the output buffer, then the taps
                     # kernel adds them back through pre_add and applies the epilogue
@@ -685,9 +693,9 @@ class SRFlowEngine(object):
             h2 = self._hid.get("ffh%d" % level)
             if h2 is None or tuple(h2.shape) != (B, 8, 2, hl, wl, 8):
                 self._hid["ffh%d" % level] = self.ops.h2_empty(B, 64, hl, wl)
-        if hz.get("up2") and hz.get("h2t") is not None:
+        if hz.get("up2") and (hz.get("h2t") is not None or hz.get("h4t") is not None):
             taps = ft[self._lr_level()][:, 64:]
-            key = (B, taps.shape[1] + 4 * 64) + tuple(taps.shape[2:])
+            key = (B, taps.shape[1] + (4 * 64 if hz.get("h2t") is not None else 0)) + tuple(taps.shape[2:])
             if getattr(self, "_taps_h2", None) is None:
                 self._taps_h2 = {}
             if level not in self._taps_h2 or self._taps_h2[level][0] != key:
@@ -702,6 +710,16 @@ class SRFlowEngine(object):
                 self._ft_h2[level] = (key, self.ops.h2_empty(*key))
         elif getattr(self, "_ft_h2", None):
             self._ft_h2.pop(level, None)
+        # levels whose coupled steps all run the unfused h2 chain (C = 96): pre_aff only ever enters a conv_h2x launch as its residual -> h2 tensor
+        if getattr(self, "_pre_h2", None) is None:
+            self._pre_h2 = {}
+        if (level in getattr(self, "_ft_h2", {}) and os.environ.get("BFSR_L3", "h2x") == "h2x"
+                and all(getattr(self.steps[i], "chain", None) is not None for i in hz["idxs"])):
+            key = (B, K * 64, hl, wl)
+            if level not in self._pre_h2 or self._pre_h2[level][0] != key:
+                self._pre_h2[level] = (key, self.ops.h2_empty(*key))
+        else:
+            self._pre_h2.pop(level, None)
         return (ws.get("hoist_hid%d" % level, B, K * 64, hl, wl), ws.get("pre_aff%d" % level, B, K * 64, hl, wl),
                 ws.get("h_ft%d" % level, B, K * 2 * Cz, hl, wl), Cz)
 
@@ -709,6 +727,7 @@ class SRFlowEngine(object):
         ops = self.ops
         f = ft[level]
         hid, pre_aff, h_ft, Cz = self._hoist_buffers(level, hz, ft, B)
+        pre_h2 = None
         # quad-major hand-over to the coupling pair: pre_aff as a whole (one batched conv writes it) when every step of the level is
         # fused and its producers can (the x4 taps kernel cannot); h_ft per step (each step's Conv2dZeros writes its own slice) when the
         # step's h_ft is only ever read by coupling_tail -- i.e. not by flow_pointwise as the first step of an encode pass
@@ -716,8 +735,18 @@ class SRFlowEngine(object):
         hq = {i: int(quads and i in hz.get("hft_q4", ())) for i in hz["idxs"]}
         kq = dict(y_fmt=1) if pq else {}
         ff = bool(hz.get("ffast")) and hz.get("x3", True) is not False
-        ffq = int(ff and not (hz["up2"] and hz.get("up") == 2))     # layout of the raw fFeatures.0 result the 1x1-only head reads: 1 quad-major, 0 NCHW
-        if hz["up2"]:
+        h4t = hz.get("h4t") if (ff and pq and hz.get("x3s") and hz.get("up2") and hz.get("up") == 2) else None
+        ffq = int(ff and not (hz["up2"] and hz.get("up") == 2 and h4t is None))     # layout of the raw fFeatures.0 result the 1x1-only head reads: 1 quad-major, 0 NCHW
+        if h4t is not None:
+            # x4 level on conv_up4_h2t: the key convs (channels at output resolution) write quad-major, the taps kernel adds its result in place
+            taps = ft[self._lr_level()][:, 64:]
+            taps_h2 = ops.h2_pack(taps, self._taps_h2[level][1])
+            f3 = ops.x3_pack(f, self._ftx3[level][1])
+            ops.conv_x3s(f3, hz["ft0_key"], hid, y_fmt=1)
+            ops.conv_up4_h2t(taps_h2, h4t[0], hid, pre_add=hid)
+            ops.conv_x3s(f3, hz["aff0_key"], pre_aff, y_fmt=1)
+            ops.conv_up4_h2t(taps_h2, h4t[1], pre_aff, pre_add=pre_aff)
+        elif hz["up2"]:
             taps = ft[self._lr_level()][:, 64:]
             if hz["x3"]:
                 up = ops.conv_up4_x3 if hz["up"] == 2 else ops.conv_up2_x3
@@ -765,7 +794,10 @@ class SRFlowEngine(object):
                 ops.conv_h2x(fh, hz["ft0_raw"].pw, hid, epi=hz["ft0_raw"].epi, y_fmt=1)
             else:
                 ops.conv_h2x(fh, hz["ft0"].pw, hid, epi=hz["ft0"].epi, act=ACT_RELU)
-            ops.conv_h2x(fh, hz["aff0"].pw, pre_aff, epi=hz["aff0"].epi, **kq)
+            if level in self._pre_h2:
+                pre_h2 = ops.conv_h2x(fh, hz["aff0"].pw, self._pre_h2[level][1], epi=hz["aff0"].epi)
+            else:
+                ops.conv_h2x(fh, hz["aff0"].pw, pre_aff, epi=hz["aff0"].epi, **kq)
         else:
             if ff:
                 hz["ft0_raw"].run(ops, f, hid, y_fmt=1)
@@ -786,7 +818,7 @@ class SRFlowEngine(object):
                 continue
             st.ft2.run(ops, hk, hk, act=ACT_RELU)            # 1x1, in place (disjoint pixel tiles)
             st.ft4.run(ops, hk, h_ft[:, 2 * Cz * k: 2 * Cz * (k + 1)], **(dict(y_fmt=1) if hq[i] else {}))
-        return dict(pre_aff=pre_aff, h_ft=h_ft, slot={i: k for k, i in enumerate(hz["idxs"])}, C=Cz, pre_fmt=pq, h_ft_fmt=hq)
+        return dict(pre_aff=pre_aff, h_ft=h_ft, slot={i: k for k, i in enumerate(hz["idxs"])}, C=Cz, pre_fmt=pq, h_ft_fmt=hq, pre_h2=pre_h2)
 
     # ------------------------------------------------------------------------------------------
     def _self_cond(self, st, z, cnd, k, tag):
@@ -798,7 +830,17 @@ class SRFlowEngine(object):
         if getattr(st, "chain", None) is not None and not cnd.get("pre_fmt"):
             p0, hp, p4, e4 = st.chain
             raw = ws.get("raw_%s" % tag, B, 64, H, W)
-            ops.conv_x3(z[:, :cn], p0, raw, pre_add=cnd["pre_aff"][:, 64 * k: 64 * (k + 1)])
+            if cnd.get("pre_h2") is not None:
+                # round 5: the split 3x3 on z1 on the LDS-DMA kernel too (z1 packed into an h2 tensor, the hoisted partial = its h2 residual):
+                # the register-staged kernel ran this 48 -> 64 conv at 0.15 PFLOP/s (660 us per step at 64 x 96^2, 45 us at 8 x 80^2)
+                zk = "z1h_" + tag
+                zh = self._hid.get(zk)
+                if zh is None or tuple(zh.shape) != (B, cn // 8, 2, H, W, 8):
+                    zh = self._hid[zk] = ops.h2_empty(B, cn, H, W)
+                ops.h2_pack(z[:, :cn], zh)
+                ops.conv_h2x(zh, p0, raw, res1=cnd["pre_h2"][:, 8 * k: 8 * (k + 1)], alpha1=1.0)
+            else:
+                ops.conv_x3(z[:, :cn], p0, raw, pre_add=cnd["pre_aff"][:, 64 * k: 64 * (k + 1)])
             key = "hidc_" + tag
             h2 = self._hid.get(key)
             if h2 is None or tuple(h2.shape) != (B, 8, 2, H, W, 8):
@@ -862,6 +904,8 @@ class SRFlowEngine(object):
     def _lane_cond(self, cnd, b0, b1):
         c = dict(cnd)
         c["pre_aff"], c["h_ft"] = cnd["pre_aff"][b0:b1], cnd["h_ft"][b0:b1]
+        if cnd.get("pre_h2") is not None:
+            c["pre_h2"] = cnd["pre_h2"][b0:b1]
         return c
 
     def _steps_fwd_lane(self, run, z, cond, b0, b1, lane):

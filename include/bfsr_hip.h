@@ -333,6 +333,14 @@ typedef struct BfsrUp2H2Args {
 int bfsr_conv2d_up2_h2t(const BfsrUp2H2Args* a, void* stream);
 long long bfsr_conv_up2_h2t_packed_size(int Cout, int Ct, int Ckey);                 /* fp16 elements */
 int bfsr_pack_conv_up2_h2t(const float* w_taps_oihw, const float* w_key_oihw, int Cout, int Ct, int Ckey, float scale, unsigned short* packed);
+/* bfsr_conv2d_up4_h2t (round 5): the same for a NEAREST-x4 upsampling (the level-1 conditioning of the 8x model, BASELINE config 4;
+ * RRDBNet_arch.py:105-112 fea_up4 + SRFlowNet_arch.py:122-137): x = h2 tensor of the Ct tap channels at SOURCE resolution (Cin = Ct, Ckey must be 0:
+ * channels at output resolution enter through pre_add); w = bfsr_pack_conv_up4_h2t(w_taps, Cout, Ct, scale) -- per axis the phases {0}, {1, 2}, {3}
+ * of an output pixel see 2, 1, 2 source pixels: 25 pre-summed weight blocks per 16-channel chunk instead of 16 x 9 tap products;
+ * y, pre_add: fp32 QUAD-MAJOR [B][Cout/4][4h][4w][4].  Item = 8 x 32 source pixels x 32 output channels x all nine phase classes. */
+int bfsr_conv2d_up4_h2t(const BfsrUp2H2Args* a, void* stream);
+long long bfsr_conv_up4_h2t_packed_size(int Cout, int Ct);                             /* fp16 elements */
+int bfsr_pack_conv_up4_h2t(const float* w_taps_oihw, int Cout, int Ct, float scale, unsigned short* packed);
 /* fp32 [B][C][2h][2w] view -> h2 view with 4C channels at h x w (space to depth): channel q*C + c = pixels (2y+qy, 2x+qx) of channel c, q = qy*2+qx.
  * flag as for bfsr_h2_pack. */
 int bfsr_h2_pack_s2d(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int C, int h, int w, unsigned* flag, void* stream);

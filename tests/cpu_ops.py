@@ -418,6 +418,19 @@ class CpuOps(object):
         out.copy_(self.quads(y))
         return out
 
+    def pack_conv_up4_h2t(self, w_taps):
+        w = w_taps.detach().to(torch.float32).clone()
+        return w, 1.0, w.shape[0], w.shape[1]
+
+    def conv_up4_h2t(self, x, packed, out, pre_add=None):
+        """conv3x3(nearest_up4(taps)) + pre_add: x = h2 tensor of the taps; out / pre_add hold the quad-major layout."""
+        w, _, Cout, Ct = packed
+        y = F.conv2d(F.interpolate(sum(self._h2_planes(x)), scale_factor=4, mode="nearest"), w, None, 1, 1)
+        if pre_add is not None:
+            y = y + self.quads(pre_add, inverse=True)
+        out.copy_(self.quads(y))
+        return out
+
     def check_range(self):
         pass
 

@@ -492,6 +492,40 @@ def test_conv_h2r(hip, Cout, hw):
     assert float(wq[:, :4].abs().max()) == 0.0 and float(wq[:, 4 + Cout:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("case", [(2, 32, 64, 8, 32), (1, 64, 32, 21, 37), (3, 16, 96, 5, 70), (2, 256, 64, 24, 40), (1, 16, 32, 9, 33), (1, 16, 32, 1, 1)])
+def test_conv_up4_h2t(hip, case):
+    """bfsr_conv2d_up4_h2t: conv3x3(nearest_up4(taps)) + pre_add evaluated at source resolution (25 pre-summed weight blocks, nine phase classes),
+    two-term fp16 split (three products), quad-major fp32 output with and without pre_add (also in place): against an fp64 conv of the SAME
+    22-bit inputs with the unsplit fp32 weights (SRFlowNet_arch.py:122-137 with RRDBNet_arch.py:105-112 fea_up4: F.interpolate(..., mode='nearest')
+    + Conv2d).  Ragged tiles in both directions, several output-channel groups, per-channel weight magnitudes over four decades, a 1 x 1 source."""
+    B, Ct, Cout, h, w = case
+    x = rnd(311, B, Ct, h, w)
+    wt = rnd(312, Cout, Ct, 3, 3, scale=1.0 / np.sqrt(Ct * 9)) * torch.logspace(-3, 0, Cout).view(-1, 1, 1, 1) * 2.0
+    pre = rnd(313, B, Cout, 4 * h, 4 * w)
+    xh = hip.h2_pack(hip.to_device(x), hip.h2_empty(B, Ct, h, w))
+    x22 = hip.h2_unpack(xh, hip.empty(B, Ct, h, w)).cpu()
+    ref64 = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x22.double(), scale_factor=4, mode="nearest"), wt.double(), None, 1, 1)
+    tol = 4e-6 * float(ref64.abs().max())
+    pk = hip.pack_conv_up4_h2t(wt)
+    out = hip.empty(B, Cout, 4 * h, 4 * w)
+    out.fill_(float("nan"))
+    hip.conv_up4_h2t(xh, pk, out)
+    got = CPU.quads(out.cpu(), inverse=True)
+    err = float((got.double() - ref64).abs().max())
+    assert err <= tol, "conv_up4_h2t %s: max-abs %g > %g" % (case, err, tol)
+    wide = hip.zeros(B, Cout + 8, 4 * h, 4 * w)                        # pre_add from a second buffer, output into a channel slice (quads 1 ..)
+    pq = hip.to_device(CPU.quads(pre))
+    hip.conv_up4_h2t(xh, pk, wide[:, 4:4 + Cout], pre_add=pq)
+    got2 = CPU.quads(wide[:, 4:4 + Cout].cpu().contiguous(), inverse=True)
+    assert float((got2.double() - (ref64 + pre.double())).abs().max()) <= tol + 1e-6, "conv_up4_h2t with pre_add %s" % (case,)
+    assert float(wide[:, :4].abs().max()) == 0.0 and float(wide[:, 4 + Cout:].abs().max()) == 0.0, "wrote outside its channel slice"
+    hip.conv_up4_h2t(xh, pk, pq, pre_add=pq)                           # in place
+    assert torch.equal(CPU.quads(pq.cpu(), inverse=True), got2), "conv_up4_h2t in place %s" % (case,)
+    # the register-staged x4 kernel it replaces (NCHW): same arithmetic class
+    old = hip.conv_up4_x3(hip.to_device(x), hip.pack_conv_up4_x3(wt), hip.empty(B, Cout, 4 * h, 4 * w))
+    assert float((old.cpu().double() - ref64).abs().max()) <= 2.5 * tol + 1e-7
+
+
 @pytest.mark.parametrize("case", [(2, 32, 0, 64, 16, 32), (1, 64, 16, 32, 21, 37), (3, 16, 32, 96, 5, 70), (2, 256, 64, 64, 40, 40), (1, 16, 16, 32, 9, 33)])
 def test_conv_up2_h2t(hip, case):
     """bfsr_conv2d_up2_h2t: conv3x3(cat([key, nearest_up2(taps)])) evaluated at source resolution -- the taps parity-decomposed with pre-summed

@@ -115,6 +115,28 @@ def main():
     hf3, zo3 = torch.randn(B, 192, 80, 80, device="cuda") * 0.5, ops.empty(B, 96, 80, 80)
     ab, ae = ops.vec(r(96, scale=0.1)), ops.vec(torch.exp(r(96, scale=0.1)))
     total += stress("flow_pointwise_mfma C=96 @80x80", lambda: ops.flow_pointwise(z, zo3, True, h_aff=ha, h_ft=hf3, w=ops.vec(Wm), wt=ops.vec(Wm.t().contiguous()), an_bias=ab, an_escale=ae))
+    # --- the LDS-DMA taps kernels (x2 with key chunks, x4) and a dense-block chain in one persistent launch
+    th = ops.h2_pack(torch.randn(B, 256, 80, 80, device="cuda"), ops.h2_empty(B, 256, 80, 80))
+    tk = ops.h2_empty(B, 256 + 4 * 64, 80, 80)
+    ops.h2_pack(torch.randn(B, 256, 80, 80, device="cuda"), tk[:, :32])
+    ops.h2_pack_s2d(torch.randn(B, 64, 160, 160, device="cuda"), tk[:, 32:])
+    p2 = ops.pack_conv_up2_h2t(r(128, 256, 3, 3, scale=0.02), r(128, 64, 3, 3, scale=0.03))
+    y2 = ops.empty(B, 128, 160, 160)
+    total += stress("conv_up2_h2t 256+64->128 @160x160", lambda: ops.conv_up2_h2t(tk, p2, y2))
+    p4h = ops.pack_conv_up4_h2t(r(128, 256, 3, 3, scale=0.02))
+    y4h = ops.zeros(B, 128, 320, 320)
+    total += stress("conv_up4_h2t 256->128 @320x320", lambda: ops.conv_up4_h2t(th, p4h, y4h))
+    D = ops.h2_empty(B, 192, 96, 96)
+    ops.h2_pack(torch.randn(B, 64, 96, 96, device="cuda") * 0.5, D[:, :8])
+    specs = []
+    for i in range(4):
+        specs.append(dict(x=D[:, :8 + 4 * i], pw=ops.pack_conv_x3(r(32, 64 + 32 * i, 3, 3, scale=0.03), 1, lazy=True), out=D[:, 8 + 4 * i: 12 + 4 * i],
+                          epi=ops.pack_epilogue(32, bias=r(32, scale=0.1)), act=ACT_LRELU, slope=0.2))
+    yc = ops.h2_empty(B, 64, 96, 96)
+    specs.append(dict(x=D, pw=ops.pack_conv_x3(r(64, 192, 3, 3, scale=0.03), 1, lazy=True), out=yc, epi=ops.pack_epilogue(64, bias=r(64, scale=0.1)),
+                      res1=D[:, :8], alpha1=1.0))
+    ch = ops.conv_chain(specs)
+    total += stress("conv_chain (one dense block, 5 convs) @96x96", lambda: (ch.run(), yc)[1])
     # --- x4 taps kernel (8x model) and the fp16 conv of the LINF fp16 path
     t4 = torch.randn(B, 256, 48, 48, device="cuda")
     p4 = ops.pack_conv_up4_x3(r(128, 256, 3, 3, scale=0.02))

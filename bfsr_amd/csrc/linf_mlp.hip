@@ -29,6 +29,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef BFSR_MLP_ABL
+#define BFSR_MLP_ABL 0                          // ablation builds only (tools/exp/mlp_abl.sh): bit 0 no weight loads, 1 no cf gathers, 2 no output stores, 3 no MFMAs
+#endif
+
 namespace {
 
 constexpr int NW = 8, P = 64, HID = 256, KC = 16;
@@ -174,6 +178,11 @@ __global__ __launch_bounds__(NW * 64, X3 == 0 ? 4 : 2) void linf_mlp_kernel(Bfsr
     auto gen_load = [&](int k, int c0, Gather& g) {
         const int ofs = k == 0 ? off[0] : (k == 1 ? off[1] : (k == 2 ? off[2] : off[3]));
         const float* cfp = cfb + ofs;
+        if (BFSR_MLP_ABL & 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { g.co0[e] = 0.5f + e; g.co1[e] = 0.25f * e; g.f0[e] = 0.1f * e + k; g.f1[e] = 0.3f + c0; }
+            return;
+        }
         // all 32 gathers of a chunk back to back; they are consumed by gen_finish AFTER the MFMAs of the current interval, so the
         // gather latency (PMC: the waves were 65 % parked in s_waitcnt when each pair's loads were waited for separately) is hidden
 #pragma unroll
@@ -194,7 +203,16 @@ __global__ __launch_bounds__(NW * 64, X3 == 0 ? 4 : 2) void linf_mlp_kernel(Bfsr
             float f = g.f0[e] * ry + g.f1[e] * rx;
             f = f + (cell_y * a.phase[c * 2 + 0] + cell_x * a.phase[c * 2 + 1]);
             float s, cs;
-            sincos_feat(PI * f, s, cs);
+            if constexpr (X3 == 0) {
+                // precision 'fp16': the features are rounded to fp16 (2^-11) right below, so the hardware sine / cosine (argument in
+                // revolutions, |error| ~1e-6 absolute) are exact enough: sin(pi f) = v_sin(fract(f / 2)); two quarter-rate instructions
+                // instead of the ~40 full-rate ones of sincos_feat -- the feature generation was this mode's VALU bound
+                const float t = __builtin_amdgcn_fractf(f * 0.5f);
+                s = __builtin_amdgcn_sinf(t);
+                cs = __builtin_amdgcn_cosf(t);
+            } else {
+                sincos_feat(PI * f, s, cs);
+            }
             vc[e] = (wgt * g.co0[e]) * cs;
             vs[e] = (wgt * g.co1[e]) * s;
         }
@@ -212,6 +230,7 @@ __global__ __launch_bounds__(NW * 64, X3 == 0 ? 4 : 2) void linf_mlp_kernel(Bfsr
     const unsigned short* __restrict__ wbase = a.wts;
     auto load_a = [&](const unsigned short* wl, int nchunk, int mt, int kc, frag (&dst)[PL]) {
         const unsigned short* p = wl + (((long long)mt * nchunk + kc) * PL * 64 + lane) * 8;
+        if (BFSR_MLP_ABL & 1) p = wl + lane * 8;                       // (ablation: one L1-resident fragment)
 #pragma unroll
         for (int pl = 0; pl < PL; ++pl) dst[pl] = *reinterpret_cast<const frag*>(p + pl * 64 * 8);
     };
@@ -233,6 +252,7 @@ __global__ __launch_bounds__(NW * 64, X3 == 0 ? 4 : 2) void linf_mlp_kernel(Bfsr
             BFSR_T(1, 0) BFSR_T(0, 1) BFSR_T(0, 0)
 #undef BFSR_T
         } else {
+            if (BFSR_MLP_ABL & 8) { acc[0][0] += (float)af[0][0] * (float)bf[0][0][0]; return; }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[nt] = MD::mfma(af[0], bf[0][nt], acc[nt]);
         }
@@ -347,6 +367,7 @@ __global__ __launch_bounds__(NW * 64, X3 == 0 ? 4 : 2) void linf_mlp_kernel(Bfsr
             for (int nt = 0; nt < 2; ++nt) {
                 const long long qq = q0 + nt * 32 + l31;
                 if (qq >= NQ) continue;
+                if ((BFSR_MLP_ABL & 4) && acc[nt][0] != 1234.5f) continue;
                 if (a.out_fmt == 1) {
                     // quad-major [Cout/4][NQ][4]: accumulator registers 4g .. 4g+3 are four CONSECUTIVE output rows of this lane's
                     // query point = one 16-byte store (the row-major form issued 16 four-byte stores per tile and half-wave-wide

@@ -107,8 +107,10 @@ class UNetBody(object):
         self.outc = _ConvP(ops, sd["outc%s.conv.weight" % tag], sd["outc%s.conv.bias" % tag])
 
     def run(self, ws, x, out, name, top_h2=None):
-        """x [B,dim,H,W] -> out [B,Cout,H,W].  top_h2 = (x_h2, hb): the FULL-resolution convs (inc, the last up layer) run on conv_h2x over h2
-        tensors (x_h2 = the input as an h2 view, hb = the engine's buffer factory); everything below the first pooling stays as it is."""
+        """x [B,dim,H,W] -> out [B,Cout,H,W].  top_h2 = (x_h2, hb): the convs of the FULL-resolution level (inc, the last up layer) and of every
+        lower level that still has >= 32 tiles of 16 x 32 per sample run on the LDS-DMA kernels over h2 tensors (x_h2 = the input as an h2 view,
+        hb = the engine's buffer factory; pooling and bilinear up-sampling stay fp32 kernels: pack / unpack glue around them); the small levels
+        stay on the register-staged kernels.  The choice depends on the sample size only, never on the batch."""
         ops, depth = self.ops, self.depth
         B, _, H, W = (x.shape if top_h2 is None else (top_h2[0].shape[0], None, top_h2[0].shape[3], top_h2[0].shape[4]))
         sizes = [(H, W)]
@@ -116,19 +118,22 @@ class UNetBody(object):
             sizes.append((sizes[-1][0] // 2, sizes[-1][1] // 2))
         if min(sizes[-1]) < 1:
             raise ValueError("input %dx%d too small for a depth-%d UNet" % (H, W, depth))
+        hb = top_h2[1] if top_h2 is not None else None
+        lower = os.environ.get("BFSR_PRIOR_LEVELS", "h2") == "h2"
+        on_h2 = [top_h2 is not None and (i == 0 or (lower and ((sizes[i][0] + 15) // 16) * ((sizes[i][1] + 31) // 32) >= 32)) for i in range(depth)]
         # skip feature i (i < depth) lives in the first channels of the concat buffer of up layer depth-1-i
-        feats = []
+        feats, cat_h2 = [], {}
         chans = [self.inc.out] + [d.out for d in self.downs]
         for i in range(depth):
             up = self.ups[depth - 1 - i]
             cat = ws.get("%s_cat%d" % (name, i), B, up.c1.pw.Cin, sizes[i][0], sizes[i][1])
             feats.append(cat)
+            if on_h2[i]:
+                cat_h2[i] = hb("%s_cat%d_h2" % (name, i), "h2", B, up.c1.pw.Cin, sizes[i][0], sizes[i][1])
         bottom = ws.get("%s_bottom" % name, B, chans[depth], sizes[depth][0], sizes[depth][1])
-        if top_h2 is not None:
-            x_h2, hb = top_h2
-            cat_h2 = hb("%s_cat0_h2" % name, "h2", B, self.ups[depth - 1].c1.pw.Cin, H, W)
-            self.inc.run_h2(ops, hb, "%s_inc" % name, x_h2, cat_h2[:, :chans[0] // 8], lo=True)
-            ops.h2_unpack(cat_h2[:, :chans[0] // 8], feats[0][:, :chans[0]])          # the pooling below reads fp32
+        if on_h2[0]:
+            self.inc.run_h2(ops, hb, "%s_inc" % name, top_h2[0], cat_h2[0][:, :chans[0] // 8], lo=True)
+            ops.h2_unpack(cat_h2[0][:, :chans[0] // 8], feats[0][:, :chans[0]])          # the pooling below reads fp32
         else:
             self.inc.run(ops, ws, "%s_inc" % name, x, feats[0][:, :chans[0]])
         cur = feats[0][:, :chans[0]]
@@ -136,7 +141,13 @@ class UNetBody(object):
             pooled = ws.get("%s_pool%d" % (name, i), B, chans[i], sizes[i + 1][0], sizes[i + 1][1])
             ops.maxpool2(cur, pooled)
             dst = feats[i + 1][:, :chans[i + 1]] if i + 1 < depth else bottom
-            self.downs[i].run(ops, ws, "%s_down%d" % (name, i), pooled, dst)
+            if i + 1 < depth and on_h2[i + 1]:
+                ph = ops.h2_pack(pooled, hb("%s_pool%d_h2" % (name, i), "h2", B, chans[i], sizes[i + 1][0], sizes[i + 1][1]))
+                sk = cat_h2[i + 1][:, :chans[i + 1] // 8]
+                self.downs[i].run_h2(ops, hb, "%s_down%d" % (name, i), ph, sk, lo=True)
+                ops.h2_unpack(sk, dst)
+            else:
+                self.downs[i].run(ops, ws, "%s_down%d" % (name, i), pooled, dst)
             cur = dst
         for j in range(depth):
             i = depth - 1 - j            # skip level
@@ -150,9 +161,9 @@ class UNetBody(object):
             r_w = float(w1 - 1) / float(uw - 1) if uw > 1 else 0.0
             ops.resize(cur, cat[:, cs:], MODE_BILINEAR_AC, r_h, r_w, window=(dy // 2, dx // 2, uh, uw))
             o = ws.get("%s_up%d" % (name, j), B, self.ups[j].out, Hs, Ws)
-            if top_h2 is not None and i == 0:
-                ops.h2_pack(cat[:, cs:], cat_h2[:, cs // 8:])                     # the upsampled half joins the skip half (already h2)
-                self.ups[j].run_h2(ops, hb, "%s_upc%d" % (name, j), cat_h2, o)
+            if on_h2[i]:
+                ops.h2_pack(cat[:, cs:], cat_h2[i][:, cs // 8:])                  # the upsampled half joins the skip half (already h2)
+                self.ups[j].run_h2(ops, hb, "%s_upc%d" % (name, j), cat_h2[i], o)
             else:
                 self.ups[j].run(ops, ws, "%s_upc%d" % (name, j), cat, o)
             cur = o

@@ -16,6 +16,14 @@ def test_mfma_kernels_are_run_to_run_deterministic():
     assert r.returncode == 0 and "TOTAL differing launches: 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_kernel_fuzz_random_shapes():
+    """tools/fuzz_kernels.py: ~230 random shapes (1-pixel images, ragged tiles, odd channel counts, channel-slice views, 1-3 samples) over the conv
+    families -- the register-staged split / fp16 / x2 / x4 / wide-1x1 kernels against the CPU double, the LDS-DMA family over h2 tensors (conv_h2x, a
+    conv_chain of random length bit-identical to its launches, conv_up2_h2t, conv_up4_h2t) against fp64 convs of the same 22-bit inputs."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_kernels.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "mismatches: 0" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("scale,lr_size,overlap,rounds,batch", [(4, 160, None, 100, 2), (4, 160, "0", 40, 2), (8, 96, None, 100, 2), (4, 160, None, 30, 8)])
 def test_engine_is_reproducible_run_to_run(scale, lr_size, overlap, rounds, batch, monkeypatch):
     """The fault class that isolated kernel stress does not see (round 3: the 8-wave coupling_head wrote a wrong half row once in

@@ -115,7 +115,7 @@ class BfsrLinfMlpArgs(C.Structure):
         ("dy_neg", C.c_float), ("dy_pos", C.c_float), ("dx_neg", C.c_float), ("dx_pos", C.c_float),
         ("clamp_lo", C.c_float), ("clamp_hi", C.c_float),
         ("cy0", C.c_float), ("cy1", C.c_float), ("cx0", C.c_float), ("cx1", C.c_float),
-        ("out_fmt", C.c_int), ("acc_scale", C.c_float * 4), ("flag", C.c_void_p),
+        ("out_fmt", C.c_int), ("acc_scale", C.c_float * 4), ("flag", C.c_void_p), ("cf_fmt", C.c_int),
     ]
 
 
@@ -244,7 +244,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.bfsr_abi_version() != 3:
+    if lib.bfsr_abi_version() != 4:
         raise RuntimeError("bfsr_amd: ABI version mismatch")
     _lib = lib
     return lib

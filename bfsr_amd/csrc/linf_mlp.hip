@@ -178,6 +178,19 @@ __global__ __launch_bounds__(NW * 64, X3 == 0 ? 4 : 2) void linf_mlp_kernel(Bfsr
     auto gen_load = [&](int k, int c0, Gather& g) {
         const int ofs = k == 0 ? off[0] : (k == 1 ? off[1] : (k == 2 ? off[2] : off[3]));
         const float* cfp = cfb + ofs;
+        if (a.cf_fmt == 1) {
+            // cf as an h2 tensor [512/8][hi, lo][h*w][8] fp16: the 8 channels of a block are ONE 16-byte word per plane -- 8 loads instead of 32
+            // (the raw words travel in the Gather's float slots: [0..3] = hi plane, [4..7] = lo plane; decoded in gen_finish)
+            const unsigned short* cfh = reinterpret_cast<const unsigned short*>(a.cf) + (long long)b * a.cf_bs;
+            auto ld = [&](int oct, float (&dst)[8]) {
+                const unsigned short* p0 = cfh + ((long long)(oct * 2) * hw + ofs) * 8;
+                const float4 vh = *reinterpret_cast<const float4*>(p0), vl = *reinterpret_cast<const float4*>(p0 + hw * 8);
+                dst[0] = vh.x; dst[1] = vh.y; dst[2] = vh.z; dst[3] = vh.w; dst[4] = vl.x; dst[5] = vl.y; dst[6] = vl.z; dst[7] = vl.w;
+            };
+            const int o = c0 >> 3;
+            ld(o, g.co0); ld(HID / 16 + o, g.co1); ld(HID / 8 + o, g.f0); ld(HID / 8 + HID / 16 + o, g.f1);
+            return;
+        }
         if (BFSR_MLP_ABL & 2) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { g.co0[e] = 0.5f + e; g.co1[e] = 0.25f * e; g.f0[e] = 0.1f * e + k; g.f1[e] = 0.3f + c0; }
@@ -192,11 +205,24 @@ __global__ __launch_bounds__(NW * 64, X3 == 0 ? 4 : 2) void linf_mlp_kernel(Bfsr
             g.f0[e] = cfp[(long long)(HID + c) * hw]; g.f1[e] = cfp[(long long)(HID + HID / 2 + c) * hw];
         }
     };
-    auto gen_finish = [&](int k, int c0, const Gather& g, unsigned char* dst) {
+    auto gen_finish = [&](int k, int c0, const Gather& g_, unsigned char* dst) {
         const float ry = k == 0 ? rel_y[0] : (k == 1 ? rel_y[1] : (k == 2 ? rel_y[2] : rel_y[3]));
         const float rx = k == 0 ? rel_x[0] : (k == 1 ? rel_x[1] : (k == 2 ? rel_x[2] : rel_x[3]));
         const float wgt = k == 0 ? wk[0] : (k == 1 ? wk[1] : (k == 2 ? wk[2] : wk[3]));
         float vc[8], vs[8];
+        Gather d;
+        if (a.cf_fmt == 1) {
+            auto dec = [&](const float (&raw)[8], float (&out)[8]) {
+                const f16x8 hv = __builtin_bit_cast(f16x8, make_float4(raw[0], raw[1], raw[2], raw[3]));
+                const f16x8 lv = __builtin_bit_cast(f16x8, make_float4(raw[4], raw[5], raw[6], raw[7]));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) out[e] = (float)hv[e] + (float)lv[e];
+            };
+            dec(g_.co0, d.co0); dec(g_.co1, d.co1); dec(g_.f0, d.f0); dec(g_.f1, d.f1);
+        } else {
+            d = g_;
+        }
+        const Gather& g = d;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = c0 + e;
@@ -493,6 +519,8 @@ extern "C" int bfsr_linf_mlp(const BfsrLinfMlpArgs* a, int x3, void* stream)
     if (a->out_fmt != 0 && a->out_fmt != 1) return -1;
     if (a->out_fmt == 1 && ((a->Cout & 3) || (reinterpret_cast<unsigned long long>(a->out) & 15) || (a->out_bs & 3) ||
                             (reinterpret_cast<unsigned long long>(a->bias) & 15))) return -1;
+    if (a->cf_fmt != 0 && a->cf_fmt != 1) return -1;
+    if (a->cf_fmt == 1 && ((reinterpret_cast<unsigned long long>(a->cf) & 15) || (a->cf_bs & 7))) return -1;       // 16-byte gathers
     BfsrLinfMlpArgs c = *a;
     if (x3 == 2) {
         for (int i = 0; i < 4; ++i) if (!(c.acc_scale[i] > 0.f)) return -1;

@@ -119,15 +119,21 @@ class LINFEngine(object):
         ops, ws, HD = self.ops, self.ws, self.hidden
         B, _, h, w = feat.shape
         _, qh, qw, _ = coord.shape
-        cf = ws.get("cf", B, 2 * HD, h, w)
+        h2cf = self.fused_mlp and self.precision == "fp16" and os.environ.get("BFSR_CF", "h2") == "h2"
+        cf = None
         if (h2_mode(ops, self.precision == "fp16") is not None and self.cf.mode in ("f16", "x3") and os.environ.get("BFSR_CF", "h2") != "reg"
                 and ((h + 15) // 16) * ((w + 31) // 32) >= 32):
             # round 5: on the LDS-DMA kernel of the contraction mode over an h2 copy of feat (conv_h2s: 2.4x conv_f16's rate)
             fh = self._hb("feat_h2", "h2", B, self.nf, h, w)
             ops.h2_pack(feat, fh)
-            self.cf.run_h2(ops, fh, cf)
+            if h2cf:
+                # the fused MLP gathers coef|freq per query point: from an h2 tensor the 8 channels of a block are one 16-byte word per
+                # plane instead of eight 4-byte gathers (profiles/r05_mlp_ablation.txt: the gathers were 6.9 of its 19.5 ms)
+                cf = self.cf.run_h2(ops, fh, self._hb("cf_h2", "h2", B, 2 * HD, h, w), lo=True)
+            else:
+                cf = self.cf.run_h2(ops, fh, ws.get("cf", B, 2 * HD, h, w))
         else:
-            self.cf.run(ops, feat, cf)
+            cf = self.cf.run(ops, feat, ws.get("cf", B, 2 * HD, h, w))
         if self.precision != "fp16" and hasattr(ops, "check_channels"):
             ops.check_channels(cf)                      # the fused MLP splits coef * cos / sin features into fp16 pairs
         if self.fused_mlp:

@@ -1072,7 +1072,11 @@ class HipOps(object):
                 a.acc_scale[i] = 1.0 / scales[i]
             a.flag = self.range_flag.data_ptr()
         a.out_fmt = fmt
-        a.cf, a.cf_bs, c2, h, w = _view(cf, "linf_mlp.cf")
+        if cf.dtype == torch.float16:                                    # h2 tensor (hi + lo planes): 16-byte gathers
+            a.cf, a.cf_bs, c2, h, w = self._h2view(cf, "linf_mlp.cf")
+            a.cf_fmt = 1
+        else:
+            a.cf, a.cf_bs, c2, h, w = _view(cf, "linf_mlp.cf")
         a.out, a.out_bs, co, qh, qw = _view(out, "linf_mlp.out")
         assert c2 == 2 * hidden and co == Cout and tuple(coord.shape) == (cf.shape[0], qh, qw, 2)
         assert coord.is_contiguous() and cell.is_contiguous() and phase.is_contiguous()

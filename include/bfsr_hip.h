@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define BFSR_ABI_VERSION 3      /* 2 (round 4): BfsrConvArgs / BfsrConvX3Args grew y_fmt + flag, coupling head / tail structs redefined, bfsr_conv2d_up2_h2t, bfsr_h2_pack_s2d, bfsr_ssim_sum_w added, the step / up2_h2x entry points removed */
+#define BFSR_ABI_VERSION 4      /* 4 (round 5, late): BfsrLinfMlpArgs.cf_fmt appended; bfsr_conv2d_up4_h2t and its pack functions added.  3 (round 5): BfsrChainConv + the chain entry points, bfsr_channel_range_*, BfsrLinfMlpArgs.flag.  2 (round 4): BfsrConvArgs / BfsrConvX3Args grew y_fmt + flag, coupling head / tail structs redefined, bfsr_conv2d_up2_h2t, bfsr_h2_pack_s2d, bfsr_ssim_sum_w added, the step / up2_h2x entry points removed */
 
 enum { BFSR_ACT_NONE = 0, BFSR_ACT_RELU = 1, BFSR_ACT_LRELU = 2 };
 
@@ -426,6 +426,9 @@ typedef struct BfsrLinfMlpArgs {
                                     * instructions, full 64-byte sectors); read by bfsr_linf_flow with ai_fmt = 1 */
     float acc_scale[4];            /* x3 == 2 only: 1 / (the power of two layer i's weights were packed with, bfsr_pack_linf_mlp_f16x2) */
     unsigned* flag;                /* x3 == 2 only, optional device word: bit 0 is set when a feature or hidden activation handed to the fp16 split is >= 65504 (ABI 3) */
+    int cf_fmt;                    /* (ABI 4) 0: cf = fp32 [B,2*hidden,h,w], cf_bs in floats.  1: cf = h2 tensor [B][2*hidden/8][hi, lo][h][w][8] fp16 (what
+                                    * bfsr_conv3x3_h2s / _h2x write with y_fmt = 1), cf_bs in fp16 elements: the 8 channels of a block are one 16-byte
+                                    * gather per plane instead of eight 4-byte ones (value = hi + lo: 22 bits) */
 } BfsrLinfMlpArgs;
 /* x3: 0 = operands rounded to fp16 (LINF precision='fp16'); 1 = exact three-term bf16 split, six products; 2 = two-term fp16 split of
  * both operands, three products (fp32-class accuracy at half the matrix instructions of 1; weights from bfsr_pack_linf_mlp_f16x2) */

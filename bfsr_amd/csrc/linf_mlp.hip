@@ -113,7 +113,7 @@ __device__ __forceinline__ void encode8(const float (&v)[8], typename Mode<X3>::
 }
 
 template <int X3>
-__global__ __launch_bounds__(NW * 64, X3 == 0 ? 4 : 2) void linf_mlp_kernel(BfsrLinfMlpArgs a, int tiles_per_image)
+__global__ __launch_bounds__(NW * 64, X3 == 1 ? 2 : 4) void linf_mlp_kernel(BfsrLinfMlpArgs a, int tiles_per_image)
 {
     typedef Mode<X3> MD;
     typedef typename MD::frag frag;

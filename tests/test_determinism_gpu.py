@@ -46,6 +46,9 @@ def test_engine_is_reproducible_run_to_run(scale, lr_size, overlap, rounds, batc
     lr1, lr_up1 = lr[1:2].clone(), lr_up[1:2].clone()
     ref2 = ref1 = rt0 = None
     for it in range(rounds):
+        if it % 4 == 0:
+            lr.add_(0.0)                   # same values, new tensor version: the conditioning (RRDB trunk -- the fused conv_chain launch at B = 8 --,
+            lr1.add_(0.0)                  # taps kernels, hoists) is recomputed instead of served from the engine's cache
         ep = [e.clone() for e in eng.encode(lr_up, lr)]
         rt = eng.decode(lr, epses=[e.clone() for e in ep]).clone()
         ep1 = [e.clone() for e in eng.encode(lr_up1, lr1)]
@@ -96,14 +99,20 @@ def test_soak_coupling_pair_inside_the_engine_sequence():
     from bfsr_amd.ops import HipOps, MODE_BILINEAR
     from test_srflow_gpu import build
     rounds = int(os.environ["BFSR_SOAK"])
+    # BFSR_SOAK_CFG="scale,batch,lr" soaks another shape, e.g. "8,8,96": the 8x model (conv_up4_h2t, level-1 pair at 384^2) at a batch where the
+    # fused RRDB launch (conv_chain), the level-3 lanes and several items per persistent workgroup are active
+    scale, batch, size = (int(v) for v in os.environ.get("BFSR_SOAK_CFG", "4,2,160").split(","))
     hip = HipOps("cuda:0")
-    m, prior, opt, sd, psd = build(hip, 4)
+    m, prior, opt, sd, psd = build(hip, scale)
     eng = m.netG.module.engine()
-    lr = hip.to_device(synth.smooth_lr_batch(21, 2, 160, 160))
-    lr_up = hip.resize(lr, hip.empty(2, 3, 640, 640), MODE_BILINEAR, 0.25, 0.25)
+    lr = hip.to_device(synth.smooth_lr_batch(21, batch, size, size))
+    lr_up = hip.resize(lr, hip.empty(batch, 3, size * scale, size * scale), MODE_BILINEAR, 1.0 / scale, 1.0 / scale)
     ref_ep = ref_rt = None
     bad = 0
+    recond = int(os.environ.get("BFSR_SOAK_RECOND", "0"))       # N > 0: recompute the conditioning (RRDB / conv_chain, taps kernels, hoists) every N-th round
     for it in range(rounds):
+        if recond and it % recond == 0:
+            lr.add_(0.0)
         ep = eng.encode(lr_up, lr)
         rt = eng.decode(lr, epses=ep)
         if ref_ep is None:
@@ -114,7 +123,7 @@ def test_soak_coupling_pair_inside_the_engine_sequence():
             bad += 1
             print("round %d differs from round 0" % it, flush=True)
     n_pair = sum(1 for ly in eng.layers if ly.type == "step" and ly.coupled and getattr(eng.steps[ly.index], "fused", False))
-    print("soak: %d rounds, %d fused coupled steps per direction -> %d head and %d tail launches; %d rounds differ" % (
-        rounds, n_pair, 2 * n_pair * rounds, 2 * n_pair * rounds, bad), flush=True)
+    print("soak (%dx model, B = %d, %d^2): %d rounds, %d fused coupled steps per direction -> %d head and %d tail launches; %d rounds differ" % (
+        scale, batch, size, rounds, n_pair, 2 * n_pair * rounds, 2 * n_pair * rounds, bad), flush=True)
     hip.check_range()
     assert bad == 0

@@ -729,7 +729,7 @@ class SRFlowEngine(object):
         hid, pre_aff, h_ft, Cz = self._hoist_buffers(level, hz, ft, B)
         pre_h2 = None
         # quad-major hand-over to the coupling pair: pre_aff as a whole (one batched conv writes it) when every step of the level is
-        # fused and its producers can (the x4 taps kernel cannot); h_ft per step (each step's Conv2dZeros writes its own slice) when the
+        # fused and its producers can (the register-staged x4 taps kernel cannot, conv_up4_h2t can); h_ft per step (each step's Conv2dZeros writes its own slice) when the
         # step's h_ft is only ever read by coupling_tail -- i.e. not by flow_pointwise as the first step of an encode pass
         pq = int(quads and hz.get("pre_q4", False))
         hq = {i: int(quads and i in hz.get("hft_q4", ())) for i in hz["idxs"]}

@@ -114,7 +114,7 @@ def launch_flop(k):
     if f == "conv_up2_h2t":                                              # Ct taps channels: 2x2 source taps per output pixel; Ck key channels: 9 taps
         _, ct, ck, Cout, b_, hh, ww = k
         return 2.0 * (ct * 4 + ck * 9) * Cout * b_ * hh * ww
-    if f == "conv_up4_h2t":                                              # 25 pre-summed matrices per 16 output pixels
+    if f == "conv_up4_h2t":                                              # 25 pre-summed matrices per 16 output pixels (key[2] = 9: compact output)
         _, ct, _, Cout, b_, hh, ww = k
         return 2.0 * ct * 25.0 / 16.0 * Cout * b_ * hh * ww
     if f in ("conv_up4_x3", "conv_up4_f2"):                             # 25 pre-summed matrices per 16 output pixels

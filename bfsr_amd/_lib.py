@@ -41,6 +41,7 @@ class BfsrConvX3Args(C.Structure):
         ("res1", C.c_void_p), ("res1_bs", C.c_longlong), ("alpha1", C.c_float),
         ("res2", C.c_void_p), ("res2_bs", C.c_longlong), ("alpha2", C.c_float),
         ("tune", C.c_int), ("acc_scale", C.c_float), ("mtile", C.c_int), ("flag", C.c_void_p),
+        ("up4", C.c_void_p), ("up4_bs", C.c_longlong),
     ]
 
 
@@ -244,7 +245,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.bfsr_abi_version() != 4:
+    if lib.bfsr_abi_version() != 5:
         raise RuntimeError("bfsr_amd: ABI version mismatch")
     _lib = lib
     return lib

@@ -746,6 +746,30 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
             const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(p.y) + (long long)cur.b * p.y_bs, 0,
                                                                                 (unsigned)((long long)p.Cout * HW * 4), 0x00020000);
             if (p.y_fmt == 2) {                                          // fp32 quad-major [Cout/4][H][W][4]: the octet = two 16-byte stores
+                if (p.up4) {
+                    // + the COMPACT result of bfsr_conv2d_up4_h2t (y_fmt 3): per source pixel (y/4, x/4) and channel quad the nine phase-class values
+                    // [Cout/4][H/4][W/4][9][4] -- the x4 level's taps share, added here instead of being read back as a full-resolution pre_add
+                    const int hs = H >> 2, wsrc = W >> 2;
+                    const unsigned cq = (unsigned)(hs * wsrc) * 144u;    // bytes of one channel quad's compact image
+                    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.up4) + (long long)cur.b * p.up4_bs, 0,
+                                                                                        (unsigned)(p.Cout >> 2) * cq, 0x00020000);
+                    const int pxc = gx & 3, cxc = pxc == 0 ? 0 : (pxc == 3 ? 2 : 1);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int gy = cur.y0 + 2 * wave + j;
+                        const int pyc = gy & 3, cyc = pyc == 0 ? 0 : (pyc == 3 ? 2 : 1);
+                        const bool ok = gy < H && gx < W;
+                        const unsigned vu = ok ? (unsigned)lh * 2u * cq + (unsigned)((gy >> 2) * wsrc + (gx >> 2)) * 144u + (unsigned)(cyc * 3 + cxc) * 16u : OOB;
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const unsigned so = (unsigned)((oct0 + q * 2) * 2) * cq;
+                            const float4 r0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ru, vu, so, 0));
+                            const float4 r1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ru, vu, so + cq, 0));
+                            o[j][q][0] += r0.x; o[j][q][1] += r0.y; o[j][q][2] += r0.z; o[j][q][3] += r0.w;
+                            o[j][q][4] += r1.x; o[j][q][5] += r1.y; o[j][q][6] += r1.z; o[j][q][7] += r1.w;
+                        }
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -915,6 +939,8 @@ extern "C" int bfsr_conv3x3_h2x(const BfsrConvX3Args* a, void* stream)
     if (!(a->acc_scale > 0.f)) return -1;
     if ((a->y_fmt != 0 || a->res1 || a->res2) && (a->Cout & 7)) return -1;
     if (a->y_fmt == 2 && ((reinterpret_cast<unsigned long long>(a->y) & 15) || (a->y_bs & 3))) return -1;
+    if (a->up4 && (a->y_fmt != 2 || (a->H & 3) || (a->W & 3) || (reinterpret_cast<unsigned long long>(a->up4) & 15) || (a->up4_bs & 3) ||
+                   (long long)(a->Cout / 4) * (a->H / 4) * (a->W / 4) * 144 >= (1LL << 31))) return -1;
     if ((long long)(a->Cin / 8) * 2 * a->H * a->W * 16 >= (1LL << 31)) return -1;      // 32-bit byte offsets inside one batch item
     if ((long long)((a->Cout + 7) / 8) * 2 * a->H * a->W * 8 >= (1LL << 31)) return -1;  // 32-bit element offsets in the epilogue
     if ((reinterpret_cast<unsigned long long>(a->x) & 15) || (a->x_bs & 7)) return -1;

@@ -226,6 +226,23 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_up4_h2t_kernel(BfsrUp2H2Args
 #endif
         const int sx = cur.x0 + lx, sy = cur.y0 + wave;
         const bool ok = sy < h && sx < w;
+        if (p.y_fmt == 3) {
+            // COMPACT output [Cout/4][h][w][9 classes][4]: the nine class values of this lane's source pixel, 144 contiguous bytes per channel quad;
+            // bfsr_conv3x3_h2x (`up4`) expands them while it writes the full-resolution tensor.  No pre_add in this form.
+            const unsigned cqb = (unsigned)(h * w) * 144u;               // bytes of one channel quad's compact image
+            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.y + (long long)cur.b * p.y_bs + (long long)cur.cg * 8 * (cqb >> 2), 0, 8u * cqb, 0x00020000);
+            const unsigned vc = ok ? (unsigned)lh * cqb + (unsigned)(sy * w + sx) * 144u : OOB;
+#pragma unroll
+            for (int c = 0; c < 9; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float4 o;
+                    o.x = acc[c][4 * i + 0] * p.acc_scale; o.y = acc[c][4 * i + 1] * p.acc_scale;
+                    o.z = acc[c][4 * i + 2] * p.acc_scale; o.w = acc[c][4 * i + 3] * p.acc_scale;
+                    bfsr::store_b128(rc, __builtin_bit_cast(u32x4, o), vc + 16u * c, (unsigned)(2 * i) * cqb);
+                }
+            continue;
+        }
         // eight rounds (output row phase py, channel-quad pair) of 8 accesses (4 column phases x 2 quads); the pre_add loads of round n+1 are
         // issued before round n's arithmetic and stores (the fragment registers are free here)
         unsigned vo[4];
@@ -312,13 +329,14 @@ extern "C" int bfsr_conv2d_up4_h2t(const BfsrUp2H2Args* a, void* stream)
 {
     if (!a || !a->x || !a->w || !a->y || a->B <= 0 || a->h <= 0 || a->w_ <= 0 || a->Cin <= 0 || a->Cin % 16 || a->Cout <= 0 || a->Cout % 32) return -1;
     if (a->Ckey != 0) return -1;                                                                // channels at output resolution enter through pre_add
-    if (a->y_fmt != 1) return -1;                                                               // quad-major fp32 only
+    if (a->y_fmt != 1 && a->y_fmt != 3) return -1;                                              // quad-major fp32, or the compact class form
+    if (a->y_fmt == 3 && (a->pre_add || 8LL * a->h * a->w_ * 144 >= (1LL << 31))) return -1;   // (8 channel quads of the compact image of one sample)
     // 16-byte accesses on y / pre_add (quad-major) and LDS-DMA on x: misaligned views are refused, not faulted on
     if ((reinterpret_cast<unsigned long long>(a->x) & 15) || (a->x_bs & 7)) return -1;
     if ((reinterpret_cast<unsigned long long>(a->y) & 15) || (a->y_bs & 3)) return -1;
     if (a->pre_add && ((reinterpret_cast<unsigned long long>(a->pre_add) & 15) || (a->pre_add_bs & 3))) return -1;
     if ((long long)(a->Cin / 8) * 2 * a->h * a->w_ * 16 >= (1LL << 31)) return -1;              // 32-bit buffer offsets (source, per sample)
-    if (8LL * 16 * a->h * a->w_ * 16 >= (1LL << 31)) return -1;                                  // (8 output channel quads of one sample)
+    if (a->y_fmt == 1 && 8LL * 16 * a->h * a->w_ * 16 >= (1LL << 31)) return -1;                 // (8 output channel quads of one sample)
     if ((long long)(a->Cout / 32) * (a->Cin / 16) * W_ST >= (1LL << 32)) return -1;              // (the packed weights)
     const int tiles_x = (a->w_ + 31) / 32, tiles_y = (a->h + TR - 1) / TR, groups = a->Cout / 32;
     const long long nitems = (long long)a->B * tiles_x * tiles_y * groups;

@@ -441,12 +441,12 @@ class HipOps(object):
         _lib.check(self._launch(("x3_unpack",) + tuple(out.shape), lambda: self.lib.bfsr_x3_unpack(xp, xbs, yp, ybs, x.shape[0], Cc, H, W, self._stream())), "x3_unpack")
         return out
 
-    def conv_x3s(self, x, pw, out, epi=None, act=ACT_NONE, slope=0.2, res1=None, alpha1=1.0, res2=None, alpha2=1.0, tune=0, y_fmt=0):
+    def conv_x3s(self, x, pw, out, epi=None, act=ACT_NONE, slope=0.2, res1=None, alpha1=1.0, res2=None, alpha2=1.0, tune=0, y_fmt=0, up4=None):
         """3x3 conv over an x3 tensor `x` (weights: pack_conv_x3(w, 1)); `out` is an x3 view or an fp32 NCHW view; residuals
         are x3 views.  Same epilogue contract as conv().  h2 tensors (split == "f16x2") go to conv_h2x: same contract."""
         if x.dtype == torch.float16:
-            return self.conv_h2x(x, pw, out, epi=epi, act=act, slope=slope, res1=res1, alpha1=alpha1, res2=res2, alpha2=alpha2, tune=tune, y_fmt=y_fmt)
-        if y_fmt:
+            return self.conv_h2x(x, pw, out, epi=epi, act=act, slope=slope, res1=res1, alpha1=alpha1, res2=res2, alpha2=alpha2, tune=tune, y_fmt=y_fmt, up4=up4)
+        if y_fmt or up4 is not None:
             raise ValueError("conv_x3s: the quad-major output exists on the fp16-split kernels only")
         a = _lib.BfsrConvX3Args()
         a.x, a.x_bs, Cin, H, W = self._x3view(x, "conv_x3s.x")
@@ -524,7 +524,7 @@ class HipOps(object):
         _lib.check(self.lib.bfsr_pack_conv_weight_h2x(w.data_ptr(), Cout, Cin, mt, scale, packed.data_ptr()), "pack_h2x")
         return packed.to(self.device), scale, mt
 
-    def conv_h2x(self, x, pw, out, epi=None, act=ACT_NONE, slope=0.2, res1=None, alpha1=1.0, res2=None, alpha2=1.0, tune=0, y_fmt=0):
+    def conv_h2x(self, x, pw, out, epi=None, act=ACT_NONE, slope=0.2, res1=None, alpha1=1.0, res2=None, alpha2=1.0, tune=0, y_fmt=0, up4=None):
         """3x3 conv over an h2 tensor `x` at fp32-class accuracy (both planes x two-term fp16 weights, three products; conv_h2s.hip,
         conv3x3_h2x_kernel).  `pw` = pack_conv_x3(w, ...) (the fp16 packing is derived lazily from its kept OIHW copy); `out` is an
         h2 view (both planes) or an fp32 NCHW view; residuals are h2 views.  Same epilogue contract as conv()."""
@@ -550,6 +550,12 @@ class HipOps(object):
                 setattr(a, name, pp)
                 setattr(a, name + "_bs", bs)
                 setattr(a, "alpha" + name[-1], al)
+        if up4 is not None:                          # compact result of conv_up4_h2t(compact=True) at H/4 x W/4, added after the epilogue (quad-major output only)
+            if a.y_fmt != 2 or up4.dtype != torch.float32 or tuple(up4.shape) != (out.shape[0], Cout * 9, H // 4, W // 4) or H % 4 or W % 4:
+                raise ValueError("conv_h2x: up4 needs the quad-major output and a compact tensor [B, 9*Cout, H/4, W/4]")
+            a.up4, a.up4_bs = up4.data_ptr(), (up4.stride(0) if up4.shape[0] > 1 else up4[0].numel())
+            if not up4[0].is_contiguous():
+                raise ValueError("conv_h2x: up4 must be contiguous per sample")
         key = ("conv_h2x", Cin, Cout, out.shape[0], H, W, a.y_fmt)
         _lib.check(self._launch(key, lambda: self.lib.bfsr_conv3x3_h2x(C.byref(a), self._stream())), "conv3x3_h2x")
         return out
@@ -667,13 +673,24 @@ class HipOps(object):
         _lib.check(self.lib.bfsr_pack_conv_up4_h2t(w.data_ptr(), Cout, Ct, scale, packed.data_ptr()), "pack_conv_up4_h2t")
         return packed.to(self.device), 1.0 / scale, Cout, Ct
 
-    def conv_up4_h2t(self, x, packed, out, pre_add=None):
+    def conv_up4_h2t(self, x, packed, out, pre_add=None, compact=False):
         """conv3x3(nearest_up4(taps)) + pre_add at source resolution (conv_up4_h2t.hip: phase-decomposed, two-term fp16 split, three products).
-        `x`: h2 tensor [B,Ct/8,2,h,w,8]; `out` and `pre_add` (may be `out`) are fp32 buffers of shape [B,Cout,4h,4w] holding the QUAD-MAJOR layout."""
+        `x`: h2 tensor [B,Ct/8,2,h,w,8]; `out` and `pre_add` (may be `out`) are fp32 buffers of shape [B,Cout,4h,4w] holding the QUAD-MAJOR layout.
+        compact=True: `out` is a [B, 9*Cout, h, w] fp32 buffer that receives the nine phase-class values per source pixel and channel quad
+        ([Cout/4][h][w][9][4]; no pre_add) -- what conv_h2x(up4=...) adds to the conv over the channels at output resolution."""
         wts, acc_scale, Cout, Ct = packed
         a = _lib.BfsrUp2H2Args()
         a.x, a.x_bs, cin, h, w = self._h2view(x, "conv_up4_h2t.x")
         a.y, a.y_bs, co, H, W = _view(out, "conv_up4_h2t.out")
+        if compact:
+            if pre_add is not None or (cin, co, H, W) != (Ct, 9 * Cout, h, w) or x.shape[0] != out.shape[0] or not out[0].is_contiguous():
+                raise ValueError("conv_up4_h2t(compact): out must be a contiguous [B, 9*Cout, h, w] buffer and there is no pre_add")
+            a.Cin, a.Ckey, a.Cout, a.y_fmt = cin, 0, Cout, 3
+            a.w, a.acc_scale = wts.data_ptr(), acc_scale
+            a.B, a.h, a.w_ = out.shape[0], h, w
+            key = ("conv_up4_h2t", Ct, 9, Cout, out.shape[0], 4 * h, 4 * w)
+            _lib.check(self._launch(key, lambda: self.lib.bfsr_conv2d_up4_h2t(C.byref(a), self._stream())), "conv2d_up4_h2t")
+            return out
         if (cin, co, 4 * h, 4 * w) != (Ct, Cout, H, W) or x.shape[0] != out.shape[0]:
             raise ValueError("conv_up4_h2t: shape mismatch x%s out%s weight(Cout=%d,Ct=%d)" % (tuple(x.shape), tuple(out.shape), Cout, Ct))
         a.Cin, a.Ckey, a.Cout, a.y_fmt = cin, 0, Cout, 1

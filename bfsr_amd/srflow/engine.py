@@ -693,6 +693,9 @@ class SRFlowEngine(object):
             h2 = self._hid.get("ffh%d" % level)
             if h2 is None or tuple(h2.shape) != (B, 8, 2, hl, wl, 8):
                 self._hid["ffh%d" % level] = self.ops.h2_empty(B, 64, hl, wl)
+        if hz.get("h4t") is not None and os.environ.get("BFSR_UP4C", "0") == "1":      # compact taps result of the x4 level (see _hoist_level)
+            tp = ft[self._lr_level()]
+            ws.get("up4c%d" % level, B, 9 * K * 64, tp.shape[2], tp.shape[3])
         if hz.get("up2") and (hz.get("h2t") is not None or hz.get("h4t") is not None):
             taps = ft[self._lr_level()][:, 64:]
             key = (B, taps.shape[1] + (4 * 64 if hz.get("h2t") is not None else 0)) + tuple(taps.shape[2:])
@@ -742,10 +745,20 @@ class SRFlowEngine(object):
             taps = ft[self._lr_level()][:, 64:]
             taps_h2 = ops.h2_pack(taps, self._taps_h2[level][1])
             f3 = ops.x3_pack(f, self._ftx3[level][1])
-            ops.conv_x3s(f3, hz["ft0_key"], hid, y_fmt=1)
-            ops.conv_up4_h2t(taps_h2, h4t[0], hid, pre_add=hid)
-            ops.conv_x3s(f3, hz["aff0_key"], pre_aff, y_fmt=1)
-            ops.conv_up4_h2t(taps_h2, h4t[1], pre_aff, pre_add=pre_aff)
+            if os.environ.get("BFSR_UP4C", "0") == "1":
+                # OPTIONAL (off: measured equal within noise, tools/exp/up4c_check.py: 18.1 vs 18.5 ms per tensor at 16 x 96^2, and it needs a 21.7 GB
+                # buffer at config 4): the taps kernel writes its nine class values per source pixel (9/16 of the full-resolution bytes, no read-back)
+                # and the key conv expands and adds them while it writes the full-resolution tensor; bit-identical to the pre_add form
+                comp = self.ws.get("up4c%d" % level, B, 9 * hid.shape[1], taps.shape[2], taps.shape[3])
+                ops.conv_up4_h2t(taps_h2, h4t[0], comp, compact=True)
+                ops.conv_x3s(f3, hz["ft0_key"], hid, y_fmt=1, up4=comp)
+                ops.conv_up4_h2t(taps_h2, h4t[1], comp, compact=True)
+                ops.conv_x3s(f3, hz["aff0_key"], pre_aff, y_fmt=1, up4=comp)
+            else:
+                ops.conv_x3s(f3, hz["ft0_key"], hid, y_fmt=1)
+                ops.conv_up4_h2t(taps_h2, h4t[0], hid, pre_add=hid)
+                ops.conv_x3s(f3, hz["aff0_key"], pre_aff, y_fmt=1)
+                ops.conv_up4_h2t(taps_h2, h4t[1], pre_aff, pre_add=pre_aff)
         elif hz["up2"]:
             taps = ft[self._lr_level()][:, 64:]
             if hz["x3"]:

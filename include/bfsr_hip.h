@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define BFSR_ABI_VERSION 4      /* 4 (round 5, late): BfsrLinfMlpArgs.cf_fmt appended; bfsr_conv2d_up4_h2t and its pack functions added.  3 (round 5): BfsrChainConv + the chain entry points, bfsr_channel_range_*, BfsrLinfMlpArgs.flag.  2 (round 4): BfsrConvArgs / BfsrConvX3Args grew y_fmt + flag, coupling head / tail structs redefined, bfsr_conv2d_up2_h2t, bfsr_h2_pack_s2d, bfsr_ssim_sum_w added, the step / up2_h2x entry points removed */
+#define BFSR_ABI_VERSION 5      /* 5 (round 5, last): BfsrConvX3Args.up4 / up4_bs appended, bfsr_conv2d_up4_h2t y_fmt 3 (compact output).  4 (round 5, late): BfsrLinfMlpArgs.cf_fmt appended; bfsr_conv2d_up4_h2t and its pack functions added.  3 (round 5): BfsrChainConv + the chain entry points, bfsr_channel_range_*, BfsrLinfMlpArgs.flag.  2 (round 4): BfsrConvArgs / BfsrConvX3Args grew y_fmt + flag, coupling head / tail structs redefined, bfsr_conv2d_up2_h2t, bfsr_h2_pack_s2d, bfsr_ssim_sum_w added, the step / up2_h2x entry points removed */
 
 enum { BFSR_ACT_NONE = 0, BFSR_ACT_RELU = 1, BFSR_ACT_LRELU = 2 };
 
@@ -163,6 +163,10 @@ typedef struct BfsrConvX3Args {
     float acc_scale;                               /* bfsr_conv3x3_h2x only: 1 / (the power of two the weights were packed with) */
     int mtile;                                     /* bfsr_conv3x3_h2x only: 32-cout M tiles per workgroup the weights were packed for (0 or 1) */
     unsigned* flag;                                /* bfsr_conv3x3_h2x only, optional device word: bit 0 is set when a value written to an h2 output is >= 65504 */
+    const float* up4; long long up4_bs;            /* (ABI 5) bfsr_conv3x3_h2x with y_fmt 2 only, optional: the COMPACT output of bfsr_conv2d_up4_h2t (its y_fmt 3:
+                                                    * [B][Cout/4][H/4][W/4][9 phase classes][4] fp32, batch stride in floats), added to the result after the
+                                                    * epilogue -- the two convs of the x4 level (key channels at output resolution + nearest-x4 taps) meet here
+                                                    * instead of through a full-resolution pre_add round trip.  H and W must be multiples of 4. */
 } BfsrConvX3Args;
 int bfsr_conv3x3_x3s(const BfsrConvX3Args* a, void* stream);
 int bfsr_x3_pack(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int C, int H, int W, void* stream);
@@ -337,7 +341,9 @@ int bfsr_pack_conv_up2_h2t(const float* w_taps_oihw, const float* w_key_oihw, in
  * RRDBNet_arch.py:105-112 fea_up4 + SRFlowNet_arch.py:122-137): x = h2 tensor of the Ct tap channels at SOURCE resolution (Cin = Ct, Ckey must be 0:
  * channels at output resolution enter through pre_add); w = bfsr_pack_conv_up4_h2t(w_taps, Cout, Ct, scale) -- per axis the phases {0}, {1, 2}, {3}
  * of an output pixel see 2, 1, 2 source pixels: 25 pre-summed weight blocks per 16-channel chunk instead of 16 x 9 tap products;
- * y, pre_add: fp32 QUAD-MAJOR [B][Cout/4][4h][4w][4].  Item = 8 x 32 source pixels x 32 output channels x all nine phase classes. */
+ * y, pre_add: fp32 QUAD-MAJOR [B][Cout/4][4h][4w][4] (y_fmt 1).  y_fmt 3 (ABI 5): COMPACT output [B][Cout/4][h][w][9][4] fp32 -- the nine phase-class
+ * values per source pixel and channel quad (class = rc*3 + cc, rc / cc = 0, 1, 2 for output phases {0}, {1, 2}, {3}), no pre_add: 9/16 of the bytes, and the
+ * consumer (bfsr_conv3x3_h2x with `up4`) adds it while writing the full-resolution tensor.  Item = 8 x 32 source pixels x 32 output channels x all nine classes. */
 int bfsr_conv2d_up4_h2t(const BfsrUp2H2Args* a, void* stream);
 long long bfsr_conv_up4_h2t_packed_size(int Cout, int Ct);                             /* fp16 elements */
 int bfsr_pack_conv_up4_h2t(const float* w_taps_oihw, int Cout, int Ct, float scale, unsigned short* packed);

@@ -63,6 +63,34 @@ def test_engine_is_reproducible_run_to_run(scale, lr_size, overlap, rounds, batc
     hip.check_range()
 
 
+@pytest.mark.parametrize("scale,batch,size", [(8, 16, 96), (4, 8, 160)])
+def test_lp_pass_is_reproducible_run_to_run_with_every_overlap(scale, batch, size):
+    """The WHOLE LP pass (RRDB, encode, standardise, both prior branches, decode) four times on the same input, conditioning recomputed every time, every
+    intermediate latent and the image bit-identical -- at batches where all the stream overlaps are active at once (hoists and the prior's big branch on the
+    side stream, level-3 lanes, the fused RRDB launch).  Round 5 found the bilinear resize of the prior's branch 0 wrong in a few hundred elements per
+    pass here (8x model, B >= 16): its packed-fp32 instruction chains went wrong when their waves shared SIMDs with the MFMA waves of the 1x1-only
+    coupling_head on the other stream; the engine-level reproducibility tests above never run the prior and did not see it."""
+    import torch
+    from bfsr_amd import synth
+    from bfsr_amd.ops import HipOps
+    from bfsr_amd.srflow.test import lp_infer
+    from test_srflow_gpu import build
+    hip = HipOps("cuda:0")
+    m, prior, opt, sd, psd = build(hip, scale)
+    x = hip.to_device(synth.lr_batch(1, batch, size, size))
+    ref = None
+    for it in range(4):
+        x.add_(0.0)
+        out = lp_infer(m, prior, x, return_all=True)
+        cur = [out["sr"].clone(), out["sr_raw"].clone()] + [e.clone() for e in out["epses"]] + [e.clone() for e in out["epses_learned"]]
+        if ref is None:
+            ref = cur
+            continue
+        for i, (a, b) in enumerate(zip(cur, ref)):
+            assert torch.equal(a, b), "pass %d: tensor %d of (sr, sr_raw, epses..., epses_learned...) differs from pass 0 in %d elements" % (it, i, int((a != b).sum()))
+    assert hip.fallbacks == 0
+
+
 @pytest.mark.parametrize("precision,rounds", [("fp32", 25), ("fp16", 15)])
 def test_linf_pipeline_is_reproducible_run_to_run(precision, rounds):
     """The same guard for the LINF-LP path, in the fp32-accurate mode (conv_h2x encoder, fused MLP on the fp16 pair, flow) and on the fp16 MFMA

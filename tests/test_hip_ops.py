@@ -521,6 +521,19 @@ def test_conv_up4_h2t(hip, case):
     assert float(wide[:, :4].abs().max()) == 0.0 and float(wide[:, 4 + Cout:].abs().max()) == 0.0, "wrote outside its channel slice"
     hip.conv_up4_h2t(xh, pk, pq, pre_add=pq)                           # in place
     assert torch.equal(CPU.quads(pq.cpu(), inverse=True), got2), "conv_up4_h2t in place %s" % (case,)
+    # compact form (nine class values per source pixel) + the conv over the channels at output resolution that adds it (conv_h2x `up4`): bit-identical
+    # to that conv's quad-major result going through pre_add
+    if Cout % 32 == 0:
+        key = rnd(314, B, 32, 4 * h, 4 * w)
+        kh = hip.h2_pack(hip.to_device(key), hip.h2_empty(B, 32, 4 * h, 4 * w))
+        pk_key, epi = hip.pack_conv_x3(rnd(315, Cout, 32, 3, 3, scale=0.06), 1, lazy=True), hip.pack_epilogue(Cout, bias=rnd(316, Cout, scale=0.1))
+        via_pre = hip.conv_h2x(kh, pk_key, hip.empty(B, Cout, 4 * h, 4 * w), epi=epi, y_fmt=1)
+        hip.conv_up4_h2t(xh, pk, via_pre, pre_add=via_pre)
+        comp = hip.conv_up4_h2t(xh, pk, hip.empty(B, 9 * Cout, h, w).fill_(float("nan")), compact=True)
+        wide2 = hip.zeros(B, Cout + 8, 4 * h, 4 * w)
+        hip.conv_h2x(kh, pk_key, wide2[:, 4:4 + Cout], epi=epi, y_fmt=1, up4=comp)
+        assert torch.equal(wide2[:, 4:4 + Cout], via_pre), "compact + up4 differs from the pre_add path %s" % (case,)
+        assert float(wide2[:, :4].abs().max()) == 0.0 and float(wide2[:, 4 + Cout:].abs().max()) == 0.0
     # the register-staged x4 kernel it replaces (NCHW): same arithmetic class
     old = hip.conv_up4_x3(hip.to_device(x), hip.pack_conv_up4_x3(wt), hip.empty(B, Cout, 4 * h, 4 * w))
     assert float((old.cpu().double() - ref64).abs().max()) <= 2.5 * tol + 1e-7

@@ -58,9 +58,15 @@ __device__ __forceinline__ void split_unit(const float (&v)[8], typename Sp<PL>:
         float r = v[c];
 #pragma unroll
         for (int pl = 0; pl < PL; ++pl) {
-            const typename Sp<PL>::elt h = (typename Sp<PL>::elt)r;   // round to nearest; the residual below is exact
-            o[pl][c] = h;
-            r -= (float)h;
+            if constexpr (PL == 2) {                                  // fp16 pair: the rounded value pinned (launch_util.h, pin_f16)
+                const float hf = bfsr::pin_f16(r);
+                o[pl][c] = (typename Sp<PL>::elt)hf;
+                r -= hf;
+            } else {
+                const typename Sp<PL>::elt h = (typename Sp<PL>::elt)r;   // round to nearest; the residual below is exact
+                o[pl][c] = h;
+                r -= (float)h;
+            }
         }
     }
 }

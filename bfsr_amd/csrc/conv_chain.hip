@@ -78,8 +78,9 @@ constexpr int CHAIN_MAGIC = 0x43484e31;
 
 __device__ __forceinline__ void split2c(float v, _Float16& h, _Float16& l)
 {
-    h = (_Float16)v;
-    l = (_Float16)(v - (float)h);
+    const float hf = bfsr::pin_f16(v);
+    h = (_Float16)hf;
+    l = (_Float16)(v - hf);
 }
 
 __device__ __forceinline__ void wait_vmcnt_c(int n)

@@ -54,8 +54,9 @@ struct Item { int cg, b, x0, y0; };
 
 __device__ __forceinline__ void split2(float v, _Float16& h, _Float16& l)
 {
-    h = (_Float16)v;
-    l = (_Float16)(v - (float)h);
+    const float hf = bfsr::pin_f16(v);
+    h = (_Float16)hf;
+    l = (_Float16)(v - hf);
 }
 
 // `s_waitcnt vmcnt(n)` for a wave-uniform run-time n (the instruction takes an immediate); n = stages in flight x pieces per stage

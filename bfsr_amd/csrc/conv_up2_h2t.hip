@@ -365,8 +365,8 @@ __global__ void h2_pack_s2d_kernel(const float* __restrict__ x, long long x_bs, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float v = xb[(long long)j * 4 * hw];
-        const _Float16 hi = (_Float16)v;
-        h8[j] = hi; l8[j] = (_Float16)(v - (float)hi);
+        const float hf = bfsr::pin_f16(v);
+        h8[j] = (_Float16)hf; l8[j] = (_Float16)(v - hf);
         amax = fmaxf(amax, fabsf(v));
     }
     unsigned short* yb = y + (long long)b * y_bs + ((long long)oct * 2 * hw + pix) * 8;

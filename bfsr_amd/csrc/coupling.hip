@@ -43,8 +43,9 @@ constexpr unsigned OOB = 0x80000000u;
 
 __device__ __forceinline__ void split2(float v, _Float16& h, _Float16& l)
 {
-    h = (_Float16)v;
-    l = (_Float16)(v - (float)h);
+    const float hf = bfsr::pin_f16(v);
+    h = (_Float16)hf;
+    l = (_Float16)(v - hf);
 }
 
 // NO = ceil(Cz/8) z1 octets, NWV = waves (= tile rows) per workgroup.  NO = 0: no 3x3 stage at all -- hid = relu(AN2(W2 . relu(AN0(pre_aff)))),

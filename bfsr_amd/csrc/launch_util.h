@@ -60,4 +60,17 @@ __device__ __forceinline__ void store_b128(__amdgpu_buffer_rsrc_t rs, store_u32x
     __builtin_amdgcn_raw_buffer_store_b128(data, rs, lane_off + uniform_off, 0, 0);
 }
 
+
+// fp32 -> the fp32 value of its fp16 rounding, PINNED in a register: the hi term of the two-term fp16 split.  hipcc otherwise feels free to convert the same
+// value twice -- v_cvt_pk_f16_f32 for the stored hi plane, v_cvt_f16_f32 for the subtraction that forms the lo term -- and on gfx950 the two conversions do not
+// always return the same fp16, so hi + lo misses the value by an fp16 ulp (found in round 5: the fused LINF MLP went from 6e-7 to 3.7e-5 when a compiler flag
+// changed the instruction selection).  (_Float16)pin_f16(v) is exact, whichever conversion the compiler picks for it.
+__device__ __forceinline__ float pin_f16(float v)
+{
+    float hf = (float)(_Float16)v;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(hf));
+#endif
+    return hf;
+}
 }  // namespace bfsr

@@ -61,6 +61,8 @@ constexpr StepInfo step_info(int s) { return StepInfo{ax_cls(s % 5) * 3 + ax_cls
 constexpr int group_of(int s) { return s < 5 ? 0 : (s < 20 ? 1 : 2); }
 constexpr int group_start(int g) { return g == 0 ? 0 : (g == 1 ? 5 : (g == 2 ? 20 : NSTEP)); }
 
+// COMPACT (y_fmt 3) is a separate instantiation: as a run-time branch its 36 extra stores pushed the default kernel over its register budget (43 spills, 30 -> 40 ms)
+template <bool COMPACT>
 __global__ __launch_bounds__(NWV * 64, 1) void conv_up4_h2t_kernel(BfsrUp2H2Args p, int tiles_x, int tiles_y, int groups, int nitems)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_up4_h2t_kernel(BfsrUp2H2Args
 #endif
         const int sx = cur.x0 + lx, sy = cur.y0 + wave;
         const bool ok = sy < h && sx < w;
-        if (p.y_fmt == 3) {
+        if constexpr (COMPACT) {
             // COMPACT output [Cout/4][h][w][9 classes][4]: the nine class values of this lane's source pixel, 144 contiguous bytes per channel quad;
             // bfsr_conv3x3_h2x (`up4`) expands them while it writes the full-resolution tensor.  No pre_add in this form.
             const unsigned cqb = (unsigned)(h * w) * 144u;               // bytes of one channel quad's compact image
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_up4_h2t_kernel(BfsrUp2H2Args
     }
 }
 
-std::atomic<unsigned long long> g_lds_done{0};
+std::atomic<unsigned long long> g_lds_done{0}, g_lds_done_c{0};
 
 }  // namespace
 
@@ -341,10 +343,15 @@ extern "C" int bfsr_conv2d_up4_h2t(const BfsrUp2H2Args* a, void* stream)
     const int tiles_x = (a->w_ + 31) / 32, tiles_y = (a->h + TR - 1) / TR, groups = a->Cout / 32;
     const long long nitems = (long long)a->B * tiles_x * tiles_y * groups;
     if (nitems >= (1LL << 31)) return -1;
-    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_up4_h2t_kernel), LDS_BYTES, g_lds_done) != 0) return -2;
     const int cus = bfsr::cu_count();
     if (cus <= 0) return -2;
     const int grid = (int)(nitems < cus ? nitems : cus);
-    hipLaunchKernelGGL(conv_up4_h2t_kernel, dim3(grid), dim3(NWV * 64), LDS_BYTES, static_cast<hipStream_t>(stream), *a, tiles_x, tiles_y, groups, (int)nitems);
+    if (a->y_fmt == 3) {
+        if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_up4_h2t_kernel<true>), LDS_BYTES, g_lds_done_c) != 0) return -2;
+        hipLaunchKernelGGL(conv_up4_h2t_kernel<true>, dim3(grid), dim3(NWV * 64), LDS_BYTES, static_cast<hipStream_t>(stream), *a, tiles_x, tiles_y, groups, (int)nitems);
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
+    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_up4_h2t_kernel<false>), LDS_BYTES, g_lds_done) != 0) return -2;
+    hipLaunchKernelGGL(conv_up4_h2t_kernel<false>, dim3(grid), dim3(NWV * 64), LDS_BYTES, static_cast<hipStream_t>(stream), *a, tiles_x, tiles_y, groups, (int)nitems);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -32,6 +32,14 @@ template <int MODE> __device__ __forceinline__ f2 step(f2 v, float a, float b)
         else if (MODE == 5)
             asm volatile("v_pk_mul_f32 %0, %2, %3\n\tv_pk_mul_f32 %1, %3, %2\n\ts_nop 4\n\tv_pk_add_f32 %1, %0, %1 op_sel:[0,1] op_sel_hi:[1,0]\n\ts_nop 4\n\tv_pk_mul_f32 %1, %2, %1"
                          : "=&v"(t0), "=&v"(t1) : "v"(v), "v"(c));
+        else if (MODE == 6)      // independent VGPR x VGPR packed multiplies only
+            asm volatile("v_pk_mul_f32 %0, %2, %3\n\tv_pk_mul_f32 %1, %3, %2\n\ts_nop 4" : "=&v"(t0), "=&v"(t1) : "v"(v), "v"(c));
+        else if (MODE == 7)      // packed multiply -> dependent packed multiply (no op_sel anywhere)
+            asm volatile("v_pk_mul_f32 %0, %2, %3\n\ts_nop 4\n\tv_pk_mul_f32 %1, %0, %3\n\ts_nop 4" : "=&v"(t0), "=&v"(t1) : "v"(v), "v"(c));
+        else if (MODE == 8)      // packed add with the op_sel swizzle on independent inputs
+            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]\n\ts_nop 4" : "=&v"(t1) : "v"(v), "v"(c));
+        else if (MODE == 9)      // packed add WITHOUT op_sel, dependent on a packed multiply
+            asm volatile("v_pk_mul_f32 %0, %2, %3\n\ts_nop 4\n\tv_pk_add_f32 %1, %0, %3\n\ts_nop 4" : "=&v"(t0), "=&v"(t1) : "v"(v), "v"(c));
         r = t1;
     }
     return r;
@@ -59,6 +67,10 @@ extern "C" int run_war(int mode, const float* in, float* out, unsigned n, float 
     else if (mode == 2) hipLaunchKernelGGL(k_war<2>, g, t, 0, st, in, out, n, a, b);
     else if (mode == 3) hipLaunchKernelGGL(k_war<3>, g, t, 0, st, in, out, n, a, b);
     else if (mode == 4) hipLaunchKernelGGL(k_war<4>, g, t, 0, st, in, out, n, a, b);
-    else hipLaunchKernelGGL(k_war<5>, g, t, 0, st, in, out, n, a, b);
+    else if (mode == 5) hipLaunchKernelGGL(k_war<5>, g, t, 0, st, in, out, n, a, b);
+    else if (mode == 6) hipLaunchKernelGGL(k_war<6>, g, t, 0, st, in, out, n, a, b);
+    else if (mode == 7) hipLaunchKernelGGL(k_war<7>, g, t, 0, st, in, out, n, a, b);
+    else if (mode == 8) hipLaunchKernelGGL(k_war<8>, g, t, 0, st, in, out, n, a, b);
+    else hipLaunchKernelGGL(k_war<9>, g, t, 0, st, in, out, n, a, b);
     return (int)hipGetLastError();
 }

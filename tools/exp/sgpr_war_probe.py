@@ -17,10 +17,12 @@ N = 1 << 22
 xin, out = torch.randn(2 * N, device="cuda"), torch.empty(2 * N, device="cuda")
 names = {0: "v_pk_mul_f32 reads s[12:13]; next: s_mov_b64 s[12:13], -1   (the compiled pattern)", 1: "the same with s_nop 7 in between",
          2: "v_mul_f32 reads s12; next: s_mov_b32 s12, -1", 3: "v_pk_mul_f32 reads s[12:13], pair not overwritten (control)",
-         4: "dependent packed chain pk_mul -> pk_add(op_sel) -> pk_mul -> add with s_nop 0 between (as compiled)", 5: "the same chain with s_nop 4 between"}
+         4: "dependent packed chain pk_mul -> pk_add(op_sel) -> pk_mul -> add with s_nop 0 between (as compiled)", 5: "the same chain with s_nop 4 between",
+         6: "two independent VGPR x VGPR v_pk_mul_f32", 7: "v_pk_mul_f32 -> dependent v_pk_mul_f32 (s_nop 4)", 8: "v_pk_add_f32 with op_sel:[0,1] op_sel_hi:[1,0], independent inputs",
+         9: "v_pk_mul_f32 -> dependent v_pk_add_f32 without op_sel (s_nop 4)"}
 main, side = torch.cuda.current_stream(), torch.cuda.Stream()
 aggr(); torch.cuda.synchronize()
-for mode in (0, 3, 4, 5):
+for mode in (4, 6, 7, 8, 9):
     run = lambda: (lib.run_war(mode, C.c_void_p(xin.data_ptr()), C.c_void_p(out.data_ptr()), N, C.c_float(0.4947), C.c_float(1.25), st()), out)[1]
     ref = run().clone(); torch.cuda.synchronize()
     assert torch.equal(ref, run()), "alone not deterministic"

@@ -79,7 +79,7 @@ def test_lp_pass_is_reproducible_run_to_run_with_every_overlap(scale, batch, siz
     m, prior, opt, sd, psd = build(hip, scale)
     x = hip.to_device(synth.lr_batch(1, batch, size, size))
     ref = None
-    for it in range(4):
+    for it in range(int(os.environ.get("BFSR_LP_PASSES", "4"))):          # BFSR_LP_PASSES=<n>: the same check as a soak (profiles/r05_lp_soak.txt)
         x.add_(0.0)
         out = lp_infer(m, prior, x, return_all=True)
         cur = [out["sr"].clone(), out["sr_raw"].clone()] + [e.clone() for e in out["epses"]] + [e.clone() for e in out["epses_learned"]]

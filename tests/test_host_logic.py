@@ -424,3 +424,32 @@ def test_no_wide_buffer_store_with_register_soffset():
                         bad.append(line.strip())
     assert objs >= 10 and wide >= 50, "the disassembly did not find the kernels (%d code objects, %d wide buffer stores)" % (objs, wide)
     assert not bad, "wide buffer stores with a register soffset: %s" % bad[:4]
+
+
+def test_library_has_no_packed_fp32_instructions(tmp_path):
+    """The device code must be built without packed-fp32 VALU instructions (bfsr_amd/csrc/build.sh, NOPK): on MI355X their swizzled form (`v_pk_add_f32 ...
+    op_sel`) returns wrong values when the wave shares a SIMD with MFMA waves of another kernel (two streams; DESIGN.md section 5 round 5,
+    profiles/r05_packed_fp32_hazard.txt).  Disassembles every code object of the built library; skipped when the LLVM tools of the ROCm image are absent."""
+    import re
+    import shutil
+    import subprocess
+    from bfsr_amd import _lib
+    bundler, objdump = "/opt/rocm/lib/llvm/bin/clang-offload-bundler", "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(bundler) and os.path.exists(objdump) and shutil.which("objcopy")):
+        pytest.skip("LLVM / binutils tools not available")
+    fat = str(tmp_path / "fat.bin")
+    subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", _lib.LIB_PATH, fat])
+    data = open(fat, "rb").read()
+    starts = [m.start() for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", data)]
+    assert len(starts) >= 10, "expected one offload bundle per kernel source"
+    packed = mfma = 0
+    for n, i in enumerate(starts):
+        one, co = str(tmp_path / "b.bin"), str(tmp_path / "dev.co")
+        open(one, "wb").write(data[i: starts[n + 1] if n + 1 < len(starts) else len(data)])
+        subprocess.check_call([bundler, "--type=o", "--input=" + one, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co, "--unbundle"])
+        asm = subprocess.run([objdump, "-d", co], capture_output=True, text=True, check=True).stdout
+        packed += len(re.findall(r"v_pk_\w+_f32", asm))
+        mfma += asm.count("v_mfma_")
+    assert mfma > 1000, "disassembly looks empty"
+    assert packed == 0, "%d packed-fp32 instructions in libbfsr_hip.so: build it with bfsr_amd/csrc/build.sh" % packed
+

@@ -1,5 +1,6 @@
 """Which main-stream kernel corrupts the prior's branch 0 when the two run concurrently (8x model, eps0 = [B,6,384,384])?  The victim runs on a side
-stream while ONE candidate kernel loops on the main stream; its output is compared with the result computed alone.  GPU box: python tools/exp/aggressor_probe.py [B]"""
+stream while ONE candidate kernel loops on the main stream; its output is compared with the result computed alone.  (Against the packed build: bash tools/exp/build_pk.sh && BFSR_HIP_LIB=$PWD/tools/exp/libpk.so python tools/exp/aggressor_probe.py 32 -- the product build is clean.)
+GPU box: python tools/exp/aggressor_probe.py [B]"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))

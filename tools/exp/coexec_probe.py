@@ -1,4 +1,5 @@
 """Victim kernels of one instruction class each (tools/exp/coexec_probe.hip) on a side stream against the 1x1-only coupling_head looping on the main stream.
+Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o tools/exp/libcoexec.so tools/exp/coexec_probe.hip; the resize cases need the packed product build (BFSR_HIP_LIB=$PWD/tools/exp/libpk.so).
 GPU box: python tools/exp/coexec_probe.py"""
 import ctypes as C, os, sys
 import numpy as np, torch

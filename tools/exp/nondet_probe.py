@@ -1,4 +1,5 @@
 """Run-to-run determinism of the 8x LP pass at a given batch under different knob settings (bisecting a nondeterminism seen at B >= 16).
+(The nondeterminism needs the packed build: BFSR_HIP_LIB=$PWD/tools/exp/libpk.so, see tools/exp/build_pk.sh.)
 GPU box: python tools/exp/nondet_probe.py B [scale lr]"""
 import os, sys, subprocess
 B = sys.argv[1] if len(sys.argv) > 1 else "64"

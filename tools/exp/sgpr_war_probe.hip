@@ -1,6 +1,7 @@
 // sgpr_war_probe.hip -- is an SALU write to an SGPR (pair) that directly follows a VALU instruction READING it safe on gfx950 when the VALU of the SIMD is
 // kept busy by MFMAs of another wave?  (hipcc -O3 emits exactly `v_pk_mul_f32 v[4:5], s[12:13], v[4:5]; s_mov_b64 s[12:13], -1` in resize_kernel.)
 // Victim kernels for tools/exp/sgpr_war_probe.py; every thread repeats the pattern REP times and accumulates.
+// Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o tools/exp/libsgprwar.so tools/exp/sgpr_war_probe.hip   (inline asm: not affected by the library's NOPK flag)
 #include <hip/hip_runtime.h>
 typedef float f2 __attribute__((ext_vector_type(2)));
 #define REP 64

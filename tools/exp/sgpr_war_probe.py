@@ -1,4 +1,5 @@
-"""tools/exp/sgpr_war_probe.hip against the 1x1-only coupling_head (MFMA-heavy, leaves room for other waves on its SIMDs).  GPU box: python tools/exp/sgpr_war_probe.py"""
+"""tools/exp/sgpr_war_probe.hip against the 1x1-only coupling_head (MFMA-heavy, leaves room for other waves on its SIMDs).  Build the victim library first (see the .hip header).  The aggressor is the product library's kernel as built (NOPK or not: it only has to run MFMAs).
+GPU box: python tools/exp/sgpr_war_probe.py"""
 import ctypes as C, os, sys
 import numpy as np, torch
 HERE = os.path.dirname(os.path.abspath(__file__))

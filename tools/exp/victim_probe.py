@@ -1,4 +1,6 @@
-"""Which kernels give wrong results when they run on a side stream while the 1x1-only coupling_head loops on the main stream?  GPU box: python tools/exp/victim_probe.py [B]"""
+"""Which kernels give wrong results when they run on a side stream while the 1x1-only coupling_head loops on the main stream?  The product build has no packed-fp32 instructions any more: to reproduce the fault run it against the packed build,
+  bash tools/exp/build_pk.sh && BFSR_HIP_LIB=$PWD/tools/exp/libpk.so python tools/exp/victim_probe.py 32
+GPU box: python tools/exp/victim_probe.py [B]"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))

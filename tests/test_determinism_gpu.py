@@ -63,6 +63,59 @@ def test_engine_is_reproducible_run_to_run(scale, lr_size, overlap, rounds, batc
     hip.check_range()
 
 
+def test_plain_kernels_next_to_an_mfma_kernel_on_another_stream():
+    """The co-residency case behind the packed-fp32 finding, kernel by kernel: the 1x1-only coupling_head (the one MFMA kernel of the library that leaves registers
+    and LDS free on its SIMDs) loops on the main stream while a plain kernel runs on a side stream; the plain kernel's result must equal what it computes alone.
+    (On a library built WITH packed fp32 the bilinear resize fails this in every run: tools/exp/victim_probe.py, profiles/r05_packed_fp32_hazard.txt.)"""
+    import numpy as np
+    import torch
+    from bfsr_amd.ops import HipOps, MODE_BILINEAR, MODE_BILINEAR_AC
+    ops = HipOps("cuda:0")
+    g = np.random.Generator(np.random.PCG64(3))
+    r = lambda *sh, scale=1.0: torch.from_numpy((g.standard_normal(sh) * scale).astype(np.float32))
+    B = 32
+    hp1 = ops.pack_coupling_head(None, r(64, 64, 1, 1, scale=0.1), r(64, scale=0.1), torch.exp(r(64, scale=0.1)), r(64, scale=0.1), torch.exp(r(64, scale=0.1)))
+    raw, h2b = torch.randn(B, 64, 96, 96, device="cuda"), ops.h2_empty(B, 64, 96, 96)
+    aggr = lambda: ops.coupling_head(None, hp1, raw, h2b, pre_fmt=0)
+    bottom, cat = torch.randn(B, 256, 48, 48, device="cuda"), ops.empty(B, 512, 96, 96)
+    b96, c192 = torch.randn(B, 64, 96, 96, device="cuda"), ops.empty(B, 64, 192, 192)
+    z, zo = torch.randn(B, 24, 192, 192, device="cuda"), ops.empty(B, 24, 192, 192)
+    haff, hft = torch.randn(B, 24, 192, 192, device="cuda") * 0.5, torch.randn(B, 48, 192, 192, device="cuda") * 0.5
+    Wm = torch.from_numpy(np.linalg.qr(g.standard_normal((24, 24)))[0].astype(np.float32))
+    wv, wt, ab, ae = ops.vec(Wm), ops.vec(Wm.t().contiguous()), ops.vec(r(24, scale=0.1)), ops.vec(torch.exp(r(24, scale=0.1)))
+    e6, n6 = torch.randn(B, 6, 384, 384, device="cuda"), ops.empty(B, 6, 384, 384)
+    p48, sq = ops.empty(B, 64, 48, 48), ops.empty(B, 96, 96, 96)
+    xh, f96 = ops.h2_pack(b96, ops.h2_empty(B, 64, 96, 96)), ops.empty(B, 64, 96, 96)
+    victims = {
+        "resize bilinear (align_corners) 48 -> 96": lambda: ops.resize(bottom, cat[:, 256:], MODE_BILINEAR_AC, 47.0 / 95.0, 47.0 / 95.0, window=(0, 0, 96, 96)),
+        "resize bilinear 96 -> 192": lambda: ops.resize(b96, c192, MODE_BILINEAR, 0.5, 0.5),
+        "flow_pointwise C = 24 (reverse, both conditionals)": lambda: ops.flow_pointwise(z, zo, True, h_aff=haff, h_ft=hft, w=wv, wt=wt, an_bias=ab, an_escale=ae),
+        "standardize 6 ch @384^2": lambda: ops.standardize(e6, n6),
+        "maxpool2 96 -> 48": lambda: ops.maxpool2(b96, p48),
+        "squeeze2d 24 ch @192^2": lambda: ops.squeeze2d(z, sq),
+        "axpb_clamp 64 ch @192^2": lambda: ops.axpb_clamp(c192, c192, 1.0, 0.0, -3.0, 3.0),
+        "h2_unpack 64 ch @96^2": lambda: ops.h2_unpack(xh, f96),
+    }
+    main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+    aggr()
+    torch.cuda.synchronize()
+    for name, fn in victims.items():
+        ref = fn().clone()
+        torch.cuda.synchronize()
+        for rep in range(3):
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    out = fn()
+                ev = side.record_event()
+            while not ev.query():
+                for _ in range(8):
+                    aggr()
+            torch.cuda.synchronize()
+            bad = int((out != ref).sum())
+            assert bad == 0, "%s: %d elements differ from the result computed alone (overlapped run %d)" % (name, bad, rep)
+
+
 @pytest.mark.parametrize("scale,batch,size", [(8, 16, 96), (4, 8, 160)])
 def test_lp_pass_is_reproducible_run_to_run_with_every_overlap(scale, batch, size):
     """The WHOLE LP pass (RRDB, encode, standardise, both prior branches, decode) four times on the same input, conditioning recomputed every time, every

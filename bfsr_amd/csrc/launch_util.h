@@ -61,10 +61,12 @@ __device__ __forceinline__ void store_b128(__amdgpu_buffer_rsrc_t rs, store_u32x
 }
 
 
-// fp32 -> the fp32 value of its fp16 rounding, PINNED in a register: the hi term of the two-term fp16 split.  hipcc otherwise feels free to convert the same
-// value twice -- v_cvt_pk_f16_f32 for the stored hi plane, v_cvt_f16_f32 for the subtraction that forms the lo term -- and on gfx950 the two conversions do not
-// always return the same fp16, so hi + lo misses the value by an fp16 ulp (found in round 5: the fused LINF MLP went from 6e-7 to 3.7e-5 when a compiler flag
-// changed the instruction selection).  (_Float16)pin_f16(v) is exact, whichever conversion the compiler picks for it.
+// fp32 -> the fp32 value of its fp16 rounding, PINNED in a register: the hi term of the two-term fp16 split.  Without the pin hipcc may form the hi term twice in
+// two different ways: where the value is a product, `(_Float16)(a * b)` for the subtraction that forms the lo term is contracted into v_fma_mixlo_f16 (ONE rounding
+// of the exact product, in spite of -ffp-contract=off) while the stored hi plane is converted from the fp32-rounded product (v_cvt_pk_f16_f32: TWO roundings).  Where
+// the two disagree (the fp32 product lands on an fp16 tie) hi + lo misses the value by an fp16 ulp -- found in round 5, when a compiler flag changed the instruction
+// selection of the fused LINF MLP: 6e-7 -> 3.7e-5 against the CPU double (the two v_cvt instructions themselves agree on 2.7e8 inputs, tools/exp/cvt_probe.hip).
+// (_Float16)pin_f16(v) is exact, so both uses see the same rounded value whatever the compiler picks.
 __device__ __forceinline__ float pin_f16(float v)
 {
     float hf = (float)(_Float16)v;

@@ -102,8 +102,7 @@ __device__ __forceinline__ void encode8(const float (&v)[8], typename Mode<X3>::
     } else if constexpr (X3 == 2) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            // the rounded value is pinned in a register: hipcc otherwise converts v twice (v_cvt_pk_f16_f32 for the stored hi plane, v_cvt_f16_f32 for the
-            // subtraction) and the two results are not always the same fp16 -- hi + lo then misses v by an fp16 ulp (measured: 6e-7 -> 3.7e-5 on the MLP output)
+            // the rounded value is pinned in a register (launch_util.h, pin_f16): both the stored hi plane and the subtraction must use the SAME fp16 rounding of v
             const float hf = bfsr::pin_f16(v[e]);
             out[0][e] = (_Float16)hf; out[1][e] = (_Float16)(v[e] - hf);
             amax = fmaxf(amax, fabsf(v[e]));                             // range guard of the fp16 split (a.flag)

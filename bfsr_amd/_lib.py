@@ -223,8 +223,8 @@ SYMBOLS = {
     "bfsr_ssim_sum": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, C.c_double, _VP, _VP, _VP]),
     "bfsr_ssim_sum_w": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, C.c_double, _I, _VP, C.c_double, _VP, _VP]),
     "bfsr_to_uint8": (_I, [_VP, _LL, _VP, _I, _LL, _VP]),
-    "bfsr_channel_range_scratch": (_LL, [_I]),
-    "bfsr_channel_range_check": (_I, [_VP, _LL, _I, _I, _I, _I, _F, _F, _VP, _VP, _VP]),
+    "bfsr_channel_range_scratch": (_LL, [_I, _I]),
+    "bfsr_channel_range_check": (_I, [_VP, _LL, _I, _I, _I, _I, _F, _F, _F, _VP, _VP, _VP, _VP]),
     "bfsr_conv2d_direct": (_I, [_VP, _LL, _VP, _VP, _VP, _LL, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _VP]),
 }
 
@@ -245,7 +245,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.bfsr_abi_version() != 5:
+    if lib.bfsr_abi_version() != 6:
         raise RuntimeError("bfsr_amd: ABI version mismatch")
     _lib = lib
     return lib

@@ -22,8 +22,10 @@
 //     rows per wave, 8-channel LDS stages three deep, K = two taps x 8 channels -- needs 40 % fewer LDS reads and 20 % fewer staged bytes per MFMA
 //     and ran NO faster under sustained load: the chip is power-limited there (MFMA busy 0.76 at ~1.65 GHz against conv_h2x's 0.84 at ~1.51 GHz,
 //     the same product), and that version's half-empty MFMA for the ninth tap (14 instead of 13.5 per row and octet) cost exactly its 3.7 %.
-// The spin on the counters is bounded: after ~2 s without progress a workgroup raises bit 2 of the status word and every waiter gives up (the
-// results are then garbage and the host raises) -- a hung GPU is never the failure mode.
+// The spin on the counters is bounded: after ~2 s without progress a workgroup raises the launch's PRIVATE give-up word (one word behind the
+// progress counters, zeroed with them at every launch) and every waiter of THIS launch gives up; bit 2 of the caller's status word is raised as
+// well so that the host can tell (the results are then garbage and the host raises) -- a hung GPU is never the failure mode, and a launch that
+// gave up does not poison the launches after it (round 6: the give-up bit used to live in the shared, sticky status word only).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <cstring>
@@ -102,7 +104,7 @@ __device__ __forceinline__ f32x16 mm_(half8 a, half8 b, f32x16 c)
 }
 
 __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv_chain_kernel(const ChainRec* __restrict__ recs, int B, int H, int W, int tiles_x, int tiles_y,
-                                                                         int nitems, unsigned* progress, unsigned* status, int defer_ok)
+                                                                         int nitems, unsigned* progress, unsigned* giveup, unsigned* status, int defer_ok)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     volatile int* lds_ready = reinterpret_cast<volatile int*>(smem + RING);
@@ -145,14 +147,14 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv_chain_kernel(const Ch
             const bool nb = lane < 9 && ty >= 0 && ty < tiles_y && tx >= 0 && tx < tiles_x;
             unsigned v = 0xffffffffu;
             if (nb) v = __hip_atomic_load((gu32*)(progress + ((long long)c.b * tiles_y + ty) * tiles_x + tx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (lane == 9) v = __hip_atomic_load((gu32*)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 9) v = __hip_atomic_load((gu32*)giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const bool ok = lane == 9 ? true : v >= r.wait_target;
             const bool dead = lane == 9 && (v & 4u);
             if (__any((int)dead)) return true;                            // another workgroup gave up: do not add a second timeout on top
             if (__all((int)ok)) { polls = 0; return true; }
             if (++polls > POLL_LIMIT) {
-                if (lane == 0) atomicOr(status, 4u);
+                if (lane == 0) { atomicOr(giveup, 4u); atomicOr(status, 4u); }
                 return true;
             }
             return false;
@@ -572,7 +574,7 @@ extern "C" long long bfsr_conv_chain_progress_words(const void* table_host)
     if (!table_host) return -1;
     const ChainHeader* hd = static_cast<const ChainHeader*>(table_host);
     if (hd->magic != CHAIN_MAGIC) return -1;
-    return (long long)hd->tiles_x * hd->tiles_y * hd->B;
+    return (long long)hd->tiles_x * hd->tiles_y * hd->B + 1;             // one counter per tile + the launch's give-up word
 }
 
 extern "C" int bfsr_conv_chain_launch(const void* table_host, const void* table_dev, unsigned* progress, unsigned* status, int tune, void* stream)
@@ -591,11 +593,12 @@ extern "C" int bfsr_conv_chain_launch(const void* table_host, const void* table_
     const int grid = hd->nitems < cus ? hd->nitems : cus;
     static std::atomic<unsigned long long> lds_done{0};
     if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_chain_kernel), LDS_TOTAL, lds_done) != 0) return -1;
-    const long long words = (long long)hd->tiles_x * hd->tiles_y * hd->B;
-    if (hd->nconv == 1) progress = nullptr;                              // a chain of one has no dependencies: no counters, no memset node
+    const long long words = (long long)hd->tiles_x * hd->tiles_y * hd->B + 1;
+    unsigned* giveup = progress + (words - 1);
+    if (hd->nconv == 1) progress = nullptr;                              // a chain of one has no dependencies: no counters, no memset node (and nothing polls the give-up word)
     else if (hipMemsetAsync(progress, 0, (size_t)words * sizeof(unsigned), st) != hipSuccess) return -1;
     const ChainRec* recs = reinterpret_cast<const ChainRec*>(static_cast<const unsigned char*>(table_dev) + sizeof(ChainHeader));
     hipLaunchKernelGGL(conv_chain_kernel, dim3((unsigned)grid), dim3((NW + NLW) * 64), LDS_TOTAL, st, recs, hd->B, hd->H, hd->W, hd->tiles_x, hd->tiles_y,
-                       hd->nitems, progress, status, defer_ok);
+                       hd->nitems, progress, giveup, status, defer_ok);
     return (int)hipGetLastError();
 }

@@ -74,6 +74,8 @@ class LINFEngine(object):
         # coef | freq as one conv (both read the same feat)
         self.cf = _ConvP(ops, torch.cat([sd["coef.weight"], sd["freq.weight"]], 0),
                          torch.cat([sd["coef.bias"], sd["freq.bias"]], 0), mtile=2, f16=f16)
+        if hasattr(self.encoder, "out_gain") and hasattr(ops, "channel_gain"):
+            self.encoder.out_gain = ops.channel_gain(torch.cat([sd["coef.weight"], sd["freq.weight"]], 0))    # the conv that contracts the encoder's output (range check)
         self.phase = ops.vec(sd["phase.weight"])
         # Fourier features + shared MLP as ONE kernel (linf_mlp.hip) when the MLP has the reference's shape (3 hidden layers of
         # 256); otherwise, or on the all-native-fp32 backend (BFSR_CONV=f32): features kernel + 1x1 convs

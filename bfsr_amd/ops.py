@@ -933,19 +933,42 @@ class HipOps(object):
                                "bit 1 = non-finite flow state, bit 3 = a channel that is tiny everywhere); the guarded entry points re-run such "
                                "a pass under BFSR_SPLIT=bf16x3 (fp32's exponent range, six products) automatically" % v)
 
-    def check_channels(self, x, tiny=2.0 ** -7, huge=65504.0):
-        """Per-channel dynamic-range check of an fp32 tensor that enters a region computed with the fp16-pair split (range_check.hip): raises
-        bit 3 of the range flag when a channel is tiny everywhere (0 < max |x| < tiny: the pair would keep fewer than 18 significant bits of
-        it), bit 0 when a channel reaches `huge`.  Asynchronous; guard.run_guarded reads the flag at the end of the pass.  No-op under the
-        bf16x3 split and the native fp32 MFMA."""
+    def check_channels(self, x, gain=None, tiny=2.0 ** -7, huge=65504.0, ratio=2.0 ** -5):
+        """Per-sample, per-channel dynamic-range check of an fp32 tensor that enters a region computed with the fp16-pair split (range_check.hip):
+        raises bit 0 of the range flag when a channel reaches `huge`, bit 3 when a channel of a sample is tiny (0 < max |x| < tiny) AND the absolute
+        error the pair leaves on it (2^-25 x the consumer's weight mass on that channel) exceeds 2^-20 of the largest per-channel contribution of the
+        same sample: max_c(m_c g_c) < g_c * ratio.  `gain` = channel_gain(...) of the convs that read x ([C] device floats in [0, 1]); None = 1 for
+        every channel, i.e. the rule fires only when the whole sample is tiny.  tiny=0 checks the overflow side only.  Asynchronous; the scratch is
+        private to the current stream (the two half-batch lanes of the RRDB check concurrently); guard.run_guarded reads the flag at the end of the
+        pass.  No-op under the bf16x3 split and the native fp32 MFMA."""
         if self.conv_mode != "x3" or self.split != "f16x2":
             return
         xp, xbs, Cc, H, W = _view(x, "check_channels.x")
-        n = self.lib.bfsr_channel_range_scratch(Cc)
-        if self._range_scratch is None or self._range_scratch.numel() < n:
-            self._range_scratch = torch.empty(n, dtype=torch.float32, device=self.device)
+        if gain is not None and (gain.dtype != torch.float32 or gain.numel() != Cc or not gain.is_contiguous() or gain.device != self.device):
+            raise ValueError("check_channels: gain must be a contiguous fp32 device vector of %d channels" % Cc)
+        n = self.lib.bfsr_channel_range_scratch(x.shape[0], Cc)
+        if self._range_scratch is None:
+            self._range_scratch = {}
+        sk = torch.cuda.current_stream(self.device).cuda_stream
+        sc = self._range_scratch.get(sk)
+        if sc is None or sc.numel() < n:
+            sc = self._range_scratch[sk] = torch.empty(n, dtype=torch.float32, device=self.device)    # allocated on (and only ever used on) this stream
         _lib.check(self._launch(("range_check", Cc, x.shape[0], H, W), lambda: self.lib.bfsr_channel_range_check(
-            xp, xbs, x.shape[0], Cc, H, W, tiny, huge, self._range_scratch.data_ptr(), self.range_flag.data_ptr(), self._stream())), "channel_range_check")
+            xp, xbs, x.shape[0], Cc, H, W, tiny, huge, ratio, _ptr(gain), sc.data_ptr(), self.range_flag.data_ptr(), self._stream())), "channel_range_check")
+
+    def channel_gain(self, *convs):
+        """[C] device vector for check_channels: per channel of a tensor the weight mass of the convs that read it -- sum |w| over the taps, max
+        over the output channels -- normalised per conv to its largest INPUT channel (all of them, not only the slice), max over the convs.
+        `convs`: OIHW weight tensors, or (w, lo, hi) when the tensor is input channels lo..hi of that conv."""
+        g = None
+        for cv in convs:
+            w, lo, hi = cv if isinstance(cv, (tuple, list)) else (cv, 0, cv.shape[1])
+            m = w.detach().to("cpu").abs().double().sum(dim=(2, 3)).max(dim=0)[0]
+            top = float(m.max())
+            m = (m / top) if top > 0.0 else torch.ones_like(m)
+            m = m[lo:hi]
+            g = m if g is None else torch.maximum(g, m)
+        return self.vec(g.float())
 
     def read_range_flag(self):
         """The flag word (and clear it).  One 4-byte device->host copy: synchronises the current stream."""

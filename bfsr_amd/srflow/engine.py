@@ -88,12 +88,19 @@ def h2_mode(ops, f16):
     return None
 
 
-def _chk(ops, t):
-    """Per-channel dynamic-range check of an fp32 tensor that enters an fp16-pair region (ops.check_channels; a no-op on other splits / backends)."""
+def _chk(ops, t, gain=None, **kw):
+    """Per-sample, per-channel dynamic-range check of an fp32 tensor that enters an fp16-pair region (ops.check_channels; a no-op on other splits /
+    backends).  gain: _gain(ops, ...) of the convs that read t."""
     f = getattr(ops, "check_channels", None)
     if f is not None:
-        f(t)
+        f(t, gain, **kw) if (gain is not None or kw) else f(t)
     return t
+
+
+def _gain(ops, *convs):
+    """ops.channel_gain(...) where the backend has it (HipOps), else None (the check then treats every channel alike)."""
+    f = getattr(ops, "channel_gain", None)
+    return f(*convs) if f is not None and convs else None
 
 
 class _Workspace(object):
@@ -141,6 +148,11 @@ class RRDBEncoder(object):
             self.blocks.append(rdbs)
         self.trunk_conv = mk(g("trunk_conv.weight"), g("trunk_conv.bias"))
         self.ws = _Workspace(ops)
+        # range check of the two fp32 tensors at the ends of the packed region (ops.check_channels): conv_first's output is read by the five convs of
+        # the first dense block (and, as the LINF skip, by nothing else that contracts it); `out_gain` = the convs that read the trunk output, set by
+        # the owner (SRFlowEngine: upconv1 + the key rows of the hoisted convs; LINF: coef | freq)
+        self.first_gain = _gain(ops, *[(g("RRDB_trunk.0.RDB1.conv%d.weight" % i), 0, nf) for i in range(1, 6)]) if nb > 0 else None
+        self.out_gain = None
 
     def forward(self, x, out, on_block=None, taps=None):
         """x [B,3,h,w] -> out (a [B,nf,h,w] view) = fea + trunk_conv(fea).  `on_block(idx, fea_view, b0, b1)` is called after RRDB idx (for the samples b0..b1 the view holds)
@@ -237,7 +249,7 @@ class RRDBEncoder(object):
             self._chain = (ckey, [ops.conv_chain(specs)], tapbuf)
         _, chains, tapbuf = self._chain
         self.conv_first.run(ops, x, tmp)
-        _chk(ops, tmp)
+        _chk(ops, tmp, self.first_gain)
         ops.h2_pack(tmp, ring[0][:, :o(nf)])
         if self.skip_from_first:
             ops.h2_pack(tmp, self._first)
@@ -246,7 +258,7 @@ class RRDBEncoder(object):
         ops.axpb_clamp(trunk_out, out)
         for idx in want:
             on_block(idx, tapbuf[idx], 0, B)
-        _chk(ops, out)
+        _chk(ops, out, self.out_gain)
         return out
 
     def _forward_packed(self, x, out, on_block, taps):
@@ -275,7 +287,7 @@ class RRDBEncoder(object):
             cur = 0
             self.conv_first.run(ops, xs, tmps)
             if self.x3s:
-                _chk(ops, tmps)
+                _chk(ops, tmps, self.first_gain)
             pack(tmps, rg[cur][:, :o(nf)])
             if self.skip_from_first:
                 pack(tmps, first)
@@ -299,7 +311,7 @@ class RRDBEncoder(object):
             fea = rg[cur][:, :o(nf)]
             self.trunk_conv.run(ops, fea, outs, res1=first if self.skip_from_first else fea, alpha1=1.0)
             if self.x3s:
-                _chk(ops, outs)
+                _chk(ops, outs, self.out_gain)
             yield
 
         # Tile quantisation: a dense-block conv of B x (h/16) x (w/32) tiles runs in ceil(tiles / CUs) rounds of one persistent workgroup per CU
@@ -475,6 +487,7 @@ class SRFlowEngine(object):
                                                post_scale=torch.exp(sd[p + "conv.logs"] * 3))
         # batched hoisted first convs per level
         self.hoist = {}
+        lvl_w = {}                                                      # level -> the two stacked first convs over the level's conditional (for the range-check gains below)
         for level in range(1, self.L + 1):
             idxs = [ly.index for ly in self.layers if ly.type == "step" and ly.coupled and ly.level == level]
             if not idxs:
@@ -483,6 +496,7 @@ class SRFlowEngine(object):
             sh = torch.cat([self.steps[i].ft0_shift for i in idxs], 0)
             sc = torch.cat([self.steps[i].ft0_scale for i in idxs], 0)
             wa = torch.cat([self.steps[i].aff0_ft_w for i in idxs], 0)
+            lvl_w[level] = (wf, wa)
             hz = dict(idxs=idxs, up2=False)
             # quad-major hand-over (see _hoist_level): which hoisted tensors of this level only the coupling pair reads
             fused_all = all(getattr(self.steps[i], "fused", False) for i in idxs)
@@ -543,6 +557,25 @@ class SRFlowEngine(object):
             self.hoist[level] = hz
             for i in idxs:
                 del self.steps[i].ft0_w, self.steps[i].aff0_ft_w
+        # Range-check gains (ops.check_channels): which convs contract each fp32 tensor that enters the fp16-pair region.  The conditional of a level is
+        # cat[key (64), tap_0 .. tap_3 (64 each)] (SRFlowNet_arch.py:122-137): tap k is read by rows 64(k+1)..64(k+2) of every level's two first convs,
+        # a key tensor by rows 0..64 of its level's (fea_up0 is a bilinear resize of fea_up1: its level counts as a reader of fea_up1) and by the next
+        # upconv.
+        self._tap_gain, self._key_gain = {}, {}
+        if self.concat and self.block_idxs and lvl_w:
+            for k in range(len(self.block_idxs)):
+                self._tap_gain[k] = _gain(ops, *[(w, 64 * (k + 1), 64 * (k + 2)) for ws_ in lvl_w.values() for w in ws_ if w.shape[1] >= 64 * (k + 2)])
+        readers = {}
+        for level, ws_ in lvl_w.items():
+            name = self.level_names[level]
+            readers.setdefault("fea_up1" if name == "fea_up0" else name, []).extend((w, 0, 64) for w in ws_)
+        prev_name = "fea_up1"
+        for kname, n in chain[:deepest + 1]:
+            readers.setdefault(prev_name, []).append((g(n + ".weight"), 0, 64))
+            prev_name = kname
+        for name, cv in readers.items():
+            self._key_gain[name] = _gain(ops, *cv)
+        self.rrdb.out_gain = self._key_gain.get("fea_up1")
 
     def _level_shift(self, level):
         return _KEY_SHIFT.get(self.level_names[level])
@@ -605,8 +638,8 @@ class SRFlowEngine(object):
         def on_block(idx, fea, b0, b1):
             # nearest-resize the tapped RRDB output (samples b0..b1) into its 64-ch slot of every level (SRFlowNet_arch.py:122-137)
             if idx in self.block_idxs and self.concat:
-                _chk(ops, fea)
                 k = self.block_idxs.index(idx)
+                _chk(ops, fea, self._tap_gain.get(k))
                 for level in range(1, self.L + 1):
                     if self._taps_up2(level):
                         continue
@@ -627,7 +660,7 @@ class SRFlowEngine(object):
             if name in self.upconvs:
                 cur = key_view(name)
                 self.upconvs[name].run(ops, prev, cur, in_shift=1, act=ACT_LRELU, slope=0.2)
-                _chk(ops, cur)
+                _chk(ops, cur, self._key_gain.get(name))
                 prev = cur
         if "fea_up0" in self.need_keys:
             dst = key_view("fea_up0")       # bilinear 1/2, align_corners=False, recompute_scale_factor=True
@@ -1017,7 +1050,7 @@ class SRFlowEngine(object):
                     ops.flow_pointwise(z, z, False, h_aff=pending)
                     pending = None
                 out = ws.get("enc_z%d" % ly.level, B, ly.C, H // 2, W // 2)
-                z = _chk(ops, ops.squeeze2d(z, out))        # the coupling heads split z1 into fp16 pairs
+                z = _chk(ops, ops.squeeze2d(z, out), tiny=0.0)        # the coupling heads split z1 into fp16 pairs (overflow side only: see decode)
             elif ly.type == "step":
                 st = self.steps[ly.index]
                 if ly.coupled:
@@ -1090,7 +1123,10 @@ class SRFlowEngine(object):
         B = zin.shape[0]
         cur = ws.get("dec_z_top", *zin.shape)
         ops.axpb_clamp(zin, cur)
-        z = _chk(ops, cur)                                   # the coupling heads split z1 into fp16 pairs
+        # the coupling heads split z1 into fp16 pairs: checked for overflow only.  A tiny flow state (a dark crop) is harmless: the 3x3 conv on z1 is a
+        # RESIDUAL on the hoisted partial pre_aff, so what its absolute split error (<= 2^-25 x the weight mass) is compared with is the hidden
+        # pre-activation, whose size does not depend on z
+        z = _chk(ops, cur, tiny=0.0)
         # the buffer the next (lower-index) split layer concatenates into is prepared when we reach a squeeze
         skip_to = len(self.layers)
         for pos in reversed(range(len(self.layers))):

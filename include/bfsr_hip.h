@@ -11,8 +11,11 @@
  *   - all tensors fp32, NCHW; a "view" is (ptr, batch_stride_in_floats, C, H, W) with contiguous
  *     H*W planes and channel stride H*W, so a channel slice of a larger buffer is a valid view;
  *   - the caller owns every buffer (inputs, outputs, scratch); nothing is retained after a call;
- *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), no internal sync,
- *     no global mutable state => re-entrant across streams;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), no internal sync;
+ *     the only process-global state are two idempotent per-DEVICE caches in the launchers (launch_util.h): the CU count
+ *     and one "dynamic-LDS attribute already raised" bit per kernel and device (std::atomic, a racing second caller
+ *     repeats the same hipFuncSetAttribute) -- nothing that depends on call order or arguments => re-entrant across
+ *     host threads, streams and devices;
  *   - return value: 0 on success, otherwise a hipError_t (or -1 for an unsupported argument);
  *     no exceptions cross the ABI.
  */
@@ -23,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BFSR_ABI_VERSION 5      /* 5 (round 5, last): BfsrConvX3Args.up4 / up4_bs appended, bfsr_conv2d_up4_h2t y_fmt 3 (compact output).  4 (round 5, late): BfsrLinfMlpArgs.cf_fmt appended; bfsr_conv2d_up4_h2t and its pack functions added.  3 (round 5): BfsrChainConv + the chain entry points, bfsr_channel_range_*, BfsrLinfMlpArgs.flag.  2 (round 4): BfsrConvArgs / BfsrConvX3Args grew y_fmt + flag, coupling head / tail structs redefined, bfsr_conv2d_up2_h2t, bfsr_h2_pack_s2d, bfsr_ssim_sum_w added, the step / up2_h2x entry points removed */
+#define BFSR_ABI_VERSION 6      /* 6 (round 6): bfsr_channel_range_check per sample + gain / ratio arguments, bfsr_channel_range_scratch(B, C); bfsr_conv_chain_progress_words counts the give-up word.  5 (round 5, last): BfsrConvX3Args.up4 / up4_bs appended, bfsr_conv2d_up4_h2t y_fmt 3 (compact output).  4 (round 5, late): BfsrLinfMlpArgs.cf_fmt appended; bfsr_conv2d_up4_h2t and its pack functions added.  3 (round 5): BfsrChainConv + the chain entry points, bfsr_channel_range_*, BfsrLinfMlpArgs.flag.  2 (round 4): BfsrConvArgs / BfsrConvX3Args grew y_fmt + flag, coupling head / tail structs redefined, bfsr_conv2d_up2_h2t, bfsr_h2_pack_s2d, bfsr_ssim_sum_w added, the step / up2_h2x entry points removed */
 
 enum { BFSR_ACT_NONE = 0, BFSR_ACT_RELU = 1, BFSR_ACT_LRELU = 2 };
 
@@ -213,8 +216,10 @@ int bfsr_h2_unpack(const unsigned short* x, long long x_bs, float* y, long long 
  * hi + lo, i.e. exactly bfsr_h2_unpack(y).
  *   bfsr_conv_chain_prepare validates the descriptors and fills an opaque table (bfsr_conv_chain_table_size bytes, host memory); the
  *   caller keeps a device copy of the same bytes.  bfsr_conv_chain_launch zeroes `progress` (bfsr_conv_chain_progress_words unsigned
- *   words of device memory) and launches.  `status` (device word, required): bit 0 = fp16-split range overflow (as BfsrConvX3Args.flag),
- *   bit 2 = a dependency wait timed out (~2 s; results invalid).  tune > 0 shrinks the persistent grid. */
+ *   words of device memory: one counter per tile + the launch's private give-up word) and launches.  `status` (device word, required):
+ *   bit 0 = fp16-split range overflow (as BfsrConvX3Args.flag), bit 2 = a dependency wait of some launch timed out (~2 s; that launch's
+ *   results are invalid).  Bit 2 is only ever WRITTEN by the launches: whether waiters give up is decided by the private word, so a sticky
+ *   status bit does not make later launches skip their waits (round 6).  tune > 0 shrinks the persistent grid. */
 typedef struct BfsrChainConv {
     const unsigned short* x; long long x_bs; int Cin;      /* h2 view */
     const unsigned short* w;                                /* bfsr_pack_conv_weight_h2x(mtile = 1) */
@@ -233,11 +238,16 @@ int bfsr_conv_chain_launch(const void* table_host, const void* table_dev, unsign
 /* ---- per-channel dynamic-range check of a tensor entering an fp16-split region (round 5, range_check.hip; bfsr_amd/guard.py) -----------
  * The two-term fp16 split of the default path (bfsr_conv3x3_h2x and friends) holds 22 significant bits for 2^-3 <= |x| < 65504.  Replaces
  * nothing in the reference: it is what lets the engine keep the reference's fp32 contract (RRDBNet_arch.py:39-45, LINF-LP/models/rrdb.py:52-58
- * contract in true fp32) -- a pass whose tensors leave that range is re-run under the bf16x3 split.  Raises in *flag: bit 3 when a channel's
- * max |x| over the whole [B,C,H,W] view is in (0, tiny), bit 0 when it is >= huge or not finite.  scratch: bfsr_channel_range_scratch(C) floats. */
-long long bfsr_channel_range_scratch(int C);
-int bfsr_channel_range_check(const float* x, long long x_bs, int B, int C, int H, int W, float tiny, float huge, float* scratch,
-                             unsigned* flag, void* stream);
+ * contract in true fp32) -- a pass whose tensors leave that range is re-run under the bf16x3 split.  Per SAMPLE b and channel c, m = max |x|
+ * over the sample's plane; raises in *flag: bit 0 when some m >= huge or not finite; bit 3 when some channel with 0 < m_c < tiny has
+ * max_c'(m_c' * g_c') < g_c * ratio over the same sample -- with ratio = 2^-5 the channel's absolute split error, 2^-25 * g_c, then exceeds
+ * 2^-20 of the largest per-channel contribution to the conv that reads the tensor.  gain (optional, device, C floats in [0, 1]): the consumer
+ * convs' weight mass per input channel, normalised to its maximum; NULL = 1 for every channel (the rule then fires only when the whole sample
+ * is tiny).  Round 6 (ABI 6): per sample instead of per batch, weight-aware; round 5 flagged every channel with max |x| < tiny over the batch.
+ * scratch: bfsr_channel_range_scratch(B, C) floats, private to the stream of the call. */
+long long bfsr_channel_range_scratch(int B, int C);
+int bfsr_channel_range_check(const float* x, long long x_bs, int B, int C, int H, int W, float tiny, float huge, float ratio, const float* gain,
+                             float* scratch, unsigned* flag, void* stream);
 
 /* ---- fused flow-step pointwise chain -----------------------------------------------------------
  * One read of z / h_aff / h_ft, one write of z (the HBM-roofline "coupling inverse" kernel of

@@ -204,8 +204,10 @@ def test_chain_timeout_degrades_to_launches(hip):
 
 @pytest.mark.parametrize("shape", [(3, 20, 16, 24), (2, 7, 9, 13)])          # 16-byte vector path (H*W % 4 == 0) | scalar path
 def test_channel_range_check_bits(hip, shape):
-    """bfsr_channel_range_check on a channel-slice view: bit 3 iff some channel is tiny EVERYWHERE (0 < max |x| < 2^-7), bit 0 iff a channel reaches
-    65504 or is not finite; an all-zero channel and a channel with a few tiny elements among normal ones raise nothing."""
+    """bfsr_channel_range_check on a channel-slice view (round 6 rule, per SAMPLE): bit 0 iff a channel reaches 65504 or is not finite; bit 3 iff
+    a channel of some sample is tiny everywhere (0 < max |x| < 2^-7) AND its absolute split error matters: max_c(m_c g_c) < g_c / 32 -- the whole
+    sample is tiny, or the weights that read the tiny channel are far above the rest (gain).  An all-zero channel, a few tiny elements among
+    normal ones and a tiny channel read by ordinary weights next to normal channels raise nothing."""
     B, C, H, W = shape
     g = torch.Generator().manual_seed(7)
     base = torch.randn(B, C + 3, H, W, generator=g)
@@ -216,10 +218,27 @@ def test_channel_range_check_bits(hip, shape):
     hip.read_range_flag()
     hip.check_channels(view)
     assert hip.read_range_flag() == 0
-    x[:, 3] *= 1.0e-4                                      # channel 2 of the view: max ~ 4e-4 < 2^-7
+    x[:, 3] *= 1.0e-4                                      # channel 2 of the view: max ~ 4e-4 < 2^-7, next to normal channels read by the same weights
+    hip.check_channels(view)
+    assert hip.read_range_flag() == 0                      # (round 5 flagged this)
+    gain = torch.full((C,), 2.0 ** -13, device=x.device)
+    gain[2] = 1.0                                          # ... but read by weights 2^13 above the rest: its error is what the consumer sees
+    hip.check_channels(view, gain)
+    assert hip.read_range_flag() == 8
+    gain[2] = 2.0 ** -13
+    gain[5] = 1.0                                          # the heavy weights read a normal channel instead
+    hip.check_channels(view, gain)
+    assert hip.read_range_flag() == 0
+    x[:, 3] *= 1.0e4
+    keep = x[B - 1].clone()
+    x[B - 1] *= 2.0 ** -12                                 # ONE sample tiny as a whole: its trigger does not depend on its batch-mates
     hip.check_channels(view)
     assert hip.read_range_flag() == 8
-    x[:, 3] *= 1.0e4
+    hip.check_channels(view, tiny=0.0)                     # overflow side only
+    assert hip.read_range_flag() == 0
+    x[B - 1] = keep
+    hip.check_channels(view[:B - 1])
+    assert hip.read_range_flag() == 0
     x[B - 1, C, H - 1, W - 1] = 7.0e4                      # last channel of the view
     hip.check_channels(view)
     assert hip.read_range_flag() == 1
@@ -230,3 +249,17 @@ def test_channel_range_check_bits(hip, shape):
     x[:, C + 1] = 1.0e5                                    # outside the view: not looked at
     hip.check_channels(view)
     assert hip.read_range_flag() == 0
+
+
+def test_channel_gain_vector(hip):
+    """ops.channel_gain: per input channel sum |w| over the taps, max over the couts, normalised to the conv's largest input channel (over ALL of its
+    channels, also when only a slice is asked for), max over the convs."""
+    g = torch.Generator().manual_seed(3)
+    w1, w2 = torch.randn(8, 12, 3, 3, generator=g), torch.randn(5, 20, 3, 3, generator=g)
+    w1[:, 4] *= 64.0
+    def ref(w):
+        m = w.abs().double().sum(dim=(2, 3)).max(dim=0)[0]
+        return (m / m.max()).float()
+    got = hip.channel_gain((w1, 2, 10), (w2, 6, 14)).cpu()
+    want = torch.maximum(ref(w1)[2:10], ref(w2)[6:14])
+    assert torch.allclose(got, want, rtol=1e-6, atol=0) and float(got[2]) == 1.0 and float(got.min()) < 0.1

@@ -9,6 +9,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=int, default=5, choices=[3, 5])
     ap.add_argument("--top", type=int, default=40)
+    ap.add_argument("--batch", type=int, default=None)
     a = ap.parse_args()
     from bfsr_amd import synth
     from bfsr_amd.ops import HipOps
@@ -16,6 +17,8 @@ def main():
     from bfsr_amd.linf.models import make
     from bfsr_amd.linf.test import infer_from_lr
     B, h, scale, precision = (16, 256, 4.0, "fp32") if a.config == 3 else (128, 128, 6.0, "fp16")
+    if a.batch:
+        B = a.batch
     ops = HipOps("cuda:0")
     mspec = {"name": "linf-patch", "args": {"encoder_spec": {"name": "rrdb", "args": {"no_upsampling": True}},
                                              "imnet_spec": {"name": "flow", "args": {"name": "flow"}}, "flow_layers": 10, "num_layer": 3, "hidden_dim": 256}}
@@ -33,6 +36,14 @@ def main():
     x.add_(0.0)
     infer_from_lr(model, prior, x, scale)
     torch.cuda.synchronize()
+    import time
+    t0 = time.time()
+    for _ in range(5):
+        x.add_(0.0)
+        infer_from_lr(model, prior, x, scale)
+    th = time.time() - t0
+    torch.cuda.synchronize()
+    print("5 passes without events: host enqueue %.1f ms, wall %.1f ms per pass" % (th / 5 * 1e3, (time.time() - t0) / 5 * 1e3))
     rows = sorted(((sum(s.elapsed_time(e) for s, e in ev), len(ev), k) for k, ev in ops.profile.items()), reverse=True)
     print("total event time %.1f ms over %d launches" % (sum(r[0] for r in rows), sum(r[1] for r in rows)))
     for t, n, k in rows[:a.top]:

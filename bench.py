@@ -123,7 +123,22 @@ def launch_flop(k):
     return None
 
 
-def roof_entry(t, k, f, n, steps, step_ms, traffic_db):
+def rocprof_avg_ms(cfg, sym):
+    """Average duration of a kernel symbol in the committed rocprofv3 --kernel-trace --stats summary of this configuration (the latest
+    profiles/rNN*_cfg<cfg>_kernel_stats.csv), or (None, None).  Only meaningful for a launch shape that is the symbol's only one."""
+    import csv
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_cfg%d_kernel_stats.csv" % cfg)))
+    if not fs:
+        return None, None
+    base = sym.split("<")[0].split(" ")[0]
+    rows = [r for r in csv.DictReader(open(fs[-1])) if base in r.get("Name", "")]
+    if len(rows) != 1:
+        return None, None
+    return float(rows[0]["AverageNs"]) * 1e-6, os.path.basename(fs[-1])
+
+
+def roof_entry(t, k, f, n, steps, step_ms, traffic_db, cfg=None):
     sym, hw_peak, per_prod, arith = FAMILIES[k[0]]
     a = f / (t / n * 1e-3) / 1e12
     peak = hw_peak / per_prod
@@ -139,6 +154,14 @@ def roof_entry(t, k, f, n, steps, step_ms, traffic_db):
     if ent:
         e["traffic"] = ent["hbm_bytes_per_launch"]
         e["traffic_unit"] = ent.get("unit", "HBM-side bytes per launch (rocprofv3 FETCH_SIZE raw + WRITE_SIZE, profiles/)")
+    # the same fraction from the rocprofv3 average of the committed kernel-stats file (its launches are spaced by the profiler and run a few
+    # per cent slower than back to back under HIP events: both are printed)
+    if cfg is not None and k[0] in ("conv_chain",):
+        ms, src = rocprof_avg_ms(cfg, sym)
+        if ms:
+            e["avg_launch_ms_rocprof"] = round(ms, 4)
+            e["frac_rocprof"] = round(f / (ms * 1e-3) / 1e12 / peak, 4)
+            e["frac_rocprof_source"] = "profiles/%s (committed; rocprofv3 --kernel-trace --stats of this command)" % src
     return e
 
 
@@ -168,6 +191,10 @@ def main():
     from bfsr_amd import dist as bdist, synth
     from bfsr_amd.ops import HipOps
 
+    # the container's CPU quota (16 of the host's 256 hardware threads on the pool): torch's default intra-op pool (128 threads) gets the whole
+    # process throttled by the cgroup the moment any CPU tensor op runs (bfsr_amd/hostenv.py; measured: LINF passes 21 -> 21 / 57 / 96 ms at random)
+    from bfsr_amd import hostenv
+    host_threads = hostenv.cap_torch_threads()
     rank, world, local = bdist.init()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
@@ -323,7 +350,7 @@ def main():
         if f is not None:
             totals.append((sum(s_.elapsed_time(e_) for s_, e_ in ev), k, f, len(ev)))
     totals.sort(reverse=True)
-    roofline = roof_entry(*totals[0], args.steps, step_ms, traffic_db) if totals else None
+    roofline = roof_entry(*totals[0], args.steps, step_ms, traffic_db, cfg) if totals else None
     roofline_next = [roof_entry(*x, args.steps, step_ms, traffic_db) for x in totals[1:4]]
     by_symbol = [{"kernel": fam, "ms_per_step": round(t, 3), "share_of_event_time": round(t / warm_total_ms, 4)}
                  for fam, t in sorted(warm_by_family.items(), key=lambda kv: -kv[1])[:8]] if warm_total_ms else None
@@ -398,7 +425,7 @@ def main():
         ncpu = os.cpu_count() or 1
         # the oracle is a torch-CPU (MKL-DNN) program: measured on the GPU box's 256-core host it is fastest at 16 threads
         # (8/16/32/64/128 threads: 7.4 / 5.7 / 6.8 / 16.1 / 30.5 s per 160x160 crop, profiles/r03_cpu_thread_sweep.json)
-        nt = min(16, ncpu)
+        nt = min(16, ncpu, hostenv.effective_cpus())
         torch.set_num_threads(nt)
         if srflow:
             import numpy as np
@@ -465,7 +492,9 @@ def main():
                          "tests/test_hip_ops.py::test_conv_bf16x3_is_fp32_accurate; RRDB block activations are STORED as that exact split = lossless)")
             arithmetic = ("fp32 tensors and accumulation; 3x3 convs with >=32 input channels contract on the 16-bit matrix pipe with the "
                           + split_txt + "; everything else native fp32" if ops.conv_mode == "x3" else "native fp32 MFMA / fp32 VALU")
-            dtype = "f32"
+            dtype = ("f32" if ops.conv_mode != "x3" else
+                     "f32 (fp16x2-split operands: 22-bit hi + lo pairs on the fp16 MFMA, fp32 accumulate)" if getattr(ops, "split", "") == "f16x2" else
+                     "f32 (bf16x3-split operands: exact 24-bit triples on the bf16 MFMA, fp32 accumulate)")
         else:
             name = "LINF-LP rrdb-linf-LP x%g arbitrary-scale SR (%d->%d)" % (scale, h, H)
             path = "LP path: input prep + RRDB encoder + query_log_p + prior UNet + query_rgb + fold + skip + clamp"
@@ -474,7 +503,8 @@ def main():
                           "fp16 MFMA path (BASELINE config 5): encoder / coef|freq / MLP / prior contractions round their operands to fp16, "
                           "fp32 accumulation, fp32 tensors, the flow itself in fp32; tolerance vs the fp32 reference 1e-3 on the output "
                           "(tests/test_linf_gpu.py::test_fp16_mfma_path_vs_reference_golden)")
-            dtype = "f32" if cfg == 3 else "f16"
+            dtype = (("f32 (fp16x2-split operands: 22-bit hi + lo pairs on the fp16 MFMA, fp32 accumulate)" if getattr(ops, "split", "") == "f16x2" and ops.conv_mode == "x3"
+                      else "f32") if cfg == 3 else "f16")
         batch_txt = ("batch=%d/GPU" % B) if scaling == "weak" else ("named batch of %d crops sharded over %d GPU(s) = %d/GPU" % (global_B, world, B))
         line = {
             "metric": "HR MPix/s, %s, %s" % (name, "LP pipeline" if args.mode == "lp" or not srflow else path),
@@ -494,6 +524,7 @@ def main():
             # passes that the range guard of the fp16-pair split re-ran under the bf16x3 split (bfsr_amd/guard.py); the guard's 4-byte read-back at
             # the end of every pass is INSIDE the timed region
             "fallbacks": int(getattr(ops, "fallbacks", 0)),
+            "host": {"torch_threads": host_threads, "effective_cpus": hostenv.effective_cpus(), "cpu_count": os.cpu_count()},
         }
         if fp32_only is not None or cfg == 2:
             line["value_native_fp32_mfma"] = fp32_only

@@ -68,6 +68,10 @@ def run_guarded(hosts, fn):
     guarded = [o for o in opss if getattr(o, "split", None) == "f16x2" and getattr(o, "conv_mode", None) == "x3" and hasattr(o, "read_range_flag")]
     if not guarded or any(o._guard_depth for o in guarded) or any(h._fb_active for h in hosts):
         return fn()
+    from . import rng
+    # the pass may draw noise (SRFlow's tau path samples eps inside decode, LINF query_rgb with temperature > 0): a re-run must see the same draws
+    noise = [rng.snapshot(o.device) for o in guarded]
+    rewind = lambda: [rng.restore(st) for st in noise]
     for o in guarded:
         o._guard_depth += 1
         o.range_flag.zero_()
@@ -87,6 +91,7 @@ def run_guarded(hosts, fn):
             o.chain_disabled = True
             o.chain_timeouts = getattr(o, "chain_timeouts", 0) + 1
             o.range_flag.zero_()
+        rewind()
         out = fn()
         raised = 0
         for o in guarded:
@@ -98,6 +103,7 @@ def run_guarded(hosts, fn):
     for o in guarded:
         o.fallbacks += 1
         o.fallback_ops().range_flag.zero_()
+    rewind()
     with _fallback_engines(hosts):
         out = fn()
     bad = 0

@@ -11,6 +11,7 @@ from ..ops import MODE_BILINEAR
 from .utils import make_coord
 
 _coord_cache = {}
+_dev_cache = {}     # (device, B, H, W, ps, always_pad) -> (coord [B,qh,qw,2], cell [B,2]) on the device
 
 
 def patch_grid(H, W, ps=3, always_pad=True):
@@ -30,6 +31,23 @@ def patch_grid(H, W, ps=3, always_pad=True):
     return _coord_cache[key]
 
 
+def _device_grid(ops, key, make, B, H, W):
+    """The batch-expanded coordinate grid and cell of a (batch, HR size) on the device, built once per shape: they depend on nothing else, and
+    rebuilding them per pass was a CPU tensor op (a 128-thread OpenMP region on the pool's hosts: see hostenv.py) plus two pageable host-to-device
+    copies that drained the launch queue at the start of every pass (2.5 ms each at 16 x 257 x 257; they also made the pass impossible to capture
+    in a HIP graph).  Treated as read-only by every consumer."""
+    key = (str(ops.device),) + key
+    hit = _dev_cache.get(key)
+    if hit is None:
+        if len(_dev_cache) > 32:
+            _dev_cache.clear()
+        c = make()
+        coord = ops.to_device(c.unsqueeze(0).expand(B, c.shape[0], c.shape[1], 2).contiguous())
+        cell = ops.to_device(torch.tensor([[2 / H, 2 / W]], dtype=torch.float32).expand(B, 2).contiguous())
+        hit = _dev_cache[key] = (coord, cell)
+    return hit
+
+
 def prepare_batch_pixelwise(ops, inp01, hr_hw):
     """The non-patch wrapper `SRImplicitPairedFast` (datasets/wrappers.py:92-152): coord = the full HR pixel grid,
     gt_lr_up = the LR-upsample residual [B,3,H,W]."""
@@ -40,8 +58,7 @@ def prepare_batch_pixelwise(ops, inp01, hr_hw):
     down = ops.resize(lr_up, ops.empty(B, 3, h, w), MODE_BILINEAR, float(H) / h, float(W) / w)
     up2 = ops.resize(down, ops.empty(B, 3, H, W), MODE_BILINEAR, float(h) / H, float(w) / W)
     res = ops.axpb_clamp(up2, up2, -1.0, 0.0, r=lr_up)
-    coord = ops.to_device(make_coord([H, W], flatten=False).unsqueeze(0).expand(B, H, W, 2).contiguous())
-    cell = ops.to_device(torch.tensor([[2 / H, 2 / W]], dtype=torch.float32).expand(B, 2).contiguous())
+    coord, cell = _device_grid(ops, ("pix", B, H, W), lambda: make_coord([H, W], flatten=False), B, H, W)
     return dict(inp=inp01, coord=coord, cell=cell, gt_lr_up=res)
 
 
@@ -57,6 +74,5 @@ def prepare_batch(ops, inp01, hr_hw, ps=3, always_pad=True):
     up2 = ops.resize(down, ops.empty(B, 3, H, W), MODE_BILINEAR, float(h) / H, float(w) / W)
     res = ops.axpb_clamp(up2, up2, -1.0, 0.0, r=lr_up)                               # lr_up - up(down(lr_up))
     gt = ops.patch_unfold(res, ops.empty(B, 3 * ps * ps, qh, qw), ps)
-    coord_b = ops.to_device(coord.unsqueeze(0).expand(B, qh, qw, 2).contiguous())
-    cell = ops.to_device(torch.tensor([[2 / H, 2 / W]], dtype=torch.float32).expand(B, 2).contiguous())
+    coord_b, cell = _device_grid(ops, ("patch", B, H, W, ps, bool(always_pad)), lambda: coord, B, H, W)
     return dict(inp=inp01, coord=coord_b, cell=cell, gt_lr_up=gt)

@@ -24,3 +24,20 @@ def randn(shape, device):
                 raise ValueError("noise source returned shape %s for a request of %s" % (tuple(t.shape), shape))
             return t.to(device=device, dtype=torch.float32)
     return torch.randn(*shape, device=device, dtype=torch.float32)
+
+
+def snapshot(device):
+    """State of the default noise source (the device's Philox generator) -- guard.run_guarded takes it before a guarded pass and restores it before
+    a re-run, so that a pass repeated under the bf16x3 split (or on per-conv launches) draws the SAME noise: the returned sample stays reproducible
+    from the seed.  An injected source (`set_source`) is the caller's to rewind: None."""
+    if _source is not None:
+        return None
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return None
+    return (dev, torch.cuda.get_rng_state(dev))
+
+
+def restore(state):
+    if state is not None:
+        torch.cuda.set_rng_state(state[1], state[0])

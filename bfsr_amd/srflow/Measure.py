@@ -3,8 +3,12 @@ networks, computed on the device from uint8 HWC images: `psnr` (skimage's `peak_
 inputs) and `ssim` (skimage's 7x7 uniform-window `structural_similarity`; the restatement it is tested against is unpinned -- scikit-image
 is not in this image, oracle/metrics_ref.py says so).  LPIPS needs the pretrained AlexNet weights (a download): `measure` keeps the
 reference's three-element return value with NaN in the LPIPS slot (INTEGRATION.md lists the deviation); `lpips` itself raises."""
+import warnings
+
 import numpy as np
 import torch
+
+_warned_lpips = False
 
 
 class Measure(object):
@@ -43,5 +47,10 @@ class Measure(object):
         so drop-in callers that unpack three values keep working.  with_lpips=False returns [psnr, ssim]."""
         out = [float(self.psnr(imgA, imgB)), float(self.ssim(imgA, imgB))]
         if with_lpips:
+            global _warned_lpips
+            if not _warned_lpips:           # once per process: a NaN column in the caller's CSV must not pass for a computed metric
+                _warned_lpips = True
+                warnings.warn("bfsr_amd Measure.measure: LPIPS is NOT computed (pretrained AlexNet weights are a download) -- the third value is NaN; "
+                              "pass with_lpips=False for [psnr, ssim]", RuntimeWarning, stacklevel=2)
             out.append(float("nan"))
         return out

@@ -20,7 +20,8 @@ def _cpu_threads():
     """The CPU oracle runs in many tests; on the 256-thread hosts of the GPU boxes torch's default (all threads) is 3-5x SLOWER than 16
     (profiles/r03_cpu_thread_sweep.json: 5.7 s at 16 threads, 16 s at 64, 30 s at 128 for one 160 x 160 crop)."""
     import torch
-    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    from bfsr_amd import hostenv
+    torch.set_num_threads(max(1, min(16, hostenv.effective_cpus())))       # (and never more than the container's CPU quota: hostenv.py)
     yield
 
 

@@ -94,6 +94,35 @@ class BfsrCouplingTailArgs(C.Structure):
     ]
 
 
+class BfsrWideHeadArgs(C.Structure):
+    _fields_ = [
+        ("z1", C.c_void_p), ("z1_bs", C.c_longlong), ("Cz", C.c_int),
+        ("w0", C.c_void_p), ("acc_scale0", C.c_float),
+        ("pre", C.c_void_p), ("pre_bs", C.c_longlong),
+        ("w2", C.c_void_p), ("acc_scale2", C.c_float),
+        ("epi0", C.c_void_p), ("epi2", C.c_void_p),
+        ("hid", C.c_void_p), ("hid_bs", C.c_longlong),
+        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("flag", C.c_void_p),
+    ]
+
+
+class BfsrWideTailArgs(C.Structure):
+    _fields_ = [
+        ("hid", C.c_void_p), ("hid_bs", C.c_longlong),
+        ("w", C.c_void_p), ("acc_scale", C.c_float),
+        ("bias", C.c_void_p), ("post_scale", C.c_void_p),
+        ("z_in", C.c_void_p), ("z_in_bs", C.c_longlong),
+        ("z_out", C.c_void_p), ("z_out_bs", C.c_longlong),
+        ("h_ft", C.c_void_p), ("h_ft_bs", C.c_longlong), ("h_ft_fmt", C.c_int),
+        ("wperm", C.c_void_p), ("an_bias", C.c_void_p), ("an_escale", C.c_void_p),
+        ("z1h", C.c_void_p), ("z1h_bs", C.c_longlong),
+        ("B", C.c_int), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("reverse", C.c_int),
+        ("eps", C.c_float),
+        ("flag", C.c_void_p),
+    ]
+
+
 class BfsrLinfFeatArgs(C.Structure):
     _fields_ = [
         ("cf", C.c_void_p), ("cf_bs", C.c_longlong),
@@ -193,6 +222,13 @@ SYMBOLS = {
     "bfsr_coupling_tail_packed_size": (_LL, [_I, _I]),
     "bfsr_pack_coupling_tail": (_I, [_VP, _I, _I, C.c_float, _VP]),
     "bfsr_conv3x3_h2r": (_I, [C.POINTER(BfsrConvX3Args), _VP]),
+    "bfsr_coupling_wide_head": (_I, [C.POINTER(BfsrWideHeadArgs), _VP]),
+    "bfsr_coupling_wide_tail": (_I, [C.POINTER(BfsrWideTailArgs), _VP]),
+    "bfsr_coupling_wide_conv_packed_size": (_LL, [_I, _I]),
+    "bfsr_pack_coupling_wide_conv": (_I, [_VP, _I, _I, C.c_float, _VP]),
+    "bfsr_coupling_wide_w2_packed_size": (_LL, []),
+    "bfsr_pack_coupling_wide_w2": (_I, [_VP, C.c_float, _VP]),
+    "bfsr_pack_coupling_wide_wmat": (_I, [_VP, _VP]),
     "bfsr_conv2d_up2_h2t": (_I, [C.POINTER(BfsrUp2H2Args), _VP]),
     "bfsr_conv_up2_h2t_packed_size": (_LL, [_I, _I, _I]),
     "bfsr_pack_conv_up2_h2t": (_I, [_VP, _VP, _I, _I, _I, C.c_float, _VP]),
@@ -245,7 +281,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.bfsr_abi_version() != 6:
+    if lib.bfsr_abi_version() != 7:
         raise RuntimeError("bfsr_amd: ABI version mismatch")
     _lib = lib
     return lib

@@ -904,6 +904,78 @@ class HipOps(object):
         _lib.check(self._launch(key, lambda: self.lib.bfsr_coupling_tail(C.byref(a), self._stream())), "coupling_tail(C=%d)" % Cc)
         return z_out
 
+    # ---- the coupled FlowStep of the wide level (C = 96) as two streaming kernels (coupling_wide.hip, round 6) ----------------------
+    def pack_coupling_wide(self, w0_z1, w2, shift0, scale0, shift2, scale2, w4, bias4, post4):
+        """fAffine.0 restricted to the z1 rows [64,Cz,3,3], fAffine.2 [64,64(,1,1)] with their ActNorm (bias, exp(logs)) vectors, and fAffine.4
+        (Conv2dZeros [96,64,3,3], bias, exp(3*logs)): two-term fp16 splits of w * 2^k in the layouts the two kernels stream / keep resident."""
+        w0 = w0_z1.detach().to("cpu", torch.float32).contiguous()
+        w2 = w2.detach().to("cpu", torch.float32).reshape(64, 64).contiguous()
+        w4 = w4.detach().to("cpu", torch.float32).contiguous()
+        Cz = w0.shape[1]
+        if w0.shape[0] != 64 or Cz % 16 or tuple(w4.shape) != (96, 64, 3, 3):
+            raise ValueError("pack_coupling_wide: unsupported shapes %s %s" % (tuple(w0.shape), tuple(w4.shape)))
+        s0, s2, s4 = self.pow2_scale(w0), self.pow2_scale(w2), self.pow2_scale(w4)
+        p0 = torch.empty(self.lib.bfsr_coupling_wide_conv_packed_size(64, Cz), dtype=torch.int16)
+        _lib.check(self.lib.bfsr_pack_coupling_wide_conv(w0.data_ptr(), 64, Cz, s0, p0.data_ptr()), "pack_coupling_wide_conv(0)")
+        p2 = torch.empty(self.lib.bfsr_coupling_wide_w2_packed_size(), dtype=torch.int16)
+        _lib.check(self.lib.bfsr_pack_coupling_wide_w2(w2.data_ptr(), s2, p2.data_ptr()), "pack_coupling_wide_w2")
+        p4 = torch.empty(self.lib.bfsr_coupling_wide_conv_packed_size(96, 64), dtype=torch.int16)
+        _lib.check(self.lib.bfsr_pack_coupling_wide_conv(w4.data_ptr(), 96, 64, s4, p4.data_ptr()), "pack_coupling_wide_conv(4)")
+
+        def epi(shift, scale):
+            e = torch.zeros(64, 4, dtype=torch.float32)
+            e[:, 0] = shift.detach().reshape(-1).to("cpu", torch.float32)
+            e[:, 1] = scale.detach().reshape(-1).to("cpu", torch.float32)
+            return e.to(self.device)
+        return dict(Cz=Cz, w0=p0.to(self.device), as0=1.0 / s0, w2=p2.to(self.device), as2=1.0 / s2, e0=epi(shift0, scale0), e2=epi(shift2, scale2),
+                    w4=p4.to(self.device), as4=1.0 / s4, bias=self.vec(bias4), ps=self.vec(post4))
+
+    def pack_wide_wmat(self, w):
+        """A [96,96] matrix of the invertible 1x1 conv with its K axis in the order coupling_wide_tail contracts it."""
+        w = w.detach().to("cpu", torch.float32).contiguous()
+        if tuple(w.shape) != (96, 96):
+            raise ValueError("pack_wide_wmat: [96, 96] only")
+        out = torch.empty(96 * 96, dtype=torch.float32)
+        _lib.check(self.lib.bfsr_pack_coupling_wide_wmat(w.data_ptr(), out.data_ptr()), "pack_coupling_wide_wmat")
+        return out.to(self.device)
+
+    def coupling_wide_head(self, z1h, packed, pre_h2, hid):
+        """hid (h2, 64 ch) = relu(AN2(W2 . relu(AN0(conv3x3(z1h) + pre_h2)))): z1h = h2 view of the step's z1 channels, pre_h2 = h2 view (64 ch)."""
+        a = _lib.BfsrWideHeadArgs()
+        a.z1, a.z1_bs, Cz, H, W = self._h2view(z1h, "coupling_wide_head.z1h")
+        a.pre, a.pre_bs, c1, h1, w1 = self._h2view(pre_h2, "coupling_wide_head.pre")
+        a.hid, a.hid_bs, c2, h2, w2 = self._h2view(hid, "coupling_wide_head.hid")
+        if Cz != packed["Cz"] or (c1, h1, w1) != (64, H, W) or (c2, h2, w2) != (64, H, W):
+            raise ValueError("coupling_wide_head: shape mismatch z1h%s pre%s hid%s" % (tuple(z1h.shape), tuple(pre_h2.shape), tuple(hid.shape)))
+        a.Cz, a.w0, a.acc_scale0, a.w2, a.acc_scale2 = Cz, packed["w0"].data_ptr(), packed["as0"], packed["w2"].data_ptr(), packed["as2"]
+        a.epi0, a.epi2 = packed["e0"].data_ptr(), packed["e2"].data_ptr()
+        a.B, a.H, a.W, a.flag = z1h.shape[0], H, W, self.range_flag.data_ptr()
+        key = ("coupling_wide_head", Cz, z1h.shape[0], H, W)
+        _lib.check(self._launch(key, lambda: self.lib.bfsr_coupling_wide_head(C.byref(a), self._stream())), "coupling_wide_head")
+        return hid
+
+    def coupling_wide_tail(self, hid, packed, z_in, z_out, reverse, h_ft=None, w=None, an_bias=None, an_escale=None, eps=1e-4, h_ft_fmt=0, z1h=None):
+        """h_aff = Conv2dZeros(hid) (64 -> 96), then flow_pointwise(z_in, z_out, reverse, h_aff, h_ft, w, an_*) as the conv's epilogue;
+        `w` = pack_wide_wmat(W) (None: no matvec, forward only); z1h (optional h2 view, 48 ch) receives the first 48 result channels."""
+        a = _lib.BfsrWideTailArgs()
+        a.hid, a.hid_bs, cin, H, W = self._h2view(hid, "coupling_wide_tail.hid")
+        a.z_in, a.z_in_bs, Cc, h1, w1 = _view(z_in, "coupling_wide_tail.z_in")
+        a.z_out, a.z_out_bs, c2, h2, w2 = _view(z_out, "coupling_wide_tail.z_out")
+        assert cin == 64 and (Cc, h1, w1) == (c2, h2, w2) == (96, H, W)
+        if h_ft is not None:
+            a.h_ft, a.h_ft_bs, c, h, ww = _view(h_ft, "coupling_wide_tail.h_ft")
+            assert (c, h, ww) == (2 * Cc, H, W)
+        if z1h is not None:
+            a.z1h, a.z1h_bs, c, h, ww = self._h2view(z1h, "coupling_wide_tail.z1h")
+            assert (c, h, ww) == (48, H, W)
+        a.w, a.acc_scale, a.bias, a.post_scale = packed["w4"].data_ptr(), packed["as4"], packed["bias"].data_ptr(), packed["ps"].data_ptr()
+        a.wperm, a.an_bias, a.an_escale = _ptr(w), _ptr(an_bias), _ptr(an_escale)
+        a.B, a.C, a.H, a.W, a.reverse, a.eps, a.h_ft_fmt = z_in.shape[0], Cc, H, W, int(bool(reverse)), eps, int(h_ft_fmt)
+        a.flag = self.range_flag.data_ptr()
+        key = ("coupling_wide_tail", int(bool(reverse)), z_in.shape[0], H, W, h_ft is not None, w is not None, z1h is not None)
+        _lib.check(self._launch(key, lambda: self.lib.bfsr_coupling_wide_tail(C.byref(a), self._stream())), "coupling_wide_tail")
+        return z_out
+
     def conv_h2r(self, x, packed, out, epi=None, act=ACT_NONE, slope=0.2, y_fmt=0):
         """3x3 conv 64 -> Cout <= 32 over the h2 tensor `x` on the coupling tail's conv kernel (coupling_tail.hip, plain epilogue);
         `packed` = pack_coupling_tail(w, ...) (only its weights and scale are used here); out fp32 NCHW or, y_fmt=1, quad-major."""

@@ -386,6 +386,8 @@ class SRFlowEngine(object):
         self._cond_key, self._cond = None, None
         self._side_stream = None
         self._hid = {}                  # h2 tensors between coupling_head and coupling_tail, per (direction, level)
+        self._wide_w = {}               # data_ptr of a step's W / W^-1 -> its K-permuted copy for coupling_wide_tail
+        self._z1h_next = {}             # tag -> (z.data_ptr(), layer index): the h2 copy of z1 the last wide tail wrote is valid for exactly that step
         self._load(sd)
 
     # ------------------------------------------------------------------------------------------
@@ -423,6 +425,9 @@ class SRFlowEngine(object):
                 st.an_expneg = ops.vec(torch.exp(-logs))
                 # per-pixel logdet of actnorm + invconv (FlowActNorms.py:85-91, Permutations.py:37)
                 st.ld_const = float(logs.double().sum()) + float(torch.slogdet(W.detach().cpu().double())[1])
+                if C == 96 and hasattr(ops, "pack_wide_wmat"):          # the K-permuted copies coupling_wide_tail contracts (coupled or not: a tail applies the NEXT step's W in encode)
+                    self._wide_w[st.w_fwd.data_ptr()] = ops.pack_wide_wmat(W)
+                    self._wide_w[st.w_inv.data_ptr()] = ops.pack_wide_wmat(Winv)
                 if ly.coupled:
                     cn = C // 2
                     a = p + "affine.fAffine."
@@ -459,6 +464,14 @@ class SRFlowEngine(object):
                                     ops.pack_coupling_head(None, sd[a + "2.weight"], sd[a + "0.actnorm.bias"], torch.exp(sd[a + "0.actnorm.logs"]),
                                                            sd[a + "2.actnorm.bias"], torch.exp(sd[a + "2.actnorm.logs"])),
                                     ops.pack_conv_x3(sd[a + "4.weight"], 1, lazy=True), st.aff4.epi)
+                    # Round 6: the same step as TWO streaming kernels (coupling_wide.hip): split 3x3 on the h2 copy of z1 + hoisted partial + 1x1 chained in
+                    # registers -> hid (h2); Conv2dZeros 64 -> 96 with the whole pointwise chain as its epilogue, which also hands the next step its z1
+                    # as an h2 tensor.  Five launches -> two per step (BFSR_WIDE=0 keeps the launches above; the log-det paths always do).
+                    st.wide = None
+                    if (st.chain is not None and C == 96 and hasattr(ops, "coupling_wide_head") and os.environ.get("BFSR_WIDE", "1") != "0"):
+                        st.wide = ops.pack_coupling_wide(w0[:, :cn].contiguous(), sd[a + "2.weight"], sd[a + "0.actnorm.bias"], torch.exp(sd[a + "0.actnorm.logs"]),
+                                                         sd[a + "2.actnorm.bias"], torch.exp(sd[a + "2.actnorm.logs"]), sd[a + "4.weight"], sd[a + "4.bias"],
+                                                         torch.exp(sd[a + "4.logs"] * 3))
                     f = p + "affine.fFeatures."
                     st.ft0_w = sd[f + "0.weight"]
                     st.ft0_shift = sd[f + "0.actnorm.bias"].reshape(-1)
@@ -506,6 +519,11 @@ class SRFlowEngine(object):
                 return (pv is not None and pv.type == "step" and pv.coupled and pv.level == level
                         and getattr(self.steps[pv.index], "fused", False))
             hz["hft_q4"] = set(i for i in idxs if getattr(self.steps[i], "fused", False) and _prev_is_fused_step(i))
+            def _prev_is_wide_step(i):
+                pv = self.layers[pos_of[i] - 1] if pos_of[i] > 0 else None
+                return (pv is not None and pv.type == "step" and pv.coupled and pv.level == level and getattr(self.steps[pv.index], "wide", None) is not None)
+            # ... and the same for the wide level's streaming pair (only while the level's pre_aff is an h2 tensor: see _hoist_level)
+            hz["hft_q4_wide"] = set(i for i in idxs if getattr(self.steps[i], "wide", None) is not None and _prev_is_wide_step(i))
             # (the register-staged x4 taps kernel has no quad-major epilogue: without conv_up4_h2t the raw fFeatures.0 result of that level stays
             # NCHW and the 1x1-only head reads it so)
             h4t_ok = (self._taps_up2(level) == 2 and getattr(ops, "conv_mode", "f32") == "x3" and getattr(ops, "split", "") == "f16x2"
@@ -768,7 +786,7 @@ class SRFlowEngine(object):
         # fused and its producers can (the register-staged x4 taps kernel cannot, conv_up4_h2t can); h_ft per step (each step's Conv2dZeros writes its own slice) when the
         # step's h_ft is only ever read by coupling_tail -- i.e. not by flow_pointwise as the first step of an encode pass
         pq = int(quads and hz.get("pre_q4", False))
-        hq = {i: int(quads and i in hz.get("hft_q4", ())) for i in hz["idxs"]}
+        hq = {i: int(quads and (i in hz.get("hft_q4", ()) or (i in hz.get("hft_q4_wide", ()) and level in self._pre_h2))) for i in hz["idxs"]}
         kq = dict(y_fmt=1) if pq else {}
         ff = bool(hz.get("ffast")) and hz.get("x3", True) is not False
         h4t = hz.get("h4t") if (ff and pq and hz.get("x3s") and hz.get("up2") and hz.get("up") == 2) else None
@@ -901,10 +919,47 @@ class SRFlowEngine(object):
         st.aff4.run(ops, hid, h_aff)
         return h_aff
 
-    def _pair(self, st, z, pre_k, tag, reverse, kw, pre_fmt=0):
+    def _pairs(self, st, cnd, logdet=None):
+        """Does this coupled step run as a head / tail kernel pair (levels 1 / 2: coupling.hip + coupling_tail.hip; the wide level: coupling_wide.hip)?"""
+        if logdet is not None:
+            return False
+        return bool(getattr(st, "fused", False)) or (getattr(st, "wide", None) is not None and cnd.get("pre_h2") is not None)
+
+    def _wide_info(self, st, cnd, k, ly, nxt):
+        """What the wide pair needs beyond the pair's arguments: the h2 view of the hoisted partial, this step's layer index and -- when the step that
+        runs next on this z is another wide step -- that step's index (the tail then writes its z1 as an h2 tensor)."""
+        if getattr(st, "wide", None) is None or cnd.get("pre_h2") is None:
+            return None
+        nx = None
+        if nxt is not None and nxt.type == "step" and nxt.coupled and nxt.level == ly.level and getattr(self.steps[nxt.index], "wide", None) is not None:
+            nx = nxt.index
+        return dict(pre_h2=cnd["pre_h2"][:, 8 * k: 8 * (k + 1)], idx=ly.index, nxt=nx)
+
+    def _pair(self, st, z, pre_k, tag, reverse, kw, pre_fmt=0, wide=None):
         """coupling_head -> coupling_tail, in place on z; `hid` travels between them as an h2 tensor (fp16 hi + lo planes)."""
         ops = self.ops
         B, _, H, W = z.shape
+        if wide is not None:
+            cn = st.wide["Cz"]
+            zk = "z1h_" + tag
+            zh = self._hid.get(zk)
+            if zh is None or tuple(zh.shape) != (B, cn // 8, 2, H, W, 8):
+                zh = self._hid[zk] = ops.h2_empty(B, cn, H, W)
+                self._z1h_next.pop(tag, None)
+            if self._z1h_next.pop(tag, None) != (z.data_ptr(), wide["idx"]):
+                ops.h2_pack(z[:, :cn], zh)                  # first wide step of a run: the previous kernel on z was not a wide tail
+            hk = "hidc_" + tag
+            hid = self._hid.get(hk)
+            if hid is None or tuple(hid.shape) != (B, 8, 2, H, W, 8):
+                hid = self._hid[hk] = ops.h2_empty(B, 64, H, W)
+            ops.coupling_wide_head(zh, st.wide, wide["pre_h2"], hid)
+            kw = dict(kw)
+            if kw.get("w") is not None:
+                kw["w"] = self._wide_w[kw["w"].data_ptr()]
+            ops.coupling_wide_tail(hid, st.wide, z, z, reverse, z1h=zh if wide["nxt"] is not None else None, **kw)
+            if wide["nxt"] is not None:
+                self._z1h_next[tag] = (z.data_ptr(), wide["nxt"])
+            return z
         key = "hid_" + tag
         hid = self._hid.get(key)
         if hid is None or tuple(hid.shape) != (B, 8, 2, H, W, 8):
@@ -970,7 +1025,7 @@ class SRFlowEngine(object):
                     pending = None
                     yield
                 head_done = False
-                if getattr(st, "fused", False):
+                if self._pairs(st, cnd):
                     nxt = run[n + 1] if n + 1 < len(run) else None      # (the layer behind a whole-level run is never a step)
                     kw = {}
                     if nxt is not None:
@@ -981,7 +1036,7 @@ class SRFlowEngine(object):
                             kw["h_ft"] = cnd["h_ft"][:, 2 * ly.C * kn: 2 * ly.C * (kn + 1)]
                             kw["h_ft_fmt"] = cnd["h_ft_fmt"][nxt.index]
                         head_done = True
-                    self._pair(st, zl, cnd["pre_aff"][:, 64 * k: 64 * (k + 1)], tag, False, kw, cnd["pre_fmt"])
+                    self._pair(st, zl, cnd["pre_aff"][:, 64 * k: 64 * (k + 1)], tag, False, kw, cnd["pre_fmt"], wide=self._wide_info(st, cnd, k, ly, nxt))
                 else:
                     pending = self._self_cond(st, zl, cnd, k, tag)
                 yield
@@ -999,16 +1054,17 @@ class SRFlowEngine(object):
         ops = self.ops
         zl = z[b0:b1]
         C = zl.shape[1]
-        for ly in run:
+        for n, ly in enumerate(run):
             st = self.steps[ly.index]
             tag = "dec%d_l%d" % (ly.level, lane)
             if ly.coupled:
                 cnd = self._lane_cond(self._await(cond[ly.level]), b0, b1)
                 k = cnd["slot"][ly.index]
-                if getattr(st, "fused", False):
+                if self._pairs(st, cnd):
                     kw = dict(h_ft=cnd["h_ft"][:, 2 * C * k: 2 * C * (k + 1)], h_ft_fmt=cnd["h_ft_fmt"][ly.index], w=st.w_inv,
                               an_bias=st.an_bias, an_escale=st.an_expneg)
-                    self._pair(st, zl, cnd["pre_aff"][:, 64 * k: 64 * (k + 1)], tag, True, kw, cnd["pre_fmt"])
+                    nxt = run[n + 1] if n + 1 < len(run) else None      # the step that runs next (the run walks the layers backwards)
+                    self._pair(st, zl, cnd["pre_aff"][:, 64 * k: 64 * (k + 1)], tag, True, kw, cnd["pre_fmt"], wide=self._wide_info(st, cnd, k, ly, nxt))
                     yield
                 else:
                     h_aff = self._self_cond(st, zl, cnd, k, tag)
@@ -1061,7 +1117,7 @@ class SRFlowEngine(object):
                                            w=st.w_fwd, wt=st.w_fwd_t, h_ft=cnd["h_ft"][:, 2 * ly.C * k: 2 * ly.C * (k + 1)])
                         pending = None
                     head_done = False
-                    if getattr(st, "fused", False) and logdet is None:
+                    if self._pairs(st, cnd, logdet):
                         # the tail applies this step's self-conditional affine and, when the next layer is another step of this
                         # level, that step's head (what the generic path does lazily through `pending`)
                         nxt = self.layers[pos + 1] if pos + 1 < len(self.layers) else None
@@ -1075,7 +1131,7 @@ class SRFlowEngine(object):
                                 kw["h_ft_fmt"] = cnd["h_ft_fmt"][nxt.index]
                             head_done = True
                         pre_k = cnd["pre_aff"][:, 64 * k: 64 * (k + 1)]
-                        z = self._pair(st, z, pre_k, "enc%d" % ly.level, False, kw, cnd["pre_fmt"])
+                        z = self._pair(st, z, pre_k, "enc%d" % ly.level, False, kw, cnd["pre_fmt"], wide=self._wide_info(st, cnd, k, ly, nxt))
                     else:
                         pending = self._self_cond(st, z, cnd, k, "enc%d" % ly.level)
                         if logdet is not None:
@@ -1145,11 +1201,12 @@ class SRFlowEngine(object):
                 if ly.coupled:
                     cnd = self._await(cond[ly.level])
                     k = cnd["slot"][ly.index]
-                    if getattr(st, "fused", False) and logdet is None:
+                    if self._pairs(st, cnd, logdet):
                         pre_k = cnd["pre_aff"][:, 64 * k: 64 * (k + 1)]
                         kw = dict(h_ft=cnd["h_ft"][:, 2 * C * k: 2 * C * (k + 1)], h_ft_fmt=cnd["h_ft_fmt"][ly.index], w=st.w_inv,
                                   an_bias=st.an_bias, an_escale=st.an_expneg)
-                        z = self._pair(st, z, pre_k, "dec%d" % ly.level, True, kw, cnd["pre_fmt"])
+                        z = self._pair(st, z, pre_k, "dec%d" % ly.level, True, kw, cnd["pre_fmt"],
+                                       wide=self._wide_info(st, cnd, k, ly, self.layers[pos - 1] if pos > 0 else None))
                     else:
                         h_aff = self._self_cond(st, z, cnd, k, "dec%d" % ly.level)
                         if logdet is not None:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BFSR_ABI_VERSION 6      /* 6 (round 6): bfsr_channel_range_check per sample + gain / ratio arguments, bfsr_channel_range_scratch(B, C); bfsr_conv_chain_progress_words counts the give-up word.  5 (round 5, last): BfsrConvX3Args.up4 / up4_bs appended, bfsr_conv2d_up4_h2t y_fmt 3 (compact output).  4 (round 5, late): BfsrLinfMlpArgs.cf_fmt appended; bfsr_conv2d_up4_h2t and its pack functions added.  3 (round 5): BfsrChainConv + the chain entry points, bfsr_channel_range_*, BfsrLinfMlpArgs.flag.  2 (round 4): BfsrConvArgs / BfsrConvX3Args grew y_fmt + flag, coupling head / tail structs redefined, bfsr_conv2d_up2_h2t, bfsr_h2_pack_s2d, bfsr_ssim_sum_w added, the step / up2_h2x entry points removed */
+#define BFSR_ABI_VERSION 7      /* 7 (round 6): bfsr_coupling_wide_head / _tail (the coupled FlowStep of the C = 96 level as two streaming kernels) and their pack functions added.  6 (round 6): bfsr_channel_range_check per sample + gain / ratio arguments, bfsr_channel_range_scratch(B, C); bfsr_conv_chain_progress_words counts the give-up word.  5 (round 5, last): BfsrConvX3Args.up4 / up4_bs appended, bfsr_conv2d_up4_h2t y_fmt 3 (compact output).  4 (round 5, late): BfsrLinfMlpArgs.cf_fmt appended; bfsr_conv2d_up4_h2t and its pack functions added.  3 (round 5): BfsrChainConv + the chain entry points, bfsr_channel_range_*, BfsrLinfMlpArgs.flag.  2 (round 4): BfsrConvArgs / BfsrConvX3Args grew y_fmt + flag, coupling head / tail structs redefined, bfsr_conv2d_up2_h2t, bfsr_h2_pack_s2d, bfsr_ssim_sum_w added, the step / up2_h2x entry points removed */
 
 enum { BFSR_ACT_NONE = 0, BFSR_ACT_RELU = 1, BFSR_ACT_LRELU = 2 };
 
@@ -325,6 +325,53 @@ int bfsr_pack_coupling_tail(const float* w4, int Cin, int Cout, float scale, uns
  * quad-major [B][Cout/4][H][W][4] (y_fmt 2); a->epi / act / slope as for bfsr_conv2d; no residuals.
  * bfsr_coupling_head with Cz = 0 (w0 = NULL at pack time, z = NULL) is the matching producer: hid = relu(AN2(W2 . relu(AN0(pre_aff)))). */
 int bfsr_conv3x3_h2r(const BfsrConvX3Args* a, void* stream);
+
+/* ---- the coupled FlowStep of the WIDE level (C = 96 flow channels, level 3 of both SRFlow-LP models) as two streaming kernels (round 6,
+ * coupling_wide.hip).  Same reference code as bfsr_coupling_head / _tail (FlowAffineCouplingsAblation.py:57-135, FlowStep.py:88-129,
+ * flow.py:26-83, Permutations.py:37-58, FlowActNorms.py:61-113); what differs is the machine mapping: fAffine.0 on 48 z1 channels and fAffine.4
+ * (64 -> 96) do not fit LDS, so both kernels stream their weights chunk by chunk the way bfsr_conv3x3_h2x does (same two-term fp16 split, same
+ * summation order per output pixel: the conv results are bit-identical to that entry point's), with ALL output channels of an 8 x 32 tile in one
+ * workgroup.
+ *   bfsr_coupling_wide_head: hid = relu(AN2(W2 . relu(AN0(conv3x3(z1; W0z) + pre))))  -- z1: h2 view of the step's first Cz = 48 channels
+ *       (written by the previous step's tail, or by bfsr_h2_pack), pre: h2 view (64 channels) of the hoisted partial, read as hi + lo;
+ *       w0 = bfsr_pack_coupling_wide_conv(fAffine.0[:, :Cz], 64, Cz, scale0), w2 = bfsr_pack_coupling_wide_w2(fAffine.2, scale2), epi0 / epi2 as
+ *       for bfsr_coupling_head; hid: h2 tensor (64 channels).
+ *   bfsr_coupling_wide_tail: h_aff = (conv3x3(hid; W4) + bias) * post_scale, then the pointwise chain of bfsr_flow_pointwise with that h_aff
+ *       (same argument meaning: z_in / z_out (may alias), h_ft (+ h_ft_fmt 1: quad-major [B][2C/4][H][W][4]), an_bias / an_escale, reverse, eps);
+ *       the C x C matrix is passed as wperm = bfsr_pack_coupling_wide_wmat(W) (K axis in the order the kernel contracts it; NULL = no matvec,
+ *       forward only: the last step of a level); w = bfsr_pack_coupling_wide_conv(fAffine.4, 96, 64, scale), acc_scale = 1/scale.
+ *       z1h (optional): the first 48 channels of the result once more as an h2 view -- the next step's z1.
+ *   flag: bit 0 = a value handed to the fp16 split is out of range, bit 1 = the flow state left the finite range. */
+typedef struct BfsrWideHeadArgs {
+    const unsigned short* z1; long long z1_bs; int Cz;
+    const unsigned short* w0; float acc_scale0;
+    const unsigned short* pre; long long pre_bs;
+    const unsigned short* w2; float acc_scale2;
+    const float* epi0; const float* epi2;             /* [64] float4 {ActNorm shift, scale, 0, 0} of fAffine.0 / fAffine.2 */
+    unsigned short* hid; long long hid_bs;
+    int B, H, W;
+    unsigned* flag;
+} BfsrWideHeadArgs;
+typedef struct BfsrWideTailArgs {
+    const unsigned short* hid; long long hid_bs;
+    const unsigned short* w; float acc_scale;
+    const float* bias; const float* post_scale;       /* [96] each: Conv2dZeros bias and exp(3*logs) */
+    const float* z_in; long long z_in_bs;
+    float* z_out; long long z_out_bs;
+    const float* h_ft; long long h_ft_bs; int h_ft_fmt;
+    const float* wperm; const float* an_bias; const float* an_escale;
+    unsigned short* z1h; long long z1h_bs;
+    int B, C, H, W, reverse;
+    float eps;
+    unsigned* flag;
+} BfsrWideTailArgs;
+int bfsr_coupling_wide_head(const BfsrWideHeadArgs* a, void* stream);
+int bfsr_coupling_wide_tail(const BfsrWideTailArgs* a, void* stream);
+long long bfsr_coupling_wide_conv_packed_size(int Cout, int Cin);                    /* fp16 elements; Cout in {32, 64, 96}, Cin % 16 == 0 */
+int bfsr_pack_coupling_wide_conv(const float* w_oihw, int Cout, int Cin, float scale, unsigned short* packed);
+long long bfsr_coupling_wide_w2_packed_size(void);                                   /* fp16 elements */
+int bfsr_pack_coupling_wide_w2(const float* w2, float scale2, unsigned short* packed);   /* w2 [64][64] */
+int bfsr_pack_coupling_wide_wmat(const float* w, float* wperm);                       /* w [96][96] row-major -> wperm [96][96] */
 
 /* bfsr_conv2d_up2_h2t: the first 3x3 conv of a level's conditioning nets over torch.cat([key, F.interpolate(taps, mode='nearest')]) (key: Ckey
  * channels at the output resolution 2h x 2w; taps: Ct channels at h x w -- the stacked RRDB block outputs), evaluated at the SOURCE resolution by

@@ -97,7 +97,7 @@ def launch_flop(k):
         _, Cin, Cout, b_, hh, ww = k
         return 2.0 * (Cin * 9 + 64) * Cout * b_ * hh * ww
     if f in ("conv_x3s", "conv_h2s", "conv_h2x", "conv_h2r"):
-        _, Cin, Cout, b_, hh, ww, _fmt = k
+        _, Cin, Cout, b_, hh, ww, _fmt = k[:7]                             # (conv_h2s keys carry the workgroup's M-tile count behind the format)
         return 2.0 * Cin * 9 * Cout * b_ * hh * ww
     if f == "conv_chain":                                               # key: number of convs, sum over them of Cin x Cout, batch, H, W
         _, _n, cc, b_, hh, ww = k

@@ -193,6 +193,8 @@ SYMBOLS = {
     "bfsr_conv3x3_h2s": (_I, [C.POINTER(BfsrConvX3Args), _VP]),
     "bfsr_conv_packed_size_h2s": (_LL, [_I, _I]),
     "bfsr_pack_conv_weight_h2s": (_I, [_VP, _I, _I, _VP]),
+    "bfsr_conv_packed_size_h2s_mt": (_LL, [_I, _I, _I]),
+    "bfsr_pack_conv_weight_h2s_mt": (_I, [_VP, _I, _I, _I, _VP]),
     "bfsr_conv3x3_h2x": (_I, [C.POINTER(BfsrConvX3Args), _VP]),
     "bfsr_conv_packed_size_h2x": (_LL, [_I, _I, _I]),
     "bfsr_pack_conv_weight_h2x": (_I, [_VP, _I, _I, _I, C.c_float, _VP]),

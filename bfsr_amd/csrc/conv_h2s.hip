@@ -42,13 +42,17 @@ constexpr int SUB = NPOSP * 16;                 // bytes of one k-half sub-image
 constexpr int IN_BYTES = 2 * SUB;               // 20 480
 constexpr unsigned OOB = 0x80000000u;
 
-constexpr int MT = 1;                           // 32-cout M tiles per workgroup (the loops below are written for MT tiles; see the launcher for why 1)
-constexpr int W_BYTES = 9 * 1024;               // weights of one chunk: [9 taps][2 k halves][32 couts][8] fp16, one 1-KiB piece per tap
-constexpr int STAGE = IN_BYTES + W_BYTES;       // 29 696
-constexpr int NS = 5;                           // LDS ring: 148 480 B
-constexpr int LDS_TOTAL = NS * STAGE;
-constexpr int NPIECE = 20 + W_BYTES / 1024;     // 1-KiB LDS-DMA pieces per stage: 29
-constexpr int NJ = (NPIECE + NLW - 1) / NLW;
+// MT = 32-cout M tiles per workgroup.  1: the dense blocks' 32-channel convs.  2 (round 6): 64-channel convs (conv5 of a dense block, trunk convs,
+// coef | freq, the priors) -- the input tile is staged ONCE for 64 output channels, four MFMAs per four LDS reads instead of two per three; the ring
+// has four stages then (a chunk is twice the matrix work, so two chunks in flight cover the same time as three did).
+template <int MT> struct SGeo {
+    static constexpr int W_BYTES = 9 * 1024 * MT;               // weights of one chunk: [9 taps][2 k halves][32 MT couts][8] fp16
+    static constexpr int STAGE = IN_BYTES + W_BYTES;            // 29 696 | 38 912
+    static constexpr int NS = MT == 1 ? 5 : 4;                  // LDS ring: 148 480 | 155 648 B
+    static constexpr int LDS_TOTAL = NS * STAGE;
+    static constexpr int NPIECE = 20 + W_BYTES / 1024;          // 1-KiB LDS-DMA pieces per stage: 29 | 38
+    static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
+};
 
 struct Item { int cg, b, x0, y0; };
 
@@ -64,7 +68,7 @@ __device__ __forceinline__ void wait_vmcnt(int n)
 {
     switch (n) {
 #define W_(N_) case N_: asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory"); break;
-        W_(6) W_(7) W_(8) W_(9) W_(10) W_(12) W_(14) W_(16) W_(18)
+        W_(6) W_(7) W_(8) W_(9) W_(10) W_(12) W_(14) W_(16) W_(18) W_(20)
 #undef W_
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
@@ -76,13 +80,13 @@ __device__ __forceinline__ void wait_vmcnt(int n)
 // of pieces for every chunk -- and only ONE KIND of load: LDS-DMA pieces and ordinary register loads of one wave do NOT complete
 // in issue order relative to each other (measured: a wave mixing them passed the barrier with input pieces still in flight).
 //   Four DMA loaders: piece i of a stage (i < 20: input position group i>>1, k half i&1; else weight piece i-20) -> loader i % 4.
-template <class Decode>
+template <int MT, class Decode>
 __device__ __forceinline__ void h2s_loader_wave(const BfsrConvX3Args& p, unsigned char* smem, int wave, int lane, int slot, int G, int groups,
                                                 int nchunk, int T, unsigned HW16, Decode decode)
 {
     const int H = p.H, W = p.W;
     const int ld = wave - NW;
-    constexpr int NWPIECE = W_BYTES / 1024;                          // 9
+    constexpr int W_BYTES = SGeo<MT>::W_BYTES, STAGE = SGeo<MT>::STAGE, NS = SGeo<MT>::NS, NPIECE = SGeo<MT>::NPIECE;
     // ---- DMA loaders
     constexpr int ND = NLW;                                          // DMA loaders
     constexpr int NPALL = NPIECE;                                    // pieces they share
@@ -111,7 +115,7 @@ __device__ __forceinline__ void h2s_loader_wave(const BfsrConvX3Args& p, unsigne
         unsigned char* base = smem + buf * STAGE;
         const unsigned wsoff = (unsigned)(cg_ * nchunk + k) * (unsigned)W_BYTES;
 #pragma unroll
-        for (int j = 0; j < NJI + 3; ++j) {
+        for (int j = 0; j < (NPALL + ND - 1) / ND; ++j) {
             const int i = ld + j * ND;
             if (i >= NPALL) continue;
             if (j < NJI && i < 20) {
@@ -141,8 +145,10 @@ __device__ __forceinline__ void h2s_loader_wave(const BfsrConvX3Args& p, unsigne
     }
 }
 
+template <int MT>
 __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrConvX3Args p, int tiles_x, int tiles_y, int groups, int nitems)
 {
+    constexpr int STAGE = SGeo<MT>::STAGE, NS = SGeo<MT>::NS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -165,7 +171,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
     };
 
     if (wave >= NW) {
-        h2s_loader_wave(p, smem, wave, lane, slot, G, groups, nchunk, T, HW16, decode);
+        h2s_loader_wave<MT>(p, smem, wave, lane, slot, G, groups, nchunk, T, HW16, decode);
         return;
     }
 
@@ -250,13 +256,8 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
         // ds_bpermute (reading epi[co] directly = 16 broadcast loads of 1 KiB per octet, after the last MFMA).  Residual
         // operands: ALL groups' loads are issued before the first is used -- one HBM round trip per residual and tile, not one
         // per octet (measured: the serialised version cost more than the K loop of the 192-channel conv).
-        bool plain = true;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) plain = plain && ((lane & 1) ? pm[m].x == 1.f : (pm[m].y == 0.f && pm[m].z == 1.f && pm[m].w == 0.f));
-        const bool bias_only = __all(plain);
-        const bool fast = bias_only && slope >= 0.f && slope <= 1.f;
+        const bool fast_slope = slope >= 0.f && slope <= 1.f;
         auto fetch = [&](float val, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane * 4, __float_as_int(val))); };
-        float o[MT][2][2][8];                                            // [m tile][row][octet q][channel]
         int lh = lhi, lx = l31;                                          // opaque copies: keeps the per-lane address arithmetic of the epilogue
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("" : "+v"(lh), "+v"(lx));                           // INSIDE the tile loop (hoisted, it is spilled to scratch and reloaded here)
@@ -276,130 +277,112 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
         auto res_rsrc = [&](const unsigned short* res, long long bs) {
             return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(res + (long long)cur.b * bs), 0, h2_bytes, 0x00020000);
         };
-        // operands of the first residual: issued NOW, consumed after the parameter stage (their HBM round trip runs under the swaps,
-        // the bpermute exchange and the bias/activation arithmetic instead of in front of the adds)
-        half8 r1h[MT][2][2], r1l[MT][2][2];
-        if (p.res1) {
-            const __amdgpu_buffer_rsrc_t rr = res_rsrc(p.res1, p.res1_bs);
+        typedef unsigned u32x4s_ __attribute__((ext_vector_type(4)));
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");       // MFMA result -> VALU read inside the asm below: 20 wait states (>= 19 of a 16-pass XDL op), self-sufficient
+        // ONE (M TILE, ROW) AT A TIME (round 6): 16 results per lane, their residual operands and parameters -- with MT = 2 the all-at-once form of
+        // round 3 spilled (64 accumulators + 64 registers of residual operands; 1.05 ms against 0.61 ms for conv5 at 128 x 128^2), and a per-M-tile
+        // form still made hipcc park the residual loads in scratch one by one (`load, s_waitcnt vmcnt(0), scratch_store`: 0.71 ms)
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
+        for (int m = 0; m < MT; ++m) {
+            const bool plain = (lane & 1) ? pm[m].x == 1.f : (pm[m].y == 0.f && pm[m].z == 1.f && pm[m].w == 0.f);
+            const bool bias_only = __all(plain);
+            const bool fast = bias_only && fast_slope;
+            const int oct0 = (cur.cg * MT + m) * 4;                      // first of this M tile's four channel octets (+ q*2 + lh)
+            // the row's epilogue; `act(q, i, u)` = the per-channel parameter stage (bias / affine / activation / post-scale) of octet q, channel i
+            auto do_row = [&](int j, auto&& act) {
+                // operands of the first residual: issued FIRST, consumed after the parameter stage (their HBM round trip runs under the swaps,
+                // the bpermute exchange and the bias/activation arithmetic instead of in front of the adds)
+                half8 r1h[2], r1l[2];
+                if (p.res1) {
+                    const __amdgpu_buffer_rsrc_t rr = res_rsrc(p.res1, p.res1_bs);
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        const unsigned so = (unsigned)(((cur.cg * MT + m) * 4 + q * 2) * 2) * (unsigned)(HW * 16);
-                        r1h[m][j][q] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rr, vo16[j], so, 0));
-                        r1l[m][j][q] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rr, vo16[j], so + (unsigned)(HW * 16), 0));
+                        const unsigned so = (unsigned)((oct0 + q * 2) * 2) * (unsigned)(HW * 16);
+                        r1h[q] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rr, vo16[j], so, 0));
+                        r1l[q] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rr, vo16[j], so + (unsigned)(HW * 16), 0));
                     }
-        }
-        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");       // MFMA result -> VALU read inside the asm below: 20 wait states (>= 19 of a 16-pass XDL op), self-sufficient
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
+                }
+                float o[2][8];                                           // [octet q][channel]
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         float lo = acc[m][j][8 * q + i], hi = acc[m][j][8 * q + 4 + i];
                         asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
-                        o[m][j][q][i] = lo;
-                        o[m][j][q][4 + i] = hi;
+                        o[q][i] = lo;
+                        o[q][4 + i] = hi;
                     }
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+                for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                float e0[8], e1[8], e2[8], e3[8], e4[8];                 // every lane takes part in the exchange (before any divergence)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int src = ((q * 2 + lh) * 8 + i) * 2;         // lane holding this channel's first float4
-                    e0[i] = fetch(pm[m].x, src);
-                    e1[i] = 0.f; e2[i] = 1.f; e3[i] = 0.f; e4[i] = 1.f;
-                    if (!bias_only) { e1[i] = fetch(pm[m].y, src); e2[i] = fetch(pm[m].z, src); e3[i] = fetch(pm[m].w, src); e4[i] = fetch(pm[m].x, src + 1); }
-                }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (fast) {                                          // bias + (leaky) ReLU only: 3 VALU ops per channel instead of 8
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const float u = o[m][j][q][i] + e0[i];
-                            o[m][j][q][i] = fmaxf(u, u * slope);         // = u > 0 ? u : u*slope for 0 <= slope <= 1
-                        }
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            float u = o[m][j][q][i] + e0[i];
-                            u = (u + e1[i]) * e2[i] + e3[i];
-                            u = u > 0.f ? u : u * slope;
-                            o[m][j][q][i] = u * e4[i];
-                        }
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);                       // one (M tile, octet) at a time: short live ranges
-            }
-        auto add_res = [&](const unsigned short* res, long long bs, float alpha) {
-            const __amdgpu_buffer_rsrc_t rr = res_rsrc(res, bs);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {                               // one M tile (4 groups, 32 registers) per round trip
-                half8 rh[2][2], rl[2][2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const unsigned so = (unsigned)(((cur.cg * MT + m) * 4 + q * 2) * 2) * (unsigned)(HW * 16);
-                        rh[j][q] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rr, vo16[j], so, 0));
-                        rl[j][q] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rr, vo16[j], so + (unsigned)(HW * 16), 0));
-                    }
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
+                    for (int i = 0; i < 8; ++i) o[q][i] = act(q, i, o[q][i]);
+                if (p.res1) {
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) o[m][j][q][i] = alpha * o[m][j][q][i] + ((float)rh[j][q][i] + (float)rl[j][q][i]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        if (p.res1) {
+                        for (int i = 0; i < 8; ++i) o[q][i] = p.alpha1 * o[q][i] + ((float)r1h[q][i] + (float)r1l[q][i]);
+                }
+                if (p.res2) {
+                    const __amdgpu_buffer_rsrc_t rr = res_rsrc(p.res2, p.res2_bs);
+                    half8 rh[2], rl[2];
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
+                    for (int q = 0; q < 2; ++q) {
+                        const unsigned so = (unsigned)((oct0 + q * 2) * 2) * (unsigned)(HW * 16);
+                        rh[q] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rr, vo16[j], so, 0));
+                        rl[q] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rr, vo16[j], so + (unsigned)(HW * 16), 0));
+                    }
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) o[m][j][q][i] = p.alpha1 * o[m][j][q][i] + ((float)r1h[m][j][q][i] + (float)r1l[m][j][q][i]);
-        }
-        if (p.res2) add_res(p.res2, p.res2_bs, p.alpha2);
-        typedef unsigned u32x4s_ __attribute__((ext_vector_type(4)));
-        if (p.y_fmt != 0) {                                              // h2 output: both planes (1) or the hi plane only (2)
-            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned short*>(p.y) + (long long)cur.b * p.y_bs, 0, h2_bytes, 0x00020000);
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
+                        for (int i = 0; i < 8; ++i) o[q][i] = p.alpha2 * o[q][i] + ((float)rh[q][i] + (float)rl[q][i]);
+                }
+                if (p.y_fmt != 0) {                                      // h2 output: both planes (1) or the hi plane only (2)
+                    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned short*>(p.y) + (long long)cur.b * p.y_bs, 0, h2_bytes, 0x00020000);
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        const unsigned so = (unsigned)(((cur.cg * MT + m) * 4 + q * 2) * 2) * (unsigned)(HW * 16);
+                        const unsigned so = (unsigned)((oct0 + q * 2) * 2) * (unsigned)(HW * 16);
                         half8 h8, l8;
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) { _Float16 h, l; split2(o[m][j][q][i], h, l); h8[i] = h; l8[i] = l; }
+                        for (int i = 0; i < 8; ++i) { _Float16 h, l; split2(o[q][i], h, l); h8[i] = h; l8[i] = l; }
                         bfsr::store_b128(ry, __builtin_bit_cast(u32x4s_, h8), vo16[j], so);
                         if (p.y_fmt == 1) bfsr::store_b128(ry, __builtin_bit_cast(u32x4s_, l8), vo16[j], so + (unsigned)(HW * 16));
                     }
-        } else {                                                         // fp32 NCHW: channels >= Cout fall beyond the descriptor
-            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(p.y) + (long long)cur.b * p.y_bs, 0,
-                                                                                (unsigned)((long long)p.Cout * HW * 4), 0x00020000);
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
+                } else {                                                 // fp32 NCHW: channels >= Cout fall beyond the descriptor
+                    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(p.y) + (long long)cur.b * p.y_bs, 0,
+                                                                                        (unsigned)((long long)p.Cout * HW * 4), 0x00020000);
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
 #pragma unroll
                         for (int i = 0; i < 8; ++i)
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o[m][j][q][i]), ry, vo4[j],
-                                                                  (unsigned)((((cur.cg * MT + m) * 4 + q * 2) * 8 + i) * HW * 4), 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o[q][i]), ry, vo4[j],
+                                                                  (unsigned)(((oct0 + q * 2) * 8 + i) * HW * 4), 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            // two code paths WITHOUT shared default-valued parameter arrays: as `e1[i] = 0.f; ... if (!bias_only) e1[i] = fetch(...)` the defaults of
+            // every (M tile, octet, channel) became live registers across the whole epilogue (128 with MT = 2).  The branch is wave-uniform (`fast`
+            // comes from __all), so every lane takes part in each ds_bpermute exchange.
+            if (fast) {                                                  // bias + (leaky) ReLU only: 3 VALU ops per channel instead of 8
+                float e0[2][8];
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) e0[q][i] = fetch(pm[m].x, ((q * 2 + lh) * 8 + i) * 2);   // lane holding this channel's first float4
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    do_row(j, [&](int q, int i, float v) { const float u = v + e0[q][i]; return fmaxf(u, u * slope); });   // = u > 0 ? u : u*slope for 0 <= slope <= 1
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    do_row(j, [&](int q, int i, float v) {
+                        const int src = ((q * 2 + lh) * 8 + i) * 2;
+                        const float e0 = fetch(pm[m].x, src), e1 = fetch(pm[m].y, src), e2 = fetch(pm[m].z, src), e3 = fetch(pm[m].w, src), e4 = fetch(pm[m].x, src + 1);
+                        float u = v + e0;
+                        u = (u + e1) * e2 + e3;
+                        u = u > 0.f ? u : u * slope;
+                        return u * e4;
+                    });
+            }
         }
         if (c < T) load_step(I0(), st, 0);                               // first fragments of the next tile (its barrier is already behind us)
     }
@@ -840,25 +823,23 @@ inline unsigned short f32_to_f16_bits(float v)
 
 }  // namespace
 
-// Wider convs (192 -> 64) run as two 32-cout passes over the input tile.  A 64-cout workgroup tile (MT = 2: one staging of the input,
-// twice the MFMAs per input fragment) was built and measured SLOWER: 64 accumulators + the residual operands spill to scratch in the
-// epilogue -- 1.05 ms against 0.61 ms at 128 x 128x128 (tools/exp/h2s_bench.py).
-static inline int h2s_mtile(int Cout) { (void)Cout; return MT; }
-
-extern "C" long long bfsr_conv_packed_size_h2s(int Cout, int Cin)
+// 64-cout workgroup tiles (mtile 2): built in round 2 with an all-tiles-at-once epilogue that spilled (1.05 ms against 0.61 ms for conv5 at
+// 128 x 128x128, tools/exp/h2s_bench.py); rebuilt in round 6 with the per-M-tile epilogue above.  The weight image depends on the tile width,
+// so the caller chooses at pack time and passes the same mtile in BfsrConvX3Args.mtile (0 = 1).
+extern "C" long long bfsr_conv_packed_size_h2s_mt(int Cout, int Cin, int mtile)
 {
-    if (Cout <= 0 || Cin <= 0 || (Cin & 31)) return -1;
-    const int MW = h2s_mtile(Cout) * 32;
+    if (Cout <= 0 || Cin <= 0 || (Cin & 31) || (mtile != 1 && mtile != 2)) return -1;
+    const int MW = mtile * 32;
     return (long long)((Cout + MW - 1) / MW) * (Cin / 16) * 9 * 2 * MW * 8;      // fp16 elements
 }
 
-extern "C" int bfsr_pack_conv_weight_h2s(const float* w, int Cout, int Cin, unsigned short* packed)
+extern "C" int bfsr_pack_conv_weight_h2s_mt(const float* w, int Cout, int Cin, int mtile, unsigned short* packed)
 {
-    // w [Cout][Cin][3][3] fp32 -> fp16 [cout group of MW = 32 (Cout <= 32) or 64][16-channel chunk][tap = dx*3 + dy][k half][MW][8],
+    // w [Cout][Cin][3][3] fp32 -> fp16 [cout group of MW = 32 * mtile][16-channel chunk][tap = dx*3 + dy][k half][MW][8],
     // zero padded (tap-column-major: the kernel consumes one tap column dx per pipeline step)
-    if (!w || !packed || Cout <= 0 || Cin <= 0 || (Cin & 31)) return -1;
-    const int nchunk = Cin / 16, MW = h2s_mtile(Cout) * 32;
-    const long long n = bfsr_conv_packed_size_h2s(Cout, Cin);
+    if (!w || !packed || Cout <= 0 || Cin <= 0 || (Cin & 31) || (mtile != 1 && mtile != 2)) return -1;
+    const int nchunk = Cin / 16, MW = mtile * 32;
+    const long long n = bfsr_conv_packed_size_h2s_mt(Cout, Cin, mtile);
     for (long long i = 0; i < n; ++i) packed[i] = 0;
     for (int co = 0; co < Cout; ++co)
         for (int ci = 0; ci < Cin; ++ci)
@@ -869,25 +850,18 @@ extern "C" int bfsr_pack_conv_weight_h2s(const float* w, int Cout, int Cin, unsi
     return 0;
 }
 
-extern "C" int bfsr_conv3x3_h2s(const BfsrConvX3Args* a, void* stream)
+extern "C" long long bfsr_conv_packed_size_h2s(int Cout, int Cin) { return bfsr_conv_packed_size_h2s_mt(Cout, Cin, 1); }
+extern "C" int bfsr_pack_conv_weight_h2s(const float* w, int Cout, int Cin, unsigned short* packed) { return bfsr_pack_conv_weight_h2s_mt(w, Cout, Cin, 1, packed); }
+
+namespace {
+template <int MT>
+int launch_h2s(const BfsrConvX3Args* a, hipStream_t st)
 {
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (!a || !a->x || !a->w || !a->y) return -1;
-    if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cin <= 0 || (a->Cin & 31) || a->Cout <= 0) return -1;
-    if (a->y_fmt < 0 || a->y_fmt > 2) return -1;
-    if ((a->y_fmt != 0 || a->res1 || a->res2) && (a->Cout & 7)) return -1;
-    if ((long long)(a->Cin / 8) * 2 * a->H * a->W * 16 >= (1LL << 31)) return -1;      // 32-bit byte offsets inside one batch item
-    if ((long long)((a->Cout + 7) / 8) * 2 * a->H * a->W * 8 >= (1LL << 31)) return -1;  // 32-bit element offsets in the epilogue
-    if ((reinterpret_cast<unsigned long long>(a->x) & 15) || (a->x_bs & 7)) return -1;
-    if (a->y_fmt != 0 && ((reinterpret_cast<unsigned long long>(a->y) & 15) || (a->y_bs & 7))) return -1;
-    if (a->res1 && ((reinterpret_cast<unsigned long long>(a->res1) & 15) || (a->res1_bs & 7))) return -1;
-    if (a->res2 && ((reinterpret_cast<unsigned long long>(a->res2) & 15) || (a->res2_bs & 7))) return -1;
     const int tiles_x = (a->W + 31) / 32, tiles_y = (a->H + TH - 1) / TH;
-    const int mt = h2s_mtile(a->Cout);
-    const int groups = (a->Cout + mt * 32 - 1) / (mt * 32);
+    const int groups = (a->Cout + MT * 32 - 1) / (MT * 32);
     const long long nitems = (long long)tiles_x * tiles_y * groups * a->B;
     if (nitems > 0x7fffffffLL) return -1;
-    if (bfsr_conv_packed_size_h2s(a->Cout, a->Cin) * 2 >= (1LL << 32)) return -1;
+    if (bfsr_conv_packed_size_h2s_mt(a->Cout, a->Cin, MT) * 2 >= (1LL << 32)) return -1;
     int cus = bfsr::cu_count();                             // cached per device; no silent default
     if (cus <= 0) return -1;
     if (a->tune > 0) cus = a->tune;
@@ -895,9 +869,27 @@ extern "C" int bfsr_conv3x3_h2s(const BfsrConvX3Args* a, void* stream)
     // (round 3's ping-pong compute groups and register-staged weight loader were parity-tested and measured within box noise of this
     // kernel: tools/exp/kernels/conv_h2s_r3.hip)
     static std::atomic<unsigned long long> lds_done{0};
-    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2s_kernel), LDS_TOTAL, lds_done) != 0) return -1;
-    hipLaunchKernelGGL(conv3x3_h2s_kernel, dim3((unsigned)grid), dim3((NW + NLW) * 64), LDS_TOTAL, st, *a, tiles_x, tiles_y, groups, (int)nitems);
+    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2s_kernel<MT>), SGeo<MT>::LDS_TOTAL, lds_done) != 0) return -1;
+    hipLaunchKernelGGL((conv3x3_h2s_kernel<MT>), dim3((unsigned)grid), dim3((NW + NLW) * 64), SGeo<MT>::LDS_TOTAL, st, *a, tiles_x, tiles_y, groups, (int)nitems);
     return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int bfsr_conv3x3_h2s(const BfsrConvX3Args* a, void* stream)
+{
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!a || !a->x || !a->w || !a->y) return -1;
+    if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cin <= 0 || (a->Cin & 31) || a->Cout <= 0) return -1;
+    if (a->y_fmt < 0 || a->y_fmt > 2) return -1;
+    if (a->mtile < 0 || a->mtile > 2) return -1;
+    if ((a->y_fmt != 0 || a->res1 || a->res2) && (a->Cout & 7)) return -1;
+    if ((long long)(a->Cin / 8) * 2 * a->H * a->W * 16 >= (1LL << 31)) return -1;      // 32-bit byte offsets inside one batch item
+    if ((long long)((a->Cout + 7) / 8) * 2 * a->H * a->W * 8 >= (1LL << 31)) return -1;  // 32-bit element offsets in the epilogue
+    if ((reinterpret_cast<unsigned long long>(a->x) & 15) || (a->x_bs & 7)) return -1;
+    if (a->y_fmt != 0 && ((reinterpret_cast<unsigned long long>(a->y) & 15) || (a->y_bs & 7))) return -1;
+    if (a->res1 && ((reinterpret_cast<unsigned long long>(a->res1) & 15) || (a->res1_bs & 7))) return -1;
+    if (a->res2 && ((reinterpret_cast<unsigned long long>(a->res2) & 15) || (a->res2_bs & 7))) return -1;
+    return a->mtile == 2 ? launch_h2s<2>(a, st) : launch_h2s<1>(a, st);
 }
 
 extern "C" long long bfsr_conv_packed_size_h2x(int Cout, int Cin, int mtile)

@@ -703,15 +703,18 @@ class HipOps(object):
         _lib.check(self._launch(key, lambda: self.lib.bfsr_conv2d_up4_h2t(C.byref(a), self._stream())), "conv2d_up4_h2t")
         return out
 
-    def pack_conv_h2s(self, w):
+    def pack_conv_h2s(self, w, mtile=None):
         """OIHW 3x3 fp32 weights -> fp16 packing of conv_h2s (32- or 64-cout workgroup tiles, 16-channel chunks)."""
         w = w.detach().to("cpu", torch.float32).contiguous()
         Cout, Cin, KS, _ = w.shape
         if KS != 3 or Cin % 32:
             raise ValueError("conv_h2s: 3x3 weights with Cin % 32 == 0 only")
-        packed = torch.empty(self.lib.bfsr_conv_packed_size_h2s(Cout, Cin), dtype=torch.int16)
-        _lib.check(self.lib.bfsr_pack_conv_weight_h2s(w.data_ptr(), Cout, Cin, packed.data_ptr()), "pack_h2s")
-        return PackedConv(packed.to(self.device), Cout, Cin, 3, 1, fixed=True, w=None, ops=self)
+        # round 6: 64-cout workgroup tiles where the conv has them (conv5 of a dense block, trunk convs, coef | freq, the priors): the input tile is
+        # staged once per 64 output channels.  Same summation order per output element -> the bits of the 32-cout form (BFSR_H2S_MT=1 keeps that form).
+        mt = mtile if mtile is not None else (2 if (Cout % 64 == 0 and os.environ.get("BFSR_H2S_MT", "2") != "1") else 1)
+        packed = torch.empty(self.lib.bfsr_conv_packed_size_h2s_mt(Cout, Cin, mt), dtype=torch.int16)
+        _lib.check(self.lib.bfsr_pack_conv_weight_h2s_mt(w.data_ptr(), Cout, Cin, mt, packed.data_ptr()), "pack_h2s")
+        return PackedConv(packed.to(self.device), Cout, Cin, 3, mt, fixed=True, w=None, ops=self)
 
     def conv_h2s(self, x, pw, out, epi=None, act=ACT_NONE, slope=0.2, res1=None, alpha1=1.0, res2=None, alpha2=1.0, hi_only=False, tune=0):
         """3x3 conv over an h2 tensor `x` (weights: pack_conv_h2s); `out` is an h2 view (hi_only: the lo plane is not written --
@@ -727,7 +730,7 @@ class HipOps(object):
         if (Cin, Cout, H, W) != (pw.Cin, pw.Cout, H2, W2) or pw.KS != 3 or x.shape[0] != out.shape[0]:
             raise ValueError("conv_h2s: shape mismatch x%s out%s weight(Cout=%d,Cin=%d)" % (tuple(x.shape), tuple(out.shape), pw.Cout, pw.Cin))
         a.Cin, a.Cout = Cin, Cout
-        a.w = pw.data.data_ptr()
+        a.w, a.mtile = pw.data.data_ptr(), pw.mtile
         a.B, a.H, a.W = out.shape[0], H, W
         a.epi, a.act, a.slope, a.tune = _ptr(epi), act, slope, tune
         for name, t, al in (("res1", res1, alpha1), ("res2", res2, alpha2)):
@@ -737,7 +740,7 @@ class HipOps(object):
                 setattr(a, name, pp)
                 setattr(a, name + "_bs", bs)
                 setattr(a, "alpha" + name[-1], al)
-        key = ("conv_h2s", Cin, Cout, out.shape[0], H, W, a.y_fmt)
+        key = ("conv_h2s", Cin, Cout, out.shape[0], H, W, a.y_fmt, pw.mtile)
         _lib.check(self._launch(key, lambda: self.lib.bfsr_conv3x3_h2s(C.byref(a), self._stream())), "conv3x3_h2s")
         return out
 

@@ -164,7 +164,7 @@ typedef struct BfsrConvX3Args {
     const unsigned short* res2; long long res2_bs; float alpha2;
     int tune;
     float acc_scale;                               /* bfsr_conv3x3_h2x only: 1 / (the power of two the weights were packed with) */
-    int mtile;                                     /* bfsr_conv3x3_h2x only: 32-cout M tiles per workgroup the weights were packed for (0 or 1) */
+    int mtile;                                     /* bfsr_conv3x3_h2x: 32-cout M tiles per workgroup the weights were packed for (0 or 1); bfsr_conv3x3_h2s: 0, 1 or 2 */
     unsigned* flag;                                /* bfsr_conv3x3_h2x only, optional device word: bit 0 is set when a value written to an h2 output is >= 65504 */
     const float* up4; long long up4_bs;            /* (ABI 5) bfsr_conv3x3_h2x with y_fmt 2 only, optional: the COMPACT output of bfsr_conv2d_up4_h2t (its y_fmt 3:
                                                     * [B][Cout/4][H/4][W/4][9 phase classes][4] fp32, batch stride in floats), added to the result after the
@@ -189,6 +189,11 @@ int bfsr_x3_unpack(const unsigned short* x, long long x_bs, float* y, long long 
 int bfsr_conv3x3_h2s(const BfsrConvX3Args* a, void* stream);
 long long bfsr_conv_packed_size_h2s(int Cout, int Cin);
 int bfsr_pack_conv_weight_h2s(const float* w_oihw, int Cout, int Cin, unsigned short* packed);
+/* (round 6) the same with 32 * mtile output channels per workgroup tile, mtile in {1, 2}: mtile 2 stages the input tile once for 64 output channels
+ * (conv5 of a dense block, trunk convs); the caller passes the mtile the weights were packed with in BfsrConvX3Args.mtile (0 = 1).  Same summation
+ * order per output element: bit-identical results. */
+long long bfsr_conv_packed_size_h2s_mt(int Cout, int Cin, int mtile);
+int bfsr_pack_conv_weight_h2s_mt(const float* w_oihw, int Cout, int Cin, int mtile, unsigned short* packed);
 /* bfsr_conv3x3_h2x: the same conv at fp32-class accuracy on the fp16 matrix pipe -- both planes of the h2 input (22 significant
  * bits) against a two-term fp16 split of the weights, three products lo*hi + hi*lo + hi*hi in the fp32 accumulator (half the
  * matrix instructions and 2/3 of the operand bytes of the 3xBF16 scheme of bfsr_conv3x3_x3s; end to end indistinguishable from

@@ -217,6 +217,33 @@ def test_conv_h2s_dense_block_views_and_residuals(hip):
     close(hip.h2_unpack(nxt[:, :8], hip.empty(B, 64, H, W)), out_ref, 2e-5, "h2 conv5 residuals")
 
 
+@pytest.mark.parametrize("case", [(2, 192, 64, 21, 37), (1, 64, 64, 16, 32), (3, 64, 128, 40, 70), (2, 96, 64, 5, 3), (1, 128, 192, 33, 33)])
+def test_conv_h2s_64_cout_tiles_give_the_bits_of_32_cout_tiles(hip, case):
+    """conv_h2s with 64 output channels per workgroup tile (mtile 2, round 6: the input tile staged once for 64 channels, per-M-tile epilogue) against
+    the 32-channel form: same summation order per output element -> identical bits, with every epilogue stage and both residuals, all three outputs."""
+    B, Cin, Cout, H, W = case
+    x, w = rnd(131, B, Cin, H, W), rnd(132, Cout, Cin, 3, 3, scale=1.0 / np.sqrt(Cin * 9))
+    r1, r2 = rnd(133, B, Cout, H, W), rnd(134, B, Cout, H, W)
+    xh = hip.h2_pack(hip.to_device(x), hip.h2_empty(B, Cin, H, W))
+    r1h = hip.h2_pack(hip.to_device(r1), hip.h2_empty(B, Cout, H, W))
+    r2h = hip.h2_pack(hip.to_device(r2), hip.h2_empty(B, Cout, H, W))
+    p1, p2 = hip.pack_conv_h2s(w, mtile=1), hip.pack_conv_h2s(w, mtile=2)
+    assert (p1.mtile, p2.mtile) == (1, 2)
+    epis = [hip.pack_epilogue(Cout, bias=rnd(135, Cout, scale=0.3)),
+            hip.pack_epilogue(Cout, bias=rnd(135, Cout, scale=0.3), aff_shift=rnd(136, Cout, scale=0.1), aff_scale=torch.exp(rnd(137, Cout, scale=0.1)),
+                              post_scale=torch.exp(rnd(138, Cout, scale=0.1)))]
+    for epi in epis:
+        for kw in (dict(), dict(res1=r1h, alpha1=0.2), dict(res1=r1h, alpha1=0.2, res2=r2h, alpha2=0.2)):
+            a = hip.conv_h2s(xh, p1, hip.empty(B, Cout, H, W), epi=epi, act=2, slope=0.2, **kw)
+            b = hip.conv_h2s(xh, p2, hip.empty(B, Cout, H, W), epi=epi, act=2, slope=0.2, **kw)
+            assert torch.equal(a.cpu(), b.cpu()), "fp32 output differs (%s)" % sorted(kw)
+            for hi_only in (False, True):
+                ya, yb = hip.h2_empty(B, Cout, H, W).zero_(), hip.h2_empty(B, Cout, H, W).zero_()
+                hip.conv_h2s(xh, p1, ya, epi=epi, act=2, slope=0.2, hi_only=hi_only, **kw)
+                hip.conv_h2s(xh, p2, yb, epi=epi, act=2, slope=0.2, hi_only=hi_only, **kw)
+                assert torch.equal(ya.cpu(), yb.cpu()), "h2 output differs (hi_only=%s, %s)" % (hi_only, sorted(kw))
+
+
 H2X_CASES = [(1, 32, 32, 16, 32), (2, 64, 32, 19, 45), (1, 192, 64, 33, 65), (3, 96, 32, 128, 128), (2, 64, 24, 9, 33), (1, 16, 40, 70, 70),
              (5, 48, 32, 40, 40), (2, 64, 64, 50, 40), (1, 160, 104, 17, 31)]
 

@@ -73,21 +73,49 @@ __global__ __launch_bounds__(256) void linf_features_kernel(BfsrLinfFeatArgs a)
 // lin_b: [L+1][D]; affine_info ai [B, 2*D*L, qh, qw]: for layer i  s = ai[2Di : 2Di+D], shift = ai[2Di+D : 2D(i+1)].
 //   forward : for i<L: x = W_i x + b_i ; x = x*scale_i + shift_i ;  then x = W_L x + b_L
 //   inverse : x = Winv_L (x - b_L) ; for i=L-1..0: x = (x - shift_i)/scale_i ; x = Winv_i (x - b_i)
-template <int D>
+// FAST (round 6): the sigmoid of the 2*D*L conditional scales per query point as v_exp_f32 of x * log2(e) and quotients as v_rcp_f32 + one Newton
+// step on the quotient (<= 1-2 ulp; coupling_tail_kernel's choices) instead of libm expf + two IEEE divisions -- this kernel is VALU-bound (one query
+// point per lane: 270 sigmoids next to 8 019 FMAs) and those were 60 % of its instructions.  Used by the inverse and by the forward pass when no
+// log-density is asked for; the log_p form (its logf included) and the vector-Jacobian product keep the libm forms.
+template <int D, int FAST>
 __global__ __launch_bounds__(256) void linf_flow_kernel(BfsrLinfFlowArgs a)
 {
+    auto fdiv = [](float n, float d) {
+        const float r = __builtin_amdgcn_rcpf(d);
+        const float qt = n * r;
+        return fmaf(fmaf(-d, qt, n), r, qt);
+    };
     const long long NQ = (long long)a.qh * a.qw;
     const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (q >= NQ) return;
     const int b = blockIdx.y, L = a.layers;
+    // the (L+1) linears' matrices and biases in LDS, read back as broadcasts (round 6).  As wave-uniform global loads they went through the scalar
+    // cache: 32 KB of matrices per pass against a 16 KB cache, ~100 SGPRs to land them in -- every ~64 FMAs waited for a scalar load from L2 and
+    // the kernel ran at 1.9 TB/s of its 18 GB, neither VALU- nor HBM-bound (cfg5: 9.3 ms per direction)
+    extern __shared__ float sLin[];
+    {
+        const int nw = (L + 1) * D * D, nb = (L + 1) * D;
+        for (int i = threadIdx.x; i < nw; i += 256) sLin[i] = a.lin_w[i];
+        for (int i = threadIdx.x; i < nb; i += 256) sLin[nw + i] = a.lin_b[i];
+        __syncthreads();
+    }
+    if (q >= NQ) return;
+    // an opaque per-lane zero in the LDS addresses: hipcc otherwise proves the loaded values wave-uniform and moves every one of them into an SGPR
+    // (v_readfirstlane per weight + 151 spilled SGPRs); as "divergent" values they stay in the VGPRs the broadcast reads deliver them in
+    int lz = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(lz));
+#endif
+    const float* sMat = sLin + lz;
+    const float* sBias = sMat + (L + 1) * D * D;
     const float* xi = a.x + (long long)b * a.x_bs + q;
     const float* ai = a.ai + (long long)b * a.ai_bs + q;
     float x[D], y[D];
     // conditioning values of one flow layer: lv[d] = raw scale, lv[D + d] = shift.  ai_fmt 1 = the quad-major layout the fused MLP
     // kernel writes ([layers][QB quads][NQ][4], a layer's 2*D values padded to QB*4): QB 16-byte loads per layer instead of 2*D
     // four-byte ones (the row-major form streamed at 2.4 TB/s, load-issue bound: 540 loads per query point)
-    constexpr int QB = (2 * D + 3) / 4;
+    constexpr int SH = (D + 3) / 4 * 4, QB = 2 * SH / 4;                  // ai_fmt 1: a layer = [SH raw scales (D used) | SH shifts (D used)]
     float lv[QB * 4];
+    const int so = a.ai_fmt == 1 ? SH : D;                               // where the shifts start inside lv
     const float4* aq = reinterpret_cast<const float4*>(a.ai + (long long)b * a.ai_bs) + q;
     auto load_layer = [&](int i) {
         if (a.ai_fmt == 1) {
@@ -105,8 +133,8 @@ __global__ __launch_bounds__(256) void linf_flow_kernel(BfsrLinfFlowArgs a)
     for (int d = 0; d < D; ++d) x[d] = xi[(long long)d * NQ];
 
     auto linear = [&](int layer, bool sub_bias_first) {
-        const float* __restrict__ W = a.lin_w + (long long)layer * D * D;
-        const float* __restrict__ bb = a.lin_b + (long long)layer * D;
+        const float* __restrict__ W = sMat + layer * D * D;
+        const float* __restrict__ bb = sBias + layer * D;
         if (sub_bias_first) {
 #pragma unroll
             for (int d = 0; d < D; ++d) x[d] -= bb[d];
@@ -130,7 +158,11 @@ __global__ __launch_bounds__(256) void linf_flow_kernel(BfsrLinfFlowArgs a)
             linear(i, false);
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                const float sr = lv[d], sh = lv[D + d];
+                const float sr = lv[d], sh = lv[so + d];
+                if constexpr (FAST) {
+                    x[d] = x[d] * (fdiv(1.f, 1.f + __expf(-(sr + 2.f))) + a.eps) + sh;
+                    continue;
+                }
                 const float sc = 1.f / (1.f + expf(-(sr + 2.f))) + a.eps;
                 x[d] = x[d] * sc + sh;
                 if (want_lp) ld += logf(sc);
@@ -149,7 +181,7 @@ __global__ __launch_bounds__(256) void linf_flow_kernel(BfsrLinfFlowArgs a)
         // The caller passes lin_w[i] = Winv_i^T; biases and shifts do not enter.  (LINF-LP/train.py:143: the image-space loss of the
         // latent module back-propagates through query_rgb into z_lr_learned.)
         auto matvec = [&](int layer) {
-            const float* __restrict__ W = a.lin_w + (long long)layer * D * D;
+            const float* __restrict__ W = sMat + layer * D * D;
 #pragma unroll
             for (int i = 0; i < D; ++i) {
                 float s = 0.f;
@@ -176,7 +208,12 @@ __global__ __launch_bounds__(256) void linf_flow_kernel(BfsrLinfFlowArgs a)
             load_layer(i);
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                const float sr = lv[d], sh = lv[D + d];
+                const float sr = lv[d], sh = lv[so + d];
+                if constexpr (FAST) {
+                    const float t = 1.f + __expf(-(sr + 2.f));
+                    x[d] = (x[d] - sh) * fdiv(t, fmaf(a.eps, t, 1.f));       // 1 / (1/t + eps) = t / (1 + eps t)
+                    continue;
+                }
                 x[d] = (x[d] - sh) / (1.f / (1.f + expf(-(sr + 2.f))) + a.eps);
             }
             linear(i, true);
@@ -185,6 +222,130 @@ __global__ __launch_bounds__(256) void linf_flow_kernel(BfsrLinfFlowArgs a)
     float* yo = a.y + (long long)b * a.y_bs + q;
 #pragma unroll
     for (int d = 0; d < D; ++d) yo[(long long)d * NQ] = x[d];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same flow for D = 27 on the fp32 matrix pipe (round 6): the one-query-per-lane form above spends its time feeding 8 019 FMAs per query
+// with wave-uniform weights (scalar loads through a 16 KB cache for 32 KB of matrices; as LDS broadcasts the return path moves 64 copies of
+// every weight) and ran at 1.9 TB/s of its 18 GB at BASELINE config 5.  Here a wave owns 64 query points as two 32-column tiles of
+// v_mfma_f32_32x32x2_f32: M = output row (27 of 32), N = query point, K = input row.  The accumulator layout of one linear (lane (l31, half):
+// register r = row 8(r>>2) + (r&3) + 4*half of query l31) IS the B operand of the next if that linear's K axis is contracted in the order
+// k(r, half) -- the chain never leaves that layout (coupling_head_kernel's trick); in it a lane owns whole (scale | shift) QUADS of the conditioning
+// ([layer][14 quads][NQ][4]: raw scales of rows 4j..4j+3 in quad j, shifts in quad 7 + j), so the affine stage is 16-byte loads and no exchange.
+// A operands ([layer][r][64 lanes], zero beyond 27) and biases live in LDS (46 KB), filled once per block; blocks walk query chunks grid-stride.
+// Per layer and wave: 32 MFMAs (2 048 matrix-pipe cycles) instead of 729 x 4 VALU cycles, 16 conflict-free ds_read_b32, 16 x 16-byte loads.
+// Sigmoid / quotient: the FAST forms of linf_flow_kernel.  REV 0: forward without log-density, REV 1: inverse.
+typedef float flow_f32x16 __attribute__((ext_vector_type(16)));
+template <int REV>
+__global__ __launch_bounds__(256) void linf_flow27_mfma_kernel(BfsrLinfFlowArgs a, int nchunks)
+{
+    constexpr int D = 27, QB = 14;
+    extern __shared__ float sLin[];
+    const int L = a.layers, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int nA = (L + 1) * 1024;
+    for (int i = tid; i < nA; i += 256) {
+        const int ln = i & 63, r = (i >> 6) & 15, layer = i >> 10;
+        const int row = ln & 31, k = 8 * (r >> 2) + (r & 3) + 4 * (ln >> 5);
+        sLin[i] = (row < D && k < D) ? a.lin_w[(layer * D + row) * D + k] : 0.f;
+    }
+    for (int i = tid; i < (L + 1) * 32; i += 256) {
+        const int row = i & 31, layer = i >> 5;
+        sLin[nA + i] = row < D ? a.lin_b[layer * D + row] : 0.f;
+    }
+    __syncthreads();
+    const float* sB = sLin + nA;
+    auto fdiv = [](float n, float d) {
+        const float r = __builtin_amdgcn_rcpf(d);
+        const float qt = n * r;
+        return fmaf(fmaf(-d, qt, n), r, qt);
+    };
+    const long long NQ = (long long)a.qh * a.qw;
+    const int b = blockIdx.y;
+    const float* xb = a.x + (long long)b * a.x_bs;
+    float* yb = a.y + (long long)b * a.y_bs;
+    const float4* aq = reinterpret_cast<const float4*>(a.ai + (long long)b * a.ai_bs);
+    const float eps = a.eps;
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const long long q0 = (long long)chunk * 256 + wave * 64;
+        if (q0 >= NQ) continue;                                           // (wave-uniform)
+        long long qc[2];
+        bool ok[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { const long long qn = q0 + 32 * t + l31; ok[t] = qn < NQ; qc[t] = ok[t] ? qn : NQ - 1; }
+        float xv[2][16];                                                  // [tile][r]: row 8(r>>2) + (r&3) + 4*lhi of query qc[tile]
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 8 * (r >> 2) + (r & 3) + 4 * lhi;
+                xv[t][r] = row < D ? xb[(long long)row * NQ + qc[t]] : 0.f;
+            }
+        auto matvec = [&](int layer, bool sub_bias_first) {               // x = W x + b  |  x = W (x - b)
+            const float* A = sLin + layer * 1024 + lane;
+            const float* bb = sB + layer * 32 + 4 * lhi;
+            flow_f32x16 acc[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float bias = bb[8 * (r >> 2) + (r & 3)];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (sub_bias_first) { xv[t][r] -= bias; acc[t][r] = 0.f; }
+                    else acc[t][r] = bias;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float ar = A[r * 64];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, xv[t][r], acc[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xv[t][r] = acc[t][r];
+        };
+        auto affine = [&](int layer) {                                    // forward: x = x * scale + shift; inverse: x = (x - shift) / scale
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float4 sc4[4], sh4[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const bool pad = g == 3 && lhi;                       // rows 28..31 do not exist (their x stays 0: zero weights, zero shift)
+                    const int qd = pad ? 6 : 2 * g + lhi;
+                    sc4[g] = aq[(long long)(layer * QB + qd) * NQ + qc[t]];
+                    sh4[g] = aq[(long long)(layer * QB + 7 + qd) * NQ + qc[t]];
+                    if (pad) { sc4[g] = make_float4(0.f, 0.f, 0.f, 0.f); sh4[g] = make_float4(0.f, 0.f, 0.f, 0.f); }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float sr[4] = {sc4[g].x, sc4[g].y, sc4[g].z, sc4[g].w}, sh[4] = {sh4[g].x, sh4[g].y, sh4[g].z, sh4[g].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float tt = 1.f + __expf(-(sr[e] + 2.f));
+                        float& v = xv[t][4 * g + e];
+                        if (REV) v = (v - sh[e]) * fdiv(tt, fmaf(eps, tt, 1.f));      // 1 / (1/t + eps) = t / (1 + eps t)
+                        else v = v * (fdiv(1.f, tt) + eps) + sh[e];
+                    }
+                }
+            }
+            // row 27 (r = 15 of the lower half-wave) is padding too: keep it exactly 0 whatever the producer left in the 28th slot
+            if (!lhi) { xv[0][15] = 0.f; xv[1][15] = 0.f; }
+        };
+        if (!REV) {
+            for (int i = 0; i < L; ++i) { matvec(i, false); affine(i); }
+            matvec(L, false);
+        } else {
+            matvec(L, true);
+            for (int i = L - 1; i >= 0; --i) { affine(i); matvec(i, true); }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 8 * (r >> 2) + (r & 3) + 4 * lhi;
+                if (ok[t] && row < D) yb[(long long)row * NQ + qc[t]] = xv[t][r];
+            }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -292,10 +453,27 @@ extern "C" int bfsr_linf_flow(const BfsrLinfFlowArgs* a, void* stream)
     const long long NQ = (long long)a->qh * a->qw;
     dim3 grid((unsigned)((NQ + 255) / 256), (unsigned)a->B);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (a->D == 27) hipLaunchKernelGGL((linf_flow_kernel<27>), grid, dim3(256), 0, st, *a);
-    else if (a->D == 3) hipLaunchKernelGGL((linf_flow_kernel<3>), grid, dim3(256), 0, st, *a);
-    else if (a->D == 12) hipLaunchKernelGGL((linf_flow_kernel<12>), grid, dim3(256), 0, st, *a);
+    const bool fast = (a->reverse == 1) || (a->reverse == 0 && !a->log_p);
+    if (a->layers < 0 || a->layers > 15) return -1;
+    if (fast && a->D == 27 && a->ai_fmt == 1 && a->layers <= 13 && a->x != a->y) {                 // the matrix-pipe form (46 KB of LDS at 10 layers)
+        const long long nchunks = (NQ + 255) / 256;
+        if (nchunks > 0x7fffffffLL) return -1;
+        long long gx = 1536 / (a->B > 0 ? a->B : 1);
+        gx = gx < 1 ? 1 : (gx > nchunks ? nchunks : gx);
+        const unsigned ldsm = (unsigned)((a->layers + 1) * (1024 + 32) * 4);
+        dim3 gm((unsigned)gx, (unsigned)a->B);
+        if (a->reverse) hipLaunchKernelGGL((linf_flow27_mfma_kernel<1>), gm, dim3(256), ldsm, st, *a, (int)nchunks);
+        else hipLaunchKernelGGL((linf_flow27_mfma_kernel<0>), gm, dim3(256), ldsm, st, *a, (int)nchunks);
+        return (int)hipGetLastError();
+    }
+    const unsigned lds = (unsigned)((a->layers + 1) * a->D * (a->D + 1) * 4);       // <= 48 KB (D = 27, 16 linears): under the default dynamic-LDS limit
+#define BFSR_FLOW_(D_) do { if (fast) hipLaunchKernelGGL((linf_flow_kernel<D_, 1>), grid, dim3(256), lds, st, *a); \
+                             else hipLaunchKernelGGL((linf_flow_kernel<D_, 0>), grid, dim3(256), lds, st, *a); } while (0)
+    if (a->D == 27) BFSR_FLOW_(27);
+    else if (a->D == 3) BFSR_FLOW_(3);
+    else if (a->D == 12) BFSR_FLOW_(12);
     else return -1;
+#undef BFSR_FLOW_
     return (int)hipGetLastError();
 }
 

@@ -14,8 +14,15 @@ from . import prep
 
 
 def batched_predict_log_p(model, inp, coord, cell, gt):
+    """-> z (the reference's `model.query_log_p(...)[1]`, LINF-LP/test.py:36-52 + 145).  The LP branch discards the log-density the reference computes
+    alongside (270 logf + the Gaussian term per query point), so the engine is asked for z alone: same z up to the rounding of the scale's sigmoid
+    (the flow kernel then evaluates it with v_exp / v_rcp, see linf_ops.hip); `model("query_log_p", ...)` still returns the reference's pair."""
     feat = model("gen_feat", inp=inp)
-    return model("query_log_p", inp=inp, feat=feat, coord=coord, cell=cell, gt=gt)[1]
+    eng = model.engine() if hasattr(model, "engine") else None
+    if eng is None or not hasattr(eng, "query_log_p"):
+        return model("query_log_p", inp=inp, feat=feat, coord=coord, cell=cell, gt=gt)[1]
+    d = eng.ops.to_device
+    return eng.query_log_p(d(feat), d(coord), d(cell), d(gt), with_logp=False)
 
 
 def batched_predict(model, inp, coord, cell, temperature, zmap=None):

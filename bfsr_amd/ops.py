@@ -1141,19 +1141,21 @@ class HipOps(object):
     def pack_linf_mlp(self, ws, bs, x3=True, quad_layers=None):
         """ws = [w1 [256,1024(,1,1)], w2, w3 [256,256], w4 [Cout,256]], bs = the four biases -> (packed weights, bias vector, Cout).
         quad_layers = (layers, D): the output is wanted in the private quad-major layout of linf_flow(ai_fmt=1) -- the last layer's
-        rows are re-ordered so that every flow layer's 2*D values start at a multiple of four (zero rows as padding); the returned
+        rows are re-ordered so that every flow layer's D scales and D shifts each start at a multiple of four (zero rows as padding); the returned
         Cout is the padded row count and `linf_mlp` then writes [B][Cout/4][qh*qw][4]."""
         w = [t.detach().to("cpu", torch.float32).reshape(t.shape[0], t.shape[1]).contiguous() for t in ws]
         bs = [b.detach().to("cpu", torch.float32).reshape(-1) for b in bs]
         if quad_layers is not None:
             L, D = quad_layers
-            blk = (2 * D + 3) // 4 * 4
+            S = (D + 3) // 4 * 4                    # per layer: S raw scales (D used), then S shifts (D used): both halves start on a quad
+            blk = 2 * S
             assert w[3].shape[0] == 2 * D * L
             w4 = torch.zeros(L * blk, w[3].shape[1])
             b4 = torch.zeros(L * blk)
             for i in range(L):
-                w4[i * blk: i * blk + 2 * D] = w[3][2 * D * i: 2 * D * (i + 1)]
-                b4[i * blk: i * blk + 2 * D] = bs[3][2 * D * i: 2 * D * (i + 1)]
+                for h in (0, 1):
+                    w4[i * blk + h * S: i * blk + h * S + D] = w[3][2 * D * i + h * D: 2 * D * i + (h + 1) * D]
+                    b4[i * blk + h * S: i * blk + h * S + D] = bs[3][2 * D * i + h * D: 2 * D * i + (h + 1) * D]
             w[3], bs = w4.contiguous(), bs[:3] + [b4]
         hidden, Cout = w[1].shape[0], w[3].shape[0]
         mode = (2 if self.split == "f16x2" else 1) if x3 else 0         # the fp32-accurate mode follows BFSR_SPLIT
@@ -1293,7 +1295,7 @@ class HipOps(object):
         a.x, a.x_bs, D, qh, qw = _view(x, "linf_flow.x")
         a.ai, a.ai_bs, ca, _, _ = _view(ai, "linf_flow.ai")
         a.y, a.y_bs, _, _, _ = _view(y, "linf_flow.y")
-        assert ca == (((2 * D + 3) // 4 * 4) * layers if ai_fmt else 2 * D * layers)
+        assert ca == ((2 * ((D + 3) // 4 * 4)) * layers if ai_fmt else 2 * D * layers)
         assert lin_w.numel() == (layers + 1) * D * D and lin_b.numel() == (layers + 1) * D
         a.lin_w, a.lin_b = lin_w.data_ptr(), lin_b.data_ptr()
         mode = int(reverse)                      # 0 forward, 1 (True) inverse, 2 = VJP of the inverse w.r.t. its input

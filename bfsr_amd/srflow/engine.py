@@ -1084,6 +1084,7 @@ class SRFlowEngine(object):
         the prior on the side stream while the remaining levels of the chain run, srflow/test.py)."""
         ops, ws = self.ops, self.ws
         cond = self.conditioning(lr, quads=logdet is None)
+        self._z1h_next.clear()      # (a pass that was interrupted must not leave a "z1 copy is valid" note behind)
         z = gt
         epses = []
         pending = None           # h_aff of the previous coupled step, applied lazily by the next head
@@ -1173,6 +1174,7 @@ class SRFlowEngine(object):
         eps_ready: optional {index into epses: event}: the current stream waits for the event right before that latent is consumed."""
         ops, ws = self.ops, self.ws
         cond = self.conditioning(lr, reverse=True, quads=logdet is None)
+        self._z1h_next.clear()
         ld_const, ld_levels = 0.0, set()
         epses = list(epses) if epses is not None else None
         zin = epses.pop() if epses is not None else z

@@ -522,8 +522,10 @@ typedef struct BfsrLinfFlowArgs {
     float* log_p;              /* optional (forward only): [B][qh*qw] total log-det + base log-prob per query point
                                 * (flow.py:44-55); logdet_const = sum over the layers+1 linears of slogdet(W)[1] */
     float logdet_const;
-    int ai_fmt;                /* 0: ai [B, 2*D*layers, qh, qw].  1: quad-major with each layer's 2*D values padded to a multiple of
-                                * four: [B][layers][ceil(2D/4)][qh*qw][4] (the producer's rows are laid out in that padded order) */
+    int ai_fmt;                /* 0: ai [B, 2*D*layers, qh, qw].  1: quad-major [B][layers][2*S/4][qh*qw][4] with S = D rounded up to a multiple of
+                                * four: per layer S raw scales (D used) then S shifts (D used), so both halves start on a quad (round 6: before, the
+                                * shifts followed the scales directly); the producer's rows are laid out in that padded order.  With D = 27 the
+                                * forward (log_p == NULL) and inverse passes run on the fp32 matrix pipe in this format. */
 } BfsrLinfFlowArgs;
 int bfsr_linf_flow(const BfsrLinfFlowArgs* a, void* stream);
 

@@ -437,19 +437,21 @@ class CpuOps(object):
     @staticmethod
     def _ai_quads(ai, layers, D, inverse=False):
         """[B, 2*D*layers, qh, qw] values <-> the quad-major padded layout of linf_mlp(out_fmt=1) / linf_flow(ai_fmt=1), held in a
-        [B, blk*layers, qh, qw] buffer (blk = 2*D rounded up to a multiple of four): [B][layers][blk/4][qh*qw][4]."""
+        [B, blk*layers, qh, qw] buffer (blk = 2*S, S = D rounded up to a multiple of four): [B][layers][blk/4][qh*qw][4]."""
         B, _, qh, qw = ai.shape
-        blk = (2 * D + 3) // 4 * 4
+        S = (D + 3) // 4 * 4                     # per layer: S raw scales (D used), then S shifts (D used)
+        blk = 2 * S
         if inverse:
             v = ai.reshape(B, layers, blk // 4, qh * qw, 4).permute(0, 1, 2, 4, 3).reshape(B, layers, blk, qh, qw)
-            return v[:, :, :2 * D].reshape(B, 2 * D * layers, qh, qw)
+            return torch.cat([v[:, :, :D], v[:, :, S:S + D]], 2).reshape(B, 2 * D * layers, qh, qw)
         v = torch.zeros(B, layers, blk, qh, qw)
-        v[:, :, :2 * D] = ai.reshape(B, layers, 2 * D, qh, qw)
+        a5 = ai.reshape(B, layers, 2 * D, qh, qw)
+        v[:, :, :D], v[:, :, S:S + D] = a5[:, :, :D], a5[:, :, D:]
         return v.reshape(B, layers, blk // 4, 4, qh * qw).permute(0, 1, 2, 4, 3).reshape(B, layers * blk, qh, qw)
 
     def pack_linf_mlp(self, ws, bs, x3=True, quad_layers=None):
         rnd = (lambda t: t) if x3 else (lambda t: t.half().float())
-        cout = ws[3].shape[0] if quad_layers is None else ((2 * quad_layers[1] + 3) // 4 * 4) * quad_layers[0]
+        cout = ws[3].shape[0] if quad_layers is None else (2 * ((quad_layers[1] + 3) // 4 * 4)) * quad_layers[0]
         return ([rnd(t.detach().to(torch.float32).reshape(t.shape[0], t.shape[1], 1, 1)).clone() for t in ws],
                 [b.detach().to(torch.float32).reshape(-1).clone() for b in bs], cout, quad_layers)
 

@@ -110,9 +110,45 @@ def test_linf_flow(hip, D, reverse):
     ref = CPU.linf_flow(x, ai, torch.empty_like(x), Wuse.reshape(-1), bb.reshape(-1), L, reverse)
     out = hip.linf_flow(hip.to_device(x), hip.to_device(ai), hip.empty(*x.shape), hip.vec(Wuse), hip.vec(bb), L, reverse)
     close(out, ref, 1e-5, "linf_flow")
-    # conditioning handed over in the quad-major padded layout: bit-identical result
-    outq = hip.linf_flow(hip.to_device(x), hip.to_device(CPU._ai_quads(ai, L, D).contiguous()), hip.empty(*x.shape), hip.vec(Wuse), hip.vec(bb), L, reverse, ai_fmt=1)
-    assert torch.equal(outq.cpu(), out.cpu()), "linf_flow ai_fmt=1 differs from ai_fmt=0"
+    # conditioning handed over in the quad-major padded layout.  D = 3: the same kernel, bit-identical; D = 27: the matrix-pipe kernel
+    # (linf_flow27_mfma_kernel: fp32 MFMAs in another summation order, v_exp / v_rcp sigmoid) -- held to the same bound against the CPU semantics
+    aiq = hip.to_device(CPU._ai_quads(ai, L, D).contiguous())
+    outq = hip.linf_flow(hip.to_device(x), aiq, hip.empty(*x.shape), hip.vec(Wuse), hip.vec(bb), L, reverse, ai_fmt=1)
+    if D == 27:
+        close(outq, ref, 1e-5, "linf_flow (matrix pipe)")
+    else:
+        assert torch.equal(outq.cpu(), out.cpu()), "linf_flow ai_fmt=1 differs from ai_fmt=0"
+    if not reverse:     # the log-density form keeps the one-point-per-lane kernel in both layouts: identical z, identical log_p
+        lp0, lp1 = hip.empty(B * qh * qw), hip.empty(B * qh * qw)
+        z0 = hip.linf_flow(hip.to_device(x), hip.to_device(ai), hip.empty(*x.shape), hip.vec(Wuse), hip.vec(bb), L, reverse, log_p=lp0, logdet_const=0.25)
+        z1 = hip.linf_flow(hip.to_device(x), aiq, hip.empty(*x.shape), hip.vec(Wuse), hip.vec(bb), L, reverse, log_p=lp1, logdet_const=0.25, ai_fmt=1)
+        assert torch.equal(z0.cpu(), z1.cpu()) and torch.equal(lp0.cpu(), lp1.cpu()), "log_p form differs between the two layouts"
+        close(z0, ref, 1e-5, "linf_flow (log_p form)")
+
+
+@pytest.mark.parametrize("reverse", [0, 1])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (3, 16, 16), (2, 31, 33), (1, 70, 70)])
+def test_linf_flow_matrix_pipe_ragged(hip, shape, reverse):
+    """linf_flow27_mfma_kernel on query grids that are not multiples of its 64-point waves / 256-point chunks (clamped loads, masked stores),
+    several chunks per block, batch slices; a forward / inverse round trip returns the input."""
+    B, qh, qw = shape
+    L, D = 10, 27
+    q = np.stack([np.linalg.qr(np.random.Generator(np.random.PCG64(40 + i)).standard_normal((D, D)))[0] for i in range(L + 1)])
+    Wm = torch.from_numpy(q.astype(np.float32)) * torch.from_numpy(np.random.Generator(np.random.PCG64(6)).uniform(0.8, 1.25, (L + 1, 1, D)).astype(np.float32))
+    Winv = torch.inverse(Wm.double()).float()
+    bb = rnd(13, L + 1, D, scale=0.1)
+    x, ai = rnd(14, B, D, qh, qw), rnd(15, B, 2 * D * L, qh, qw, scale=0.5)
+    Wuse = Winv if reverse else Wm
+    ref = CPU.linf_flow(x, ai, torch.empty_like(x), Wuse.reshape(-1), bb.reshape(-1), L, reverse)
+    aiq = hip.to_device(CPU._ai_quads(ai, L, D).contiguous())
+    ybuf = hip.empty(B, D, qh, qw).fill_(float("nan"))
+    out = hip.linf_flow(hip.to_device(x), aiq, ybuf, hip.vec(Wuse), hip.vec(bb), L, reverse, ai_fmt=1)
+    close(out, ref, 1e-5, "linf_flow matrix pipe %s" % (shape,))
+    back = hip.linf_flow(out, aiq, hip.empty(B, D, qh, qw), hip.vec(Wm if reverse else Winv), hip.vec(bb), L, not reverse, ai_fmt=1)
+    close(back, x, 2e-5, "round trip")
+    if B > 1:           # per-sample: a batch slice gives the bits of the batch
+        part = hip.linf_flow(hip.to_device(x)[1:], aiq[1:], hip.empty(B - 1, D, qh, qw), hip.vec(Wuse), hip.vec(bb), L, reverse, ai_fmt=1)
+        assert torch.equal(part.cpu(), out[1:].cpu())
 
 
 def test_fold_unfold_direct_conv(hip):

@@ -145,7 +145,7 @@ class BfsrLinfMlpArgs(C.Structure):
         ("dy_neg", C.c_float), ("dy_pos", C.c_float), ("dx_neg", C.c_float), ("dx_pos", C.c_float),
         ("clamp_lo", C.c_float), ("clamp_hi", C.c_float),
         ("cy0", C.c_float), ("cy1", C.c_float), ("cx0", C.c_float), ("cx1", C.c_float),
-        ("out_fmt", C.c_int), ("acc_scale", C.c_float * 4), ("flag", C.c_void_p), ("cf_fmt", C.c_int),
+        ("out_fmt", C.c_int), ("acc_scale", C.c_float * 4), ("flag", C.c_void_p), ("cf_fmt", C.c_int), ("tile", C.c_int),
     ]
 
 

@@ -35,7 +35,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-constexpr int NW = 8, P = 64, HID = 256, KC = 16;
+constexpr int NW = 8, HID = 256, KC = 16;
 constexpr int K1 = 4 * HID;                    // 1024 feature channels
 constexpr int NCH_HID = HID / KC;              // 16 chunks of 16 channels in a hidden activation
 
@@ -113,12 +113,16 @@ __device__ __forceinline__ void encode8(const float (&v)[8], typename Mode<X3>::
     }
 }
 
-template <int X3>
-__global__ __launch_bounds__(NW * 64, X3 == 1 ? 2 : 4) void linf_mlp_kernel(BfsrLinfMlpArgs a, int tiles_per_image)
+// NT = 32-point column tiles per wave: 2 (64-point workgroup tiles) or 4 (round 6: 128-point tiles -- every weight fragment a wave pulls from L2 feeds four
+// MFMAs instead of two, half the tiles, half the weight traffic per query point: each tile streams the whole 1.06 MB (fp16) of weights; same summation
+// order per point, so the two widths give identical bits.  One workgroup per CU then: 64 accumulators + two gathers in flight per lane).
+template <int X3, int NT>
+__global__ __launch_bounds__(NW * 64, NT == 4 ? 1 : (X3 == 1 ? 2 : 4)) void linf_mlp_kernel(BfsrLinfMlpArgs a, int tiles_per_image)
 {
     typedef Mode<X3> MD;
     typedef typename MD::frag frag;
     constexpr int PL = MD::PL;
+    constexpr int P = 32 * NT, PG = NT / 2;            // points per tile; 64-lane point groups of the feature generation
     constexpr int CHUNK = PL * 2 * P * 16;            // bytes of one 16-channel activation chunk: [plane][k half][64 points][8]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // 16 chunks: stage A = chunks 0-7, stage B = 8-15
     float amax = 0.f;                                  // largest |value| this thread hands to the fp16 split (X3 == 2): range guard
@@ -133,16 +137,16 @@ __global__ __launch_bounds__(NW * 64, X3 == 1 ? 2 : 4) void linf_mlp_kernel(Bfsr
     const int b = bid / tiles_per_image;
     const long long NQ = (long long)a.qh * a.qw;
     const long long q0 = (long long)(bid - b * tiles_per_image) * P;
-    const long long q = q0 + lane;                     // this lane's query point during feature generation
-    const bool qok = q < NQ;
 
     // ---- per-point geometry, identical arithmetic to linf_features_kernel (linf.py:332-383) ------------------------------
     const int h = a.h, w = a.w;
     const float fh = (float)h, fw = (float)w;
-    float rel_y[4], rel_x[4], wk[4];
-    int off[4];
-    {
-        const long long qq = qok ? q : NQ - 1;
+    float rel_y[PG][4], rel_x[PG][4], wk[PG][4];       // [point group]: this lane's query point q0 + 64 pg + lane during feature generation
+    int off[PG][4];
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) {
+        const long long q = q0 + 64 * pg + lane;
+        const long long qq = q < NQ ? q : NQ - 1;
         const float cy = a.coord[((long long)b * NQ + qq) * 2 + 0];
         const float cx = a.coord[((long long)b * NQ + qq) * 2 + 1];
         float area[4];
@@ -158,13 +162,13 @@ __global__ __launch_bounds__(NW * 64, X3 == 1 ? 2 : 4) void linf_mlp_kernel(Bfsr
             jx = min(max(jx, 0), w - 1);
             const float qy = a.cy0 + a.cy1 * (float)jy;
             const float qx = a.cx0 + a.cx1 * (float)jx;
-            rel_y[j] = (cy - qy) * fh; rel_x[j] = (cx - qx) * fw;
-            area[j] = fabsf(rel_y[j] * rel_x[j]) + 1e-9f;
-            off[j] = jy * w + jx;
+            rel_y[pg][j] = (cy - qy) * fh; rel_x[pg][j] = (cx - qx) * fw;
+            area[j] = fabsf(rel_y[pg][j] * rel_x[pg][j]) + 1e-9f;
+            off[pg][j] = jy * w + jx;
         }
         const float tot = ((area[0] + area[1]) + area[2]) + area[3];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wk[j] = area[3 - j] / tot;
+        for (int j = 0; j < 4; ++j) wk[pg][j] = area[3 - j] / tot;
     }
     const float cell_y = a.cell[b * 2 + 0] * fh, cell_x = a.cell[b * 2 + 1] * fw;
     const long long hw = (long long)h * w;
@@ -176,8 +180,9 @@ __global__ __launch_bounds__(NW * 64, X3 == 1 ? 2 : 4) void linf_mlp_kernel(Bfsr
     // k is wave-uniform but not a compile-time constant: the four per-neighbour values are picked with selects (an array
     // indexed by a run-time k would be demoted to scratch memory)
     struct Gather { float co0[8], co1[8], f0[8], f1[8]; };
-    auto gen_load = [&](int k, int c0, Gather& g) {
-        const int ofs = k == 0 ? off[0] : (k == 1 ? off[1] : (k == 2 ? off[2] : off[3]));
+    auto gen_load = [&](int k, int c0, Gather& g, auto pg_) {
+        constexpr int pg = decltype(pg_)::value;
+        const int ofs = k == 0 ? off[pg][0] : (k == 1 ? off[pg][1] : (k == 2 ? off[pg][2] : off[pg][3]));
         const float* cfp = cfb + ofs;
         if (a.cf_fmt == 1) {
             // cf as an h2 tensor [512/8][hi, lo][h*w][8] fp16: the 8 channels of a block are ONE 16-byte word per plane -- 8 loads instead of 32
@@ -206,10 +211,11 @@ __global__ __launch_bounds__(NW * 64, X3 == 1 ? 2 : 4) void linf_mlp_kernel(Bfsr
             g.f0[e] = cfp[(long long)(HID + c) * hw]; g.f1[e] = cfp[(long long)(HID + HID / 2 + c) * hw];
         }
     };
-    auto gen_finish = [&](int k, int c0, const Gather& g_, unsigned char* dst) {
-        const float ry = k == 0 ? rel_y[0] : (k == 1 ? rel_y[1] : (k == 2 ? rel_y[2] : rel_y[3]));
-        const float rx = k == 0 ? rel_x[0] : (k == 1 ? rel_x[1] : (k == 2 ? rel_x[2] : rel_x[3]));
-        const float wgt = k == 0 ? wk[0] : (k == 1 ? wk[1] : (k == 2 ? wk[2] : wk[3]));
+    auto gen_finish = [&](int k, int c0, const Gather& g_, unsigned char* dst, auto pg_) {
+        constexpr int pg = decltype(pg_)::value;
+        const float ry = k == 0 ? rel_y[pg][0] : (k == 1 ? rel_y[pg][1] : (k == 2 ? rel_y[pg][2] : rel_y[pg][3]));
+        const float rx = k == 0 ? rel_x[pg][0] : (k == 1 ? rel_x[pg][1] : (k == 2 ? rel_x[pg][2] : rel_x[pg][3]));
+        const float wgt = k == 0 ? wk[pg][0] : (k == 1 ? wk[pg][1] : (k == 2 ? wk[pg][2] : wk[pg][3]));
         float vc[8], vs[8];
         Gather d;
         if (a.cf_fmt == 1) {
@@ -248,8 +254,8 @@ __global__ __launch_bounds__(NW * 64, X3 == 1 ? 2 : 4) void linf_mlp_kernel(Bfsr
         encode8<X3>(vs, fs, amax);
 #pragma unroll
         for (int pl = 0; pl < PL; ++pl) {
-            *reinterpret_cast<frag*>(dst + ((pl * 2 + 0) * P + lane) * 16) = fc[pl];
-            *reinterpret_cast<frag*>(dst + ((pl * 2 + 1) * P + lane) * 16) = fs[pl];
+            *reinterpret_cast<frag*>(dst + ((pl * 2 + 0) * P + 64 * pg + lane) * 16) = fc[pl];
+            *reinterpret_cast<frag*>(dst + ((pl * 2 + 1) * P + 64 * pg + lane) * 16) = fs[pl];
         }
     };
 
@@ -261,34 +267,34 @@ __global__ __launch_bounds__(NW * 64, X3 == 1 ? 2 : 4) void linf_mlp_kernel(Bfsr
 #pragma unroll
         for (int pl = 0; pl < PL; ++pl) dst[pl] = *reinterpret_cast<const frag*>(p + pl * 64 * 8);
     };
-    auto load_b = [&](const unsigned char* chunk, frag (&dst)[PL][2]) {
+    auto load_b = [&](const unsigned char* chunk, frag (&dst)[PL][NT]) {
 #pragma unroll
         for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
                 dst[pl][nt] = *reinterpret_cast<const frag*>(chunk + ((pl * 2 + lhi) * P + nt * 32 + l31) * 16);
     };
     // acc[nt] += A(tile) x B(chunk): X3 = six cross products, small terms first
-    auto mma = [&](f32x16 (&acc)[2], const frag (&af)[PL], const frag (&bf)[PL][2]) {
+    auto mma = [&](f32x16 (&acc)[NT], const frag (&af)[PL], const frag (&bf)[PL][NT]) {
         if constexpr (X3 == 1) {
-#define BFSR_T(PA_, PB_) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) acc[nt] = MD::mfma(af[PA_], bf[PB_][nt], acc[nt]);
+#define BFSR_T(PA_, PB_) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[nt] = MD::mfma(af[PA_], bf[PB_][nt], acc[nt]);
             BFSR_T(2, 0) BFSR_T(0, 2) BFSR_T(1, 1) BFSR_T(1, 0) BFSR_T(0, 1) BFSR_T(0, 0)
 #undef BFSR_T
         } else if constexpr (X3 == 2) {
-#define BFSR_T(PA_, PB_) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) acc[nt] = MD::mfma(af[PA_], bf[PB_][nt], acc[nt]);
+#define BFSR_T(PA_, PB_) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[nt] = MD::mfma(af[PA_], bf[PB_][nt], acc[nt]);
             BFSR_T(1, 0) BFSR_T(0, 1) BFSR_T(0, 0)
 #undef BFSR_T
         } else {
             if (BFSR_MLP_ABL & 8) { acc[0][0] += (float)af[0][0] * (float)bf[0][0][0]; return; }
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) acc[nt] = MD::mfma(af[0], bf[0][nt], acc[nt]);
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = MD::mfma(af[0], bf[0][nt], acc[nt]);
         }
     };
     // K loop of one output tile over n chunks of 16 channels whose B operands sit at chunk0, chunk0 + CHUNK, ...: the A fragments
     // (weights, straight from global / L2: ~1 us away) run THREE chunks ahead in a ring of four -- with one chunk of lookahead
     // the loop was bound by the weight-load latency (12 MFMAs = 384 cycles per chunk vs > 1000 cycles of L2 latency)
-    auto k_loop = [&](f32x16 (&acc_)[2], const unsigned short* wl, int nchunk_total, int mt, int kc0, int n, const unsigned char* chunk0) {
-        frag af[4][PL], bf[PL][2];
+    auto k_loop = [&](f32x16 (&acc_)[NT], const unsigned short* wl, int nchunk_total, int mt, int kc0, int n, const unsigned char* chunk0) {
+        frag af[4][PL], bf[PL][NT];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             if (i < n) load_a(wl, nchunk_total, mt, kc0 + i, af[i]);
@@ -300,9 +306,9 @@ __global__ __launch_bounds__(NW * 64, X3 == 1 ? 2 : 4) void linf_mlp_kernel(Bfsr
         }
     };
     // one output tile of a hidden layer -> bias, ReLU, channel-octet transposition, re-encode, write as activation chunks
-    auto store_hidden = [&](const f32x16 (&acc)[2], const float* __restrict__ bias, int mt, float asc) {
+    auto store_hidden = [&](const f32x16 (&acc)[NT], const float* __restrict__ bias, int mt, float asc) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             float v[2][8];
             asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");       // MFMA result -> VALU read inside the asm below: 20 wait states (>= 19 of a 16-pass XDL op), self-sufficient                 // MFMA result -> VALU read inside the asm below
 #pragma unroll
@@ -334,15 +340,19 @@ __global__ __launch_bounds__(NW * 64, X3 == 1 ? 2 : 4) void linf_mlp_kernel(Bfsr
     const unsigned short* w1 = wbase;
     constexpr long long WSZ1 = (long long)(HID / 32) * (K1 / KC) * PL * 64 * 8;
     constexpr long long WSZH = (long long)(HID / 32) * NCH_HID * PL * 64 * 8;
-    f32x16 acc[2];
+    typedef std::integral_constant<int, 0> G0;
+    typedef std::integral_constant<int, 1> G1;
+    f32x16 acc[NT];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
     {
-        Gather g0;
-        gen_load(0, wave * 8, g0);
-        gen_finish(0, wave * 8, g0, smem + wave * CHUNK);             // interval 0 (chunk kc = wave) -> stage A
+        Gather g0[PG];
+        gen_load(0, wave * 8, g0[0], G0());
+        if constexpr (PG > 1) gen_load(0, wave * 8, g0[PG - 1], G1());
+        gen_finish(0, wave * 8, g0[0], smem + wave * CHUNK, G0());    // interval 0 (chunk kc = wave) -> stage A
+        if constexpr (PG > 1) gen_finish(0, wave * 8, g0[PG - 1], smem + wave * CHUNK, G1());
     }
     __syncthreads();
 #pragma unroll 1
@@ -350,10 +360,16 @@ __global__ __launch_bounds__(NW * 64, X3 == 1 ? 2 : 4) void linf_mlp_kernel(Bfsr
         // interval t+1: chunk kc = (t+1)*8 + wave -> neighbour (t+1)/2, pair block kc % 16: gathers issued, then the MFMAs of
         // interval t (which read stage t), then the arithmetic of interval t+1 into the other stage
         const int nk = (t + 1) >> 1, nc0 = ((((t + 1) & 1) * 8) + wave) * 8;
-        Gather g;
-        if (t + 1 < 8) gen_load(nk, nc0, g);
+        Gather g[PG];
+        if (t + 1 < 8) {
+            gen_load(nk, nc0, g[0], G0());
+            if constexpr (PG > 1) gen_load(nk, nc0, g[PG - 1], G1());
+        }
         k_loop(acc, w1, K1 / KC, wave, t * 8, 8, smem + (t & 1) * 8 * CHUNK);
-        if (t + 1 < 8) gen_finish(nk, nc0, g, smem + (((t + 1) & 1) * 8 + wave) * CHUNK);
+        if (t + 1 < 8) {
+            gen_finish(nk, nc0, g[0], smem + (((t + 1) & 1) * 8 + wave) * CHUNK, G0());
+            if constexpr (PG > 1) gen_finish(nk, nc0, g[PG - 1], smem + (((t + 1) & 1) * 8 + wave) * CHUNK, G1());
+        }
         __syncthreads();
     }
     store_hidden(acc, a.bias, wave, a.acc_scale[0]);                 // all waves are past the last interval's reads (barrier above)
@@ -363,7 +379,7 @@ __global__ __launch_bounds__(NW * 64, X3 == 1 ? 2 : 4) void linf_mlp_kernel(Bfsr
     for (int layer = 1; layer <= 2; ++layer) {
         const unsigned short* wl = wbase + WSZ1 + (layer - 1) * WSZH;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
         k_loop(acc, wl, NCH_HID, wave, 0, NCH_HID, smem);
@@ -380,18 +396,18 @@ __global__ __launch_bounds__(NW * 64, X3 == 1 ? 2 : 4) void linf_mlp_kernel(Bfsr
         float* __restrict__ outb = a.out + (long long)b * a.out_bs;
         for (int mt = wave; mt < mtiles; mt += NW) {
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
             k_loop(acc, wl, NCH_HID, mt, 0, NCH_HID, smem);
             if constexpr (X3 == 2) {
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[nt][r] *= a.acc_scale[3];
             }
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+            for (int nt = 0; nt < NT; ++nt) {
                 const long long qq = q0 + nt * 32 + l31;
                 if (qq >= NQ) continue;
                 if ((BFSR_MLP_ABL & 4) && acc[nt][0] != 1234.5f) continue;
@@ -421,17 +437,19 @@ __global__ __launch_bounds__(NW * 64, X3 == 1 ? 2 : 4) void linf_mlp_kernel(Bfsr
     if (X3 == 2 && a.flag && __any((int)!(amax < 65504.f))) { if (lane == 0) atomicOr(a.flag, 1u); }
 }
 
-template <int X3>
+template <int X3, int NT>
 int launch_mlp(const BfsrLinfMlpArgs& a, hipStream_t st)
 {
-    constexpr int LDS = 16 * Mode<X3>::PL * 2 * P * 16;              // 98 304 B (x3) / 32 768 B (fp16)
+    constexpr int P = 32 * NT;
+    constexpr int LDS = 16 * Mode<X3>::PL * 2 * P * 16;              // NT = 2: 98 304 B (x3) / 65 536 (f16x2) / 32 768 B (fp16); NT = 4: 131 072 (f16x2) / 65 536 (fp16)
+    static_assert(LDS <= 160 * 1024, "LDS budget");
     static std::atomic<unsigned long long> lds_done{0};
-    if (LDS > 65536 && bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&linf_mlp_kernel<X3>), LDS, lds_done) != 0) return -1;
+    if (LDS > 65536 && bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&linf_mlp_kernel<X3, NT>), LDS, lds_done) != 0) return -1;
     const long long NQ = (long long)a.qh * a.qw;
     const long long tiles = (NQ + P - 1) / P;
     const long long nblk = tiles * a.B;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return -1;
-    hipLaunchKernelGGL(linf_mlp_kernel<X3>, dim3((unsigned)nblk), dim3(NW * 64), LDS, st, a, (int)tiles);
+    hipLaunchKernelGGL((linf_mlp_kernel<X3, NT>), dim3((unsigned)nblk), dim3(NW * 64), LDS, st, a, (int)tiles);
     return (int)hipGetLastError();
 }
 
@@ -522,10 +540,13 @@ extern "C" int bfsr_linf_mlp(const BfsrLinfMlpArgs* a, int x3, void* stream)
                             (reinterpret_cast<unsigned long long>(a->bias) & 15))) return -1;
     if (a->cf_fmt != 0 && a->cf_fmt != 1) return -1;
     if (a->cf_fmt == 1 && ((reinterpret_cast<unsigned long long>(a->cf) & 15) || (a->cf_bs & 7))) return -1;       // 16-byte gathers
+    if (a->tile != 0 && a->tile != 64 && a->tile != 128) return -1;
+    if (a->tile == 128 && x3 == 1) return -1;                            // the bf16x3 activations of 128 points do not fit LDS (196 KB)
     BfsrLinfMlpArgs c = *a;
     if (x3 == 2) {
         for (int i = 0; i < 4; ++i) if (!(c.acc_scale[i] > 0.f)) return -1;
-        return launch_mlp<2>(c, st);
+        return a->tile == 128 ? launch_mlp<2, 4>(c, st) : launch_mlp<2, 2>(c, st);
     }
-    return x3 ? launch_mlp<1>(c, st) : launch_mlp<0>(c, st);
+    if (x3) return launch_mlp<1, 2>(c, st);
+    return a->tile == 128 ? launch_mlp<0, 4>(c, st) : launch_mlp<0, 2>(c, st);
 }

@@ -1176,7 +1176,7 @@ class HipOps(object):
         fmt = 1 if quad_layers is not None else 0
         return packed.to(self.device), bias.to(self.device), Cout, (fmt if scales is None else (fmt, tuple(scales)))
 
-    def linf_mlp(self, cf, coord, cell, phase, packed, out, hidden, x3=True):
+    def linf_mlp(self, cf, coord, cell, phase, packed, out, hidden, x3=True, tile=None):
         """fused Fourier features + shared MLP: cf [B,2*hidden,h,w], coord [B,qh,qw,2], cell [B,2] -> out = affine_info [B,Cout,qh,qw]
         (the same buffer in the quad-major layout when the weights were packed with quad_layers)."""
         wts, bias, Cout, fmt = packed
@@ -1205,6 +1205,12 @@ class HipOps(object):
         a.cy0, a.cy1, a.cx0, a.cx1 = -1 + 1.0 / h, 2 * (1.0 / h), -1 + 1.0 / w, 2 * (1.0 / w)
         if fmt and (out.data_ptr() & 15 or a.out_bs & 3):
             raise ValueError("linf_mlp: the quad-major output needs a 16-byte aligned buffer")
+        # 128-point workgroup tiles (round 6; fp16 and fp16-pair arithmetic: the activations of 128 points fit LDS): half the weight traffic per
+        # point, identical bits -- and SLOWER (config 5: 19.1 against 15.6 ms, config 3: 8.6 against 8.2): at 181-220 registers one workgroup per CU
+        # is left, and the kernel lives on the latency hiding of four waves per SIMD (profiles/r06m_*).  Off by default; BFSR_MLP_TILE=128 selects it.
+        if tile is None:
+            tile = int(os.environ.get("BFSR_MLP_TILE", "64"))
+        a.tile = 128 if (tile == 128 and mode != 1 and qh * qw >= 128) else 64
         key = (("linf_mlp_f2" if mode == 2 else "linf_mlp_x3") if x3 else "linf_mlp_f16", hidden, Cout, cf.shape[0], qh, qw)
         _lib.check(self._launch(key, lambda: self.lib.bfsr_linf_mlp(C.byref(a), mode, self._stream())), "linf_mlp")
         return out

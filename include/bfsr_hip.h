@@ -497,6 +497,8 @@ typedef struct BfsrLinfMlpArgs {
     int cf_fmt;                    /* (ABI 4) 0: cf = fp32 [B,2*hidden,h,w], cf_bs in floats.  1: cf = h2 tensor [B][2*hidden/8][hi, lo][h][w][8] fp16 (what
                                     * bfsr_conv3x3_h2s / _h2x write with y_fmt = 1), cf_bs in fp16 elements: the 8 channels of a block are one 16-byte
                                     * gather per plane instead of eight 4-byte ones (value = hi + lo: 22 bits) */
+    int tile;                      /* (ABI 7) query points per workgroup tile: 0 or 64, or 128 (x3 = 0 / 2 only): every weight fragment pulled from L2 feeds four
+                                    * MFMAs instead of two; identical results */
 } BfsrLinfMlpArgs;
 /* x3: 0 = operands rounded to fp16 (LINF precision='fp16'); 1 = exact three-term bf16 split, six products; 2 = two-term fp16 split of
  * both operands, three products (fp32-class accuracy at half the matrix instructions of 1; weights from bfsr_pack_linf_mlp_f16x2) */

@@ -89,6 +89,10 @@ def _linf_mlp_fused_body(hip, O, hw, q, x3):
     outq = hip.linf_mlp(hip.to_device(cf), hip.to_device(coord), hip.to_device(cell), hip.vec(phase), hip.pack_linf_mlp(ws, bs, x3=x3, quad_layers=(L, D)),
                         hip.empty(B, 56 * L, qh, qw), HD, x3=x3)
     assert torch.equal(CPU._ai_quads(outq.cpu(), L, D, inverse=True), out.cpu()), "out_fmt=1 must hold the values of out_fmt=0"
+    # 128-point workgroup tiles (optional, BFSR_MLP_TILE=128; the bf16x3 mode has no such form): same summation order per point -> identical bits
+    o128 = hip.linf_mlp(hip.to_device(cf), hip.to_device(coord), hip.to_device(cell), hip.vec(phase), hip.pack_linf_mlp(ws, bs, x3=x3),
+                        hip.empty(B, Cout, qh, qw), HD, x3=x3, tile=128)
+    assert torch.equal(o128.cpu(), out.cpu()), "64- and 128-point tiles must give identical bits"
     # cf handed over as an h2 tensor (cf_fmt = 1: 16-byte gathers of 8 channels per plane): bit-identical to the fp32 map holding hi + lo
     cfh = hip.h2_pack(hip.to_device(cf), hip.h2_empty(B, 2 * HD, h, w))
     cf22 = hip.h2_unpack(cfh, hip.empty(B, 2 * HD, h, w))

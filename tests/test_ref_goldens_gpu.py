@@ -194,3 +194,67 @@ def test_flowstep_goldens_through_the_fused_pair(hip, golden_dir, tag, la, lb, q
     z = eng._pair(sb, z, pre(lb), "gold_enc", False, {}, cnd["pre_fmt"])
     close(z, T(g[tag + "_fwd_ab"]), 2e-5, "fused pairs, forward, steps %d + %d (quads %s)" % (la, lb, quads))
     ops.check_range()
+
+
+@pytest.mark.parametrize("quads", [True, False])
+def test_flowstep_goldens_through_the_wide_pair(hip, golden_dir, quads):
+    """Reference goldens of two CONSECUTIVE coupled FlowSteps of level 3 (C = 96; FlowStep.py:88-129 on the genuine modules,
+    tests/golden/make_golden_steps_wide.py) through the engine's level-3 hot path of round 6: the batched 320 -> 16*64 hoists (pre_aff as an h2
+    tensor), the fFeatures nets, then coupling_wide_head -> coupling_wide_tail (coupling_wide.hip) -- in decode order (b then a: step a's z1 is the
+    h2 copy step b's tail wrote, no pack launch) and in encode order (the tail of step a applies the head of step b), with quad-major and NCHW h_ft.
+    B = 2, 10 x 36: two 8-row x two 32-pixel tiles, ragged both ways."""
+    from test_srflow_gpu import build
+    m, prior, opt, sd, psd = build(hip, 4)
+    g = np.load(os.path.join(golden_dir, "srflow_steps_wide.npz"))
+    if bytes(g["weights_sha256"]).decode() != synth.digest(sd):
+        pytest.skip("synthetic weights differ on this machine (numpy/LAPACK build)")
+    eng = m.netG.module.engine()
+    ops, d = eng.ops, hip.to_device
+    la, lb = 42, 43
+    lya, lyb = [ly for ly in eng.layers if ly.index == la][0], [ly for ly in eng.layers if ly.index == lb][0]
+    z0 = d(T(g["l3_z"]))
+    B, C, H, W = z0.shape
+    level = lya.level
+    assert (level, C, lya.coupled, lyb.coupled) == (3, 96, True, True)
+    ft = {level: d(T(g["l3_ft"]))}
+    hz = eng.hoist[level]
+    eng._hoist_buffers(level, hz, ft, B)
+    cnd = eng._hoist_level(level, hz, ft, B, quads)
+    sa, sb = eng.steps[la], eng.steps[lb]
+    assert sa.wide is not None and sb.wide is not None and cnd["pre_h2"] is not None, "the default path of level 3 is the wide pair"
+    assert cnd["h_ft_fmt"][la] == 0 and cnd["h_ft_fmt"][lb] == int(quads)
+
+    def hft(idx):
+        k = cnd["slot"][idx]
+        return cnd["h_ft"][:, 2 * C * k: 2 * C * (k + 1)]
+
+    def pre(idx):
+        k = cnd["slot"][idx]
+        return cnd["pre_aff"][:, 64 * k: 64 * (k + 1)]
+
+    def wide(st, ly, nxt):
+        w = eng._wide_info(st, cnd, cnd["slot"][ly.index], ly, nxt)
+        assert w is not None and (w["nxt"] is None) == (nxt is None)
+        return w
+
+    # ---- decode order: step b reversed (its tail writes step a's z1 as an h2 tensor), then step a
+    z = z0.clone()
+    eng._z1h_next.clear()
+    for st, ly, nxt, ref in ((sb, lyb, lya, "_rev_b"), (sa, lya, None, "_rev_ba")):
+        kw = dict(h_ft=hft(ly.index), h_ft_fmt=cnd["h_ft_fmt"][ly.index], w=st.w_inv, an_bias=st.an_bias, an_escale=st.an_expneg)
+        z = eng._pair(st, z, pre(ly.index), "gold_dec3", True, kw, cnd["pre_fmt"], wide=wide(st, ly, nxt))
+        close(z, T(g["l3" + ref]), 2e-5, "wide pair, reverse, step %d (quads %s)" % (ly.index, quads))
+        if nxt is not None:
+            assert eng._z1h_next.get("gold_dec3") == (z.data_ptr(), nxt.index), "the tail must have left the next step's z1 behind"
+    # ---- encode order: the head of step a on the generic kernel (its h_ft slot stays NCHW: the level's first coupled step), then pair(a)
+    # whose tail applies step b's ActNorm, W and feature-conditional affine, then pair(b)
+    z = z0.clone()
+    ops.flow_pointwise(z, z, False, an_bias=sa.an_bias, an_escale=sa.an_exp, w=sa.w_fwd, wt=sa.w_fwd_t, h_ft=hft(la))
+    z1 = eng._pair(sa, z.clone(), pre(la), "gold_enc3", False, {}, cnd["pre_fmt"], wide=wide(sa, lya, None))
+    close(z1, T(g["l3_fwd_a"]), 2e-5, "wide pair, forward, step %d alone (quads %s)" % (la, quads))
+    kw = dict(an_bias=sb.an_bias, an_escale=sb.an_exp, w=sb.w_fwd, h_ft=hft(lb), h_ft_fmt=cnd["h_ft_fmt"][lb])
+    z = eng._pair(sa, z, pre(la), "gold_enc3", False, kw, cnd["pre_fmt"], wide=wide(sa, lya, lyb))
+    z = eng._pair(sb, z, pre(lb), "gold_enc3", False, {}, cnd["pre_fmt"], wide=wide(sb, lyb, None))
+    close(z, T(g["l3_fwd_ab"]), 2e-5, "wide pairs, forward, steps %d + %d (quads %s)" % (la, lb, quads))
+    ops.check_range()
+

@@ -68,7 +68,7 @@ __device__ __forceinline__ void wait_vmcnt(int n)
 {
     switch (n) {
 #define W_(N_) case N_: asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory"); break;
-        W_(6) W_(7) W_(8) W_(9) W_(10) W_(12) W_(14) W_(16) W_(18) W_(20)
+        W_(5) W_(6) W_(7) W_(8) W_(9) W_(10) W_(12) W_(14) W_(15) W_(16) W_(18) W_(20)
 #undef W_
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
@@ -80,13 +80,18 @@ __device__ __forceinline__ void wait_vmcnt(int n)
 // of pieces for every chunk -- and only ONE KIND of load: LDS-DMA pieces and ordinary register loads of one wave do NOT complete
 // in issue order relative to each other (measured: a wave mixing them passed the barrier with input pieces still in flight).
 //   Four DMA loaders: piece i of a stage (i < 20: input position group i>>1, k half i&1; else weight piece i-20) -> loader i % 4.
-template <int MT, class Decode>
+// RES (round 6): the conv's WHOLE weight tensor resident in LDS (convs with one output-channel group and <= 8 chunks: conv1..3 of a dense block, the
+// 64 -> 64 convs): staged once per workgroup in front of the ring, whose stages then hold input only (`ns` of them, as many as fit).  As streamed
+// pieces the weights were 30-47 % of the L2 -> LDS fill of these convs, and the fill (5.4 of ~6.4 TB/s at conv1) is what they are bound by.
+template <int MT, int RES, class Decode>
 __device__ __forceinline__ void h2s_loader_wave(const BfsrConvX3Args& p, unsigned char* smem, int wave, int lane, int slot, int G, int groups,
-                                                int nchunk, int T, unsigned HW16, Decode decode)
+                                                int nchunk, int T, unsigned HW16, int ns, Decode decode)
 {
     const int H = p.H, W = p.W;
     const int ld = wave - NW;
-    constexpr int W_BYTES = SGeo<MT>::W_BYTES, STAGE = SGeo<MT>::STAGE, NS = SGeo<MT>::NS, NPIECE = SGeo<MT>::NPIECE;
+    constexpr int W_BYTES = SGeo<MT>::W_BYTES, STAGE = RES ? IN_BYTES : SGeo<MT>::STAGE, NPIECE = RES ? 20 : SGeo<MT>::NPIECE;
+    const int NS = RES ? ns : SGeo<MT>::NS;
+    unsigned char* ring = smem + (RES ? nchunk * W_BYTES : 0);
     // ---- DMA loaders
     constexpr int ND = NLW;                                          // DMA loaders
     constexpr int NPALL = NPIECE;                                    // pieces they share
@@ -111,8 +116,13 @@ __device__ __forceinline__ void h2s_loader_wave(const BfsrConvX3Args& p, unsigne
             vg[j] = ok ? (unsigned)(gy * W + gx) * 16u : OOB;        // out of range -> the DMA writes zeros (= the padding)
         }
     };
+    if (RES) {                                                        // the resident weights: issued first, so every later `vmcnt` wait covers them
+        const int nwp = nchunk * (W_BYTES / 1024);
+        for (int pi = ld; pi < nwp; pi += ND)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void*)(smem + pi * 1024), 16, (unsigned)lane * 16u + (unsigned)pi * 1024u, 0, 0, 0);
+    }
     auto lstage = [&](int k, int buf, int skip) {
-        unsigned char* base = smem + buf * STAGE;
+        unsigned char* base = ring + buf * STAGE;
         const unsigned wsoff = (unsigned)(cg_ * nchunk + k) * (unsigned)W_BYTES;
 #pragma unroll
         for (int j = 0; j < (NPALL + ND - 1) / ND; ++j) {
@@ -145,10 +155,11 @@ __device__ __forceinline__ void h2s_loader_wave(const BfsrConvX3Args& p, unsigne
     }
 }
 
-template <int MT>
-__global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrConvX3Args p, int tiles_x, int tiles_y, int groups, int nitems)
+template <int MT, int RES>
+__global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrConvX3Args p, int tiles_x, int tiles_y, int groups, int nitems, int ns)
 {
-    constexpr int STAGE = SGeo<MT>::STAGE, NS = SGeo<MT>::NS;
+    constexpr int STAGE = RES ? IN_BYTES : SGeo<MT>::STAGE, W_BYTES_ = SGeo<MT>::W_BYTES;
+    const int NS = RES ? ns : SGeo<MT>::NS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -171,7 +182,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
     };
 
     if (wave >= NW) {
-        h2s_loader_wave<MT>(p, smem, wave, lane, slot, G, groups, nchunk, T, HW16, decode);
+        h2s_loader_wave<MT, RES>(p, smem, wave, lane, slot, G, groups, nchunk, T, HW16, ns, decode);
         return;
     }
 
@@ -180,11 +191,12 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
     // across chunk and tile boundaries: barrier c+1 is passed BEFORE the last step of chunk c so that the first fragments of chunk
     // c+1 are in flight under it.  Register double buffer: chunk parity P (compile-time, two instantiations of the body).
     half8 bq[2][4], aq[2][3 * MT];
-    auto load_step = [&](auto buf_, int st, int dx) {
+    const unsigned char* ring = smem + (RES ? nchunk * W_BYTES_ : 0);
+    auto load_step = [&](auto buf_, int st, int dx, int kw) {            // kw: the chunk's index inside its item (where its resident weights sit)
         constexpr int BUF = decltype(buf_)::value;
-        const unsigned char* sIn = smem + st * STAGE;
+        const unsigned char* sIn = ring + st * STAGE;
         const unsigned char* inB = sIn + (lhi * NPOSP + 2 * wave * PW + l31 + dx) * 16;
-        const unsigned char* wA = sIn + IN_BYTES + (lhi * MT * 32 + l31) * 16 + dx * 3 * (MT * 1024);   // tap = dx*3 + dy
+        const unsigned char* wA = (RES ? smem + kw * W_BYTES_ : sIn + IN_BYTES) + (lhi * MT * 32 + l31) * 16 + dx * 3 * (MT * 1024);   // tap = dx*3 + dy
 #pragma unroll
         for (int r = 0; r < 4; ++r) bq[BUF][r] = *reinterpret_cast<const half8*>(inB + r * PW * 16);
 #pragma unroll
@@ -205,31 +217,32 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
     };
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
-    int c = 0, st = 0;                                                   // chunk counter, its LDS stage
+    int c = 0, st = 0, kc = 0;                                           // chunk counter, its LDS stage, its index inside the item
     auto chunk_body = [&](auto p_, auto q_, bool pf) {                   // p_ = buffer of this chunk's first step, q_ = the other; pf: prefetch the next chunk's first step
         const int nst = st + 1 == NS ? 0 : st + 1;
-        load_step(q_, st, 1);
+        const int nkc = kc + 1 == nchunk ? 0 : kc + 1;
+        load_step(q_, st, 1, kc);
         __builtin_amdgcn_sched_barrier(0);
         mfma_step(p_);
         __builtin_amdgcn_sched_barrier(0);
-        load_step(p_, st, 2);
+        load_step(p_, st, 2, kc);
         __builtin_amdgcn_sched_barrier(0);
         mfma_step(q_);
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < T) {
             __builtin_amdgcn_s_barrier();
-            if (pf) load_step(q_, nst, 0);
+            if (pf) load_step(q_, nst, 0, nkc);
         }
         __builtin_amdgcn_sched_barrier(0);
         mfma_step(p_);
         __builtin_amdgcn_sched_barrier(0);
-        st = nst; ++c;
+        st = nst; kc = nkc; ++c;
     };
     const float slope = p.act == BFSR_ACT_NONE ? 1.f : (p.act == BFSR_ACT_RELU ? 0.f : p.slope);
     const float4* __restrict__ epi = reinterpret_cast<const float4*>(p.epi);
     const long long HW = (long long)H * W;
     __builtin_amdgcn_s_barrier();                                        // barrier 0
-    load_step(I0(), 0, 0);
+    load_step(I0(), 0, 0, 0);
     for (int it = slot; it < nitems; it += G) {
         const Item cur = decode(it);
         float4 pm[MT];
@@ -384,7 +397,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2s_kernel(BfsrCon
                     });
             }
         }
-        if (c < T) load_step(I0(), st, 0);                               // first fragments of the next tile (its barrier is already behind us)
+        if (c < T) load_step(I0(), st, 0, 0);                            // first fragments of the next tile (its barrier is already behind us)
     }
 }
 
@@ -855,7 +868,7 @@ extern "C" int bfsr_pack_conv_weight_h2s(const float* w, int Cout, int Cin, unsi
 
 namespace {
 template <int MT>
-int launch_h2s(const BfsrConvX3Args* a, hipStream_t st)
+int launch_h2s(const BfsrConvX3Args* a, hipStream_t st, bool allow_res)
 {
     const int tiles_x = (a->W + 31) / 32, tiles_y = (a->H + TH - 1) / TH;
     const int groups = (a->Cout + MT * 32 - 1) / (MT * 32);
@@ -868,9 +881,20 @@ int launch_h2s(const BfsrConvX3Args* a, hipStream_t st)
     const long long grid = nitems < cus ? nitems : cus;                  // one persistent workgroup per CU
     // (round 3's ping-pong compute groups and register-staged weight loader were parity-tested and measured within box noise of this
     // kernel: tools/exp/kernels/conv_h2s_r3.hip)
+    // resident weights: one output-channel group, and room for at least four input stages behind the weight tensor
+    const int wb = (a->Cin / 16) * SGeo<MT>::W_BYTES;
+    int ns = (160 * 1024 - wb) / IN_BYTES;
+    ns = ns > 6 ? 6 : ns;
+    if (allow_res && groups == 1 && ns >= 4) {
+        const int lds = wb + ns * IN_BYTES;
+        static std::atomic<unsigned long long> lds_res{0};
+        if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2s_kernel<MT, 1>), 160 * 1024, lds_res) != 0) return -1;
+        hipLaunchKernelGGL((conv3x3_h2s_kernel<MT, 1>), dim3((unsigned)grid), dim3((NW + NLW) * 64), lds, st, *a, tiles_x, tiles_y, groups, (int)nitems, ns);
+        return (int)hipGetLastError();
+    }
     static std::atomic<unsigned long long> lds_done{0};
-    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2s_kernel<MT>), SGeo<MT>::LDS_TOTAL, lds_done) != 0) return -1;
-    hipLaunchKernelGGL((conv3x3_h2s_kernel<MT>), dim3((unsigned)grid), dim3((NW + NLW) * 64), SGeo<MT>::LDS_TOTAL, st, *a, tiles_x, tiles_y, groups, (int)nitems);
+    if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2s_kernel<MT, 0>), SGeo<MT>::LDS_TOTAL, lds_done) != 0) return -1;
+    hipLaunchKernelGGL((conv3x3_h2s_kernel<MT, 0>), dim3((unsigned)grid), dim3((NW + NLW) * 64), SGeo<MT>::LDS_TOTAL, st, *a, tiles_x, tiles_y, groups, (int)nitems, 0);
     return (int)hipGetLastError();
 }
 }  // namespace
@@ -881,7 +905,9 @@ extern "C" int bfsr_conv3x3_h2s(const BfsrConvX3Args* a, void* stream)
     if (!a || !a->x || !a->w || !a->y) return -1;
     if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->Cin <= 0 || (a->Cin & 31) || a->Cout <= 0) return -1;
     if (a->y_fmt < 0 || a->y_fmt > 2) return -1;
-    if (a->mtile < 0 || a->mtile > 2) return -1;
+    const int mt_ = a->mtile & 0xff;
+    const bool allow_res = !(a->mtile & 0x100);                          // bit 8 of mtile: keep the weights streamed (A/B switch, BFSR_H2S_RES=0)
+    if (mt_ < 0 || mt_ > 2 || (a->mtile & ~0x1ff)) return -1;
     if ((a->y_fmt != 0 || a->res1 || a->res2) && (a->Cout & 7)) return -1;
     if ((long long)(a->Cin / 8) * 2 * a->H * a->W * 16 >= (1LL << 31)) return -1;      // 32-bit byte offsets inside one batch item
     if ((long long)((a->Cout + 7) / 8) * 2 * a->H * a->W * 8 >= (1LL << 31)) return -1;  // 32-bit element offsets in the epilogue
@@ -889,7 +915,7 @@ extern "C" int bfsr_conv3x3_h2s(const BfsrConvX3Args* a, void* stream)
     if (a->y_fmt != 0 && ((reinterpret_cast<unsigned long long>(a->y) & 15) || (a->y_bs & 7))) return -1;
     if (a->res1 && ((reinterpret_cast<unsigned long long>(a->res1) & 15) || (a->res1_bs & 7))) return -1;
     if (a->res2 && ((reinterpret_cast<unsigned long long>(a->res2) & 15) || (a->res2_bs & 7))) return -1;
-    return a->mtile == 2 ? launch_h2s<2>(a, st) : launch_h2s<1>(a, st);
+    return mt_ == 2 ? launch_h2s<2>(a, st, allow_res) : launch_h2s<1>(a, st, allow_res);
 }
 
 extern "C" long long bfsr_conv_packed_size_h2x(int Cout, int Cin, int mtile)

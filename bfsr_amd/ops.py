@@ -730,7 +730,9 @@ class HipOps(object):
         if (Cin, Cout, H, W) != (pw.Cin, pw.Cout, H2, W2) or pw.KS != 3 or x.shape[0] != out.shape[0]:
             raise ValueError("conv_h2s: shape mismatch x%s out%s weight(Cout=%d,Cin=%d)" % (tuple(x.shape), tuple(out.shape), pw.Cout, pw.Cin))
         a.Cin, a.Cout = Cin, Cout
-        a.w, a.mtile = pw.data.data_ptr(), pw.mtile
+        # bit 8: keep the weights streamed.  The LDS-resident form (round 6) is bit-identical and NOT faster (config 5: 141.71 vs 141.67 ms, profiles/r06o_*):
+        # off unless BFSR_H2S_RES=1
+        a.w, a.mtile = pw.data.data_ptr(), pw.mtile | (0 if os.environ.get("BFSR_H2S_RES", "0") == "1" else 0x100)
         a.B, a.H, a.W = out.shape[0], H, W
         a.epi, a.act, a.slope, a.tune = _ptr(epi), act, slope, tune
         for name, t, al in (("res1", res1, alpha1), ("res2", res2, alpha2)):

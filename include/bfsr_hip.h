@@ -164,7 +164,7 @@ typedef struct BfsrConvX3Args {
     const unsigned short* res2; long long res2_bs; float alpha2;
     int tune;
     float acc_scale;                               /* bfsr_conv3x3_h2x only: 1 / (the power of two the weights were packed with) */
-    int mtile;                                     /* bfsr_conv3x3_h2x: 32-cout M tiles per workgroup the weights were packed for (0 or 1); bfsr_conv3x3_h2s: 0, 1 or 2 */
+    int mtile;                                     /* bfsr_conv3x3_h2x: 32-cout M tiles per workgroup the weights were packed for (0 or 1); bfsr_conv3x3_h2s: 0, 1 or 2 (| 0x100: keep the weights streamed instead of LDS-resident where they would fit) */
     unsigned* flag;                                /* bfsr_conv3x3_h2x only, optional device word: bit 0 is set when a value written to an h2 output is >= 65504 */
     const float* up4; long long up4_bs;            /* (ABI 5) bfsr_conv3x3_h2x with y_fmt 2 only, optional: the COMPACT output of bfsr_conv2d_up4_h2t (its y_fmt 3:
                                                     * [B][Cout/4][H/4][W/4][9 phase classes][4] fp32, batch stride in floats), added to the result after the

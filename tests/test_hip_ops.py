@@ -244,6 +244,30 @@ def test_conv_h2s_64_cout_tiles_give_the_bits_of_32_cout_tiles(hip, case):
                 assert torch.equal(ya.cpu(), yb.cpu()), "h2 output differs (hi_only=%s, %s)" % (hi_only, sorted(kw))
 
 
+@pytest.mark.parametrize("case", [(2, 64, 32, 21, 37), (3, 96, 32, 40, 70), (1, 128, 32, 16, 32), (2, 160, 32, 33, 33), (2, 64, 64, 50, 40), (5, 128, 24, 20, 36)])
+def test_conv_h2s_resident_weights_give_the_bits_of_streamed_weights(hip, case, monkeypatch):
+    """conv_h2s with the conv's whole weight tensor resident in LDS (round 6: one output-channel group, <= 8 chunks; the ring then holds input only, 4-6
+    stages) against the streamed form (BFSR_H2S_RES=0): same fragments, same order -> identical bits.  B > 1 and several tiles per workgroup make the
+    persistent workgroups walk items with the weights staged once; (2, 160, 32, ..) is a shape that stays streamed (10 chunks) -- the switch is a no-op there."""
+    B, Cin, Cout, H, W = case
+    x, w = rnd(141, B, Cin, H, W), rnd(142, Cout, Cin, 3, 3, scale=1.0 / np.sqrt(Cin * 9))
+    xh = hip.h2_pack(hip.to_device(x), hip.h2_empty(B, Cin, H, W))
+    pw, epi = hip.pack_conv_h2s(w), hip.pack_epilogue(Cout, bias=rnd(143, Cout, scale=0.3))
+    ref = CPU.conv(x.half().float(), CPU.pack_conv(w.half().float(), 1), torch.empty(B, Cout, H, W), bias=rnd(143, Cout, scale=0.3), act=2, slope=0.2)
+    outs = {}
+    for res in ("1", "0"):
+        monkeypatch.setenv("BFSR_H2S_RES", res)
+        y = hip.h2_empty(B, (Cout + 7) // 8 * 8, H, W).zero_() if Cout % 8 == 0 else None
+        o32 = hip.conv_h2s(xh, pw, hip.empty(B, Cout, H, W), epi=epi, act=2, slope=0.2)
+        if y is not None:
+            hip.conv_h2s(xh, pw, y, epi=epi, act=2, slope=0.2, hi_only=True)
+        outs[res] = (o32.clone(), None if y is None else y.clone())
+    close(outs["1"][0], ref, 2e-5, "conv_h2s resident weights %s" % (case,))
+    assert torch.equal(outs["1"][0].cpu(), outs["0"][0].cpu()), "fp32 output differs between resident and streamed weights"
+    if outs["1"][1] is not None:
+        assert torch.equal(outs["1"][1].cpu(), outs["0"][1].cpu()), "h2 output differs between resident and streamed weights"
+
+
 H2X_CASES = [(1, 32, 32, 16, 32), (2, 64, 32, 19, 45), (1, 192, 64, 33, 65), (3, 96, 32, 128, 128), (2, 64, 24, 9, 33), (1, 16, 40, 70, 70),
              (5, 48, 32, 40, 40), (2, 64, 64, 50, 40), (1, 160, 104, 17, 31)]
 

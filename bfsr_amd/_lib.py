@@ -278,6 +278,10 @@ def load():
         raise RuntimeError(
             "bfsr_amd: %s not found -- the HIP extension is required (build with "
             "bfsr_amd/csrc/build.sh or __graft_entry__.build()); there is no CPU fallback." % LIB_PATH)
+    # torch first: PyTorch-ROCm ships its own libamdhip64 and the streams / allocations this library is handed come from THAT runtime.  Loaded before
+    # torch, libbfsr_hip.so binds to /opt/rocm's copy instead -- a second runtime instance without torch's device context: every launch then fails
+    # with hipErrorNoDevice (seen with `python __graft_entry__.py smoke`: build() loads the library before smoke() imports torch)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported

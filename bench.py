@@ -518,7 +518,7 @@ def main():
             "roofline": roofline, "roofline_next_kernels": roofline_next, "roofline_by_symbol": by_symbol,
             "roofline_by_symbol_note": "HIP-event time per kernel family in the untimed ranking step; with the side stream active (configs "
                                        "whose batch does not fill the chip) events of overlapping kernels are inflated by contention and the "
-                                       "families sum to more than ms_per_step -- profiles/r05g_keys_cfg2_no_overlap.txt has the BFSR_OVERLAP=0 table",
+                                       "families sum to more than ms_per_step -- profiles/r06k_keys_cfg2_no_overlap.txt has the BFSR_OVERLAP=0 table",
             "roofline_coupling_inverse": roof_tail,
             "cpu_baseline": cpu_baseline, "parity": parity,
             # passes that the range guard of the fp16-pair split re-ran under the bf16x3 split (bfsr_amd/guard.py); the guard's 4-byte read-back at

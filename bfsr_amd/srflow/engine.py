@@ -744,7 +744,7 @@ class SRFlowEngine(object):
             h2 = self._hid.get("ffh%d" % level)
             if h2 is None or tuple(h2.shape) != (B, 8, 2, hl, wl, 8):
                 self._hid["ffh%d" % level] = self.ops.h2_empty(B, 64, hl, wl)
-        if hz.get("h4t") is not None and os.environ.get("BFSR_UP4C", "0") == "1":      # compact taps result of the x4 level (see _hoist_level)
+        if hz.get("h4t") is not None and os.environ.get("BFSR_UP4C", "1") == "1":      # compact taps result of the x4 level (see _hoist_level)
             tp = ft[self._lr_level()]
             ws.get("up4c%d" % level, B, 9 * K * 64, tp.shape[2], tp.shape[3])
         if hz.get("up2") and (hz.get("h2t") is not None or hz.get("h4t") is not None):
@@ -796,10 +796,12 @@ class SRFlowEngine(object):
             taps = ft[self._lr_level()][:, 64:]
             taps_h2 = ops.h2_pack(taps, self._taps_h2[level][1])
             f3 = ops.x3_pack(f, self._ftx3[level][1])
-            if os.environ.get("BFSR_UP4C", "0") == "1":
-                # OPTIONAL (off: measured equal within noise, tools/exp/up4c_check.py: 18.1 vs 18.5 ms per tensor at 16 x 96^2, and it needs a 21.7 GB
-                # buffer at config 4): the taps kernel writes its nine class values per source pixel (9/16 of the full-resolution bytes, no read-back)
-                # and the key conv expands and adds them while it writes the full-resolution tensor; bit-identical to the pre_add form
+            if os.environ.get("BFSR_UP4C", "1") == "1":
+                # DEFAULT since round 6: the taps kernel writes its nine class values per source pixel (9/16 of the full-resolution bytes, no
+                # read-back of the key conv's result) and the key conv expands and adds them while it writes the full-resolution tensor; bit-identical
+                # to the pre_add form (tests/test_srflow_gpu.py::test_x4_level_compact_taps_equals_pre_add).  Config 4 (64 x 96^2): 432.9 -> 424.6 ms
+                # interleaved on one box (profiles/r06p_ab_up4c.txt); the isolated pair of launches at 16 x 96^2 had measured equal (18.1 vs 18.5 ms per
+                # tensor), the gain shows where the 38.7 GB read-back competes with the rest of the pass.  Costs a 0.34 GB-per-crop buffer (21.7 GB at 64).
                 comp = self.ws.get("up4c%d" % level, B, 9 * hid.shape[1], taps.shape[2], taps.shape[3])
                 ops.conv_up4_h2t(taps_h2, h4t[0], comp, compact=True)
                 ops.conv_x3s(f3, hz["ft0_key"], hid, y_fmt=1, up4=comp)

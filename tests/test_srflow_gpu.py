@@ -195,6 +195,23 @@ def test_lp_pass_at_bench_batch_vs_oracle(model4, hip):
     assert m.netG.module.engine().ops.fallbacks == 0
 
 
+def test_lp_pass_8x_at_config4_crop_vs_oracle(hip):
+    """The 8x model at BASELINE config 4's crop size (96 x 96 -> 768 x 768, a 4-crop shard): at this size the x4 level runs on conv_up4_h2t
+    with the compact hand-over, level 3 on the wide pair and the prior's big branch on the LDS-DMA kernels -- kernel choices the 16 x 16
+    reference golden (test_golden_e2e_8x) is too small to reach.  One crop against the pinned oracle, <= 1e-4 max-abs on sr (north_star)."""
+    import oracle.srflow_ref as O
+    from bfsr_amd.srflow.test import lp_infer
+    m, prior, opt, sd, psd = build(hip, 8)
+    lr = synth.smooth_lr_batch(78, 4, 96, 96)
+    out = lp_infer(m, prior, lr, return_all=True)
+    pick = 2
+    ref = O.lp_pipeline(lr[pick:pick + 1], sd, psd, opt, 23, return_all=True)
+    for k in ("sr_raw", "sr"):
+        err = float((out[k][pick:pick + 1].cpu() - ref[k]).abs().max())
+        assert err <= 1e-4, "%s of crop %d of the 8x shard: max-abs %.3e vs the oracle" % (k, pick, err)
+    assert m.netG.module.engine().ops.fallbacks == 0
+
+
 def test_roundtrip_and_batch_invariance_at_config4_size(hip):
     """BASELINE config 4's per-GPU batch on the 8x model (B = 8, 96x96 LR -> 768x768): decode(encode(x)) = x within 1e-4, the LP pass is
     finite, and a shard of the batch gives bit-identical latents (what the data-parallel split of the 64-crop batch relies on)."""
@@ -217,6 +234,27 @@ def test_roundtrip_and_batch_invariance_at_config4_size(hip):
     sr_s = lp_infer(m, prior, lrs)
     assert torch.isfinite(sr).all() and sr.shape == (8, 3, 768, 768)
     assert torch.equal(sr[lo:hi_], sr_s), "LP output of a shard differs from the batch call"
+
+
+def test_x4_level_compact_taps_equals_pre_add(hip, monkeypatch):
+    """The x4 level of the 8x model (RRDBNet_arch.py:105-117 feeding FlowUpsamplerNet level 1): the default form (conv_up4_h2t writes nine class
+    values per source pixel, the key conv expands and adds them: BFSR_UP4C=1) against the read-modify-write form (=0): the hoisted conditioning
+    tensors and the LP output must be the same BITS."""
+    from bfsr_amd.srflow.test import lp_infer
+    m, prior, opt, sd, psd = build(hip, 8)
+    eng = m.netG.module.engine()
+    lr = hip.to_device(synth.smooth_lr_batch(21, 3, 96, 96))
+    res = {}
+    for v in ("1", "0"):
+        monkeypatch.setenv("BFSR_UP4C", v)
+        lr.add_(0.0)                                      # defeats the conditioning cache
+        c1 = eng._await(eng.conditioning(lr)[1])
+        torch.cuda.synchronize()
+        res[v] = {k: c1[k].clone() for k in ("pre_aff", "h_ft")}
+        res[v]["sr"] = lp_infer(m, prior, lr).clone()
+    for k in ("pre_aff", "h_ft", "sr"):
+        assert torch.equal(res["1"][k], res["0"][k]), "%s differs between the compact and the pre_add form: max %.3e" % (
+            k, float((res["1"][k] - res["0"][k]).abs().max()))
 
 
 def test_tau_path_runs(model4, hip):

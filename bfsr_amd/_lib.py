@@ -287,7 +287,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.bfsr_abi_version() != 7:
+    if lib.bfsr_abi_version() != 8:
         raise RuntimeError("bfsr_amd: ABI version mismatch")
     _lib = lib
     return lib

@@ -428,7 +428,9 @@ template <int XM> struct XGeo {
     static constexpr int LDS = 2 * STAGE;       // 118 784 | 155 648
 };
 
-template <int XM>
+// UP4: the instantiation that adds the compact x4 taps result (BfsrConvX3Args.up4; quad-major output, no residuals) -- its own kernel so that the
+// default one does not carry its address arithmetic (as a run-time branch it took the default kernel from 137 to 150 registers and 13 to 37 spilled SGPRs)
+template <int XM, bool UP4 = false>
 __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrConvX3Args p, int tiles_x, int tiles_y, int groups, int nitems)
 {
     constexpr int X_WPL = XGeo<XM>::WPL, X_W = XGeo<XM>::W, X_STAGE = XGeo<XM>::STAGE;
@@ -666,6 +668,30 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
                 }
         };
         if (p.res1) load_res(p.res1, p.res1_bs);                         // lands under the swaps / parameter exchange / activation
+        // the compact x4 taps result (`up4`, added just before the stores below): fetched HERE into the residual registers (the launcher refuses
+        // residuals together with up4: the key conv of the x4 level has none), so that it lands under the swaps / activation as well -- fetched at its point of use it cost the
+        // 64 -> 1024 conv of config 4 ~4.5 ms per launch (28.5 -> 33 ms, profiles/r06q / r06u)
+        auto load_up4 = [&]() {
+            const int hs = H >> 2, wsrc = W >> 2;
+            const unsigned cq = (unsigned)(hs * wsrc) * 144u;            // bytes of one channel quad's compact image [H/4][9][W/4][4]
+            const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.up4) + (long long)cur.b * p.up4_bs, 0,
+                                                                                (unsigned)(p.Cout >> 2) * cq, 0x00020000);
+            const int pxc = gx & 3, cxc = pxc == 0 ? 0 : (pxc == 3 ? 2 : 1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int gy = cur.y0 + 2 * wave + j;
+                const int pyc = gy & 3, cyc = pyc == 0 ? 0 : (pyc == 3 ? 2 : 1);
+                const bool ok = gy < H && gx < W;
+                const unsigned vu = ok ? (unsigned)lh * 2u * cq + (unsigned)(((gy >> 2) * 9 + cyc * 3 + cxc) * wsrc + (gx >> 2)) * 16u : OOB;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const unsigned so = (unsigned)((oct0 + q * 2) * 2) * cq;
+                    rh[j][q] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(ru, vu, so, 0));
+                    rl[j][q] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(ru, vu, so + cq, 0));
+                }
+            }
+        };
+        if constexpr (UP4) load_up4();
         float o[2][2][8];
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");       // MFMA result -> VALU read inside the asm below: 20 wait states (>= 19 of a 16-pass XDL op), self-sufficient
 #pragma unroll
@@ -743,29 +769,18 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
             const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(p.y) + (long long)cur.b * p.y_bs, 0,
                                                                                 (unsigned)((long long)p.Cout * HW * 4), 0x00020000);
             if (p.y_fmt == 2) {                                          // fp32 quad-major [Cout/4][H][W][4]: the octet = two 16-byte stores
-                if (p.up4) {
+                if constexpr (UP4) {
                     // + the COMPACT result of bfsr_conv2d_up4_h2t (y_fmt 3): per source pixel (y/4, x/4) and channel quad the nine phase-class values
-                    // [Cout/4][H/4][W/4][9][4] -- the x4 level's taps share, added here instead of being read back as a full-resolution pre_add
-                    const int hs = H >> 2, wsrc = W >> 2;
-                    const unsigned cq = (unsigned)(hs * wsrc) * 144u;    // bytes of one channel quad's compact image
-                    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.up4) + (long long)cur.b * p.up4_bs, 0,
-                                                                                        (unsigned)(p.Cout >> 2) * cq, 0x00020000);
-                    const int pxc = gx & 3, cxc = pxc == 0 ? 0 : (pxc == 3 ? 2 : 1);
+                    // [Cout/4][H/4][9][W/4][4] (ABI 8: class rows, so that a wave's loads are whole cache lines) -- the x4 level's taps share, added here instead of
+                    // being read back as a full-resolution pre_add
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int gy = cur.y0 + 2 * wave + j;
-                        const int pyc = gy & 3, cyc = pyc == 0 ? 0 : (pyc == 3 ? 2 : 1);
-                        const bool ok = gy < H && gx < W;
-                        const unsigned vu = ok ? (unsigned)lh * 2u * cq + (unsigned)((gy >> 2) * wsrc + (gx >> 2)) * 144u + (unsigned)(cyc * 3 + cxc) * 16u : OOB;
+                    for (int j = 0; j < 2; ++j)
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
-                            const unsigned so = (unsigned)((oct0 + q * 2) * 2) * cq;
-                            const float4 r0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ru, vu, so, 0));
-                            const float4 r1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ru, vu, so + cq, 0));
+                            const float4 r0 = __builtin_bit_cast(float4, rh[j][q]), r1 = __builtin_bit_cast(float4, rl[j][q]);
                             o[j][q][0] += r0.x; o[j][q][1] += r0.y; o[j][q][2] += r0.z; o[j][q][3] += r0.w;
                             o[j][q][4] += r1.x; o[j][q][5] += r1.y; o[j][q][6] += r1.z; o[j][q][7] += r1.w;
                         }
-                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -958,7 +973,7 @@ extern "C" int bfsr_conv3x3_h2x(const BfsrConvX3Args* a, void* stream)
     if (!(a->acc_scale > 0.f)) return -1;
     if ((a->y_fmt != 0 || a->res1 || a->res2) && (a->Cout & 7)) return -1;
     if (a->y_fmt == 2 && ((reinterpret_cast<unsigned long long>(a->y) & 15) || (a->y_bs & 3))) return -1;
-    if (a->up4 && (a->y_fmt != 2 || (a->H & 3) || (a->W & 3) || (reinterpret_cast<unsigned long long>(a->up4) & 15) || (a->up4_bs & 3) ||
+    if (a->up4 && (a->y_fmt != 2 || a->res1 || a->res2 || (a->H & 3) || (a->W & 3) || (reinterpret_cast<unsigned long long>(a->up4) & 15) || (a->up4_bs & 3) ||
                    (long long)(a->Cout / 4) * (a->H / 4) * (a->W / 4) * 144 >= (1LL << 31))) return -1;
     if ((long long)(a->Cin / 8) * 2 * a->H * a->W * 16 >= (1LL << 31)) return -1;      // 32-bit byte offsets inside one batch item
     if ((long long)((a->Cout + 7) / 8) * 2 * a->H * a->W * 8 >= (1LL << 31)) return -1;  // 32-bit element offsets in the epilogue
@@ -977,6 +992,12 @@ extern "C" int bfsr_conv3x3_h2x(const BfsrConvX3Args* a, void* stream)
     if (cus <= 0) return -1;
     if (a->tune > 0) cus = a->tune;
     const long long grid = nitems < cus ? nitems : cus;                  // one persistent workgroup per CU
+    if (a->up4) {
+        static std::atomic<unsigned long long> lds_up4{0};
+        if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2x_kernel<1, true>), XGeo<1>::LDS, lds_up4) != 0) return -1;
+        hipLaunchKernelGGL((conv3x3_h2x_kernel<1, true>), dim3((unsigned)grid), dim3((NW + NLW) * 64), XGeo<1>::LDS, st, *a, tiles_x, tiles_y, groups, (int)nitems);
+        return (int)hipGetLastError();
+    }
     static std::atomic<unsigned long long> lds_done{0};
     if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_h2x_kernel<1>), XGeo<1>::LDS, lds_done) != 0) return -1;
     hipLaunchKernelGGL((conv3x3_h2x_kernel<1>), dim3((unsigned)grid), dim3((NW + NLW) * 64), XGeo<1>::LDS, st, *a, tiles_x, tiles_y, groups, (int)nitems);

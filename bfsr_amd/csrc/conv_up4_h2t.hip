@@ -229,11 +229,14 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_up4_h2t_kernel(BfsrUp2H2Args
         const int sx = cur.x0 + lx, sy = cur.y0 + wave;
         const bool ok = sy < h && sx < w;
         if constexpr (COMPACT) {
-            // COMPACT output [Cout/4][h][w][9 classes][4]: the nine class values of this lane's source pixel, 144 contiguous bytes per channel quad;
+            // COMPACT output [Cout/4][h][9 classes][w][4]: the nine class values of this lane's source pixel, one ROW of w float4 per (source row, class) --
+            // a wave's store for one class is 32 x 16 contiguous bytes (ABI 8; the [h][w][9][4] form of ABI 5 wrote 16 bytes at a 144-byte stride: WRITE_SIZE
+            // 51.5 GB per config-4 launch for 21.7 GB of payload, and the consumer fetched 1.6x what it read, profiles/r06q_pmc_traffic_cfg4.json).
             // bfsr_conv3x3_h2x (`up4`) expands them while it writes the full-resolution tensor.  No pre_add in this form.
             const unsigned cqb = (unsigned)(h * w) * 144u;               // bytes of one channel quad's compact image
             const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.y + (long long)cur.b * p.y_bs + (long long)cur.cg * 8 * (cqb >> 2), 0, 8u * cqb, 0x00020000);
-            const unsigned vc = ok ? (unsigned)lh * cqb + (unsigned)(sy * w + sx) * 144u : OOB;
+            const unsigned vc = ok ? (unsigned)lh * cqb + (unsigned)(sy * 9 * w + sx) * 16u : OOB;
+            const unsigned crow = (unsigned)w * 16u;                     // bytes of one class row
 #pragma unroll
             for (int c = 0; c < 9; ++c)
 #pragma unroll
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_up4_h2t_kernel(BfsrUp2H2Args
                     float4 o;
                     o.x = acc[c][4 * i + 0] * p.acc_scale; o.y = acc[c][4 * i + 1] * p.acc_scale;
                     o.z = acc[c][4 * i + 2] * p.acc_scale; o.w = acc[c][4 * i + 3] * p.acc_scale;
-                    bfsr::store_b128(rc, __builtin_bit_cast(u32x4, o), vc + 16u * c, (unsigned)(2 * i) * cqb);
+                    bfsr::store_b128(rc, __builtin_bit_cast(u32x4, o), vc, (unsigned)(2 * i) * cqb + (unsigned)c * crow);
                 }
             continue;
         }

@@ -677,7 +677,7 @@ class HipOps(object):
         """conv3x3(nearest_up4(taps)) + pre_add at source resolution (conv_up4_h2t.hip: phase-decomposed, two-term fp16 split, three products).
         `x`: h2 tensor [B,Ct/8,2,h,w,8]; `out` and `pre_add` (may be `out`) are fp32 buffers of shape [B,Cout,4h,4w] holding the QUAD-MAJOR layout.
         compact=True: `out` is a [B, 9*Cout, h, w] fp32 buffer that receives the nine phase-class values per source pixel and channel quad
-        ([Cout/4][h][w][9][4]; no pre_add) -- what conv_h2x(up4=...) adds to the conv over the channels at output resolution."""
+        ([Cout/4][h][9][w][4]; no pre_add) -- what conv_h2x(up4=...) adds to the conv over the channels at output resolution."""
         wts, acc_scale, Cout, Ct = packed
         a = _lib.BfsrUp2H2Args()
         a.x, a.x_bs, cin, h, w = self._h2view(x, "conv_up4_h2t.x")

@@ -15,6 +15,12 @@ from ..ops import ACT_LRELU, ACT_NONE, MODE_BILINEAR_AC
 from .engine import _ConvP, _Workspace, h2_mode
 
 
+def _min_tiles():
+    """Tiles of 16 x 32 a SAMPLE must have for a UNet level to run on the LDS-DMA kernels (below it the register-staged split conv with its
+    smaller tiles fills the chip better at small batches); BFSR_PRIOR_MIN_TILES overrides it for measurements."""
+    return int(os.environ.get("BFSR_PRIOR_MIN_TILES", "32"))
+
+
 def _bn_conv(ops, sd, wkey, bnp, eps=1e-5, f16=False):
     s = sd[bnp + ".weight"] / torch.sqrt(sd[bnp + ".running_var"] + eps)
     return _ConvP(ops, sd[wkey], aff_shift=-sd[bnp + ".running_mean"], aff_scale=s, aff_post=sd[bnp + ".bias"], f16=f16)
@@ -120,7 +126,8 @@ class UNetBody(object):
             raise ValueError("input %dx%d too small for a depth-%d UNet" % (H, W, depth))
         hb = top_h2[1] if top_h2 is not None else None
         lower = os.environ.get("BFSR_PRIOR_LEVELS", "h2") == "h2"
-        on_h2 = [top_h2 is not None and (i == 0 or (lower and ((sizes[i][0] + 15) // 16) * ((sizes[i][1] + 31) // 32) >= 32)) for i in range(depth)]
+        mt = _min_tiles()
+        on_h2 = [top_h2 is not None and (i == 0 or (lower and ((sizes[i][0] + 15) // 16) * ((sizes[i][1] + 31) // 32) >= mt)) for i in range(depth)]
         # skip feature i (i < depth) lives in the first channels of the concat buffer of up layer depth-1-i
         feats, cat_h2 = [], {}
         chans = [self.inc.out] + [d.out for d in self.downs]
@@ -200,7 +207,7 @@ class SRFlowPriorEngine(object):
         fp16-pair split is active and the latent has at least 32 tiles of 16 x 32 per sample (branch 0: 6 channels at half the HR resolution)."""
         B, C, H, W = e.shape
         return (h2_mode(self.ops, False) == "h2x" and os.environ.get("BFSR_PRIOR", "h2x") == "h2x"
-                and ((H + 15) // 16) * ((W + 31) // 32) >= 32)          # per SAMPLE: the kernel choice must not depend on the batch (bit-identical shards)
+                and ((H + 15) // 16) * ((W + 31) // 32) >= _min_tiles())          # per SAMPLE: the kernel choice must not depend on the batch (bit-identical shards)
 
     def forward_branch(self, b, e, out=None):
         """Branch b of the prior on latent b (the two branches share nothing, models/unet.py:154-181); `out` may be preallocated by the caller

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BFSR_ABI_VERSION 7      /* 7 (round 6): bfsr_coupling_wide_head / _tail (the coupled FlowStep of the C = 96 level as two streaming kernels) and their pack functions added.  6 (round 6): bfsr_channel_range_check per sample + gain / ratio arguments, bfsr_channel_range_scratch(B, C); bfsr_conv_chain_progress_words counts the give-up word.  5 (round 5, last): BfsrConvX3Args.up4 / up4_bs appended, bfsr_conv2d_up4_h2t y_fmt 3 (compact output).  4 (round 5, late): BfsrLinfMlpArgs.cf_fmt appended; bfsr_conv2d_up4_h2t and its pack functions added.  3 (round 5): BfsrChainConv + the chain entry points, bfsr_channel_range_*, BfsrLinfMlpArgs.flag.  2 (round 4): BfsrConvArgs / BfsrConvX3Args grew y_fmt + flag, coupling head / tail structs redefined, bfsr_conv2d_up2_h2t, bfsr_h2_pack_s2d, bfsr_ssim_sum_w added, the step / up2_h2x entry points removed */
+#define BFSR_ABI_VERSION 8      /* 8 (round 6, late): the COMPACT output of bfsr_conv2d_up4_h2t (y_fmt 3) and BfsrConvX3Args.up4 are [Cout/4][h][9][w][4] (class rows: whole cache lines on both sides) instead of [Cout/4][h][w][9][4].  7 (round 6): bfsr_coupling_wide_head / _tail (the coupled FlowStep of the C = 96 level as two streaming kernels) and their pack functions added.  6 (round 6): bfsr_channel_range_check per sample + gain / ratio arguments, bfsr_channel_range_scratch(B, C); bfsr_conv_chain_progress_words counts the give-up word.  5 (round 5, last): BfsrConvX3Args.up4 / up4_bs appended, bfsr_conv2d_up4_h2t y_fmt 3 (compact output).  4 (round 5, late): BfsrLinfMlpArgs.cf_fmt appended; bfsr_conv2d_up4_h2t and its pack functions added.  3 (round 5): BfsrChainConv + the chain entry points, bfsr_channel_range_*, BfsrLinfMlpArgs.flag.  2 (round 4): BfsrConvArgs / BfsrConvX3Args grew y_fmt + flag, coupling head / tail structs redefined, bfsr_conv2d_up2_h2t, bfsr_h2_pack_s2d, bfsr_ssim_sum_w added, the step / up2_h2x entry points removed */
 
 enum { BFSR_ACT_NONE = 0, BFSR_ACT_RELU = 1, BFSR_ACT_LRELU = 2 };
 
@@ -166,8 +166,8 @@ typedef struct BfsrConvX3Args {
     float acc_scale;                               /* bfsr_conv3x3_h2x only: 1 / (the power of two the weights were packed with) */
     int mtile;                                     /* bfsr_conv3x3_h2x: 32-cout M tiles per workgroup the weights were packed for (0 or 1); bfsr_conv3x3_h2s: 0, 1 or 2 (| 0x100: keep the weights streamed instead of LDS-resident where they would fit) */
     unsigned* flag;                                /* bfsr_conv3x3_h2x only, optional device word: bit 0 is set when a value written to an h2 output is >= 65504 */
-    const float* up4; long long up4_bs;            /* (ABI 5) bfsr_conv3x3_h2x with y_fmt 2 only, optional: the COMPACT output of bfsr_conv2d_up4_h2t (its y_fmt 3:
-                                                    * [B][Cout/4][H/4][W/4][9 phase classes][4] fp32, batch stride in floats), added to the result after the
+    const float* up4; long long up4_bs;            /* (ABI 5) bfsr_conv3x3_h2x with y_fmt 2 and no residuals only, optional: the COMPACT output of bfsr_conv2d_up4_h2t (its y_fmt 3:
+                                                    * [B][Cout/4][H/4][9 phase classes][W/4][4] fp32 (ABI 8), batch stride in floats), added to the result after the
                                                     * epilogue -- the two convs of the x4 level (key channels at output resolution + nearest-x4 taps) meet here
                                                     * instead of through a full-resolution pre_add round trip.  H and W must be multiples of 4. */
 } BfsrConvX3Args;
@@ -403,8 +403,8 @@ int bfsr_pack_conv_up2_h2t(const float* w_taps_oihw, const float* w_key_oihw, in
  * RRDBNet_arch.py:105-112 fea_up4 + SRFlowNet_arch.py:122-137): x = h2 tensor of the Ct tap channels at SOURCE resolution (Cin = Ct, Ckey must be 0:
  * channels at output resolution enter through pre_add); w = bfsr_pack_conv_up4_h2t(w_taps, Cout, Ct, scale) -- per axis the phases {0}, {1, 2}, {3}
  * of an output pixel see 2, 1, 2 source pixels: 25 pre-summed weight blocks per 16-channel chunk instead of 16 x 9 tap products;
- * y, pre_add: fp32 QUAD-MAJOR [B][Cout/4][4h][4w][4] (y_fmt 1).  y_fmt 3 (ABI 5): COMPACT output [B][Cout/4][h][w][9][4] fp32 -- the nine phase-class
- * values per source pixel and channel quad (class = rc*3 + cc, rc / cc = 0, 1, 2 for output phases {0}, {1, 2}, {3}), no pre_add: 9/16 of the bytes, and the
+ * y, pre_add: fp32 QUAD-MAJOR [B][Cout/4][4h][4w][4] (y_fmt 1).  y_fmt 3 (ABI 5; layout of ABI 8): COMPACT output [B][Cout/4][h][9][w][4] fp32 -- the nine phase-class
+ * values per source pixel and channel quad, one row of w float4 per (source row, class) (class = rc*3 + cc, rc / cc = 0, 1, 2 for output phases {0}, {1, 2}, {3}), no pre_add: 9/16 of the bytes, and the
  * consumer (bfsr_conv3x3_h2x with `up4`) adds it while writing the full-resolution tensor.  Item = 8 x 32 source pixels x 32 output channels x all nine classes. */
 int bfsr_conv2d_up4_h2t(const BfsrUp2H2Args* a, void* stream);
 long long bfsr_conv_up4_h2t_packed_size(int Cout, int Ct);                             /* fp16 elements */

@@ -119,7 +119,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.bfsr_abi_version() == 7
+    assert lib.bfsr_abi_version() == 8
 
 
 def test_weight_packing_layout():

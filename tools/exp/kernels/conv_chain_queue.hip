@@ -1,3 +1,7 @@
+// ARCHIVED EXPERIMENT (round 6, not built): conv_chain.hip with CLAIMED items -- one queue per XCD (BFSR_CHAIN_DEAL=xcd) or one global queue (=global)
+// instead of the static round-robin deal (=static).  Bit-identical results (tests/test_conv_chain.py: 79 passed), no gain: config 2 60.40 ms (xcd) against
+// 60.17 (static), config 4 433.1 against 432.6; the global queue loses the L2 locality of neighbouring tiles (+13 % on the launch).  profiles/r06s_*.
+// To rebuild the experiment: copy over bfsr_amd/csrc/conv_chain.hip, bfsr_amd/csrc/build.sh (bfsr_conv_chain_progress_words grows by 257 words).
 // conv_chain.hip -- a CHAIN of bfsr_conv3x3_h2x convs in ONE persistent launch: the dense blocks of the RRDB encoder
 // (SRFlow-LP/code/models/modules/RRDBNet_arch.py:25-65, LINF-LP/models/rrdb.py:38-74: five convs per ResidualDenseBlock, three blocks
 // per RRDB, 23 RRDBs per trunk).  The arithmetic is conv3x3_h2x_kernel's (conv_h2s.hip), instruction for instruction: 16 x 32 tiles, two rows
@@ -44,7 +48,7 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 #endif
 
 #ifndef BFSR_CHAIN_TRACE
-#define BFSR_CHAIN_TRACE 0                      // measurement builds only (tools/exp/chain_trace.sh): per-item phase timestamps of sixteen workgroups
+#define BFSR_CHAIN_TRACE 0                      // measurement builds only (tools/exp/chain_trace.sh): per-item phase timestamps of a few workgroups
 #endif
 
 namespace {
@@ -52,12 +56,11 @@ namespace {
 #if BFSR_CHAIN_TRACE
 constexpr int TR_WG = 16, TR_ITEMS = 1024, TR_F = 12;                    // workgroups with slot % 16 == 0, items per workgroup, fields per item
 __device__ unsigned long long g_chain_trace[TR_WG * TR_ITEMS * TR_F];
-__device__ __forceinline__ void tr_put(int slot, int G, int it, int f, unsigned long long v, int lane)
+__device__ __forceinline__ void tr_put(int slot, int n, int f, unsigned long long v, int lane)
 {
-    const int n = (it - slot) / G;
     if (lane == 0 && (slot & 15) == 0 && (slot >> 4) < TR_WG && n < TR_ITEMS) g_chain_trace[((slot >> 4) * TR_ITEMS + n) * TR_F + f] = v;
 }
-#define TR_PUT(it_, f_, v_) tr_put(slot, G, it_, f_, v_, lane)
+#define TR_PUT(n_, f_, v_) tr_put(slot, n_, f_, v_, lane)
 #else
 #define TR_PUT(it_, f_, v_) ((void)0)
 #endif
@@ -71,7 +74,7 @@ constexpr int X_W = 2 * X_WPL;                  // 18 432 = eighteen 1-KiB DMA p
 constexpr int STAGE = X_IN + X_W;               // 59 392
 constexpr int NS = 2;
 constexpr int RING = NS * STAGE;                // 118 784
-constexpr int LDS_TOTAL = RING + 16;            // + one word: the newest item whose dependencies loader 0 has seen satisfied
+constexpr int LDS_TOTAL = RING + 16 + 32;       // + one word: the newest item (sequence number) whose dependencies loader 0 has seen satisfied; + four {sequence number, item} pairs: the item queue
 constexpr unsigned OOB = 0x80000000u;
 constexpr int AUX_SC1 = (BFSR_CHAIN_ABL & 32) ? 0 : 16;                     // cache-policy bit of the buffer builtins: sc1 (agent scope: bypass L1 / write through)
 constexpr unsigned POLL_LIMIT = 1u << 21;       // unsuccessful polls (~1 us each) before a workgroup gives up
@@ -121,10 +124,21 @@ __device__ __forceinline__ f32x16 mm_(half8 a, half8 b, f32x16 c)
 }
 
 __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv_chain_kernel(const ChainRec* __restrict__ recs, int B, int H, int W, int tiles_x, int tiles_y,
-                                                                         int nitems, unsigned* progress, unsigned* giveup, unsigned* status, int defer_ok)
+                                                                         int nitems, unsigned* progress, unsigned* giveup, unsigned* queue, int qcpx, unsigned* status, int defer_ok)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     volatile int* lds_ready = reinterpret_cast<volatile int*>(smem + RING);
+    // The item queue (round 6).  The n-th item of a workgroup is slot + n * G when `queue` is null (static round-robin deal) and otherwise -- for
+    // n >= 1 -- claimed by loader 0 with one agent-scope atomic add when it is about to stage the item's first chunk, and handed as {n, item} to
+    // the other eleven waves through four LDS slots.  qcpx > 0 (workgroups per XCD): every XCD keeps the contiguous range of each round the static
+    // deal gives it (neighbouring tiles and the cout groups of a tile in one L2) and its workgroups claim from that sequence in order through the
+    // XCD's own counter; qcpx == 0: one counter for the whole list (loses the L2 locality: measured slower, kept for A/B).  Either way a claimed
+    // item's dependencies are earlier items of the list, and the earliest unfinished item of the launch is always running or claimable by a free
+    // workgroup of its XCD (the items a workgroup holds are all earlier than any it has not claimed) -- no deadlock, as with the static deal.
+    // Why: with the static deal a workgroup that falls behind keeps its share of every later round, and at 1.5 rounds between a tile and its
+    // consumers (config 2: 400 tiles on 256 workgroups) its lateness becomes dependency waits of workgroups that are not behind (measured with
+    // -DBFSR_CHAIN_TRACE: 3-5 us per conv1 / conv2 item, p90 10-15 us, where a launch with far-apart dependencies shows 1 us).
+    volatile unsigned long long* lds_q = reinterpret_cast<volatile unsigned long long*>(smem + RING + 16);      // (sequence number << 32) | item
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -151,14 +165,18 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv_chain_kernel(const Ch
         unsigned vg[NG];
         __amdgpu_buffer_rsrc_t rs_in, rs_w;
         int cur_nchunk = 0, cur_grp = 0;
-        int it_issue = slot, k_issue = 0, c_issue = 0;
-        bool have = true, ready = false;
+        int it_issue = slot, n_issue = 0, k_issue = 0, c_issue = 0;
+        bool have = true, ready = false, claimed = true;                 // item 0 is the workgroup's slot
         unsigned polls = 0;
         int issued = 0, consumed = 0;
 #if BFSR_CHAIN_TRACE
         bool tr_polled = false;
 #endif
-        if (ld == 0 && lane == 0) *lds_ready = -1;                       // read by the compute waves at the end of their first item at the earliest
+        if (ld == 0 && lane == 0) {
+            *lds_ready = -1;                                             // read by the compute waves at the end of their first item at the earliest
+#pragma unroll
+            for (int q = 0; q < 4; ++q) lds_q[q] = ~0ull;                // (first looked at after the first chunk barrier of item 0)
+        }
 
         auto deps_ready = [&](const ChainRec& r, const CItem& c) -> bool {
             if (r.wait_target == 0) return true;
@@ -212,23 +230,48 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv_chain_kernel(const Ch
         };
         auto try_issue = [&]() -> bool {
             if (k_issue == 0 && !ready) {
+                if (!claimed) {
+                    if (queue == nullptr) {
+                        it_issue = slot + n_issue * G;
+                    } else if (ld == 0) {
+                        unsigned v = 0;
+                        const int xcd = (int)(blockIdx.x & 7u);
+                        if (lane == 0) v = __hip_atomic_fetch_add((gu32*)(queue + (qcpx > 0 ? xcd * 32 : 0)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        v = __builtin_amdgcn_readfirstlane(v);
+                        if (qcpx > 0) {
+                            const unsigned m = (unsigned)qcpx + v, r = m / (unsigned)qcpx;
+                            const unsigned long long i64 = (unsigned long long)r * (unsigned)G + (unsigned)(xcd * qcpx) + (m - r * (unsigned)qcpx);
+                            it_issue = i64 > (unsigned long long)nitems ? nitems : (int)i64;
+                        } else {
+                            it_issue = v > (unsigned)(nitems - G) ? nitems : G + (int)v;
+                        }
+                        if (it_issue > nitems) it_issue = nitems;
+                        if (lane == 0) lds_q[n_issue & 3] = ((unsigned long long)(unsigned)n_issue << 32) | (unsigned)it_issue;
+                    } else {
+                        const unsigned long long e = lds_q[n_issue & 3];
+                        if ((int)(e >> 32) != n_issue) return false;     // loader 0 has not claimed it yet
+                        it_issue = __builtin_amdgcn_readfirstlane((int)(unsigned)e);
+                    }
+                    claimed = true;
+                    if (it_issue >= nitems) { have = false; return false; }
+                }
                 while (it_issue >= recs[c_issue + 1].item_base) ++c_issue;
                 const ChainRec& r = recs[c_issue];
                 const CItem c = decode(r, it_issue);
 #if BFSR_CHAIN_TRACE
-                if (ld == 0 && !tr_polled) { tr_polled = true; TR_PUT(it_issue, 7, wall_clock64()); }
+                if (ld == 0 && !tr_polled) { tr_polled = true; TR_PUT(n_issue, 7, wall_clock64()); }
 #endif
                 if (!deps_ready(r, c)) return false;
 #if BFSR_CHAIN_TRACE
-                if (ld == 0) { TR_PUT(it_issue, 8, wall_clock64()); tr_polled = false; }
+                if (ld == 0) { TR_PUT(n_issue, 8, wall_clock64()); tr_polled = false; }
 #endif
-                if (ld == 0 && lane == 0) *lds_ready = it_issue;         // item it_issue WILL start (the counters only grow): see the deferred publish
+                if (ld == 0 && lane == 0) *lds_ready = n_issue;          // the workgroup's item n_issue WILL start (the counters only grow): see the deferred publish
                 lsetup(r, c);
                 ready = true;
             }
             lstage(k_issue, issued % NS);
             ++issued;
-            if (++k_issue == cur_nchunk) { k_issue = 0; ready = false; it_issue += G; have = it_issue < nitems; }
+            if (++k_issue == cur_nchunk) { k_issue = 0; ready = false; claimed = false; ++n_issue; }
             return true;
         };
         while (true) {
@@ -334,7 +377,14 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv_chain_kernel(const Ch
         pend = -1;
     };
     int c = 0;
-    for (int it = slot; it < nitems; it += G) {
+    for (int n = 0;; ++n) {
+        int it = slot + n * G;
+        if (queue != nullptr && n > 0) {                                 // the loaders claimed it while the previous item was in the matrix pipe
+            unsigned long long e = lds_q[n & 3];
+            while ((int)(e >> 32) != n) { __builtin_amdgcn_s_sleep(1); e = lds_q[n & 3]; }
+            it = __builtin_amdgcn_readfirstlane((int)(unsigned)e);
+        }
+        if (it >= nitems) break;
         while (it >= recs[c + 1].item_base) ++c;
         const ChainRec& rec = recs[c];
         const CItem cur = decode(rec, it);
@@ -356,11 +406,11 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv_chain_kernel(const Ch
         for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
         const int nchunk = rec.nchunk;
 #if BFSR_CHAIN_TRACE
-        if (wave == 0) { TR_PUT(it, 0, wall_clock64()); TR_PUT(it, 5, clock64()); TR_PUT(it, 6, (unsigned long long)c | ((unsigned long long)nchunk << 16) | ((unsigned long long)cur.grp << 32)); }
+        if (wave == 0) { TR_PUT(n, 0, wall_clock64()); TR_PUT(n, 5, clock64()); TR_PUT(n, 6, (unsigned long long)c | ((unsigned long long)nchunk << 16) | ((unsigned long long)cur.grp << 32)); }
 #endif
         __builtin_amdgcn_s_barrier();                                    // the item's first chunk has landed
 #if BFSR_CHAIN_TRACE
-        if (wave == 0) TR_PUT(it, 1, wall_clock64());
+        if (wave == 0) TR_PUT(n, 1, wall_clock64());
 #endif
         load_step(I0(), st, 0);
         {
@@ -374,7 +424,7 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv_chain_kernel(const Ch
         }
         if (pend >= 0) publish_pending();
 #if BFSR_CHAIN_TRACE
-        if (wave == 0) TR_PUT(it, 2, wall_clock64());
+        if (wave == 0) TR_PUT(n, 2, wall_clock64());
 #endif
 
         if (BFSR_CHAIN_ABL & 8) {                                        // keep the accumulators alive
@@ -534,17 +584,17 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv_chain_kernel(const Ch
             __builtin_amdgcn_sched_barrier(0);
         }
 #if BFSR_CHAIN_TRACE
-        if (wave == 0) TR_PUT(it, 3, wall_clock64());
+        if (wave == 0) TR_PUT(n, 3, wall_clock64());
 #endif
         // ---- publish: this wave's stores have left the CU (write-through) -> one more finished wave on the tile's counter
         if (!progress) continue;                                         // a chain of one: nobody waits
         pend = ((long long)cur.b * tiles_y + cur.ty) * tiles_x + cur.tx;
         // defer only if the workgroup's next item is known to start: loader 0 has already seen its dependencies satisfied (it runs ahead of the
         // matrix pipe, so this is the common case) -- then the publication cannot be what anybody is (transitively) waiting for before that start
-        const bool defer = defer_ok && it + G < nitems && *lds_ready >= it + G;
+        const bool defer = defer_ok && *lds_ready >= n + 1;
         if (!defer) publish_pending();
 #if BFSR_CHAIN_TRACE
-        if (wave == 0) { TR_PUT(it, 4, defer ? 0ull : (unsigned long long)wall_clock64()); TR_PUT(it, 9, clock64()); }
+        if (wave == 0) { TR_PUT(n, 4, defer ? 0ull : (unsigned long long)wall_clock64()); TR_PUT(n, 9, clock64()); }
 #endif
     }
     if (pend >= 0) publish_pending();
@@ -558,6 +608,12 @@ extern "C" int bfsr_chain_trace_read(void* dst, long long bytes)          // mea
 {
     if (bytes > (long long)sizeof(g_chain_trace)) bytes = sizeof(g_chain_trace);
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_chain_trace), (size_t)bytes, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int bfsr_chain_trace_clear()
+{
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_chain_trace)) != hipSuccess) return -1;
+    return (int)hipMemset(p, 0, sizeof(g_chain_trace));
 }
 #endif
 
@@ -623,7 +679,7 @@ extern "C" long long bfsr_conv_chain_progress_words(const void* table_host)
     if (!table_host) return -1;
     const ChainHeader* hd = static_cast<const ChainHeader*>(table_host);
     if (hd->magic != CHAIN_MAGIC) return -1;
-    return (long long)hd->tiles_x * hd->tiles_y * hd->B + 1;             // one counter per tile + the launch's give-up word
+    return (long long)hd->tiles_x * hd->tiles_y * hd->B + 2 + 8 * 32;    // one counter per tile + the launch's give-up word + the heads of its item queues (one per XCD, 128 bytes apart)
 }
 
 extern "C" int bfsr_conv_chain_launch(const void* table_host, const void* table_dev, unsigned* progress, unsigned* status, int tune, void* stream)
@@ -638,17 +694,28 @@ extern "C" int bfsr_conv_chain_launch(const void* table_host, const void* table_
     // more workgroups than CUs.  `tune` may only shrink the grid.
     int defer_ok = !(tune & 0x10000);                                    // bit 16 of tune / BFSR_CHAIN_DEFER=0: publish every item right after its epilogue (A/B)
     if (const char* e = std::getenv("BFSR_CHAIN_DEFER")) defer_ok = e[0] != '0';
+    // how items reach workgroups: 1 static round-robin deal (rounds 5 / 6a), 2 one queue per XCD (default), 3 one global queue; bits 17-18 of tune or
+    // BFSR_CHAIN_DEAL=static|xcd|global (measurements)
+    int deal = (tune >> 17) & 3;
+    if (deal == 0) {
+        const char* e = std::getenv("BFSR_CHAIN_DEAL");
+        deal = e && e[0] == 's' ? 1 : (e && e[0] == 'g' ? 3 : 2);
+    }
     tune &= 0xffff;
     if (tune > 0 && tune < cus) cus = tune;
     const int grid = hd->nitems < cus ? hd->nitems : cus;
     static std::atomic<unsigned long long> lds_done{0};
     if (bfsr::ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_chain_kernel), LDS_TOTAL, lds_done) != 0) return -1;
-    const long long words = (long long)hd->tiles_x * hd->tiles_y * hd->B + 1;
-    unsigned* giveup = progress + (words - 1);
+    const long long tiles = (long long)hd->tiles_x * hd->tiles_y * hd->B;
+    const long long words = tiles + 2 + 8 * 32;
+    unsigned* giveup = progress + tiles;
+    if ((grid & 7) && deal == 2) deal = 1;                               // the per-XCD queues need the same number of workgroups on every XCD
+    unsigned* queue = deal == 1 || hd->nconv == 1 ? nullptr : progress + (tiles + 2);
+    const int qcpx = deal == 2 ? grid / 8 : 0;
     if (hd->nconv == 1) progress = nullptr;                              // a chain of one has no dependencies: no counters, no memset node (and nothing polls the give-up word)
     else if (hipMemsetAsync(progress, 0, (size_t)words * sizeof(unsigned), st) != hipSuccess) return -1;
     const ChainRec* recs = reinterpret_cast<const ChainRec*>(static_cast<const unsigned char*>(table_dev) + sizeof(ChainHeader));
     hipLaunchKernelGGL(conv_chain_kernel, dim3((unsigned)grid), dim3((NW + NLW) * 64), LDS_TOTAL, st, recs, hd->B, hd->H, hd->W, hd->tiles_x, hd->tiles_y,
-                       hd->nitems, progress, giveup, status, defer_ok);
+                       hd->nitems, progress, giveup, queue, qcpx, status, defer_ok);
     return (int)hipGetLastError();
 }

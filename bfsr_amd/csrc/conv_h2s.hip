@@ -787,8 +787,8 @@ __global__ __launch_bounds__((NW + NLW) * 64, 1) void conv3x3_h2x_kernel(BfsrCon
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         const unsigned so = (unsigned)((oct0 + q * 2) * 2) * (unsigned)(HW * 16);
-                        bfsr::store_b128(ry, __builtin_bit_cast(u32x4_, make_float4(o[j][q][0], o[j][q][1], o[j][q][2], o[j][q][3])), vo16[j], so);
-                        bfsr::store_b128(ry, __builtin_bit_cast(u32x4_, make_float4(o[j][q][4], o[j][q][5], o[j][q][6], o[j][q][7])), vo16[j], so + (unsigned)(HW * 16));
+                        bfsr::store_b128_stream(ry, __builtin_bit_cast(u32x4_, make_float4(o[j][q][0], o[j][q][1], o[j][q][2], o[j][q][3])), vo16[j], so);
+                        bfsr::store_b128_stream(ry, __builtin_bit_cast(u32x4_, make_float4(o[j][q][4], o[j][q][5], o[j][q][6], o[j][q][7])), vo16[j], so + (unsigned)(HW * 16));
                     }
             } else {                                                     // fp32 NCHW: channels >= Cout fall beyond the descriptor
 #pragma unroll

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_up2_h2t_kernel(BfsrUp2H2Args
                     o.y = a[4 * i + 1] * p.acc_scale + pre[BUF][px][i].y;
                     o.z = a[4 * i + 2] * p.acc_scale + pre[BUF][px][i].z;
                     o.w = a[4 * i + 3] * p.acc_scale + pre[BUF][px][i].w;
-                    bfsr::store_b128(rs_y, __builtin_bit_cast(u32x4, o), vo[N] + 16u * px, (unsigned)(2 * i) * Q16);
+                    bfsr::store_b128_stream(rs_y, __builtin_bit_cast(u32x4, o), vo[N] + 16u * px, (unsigned)(2 * i) * Q16);
                 }
         };
         // (in place, y already holding pre_add, one fire-and-forget buffer_atomic_add_f32 per element instead of load + add + store was

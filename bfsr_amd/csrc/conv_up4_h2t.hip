@@ -244,7 +244,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_up4_h2t_kernel(BfsrUp2H2Args
                     float4 o;
                     o.x = acc[c][4 * i + 0] * p.acc_scale; o.y = acc[c][4 * i + 1] * p.acc_scale;
                     o.z = acc[c][4 * i + 2] * p.acc_scale; o.w = acc[c][4 * i + 3] * p.acc_scale;
-                    bfsr::store_b128(rc, __builtin_bit_cast(u32x4, o), vc, (unsigned)(2 * i) * cqb + (unsigned)c * crow);
+                    bfsr::store_b128_stream(rc, __builtin_bit_cast(u32x4, o), vc, (unsigned)(2 * i) * cqb + (unsigned)c * crow);
                 }
             continue;
         }
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_up4_h2t_kernel(BfsrUp2H2Args
                     o.y = a[4 * i + 1] * p.acc_scale + pre[BUF][px][j].y;
                     o.z = a[4 * i + 2] * p.acc_scale + pre[BUF][px][j].z;
                     o.w = a[4 * i + 3] * p.acc_scale + pre[BUF][px][j].w;
-                    bfsr::store_b128(rs_y, __builtin_bit_cast(u32x4, o), vo[PY] + 16u * px, (unsigned)(2 * i) * Q16);
+                    bfsr::store_b128_stream(rs_y, __builtin_bit_cast(u32x4, o), vo[PY] + 16u * px, (unsigned)(2 * i) * Q16);
                 }
         };
         load_pre(I0(), 0);

@@ -59,6 +59,15 @@ __device__ __forceinline__ void store_b128(__amdgpu_buffer_rsrc_t rs, store_u32x
 {
     __builtin_amdgcn_raw_buffer_store_b128(data, rs, lane_off + uniform_off, 0, 0);
 }
+// The same store for the LARGE streamed outputs of the hoisted conditioning convs (quad-major fp32 tensors of 1024 channels: gigabytes per launch, read by
+// a later launch at the earliest): cache policy BFSR_OUT_AUX (0 default; 2 = nt, a measurement build: tools/exp/build_nt.sh).
+#ifndef BFSR_OUT_AUX
+#define BFSR_OUT_AUX 0
+#endif
+__device__ __forceinline__ void store_b128_stream(__amdgpu_buffer_rsrc_t rs, store_u32x4 data, unsigned lane_off, unsigned uniform_off)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(data, rs, lane_off + uniform_off, 0, BFSR_OUT_AUX);
+}
 
 
 // fp32 -> the fp32 value of its fp16 rounding, PINNED in a register: the hi term of the two-term fp16 split.  Without the pin hipcc may form the hi term twice in

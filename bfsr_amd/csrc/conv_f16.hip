@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "../../include/bfsr_hip.h"
+#include "launch_util.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -34,7 +35,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_f16_kernel(BfsrConvArgs p, in
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
-    int bid = blockIdx.x;
+    // XCD-aware block order (round 6): the cout groups of a tile run on ONE XCD, i.e. behind one L2 -- in plain block order they were dealt to all eight and every
+    // XCD fetched the fp32 input tile for itself (PMC: 8.8 GB fetched for a 1.07 GB input at 128 x 64^2, 512 -> 256: the launch was HBM-bound on re-reads).
+    // config 5: conv_f16 4.26 -> 3.64 ms per pass (profiles/r06z_block_order.txt).  The split-precision twins (conv_bf16x3.hip, conv_mfma.hip, conv1x1.hip) keep
+    // the plain order: the same change measured 2-4 % SLOWER there (their weight tensors are 2-3x larger: with plain order an XCD keeps re-using one group's weights).
+    int bid = (int)bfsr::xcd_order(blockIdx.x, gridDim.x);
     const int cg = bid % groups; bid /= groups;
     const int tile = bid % tiles_xy; const int b = bid / tiles_xy;
     const int x0 = (tile % tiles_x) * TW, y0 = (tile / tiles_x) * TH;

@@ -29,6 +29,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef BFSR_MLP_NT
+#define BFSR_MLP_NT 0                           // measurement builds only: the affine_info rows leave with the nt cache policy
+#endif
 #ifndef BFSR_MLP_ABL
 #define BFSR_MLP_ABL 0                          // ablation builds only (tools/exp/mlp_abl.sh): bit 0 no weight loads, 1 no cf gathers, 2 no output stores, 3 no MFMAs
 #endif
@@ -420,8 +423,14 @@ __global__ __launch_bounds__(NW * 64, NT == 4 ? 1 : (X3 == 1 ? 2 : 4)) void linf
                         const int co = mt * 32 + 8 * gq + 4 * lhi;
                         if (co < a.Cout) {
                             const float4 bq = *reinterpret_cast<const float4*>(b4 + co);
-                            *reinterpret_cast<float4*>(outb + ((long long)(co >> 2) * NQ + qq) * 4) =
-                                make_float4(acc[nt][4 * gq] + bq.x, acc[nt][4 * gq + 1] + bq.y, acc[nt][4 * gq + 2] + bq.z, acc[nt][4 * gq + 3] + bq.w);
+                            const float4 ov = make_float4(acc[nt][4 * gq] + bq.x, acc[nt][4 * gq + 1] + bq.y, acc[nt][4 * gq + 2] + bq.z, acc[nt][4 * gq + 3] + bq.w);
+                            float4* op = reinterpret_cast<float4*>(outb + ((long long)(co >> 2) * NQ + qq) * 4);
+#if BFSR_MLP_NT
+                            __builtin_nontemporal_store(ov.x, &op->x); __builtin_nontemporal_store(ov.y, &op->y);
+                            __builtin_nontemporal_store(ov.z, &op->z); __builtin_nontemporal_store(ov.w, &op->w);
+#else
+                            *op = ov;
+#endif
                         }
                     }
                     continue;

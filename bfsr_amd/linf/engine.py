@@ -165,9 +165,10 @@ class LINFEngine(object):
         self.ops.linf_flow(gt, ai, z, self.lin_w, self.lin_b, self.L, reverse=False, log_p=lp, logdet_const=self.logdet_const, ai_fmt=self.ai_fmt)
         return lp, z
 
-    def query_rgb(self, feat, coord, cell, zmap, inp=None):
+    def query_rgb(self, feat, coord, cell, zmap, inp=None, fold=True):
         """patch model: -> folded prediction [B,3,ps*qh,ps*qw] (no skip; the harness adds it, LINF-LP/test.py:169-171).
-        pixel-wise model (ps=1): -> [B,3,qh,qw] WITH the bilinear grid_sample skip of `inp` (linf.py:193-194)."""
+        pixel-wise model (ps=1): -> [B,3,qh,qw] WITH the bilinear grid_sample skip of `inp` (linf.py:193-194).
+        fold=False (patch model, the engine's own harness): -> the inverse flow's output [B,D,qh,qw] as it is, for ops.linf_fold_skip."""
         ops = self.ops
         ai = self.affine_info(feat, coord, cell)
         B, _, qh, qw = zmap.shape
@@ -175,6 +176,8 @@ class LINFEngine(object):
         ops.linf_flow(zmap, ai, p, self.lin_winv, self.lin_b, self.L, reverse=True, ai_fmt=self.ai_fmt)
         if self.ps == 1:
             return ops.grid_sample_add(inp, coord, p, ops.empty(B, 3, qh, qw))
+        if not fold:
+            return p
         img = ops.empty(B, 3, self.ps * qh, self.ps * qw)
         return ops.patch_fold(p, img, self.ps)
 

@@ -4,6 +4,7 @@
 `cell = [2/H, 2/W]`, `gt_lr_up` = ps x ps-unfolded LR-upsample residual
 `lr_up - up(down(lr_up))` (bilinear, align_corners=False).  The residual / unfold run on the HIP kernels; the
 coordinate grid is tiny index math done once per shape on the host with the reference's float arithmetic."""
+import os
 import torch
 import torch.nn.functional as F
 
@@ -48,16 +49,25 @@ def _device_grid(ops, key, make, B, H, W):
     return hit
 
 
+def _fused(ops):
+    """The fused glue kernels (bfsr_linf_prep_* / bfsr_linf_fold_skip) unless BFSR_LINF_GLUE=launches asks for the launch sequences they replace (read per call;
+    the results are the same bits) or `ops` is a test double without them."""
+    return os.environ.get("BFSR_LINF_GLUE", "fused") != "launches" and hasattr(ops, "linf_prep_residual")
+
+
 def prepare_batch_pixelwise(ops, inp01, hr_hw):
     """The non-patch wrapper `SRImplicitPairedFast` (datasets/wrappers.py:92-152): coord = the full HR pixel grid,
     gt_lr_up = the LR-upsample residual [B,3,H,W]."""
     H, W = hr_hw
     B, _, h, w = inp01.shape
-    inp_n = ops.axpb_clamp(inp01, ops.empty(B, 3, h, w), 2.0, -1.0)
-    lr_up = ops.resize(inp_n, ops.empty(B, 3, H, W), MODE_BILINEAR, float(h) / H, float(w) / W)
-    down = ops.resize(lr_up, ops.empty(B, 3, h, w), MODE_BILINEAR, float(H) / h, float(W) / w)
-    up2 = ops.resize(down, ops.empty(B, 3, H, W), MODE_BILINEAR, float(h) / H, float(w) / W)
-    res = ops.axpb_clamp(up2, up2, -1.0, 0.0, r=lr_up)
+    if _fused(ops):
+        res = ops.linf_prep_residual(inp01, (H, W), 1, H, W)             # ps = 1: the residual image itself
+    else:
+        inp_n = ops.axpb_clamp(inp01, ops.empty(B, 3, h, w), 2.0, -1.0)
+        lr_up = ops.resize(inp_n, ops.empty(B, 3, H, W), MODE_BILINEAR, float(h) / H, float(w) / W)
+        down = ops.resize(lr_up, ops.empty(B, 3, h, w), MODE_BILINEAR, float(H) / h, float(W) / w)
+        up2 = ops.resize(down, ops.empty(B, 3, H, W), MODE_BILINEAR, float(h) / H, float(w) / W)
+        res = ops.axpb_clamp(up2, up2, -1.0, 0.0, r=lr_up)
     coord, cell = _device_grid(ops, ("pix", B, H, W), lambda: make_coord([H, W], flatten=False), B, H, W)
     return dict(inp=inp01, coord=coord, cell=cell, gt_lr_up=res)
 
@@ -68,11 +78,15 @@ def prepare_batch(ops, inp01, hr_hw, ps=3, always_pad=True):
     H, W = hr_hw
     B, _, h, w = inp01.shape
     qh, qw, coord = patch_grid(H, W, ps, always_pad)
-    inp_n = ops.axpb_clamp(inp01, ops.empty(B, 3, h, w), 2.0, -1.0)                 # (x - 0.5) / 0.5
-    lr_up = ops.resize(inp_n, ops.empty(B, 3, H, W), MODE_BILINEAR, float(h) / H, float(w) / W)
-    down = ops.resize(lr_up, ops.empty(B, 3, h, w), MODE_BILINEAR, float(H) / h, float(W) / w)
-    up2 = ops.resize(down, ops.empty(B, 3, H, W), MODE_BILINEAR, float(h) / H, float(w) / W)
-    res = ops.axpb_clamp(up2, up2, -1.0, 0.0, r=lr_up)                               # lr_up - up(down(lr_up))
-    gt = ops.patch_unfold(res, ops.empty(B, 3 * ps * ps, qh, qw), ps)
+    if _fused(ops):
+        # one LR-sized launch + one launch that writes gt: lr_up, up2 and the residual image never exist in HBM (round 6; the same bits as the launches below)
+        gt = ops.linf_prep_residual(inp01, (H, W), ps, qh, qw)
+    else:
+        inp_n = ops.axpb_clamp(inp01, ops.empty(B, 3, h, w), 2.0, -1.0)                 # (x - 0.5) / 0.5
+        lr_up = ops.resize(inp_n, ops.empty(B, 3, H, W), MODE_BILINEAR, float(h) / H, float(w) / W)
+        down = ops.resize(lr_up, ops.empty(B, 3, h, w), MODE_BILINEAR, float(H) / h, float(W) / w)
+        up2 = ops.resize(down, ops.empty(B, 3, H, W), MODE_BILINEAR, float(h) / H, float(w) / W)
+        res = ops.axpb_clamp(up2, up2, -1.0, 0.0, r=lr_up)                               # lr_up - up(down(lr_up))
+        gt = ops.patch_unfold(res, ops.empty(B, 3 * ps * ps, qh, qw), ps)
     coord_b, cell = _device_grid(ops, ("patch", B, H, W, ps, bool(always_pad)), lambda: coord, B, H, W)
     return dict(inp=inp01, coord=coord_b, cell=cell, gt_lr_up=gt)

@@ -53,6 +53,16 @@ def _lp_infer(model, prior_model, batch, hr_hw, temperature, return_all):
             t = ops.empty(*z_lr.shape)
             ops.resize(z_learned, t, MODE_BILINEAR, float(z_learned.shape[2]) / t.shape[2], float(z_learned.shape[3]) / t.shape[3])
             z_learned = t
+        if model.patch_size != 1 and prep._fused(ops) and hasattr(eng, "query_rgb"):
+            # fold + crop + `+= bilinear(inp)` + clamp(0.5 x + 0.5) as ONE launch over the inverse flow's output (test.py:165-171, 217; round 6: the folded
+            # image, the skip image and pred_raw were three more trips of the HR batch through HBM); the same bits as the launches below
+            feat = model("gen_feat", inp=inp)
+            p = eng.query_rgb(d(feat), coord, cell, z_learned, fold=False)
+            pred_raw = ops.empty(B, 3, H, W) if return_all else None
+            _, out = ops.linf_fold_skip(p, inp, H, W, eng.ps, raw=pred_raw, out=ops.empty(B, 3, H, W))
+            if return_all:
+                return dict(z_lr=z_lr, z_learned=z_learned, pred_raw=pred_raw, pred=out)
+            return out
         full = batched_predict(model, inp, coord, cell, temperature, z_learned)  # test.py:165
         if model.patch_size == 1:        # pixel-wise LINF: the skip is already inside query_rgb, no fold (test.py:168, 217)
             pred_raw = full[..., :H, :W].contiguous()

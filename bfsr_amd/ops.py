@@ -1320,6 +1320,39 @@ class HipOps(object):
         _lib.check(self._launch(("patch_fold",) + tuple(img.shape), lambda: self.lib.bfsr_patch_fold(pp, pbs, ip, ibs, p.shape[0], Cc, qh, qw, H, W, ps, self._stream())), "patch_fold")
         return img
 
+    def linf_fold_skip(self, p, inp, H, W, ps, raw=None, out=None):
+        """The tail of the LINF-LP harness in one launch (LINF-LP/test.py:168-171, 217): raw = fold(p)[.., :H, :W] + bilinear(inp -> H x W),
+        out = clamp(0.5 raw + 0.5, 0, 1); p [B,C*ps*ps,qh,qw], inp [B,C,h,w] normalised; raw / out: [B,C,H,W] tensors or None (at least one).
+        Bit-identical to patch_fold + resize + two axpb_clamp launches."""
+        pp, pbs, cp, qh, qw = _view(p)
+        ip, ibs, Cc, h, w = _view(inp)
+        assert cp == Cc * ps * ps and (raw is not None or out is not None)
+        rp, rbs = (None, 0) if raw is None else _view(raw)[:2]
+        op_, obs = (None, 0) if out is None else _view(out)[:2]
+        for t in (raw, out):
+            assert t is None or tuple(t.shape) == (p.shape[0], Cc, H, W)
+        _lib.check(self._launch(("linf_fold_skip", p.shape[0], Cc, H, W), lambda: self.lib.bfsr_linf_fold_skip(
+            pp, pbs, ip, ibs, rp, rbs, op_, obs, p.shape[0], Cc, qh, qw, H, W, ps, h, w, float(h) / H, float(w) / W, self._stream())), "linf_fold_skip")
+        return raw, out
+
+    def linf_prep_residual(self, inp01, hr_hw, ps, qh, qw):
+        """The LR-upsample residual of the dataset wrappers, unfolded, from the LR image alone (datasets/wrappers.py:203-228):
+        gt [B,C*ps*ps,qh,qw] = unfold(zero-pad(lr_up - up(down(lr_up)))), lr_up = bilinear(2 inp01 - 1 -> H x W).  Two launches (the LR-sized `down`, then gt);
+        bit-identical to axpb_clamp + three resize + axpb_clamp + patch_unfold."""
+        H, W = hr_hw
+        ip, ibs, Cc, h, w = _view(inp01)
+        B = inp01.shape[0]
+        down = self.empty(B, Cc, h, w)
+        gt = self.empty(B, Cc * ps * ps, qh, qw)
+        dp, dbs = _view(down)[:2]
+        gp, gbs = _view(gt)[:2]
+        ru_h, ru_w, rd_h, rd_w = float(h) / H, float(w) / W, float(H) / h, float(W) / w
+        _lib.check(self._launch(("linf_prep_down", B, Cc, h, w), lambda: self.lib.bfsr_linf_prep_down(ip, ibs, dp, dbs, B, Cc, h, w, H, W, ru_h, ru_w, rd_h, rd_w,
+                                                                                                       self._stream())), "linf_prep_down")
+        _lib.check(self._launch(("linf_prep_residual", B, Cc, H, W), lambda: self.lib.bfsr_linf_prep_residual(ip, ibs, dp, dbs, gp, gbs, B, Cc, h, w, H, W, qh, qw, ps,
+                                                                                                               ru_h, ru_w, self._stream())), "linf_prep_residual")
+        return gt
+
     def patch_unfold(self, img, p, ps):
         pp, pbs, cp, qh, qw = _view(p)
         ip, ibs, Cc, H, W = _view(img)

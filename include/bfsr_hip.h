@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BFSR_ABI_VERSION 8      /* 8 (round 6, late): the COMPACT output of bfsr_conv2d_up4_h2t (y_fmt 3) and BfsrConvX3Args.up4 are [Cout/4][h][9][w][4] (class rows: whole cache lines on both sides) instead of [Cout/4][h][w][9][4].  7 (round 6): bfsr_coupling_wide_head / _tail (the coupled FlowStep of the C = 96 level as two streaming kernels) and their pack functions added.  6 (round 6): bfsr_channel_range_check per sample + gain / ratio arguments, bfsr_channel_range_scratch(B, C); bfsr_conv_chain_progress_words counts the give-up word.  5 (round 5, last): BfsrConvX3Args.up4 / up4_bs appended, bfsr_conv2d_up4_h2t y_fmt 3 (compact output).  4 (round 5, late): BfsrLinfMlpArgs.cf_fmt appended; bfsr_conv2d_up4_h2t and its pack functions added.  3 (round 5): BfsrChainConv + the chain entry points, bfsr_channel_range_*, BfsrLinfMlpArgs.flag.  2 (round 4): BfsrConvArgs / BfsrConvX3Args grew y_fmt + flag, coupling head / tail structs redefined, bfsr_conv2d_up2_h2t, bfsr_h2_pack_s2d, bfsr_ssim_sum_w added, the step / up2_h2x entry points removed */
+#define BFSR_ABI_VERSION 8      /* 8 (round 6, late): bfsr_linf_fold_skip / bfsr_linf_prep_down / bfsr_linf_prep_residual added; the COMPACT output of bfsr_conv2d_up4_h2t (y_fmt 3) and BfsrConvX3Args.up4 are [Cout/4][h][9][w][4] (class rows: whole cache lines on both sides) instead of [Cout/4][h][w][9][4].  7 (round 6): bfsr_coupling_wide_head / _tail (the coupled FlowStep of the C = 96 level as two streaming kernels) and their pack functions added.  6 (round 6): bfsr_channel_range_check per sample + gain / ratio arguments, bfsr_channel_range_scratch(B, C); bfsr_conv_chain_progress_words counts the give-up word.  5 (round 5, last): BfsrConvX3Args.up4 / up4_bs appended, bfsr_conv2d_up4_h2t y_fmt 3 (compact output).  4 (round 5, late): BfsrLinfMlpArgs.cf_fmt appended; bfsr_conv2d_up4_h2t and its pack functions added.  3 (round 5): BfsrChainConv + the chain entry points, bfsr_channel_range_*, BfsrLinfMlpArgs.flag.  2 (round 4): BfsrConvArgs / BfsrConvX3Args grew y_fmt + flag, coupling head / tail structs redefined, bfsr_conv2d_up2_h2t, bfsr_h2_pack_s2d, bfsr_ssim_sum_w added, the step / up2_h2x entry points removed */
 
 enum { BFSR_ACT_NONE = 0, BFSR_ACT_RELU = 1, BFSR_ACT_LRELU = 2 };
 
@@ -537,6 +537,20 @@ int bfsr_patch_fold(const float* p, long long p_bs, float* img, long long img_bs
 /* zero-pad + unfold (datasets/wrappers.py:224-228): img [B,C,H,W] -> p [B,C*ps*ps,qh,qw] */
 int bfsr_patch_unfold(const float* img, long long img_bs, float* p, long long p_bs, int B, int C, int qh, int qw,
                       int H, int W, int ps, void* stream);
+/* ---- LINF-LP harness glue, fused (ABI 8, round 6; resample.hip).  Bit-identical to the sequences of bfsr_resize / bfsr_axpb_clamp / bfsr_patch_fold /
+ * bfsr_patch_unfold launches they replace (the same float operations in the same order).
+ * bfsr_linf_fold_skip: the tail of LINF-LP/test.py:168-171, 217 -- raw = fold(p)[.., :H, :W] + F.interpolate(inp, (H, W), bilinear) and
+ *   out01 = clamp(0.5 raw + 0.5, 0, 1); p [B,C*ps*ps,qh,qw] (the inverse flow's output), inp [B,C,h,w] (normalised LR), raw / out01 [B,C,H,W] (either may be
+ *   NULL), r_h = h / H, r_w = w / W as floats (the ratios bfsr_resize takes).
+ * bfsr_linf_prep_down / bfsr_linf_prep_residual: the input prep of datasets/wrappers.py:203-228 (`SRImplicitPairedFastPatch`) from inp01 [B,C,h,w] in [0,1] alone:
+ *   lr_up = bilinear(2 inp01 - 1 -> H x W) is never stored; down [B,C,h,w] = bilinear(lr_up -> h x w) (ratios rd_*: H / h, W / w);
+ *   gt [B,C*ps*ps,qh,qw] = unfold(zero-pad(lr_up - bilinear(down -> H x W))) (ratios ru_*: h / H, w / W; ps = 1: the pixel-wise wrapper's residual image). */
+int bfsr_linf_fold_skip(const float* p, long long p_bs, const float* inp, long long inp_bs, float* raw, long long raw_bs, float* out01, long long out_bs,
+                        int B, int C, int qh, int qw, int H, int W, int ps, int h, int w, float r_h, float r_w, void* stream);
+int bfsr_linf_prep_down(const float* inp01, long long in_bs, float* down, long long down_bs, int B, int C, int h, int w, int H, int W,
+                        float ru_h, float ru_w, float rd_h, float rd_w, void* stream);
+int bfsr_linf_prep_residual(const float* inp01, long long in_bs, const float* down, long long down_bs, float* gt, long long gt_bs, int B, int C, int h, int w,
+                            int H, int W, int qh, int qw, int ps, float ru_h, float ru_w, void* stream);
 /* out = acc + F.grid_sample(x, coord.flip(-1), bilinear, padding_mode='border', align_corners=False): the in-method
  * LR skip of the pixel-wise LINF (LINF-LP/models/linf.py:193-194); x [B,C,h,w], coord [B,qh,qw,2] (y,x), acc/out [B,C,qh,qw] */
 int bfsr_grid_sample_add(const float* x, long long x_bs, const float* coord, const float* acc, long long acc_bs, float* out,

@@ -192,6 +192,59 @@ def test_golden_e2e(hip, golden_dir, tag, enc, seed, c):
         close(m("gen_feat", inp=(lr - 0.5) / 0.5), T(g["feat"]), 2e-5, "encoder")
 
 
+@pytest.mark.parametrize("B,h,w,H,W,ps,pad", [(2, 24, 20, 96, 80, 3, True), (1, 16, 16, 42, 45, 3, True), (2, 15, 17, 45, 51, 3, False), (1, 12, 12, 27, 31, 1, True),
+                                              (3, 32, 32, 192, 192, 3, True)])
+def test_fused_glue_equals_launches(hip, monkeypatch, B, h, w, H, W, ps, pad):
+    """The fused harness glue of round 6 (bfsr_linf_prep_down / _prep_residual: datasets/wrappers.py:203-228; bfsr_linf_fold_skip: LINF-LP/test.py:168-171, 217)
+    against the launch sequences it replaces (resize x3, axpb_clamp x2, patch_unfold | patch_fold, resize, axpb_clamp x2): the same BITS, for HR sizes that are
+    and are not multiples of the patch size / of four, with and without the wrapper's always-pad rule, and for the pixel-wise wrapper (ps = 1)."""
+    from bfsr_amd.linf import prep
+    from bfsr_amd.ops import MODE_BILINEAR
+    inp01 = hip.to_device(synth.lr_batch(700 + H, B, h, w))
+    res = {}
+    for mode in ("fused", "launches"):
+        monkeypatch.setenv("BFSR_LINF_GLUE", mode)
+        bt = prep.prepare_batch_pixelwise(hip, inp01, (H, W)) if ps == 1 else prep.prepare_batch(hip, inp01, (H, W), ps, pad)
+        torch.cuda.synchronize()
+        res[mode] = bt["gt_lr_up"].clone()
+    assert res["fused"].shape == res["launches"].shape
+    assert torch.equal(res["fused"], res["launches"]), "prep: max diff %.3e" % float((res["fused"] - res["launches"]).abs().max())
+    if ps == 1:
+        return
+    qh, qw = res["fused"].shape[2:]
+    p = hip.to_device(rnd(800 + W, B, 3 * ps * ps, qh, qw))
+    inp = hip.axpb_clamp(inp01, hip.empty(B, 3, h, w), 2.0, -1.0)
+    full = hip.patch_fold(p, hip.empty(B, 3, ps * qh, ps * qw), ps)
+    pred = hip.patch_fold(p, hip.empty(B, 3, H, W), ps)
+    assert torch.equal(pred, full[..., :H, :W])
+    skip = hip.resize(inp, hip.empty(B, 3, H, W), MODE_BILINEAR, float(h) / H, float(w) / W)
+    raw_l = hip.axpb_clamp(pred, hip.empty(B, 3, H, W), 1.0, 0.0, r=skip)
+    out_l = hip.axpb_clamp(raw_l, hip.empty(B, 3, H, W), 0.5, 0.5, 0.0, 1.0)
+    raw_f, out_f = hip.linf_fold_skip(p, inp, H, W, ps, raw=hip.empty(B, 3, H, W), out=hip.empty(B, 3, H, W))
+    assert torch.equal(raw_f, raw_l) and torch.equal(out_f, out_l), "fold + skip + clamp: max diff %.3e" % float((raw_f - raw_l).abs().max())
+    _, out_only = hip.linf_fold_skip(p, inp, H, W, ps, out=hip.empty(B, 3, H, W))
+    assert torch.equal(out_only, out_l)
+
+
+def test_lp_infer_fused_glue_equals_launches(hip, monkeypatch):
+    """The whole LP pass (rrdb, x4 and a x2.5 case whose HR width is cropped inside a patch) with the fused glue and with the launches: identical outputs."""
+    from bfsr_amd.linf.models import make
+    from bfsr_amd.linf.test import infer_from_lr
+    sd, psd = weights("rrdb", 2024)
+    m = make(mspec("rrdb"), args={"ops": hip}).eval()
+    m.load_state_dict(sd)
+    prior = make({"name": "unet", "args": {"in_chans": 27, "depth": 3, "dim": 64, "bilinear": True}}, args={"ops": hip}).eval()
+    prior.load_state_dict(psd)
+    for (hh, ww, scale) in ((32, 24, 4), (20, 20, 2.5)):
+        lr = synth.smooth_lr_batch(5, 2, hh, ww)
+        res = {}
+        for mode in ("fused", "launches"):
+            monkeypatch.setenv("BFSR_LINF_GLUE", mode)
+            res[mode] = infer_from_lr(m, prior, lr, scale, return_all=True)
+        for k in ("z_lr", "z_learned", "pred_raw", "pred"):
+            assert torch.equal(res["fused"][k], res["launches"][k]), "%s at x%s: max diff %.3e" % (k, scale, float((res["fused"][k] - res["launches"][k]).abs().max()))
+
+
 def test_vs_oracle_and_roundtrip_bigger(hip):
     """Fresh input at a larger size (rrdb, x4, 64x48 LR, B=2) vs the oracle + decode(encode(x)) == x."""
     import oracle.linf_ref as O

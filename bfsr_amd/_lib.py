@@ -254,6 +254,8 @@ SYMBOLS = {
     "bfsr_gaussian_logp": (_I, [_VP, _LL, _VP, _LL, _I, _I, _LL, C.c_double, _VP, _VP]),
     "bfsr_linf_flow": (_I, [C.POINTER(BfsrLinfFlowArgs), _VP]),
     "bfsr_patch_fold": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _I, _I, _I, _VP]),
+    "bfsr_resize_h2": (_I, [_VP, _LL, _I, _I, _VP, _LL, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _VP, _VP]),
+    "bfsr_maxpool2_h2": (_I, [_VP, _LL, _VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP, _VP]),
     "bfsr_linf_fold_skip": (_I, [_VP, _LL, _VP, _LL, _VP, _LL, _VP, _LL, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _VP]),
     "bfsr_linf_prep_down": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _I, _I, _F, _F, _F, _F, _VP]),
     "bfsr_linf_prep_residual": (_I, [_VP, _LL, _VP, _LL, _VP, _LL, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _VP]),

@@ -6,6 +6,9 @@
 // and the bilinear blend is  hl0*(wl0*p00 + wl1*p01) + hl1*(wl0*p10 + wl1*p11).
 #include <hip/hip_runtime.h>
 #include "../../include/bfsr_hip.h"
+#include "launch_util.h"
+
+typedef _Float16 rs_half8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -142,6 +145,85 @@ __global__ void axpb_clamp4_kernel(const float* __restrict__ x, long long x_bs, 
     *reinterpret_cast<float4*>(y + (long long)b * y_bs + i * 4) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// ---- h2 forms of the learned priors' glue (round 6): the UNet levels that run on the LDS-DMA kernels keep their activations as h2 tensors
+// ([B][C/8][plane hi, lo][H][W][8] fp16); pooling and bilinear up-sampling used to go through fp32 (h2_unpack -> maxpool2 -> h2_pack; resize -> h2_pack:
+// 4.4 ms of a config-5 pass).  Same float operations as those launches (unpack = hi + lo, fmaxf tree of maxpool2_kernel, resize_one, h2_pack's split with the
+// pinned hi value and its range flag), so the results are the same bits (tests/test_hip_ops.py::test_h2_glue_equals_launches).
+__device__ __forceinline__ void rs_split2(float v, _Float16& h, _Float16& l)
+{
+    const float hf = bfsr::pin_f16(v);
+    h = (_Float16)hf;
+    l = (_Float16)(v - hf);
+}
+
+// one thread = one channel octet of one output pixel
+__global__ void resize_h2_kernel(const float* __restrict__ x, long long x_bs, int IH, int IW, unsigned short* __restrict__ y, long long y_bs, int OH, int OW, int RH, int RW,
+                                 int oy0, int ox0, int C8, unsigned n, int mode, float r_h, float r_w, unsigned* flag)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = blockIdx.y;
+    const unsigned HWo = (unsigned)(OH * OW);
+    const unsigned oct = i / HWo, pix = i - oct * HWo;
+    const int oy = (int)(pix / (unsigned)OW), ox = (int)(pix - (pix / (unsigned)OW) * (unsigned)OW);
+    const float* xb = x + (long long)b * x_bs + (long long)oct * 8 * IH * IW;
+    rs_half8 h8, l8;
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = resize_one(xb + (long long)j * IH * IW, IH, IW, oy - oy0, ox - ox0, RH, RW, mode, r_h, r_w);
+        _Float16 h, l;
+        rs_split2(v, h, l);
+        h8[j] = h; l8[j] = l;
+        amax = fmaxf(amax, fabsf(v));
+    }
+    unsigned short* yb = y + (long long)b * y_bs + ((long long)oct * 2 * HWo + pix) * 8;
+    *reinterpret_cast<rs_half8*>(yb) = h8;
+    *reinterpret_cast<rs_half8*>(yb + (long long)HWo * 8) = l8;
+    if (flag && !(amax < 65504.f)) atomicOr(flag, 1u);
+}
+
+// 2 x 2 max-pool of an h2 tensor -> h2 tensor and / or fp32 NCHW tensor; one thread = one channel octet of one output pixel
+__global__ void maxpool2_h2_kernel(const unsigned short* __restrict__ x, long long x_bs, unsigned short* __restrict__ yh, long long yh_bs, float* __restrict__ yf,
+                                   long long yf_bs, int C8, int H, int W, unsigned n, unsigned* flag)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = blockIdx.y;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const unsigned HWo = (unsigned)(Ho * Wo);
+    const long long HW = (long long)H * W;
+    const unsigned oct = i / HWo, pix = i - oct * HWo;
+    const int oy = (int)(pix / (unsigned)Wo), ox = (int)(pix - (pix / (unsigned)Wo) * (unsigned)Wo);
+    const unsigned short* xb = x + (long long)b * x_bs + (long long)oct * 2 * HW * 8;
+    float v[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long long p = (long long)(2 * oy + (q >> 1)) * W + 2 * ox + (q & 1);
+        const rs_half8 h = *reinterpret_cast<const rs_half8*>(xb + p * 8);
+        const rs_half8 l = *reinterpret_cast<const rs_half8*>(xb + (HW + p) * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[q][j] = (float)h[j] + (float)l[j];               // h2_unpack
+    }
+    rs_half8 h8, l8;
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float m = fmaxf(fmaxf(v[0][j], v[1][j]), fmaxf(v[2][j], v[3][j]));      // maxpool2_kernel
+        if (yf) yf[(long long)b * yf_bs + ((long long)oct * 8 + j) * HWo + pix] = m;
+        _Float16 h, l;
+        rs_split2(m, h, l);
+        h8[j] = h; l8[j] = l;
+        amax = fmaxf(amax, fabsf(m));
+    }
+    if (yh) {
+        unsigned short* yb = yh + (long long)b * yh_bs + ((long long)oct * 2 * HWo + pix) * 8;
+        *reinterpret_cast<rs_half8*>(yb) = h8;
+        *reinterpret_cast<rs_half8*>(yb + (long long)HWo * 8) = l8;
+        if (flag && !(amax < 65504.f)) atomicOr(flag, 1u);
+    }
+}
+
 // ---- LINF-LP glue, fused (round 6).  The reference's harness does these steps as separate torch ops (LINF-LP/test.py:168-171, 217;
 // datasets/wrappers.py:203-228); as separate launches they were 9 % of a config-5 pass (fold 0.84 ms twice, skip resize 0.39, two axpb 0.82; lr_up / down /
 // up2 / residual / unfold 2.5 ms), each moving the 906 MB HR image through HBM once more.  Every value below is formed by the SAME float operations in the
@@ -265,6 +347,31 @@ __global__ void linf_prep_residual_kernel(const float* __restrict__ inp01, long 
 }
 
 }  // namespace
+
+extern "C" int bfsr_resize_h2(const float* x, long long x_bs, int IH, int IW, unsigned short* y, long long y_bs, int OH, int OW, int RH, int RW, int oy0, int ox0,
+                              int B, int C, int mode, float r_h, float r_w, unsigned* flag, void* stream)
+{
+    if (!x || !y || mode < 0 || mode > 2 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || B <= 0 || C <= 0 || (C & 7)) return -1;
+    if ((reinterpret_cast<unsigned long long>(y) & 15) || (y_bs & 7)) return -1;
+    const long long n = (long long)(C / 8) * OH * OW;
+    if (n >= (1LL << 31)) return -1;
+    hipLaunchKernelGGL(resize_h2_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, x_bs, IH, IW, y, y_bs, OH, OW,
+                       RH, RW, oy0, ox0, C / 8, (unsigned)n, mode, r_h, r_w, flag);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bfsr_maxpool2_h2(const unsigned short* x, long long x_bs, unsigned short* y_h2, long long yh_bs, float* y_f32, long long yf_bs, int B, int C, int H, int W,
+                                unsigned* flag, void* stream)
+{
+    if (!x || (!y_h2 && !y_f32) || H < 2 || W < 2 || B <= 0 || C <= 0 || (C & 7)) return -1;
+    if ((reinterpret_cast<unsigned long long>(x) & 15) || (x_bs & 7)) return -1;
+    if (y_h2 && ((reinterpret_cast<unsigned long long>(y_h2) & 15) || (yh_bs & 7))) return -1;
+    const long long n = (long long)(C / 8) * (H / 2) * (W / 2);
+    if (n >= (1LL << 31)) return -1;
+    hipLaunchKernelGGL(maxpool2_h2_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, x_bs, y_h2, yh_bs, y_f32,
+                       yf_bs, C / 8, H, W, (unsigned)n, flag);
+    return (int)hipGetLastError();
+}
 
 extern "C" int bfsr_linf_fold_skip(const float* p, long long p_bs, const float* inp, long long inp_bs, float* raw, long long raw_bs, float* out01, long long out_bs,
                                    int B, int C, int qh, int qw, int H, int W, int ps, int h, int w, float r_h, float r_w, void* stream)

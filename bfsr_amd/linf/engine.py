@@ -260,8 +260,11 @@ class LINFPriorEngine(object):
                 self.lr_dense.run_h2(ops, ws, hb, "lp", e0, e1)
             else:
                 self.lr_dense.run(ops, ws, "lp", e0, e1)
-            e2 = ws.get("lr2", B, half, H, W)
-            ops.resize(e1, e2, MODE_BILINEAR, float(oh) / H, float(ow) / W)
-            ops.h2_pack(e2, cat_h2[:, half // 8:])
+            if os.environ.get("BFSR_PRIOR_GLUE", "fused") != "launches" and hasattr(ops, "resize_h2"):
+                ops.resize_h2(e1, cat_h2[:, half // 8:], MODE_BILINEAR, float(oh) / H, float(ow) / W)      # = the two launches below, without the fp32 image
+            else:
+                e2 = ws.get("lr2", B, half, H, W)
+                ops.resize(e1, e2, MODE_BILINEAR, float(oh) / H, float(ow) / W)
+                ops.h2_pack(e2, cat_h2[:, half // 8:])
         out = ops.empty(B, self.in_chans, H, W)
         return self.body.run(ws, None, out, "u", top_h2=(cat_h2, hb))

@@ -1106,6 +1106,31 @@ class HipOps(object):
                                         float(r_h), float(r_w), self._stream())), "resize")
         return y
 
+    def resize_h2(self, x, out, mode, r_h, r_w, window=None):
+        """resize(x) written as an h2 tensor (= resize + h2_pack, the same bits): x fp32 [B,C,IH,IW] view, out an h2 view [B,C/8,2,OH,OW,8]."""
+        xp, xbs, Cc, IH, IW = _view(x)
+        yp, ybs, c2, OH, OW = self._h2view(out, "resize_h2.out")
+        assert Cc == c2 and x.shape[0] == out.shape[0]
+        oy0, ox0, RH, RW = window if window is not None else (0, 0, OH, OW)
+        _lib.check(self._launch(("resize_h2", mode, x.shape[0], Cc, OH, OW), lambda: self.lib.bfsr_resize_h2(
+            xp, xbs, IH, IW, yp, ybs, OH, OW, RH, RW, oy0, ox0, x.shape[0], Cc, mode, float(r_h), float(r_w), self.range_flag.data_ptr(), self._stream())), "resize_h2")
+        return out
+
+    def maxpool2_h2(self, x, out_h2=None, out_f32=None):
+        """2 x 2 max-pool of an h2 view into an h2 view and / or an fp32 tensor (= h2_unpack + maxpool2 [+ h2_pack], the same bits)."""
+        xp, xbs, Cc, H, W = self._h2view(x, "maxpool2_h2.x")
+        hp, hbs = (None, 0)
+        if out_h2 is not None:
+            hp, hbs, c2, h2, w2 = self._h2view(out_h2, "maxpool2_h2.out")
+            assert (c2, h2, w2) == (Cc, H // 2, W // 2)
+        fp, fbs = (None, 0)
+        if out_f32 is not None:
+            fp, fbs, c3, h3, w3 = _view(out_f32, "maxpool2_h2.out_f32")
+            assert (c3, h3, w3) == (Cc, H // 2, W // 2)
+        _lib.check(self._launch(("maxpool2_h2", x.shape[0], Cc, H, W), lambda: self.lib.bfsr_maxpool2_h2(
+            xp, xbs, hp, hbs, fp, fbs, x.shape[0], Cc, H, W, self.range_flag.data_ptr(), self._stream())), "maxpool2_h2")
+        return out_h2 if out_h2 is not None else out_f32
+
     def maxpool2(self, x, y):
         xp, xbs, Cc, H, W = _view(x)
         yp, ybs, _, _, _ = _view(y)

@@ -138,21 +138,32 @@ class UNetBody(object):
             if on_h2[i]:
                 cat_h2[i] = hb("%s_cat%d_h2" % (name, i), "h2", B, up.c1.pw.Cin, sizes[i][0], sizes[i][1])
         bottom = ws.get("%s_bottom" % name, B, chans[depth], sizes[depth][0], sizes[depth][1])
+        # round 6: pooling and up-sampling of the h2 levels as h2 kernels (maxpool2_h2, resize_h2: the same bits as unpack -> pool -> pack and resize -> pack, without
+        # the fp32 round trips); BFSR_PRIOR_GLUE=launches keeps those launches (A/B, tests)
+        fused = os.environ.get("BFSR_PRIOR_GLUE", "fused") != "launches" and hasattr(ops, "maxpool2_h2")
         if on_h2[0]:
             self.inc.run_h2(ops, hb, "%s_inc" % name, top_h2[0], cat_h2[0][:, :chans[0] // 8], lo=True)
-            ops.h2_unpack(cat_h2[0][:, :chans[0] // 8], feats[0][:, :chans[0]])          # the pooling below reads fp32
+            if not fused:
+                ops.h2_unpack(cat_h2[0][:, :chans[0] // 8], feats[0][:, :chans[0]])      # the pooling below reads fp32
         else:
             self.inc.run(ops, ws, "%s_inc" % name, x, feats[0][:, :chans[0]])
         cur = feats[0][:, :chans[0]]
         for i in range(depth):
             pooled = ws.get("%s_pool%d" % (name, i), B, chans[i], sizes[i + 1][0], sizes[i + 1][1])
-            ops.maxpool2(cur, pooled)
+            nxt_h2 = i + 1 < depth and on_h2[i + 1]
+            ph = hb("%s_pool%d_h2" % (name, i), "h2", B, chans[i], sizes[i + 1][0], sizes[i + 1][1]) if nxt_h2 else None
+            if fused and on_h2[i]:
+                ops.maxpool2_h2(cat_h2[i][:, :chans[i] // 8], out_h2=ph, out_f32=None if nxt_h2 else pooled)
+            else:
+                ops.maxpool2(cur, pooled)
+                if nxt_h2:
+                    ops.h2_pack(pooled, ph)
             dst = feats[i + 1][:, :chans[i + 1]] if i + 1 < depth else bottom
-            if i + 1 < depth and on_h2[i + 1]:
-                ph = ops.h2_pack(pooled, hb("%s_pool%d_h2" % (name, i), "h2", B, chans[i], sizes[i + 1][0], sizes[i + 1][1]))
+            if nxt_h2:
                 sk = cat_h2[i + 1][:, :chans[i + 1] // 8]
                 self.downs[i].run_h2(ops, hb, "%s_down%d" % (name, i), ph, sk, lo=True)
-                ops.h2_unpack(sk, dst)
+                if not fused:
+                    ops.h2_unpack(sk, dst)
             else:
                 self.downs[i].run(ops, ws, "%s_down%d" % (name, i), pooled, dst)
             cur = dst
@@ -166,8 +177,13 @@ class UNetBody(object):
             dy, dx = Hs - uh, Ws - uw
             r_h = float(h1 - 1) / float(uh - 1) if uh > 1 else 0.0
             r_w = float(w1 - 1) / float(uw - 1) if uw > 1 else 0.0
-            ops.resize(cur, cat[:, cs:], MODE_BILINEAR_AC, r_h, r_w, window=(dy // 2, dx // 2, uh, uw))
             o = ws.get("%s_up%d" % (name, j), B, self.ups[j].out, Hs, Ws)
+            if on_h2[i] and fused:
+                ops.resize_h2(cur, cat_h2[i][:, cs // 8:], MODE_BILINEAR_AC, r_h, r_w, window=(dy // 2, dx // 2, uh, uw))      # the upsampled half joins the skip half (already h2)
+                self.ups[j].run_h2(ops, hb, "%s_upc%d" % (name, j), cat_h2[i], o)
+                cur = o
+                continue
+            ops.resize(cur, cat[:, cs:], MODE_BILINEAR_AC, r_h, r_w, window=(dy // 2, dx // 2, uh, uw))
             if on_h2[i]:
                 ops.h2_pack(cat[:, cs:], cat_h2[i][:, cs // 8:])                  # the upsampled half joins the skip half (already h2)
                 self.ups[j].run_h2(ops, hb, "%s_upc%d" % (name, j), cat_h2[i], o)

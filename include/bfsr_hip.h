@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BFSR_ABI_VERSION 8      /* 8 (round 6, late): bfsr_linf_fold_skip / bfsr_linf_prep_down / bfsr_linf_prep_residual added; the COMPACT output of bfsr_conv2d_up4_h2t (y_fmt 3) and BfsrConvX3Args.up4 are [Cout/4][h][9][w][4] (class rows: whole cache lines on both sides) instead of [Cout/4][h][w][9][4].  7 (round 6): bfsr_coupling_wide_head / _tail (the coupled FlowStep of the C = 96 level as two streaming kernels) and their pack functions added.  6 (round 6): bfsr_channel_range_check per sample + gain / ratio arguments, bfsr_channel_range_scratch(B, C); bfsr_conv_chain_progress_words counts the give-up word.  5 (round 5, last): BfsrConvX3Args.up4 / up4_bs appended, bfsr_conv2d_up4_h2t y_fmt 3 (compact output).  4 (round 5, late): BfsrLinfMlpArgs.cf_fmt appended; bfsr_conv2d_up4_h2t and its pack functions added.  3 (round 5): BfsrChainConv + the chain entry points, bfsr_channel_range_*, BfsrLinfMlpArgs.flag.  2 (round 4): BfsrConvArgs / BfsrConvX3Args grew y_fmt + flag, coupling head / tail structs redefined, bfsr_conv2d_up2_h2t, bfsr_h2_pack_s2d, bfsr_ssim_sum_w added, the step / up2_h2x entry points removed */
+#define BFSR_ABI_VERSION 8      /* 8 (round 6, late): bfsr_linf_fold_skip / bfsr_linf_prep_down / bfsr_linf_prep_residual, bfsr_resize_h2 / bfsr_maxpool2_h2 added; the COMPACT output of bfsr_conv2d_up4_h2t (y_fmt 3) and BfsrConvX3Args.up4 are [Cout/4][h][9][w][4] (class rows: whole cache lines on both sides) instead of [Cout/4][h][w][9][4].  7 (round 6): bfsr_coupling_wide_head / _tail (the coupled FlowStep of the C = 96 level as two streaming kernels) and their pack functions added.  6 (round 6): bfsr_channel_range_check per sample + gain / ratio arguments, bfsr_channel_range_scratch(B, C); bfsr_conv_chain_progress_words counts the give-up word.  5 (round 5, last): BfsrConvX3Args.up4 / up4_bs appended, bfsr_conv2d_up4_h2t y_fmt 3 (compact output).  4 (round 5, late): BfsrLinfMlpArgs.cf_fmt appended; bfsr_conv2d_up4_h2t and its pack functions added.  3 (round 5): BfsrChainConv + the chain entry points, bfsr_channel_range_*, BfsrLinfMlpArgs.flag.  2 (round 4): BfsrConvArgs / BfsrConvX3Args grew y_fmt + flag, coupling head / tail structs redefined, bfsr_conv2d_up2_h2t, bfsr_h2_pack_s2d, bfsr_ssim_sum_w added, the step / up2_h2x entry points removed */
 
 enum { BFSR_ACT_NONE = 0, BFSR_ACT_RELU = 1, BFSR_ACT_LRELU = 2 };
 
@@ -537,6 +537,13 @@ int bfsr_patch_fold(const float* p, long long p_bs, float* img, long long img_bs
 /* zero-pad + unfold (datasets/wrappers.py:224-228): img [B,C,H,W] -> p [B,C*ps*ps,qh,qw] */
 int bfsr_patch_unfold(const float* img, long long img_bs, float* p, long long p_bs, int B, int C, int qh, int qw,
                       int H, int W, int ps, void* stream);
+/* ---- h2 forms of the learned priors' glue (ABI 8, round 6; resample.hip): bfsr_resize writing an h2 tensor directly (= bfsr_resize + bfsr_h2_pack, `flag` as in
+ * bfsr_h2_pack) and the 2 x 2 max-pool of an h2 tensor into an h2 tensor and / or an fp32 NCHW tensor (= bfsr_h2_unpack + bfsr_maxpool2 [+ bfsr_h2_pack]); the same bits
+ * as those launches.  models/unet.py:58-98 (`Down`: MaxPool2d(2), `Up`: Upsample(bilinear, align_corners=True)) of both learned priors. */
+int bfsr_resize_h2(const float* x, long long x_bs, int IH, int IW, unsigned short* y, long long y_bs, int OH, int OW, int RH, int RW, int oy0, int ox0,
+                   int B, int C, int mode, float r_h, float r_w, unsigned* flag, void* stream);
+int bfsr_maxpool2_h2(const unsigned short* x, long long x_bs, unsigned short* y_h2, long long yh_bs, float* y_f32, long long yf_bs, int B, int C, int H, int W,
+                     unsigned* flag, void* stream);
 /* ---- LINF-LP harness glue, fused (ABI 8, round 6; resample.hip).  Bit-identical to the sequences of bfsr_resize / bfsr_axpb_clamp / bfsr_patch_fold /
  * bfsr_patch_unfold launches they replace (the same float operations in the same order).
  * bfsr_linf_fold_skip: the tail of LINF-LP/test.py:168-171, 217 -- raw = fold(p)[.., :H, :W] + F.interpolate(inp, (H, W), bilinear) and

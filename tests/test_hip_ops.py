@@ -1034,3 +1034,34 @@ def test_wide_conv1x1(hip, case, x3):
         e = (out.cpu().double() - truth).abs().max().item()
         e32 = max((ref.double() - truth).abs().max().item(), (o32.cpu().double() - truth).abs().max().item())
         assert e <= 2.0 * e32 + 1e-7, (e, e32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,H,W", [(2, 16, 37, 45), (1, 64, 64, 96), (3, 8, 17, 17)])
+def test_h2_glue_equals_launches(hip, B, C, H, W):
+    """Round 6: maxpool2_h2 (= h2_unpack + maxpool2 [+ h2_pack]) and resize_h2 (= resize + h2_pack, bilinear align_corners True with the Up layer's pad window, and
+    align_corners False) of the learned priors' h2 levels (models/unet.py:58-98): the same bits as the launches they replace, odd sizes included."""
+    from bfsr_amd.ops import MODE_BILINEAR, MODE_BILINEAR_AC
+    x = hip.to_device(rnd(900 + W, B, C + 8, H, W))
+    xh = hip.h2_pack(x, hip.h2_empty(B, C + 8, H, W))[:, 1:]                                   # a channel-slice view, like the skip half of a concat buffer
+    un = hip.h2_unpack(xh, hip.empty(B, C, H, W))
+    pool = hip.maxpool2(un, hip.empty(B, C, H // 2, W // 2))
+    pool_h = hip.h2_pack(pool, hip.h2_empty(B, C, H // 2, W // 2))
+    both_h, both_f = hip.h2_empty(B, C + 8, H // 2, W // 2), hip.empty(B, C, H // 2, W // 2).fill_(float("nan"))
+    hip.maxpool2_h2(xh, out_h2=both_h[:, 1:], out_f32=both_f)
+    assert torch.equal(both_f, pool) and torch.equal(both_h[:, 1:], pool_h)
+    only_f = hip.maxpool2_h2(xh, out_f32=hip.empty(B, C, H // 2, W // 2))
+    assert torch.equal(only_f, pool)
+    # Up: bilinear x2 (align_corners True) into a window of a larger image (the pad of unet.py:88-92), then joined to the concat buffer as h2
+    OH, OW = 2 * H + 1, 2 * W + 3
+    r_h, r_w = float(H - 1) / float(2 * H - 1), float(W - 1) / float(2 * W - 1)
+    win = (0, 1, 2 * H, 2 * W)
+    up = hip.resize(un, hip.empty(B, C, OH, OW), MODE_BILINEAR_AC, r_h, r_w, window=win)
+    up_h = hip.h2_pack(up, hip.h2_empty(B, C, OH, OW))
+    cat = hip.h2_empty(B, C + 16, OH, OW)
+    hip.resize_h2(un, cat[:, 2:], MODE_BILINEAR_AC, r_h, r_w, window=win)
+    assert torch.equal(cat[:, 2:], up_h)
+    oh, ow = 3 * H - 1, 3 * W + 2
+    a = hip.h2_pack(hip.resize(un, hip.empty(B, C, oh, ow), MODE_BILINEAR, float(H) / oh, float(W) / ow), hip.h2_empty(B, C, oh, ow))
+    b = hip.resize_h2(un, hip.h2_empty(B, C, oh, ow), MODE_BILINEAR, float(H) / oh, float(W) / ow)
+    assert torch.equal(a, b)

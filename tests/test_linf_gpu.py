@@ -235,11 +235,12 @@ def test_lp_infer_fused_glue_equals_launches(hip, monkeypatch):
     m.load_state_dict(sd)
     prior = make({"name": "unet", "args": {"in_chans": 27, "depth": 3, "dim": 64, "bilinear": True}}, args={"ops": hip}).eval()
     prior.load_state_dict(psd)
-    for (hh, ww, scale) in ((32, 24, 4), (20, 20, 2.5)):
+    for (hh, ww, scale) in ((32, 24, 4), (20, 20, 2.5), (48, 48, 8)):      # the last one: a 129 x 129 query grid, the prior's top level on the LDS-DMA kernels (h2 glue)
         lr = synth.smooth_lr_batch(5, 2, hh, ww)
         res = {}
         for mode in ("fused", "launches"):
             monkeypatch.setenv("BFSR_LINF_GLUE", mode)
+            monkeypatch.setenv("BFSR_PRIOR_GLUE", mode)
             res[mode] = infer_from_lr(m, prior, lr, scale, return_all=True)
         for k in ("z_lr", "z_learned", "pred_raw", "pred"):
             assert torch.equal(res["fused"][k], res["launches"][k]), "%s at x%s: max diff %.3e" % (k, scale, float((res["fused"][k] - res["launches"][k]).abs().max()))

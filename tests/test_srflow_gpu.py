@@ -139,6 +139,21 @@ def test_prior_full_resolution_convs_on_h2x_vs_oracle(model4, hip, monkeypatch):
     assert hip.fallbacks == 0
 
 
+def test_prior_h2_glue_equals_launches(model4, hip, monkeypatch):
+    """Both branches of the prior with the h2 pooling / up-sampling kernels of round 6 and with the launches they replace (BFSR_PRIOR_GLUE=launches): the same bits,
+    at a size where two levels of the big branch run on the LDS-DMA kernels and with odd sizes (pad windows)."""
+    m, prior, opt, sd, psd = model4
+    g = torch.Generator().manual_seed(6)
+    for shp in (((2, 6, 320, 320), (2, 96, 80, 80)), ((1, 6, 250, 290), (1, 96, 62, 72))):
+        e = [torch.randn(*s_, generator=g) for s_ in shp]
+        res = {}
+        for mode in ("fused", "launches"):
+            monkeypatch.setenv("BFSR_PRIOR_GLUE", mode)
+            res[mode] = [t.clone() for t in prior(e)]
+        for k in range(2):
+            assert torch.equal(res["fused"][k], res["launches"][k]), "z%d: max diff %.3e" % (k, float((res["fused"][k] - res["launches"][k]).abs().max()))
+
+
 def test_vs_oracle_fresh_input_and_roundtrip(model4, hip):
     import oracle.srflow_ref as O
     from bfsr_amd.srflow.test import lp_infer

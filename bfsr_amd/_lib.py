@@ -199,6 +199,7 @@ SYMBOLS = {
     "bfsr_conv_packed_size_h2x": (_LL, [_I, _I, _I]),
     "bfsr_pack_conv_weight_h2x": (_I, [_VP, _I, _I, _I, C.c_float, _VP]),
     "bfsr_h2_pack": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP, _VP]),
+    "bfsr_h2_pack_pad": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _I, _VP, _VP]),
     "bfsr_h2_unpack": (_I, [_VP, _LL, _VP, _LL, _I, _I, _I, _I, _VP]),
     "bfsr_conv_chain_table_size": (_LL, [_I]),
     "bfsr_conv_chain_prepare": (_I, [C.POINTER(BfsrChainConv), _I, _I, _I, _I, _VP]),

@@ -825,6 +825,31 @@ __global__ void h2_pack_kernel(const float* __restrict__ x, long long x_bs, unsi
     if (flag && !(amax < 65504.f)) atomicOr(flag, 1u);
 }
 
+// the same with fewer source channels than the h2 tensor has (the K padding of a conv's input): channel c >= Cs is zero, c < Cs is 1 * x + 0 (the copy
+// bfsr_axpb_clamp made into the zero-initialised staging tensor this replaces: the same bits, signed zeros included)
+__global__ void h2_pack_pad_kernel(const float* __restrict__ x, long long x_bs, unsigned short* __restrict__ y, long long y_bs,
+                                   int Cs, int C, long long HW, long long total, unsigned* flag)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float amax = 0.f;
+    const int C8 = C >> 3;
+    const long long pix = i % HW; const long long t = i / HW;
+    const int oct = (int)(t % C8); const int b = (int)(t / C8);
+    const float* xb = x + (long long)b * x_bs + (long long)oct * 8 * HW + pix;
+    half8 h8, l8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = 0.f;
+        if (oct * 8 + j < Cs) { v = 1.0f * xb[(long long)j * HW] + 0.0f; }
+        _Float16 h, l; split2(v, h, l); h8[j] = h; l8[j] = l; amax = fmaxf(amax, fabsf(v));
+    }
+    unsigned short* yb = y + (long long)b * y_bs + ((long long)oct * 2 * HW + pix) * 8;
+    *reinterpret_cast<half8*>(yb) = h8;
+    *reinterpret_cast<half8*>(yb + HW * 8) = l8;
+    if (flag && !(amax < 65504.f)) atomicOr(flag, 1u);
+}
+
 __global__ void h2_unpack_kernel(const unsigned short* __restrict__ x, long long x_bs, float* __restrict__ y, long long y_bs,
                                  int C, long long HW, long long total)
 {
@@ -1010,6 +1035,15 @@ extern "C" int bfsr_h2_pack(const float* x, long long x_bs, unsigned short* y, l
     if ((reinterpret_cast<unsigned long long>(y) & 15) || (y_bs & 7)) return -1;
     const long long HW = (long long)H * W, total = (long long)B * (C / 8) * HW;
     hipLaunchKernelGGL(h2_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, x_bs, y, y_bs, C, HW, total, flag);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bfsr_h2_pack_pad(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int Cs, int C, int H, int W, unsigned* flag, void* stream)
+{
+    if (!x || !y || B <= 0 || C <= 0 || (C & 7) || Cs <= 0 || Cs > C || H <= 0 || W <= 0) return -1;
+    if ((reinterpret_cast<unsigned long long>(y) & 15) || (y_bs & 7)) return -1;
+    const long long HW = (long long)H * W, total = (long long)B * (C / 8) * HW;
+    hipLaunchKernelGGL(h2_pack_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, x_bs, y, y_bs, Cs, C, HW, total, flag);
     return (int)hipGetLastError();
 }
 

@@ -498,6 +498,15 @@ class HipOps(object):
         _lib.check(self._launch(("h2_pack",) + tuple(x.shape), lambda: self.lib.bfsr_h2_pack(xp, xbs, yp, ybs, x.shape[0], Cc, H, W, self.range_flag.data_ptr(), self._stream())), "h2_pack")
         return out
 
+    def h2_pack_pad(self, x, out):
+        """h2_pack of x [B,Cs,H,W] into an h2 view with C >= Cs channels, the extra channels zero (= copying x into a zero-initialised [B,C,H,W] tensor and packing that)."""
+        xp, xbs, Cs, H, W = _view(x, "h2_pack_pad.x")
+        yp, ybs, c2, h2, w2 = self._h2view(out, "h2_pack_pad.out")
+        assert Cs <= c2 and (H, W) == (h2, w2) and x.shape[0] == out.shape[0]
+        _lib.check(self._launch(("h2_pack_pad", x.shape[0], Cs, c2, H, W), lambda: self.lib.bfsr_h2_pack_pad(xp, xbs, yp, ybs, x.shape[0], Cs, c2, H, W, self.range_flag.data_ptr(),
+                                                                                                            self._stream())), "h2_pack_pad")
+        return out
+
     def h2_unpack(self, x, out):
         xp, xbs, Cc, H, W = self._h2view(x, "h2_unpack.x")
         yp, ybs, c2, h2, w2 = _view(out, "h2_unpack.out")

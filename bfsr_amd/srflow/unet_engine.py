@@ -82,10 +82,13 @@ class DenseBlock(object):
         B, _, H, W = x.shape
         nfp, cs = self.h2_ready(ops)
         gc, o = self.gc, (lambda c: c // 8)
-        xp = hb(tag + "_xpad", "f32z", B, nfp, H, W)               # zero-initialised once: the pad channels stay zero
-        ops.axpb_clamp(x, xp[:, :self.nf])
         D = hb(tag + "_dense_h2", "h2", B, nfp + 4 * gc, H, W)
-        ops.h2_pack(xp, D[:, :o(nfp)])
+        if os.environ.get("BFSR_PRIOR_GLUE", "fused") != "launches" and hasattr(ops, "h2_pack_pad"):
+            ops.h2_pack_pad(x, D[:, :o(nfp)])                      # round 6: pad + pack in one launch (the same bits as the two below)
+        else:
+            xp = hb(tag + "_xpad", "f32z", B, nfp, H, W)           # zero-initialised once: the pad channels stay zero
+            ops.axpb_clamp(x, xp[:, :self.nf])
+            ops.h2_pack(xp, D[:, :o(nfp)])
         for i in range(4):
             cs[i].run_h2(ops, D[:, :o(nfp + i * gc)], D[:, o(nfp + i * gc): o(nfp + (i + 1) * gc)], act=ACT_LRELU, slope=0.2)
         cs[4].run_h2(ops, D, out)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BFSR_ABI_VERSION 8      /* 8 (round 6, late): bfsr_linf_fold_skip / bfsr_linf_prep_down / bfsr_linf_prep_residual, bfsr_resize_h2 / bfsr_maxpool2_h2 added; the COMPACT output of bfsr_conv2d_up4_h2t (y_fmt 3) and BfsrConvX3Args.up4 are [Cout/4][h][9][w][4] (class rows: whole cache lines on both sides) instead of [Cout/4][h][w][9][4].  7 (round 6): bfsr_coupling_wide_head / _tail (the coupled FlowStep of the C = 96 level as two streaming kernels) and their pack functions added.  6 (round 6): bfsr_channel_range_check per sample + gain / ratio arguments, bfsr_channel_range_scratch(B, C); bfsr_conv_chain_progress_words counts the give-up word.  5 (round 5, last): BfsrConvX3Args.up4 / up4_bs appended, bfsr_conv2d_up4_h2t y_fmt 3 (compact output).  4 (round 5, late): BfsrLinfMlpArgs.cf_fmt appended; bfsr_conv2d_up4_h2t and its pack functions added.  3 (round 5): BfsrChainConv + the chain entry points, bfsr_channel_range_*, BfsrLinfMlpArgs.flag.  2 (round 4): BfsrConvArgs / BfsrConvX3Args grew y_fmt + flag, coupling head / tail structs redefined, bfsr_conv2d_up2_h2t, bfsr_h2_pack_s2d, bfsr_ssim_sum_w added, the step / up2_h2x entry points removed */
+#define BFSR_ABI_VERSION 8      /* 8 (round 6, late): bfsr_linf_fold_skip / bfsr_linf_prep_down / bfsr_linf_prep_residual, bfsr_resize_h2 / bfsr_maxpool2_h2 / bfsr_h2_pack_pad added; the COMPACT output of bfsr_conv2d_up4_h2t (y_fmt 3) and BfsrConvX3Args.up4 are [Cout/4][h][9][w][4] (class rows: whole cache lines on both sides) instead of [Cout/4][h][w][9][4].  7 (round 6): bfsr_coupling_wide_head / _tail (the coupled FlowStep of the C = 96 level as two streaming kernels) and their pack functions added.  6 (round 6): bfsr_channel_range_check per sample + gain / ratio arguments, bfsr_channel_range_scratch(B, C); bfsr_conv_chain_progress_words counts the give-up word.  5 (round 5, last): BfsrConvX3Args.up4 / up4_bs appended, bfsr_conv2d_up4_h2t y_fmt 3 (compact output).  4 (round 5, late): BfsrLinfMlpArgs.cf_fmt appended; bfsr_conv2d_up4_h2t and its pack functions added.  3 (round 5): BfsrChainConv + the chain entry points, bfsr_channel_range_*, BfsrLinfMlpArgs.flag.  2 (round 4): BfsrConvArgs / BfsrConvX3Args grew y_fmt + flag, coupling head / tail structs redefined, bfsr_conv2d_up2_h2t, bfsr_h2_pack_s2d, bfsr_ssim_sum_w added, the step / up2_h2x entry points removed */
 
 enum { BFSR_ACT_NONE = 0, BFSR_ACT_RELU = 1, BFSR_ACT_LRELU = 2 };
 
@@ -206,6 +206,9 @@ int bfsr_conv3x3_h2x(const BfsrConvX3Args* a, void* stream);
 long long bfsr_conv_packed_size_h2x(int Cout, int Cin, int mtile);
 int bfsr_pack_conv_weight_h2x(const float* w_oihw, int Cout, int Cin, int mtile, float scale, unsigned short* packed);
 int bfsr_h2_pack(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int C, int H, int W, unsigned* flag /* optional range guard */, void* stream);
+/* (ABI 8) the same from a tensor with Cs <= C channels: channels >= Cs of the h2 tensor are zero (the K padding of a conv whose input channel count is not a multiple of the
+ * kernel's chunk: the 6- and 27-channel latents entering DenseBlock_5C of the learned priors, models/unet.py:10-36) */
+int bfsr_h2_pack_pad(const float* x, long long x_bs, unsigned short* y, long long y_bs, int B, int Cs, int C, int H, int W, unsigned* flag, void* stream);
 int bfsr_h2_unpack(const unsigned short* x, long long x_bs, float* y, long long y_bs, int B, int C, int H, int W, void* stream);
 
 /* ---- a CHAIN of bfsr_conv3x3_h2x convs in ONE persistent launch (round 5, conv_chain.hip) ------------------------------------------

@@ -1065,3 +1065,11 @@ def test_h2_glue_equals_launches(hip, B, C, H, W):
     a = hip.h2_pack(hip.resize(un, hip.empty(B, C, oh, ow), MODE_BILINEAR, float(H) / oh, float(W) / ow), hip.h2_empty(B, C, oh, ow))
     b = hip.resize_h2(un, hip.h2_empty(B, C, oh, ow), MODE_BILINEAR, float(H) / oh, float(W) / ow)
     assert torch.equal(a, b)
+    # pad + pack (the 6- / 27-channel latents entering the priors' DenseBlock_5C): = copy into a zero-initialised tensor + h2_pack
+    xs = un[:, :C - 5].contiguous()
+    xs[0, 0, 0, 0] = -0.0
+    padded = hip.zeros(B, C, H, W)
+    hip.axpb_clamp(xs, padded[:, :C - 5])
+    ref_p = hip.h2_pack(padded, hip.h2_empty(B, C, H, W))
+    got_p = hip.h2_pack_pad(xs, hip.h2_empty(B, C, H, W))
+    assert torch.equal(got_p.view(torch.int16), ref_p.view(torch.int16))

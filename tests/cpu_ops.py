@@ -86,11 +86,21 @@ class CpuOps(object):
         out.copy_(self._x3_to_f32(x))
         return out
 
-    def conv_x3s(self, x, pw, out, epi=None, act=0, slope=0.2, res1=None, alpha1=1.0, res2=None, alpha2=1.0, tune=0, y_fmt=0):
+    def conv_x3s(self, x, pw, out, epi=None, act=0, slope=0.2, res1=None, alpha1=1.0, res2=None, alpha2=1.0, tune=0, y_fmt=0, up4=None):
         f = self._x3_to_f32
         tmp = torch.empty(out.shape[0], pw.Cout, x.shape[3], x.shape[4]) if out.dtype == torch.bfloat16 else out
         self.conv(f(x), pw, tmp, epi=epi, act=act, slope=slope, res1=None if res1 is None else f(res1), alpha1=alpha1,
                   res2=None if res2 is None else f(res2), alpha2=alpha2, y_fmt=y_fmt)
+        if up4 is not None:                      # the compact x4 taps result (conv_up4_h2t(compact=True)), expanded and added to the quad-major result
+            assert y_fmt and out.dtype != torch.bfloat16
+            B, Cout, H4, W4 = tmp.shape
+            c5 = up4.view(B, Cout, 9, H4 // 4, W4 // 4)
+            cls = (0, 1, 1, 2)
+            full = torch.empty(B, Cout, H4, W4)
+            for py in range(4):
+                for px in range(4):
+                    full[:, :, py::4, px::4] = c5[:, :, cls[py] * 3 + cls[px]]
+            tmp.copy_(self.quads(self.quads(tmp, inverse=True) + full))
         if out.dtype == torch.bfloat16:
             self.x3_pack(tmp, out)
         return out
@@ -422,10 +432,20 @@ class CpuOps(object):
         w = w_taps.detach().to(torch.float32).clone()
         return w, 1.0, w.shape[0], w.shape[1]
 
-    def conv_up4_h2t(self, x, packed, out, pre_add=None):
-        """conv3x3(nearest_up4(taps)) + pre_add: x = h2 tensor of the taps; out / pre_add hold the quad-major layout."""
+    def conv_up4_h2t(self, x, packed, out, pre_add=None, compact=False):
+        """conv3x3(nearest_up4(taps)) + pre_add: x = h2 tensor of the taps; out / pre_add hold the quad-major layout.
+        compact=True: out [B, 9*Cout, h, w] receives the nine phase-class values per source pixel (the double keeps them as [B][Cout][9][h][w]: the layout is
+        private to the producer / consumer pair) -- what conv_x3s(up4=) expands and adds."""
         w, _, Cout, Ct = packed
         y = F.conv2d(F.interpolate(sum(self._h2_planes(x)), scale_factor=4, mode="nearest"), w, None, 1, 1)
+        if compact:
+            B, _, H4, W4 = y.shape
+            c5 = out.view(B, Cout, 9, H4 // 4, W4 // 4)
+            rep = (0, 1, 3)                      # an output phase of each class {0}, {1, 2}, {3}
+            for cy in range(3):
+                for cx in range(3):
+                    c5[:, :, cy * 3 + cx] = y[:, :, rep[cy]::4, rep[cx]::4]
+            return out
         if pre_add is not None:
             y = y + self.quads(pre_add, inverse=True)
         out.copy_(self.quads(y))

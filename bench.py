@@ -123,19 +123,29 @@ def launch_flop(k):
     return None
 
 
+def _evidence_order(path):
+    """profiles/ files in the order they were produced: round, then tag (r06a ... r06z, r06aa ... -- the two-letter tags of a round follow its one-letter ones)."""
+    tag = os.path.basename(path).split("_")[0]
+    return (tag[:3], len(tag), tag, os.path.basename(path))
+
+
 def rocprof_avg_ms(cfg, sym):
     """Average duration of a kernel symbol in the committed rocprofv3 --kernel-trace --stats summary of this configuration (the latest
     profiles/rNN*_cfg<cfg>_kernel_stats.csv), or (None, None).  Only meaningful for a launch shape that is the symbol's only one."""
     import csv
     import glob
-    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_cfg%d_kernel_stats.csv" % cfg)))
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_cfg%d_kernel_stats.csv" % cfg)), key=_evidence_order)
     if not fs:
         return None, None
     base = sym.split("<")[0].split(" ")[0]
-    rows = [r for r in csv.DictReader(open(fs[-1])) if base in r.get("Name", "")]
-    if len(rows) != 1:
+    try:
+        rows = [r for r in csv.DictReader(open(fs[-1])) if base in (r.get("Name") or "")]
+        if len(rows) != 1:
+            return None, None
+        return float(rows[0]["AverageNs"]) * 1e-6, os.path.basename(fs[-1])
+    except (ValueError, OSError, KeyError, TypeError) as e:            # evidence files are optional input
+        print("bench: ignoring %s (%s)" % (fs[-1], e), file=sys.stderr)
         return None, None
-    return float(rows[0]["AverageNs"]) * 1e-6, os.path.basename(fs[-1])
 
 
 def roof_entry(t, k, f, n, steps, step_ms, traffic_db, cfg=None):
@@ -169,8 +179,11 @@ def load_traffic():
     """per-launch HBM-side bytes from the committed PMC passes of this round (separate --pmc runs, profiles/), keyed by launch shape"""
     db = {}
     import glob
-    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_pmc_traffic*.json"))):   # rounds in order: later passes override
-        db.update(json.load(open(p)).get("kernels", {}))
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_pmc_traffic*.json")), key=_evidence_order):   # in order of production: later passes override
+        try:
+            db.update(json.load(open(p)).get("kernels", {}))
+        except (ValueError, OSError, AttributeError) as e:          # an unreadable evidence file must not take the benchmark down with it
+            print("bench: ignoring %s (%s)" % (p, e), file=sys.stderr)
     return db
 
 

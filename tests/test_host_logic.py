@@ -453,3 +453,23 @@ def test_library_has_no_packed_fp32_instructions(tmp_path):
     assert mfma > 1000, "disassembly looks empty"
     assert packed == 0, "%d packed-fp32 instructions in libbfsr_hip.so: build it with bfsr_amd/csrc/build.sh" % packed
 
+
+
+def test_bench_evidence_readers_accept_every_committed_file():
+    """bench.py reads committed evidence (profiles/rNN*_pmc_traffic*.json, *_kernel_stats.csv) for `roofline.traffic` / `frac_rocprof`: every committed file must parse
+    (an empty JSON once took the whole benchmark down), the readers must survive a broken one, and files are taken in the order they were produced (r06z before r06aa)."""
+    import glob
+    import importlib.util
+    import json
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    for p in glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]*_pmc_traffic*.json")):
+        assert isinstance(json.load(open(p)), dict), p          # (round-1 files have another schema and no "kernels": load_traffic takes them as empty)
+    spec_ = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(b)
+    assert len(b.load_traffic()) > 0
+    for cfg in (2, 3, 4, 5):
+        ms, src = b.rocprof_avg_ms(cfg, "conv_chain_kernel")
+        assert ms is None or ms > 0
+    order = sorted(["profiles/r06aa_x.json", "profiles/r06z_x.json", "profiles/r05g_x.json", "profiles/r06b_x.json"], key=b._evidence_order)
+    assert [os.path.basename(o).split("_")[0] for o in order] == ["r05g", "r06b", "r06z", "r06aa"]
